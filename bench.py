@@ -1,0 +1,271 @@
+#!/usr/bin/env python
+"""Headline benchmark: g-SpMM copy_u+sum on an ogbn-products-shaped CSR.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (dgla_spmm_csr: merge kernel + fix-up kernel) over the
+whole synthetic graph: N = 2,449,029 rows, E = 61,859,140 edges, F = 100, fp32, int32 ids,
+column ids uniform ("variant U") with inputs resident in HBM.  Rank 0 prints
+ONE JSON line with edges/s, the HBM roofline of the dominant kernel and the CPU baseline.
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns one
+C2-shaped partition (weak scaling) whose last `halo` columns are feature rows owned by the
+other ranks; each step first pulls them with one RCCL all_to_all_single and then runs the
+local SpMM.  value = total edges of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from tests.graphgen import C2_EDGES, C2_FEAT, C2_NODES, synth_csr  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak reported too
+
+
+def algorithmic_bytes(n_rows, n_edges, feat, s=4, i=4):
+    # per edge F*s + i, per row F*s + i (+ one extra indptr entry)
+    return n_edges * (feat * s + i) + (n_rows + 1) * i + n_rows * feat * s
+
+
+def measure_copy_peak(dev, nbytes=4 << 30, iters=5):
+    from dgl_amd import _capi
+
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    src.zero_()
+    for _ in range(2):
+        _capi.stream_copy(dst, src)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for k in range(iters):
+        _capi.stream_copy(dst, src)
+        ev[k + 1].record()
+    torch.cuda.synchronize()
+    best = min(ev[k].elapsed_time(ev[k + 1]) for k in range(iters))
+    del src, dst
+    return 2 * nbytes / (best * 1e-3) / 1e9
+
+
+def cpu_baseline(g, x, budget_s=12.0):
+    """The oracle's copy_u+sum (restating DGL's SpMMSumCsrNaive) on this host's cores, on the
+    SAME graph and features, for about `budget_s` seconds."""
+    import oracle
+
+    indptr = g["indptr"].cpu().numpy()
+    indices = g["indices"].cpu().numpy()
+    xh = x.cpu().numpy()
+    cores = os.cpu_count() or 1
+    out = np.zeros_like(xh)
+    t0 = time.perf_counter()
+    oracle.copy_u_sum_csr(indptr, indices, xh, cores, out)  # warm-up (page faults, OMP pool)
+    warm = time.perf_counter() - t0
+    reps = max(1, min(10, int(budget_s / max(warm, 1e-3))))
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        oracle.copy_u_sum_csr(indptr, indices, xh, cores, out)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {
+        "value": g["nnz"] / best, "unit": "edges/s", "cores": cores, "kind": "port",
+        "sample": "full workload (%d edges, F=%d), best of %d passes after 1 warm-up; "
+                  "oracle.copy_u_sum_csr = C/OpenMP restatement of DGL SpMMSumCsrNaive "
+                  "(libxsmm JIT unavailable)" % (g["nnz"], x.shape[1], reps),
+    }, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--variant", default="U", choices=["U", "L"])
+    ap.add_argument("--scale", type=int, default=1, help="divide N and E (debug only)")
+    ap.add_argument("--halo-frac", type=float, default=0.1,
+                    help="N>1: fraction of a partition's columns that are remote feature rows")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-peak", action="store_true")
+    ap.add_argument("--extra", action="store_true", help="also time variant L / int64 / API path")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dgl_amd import _capi
+
+    n = C2_NODES // args.scale
+    e = C2_EDGES // args.scale
+    f = C2_FEAT
+    n_halo = 0
+    if world > 1:
+        from dgl_amd.parallel import HaloExchange
+
+        n_halo = int(n * args.halo_frac) // (world - 1) * (world - 1)
+    g = synth_csr(n, n + n_halo, e, args.variant, seed=20250824 + rank, device=dev)
+    torch.manual_seed(12345 + rank)
+    x = torch.empty(n + n_halo, f, device=dev)
+    x[:n] = torch.rand(n, f, device=dev) + 1
+    out = torch.empty(n, f, device=dev)
+    csr = _capi.make_csr(g["indptr"], g["indices"], None, n + n_halo)
+    ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, x.dtype, x, None, out),
+                     dtype=torch.uint8, device=dev)
+    halo = HaloExchange(n, n_halo, f, dev, seed=7 + rank) if world > 1 else None
+
+    plan_valid = [False]
+
+    def step():
+        if halo is not None:
+            halo.pull(x)  # fills x[n:] with rows owned by the peers (RCCL all-to-all)
+        _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws,
+                       plan_valid=plan_valid[0])
+        plan_valid[0] = True
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+
+    # ---- timed region: EXACTLY K steps between barrier + synchronize -----------------
+    k_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            for _ in range(args.steps)]
+    for a, b in k_ev:  # create the HIP handles
+        a.record()
+        b.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in k_ev:
+        _capi.set_profile_events(a, b)
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _capi.set_profile_events(None, None)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    kern_ms = [a.elapsed_time(b) for a, b in k_ev]
+    kern_avg = float(np.mean(kern_ms))
+
+    result = None
+    if rank == 0:
+        b_alg = algorithmic_bytes(n, e, f)
+        achieved = b_alg / (kern_avg * 1e-3) / 1e9
+        result = {
+            "metric": "edges/sec for g-SpMM copy_u+sum (feat=100); % HBM roofline",
+            "value": e * world / (ms_per_step * 1e-3),
+            "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: g-SpMM copy_u+sum on ogbn-products-shaped CSR "
+                            "(N=%d rows, E=%d edges, feat=%d) fp32, int32 ids, variant %s"
+                            % (n, e, f, args.variant),
+                "per_gpu_edges": e, "halo_rows_per_gpu": n_halo,
+                "parallelism": "1 GPU" if world == 1 else
+                               "row partition per GPU + halo pull (all_to_all_single over RCCL)",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "spmm_csr_merge_kernel<int,float,VEC=4,copy_lhs,sum>",
+                "kernel_avg_ms": kern_avg, "kernel_min_ms": float(np.min(kern_ms)),
+                "algorithmic_bytes_per_launch": b_alg,
+            },
+        }
+
+    # ---- extras on rank 0, outside the timed region ----------------------------------
+    if rank == 0 and world == 1:
+        if not args.no_peak:
+            try:
+                peak = measure_copy_peak(dev, nbytes=(4 << 30) // max(1, args.scale))
+                result["roofline"]["measured_copy_peak"] = peak
+                result["roofline"]["frac_of_measured_peak"] = result["roofline"]["achieved"] / peak
+            except Exception as ex:  # pragma: no cover
+                result["roofline"]["measured_copy_peak_error"] = repr(ex)
+        if not args.no_cpu:
+            cb, ref = cpu_baseline(g, x)
+            result["cpu_baseline"] = cb
+            # the full-size run doubles as a parity check against the oracle
+            err = (out.cpu().numpy() - ref) / np.maximum(np.abs(ref), 1e-30)
+            result["parity_max_rel_err_vs_oracle"] = float(np.abs(err).max())
+            del ref
+        if args.extra:
+            result["extra"] = extras(dev, n, e, f, args)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def time_spmm(dev, g, x, reps=10):
+    from dgl_amd import _capi
+
+    n = g["num_rows"]
+    out = torch.empty(n, x.shape[1], device=dev, dtype=x.dtype)
+    csr = _capi.make_csr(g["indptr"], g["indices"], g["eids"], g["num_cols"])
+    ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, x.dtype, x, None, out),
+                     dtype=torch.uint8, device=dev)
+    _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws)
+    for _ in range(2):
+        _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, plan_valid=True)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for k in range(reps):
+        _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, plan_valid=True)
+        ev[k + 1].record()
+    torch.cuda.synchronize()
+    ts = [ev[k].elapsed_time(ev[k + 1]) for k in range(reps)]
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def extras(dev, n, e, f, args):
+    res = {}
+    torch.manual_seed(12345)
+    x = torch.rand(n, f, device=dev) + 1
+    for variant in ("U", "L"):
+        for idt in (torch.int32, torch.int64):
+            g = synth_csr(n, n, e, variant, device=dev, idtype=idt)
+            med, mn = time_spmm(dev, g, x)
+            b = algorithmic_bytes(n, e, f, i=4 if idt == torch.int32 else 8)
+            res["%s_%s" % (variant, "i32" if idt == torch.int32 else "i64")] = {
+                "ms_median": med, "ms_min": mn, "edges_per_s": e / (med * 1e-3),
+                "achieved_GBps": b / (med * 1e-3) / 1e9}
+            del g
+    return res
+
+
+if __name__ == "__main__":
+    main()

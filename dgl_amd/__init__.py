@@ -1,0 +1,10 @@
+"""dgl_amd — MI355X-native g-SpMM / g-SDDMM message-passing path behind DGL's operator API.
+
+Only the hot path is here: hand-written gfx950 HIP kernels in
+``dgl_amd/csrc`` exposed through a C ABI (``include/dgl_amd.h``), and the thin Python host
+side that mirrors ``dgl.ops`` / ``DGLGraph.update_all``.  There is no CPU fallback.
+"""
+from . import _lib  # noqa: F401  (raises ImportError if libdgl_amd.so has not been built)
+from ._lib import DGLAMDError
+
+__version__ = "0.1.0"

@@ -1,0 +1,141 @@
+"""Torch-tensor front end of the graph-free C seam (include/dgl_amd.h, `dgla_*`).
+
+Everything here is plumbing: it turns torch tensors into (pointer, shape) pairs, picks the
+current HIP stream (reference: kernels are queued on the current PyTorch stream,
+tests/python/pytorch/test_ffi-stream.py:45-64) and calls the shared library.  No arithmetic
+happens in Python.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import COO, CSR, LIB, Tensor, check_call
+
+_DTYPES = {torch.float32: 0, torch.float64: 1, torch.float16: 2, torch.bfloat16: 3}
+TARGETS = {"u": 0, "e": 1, "v": 2}
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise _lib.DGLAMDError(
+            "dgl_amd kernels run on a ROCm GPU; got a tensor on %s (no CPU fallback)" % t.device)
+
+
+def _tensor(t, keep):
+    """dgla_tensor for a contiguous torch tensor (1-D is viewed as (n, 1), the reference's
+    unsqueeze in python/dgl/_sparse_ops.py:208-217)."""
+    if t is None:
+        return Tensor(None, 0, None)
+    _require_gpu(t)
+    if not t.is_contiguous():
+        raise _lib.DGLAMDError("feature tensors must be contiguous")
+    shape = tuple(t.shape) if t.dim() > 1 else (t.shape[0], 1)
+    arr = (ctypes.c_int64 * len(shape))(*shape)
+    keep.append(arr)
+    return Tensor(t.data_ptr(), len(shape), arr)
+
+
+def _idbits(t):
+    if t.dtype == torch.int32:
+        return 32
+    if t.dtype == torch.int64:
+        return 64
+    raise _lib.DGLAMDError("index tensors must be int32 or int64")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def make_csr(indptr, indices, eids, num_cols):
+    _require_gpu(indptr)
+    return CSR(indptr.shape[0] - 1, int(num_cols), indices.shape[0], _idbits(indptr),
+               indptr.data_ptr(), _ptr(indices), _ptr(eids))
+
+
+def make_coo(row, col, eids, num_src, num_dst):
+    _require_gpu(row)
+    return COO(int(num_src), int(num_dst), row.shape[0], _idbits(row), _ptr(row), _ptr(col),
+               _ptr(eids))
+
+
+def spmm_csr_workspace_bytes(op, reduce, csr, dtype, ufeat, efeat, out):
+    keep = []
+    tu, te, to = _tensor(ufeat, keep), _tensor(efeat, keep), _tensor(out, keep)
+    return LIB.dgla_spmm_csr_workspace_bytes(op.encode(), reduce.encode(), ctypes.byref(csr),
+                                             _DTYPES[dtype], ctypes.byref(tu), ctypes.byref(te),
+                                             ctypes.byref(to))
+
+
+def spmm_csr(op, reduce, csr, ufeat, efeat, out, arg_u=None, arg_e=None, workspace=None,
+             accumulate=False, plan_valid=False):
+    """out = g-SpMM over `csr` (rows = destination nodes).  `workspace` is a uint8 tensor of
+    at least spmm_csr_workspace_bytes(); it also caches the merge plan between calls."""
+    keep = []
+    tu, te, to = _tensor(ufeat, keep), _tensor(efeat, keep), _tensor(out, keep)
+    flags = (_lib.DGLA_ACCUMULATE if accumulate else 0) | (_lib.DGLA_PLAN_VALID if plan_valid else 0)
+    check_call(LIB.dgla_spmm_csr(
+        op.encode(), reduce.encode(), ctypes.byref(csr), _DTYPES[out.dtype], ctypes.byref(tu),
+        ctypes.byref(te), ctypes.byref(to), _ptr(arg_u), _ptr(arg_e), _ptr(workspace),
+        0 if workspace is None else workspace.numel() * workspace.element_size(), flags,
+        _stream(out)))
+
+
+def spmm_coo(op, reduce, coo, ufeat, efeat, out, arg_u=None, arg_e=None):
+    keep = []
+    tu, te, to = _tensor(ufeat, keep), _tensor(efeat, keep), _tensor(out, keep)
+    check_call(LIB.dgla_spmm_coo(op.encode(), reduce.encode(), ctypes.byref(coo),
+                                 _DTYPES[out.dtype], ctypes.byref(tu), ctypes.byref(te),
+                                 ctypes.byref(to), _ptr(arg_u), _ptr(arg_e), _stream(out)))
+
+
+def sddmm_coo(op, coo, lhs, rhs, out, lhs_target, rhs_target):
+    keep = []
+    tl, tr, to = _tensor(lhs, keep), _tensor(rhs, keep), _tensor(out, keep)
+    check_call(LIB.dgla_sddmm_coo(op.encode(), ctypes.byref(coo), _DTYPES[out.dtype],
+                                  ctypes.byref(tl), ctypes.byref(tr), ctypes.byref(to),
+                                  lhs_target, rhs_target, _stream(out)))
+
+
+def sddmm_csr(op, csr, lhs, rhs, out, lhs_target, rhs_target):
+    keep = []
+    tl, tr, to = _tensor(lhs, keep), _tensor(rhs, keep), _tensor(out, keep)
+    check_call(LIB.dgla_sddmm_csr(op.encode(), ctypes.byref(csr), _DTYPES[out.dtype],
+                                  ctypes.byref(tl), ctypes.byref(tr), ctypes.byref(to),
+                                  lhs_target, rhs_target, _stream(out)))
+
+
+def edge_softmax_forward(csr, score, out):
+    keep = []
+    ts, to = _tensor(score, keep), _tensor(out, keep)
+    check_call(LIB.dgla_edge_softmax_forward(ctypes.byref(csr), _DTYPES[out.dtype],
+                                             ctypes.byref(ts), ctypes.byref(to), _stream(out)))
+
+
+def edge_softmax_backward(csr, out, sds, back):
+    keep = []
+    to, ts, tb = _tensor(out, keep), _tensor(sds, keep), _tensor(back, keep)
+    check_call(LIB.dgla_edge_softmax_backward(ctypes.byref(csr), _DTYPES[out.dtype],
+                                              ctypes.byref(to), ctypes.byref(ts),
+                                              ctypes.byref(tb), _stream(back)))
+
+
+def stream_copy(dst, src):
+    _require_gpu(dst)
+    check_call(LIB.dgla_stream_copy(dst.data_ptr(), src.data_ptr(),
+                                    src.numel() * src.element_size(), _stream(dst)))
+
+
+def set_profile_events(before, after):
+    """Record two torch.cuda.Event objects around the merge kernel of the next spmm_csr calls
+    of this thread (None, None disables).  The events must have been recorded once already so
+    that their HIP handles exist."""
+    if before is None or after is None:
+        LIB.dgla_spmm_set_profile_events(None, None)
+    else:
+        LIB.dgla_spmm_set_profile_events(before.cuda_event, after.cuda_event)

@@ -1,0 +1,88 @@
+"""Loader of libdgl_amd.so (the hand-written gfx950 kernels + C ABI).
+
+There is NO fallback: if the shared library is missing the package raises at import of
+this module, and if no ROCm device is present every compute entry point raises.  The
+reference behaves the same way when libdgl.so is absent (python/dgl/_ffi/base.py:36-50).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdgl_amd.so")
+
+
+class DGLAMDError(RuntimeError):
+    """Raised for errors reported through the C ABI (the reference's DGLError,
+    python/dgl/_ffi/base.py:58-70)."""
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "dgl_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C dgl_amd/csrc`. There is no CPU/PyTorch fallback for the "
+            "g-SpMM / g-SDDMM kernels." % LIB_PATH
+        )
+    return ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+
+LIB = _load()
+
+c_void_p, c_char_p, c_int, c_int64, c_size_t, c_uint32 = (
+    ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t,
+    ctypes.c_uint32,
+)
+
+
+class CSR(ctypes.Structure):  # dgla_csr
+    _fields_ = [("num_rows", c_int64), ("num_cols", c_int64), ("nnz", c_int64),
+                ("idtype_bits", ctypes.c_int32), ("indptr", c_void_p), ("indices", c_void_p),
+                ("data", c_void_p)]
+
+
+class COO(ctypes.Structure):  # dgla_coo
+    _fields_ = [("num_rows", c_int64), ("num_cols", c_int64), ("nnz", c_int64),
+                ("idtype_bits", ctypes.c_int32), ("row", c_void_p), ("col", c_void_p),
+                ("data", c_void_p)]
+
+
+class Tensor(ctypes.Structure):  # dgla_tensor
+    _fields_ = [("data", c_void_p), ("ndim", ctypes.c_int32),
+                ("shape", ctypes.POINTER(c_int64))]
+
+
+P = ctypes.POINTER
+LIB.dgla_last_error.restype = c_char_p
+LIB.dgla_abi_version.restype = c_int
+LIB.dgla_spmm_csr.restype = c_int
+LIB.dgla_spmm_csr.argtypes = [c_char_p, c_char_p, P(CSR), c_int, P(Tensor), P(Tensor), P(Tensor),
+                              c_void_p, c_void_p, c_void_p, c_size_t, c_uint32, c_void_p]
+LIB.dgla_spmm_csr_workspace_bytes.restype = c_size_t
+LIB.dgla_spmm_csr_workspace_bytes.argtypes = [c_char_p, c_char_p, P(CSR), c_int, P(Tensor),
+                                              P(Tensor), P(Tensor)]
+LIB.dgla_spmm_coo.restype = c_int
+LIB.dgla_spmm_coo.argtypes = [c_char_p, c_char_p, P(COO), c_int, P(Tensor), P(Tensor), P(Tensor),
+                              c_void_p, c_void_p, c_void_p]
+LIB.dgla_sddmm_coo.restype = c_int
+LIB.dgla_sddmm_coo.argtypes = [c_char_p, P(COO), c_int, P(Tensor), P(Tensor), P(Tensor), c_int,
+                               c_int, c_void_p]
+LIB.dgla_sddmm_csr.restype = c_int
+LIB.dgla_sddmm_csr.argtypes = [c_char_p, P(CSR), c_int, P(Tensor), P(Tensor), P(Tensor), c_int,
+                               c_int, c_void_p]
+LIB.dgla_edge_softmax_forward.restype = c_int
+LIB.dgla_edge_softmax_forward.argtypes = [P(CSR), c_int, P(Tensor), P(Tensor), c_void_p]
+LIB.dgla_edge_softmax_backward.restype = c_int
+LIB.dgla_edge_softmax_backward.argtypes = [P(CSR), c_int, P(Tensor), P(Tensor), P(Tensor),
+                                           c_void_p]
+LIB.dgla_spmm_set_profile_events.restype = c_int
+LIB.dgla_spmm_set_profile_events.argtypes = [c_void_p, c_void_p]
+LIB.dgla_stream_copy.restype = c_int
+LIB.dgla_stream_copy.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
+
+DGLA_ACCUMULATE = 1
+DGLA_PLAN_VALID = 2
+
+
+def check_call(ret):
+    if ret != 0:
+        raise DGLAMDError(LIB.dgla_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,364 @@
+// Auxiliary gfx950 kernels: COO g-SpMM (atomics), fused edge softmax, streaming copy.
+#include "common.h"
+
+namespace dgla {
+
+// ---------------------------------------------------------------------------------------
+// Streaming copy: 16 bytes per lane, grid-stride.  bench.py uses it to measure the HBM
+// peak the roofline fraction is quoted against (MI355X_MICROARCH.md: 6.29 TB/s float4 copy).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restrict__ src,
+                                                          uint4* __restrict__ dst, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += stride)
+    dst[i] = src[i];
+}
+
+int launch_stream_copy(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  const size_t n = bytes / 16;
+  if (n == 0) return 0;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                     stream, static_cast<const uint4*>(src), static_cast<uint4*>(dst), n);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// COO g-SpMM.  Replaces SpMMCooKernel / ArgSpMMCooKernel (src/array/cuda/spmm.cuh:410-487,
+// host :624-682): fill with the reducer identity, edge-parallel atomics into out[dst].
+// Unlike the reference's racy second pass (ties -> last writer), arg results are made
+// deterministic: among the edges that attain the extremum the LOWEST position wins, the
+// same answer the CSR path and the sequential CPU loop give.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void fill_kernel(T* p, int64_t n, T v) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride)
+    p[i] = v;
+}
+
+__device__ __forceinline__ void atomic_max_f(float* a, float v) {
+  int old = __float_as_int(*a);
+  while (__int_as_float(old) < v) {
+    const int assumed = old;
+    old = atomicCAS(reinterpret_cast<int*>(a), assumed, __float_as_int(v));
+    if (old == assumed) break;
+  }
+}
+__device__ __forceinline__ void atomic_min_f(float* a, float v) {
+  int old = __float_as_int(*a);
+  while (__int_as_float(old) > v) {
+    const int assumed = old;
+    old = atomicCAS(reinterpret_cast<int*>(a), assumed, __float_as_int(v));
+    if (old == assumed) break;
+  }
+}
+__device__ __forceinline__ void atomic_max_f(double* a, double v) {
+  unsigned long long old = __double_as_longlong(*a);
+  while (__longlong_as_double(old) < v) {
+    const unsigned long long assumed = old;
+    old = atomicCAS(reinterpret_cast<unsigned long long*>(a), assumed,
+                    static_cast<unsigned long long>(__double_as_longlong(v)));
+    if (old == assumed) break;
+  }
+}
+__device__ __forceinline__ void atomic_min_f(double* a, double v) {
+  unsigned long long old = __double_as_longlong(*a);
+  while (__longlong_as_double(old) > v) {
+    const unsigned long long assumed = old;
+    old = atomicCAS(reinterpret_cast<unsigned long long*>(a), assumed,
+                    static_cast<unsigned long long>(__double_as_longlong(v)));
+    if (old == assumed) break;
+  }
+}
+
+template <typename Idx>
+__device__ __forceinline__ void atomic_min_idx(Idx* a, Idx v);
+template <>
+__device__ __forceinline__ void atomic_min_idx<int32_t>(int32_t* a, int32_t v) {
+  atomicMin(a, v);
+}
+template <>
+__device__ __forceinline__ void atomic_min_idx<int64_t>(int64_t* a, int64_t v) {
+  atomicMin(reinterpret_cast<long long*>(a), static_cast<long long>(v));
+}
+
+struct CooSpmmParams {
+  const void* row;
+  const void* col;
+  const void* eids;
+  int64_t nnz, num_dst;
+  const void* ufeat;
+  const void* efeat;
+  void* out;
+  void* arg_u;
+  void* arg_e;
+  int out_len, lhs_len, rhs_len;
+  int use_bcast;
+  BcastDims bd;
+};
+
+template <int OP, typename T>
+__device__ __forceinline__ T coo_apply(T l, T r) {
+  if constexpr (OP == kAdd) return l + r;
+  if constexpr (OP == kSub) return l - r;
+  if constexpr (OP == kMul) return l * r;
+  if constexpr (OP == kDiv) return l / r;
+  if constexpr (OP == kCopyLhs) return l;
+  return r;
+}
+
+// PASS: 0 = reduce values, 1 = record the lowest position attaining the extremum.
+template <typename Idx, typename DT, int OP, int RED, int PASS>
+__global__ __launch_bounds__(256) void spmm_coo_kernel(const CooSpmmParams p) {
+  constexpr bool UL = op_uses_lhs(OP), UR = op_uses_rhs(OP);
+  const Idx* __restrict__ row = static_cast<const Idx*>(p.row);
+  const Idx* __restrict__ col = static_cast<const Idx*>(p.col);
+  const Idx* __restrict__ eids = static_cast<const Idx*>(p.eids);
+  const DT* __restrict__ X = static_cast<const DT*>(p.ufeat);
+  const DT* __restrict__ W = static_cast<const DT*>(p.efeat);
+  DT* out = static_cast<DT*>(p.out);
+  Idx* posbuf = static_cast<Idx*>(UR ? p.arg_e : p.arg_u);
+  const int64_t total = p.nnz * p.out_len;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; idx < total;
+       idx += stride) {
+    const int64_t i = idx / p.out_len;
+    const int k = static_cast<int>(idx - i * p.out_len);
+    const int64_t src = row[i], dst = col[i];
+    const int64_t eid = eids ? static_cast<int64_t>(eids[i]) : i;
+    int lo = k, ro = k;
+    if (p.use_bcast) bcast_offsets(p.bd, k, &lo, &ro);
+    DT l = DT(0), r = DT(0);
+    if constexpr (UL) l = X[src * p.lhs_len + lo];
+    if constexpr (UR) r = W[eid * p.rhs_len + ro];
+    const DT val = coo_apply<OP, DT>(l, r);
+    DT* o = out + dst * p.out_len + k;
+    if constexpr (PASS == 0) {
+      if constexpr (RED == kSum) {
+        atomicAdd(o, val);
+      } else if constexpr (RED == kMax) {
+        atomic_max_f(o, val);
+      } else {
+        atomic_min_f(o, val);
+      }
+    } else {
+      if (val == *o) atomic_min_idx<Idx>(posbuf + dst * p.out_len + k, static_cast<Idx>(i));
+    }
+  }
+}
+
+// pass 2: translate the winning position into (source id, edge id); untouched -> 0.
+template <typename Idx, int OP>
+__global__ __launch_bounds__(256) void spmm_coo_arg_finish_kernel(const CooSpmmParams p, Idx sentinel) {
+  constexpr bool UL = op_uses_lhs(OP), UR = op_uses_rhs(OP);
+  const Idx* __restrict__ row = static_cast<const Idx*>(p.row);
+  const Idx* __restrict__ eids = static_cast<const Idx*>(p.eids);
+  Idx* argu = static_cast<Idx*>(p.arg_u);
+  Idx* arge = static_cast<Idx*>(p.arg_e);
+  Idx* posbuf = UR ? arge : argu;
+  const int64_t total = p.num_dst * p.out_len;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; idx < total;
+       idx += stride) {
+    const Idx pos = posbuf[idx];
+    const bool hit = pos != sentinel;
+    if constexpr (UL) argu[idx] = hit ? row[pos] : Idx(0);
+    if constexpr (UR) arge[idx] = hit ? (eids ? eids[pos] : pos) : Idx(0);
+  }
+}
+
+static unsigned grid_for(int64_t work) {
+  int64_t b = (work + 255) / 256;
+  if (b > 256 * 32) b = 256 * 32;
+  if (b < 1) b = 1;
+  return static_cast<unsigned>(b);
+}
+
+template <typename Idx, typename DT, int OP, int RED>
+static int spmm_coo_run(const CooSpmmParams& p, hipStream_t s) {
+  const int64_t nout = p.num_dst * p.out_len;
+  DT ident = DT(0);
+  if (RED == kMax) ident = -static_cast<DT>(__builtin_huge_val());
+  if (RED == kMin) ident = static_cast<DT>(__builtin_huge_val());
+  hipLaunchKernelGGL((fill_kernel<DT>), dim3(grid_for(nout)), dim3(256), 0, s,
+                     static_cast<DT*>(p.out), nout, ident);
+  const unsigned g = grid_for(p.nnz * p.out_len);
+  hipLaunchKernelGGL((spmm_coo_kernel<Idx, DT, OP, RED, 0>), dim3(g), dim3(256), 0, s, p);
+  if (RED != kSum) {
+    const Idx sentinel = static_cast<Idx>((~static_cast<uint64_t>(0)) >> (65 - 8 * sizeof(Idx)));
+    Idx* posbuf = static_cast<Idx*>(op_uses_rhs(OP) ? p.arg_e : p.arg_u);
+    hipLaunchKernelGGL((fill_kernel<Idx>), dim3(grid_for(nout)), dim3(256), 0, s, posbuf, nout,
+                       sentinel);
+    hipLaunchKernelGGL((spmm_coo_kernel<Idx, DT, OP, RED, 1>), dim3(g), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((spmm_coo_arg_finish_kernel<Idx, OP>), dim3(grid_for(nout)), dim3(256), 0,
+                       s, p, sentinel);
+  }
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename Idx, typename DT, int OP>
+static int spmm_coo_red(const CooSpmmParams& p, int red, hipStream_t s) {
+  switch (red) {
+    case kSum: return spmm_coo_run<Idx, DT, OP, kSum>(p, s);
+    case kMax: return spmm_coo_run<Idx, DT, OP, kMax>(p, s);
+    case kMin: return spmm_coo_run<Idx, DT, OP, kMin>(p, s);
+  }
+  last_error() = "unsupported SpMM reducer";
+  return -1;
+}
+
+template <typename Idx, typename DT>
+static int spmm_coo_op(const CooSpmmParams& p, int op, int red, hipStream_t s) {
+  switch (op) {
+    case kAdd: return spmm_coo_red<Idx, DT, kAdd>(p, red, s);
+    case kSub: return spmm_coo_red<Idx, DT, kSub>(p, red, s);
+    case kMul: return spmm_coo_red<Idx, DT, kMul>(p, red, s);
+    case kDiv: return spmm_coo_red<Idx, DT, kDiv>(p, red, s);
+    case kCopyLhs: return spmm_coo_red<Idx, DT, kCopyLhs>(p, red, s);
+    case kCopyRhs: return spmm_coo_red<Idx, DT, kCopyRhs>(p, red, s);
+  }
+  last_error() = "unsupported SpMM binary operator";
+  return -1;
+}
+
+int launch_spmm_coo(const CooView& coo, int op, int red, int dtype, const void* ufeat,
+                    const void* efeat, void* out, void* arg_u, void* arg_e, int64_t out_len,
+                    int64_t lhs_len, int64_t rhs_len, bool use_bcast, const BcastDims& bd,
+                    hipStream_t stream) {
+  CooSpmmParams p;
+  p.row = coo.row;
+  p.col = coo.col;
+  p.eids = coo.eids;
+  p.nnz = coo.nnz;
+  p.num_dst = coo.num_cols;
+  p.ufeat = ufeat;
+  p.efeat = efeat;
+  p.out = out;
+  p.arg_u = arg_u;
+  p.arg_e = arg_e;
+  p.out_len = static_cast<int>(out_len);
+  p.lhs_len = static_cast<int>(lhs_len);
+  p.rhs_len = static_cast<int>(rhs_len);
+  p.use_bcast = use_bcast ? 1 : 0;
+  p.bd = bd;
+  if (dtype == kF32)
+    return coo.idbits == 32 ? spmm_coo_op<int32_t, float>(p, op, red, stream)
+                            : spmm_coo_op<int64_t, float>(p, op, red, stream);
+  if (dtype == kF64)
+    return coo.idbits == 32 ? spmm_coo_op<int32_t, double>(p, op, red, stream)
+                            : spmm_coo_op<int64_t, double>(p, op, red, stream);
+  // the reference refuses half types on this path as well (spmm.cuh:633-641)
+  last_error() = "SpMM on COO does not support fp16/bf16 features; use the CSR format";
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused edge softmax on the in-edge CSR (rows = destination nodes).
+// One lane group of LPE >= dim lanes per row; three sweeps over the row's edges
+// (max, exp + sum, normalise).  Same arithmetic as Edge_softmax_csr_forward /
+// _backward (src/array/cpu/spmm.h:484-570), which the reference never ported to GPU.
+// ---------------------------------------------------------------------------------------
+template <typename Idx, typename DT>
+__global__ __launch_bounds__(256) void edge_softmax_fwd_kernel(
+    const Idx* __restrict__ indptr, const Idx* __restrict__ eids, const DT* __restrict__ score,
+    DT* __restrict__ out, int64_t num_rows, int dim, int log2_lpe) {
+  using A = typename Acc<DT>::type;
+  const int lpe = 1 << log2_lpe;
+  const int lg = threadIdx.x & (lpe - 1);
+  const int64_t gpb = blockDim.x >> log2_lpe;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * gpb;
+  for (int64_t r = blockIdx.x * gpb + (threadIdx.x >> log2_lpe); r < num_rows; r += stride) {
+    const int64_t s = indptr[r], e = indptr[r + 1];
+    for (int k = lg; k < dim; k += lpe) {
+      A mx = -static_cast<A>(__builtin_huge_valf());
+      for (int64_t j = s; j < e; ++j) {
+        const int64_t eid = eids ? static_cast<int64_t>(eids[j]) : j;
+        const A v = to_acc<DT>(score[eid * dim + k]);
+        mx = mx > v ? mx : v;
+      }
+      A sum = A(0);
+      for (int64_t j = s; j < e; ++j) {
+        const int64_t eid = eids ? static_cast<int64_t>(eids[j]) : j;
+        const A ex = static_cast<A>(exp(static_cast<A>(to_acc<DT>(score[eid * dim + k]) - mx)));
+        sum += ex;
+      }
+      for (int64_t j = s; j < e; ++j) {
+        const int64_t eid = eids ? static_cast<int64_t>(eids[j]) : j;
+        const A ex = static_cast<A>(exp(static_cast<A>(to_acc<DT>(score[eid * dim + k]) - mx)));
+        out[eid * dim + k] = from_acc<DT>(ex / sum);
+      }
+    }
+  }
+}
+
+template <typename Idx, typename DT>
+__global__ __launch_bounds__(256) void edge_softmax_bwd_kernel(
+    const Idx* __restrict__ indptr, const Idx* __restrict__ eids, const DT* __restrict__ out,
+    const DT* __restrict__ sds, DT* __restrict__ back, int64_t num_rows, int dim, int log2_lpe) {
+  using A = typename Acc<DT>::type;
+  const int lpe = 1 << log2_lpe;
+  const int lg = threadIdx.x & (lpe - 1);
+  const int64_t gpb = blockDim.x >> log2_lpe;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * gpb;
+  for (int64_t r = blockIdx.x * gpb + (threadIdx.x >> log2_lpe); r < num_rows; r += stride) {
+    const int64_t s = indptr[r], e = indptr[r + 1];
+    for (int k = lg; k < dim; k += lpe) {
+      A sum = A(0);
+      for (int64_t j = s; j < e; ++j) {
+        const int64_t eid = eids ? static_cast<int64_t>(eids[j]) : j;
+        sum += to_acc<DT>(sds[eid * dim + k]);
+      }
+      for (int64_t j = s; j < e; ++j) {
+        const int64_t eid = eids ? static_cast<int64_t>(eids[j]) : j;
+        back[eid * dim + k] =
+            from_acc<DT>(to_acc<DT>(sds[eid * dim + k]) - sum * to_acc<DT>(out[eid * dim + k]));
+      }
+    }
+  }
+}
+
+template <typename Idx, typename DT>
+static int edge_softmax_run(const CsrView& csr, const void* a, const void* b, void* c, int dim,
+                            bool backward, hipStream_t s) {
+  int l2 = 0;
+  while ((1 << l2) < dim && l2 < 6) ++l2;
+  const int64_t gpb = 256 >> l2;
+  int64_t blocks = (csr.num_rows + gpb - 1) / gpb;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  if (blocks < 1) blocks = 1;
+  if (!backward)
+    hipLaunchKernelGGL((edge_softmax_fwd_kernel<Idx, DT>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(256), 0, s, static_cast<const Idx*>(csr.indptr),
+                       static_cast<const Idx*>(csr.eids), static_cast<const DT*>(a),
+                       static_cast<DT*>(c), csr.num_rows, dim, l2);
+  else
+    hipLaunchKernelGGL((edge_softmax_bwd_kernel<Idx, DT>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(256), 0, s, static_cast<const Idx*>(csr.indptr),
+                       static_cast<const Idx*>(csr.eids), static_cast<const DT*>(a),
+                       static_cast<const DT*>(b), static_cast<DT*>(c), csr.num_rows, dim, l2);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_edge_softmax(const CsrView& csr, int dtype, const void* a, const void* b, void* c,
+                        int64_t dim, bool backward, hipStream_t s) {
+  const int d = static_cast<int>(dim);
+#define DGLA_ES(DT)                                                              \
+  return csr.idbits == 32 ? edge_softmax_run<int32_t, DT>(csr, a, b, c, d, backward, s) \
+                          : edge_softmax_run<int64_t, DT>(csr, a, b, c, d, backward, s)
+  switch (dtype) {
+    case kF32: DGLA_ES(float);
+    case kF64: DGLA_ES(double);
+    case kF16: DGLA_ES(f16_t);
+    case kBF16: DGLA_ES(bf16_t);
+  }
+#undef DGLA_ES
+  last_error() = "unsupported dtype";
+  return -1;
+}
+
+}  // namespace dgla

@@ -1,0 +1,510 @@
+// C-ABI entry points of libdgl_amd.so, layer (2): the PackedFunc-style registry the
+// reference's Python FFI binds (include/dgl/runtime/c_runtime_api.h:336-338,437-445;
+// src/runtime/c_runtime_api.cc:248-277; src/runtime/registry.cc).  Functions are looked up
+// by global name and called with (DGLValue*, type codes); errors are returned as -1 with a
+// thread-local message (src/runtime/runtime_base.h:14-45).
+//
+// Registered names that exist in the reference keep the reference's argument order:
+//   sparse._CAPI_DGLKernelSpMM                (g, op, reduce, U, E, V, ArgU, ArgE)      kernel.cc:473-499
+//   sparse._CAPI_DGLKernelSDDMM               (g, op, lhs, rhs, out, lhs_tgt, rhs_tgt)  kernel.cc:603-626
+//   sparse._CAPI_DGLKernelEdge_softmax_forward  (g, op, U, E, V)                        kernel.cc:542-551
+//   sparse._CAPI_DGLKernelEdge_softmax_backward (g, op, out, sds, back, ufeat)          kernel.cc:553-561
+// The graph argument is a handle to the minimal unit-graph object below (the reference passes
+// a HeteroGraphRef; only NumVertices / NumEdges / GetCSCMatrix / GetCSRMatrix / GetCOOMatrix
+// of it are used on this path, src/array/kernel.cc:20-44,224-248).  It is built through the
+// `dgl_amd._CAPI_UnitGraph*` functions, which have no counterpart in the reference (there the
+// graph engine owns the index arrays; here PyTorch does and the handle only borrows pointers).
+#include "../../include/dgl_amd.h"
+
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace dgla {
+
+struct FfiArgs {
+  DGLValue* v;
+  int* tc;
+  int n;
+};
+
+using PackedFn = std::function<int(const FfiArgs&, DGLValue* ret, int* ret_tc)>;
+
+struct Registry {
+  std::map<std::string, PackedFn> fns;
+  std::vector<const char*> names;  // stable storage for DGLFuncListGlobalNames
+  static Registry& get() {
+    static Registry r;
+    return r;
+  }
+  void add(const char* name, PackedFn f) { fns[name] = std::move(f); }
+};
+
+struct Registrar {
+  Registrar(const char* name, PackedFn f) { Registry::get().add(name, std::move(f)); }
+};
+
+static int ffi_fail(const std::string& msg) {
+  last_error() = msg;
+  return -1;
+}
+
+// thread-local stream, like the reference's per-thread CUDAThreadEntry / current torch stream
+static thread_local hipStream_t tls_stream = nullptr;
+
+// ---- argument unpacking -------------------------------------------------------------
+static bool is_array(int tc) { return tc == kArrayHandle || tc == kNDArrayContainer; }
+
+static int get_int(const FfiArgs& a, int i, int64_t* out) {
+  if (i >= a.n || (a.tc[i] != kObjectInt && a.tc[i] != kObjectUInt))
+    return ffi_fail("argument " + std::to_string(i) + ": expected an integer");
+  *out = a.v[i].v_int64;
+  return 0;
+}
+static int get_str(const FfiArgs& a, int i, const char** out) {
+  if (i >= a.n || a.tc[i] != kStr)
+    return ffi_fail("argument " + std::to_string(i) + ": expected a string");
+  *out = a.v[i].v_str;
+  return 0;
+}
+static int get_handle(const FfiArgs& a, int i, void** out) {
+  if (i >= a.n || (a.tc[i] != kObjectHandle && a.tc[i] != kHandle))
+    return ffi_fail("argument " + std::to_string(i) + ": expected an object handle");
+  *out = a.v[i].v_handle;
+  return 0;
+}
+// An NDArray argument.  "Absent" operands are empty arrays (IsNullArray == shape[0] == 0,
+// include/dgl/aten/array_ops.h:37) or kNull.
+static int get_array(const FfiArgs& a, int i, DGLArray** out) {
+  if (i >= a.n) return ffi_fail("argument " + std::to_string(i) + " is missing");
+  if (a.tc[i] == kNull) {
+    *out = nullptr;
+    return 0;
+  }
+  if (!is_array(a.tc[i]))
+    return ffi_fail("argument " + std::to_string(i) + ": expected an NDArray");
+  *out = static_cast<DGLArray*>(a.v[i].v_handle);
+  return 0;
+}
+
+static bool null_array(const DGLArray* t) { return !t || t->ndim == 0 || t->shape[0] == 0 || !t->data; }
+
+static bool on_gpu(const DGLArray* t) {
+  return t->ctx.device_type == kDGLROCM || t->ctx.device_type == kDGLCUDA;
+}
+
+static int check_contiguous(const DGLArray* t, const char* name) {
+  // src/array/check.h:29-37
+  if (!t->strides) return 0;
+  int64_t expect = 1;
+  for (int i = t->ndim - 1; i >= 0; --i) {
+    if (t->shape[i] != 1 && t->strides[i] != expect)
+      return ffi_fail(std::string(name) + " must be contiguous");
+    expect *= t->shape[i];
+  }
+  return 0;
+}
+
+static int float_dtype(const DGLArray* t, dgla_dtype* out) {
+  const DGLDataType d = t->dtype;
+  if (d.lanes == 1) {
+    if (d.code == 2 && d.bits == 32) return *out = DGLA_F32, 0;
+    if (d.code == 2 && d.bits == 64) return *out = DGLA_F64, 0;
+    if (d.code == 2 && d.bits == 16) return *out = DGLA_F16, 0;
+    if (d.code == 4 && d.bits == 16) return *out = DGLA_BF16, 0;
+  }
+  return ffi_fail("feature arrays must be float16 / bfloat16 / float32 / float64");
+}
+
+static void* data_ptr(const DGLArray* t) {
+  return t ? static_cast<char*>(t->data) + t->byte_offset : nullptr;
+}
+
+struct TensorArg {
+  dgla_tensor t;
+  std::vector<int64_t> shape;
+};
+
+static void to_tensor(const DGLArray* a, TensorArg* out) {
+  if (null_array(a)) {
+    out->t.data = nullptr;
+    out->t.ndim = 0;
+    out->t.shape = nullptr;
+    return;
+  }
+  out->shape.assign(a->shape, a->shape + a->ndim);
+  out->t.data = data_ptr(a);
+  out->t.ndim = a->ndim;
+  out->t.shape = out->shape.data();
+}
+
+// ---- the unit graph handle ----------------------------------------------------------
+struct SparseFmt {
+  bool present = false;
+  const void* a = nullptr;  // indptr | row
+  const void* b = nullptr;  // indices | col
+  const void* data = nullptr;
+  int64_t nnz = 0;
+};
+
+struct UnitGraph {
+  int64_t num_src = 0, num_dst = 0, num_edges = 0;
+  int idbits = 64;
+  SparseFmt coo, csr /*rows = src*/, csc /*rows = dst*/;
+  // scratch for the CSR SpMM on `csc`; the merge plan inside stays valid between calls
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  bool plan_valid = false;
+};
+
+static int idbits_of(const DGLArray* t, int* bits) {
+  if (t->dtype.code != 0 || (t->dtype.bits != 32 && t->dtype.bits != 64))
+    return ffi_fail("index arrays must be int32 or int64");
+  *bits = t->dtype.bits;
+  return 0;
+}
+
+static dgla_csr csr_of(const UnitGraph* g, const SparseFmt& f, bool rows_are_dst) {
+  dgla_csr c;
+  c.num_rows = rows_are_dst ? g->num_dst : g->num_src;
+  c.num_cols = rows_are_dst ? g->num_src : g->num_dst;
+  c.nnz = f.nnz;
+  c.idtype_bits = g->idbits;
+  c.indptr = f.a;
+  c.indices = f.b;
+  c.data = f.data;
+  return c;
+}
+
+static dgla_coo coo_of(const UnitGraph* g) {
+  dgla_coo c;
+  c.num_rows = g->num_src;
+  c.num_cols = g->num_dst;
+  c.nnz = g->coo.nnz;
+  c.idtype_bits = g->idbits;
+  c.row = g->coo.a;
+  c.col = g->coo.b;
+  c.data = g->coo.data;
+  return c;
+}
+
+static int set_format(const FfiArgs& a, int which) {
+  void* h;
+  DGLArray *x, *y, *d;
+  if (get_handle(a, 0, &h) || get_array(a, 1, &x) || get_array(a, 2, &y) || get_array(a, 3, &d))
+    return -1;
+  UnitGraph* g = static_cast<UnitGraph*>(h);
+  if (!x || !y) return ffi_fail("index arrays are required");
+  int bx, by;
+  if (idbits_of(x, &bx) || idbits_of(y, &by)) return -1;
+  if (bx != g->idbits || by != g->idbits) return ffi_fail("index dtype does not match the graph");
+  if (!null_array(d)) {
+    int bd;
+    if (idbits_of(d, &bd)) return -1;
+    if (bd != g->idbits) return ffi_fail("edge-id dtype does not match the graph");
+  }
+  if (check_contiguous(x, "indptr/row") || check_contiguous(y, "indices/col")) return -1;
+  SparseFmt f;
+  f.present = true;
+  f.a = data_ptr(x);
+  f.b = null_array(y) ? nullptr : data_ptr(y);
+  f.data = null_array(d) ? nullptr : data_ptr(d);
+  f.nnz = y->ndim ? y->shape[0] : 0;
+  if (which == 0) {
+    if (x->shape[0] != f.nnz) return ffi_fail("row and col must have the same length");
+    g->coo = f;
+  } else {
+    const int64_t rows = which == 1 ? g->num_src : g->num_dst;
+    if (x->shape[0] != rows + 1) return ffi_fail("indptr must have num_rows + 1 entries");
+    (which == 1 ? g->csr : g->csc) = f;
+    if (which == 2) g->plan_valid = false;
+  }
+  g->num_edges = f.nnz;
+  return 0;
+}
+
+static Registrar r_create("dgl_amd._CAPI_UnitGraphCreate", [](const FfiArgs& a, DGLValue* ret, int* rtc) {
+  int64_t ns, nd, bits;
+  if (get_int(a, 0, &ns) || get_int(a, 1, &nd) || get_int(a, 2, &bits)) return -1;
+  if (bits != 32 && bits != 64) return ffi_fail("idtype bits must be 32 or 64");
+  UnitGraph* g = new UnitGraph();
+  g->num_src = ns;
+  g->num_dst = nd;
+  g->idbits = static_cast<int>(bits);
+  ret->v_handle = g;
+  *rtc = kObjectHandle;
+  return 0;
+});
+static Registrar r_free("dgl_amd._CAPI_UnitGraphFree", [](const FfiArgs& a, DGLValue*, int* rtc) {
+  void* h;
+  if (get_handle(a, 0, &h)) return -1;
+  delete static_cast<UnitGraph*>(h);
+  *rtc = kNull;
+  return 0;
+});
+static Registrar r_coo("dgl_amd._CAPI_UnitGraphSetCOO", [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  return set_format(a, 0);
+});
+static Registrar r_csr("dgl_amd._CAPI_UnitGraphSetCSR", [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  return set_format(a, 1);
+});
+static Registrar r_csc("dgl_amd._CAPI_UnitGraphSetCSC", [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  return set_format(a, 2);
+});
+// (g, uint8 NDArray) — scratch the SpMM may use; replaces the reference's AllocWorkspace
+// through the tensoradapter (src/runtime/cuda/cuda_device_api.cc:312-331): the caller
+// allocates with torch so the memory is stream-ordered and cached.
+static Registrar r_ws("dgl_amd._CAPI_UnitGraphSetWorkspace", [](const FfiArgs& a, DGLValue*, int* rtc) {
+  void* h;
+  DGLArray* w;
+  if (get_handle(a, 0, &h) || get_array(a, 1, &w)) return -1;
+  UnitGraph* g = static_cast<UnitGraph*>(h);
+  g->ws = null_array(w) ? nullptr : data_ptr(w);
+  g->ws_bytes = null_array(w) ? 0 : static_cast<size_t>(w->shape[0]) * ((w->dtype.bits + 7) / 8);
+  g->plan_valid = false;
+  *rtc = kNull;
+  return 0;
+});
+
+// ---- sparse._CAPI_DGLKernel* ----------------------------------------------------------
+struct SpmmCall {
+  UnitGraph* g;
+  const char *op, *reduce;
+  DGLArray *U, *E, *V, *ArgU, *ArgE;
+  dgla_dtype dtype;
+  TensorArg u, e, v;
+  dgla_csr csc;
+};
+
+static int unpack_spmm(const FfiArgs& a, SpmmCall* c) {
+  void* h;
+  if (get_handle(a, 0, &h) || get_str(a, 1, &c->op) || get_str(a, 2, &c->reduce) ||
+      get_array(a, 3, &c->U) || get_array(a, 4, &c->E) || get_array(a, 5, &c->V))
+    return -1;
+  c->ArgU = c->ArgE = nullptr;
+  if (a.n > 6 && get_array(a, 6, &c->ArgU)) return -1;
+  if (a.n > 7 && get_array(a, 7, &c->ArgE)) return -1;
+  c->g = static_cast<UnitGraph*>(h);
+  if (null_array(c->V)) return ffi_fail("out array is empty");
+  // CheckCtx / CheckContiguous (src/array/kernel.cc:483-497)
+  const DGLArray* arrs[5] = {c->U, c->E, c->V, c->ArgU, c->ArgE};
+  const char* names[5] = {"U_data", "E_data", "out", "Arg_U", "Arg_E"};
+  for (int i = 0; i < 5; ++i) {
+    if (null_array(arrs[i])) continue;
+    if (!on_gpu(arrs[i])) return ffi_fail(std::string(names[i]) + " is not on the GPU device of the graph");
+    if (check_contiguous(arrs[i], names[i])) return -1;
+  }
+  if (float_dtype(c->V, &c->dtype)) return -1;
+  for (const DGLArray* t : {c->U, c->E}) {
+    dgla_dtype d;
+    if (null_array(t)) continue;
+    if (float_dtype(t, &d)) return -1;
+    if (d != c->dtype) return ffi_fail("operand and output dtypes differ");
+  }
+  to_tensor(c->U, &c->u);
+  to_tensor(c->E, &c->e);
+  to_tensor(c->V, &c->v);
+  return 0;
+}
+
+static Registrar r_spmm_ws("sparse._CAPI_DGLKernelSpMMWorkspaceBytes",
+                           [](const FfiArgs& a, DGLValue* ret, int* rtc) {
+  SpmmCall c;
+  if (unpack_spmm(a, &c)) return -1;
+  *rtc = kObjectInt;
+  ret->v_int64 = 0;
+  if (!c.g->csc.present) return 0;  // COO path needs no scratch
+  const dgla_csr csc = csr_of(c.g, c.g->csc, true);
+  last_error().clear();
+  ret->v_int64 = static_cast<int64_t>(
+      dgla_spmm_csr_workspace_bytes(c.op, c.reduce, &csc, c.dtype, &c.u.t, &c.e.t, &c.v.t));
+  return last_error().empty() ? 0 : -1;
+});
+
+static Registrar r_spmm("sparse._CAPI_DGLKernelSpMM", [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  SpmmCall c;
+  if (unpack_spmm(a, &c)) return -1;
+  UnitGraph* g = c.g;
+  // aten::SpMM: CSC (in-edge CSR) preferred, else COO (src/array/kernel.cc:26-43)
+  if (g->csc.present) {
+    const dgla_csr csc = csr_of(g, g->csc, true);
+    uint32_t flags = g->plan_valid ? DGLA_PLAN_VALID : 0;
+    // `V` arrives zero-filled (python/dgl/_sparse_ops.py:227) so writing rows instead of
+    // accumulating into them gives the same result for the single-relation call.
+    const int rc = dgla_spmm_csr(c.op, c.reduce, &csc, c.dtype, &c.u.t, &c.e.t, &c.v.t,
+                                 null_array(c.ArgU) ? nullptr : data_ptr(c.ArgU),
+                                 null_array(c.ArgE) ? nullptr : data_ptr(c.ArgE), g->ws,
+                                 g->ws_bytes, flags, tls_stream);
+    if (rc == 0) g->plan_valid = true;
+    return rc;
+  }
+  if (g->coo.present) {
+    const dgla_coo coo = coo_of(g);
+    return dgla_spmm_coo(c.op, c.reduce, &coo, c.dtype, &c.u.t, &c.e.t, &c.v.t,
+                         null_array(c.ArgU) ? nullptr : data_ptr(c.ArgU),
+                         null_array(c.ArgE) ? nullptr : data_ptr(c.ArgE), tls_stream);
+  }
+  return ffi_fail("SpMM only supports CSC and COO formats");  // kernel.cc:41
+});
+
+// Same as above but `out += result` — what the reference's per-relation loop relies on
+// (src/array/cuda/spmm_hetero.cu:150-158, spmm.cuh:528-534).
+static Registrar r_spmm_acc("sparse._CAPI_DGLKernelSpMMAccumulate",
+                            [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  SpmmCall c;
+  if (unpack_spmm(a, &c)) return -1;
+  UnitGraph* g = c.g;
+  if (!g->csc.present) return ffi_fail("SpMMAccumulate needs the CSC format");  // kernel.cc:212-217
+  const dgla_csr csc = csr_of(g, g->csc, true);
+  const uint32_t flags = (g->plan_valid ? DGLA_PLAN_VALID : 0) | DGLA_ACCUMULATE;
+  const int rc = dgla_spmm_csr(c.op, c.reduce, &csc, c.dtype, &c.u.t, &c.e.t, &c.v.t, nullptr,
+                               nullptr, g->ws, g->ws_bytes, flags, tls_stream);
+  if (rc == 0) g->plan_valid = true;
+  return rc;
+});
+
+static Registrar r_sddmm("sparse._CAPI_DGLKernelSDDMM", [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  void* h;
+  const char* op;
+  DGLArray *lhs, *rhs, *out;
+  int64_t lt, rt;
+  if (get_handle(a, 0, &h) || get_str(a, 1, &op) || get_array(a, 2, &lhs) ||
+      get_array(a, 3, &rhs) || get_array(a, 4, &out) || get_int(a, 5, &lt) || get_int(a, 6, &rt))
+    return -1;
+  UnitGraph* g = static_cast<UnitGraph*>(h);
+  if (g->num_edges == 0) return 0;
+  if (null_array(out)) return ffi_fail("out array is empty");
+  dgla_dtype dt;
+  if (float_dtype(out, &dt)) return -1;
+  for (const DGLArray* t : {lhs, rhs, out}) {
+    if (null_array(t)) continue;
+    dgla_dtype d;
+    if (!on_gpu(t)) return ffi_fail("array is not on the GPU device of the graph");
+    if (check_contiguous(t, "array") || float_dtype(t, &d)) return -1;
+    if (d != dt) return ffi_fail("operand and output dtypes differ");
+  }
+  TensorArg l, r, o;
+  to_tensor(lhs, &l);
+  to_tensor(rhs, &r);
+  to_tensor(out, &o);
+  // aten::SDDMM: COO preferred, else CSR (src/array/kernel.cc:230-247)
+  if (g->coo.present) {
+    const dgla_coo coo = coo_of(g);
+    return dgla_sddmm_coo(op, &coo, dt, &l.t, &r.t, &o.t, static_cast<int>(lt),
+                          static_cast<int>(rt), tls_stream);
+  }
+  if (g->csr.present) {
+    const dgla_csr csr = csr_of(g, g->csr, false);
+    return dgla_sddmm_csr(op, &csr, dt, &l.t, &r.t, &o.t, static_cast<int>(lt),
+                          static_cast<int>(rt), tls_stream);
+  }
+  return ffi_fail("SDDMM only supports CSR and COO formats");  // kernel.cc:245
+});
+
+static int edge_softmax_ffi(const FfiArgs& a, bool backward) {
+  void* h;
+  const char* op;
+  DGLArray *x, *y, *z;
+  if (get_handle(a, 0, &h) || get_str(a, 1, &op) || get_array(a, 2, &x) || get_array(a, 3, &y) ||
+      get_array(a, 4, &z))
+    return -1;
+  UnitGraph* g = static_cast<UnitGraph*>(h);
+  if (!g->csc.present) return ffi_fail("edge_softmax needs the CSC format");
+  const dgla_csr csc = csr_of(g, g->csc, true);
+  dgla_dtype dt;
+  TensorArg tx, ty, tz;
+  to_tensor(x, &tx);
+  to_tensor(y, &ty);
+  to_tensor(z, &tz);
+  if (!backward) {
+    // (g, op, U(null), E = score, V = out)
+    if (null_array(y) || null_array(z)) return g->num_edges == 0 ? 0 : ffi_fail("score / out missing");
+    if (float_dtype(y, &dt)) return -1;
+    return dgla_edge_softmax_forward(&csc, dt, &ty.t, &tz.t, tls_stream);
+  }
+  // (g, op, out, sds, back_out, ufeat(null))
+  if (null_array(x) || null_array(y) || null_array(z))
+    return g->num_edges == 0 ? 0 : ffi_fail("out / sds / back missing");
+  if (float_dtype(x, &dt)) return -1;
+  return dgla_edge_softmax_backward(&csc, dt, &tx.t, &ty.t, &tz.t, tls_stream);
+}
+static Registrar r_esf("sparse._CAPI_DGLKernelEdge_softmax_forward",
+                       [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  return edge_softmax_ffi(a, false);
+});
+static Registrar r_esb("sparse._CAPI_DGLKernelEdge_softmax_backward",
+                       [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  return edge_softmax_ffi(a, true);
+});
+
+}  // namespace dgla
+
+using namespace dgla;
+
+extern "C" {
+
+const char* DGLGetLastError(void) { return last_error().c_str(); }
+void DGLAPISetLastError(const char* msg) { last_error() = msg ? msg : ""; }
+
+int DGLFuncListGlobalNames(int* out_size, const char*** out_array) {
+  Registry& r = Registry::get();
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  r.names.clear();
+  for (auto& kv : r.fns) r.names.push_back(kv.first.c_str());
+  *out_size = static_cast<int>(r.names.size());
+  *out_array = r.names.data();
+  return 0;
+}
+
+int DGLFuncGetGlobal(const char* name, DGLFunctionHandle* out) {
+  Registry& r = Registry::get();
+  auto it = r.fns.find(name ? name : "");
+  // like the reference, an unknown name yields a NULL handle, not an error
+  *out = it == r.fns.end() ? nullptr : static_cast<void*>(&it->second);
+  return 0;
+}
+
+int DGLFuncCall(DGLFunctionHandle func, DGLValue* args, int* type_codes, int num_args,
+                DGLValue* ret_val, int* ret_type_code) {
+  if (!func) {
+    last_error() = "DGLFuncCall: null function handle";
+    return -1;
+  }
+  DGLValue dummy;
+  int dummy_tc = kNull;
+  const FfiArgs a{args, type_codes, num_args};
+  try {
+    return (*static_cast<PackedFn*>(func))(a, ret_val ? ret_val : &dummy,
+                                           ret_type_code ? ret_type_code : &dummy_tc);
+  } catch (const std::exception& e) {
+    last_error() = e.what();
+    return -1;
+  }
+}
+
+int DGLFuncFree(DGLFunctionHandle) { return 0; }  // global functions are never freed
+
+int DGLSetStream(int, int, void* stream) {
+  tls_stream = static_cast<hipStream_t>(stream);
+  return 0;
+}
+int DGLGetStream(int, int, void** stream) {
+  *stream = tls_stream;
+  return 0;
+}
+
+}  // extern "C"

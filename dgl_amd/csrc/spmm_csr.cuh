@@ -1,0 +1,646 @@
+// g-SpMM on CSR for gfx950 (MI355X): merge-path row-blocked kernel.
+//
+// Replaces, from scratch, the reference's SpMMCsrKernel (src/array/cuda/spmm.cuh:496-543,
+// host :700-732) and its cuSPARSE route (spmm.cuh:196-284, chosen at spmm.cu:37-58).
+//
+// Decomposition (why it looks nothing like the reference's thread-per-(row, column) loop):
+//  * The CSR is cut by MERGE PATH into units of kWaveItems = 512 "items" (an item is one
+//    edge or one row end).  Every wavefront gets exactly one unit, so a 17k-degree row and
+//    a run of isolated nodes cost the same per wave: no degree imbalance, no tail.
+//    The unit boundaries ("plan", one int64 per wave) are found by a binary search over
+//    indptr[r] + r in a tiny pre-kernel and can be cached by the caller per graph.
+//  * A wave stages its unit's column indices, row ends (and edge ids) in LDS with
+//    coalesced loads, then splits the 64 lanes into G = 64 / LPE lane groups, LPE being the
+//    number of lanes needed to cover one feature row with 16-byte loads (F = 100 fp32 ->
+//    25 of 32 lanes live, G = 2).  Each group walks its own contiguous sub-range of the
+//    unit (found by a second merge search in LDS): for every edge all lanes of the group
+//    read the same column id from LDS (broadcast) and gather one 16-byte piece of the
+//    neighbour's feature row, U edges in flight per lane plus the next batch prefetched.
+//  * Partial sums live in registers; a row end flushes them with one coalesced row store.
+//    Rows that straddle group boundaries hand a "carry" (head part) and a "tail" to a
+//    workspace; a small fix-up kernel combines them in position order.  No atomics:
+//    results are run-to-run deterministic and arg-max / arg-min ties resolve to the lowest
+//    CSR position exactly like the reference's sequential loop (functor.cuh:246-254).
+#pragma once
+#include "common.h"
+
+namespace dgla {
+
+template <typename Idx>
+struct SpmmParams {
+  const Idx* indptr;
+  const Idx* indices;
+  const Idx* eids;
+  int64_t num_rows, nnz, num_waves;
+  const int64_t* plan;  // [num_waves + 1] row coordinate of each unit boundary
+  const void* ufeat;
+  const void* efeat;
+  void* out;
+  Idx* arg_u;
+  Idx* arg_e;
+  int out_len, lhs_len, rhs_len;
+  int log2_lpe;   // lanes per feature row = 1 << log2_lpe
+  int rhs_group;  // kBcRhsGroup
+  BcastDims bd;   // kBcGeneral
+  int accumulate;
+  // fix-up workspace, one slot per lane group: slot = wave * G + group
+  int64_t* carry_row;  // row id of the slot's carry-out, or -1
+  void* carry_val;     // [slots, out_len] accumulator type: head part of a straddling row
+  void* tail_val;      // [slots, out_len] accumulator type: tail part of a straddling row
+  Idx* carry_argu;     // max / min only
+  Idx* carry_arge;
+  Idx* tail_argu;
+  Idx* tail_arge;
+};
+
+// ---------------------------------------------------------------------------------------
+// Plan: plan[w] = number of rows that end strictly before merge diagonal w * kWaveItems.
+// Row r's end item sits at merge position indptr[r + 1] + r, so the answer is the largest
+// i in [0, N] with indptr[i] + i <= d.
+// ---------------------------------------------------------------------------------------
+template <typename Idx>
+__global__ void spmm_merge_plan_kernel(const Idx* __restrict__ indptr, int64_t num_rows,
+                                       int64_t nnz, int64_t num_waves,
+                                       int64_t* __restrict__ plan) {
+  const int64_t w = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (w > num_waves) return;
+  int64_t d = w * kWaveItems;
+  const int64_t total = num_rows + nnz;
+  if (d > total) d = total;
+  int64_t lo = 0, hi = num_rows;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (static_cast<int64_t>(indptr[mid]) + mid <= d)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  plan[w] = lo;
+}
+
+// ---------------------------------------------------------------------------------------
+template <int OP, typename A>
+__device__ __forceinline__ A apply_op(A l, A r) {
+  if constexpr (OP == kAdd) return l + r;
+  if constexpr (OP == kSub) return l - r;
+  if constexpr (OP == kMul) return l * r;
+  if constexpr (OP == kDiv) return l / r;
+  if constexpr (OP == kCopyLhs) return l;
+  return r;  // kCopyRhs
+}
+
+// The binary functor's result is rounded to the storage type before it is reduced, as in
+// the reference (`DType out = BinaryOp::Call(...)`, spmm.cuh:524); a no-op for fp32/fp64.
+template <typename DT>
+__device__ __forceinline__ typename Acc<DT>::type round_to_storage(typename Acc<DT>::type v) {
+  if constexpr (sizeof(DT) == 2)
+    return to_acc<DT>(from_acc<DT>(v));
+  else
+    return v;
+}
+
+template <typename Idx, typename DT, int VEC, int OP, int RED, int BC, int U, bool ACCUM>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
+    const SpmmParams<Idx> p) {
+  using A = typename Acc<DT>::type;
+  constexpr bool UL = op_uses_lhs(OP), UR = op_uses_rhs(OP);
+  constexpr bool ARG = RED != kSum;
+  // rhs element(s) per lane and edge: a full vector only when rhs is laid out like out
+  constexpr int RV = (BC == kBcNone) ? VEC : 1;
+
+  __shared__ int s_cols[kWavesPerBlock][kWaveItems];
+  __shared__ int s_rend[kWavesPerBlock][kWaveItems + 2];
+  __shared__ Idx s_eid[UR ? kWavesPerBlock : 1][UR ? kWaveItems : 1];
+
+  const int wib = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wib;
+  const bool has_eid = p.eids != nullptr;
+
+  int64_t i0 = 0, j0 = 0;
+  int R = 0, nE = 0;
+  if (w < p.num_waves) {
+    const int64_t total = p.num_rows + p.nnz;
+    const int64_t d0 = w * kWaveItems;
+    int64_t d1 = d0 + kWaveItems;
+    if (d1 > total) d1 = total;
+    i0 = p.plan[w];
+    const int64_t i1 = p.plan[w + 1];
+    j0 = d0 - i0;
+    R = static_cast<int>(i1 - i0);
+    nE = static_cast<int>((d1 - i1) - j0);
+    const int items = nE + R;  // <= kWaveItems
+    // Stage the unit in LDS.  All loads are issued back to back (addresses clamped instead
+    // of predicated) so one HBM round trip covers the unit's nE column ids, its R row ends
+    // (indptr[i0 + 1 .. i1]) and, when the operator reads edge features, its edge ids.
+    //   s_rend[t]     = local edge offset where local row t starts
+    //   s_rend[t + 1] = where it ends;  s_rend[0] < 0 means row i0 began in an earlier unit.
+    if (items > 0) {
+      Idx itemv[kWaveItems / 64];
+      Idx eidv[kWaveItems / 64];
+#pragma unroll
+      for (int k = 0; k < kWaveItems / 64; ++k) {
+        int it = lane + 64 * k;
+        if (it >= items) it = items - 1;
+        const Idx* src = it < nE ? p.indices + (j0 + it) : p.indptr + (i0 + 1 + (it - nE));
+        itemv[k] = *src;
+        if constexpr (UR) {
+          if (has_eid) {
+            const int ie = it < nE ? it : (nE > 0 ? nE - 1 : 0);
+            eidv[k] = nE > 0 ? p.eids[j0 + ie] : Idx(0);
+          }
+        }
+      }
+      const int64_t first = static_cast<int64_t>(p.indptr[i0]) - j0;
+#pragma unroll
+      for (int k = 0; k < kWaveItems / 64; ++k) {
+        const int it = lane + 64 * k;
+        if (it < nE) {
+          s_cols[wib][it] = static_cast<int>(itemv[k]);
+          if constexpr (UR) s_eid[wib][it] = has_eid ? eidv[k] : static_cast<Idx>(j0 + it);
+        } else if (it < items) {
+          s_rend[wib][it - nE + 1] = static_cast<int>(static_cast<int64_t>(itemv[k]) - j0);
+        }
+      }
+      if (lane == 0) s_rend[wib][0] = first < 0 ? -1 : static_cast<int>(first);
+    } else if (lane == 0) {
+      s_rend[wib][0] = 0;
+    }
+  }
+  __syncthreads();
+  if (w >= p.num_waves) return;
+
+  const int lpe = 1 << p.log2_lpe;
+  const int g = lane >> p.log2_lpe;
+  const int lg = lane & (lpe - 1);
+  const int G = 64 >> p.log2_lpe;
+  const int Tg = kWaveItems >> (6 - p.log2_lpe);
+  const int F = p.out_len;
+  const int k0 = (static_cast<int>(blockIdx.y) * 64 + lg) * VEC;  // first feature of this lane
+  if (k0 >= F) return;
+
+  const int* cols = s_cols[wib];
+  const int* rend = s_rend[wib];
+  const Idx* eidl = s_eid[UR ? wib : 0];
+
+  // ---- split the unit between the lane groups (merge search in LDS) -------------------
+  const int items = R + nE;
+  int dlo = g * Tg, dhi = dlo + Tg;
+  if (dlo > items) dlo = items;
+  if (dhi > items) dhi = items;
+  auto rows_before = [&](int d) {
+    // number of row ends at merge position < d; row end t sits at rend[t + 1] + t
+    int lo = 0, hi = R;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (rend[mid + 1] + mid < d)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    return lo;
+  };
+  const int t_s = rows_before(dlo), t_e = rows_before(dhi);
+  const int e_s = dlo - t_s, e_e = dhi - t_e;
+  const int64_t slot = w * G + g;
+
+  // ---- per-lane operand offsets -------------------------------------------------------
+  int lo_off = k0, ro_off = k0;
+  if constexpr (BC == kBcRhsGroup) ro_off = k0 / p.rhs_group;
+  if constexpr (BC == kBcGeneral) bcast_offsets(p.bd, k0, &lo_off, &ro_off);
+  const DT* __restrict__ X = static_cast<const DT*>(p.ufeat) + lo_off;
+  const DT* __restrict__ Wt = static_cast<const DT*>(p.efeat) + ro_off;
+  const int64_t lhs_len = p.lhs_len, rhs_len = p.rhs_len;
+
+  using XV = VecT<DT, VEC>;
+  using WV = VecT<DT, RV>;
+  struct Batch {
+    XV x[UL ? U : 1];
+    WV w[UR ? U : 1];
+  };
+  auto load_batch = [&](int e, Batch& b) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int ee = e + u;
+      if (ee >= e_e) ee = e_e - 1;  // clamp: re-load a valid edge, ignored when reducing
+      if constexpr (UL) {
+        const int64_t c = cols[ee];
+        b.x[u] = *reinterpret_cast<const XV*>(X + c * lhs_len);
+      }
+      if constexpr (UR) {
+        const int64_t eid = static_cast<int64_t>(eidl[ee]);
+        b.w[u] = *reinterpret_cast<const WV*>(Wt + eid * rhs_len);
+      }
+    }
+  };
+
+  A acc[VEC];
+  int best[ARG ? VEC : 1];
+  const A ident = red_identity<DT>(RED);
+  int cnt = 0;
+  auto reset = [&]() {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      acc[v] = ident;
+      if constexpr (ARG) best[v] = -1;
+    }
+    cnt = 0;
+  };
+  reset();
+
+  DT* __restrict__ out = static_cast<DT*>(p.out);
+  // Does local row t_s have edges before this group's range?  Then earlier groups hold
+  // carries for it and its total is assembled by the fix-up kernel from `tail_val`.
+  bool first_is_tail = rend[t_s] < e_s;
+
+  auto flush = [&](int t) {
+    const int64_t row = i0 + t;
+    if (first_is_tail) {
+      A* tv = static_cast<A*>(p.tail_val) + slot * F + k0;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) tv[v] = acc[v];
+      if constexpr (ARG) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const int bi = best[v];
+          if constexpr (UL) p.tail_argu[slot * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : Idx(0);
+          if constexpr (UR) p.tail_arge[slot * F + k0 + v] = bi >= 0 ? eidl[bi] : Idx(0);
+        }
+      }
+      first_is_tail = false;
+    } else {
+      DT* o = out + row * F + k0;
+      VecT<DT, VEC> ov;
+      if constexpr (ACCUM) {
+        ov = *reinterpret_cast<VecT<DT, VEC>*>(o);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(to_acc<DT>(ov.v[v]) + acc[v]);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(acc[v]);
+      }
+      *reinterpret_cast<VecT<DT, VEC>*>(o) = ov;
+      if constexpr (ARG) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const int bi = best[v];
+          if constexpr (UL) p.arg_u[row * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : Idx(0);
+          if constexpr (UR) p.arg_e[row * F + k0 + v] = bi >= 0 ? eidl[bi] : Idx(0);
+        }
+      }
+    }
+    reset();
+  };
+
+  int t = t_s;
+  int next_end = (t < R) ? rend[t + 1] : 0x7fffffff;
+
+  auto reduce_batch = [&](int e, const Batch& b) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ee = e + u;
+      if (ee < e_e) {
+        while (ee >= next_end) {
+          flush(t);
+          ++t;
+          next_end = (t < R) ? rend[t + 1] : 0x7fffffff;
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          A l = A(0), r = A(0);
+          if constexpr (UL) l = to_acc<DT>(b.x[u].v[v]);
+          if constexpr (UR) r = to_acc<DT>(b.w[u].v[RV == 1 ? 0 : v]);
+          const A val = round_to_storage<DT>(apply_op<OP, A>(l, r));
+          if constexpr (RED == kSum) {
+            acc[v] += val;
+          } else if constexpr (RED == kMax) {
+            if (acc[v] < val) {
+              acc[v] = val;
+              best[v] = ee;
+            }
+          } else {
+            if (acc[v] > val) {
+              acc[v] = val;
+              best[v] = ee;
+            }
+          }
+        }
+        ++cnt;
+      }
+    }
+  };
+
+  // ---- main loop: U gathers in flight per lane, next batch issued before reducing -----
+  // The prefetch is unconditional (load_batch clamps to the group's last edge) so the
+  // loop body is branch-free up to the reduction and the compiler can wait with a counted
+  // vmcnt(U) instead of draining the prefetched batch.
+  if (e_s < e_e) {
+    int e = e_s;
+    Batch ba, bb;  // ping-pong: copying a batch would wait for its loads
+    load_batch(e, ba);
+    for (; e < e_e; e += 2 * U) {
+      load_batch(e + U, bb);
+      reduce_batch(e, ba);
+      load_batch(e + 2 * U, ba);
+      reduce_batch(e + U, bb);
+    }
+  }
+  while (t < t_e) {  // row ends after the last edge (includes zero-degree rows)
+    flush(t);
+    ++t;
+  }
+
+  // ---- carry-out: head part of the row that continues in the next group ---------------
+  const bool has_carry = cnt > 0;
+  if (lg == 0 && blockIdx.y == 0) p.carry_row[slot] = has_carry ? i0 + t : int64_t(-1);
+  if (has_carry) {
+    A* cv = static_cast<A*>(p.carry_val) + slot * F + k0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) cv[v] = acc[v];
+    if constexpr (ARG) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const int bi = best[v];
+        if constexpr (UL) p.carry_argu[slot * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : Idx(0);
+        if constexpr (UR) p.carry_arge[slot * F + k0 + v] = bi >= 0 ? eidl[bi] : Idx(0);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fix-up: for every maximal run of slots s .. s2-1 carrying the same row, combine the
+// carries in slot (= CSR position) order, then the tail held by slot s2, and write the row.
+// One 64-lane block per slot; non-leaders exit at once.
+// ---------------------------------------------------------------------------------------
+template <typename Idx, typename DT, int OP, int RED>
+__global__ __launch_bounds__(64) void spmm_csr_fixup_kernel(const SpmmParams<Idx> p,
+                                                            int64_t num_slots) {
+  using A = typename Acc<DT>::type;
+  constexpr bool UL = op_uses_lhs(OP), UR = op_uses_rhs(OP);
+  constexpr bool ARG = RED != kSum;
+  const int64_t s = blockIdx.x;
+  const int64_t row = p.carry_row[s];
+  if (row < 0) return;
+  if (s > 0 && p.carry_row[s - 1] == row) return;
+  int64_t s2 = s + 1;
+  while (s2 < num_slots && p.carry_row[s2] == row) ++s2;
+  // slot s2 holds the tail (the group in which the row ends); it always exists because a
+  // row with a carry has its row-end item in a later slot.
+  const int F = p.out_len;
+  const A* cv = static_cast<const A*>(p.carry_val);
+  const A* tv = static_cast<const A*>(p.tail_val);
+  DT* out = static_cast<DT*>(p.out);
+  for (int k = threadIdx.x; k < F; k += 64) {
+    A acc = cv[s * F + k];
+    Idx au = 0, ae = 0;
+    if constexpr (ARG) {
+      if constexpr (UL) au = p.carry_argu[s * F + k];
+      if constexpr (UR) ae = p.carry_arge[s * F + k];
+    }
+    auto combine = [&](A val, const Idx* pu, const Idx* pe, int64_t idx) {
+      if constexpr (RED == kSum) {
+        acc += val;
+      } else {
+        const bool take = (RED == kMax) ? (acc < val) : (acc > val);
+        if (take) {
+          acc = val;
+          if constexpr (UL) au = pu[idx];
+          if constexpr (UR) ae = pe[idx];
+        }
+      }
+    };
+    for (int64_t q = s + 1; q < s2; ++q) combine(cv[q * F + k], p.carry_argu, p.carry_arge, q * F + k);
+    combine(tv[s2 * F + k], p.tail_argu, p.tail_arge, s2 * F + k);
+    const int64_t o = row * F + k;
+    if (p.accumulate)
+      out[o] = from_acc<DT>(to_acc<DT>(out[o]) + acc);
+    else
+      out[o] = from_acc<DT>(acc);
+    if constexpr (ARG) {
+      if constexpr (UL) p.arg_u[o] = au;
+      if constexpr (UR) p.arg_e[o] = ae;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Host side: workspace carving and launch.
+// ---------------------------------------------------------------------------------------
+struct SpmmGeometry {
+  int vec;       // elements per lane access
+  int log2_lpe;  // lanes per feature row
+  int groups;    // lane groups per wave
+  int chunks;    // grid.y: feature chunks of 64 * vec
+  int64_t num_waves, num_slots;
+  size_t off_plan, off_carry_row, off_carry_val, off_tail_val, off_carry_argu,
+      off_carry_arge, off_tail_argu, off_tail_arge, total;
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len, int vec,
+                                  size_t acc_bytes, int idbytes, bool with_arg) {
+  SpmmGeometry g;
+  g.vec = vec;
+  int64_t lanes = (out_len + vec - 1) / vec;
+  if (lanes > 64) lanes = 64;
+  int l2 = 0;
+  while ((1 << l2) < lanes) ++l2;
+  g.log2_lpe = l2;
+  g.groups = 64 >> l2;
+  g.chunks = static_cast<int>((out_len + 64 * vec - 1) / (64 * vec));
+  g.num_waves = spmm_num_waves(num_rows, nnz);
+  g.num_slots = g.num_waves * g.groups;
+  size_t off = 0;
+  g.off_plan = off;
+  off = align_up(off + sizeof(int64_t) * (g.num_waves + 1), 256);
+  g.off_carry_row = off;
+  off = align_up(off + sizeof(int64_t) * g.num_slots, 256);
+  g.off_carry_val = off;
+  off = align_up(off + acc_bytes * g.num_slots * out_len, 256);
+  g.off_tail_val = off;
+  off = align_up(off + acc_bytes * g.num_slots * out_len, 256);
+  g.off_carry_argu = g.off_carry_arge = g.off_tail_argu = g.off_tail_arge = off;
+  if (with_arg) {
+    const size_t a = align_up(static_cast<size_t>(idbytes) * g.num_slots * out_len, 256);
+    g.off_carry_argu = off;
+    g.off_carry_arge = off + a;
+    g.off_tail_argu = off + 2 * a;
+    g.off_tail_arge = off + 3 * a;
+    off += 4 * a;
+  }
+  g.total = off;
+  return g;
+}
+
+template <typename Idx>
+inline int launch_plan(const SpmmLaunch& L, const SpmmGeometry& g) {
+  if (L.plan_valid) return 0;
+  char* ws = static_cast<char*>(L.workspace);
+  const int64_t n = g.num_waves + 1;
+  const int threads = 256;
+  const unsigned blocks = static_cast<unsigned>((n + threads - 1) / threads);
+  hipLaunchKernelGGL(spmm_merge_plan_kernel<Idx>, dim3(blocks), dim3(threads), 0, L.stream,
+                     static_cast<const Idx*>(L.csr.indptr), L.csr.num_rows, L.csr.nnz,
+                     g.num_waves, reinterpret_cast<int64_t*>(ws + g.off_plan));
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename Idx, typename DT>
+inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
+  char* ws = static_cast<char*>(L.workspace);
+  SpmmParams<Idx> p;
+  p.indptr = static_cast<const Idx*>(L.csr.indptr);
+  p.indices = static_cast<const Idx*>(L.csr.indices);
+  p.eids = static_cast<const Idx*>(L.csr.eids);
+  p.num_rows = L.csr.num_rows;
+  p.nnz = L.csr.nnz;
+  p.num_waves = g.num_waves;
+  p.plan = reinterpret_cast<const int64_t*>(ws + g.off_plan);
+  p.ufeat = L.ufeat;
+  p.efeat = L.efeat;
+  p.out = L.out;
+  p.arg_u = static_cast<Idx*>(L.arg_u);
+  p.arg_e = static_cast<Idx*>(L.arg_e);
+  p.out_len = static_cast<int>(L.out_len);
+  p.lhs_len = static_cast<int>(L.lhs_len);
+  p.rhs_len = static_cast<int>(L.rhs_len);
+  p.log2_lpe = g.log2_lpe;
+  p.rhs_group = L.rhs_group > 0 ? L.rhs_group : 1;
+  p.bd = L.bdims;
+  p.accumulate = L.accumulate ? 1 : 0;
+  p.carry_row = reinterpret_cast<int64_t*>(ws + g.off_carry_row);
+  p.carry_val = ws + g.off_carry_val;
+  p.tail_val = ws + g.off_tail_val;
+  p.carry_argu = reinterpret_cast<Idx*>(ws + g.off_carry_argu);
+  p.carry_arge = reinterpret_cast<Idx*>(ws + g.off_carry_arge);
+  p.tail_argu = reinterpret_cast<Idx*>(ws + g.off_tail_argu);
+  p.tail_arge = reinterpret_cast<Idx*>(ws + g.off_tail_arge);
+  return p;
+}
+
+// Gathers in flight per lane (x2 with the prefetched batch).
+constexpr int kSpmmUnroll = 4;
+
+template <typename Idx, typename DT, int VEC, int OP, int RED, int BC>
+inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
+  const SpmmParams<Idx> p = make_params<Idx, DT>(L, g);
+  const unsigned blocks =
+      static_cast<unsigned>((g.num_waves + kWavesPerBlock - 1) / kWavesPerBlock);
+  const ProfileEvents pe = profile_events();
+  if (pe.before) DGLA_CHECK_HIP(hipEventRecord(pe.before, L.stream));
+  if constexpr (RED == kSum) {
+    if (L.accumulate)
+      hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, true>),
+                         dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
+    else
+      hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false>),
+                         dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
+  } else {
+    hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false>),
+                       dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
+  }
+  DGLA_CHECK_HIP(hipGetLastError());
+  if (pe.after) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
+  hipLaunchKernelGGL((spmm_csr_fixup_kernel<Idx, DT, OP, RED>),
+                     dim3(static_cast<unsigned>(g.num_slots)), dim3(64), 0, L.stream, p,
+                     g.num_slots);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename Idx, typename DT, int VEC, int OP, int RED>
+inline int launch_spmm_bc(const SpmmLaunch& L, const SpmmGeometry& g) {
+  if constexpr (!op_uses_rhs(OP) || OP == kCopyRhs) {
+    return launch_spmm_one<Idx, DT, VEC, OP, RED, kBcNone>(L, g);
+  } else {
+    switch (L.bcast) {
+      case kBcNone: return launch_spmm_one<Idx, DT, VEC, OP, RED, kBcNone>(L, g);
+      case kBcRhsGroup: return launch_spmm_one<Idx, DT, VEC, OP, RED, kBcRhsGroup>(L, g);
+      default:
+        if constexpr (VEC == 1) return launch_spmm_one<Idx, DT, 1, OP, RED, kBcGeneral>(L, g);
+    }
+    last_error() = "internal: general broadcast needs the scalar path";
+    return -1;
+  }
+}
+
+template <typename Idx, typename DT, int VEC, int OP>
+inline int launch_spmm_red(const SpmmLaunch& L, const SpmmGeometry& g) {
+  switch (L.red) {
+    case kSum: return launch_spmm_bc<Idx, DT, VEC, OP, kSum>(L, g);
+    case kMax: return launch_spmm_bc<Idx, DT, VEC, OP, kMax>(L, g);
+    case kMin: return launch_spmm_bc<Idx, DT, VEC, OP, kMin>(L, g);
+  }
+  last_error() = "unsupported SpMM reducer";
+  return -1;
+}
+
+template <typename Idx, typename DT, int VEC>
+inline int launch_spmm_op(const SpmmLaunch& L, const SpmmGeometry& g) {
+  switch (L.op) {
+    case kAdd: return launch_spmm_red<Idx, DT, VEC, kAdd>(L, g);
+    case kSub: return launch_spmm_red<Idx, DT, VEC, kSub>(L, g);
+    case kMul: return launch_spmm_red<Idx, DT, VEC, kMul>(L, g);
+    case kDiv: return launch_spmm_red<Idx, DT, VEC, kDiv>(L, g);
+    case kCopyLhs: return launch_spmm_red<Idx, DT, VEC, kCopyLhs>(L, g);
+    case kCopyRhs: return launch_spmm_red<Idx, DT, VEC, kCopyRhs>(L, g);
+  }
+  last_error() = "unsupported SpMM binary operator";
+  return -1;
+}
+
+// Chooses the access width: 16-byte lane accesses when every row start is 16-byte
+// aligned and the operand layout allows it, else element-wise.
+template <typename DT>
+inline int spmm_pick_vec(const SpmmLaunch& L) {
+  constexpr int full = 16 / sizeof(DT);
+  if (L.bcast == kBcGeneral) return 1;
+  auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (L.out_len % full) return 1;
+  if (!aligned(L.out)) return 1;
+  if (op_uses_lhs(L.op) && (L.lhs_len % full || !aligned(L.ufeat))) return 1;
+  if (op_uses_rhs(L.op) && L.bcast == kBcNone && (L.rhs_len % full || !aligned(L.efeat))) return 1;
+  if (L.bcast == kBcRhsGroup && L.rhs_group % full) return 1;
+  return full;
+}
+
+template <typename DT>
+inline int launch_spmm_csr_typed(const SpmmLaunch& L) {
+  using A = typename Acc<DT>::type;
+  const int vec = spmm_pick_vec<DT>(L);
+  const SpmmGeometry g = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
+                                       L.csr.idbits / 8, L.red != kSum);
+  if (L.workspace_bytes < g.total || (g.total && !L.workspace)) {
+    last_error() = "SpMM workspace too small: need " + std::to_string(g.total) + " bytes";
+    return -1;
+  }
+  constexpr int full = 16 / sizeof(DT);
+  if (L.csr.idbits == 32) {
+    if (launch_plan<int32_t>(L, g)) return -1;
+    return vec == 1 ? launch_spmm_op<int32_t, DT, 1>(L, g) : launch_spmm_op<int32_t, DT, full>(L, g);
+  } else {
+    if (launch_plan<int64_t>(L, g)) return -1;
+    return vec == 1 ? launch_spmm_op<int64_t, DT, 1>(L, g) : launch_spmm_op<int64_t, DT, full>(L, g);
+  }
+}
+
+// Upper bound over both access widths, so the answer does not depend on pointer alignment
+// and one allocation serves every later call on this (graph, feature width).
+template <typename DT>
+inline size_t spmm_csr_workspace_typed(const SpmmLaunch& L) {
+  using A = typename Acc<DT>::type;
+  constexpr int full = 16 / sizeof(DT);
+  size_t best = 0;
+  for (int vec : {1, full}) {
+    const size_t t = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
+                                   L.csr.idbits / 8, L.red != kSum)
+                         .total;
+    if (t > best) best = t;
+  }
+  return best;
+}
+
+}  // namespace dgla

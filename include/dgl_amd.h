@@ -1,0 +1,221 @@
+/*
+ * dgl_amd.h — C ABI of the MI355X-native g-SpMM / g-SDDMM hot path (libdgl_amd.so).
+ *
+ * Two layers are exported:
+ *
+ *  (1) the GRAPH-FREE SEAM `dgla_*` — plain pointers and sizes.  It replaces the
+ *      reference's aten::CSRSpMM / COOSpMM / CSRSDDMM / COOSDDMM
+ *      (src/array/array.cc:1148-1233, declared include/dgl/aten/csr.h:1046-1066 and
+ *      include/dgl/aten/coo.h:842-867), i.e. the template seam
+ *      SpMMCsr<XPU,IdType,DType> / SDDMMCsr / SDDMMCoo of src/array/kernel_decl.h:23-87
+ *      with XPU = the ROCm device.  This is what a libdgl build would link against.
+ *
+ *  (2) the REGISTRY LAYER `DGL*` — the PackedFunc-style FFI that python/dgl/_ffi binds
+ *      (include/dgl/runtime/c_runtime_api.h:205-212,336-338,437-445): functions are found
+ *      by name ("sparse._CAPI_DGLKernelSpMM", ...) and called with (DGLValue*, type codes).
+ *      See the second half of this header.
+ *
+ * All device pointers are HIP device pointers on the current device; every call is
+ * asynchronous on the given stream (reference: kernels run on the current PyTorch stream,
+ * src/runtime/cuda/cuda_device_api.cc:362-367).  Functions return 0 on success and -1 on
+ * error with the message available from dgla_last_error() / DGLGetLastError()
+ * (reference convention: src/runtime/runtime_base.h:14-45).
+ */
+#ifndef DGL_AMD_H_
+#define DGL_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGLA_ABI_VERSION 1
+
+/* Feature element types (DGLDataType {code,bits}: float32/64, float16, bfloat16 —
+ * ATEN_FLOAT_TYPE_SWITCH_16BITS, include/dgl/aten/macro.h:137-166). */
+typedef enum { DGLA_F32 = 0, DGLA_F64 = 1, DGLA_F16 = 2, DGLA_BF16 = 3 } dgla_dtype;
+
+/* Flags of dgla_spmm_csr. */
+#define DGLA_ACCUMULATE 1u /* out += result: the reference's contract, `out` pre-zeroed by the
+                              caller (src/array/cuda/spmm.cuh:528-534, _sparse_ops.py:227).
+                              Without it rows are written, not accumulated (no memset, no
+                              read of `out`).  Only meaningful for reduce == "sum". */
+#define DGLA_PLAN_VALID 2u /* `workspace` still holds the merge plan built by an earlier
+                              call on the SAME csr (indptr contents, num_rows, nnz). */
+
+/* CSRMatrix (include/dgl/aten/csr.h:40-49).  For SpMM the rows are DESTINATION nodes
+ * (the in-edge CSR / "CSC", src/array/kernel.cc:20-44); for SDDMM rows are SOURCE nodes. */
+typedef struct {
+  int64_t num_rows, num_cols, nnz;
+  int32_t idtype_bits;  /* 32 or 64: element type of indptr / indices / data */
+  const void* indptr;   /* [num_rows + 1] */
+  const void* indices;  /* [nnz] column ids */
+  const void* data;     /* [nnz] edge-id map, or NULL: edge id == position */
+} dgla_csr;
+
+/* COOMatrix (include/dgl/aten/coo.h): row = source ids, col = destination ids. */
+typedef struct {
+  int64_t num_rows, num_cols, nnz;
+  int32_t idtype_bits;
+  const void* row;
+  const void* col;
+  const void* data;
+} dgla_coo;
+
+/* Dense, contiguous, row-major feature tensor.  shape[0] is the number of nodes / edges,
+ * ndim >= 2 (src/array/check.h:46-50).  data == NULL means "operand absent" (the
+ * reference passes an empty int64 NDArray, python/dgl/ndarray.py:309-312). */
+typedef struct {
+  void* data;
+  int32_t ndim;
+  const int64_t* shape;
+} dgla_tensor;
+
+const char* dgla_last_error(void);
+int dgla_abi_version(void);
+
+/*
+ * g-SpMM on CSR:  out[r, k] = reduce_{j in row r} op(ufeat[indices[j], lhs_off(k)],
+ *                                                  efeat[eid(j), rhs_off(k)])
+ * Replaces aten::CSRSpMM (src/array/array.cc:1148-1168) -> SpMMCsr<kDGLCUDA,...>
+ * (src/array/cuda/spmm.cu:26-106).
+ *   op      "add" | "sub" | "mul" | "div" | "copy_lhs" | "copy_rhs"
+ *   reduce  "sum" | "max" | "min"
+ *   arg_u / arg_e   [same shape as out], element type = idtype; written for max/min only
+ *                   (arg_u iff op uses lhs, arg_e iff op uses rhs); may be NULL for sum.
+ *   workspace       device scratch of at least dgla_spmm_csr_workspace_bytes() bytes.
+ */
+int dgla_spmm_csr(const char* op, const char* reduce, const dgla_csr* csr, dgla_dtype dtype,
+                  const dgla_tensor* ufeat, const dgla_tensor* efeat, const dgla_tensor* out,
+                  void* arg_u, void* arg_e, void* workspace, size_t workspace_bytes,
+                  uint32_t flags, void* hip_stream);
+
+size_t dgla_spmm_csr_workspace_bytes(const char* op, const char* reduce, const dgla_csr* csr,
+                                     dgla_dtype dtype, const dgla_tensor* ufeat,
+                                     const dgla_tensor* efeat, const dgla_tensor* out);
+
+/*
+ * g-SpMM on COO (edge-parallel with device atomics).  Replaces aten::COOSpMM
+ * (array.cc:1170-1190) -> SpMMCoo<kDGLCUDA,...> (spmm.cu:80-106, spmm.cuh:624-682).
+ * `out` (and arg_*) are fully written by the call.  fp16 / bf16 are refused like the
+ * reference does (spmm.cuh:633-641).
+ */
+int dgla_spmm_coo(const char* op, const char* reduce, const dgla_coo* coo, dgla_dtype dtype,
+                  const dgla_tensor* ufeat, const dgla_tensor* efeat, const dgla_tensor* out,
+                  void* arg_u, void* arg_e, void* hip_stream);
+
+/*
+ * g-SDDMM:  out[eid, k] = op(lhs[sel(lhs_target), lhs_off(k)], rhs[sel(rhs_target), rhs_off(k)])
+ * Replaces aten::COOSDDMM / CSRSDDMM (array.cc:1192-1233) -> SDDMMCoo / SDDMMCsr
+ * (src/array/cuda/sddmm.cu:17-42, sddmm.cuh:97-362).
+ *   op       "add" | "sub" | "mul" | "div" | "copy_lhs" | "copy_rhs" | "dot"
+ *   targets  0 = u (source node), 1 = e (edge), 2 = v (destination node)
+ */
+int dgla_sddmm_coo(const char* op, const dgla_coo* coo, dgla_dtype dtype,
+                   const dgla_tensor* lhs, const dgla_tensor* rhs, const dgla_tensor* out,
+                   int lhs_target, int rhs_target, void* hip_stream);
+
+int dgla_sddmm_csr(const char* op, const dgla_csr* csr, dgla_dtype dtype,
+                   const dgla_tensor* lhs, const dgla_tensor* rhs, const dgla_tensor* out,
+                   int lhs_target, int rhs_target, void* hip_stream);
+
+/*
+ * Fused edge softmax over the in-edge CSR (rows = destination nodes), forward and
+ * backward.  The reference only has these on CPU (src/array/cpu/spmm.h:484-570, FFI
+ * src/array/kernel.cc:542-561; GPU is a TODO at kernel.cc:313,331 and runs 5 kernels,
+ * python/dgl/backend/pytorch/sparse.py:709-713).
+ *   score / out / grad tensors: [nnz, ...] indexed by edge id.
+ */
+int dgla_edge_softmax_forward(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* score,
+                              const dgla_tensor* out, void* hip_stream);
+int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* out,
+                               const dgla_tensor* sds, const dgla_tensor* back,
+                               void* hip_stream);
+
+/* Benchmark hook: when both are non-NULL (hipEvent_t), the calling thread's next
+ * dgla_spmm_csr calls record `before` / `after` on the launch stream around the dominant
+ * (merge) kernel only, so its duration can be read with hipEventElapsedTime.  NULL disables. */
+int dgla_spmm_set_profile_events(void* before, void* after);
+
+/* Measured-peak helper used by bench.py: streams `bytes` from src to dst with 16-byte
+ * lane accesses (the "float4 copy" the HBM roofline is quoted against). */
+int dgla_stream_copy(void* dst, const void* src, size_t bytes, void* hip_stream);
+
+/* ======================================================================================
+ * (2) Registry layer — same names and layouts as include/dgl/runtime/c_runtime_api.h.
+ * ====================================================================================== */
+
+/* type codes (c_runtime_api.h:66-91) */
+typedef enum {
+  kObjectInt = 0,
+  kObjectUInt = 1,
+  kObjectFloat = 2,
+  kHandle = 3,
+  kNull = 4,
+  kDGLDataType = 5,
+  kDGLContext = 6,
+  kArrayHandle = 7,
+  kObjectHandle = 8,
+  kModuleHandle = 9,
+  kFuncHandle = 10,
+  kStr = 11,
+  kBytes = 12,
+  kNDArrayContainer = 13
+} DGLTypeCode;
+
+/* Device types.  kDGLROCM = 10 is DLPack's kDLROCM, which PyTorch-ROCm exports; the
+ * reference only knows kDGLCPU = 1 / kDGLCUDA = 2 (c_runtime_api.h:51-60). */
+typedef enum { kDGLCPU = 1, kDGLCUDA = 2, kDGLROCM = 10 } DGLDeviceType;
+
+typedef struct {
+  int32_t device_type;
+  int32_t device_id;
+} DGLContext;
+
+typedef struct {
+  uint8_t code; /* 0 int, 1 uint, 2 float, 4 bfloat (DLPack codes) */
+  uint8_t bits;
+  uint16_t lanes;
+} DGLDataType;
+
+/* DGLValue (c_runtime_api.h:205-212) */
+typedef union {
+  int64_t v_int64;
+  double v_float64;
+  void* v_handle;
+  const char* v_str;
+  DGLDataType v_type;
+  DGLContext v_ctx;
+} DGLValue;
+
+/* DGLArray (c_runtime_api.h:150-196): DLTensor-compatible. */
+typedef struct {
+  void* data;
+  DGLContext ctx;
+  int32_t ndim;
+  DGLDataType dtype;
+  int64_t* shape;
+  int64_t* strides; /* NULL = compact row-major */
+  uint64_t byte_offset;
+} DGLArray;
+
+typedef void* DGLFunctionHandle;
+typedef DGLArray* DGLArrayHandle;
+
+const char* DGLGetLastError(void);
+void DGLAPISetLastError(const char* msg);
+int DGLFuncListGlobalNames(int* out_size, const char*** out_array);
+int DGLFuncGetGlobal(const char* name, DGLFunctionHandle* out);
+int DGLFuncCall(DGLFunctionHandle func, DGLValue* args, int* type_codes, int num_args,
+                DGLValue* ret_val, int* ret_type_code);
+int DGLFuncFree(DGLFunctionHandle func);
+/* c_runtime_api.h: DGLSetStream — the stream kernels of this thread are queued on. */
+int DGLSetStream(int device_type, int device_id, void* stream);
+int DGLGetStream(int device_type, int device_id, void** stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGL_AMD_H_ */

@@ -1,0 +1,335 @@
+"""CPU oracle for the g-SpMM / g-SDDMM hot path — TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this package.  The product package ``dgl_amd`` never does (a test greps for it).
+
+The arithmetic lives in ``oracle.c`` / ``kernels_impl.inc`` (plain C + OpenMP restating
+``src/array/cpu/{spmm.h,spmm.cc,sddmm.h,spmm_binary_ops.h}`` of the reference); this
+module is the numpy front end plus the broadcast bookkeeping of ``src/bcast.cc``.
+
+Parity status: the reference cannot be built or imported here and stores no golden
+vectors, so the oracle is pinned by the reference's closed-form test cases and by
+independent implementations (scipy / torch scatter / dense) — see oracle.c header and
+``tests/test_oracle_known_answers.py``.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "copy_lhs": 4, "copy_rhs": 5, "dot": 6}
+TARGETS = {"u": 0, "e": 1, "v": 2}
+
+
+def build(force=False):
+    """Compile oracle.c with gcc (``make -C oracle``)."""
+    src_m = max(
+        os.path.getmtime(os.path.join(_HERE, f)) for f in ("oracle.c", "kernels_impl.inc")
+    )
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+# --------------------------------------------------------------------------- #
+# Broadcast bookkeeping
+# --------------------------------------------------------------------------- #
+class BcastOff:
+    """Restates ``struct BcastOff`` (include/dgl/bcast.h:20-53) as computed by
+    ``CalcBcastOff`` (src/bcast.cc:36-90).  ``lhs_offset``/``rhs_offset`` are None when
+    ``use_bcast`` is False."""
+
+    def __init__(self, op, lhs_shape, rhs_shape):
+        # shapes include the leading (node/edge) dimension; ndim >= 2 each
+        # (src/array/check.h:46-50).  A missing operand is given the other's shape by the
+        # callers below, mirroring that copy_lhs / copy_rhs ignore it (bcast.cc:18-20).
+        lhs_shape, rhs_shape = tuple(lhs_shape), tuple(rhs_shape)
+        self.lhs_len = int(np.prod(lhs_shape[1:], dtype=np.int64))
+        self.rhs_len = int(np.prod(rhs_shape[1:], dtype=np.int64))
+        self.reduce_size = 1
+        use = False
+        if op not in ("copy_lhs", "copy_rhs"):
+            use = len(lhs_shape) != len(rhs_shape) or lhs_shape[1:] != rhs_shape[1:]
+        self.use_bcast = use
+        self.lhs_offset = self.rhs_offset = None
+        if use:
+            lnd, rnd = len(lhs_shape), len(rhs_shape)
+            max_ndim = max(lnd, rnd) - 1
+            out_len, j = 1, 0
+            if op == "dot":
+                self.reduce_size = lhs_shape[-1]
+                j = 1  # the reduce axis takes no part in the offsets (bcast.cc:50-54)
+            stride_l = stride_r = 1
+            lo, ro = [0], [0]
+            while j < max_ndim:  # axes from back to front (bcast.cc:58-83)
+                dl = 1 if lnd - 1 - j < 1 else lhs_shape[lnd - 1 - j]
+                dr = 1 if rnd - 1 - j < 1 else rhs_shape[rnd - 1 - j]
+                for i in range(1, max(dl, dr)):
+                    for k in range(out_len):
+                        lo.append(lo[k] + i * (1 if i < dl else 0) * stride_l)
+                        ro.append(ro[k] + i * (1 if i < dr else 0) * stride_r)
+                out_len *= max(dl, dr)
+                stride_l *= dl
+                stride_r *= dr
+                j += 1
+            self.out_len = out_len
+            self.lhs_offset = np.asarray(lo, dtype=np.int64)
+            self.rhs_offset = np.asarray(ro, dtype=np.int64)
+        else:
+            self.out_len = self.rhs_len if op == "copy_rhs" else self.lhs_len
+            if op == "dot":
+                self.reduce_size = lhs_shape[-1]
+                self.out_len //= self.reduce_size
+
+
+def infer_broadcast_shape(op, shp1, shp2):
+    """Output feature shape (without the leading dim).  Restates
+    python/dgl/_sparse_ops.py:10-60: numpy-style right-aligned broadcasting; for ``dot``
+    the last axis is reduced to size 1."""
+    shp1, shp2 = tuple(shp1), tuple(shp2)
+    if op == "copy_lhs":
+        return shp1
+    if op == "copy_rhs":
+        return shp2
+    pad = max(len(shp1), len(shp2))
+    a = (1,) * (pad - len(shp1)) + shp1
+    b = (1,) * (pad - len(shp2)) + shp2
+    for d1, d2 in zip(a, b):
+        if d1 != d2 and d1 != 1 and d2 != 1:
+            raise ValueError("Feature shapes {} and {} are not valid for broadcasting.".format(shp1, shp2))
+    out = tuple(max(d1, d2) for d1, d2 in zip(a, b))
+    return out[:-1] + (1,) if op == "dot" else out
+
+
+# --------------------------------------------------------------------------- #
+# helpers
+# --------------------------------------------------------------------------- #
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _sfx(dtype, idtype):
+    d = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}[np.dtype(dtype)]
+    i = {np.dtype(np.int32): "i32", np.dtype(np.int64): "i64"}[np.dtype(idtype)]
+    return d + "_" + i
+
+
+def _prep_feat(x, dtype):
+    if x is None:
+        return None
+    x = np.ascontiguousarray(x, dtype=dtype)
+    return x.reshape(x.shape[0], 1) if x.ndim == 1 else x
+
+
+def _nthreads(n):
+    return int(n) if n else (os.cpu_count() or 1)
+
+
+def _i64(v):
+    return ctypes.c_int64(int(v))
+
+
+# --------------------------------------------------------------------------- #
+# g-SpMM
+# --------------------------------------------------------------------------- #
+def spmm_csr(op, reduce, indptr, indices, eids, ufeat, efeat, nthreads=None):
+    """``out[r] = reduce_{j in row r} op(ufeat[indices[j]], efeat[eid(j)])``.
+
+    Returns ``(out, arg_u, arg_e)`` (args are None for sum / for the unused side), with
+    shapes and dtypes as python/dgl/_sparse_ops.py:156-265 produces them.
+    """
+    assert reduce in ("sum", "max", "min")
+    indptr = np.ascontiguousarray(indptr)
+    idt = indptr.dtype
+    indices = np.ascontiguousarray(indices, dtype=idt)
+    eids = None if eids is None else np.ascontiguousarray(eids, dtype=idt)
+    fdt = (ufeat if ufeat is not None else efeat).dtype
+    squeeze = (ufeat is None or ufeat.ndim == 1) and (efeat is None or efeat.ndim == 1)
+    u, e = _prep_feat(ufeat, fdt), _prep_feat(efeat, fdt)
+    use_l, use_r = op != "copy_rhs", op != "copy_lhs"
+    lshape = u.shape if use_l else e.shape
+    rshape = e.shape if use_r else u.shape
+    bc = BcastOff(op, lshape, rshape)
+    n_rows = indptr.shape[0] - 1
+    oshape = (n_rows,) + infer_broadcast_shape(op, lshape[1:], rshape[1:])
+    out = np.zeros(oshape, dtype=fdt)
+    assert int(np.prod(oshape[1:])) == bc.out_len
+    L = lib()
+    sfx = _sfx(fdt, idt)
+    lo, ro = _ptr(bc.lhs_offset), _ptr(bc.rhs_offset)
+    if reduce == "sum":
+        getattr(L, "oracle_spmm_sum_csr_" + sfx)(
+            OPS[op], _i64(n_rows), _ptr(indptr), _ptr(indices), _ptr(eids),
+            _ptr(u), _ptr(e), _ptr(out), _i64(bc.out_len), _i64(bc.lhs_len),
+            _i64(bc.rhs_len), lo, ro, _nthreads(nthreads))
+        argu = arge = None
+    else:
+        argu = np.zeros(oshape, dtype=idt)
+        arge = np.zeros(oshape, dtype=idt)
+        getattr(L, "oracle_spmm_cmp_csr_" + sfx)(
+            OPS[op], 1 if reduce == "max" else 0, _i64(n_rows), _ptr(indptr),
+            _ptr(indices), _ptr(eids), _ptr(u), _ptr(e), _ptr(out), _ptr(argu),
+            _ptr(arge), _i64(bc.out_len), _i64(bc.lhs_len), _i64(bc.rhs_len), lo, ro,
+            _nthreads(nthreads))
+        if not use_l:
+            argu = None
+        if not use_r:
+            arge = None
+    if squeeze:
+        out = out.reshape(-1)
+        argu = None if argu is None else argu.reshape(-1)
+        arge = None if arge is None else arge.reshape(-1)
+    return out, argu, arge
+
+
+def spmm_coo(op, reduce, row, col, eids, num_dst, ufeat, efeat):
+    """COO flavour (row = source ids, col = destination ids)."""
+    row = np.ascontiguousarray(row)
+    idt = row.dtype
+    col = np.ascontiguousarray(col, dtype=idt)
+    eids = None if eids is None else np.ascontiguousarray(eids, dtype=idt)
+    fdt = (ufeat if ufeat is not None else efeat).dtype
+    squeeze = (ufeat is None or ufeat.ndim == 1) and (efeat is None or efeat.ndim == 1)
+    u, e = _prep_feat(ufeat, fdt), _prep_feat(efeat, fdt)
+    use_l, use_r = op != "copy_rhs", op != "copy_lhs"
+    lshape = u.shape if use_l else e.shape
+    rshape = e.shape if use_r else u.shape
+    bc = BcastOff(op, lshape, rshape)
+    oshape = (num_dst,) + infer_broadcast_shape(op, lshape[1:], rshape[1:])
+    out = np.zeros(oshape, dtype=fdt)
+    L = lib()
+    sfx = _sfx(fdt, idt)
+    lo, ro = _ptr(bc.lhs_offset), _ptr(bc.rhs_offset)
+    nnz = row.shape[0]
+    if reduce == "sum":
+        getattr(L, "oracle_spmm_sum_coo_" + sfx)(
+            OPS[op], _i64(nnz), _i64(num_dst), _ptr(row), _ptr(col), _ptr(eids),
+            _ptr(u), _ptr(e), _ptr(out), _i64(bc.out_len), _i64(bc.lhs_len),
+            _i64(bc.rhs_len), lo, ro)
+        argu = arge = None
+    else:
+        argu = np.zeros(oshape, dtype=idt)
+        arge = np.zeros(oshape, dtype=idt)
+        getattr(L, "oracle_spmm_cmp_coo_" + sfx)(
+            OPS[op], 1 if reduce == "max" else 0, _i64(nnz), _i64(num_dst), _ptr(row),
+            _ptr(col), _ptr(eids), _ptr(u), _ptr(e), _ptr(out), _ptr(argu), _ptr(arge),
+            _i64(bc.out_len), _i64(bc.lhs_len), _i64(bc.rhs_len), lo, ro)
+        if not use_l:
+            argu = None
+        if not use_r:
+            arge = None
+    if squeeze:
+        out = out.reshape(-1)
+        argu = None if argu is None else argu.reshape(-1)
+        arge = None if arge is None else arge.reshape(-1)
+    return out, argu, arge
+
+
+def copy_u_sum_csr(indptr, indices, x, nthreads=None, out=None):
+    """Vectorisable copy_u+sum (same order as ``spmm_csr('copy_lhs','sum')``); the
+    function ``bench.py`` times as the CPU baseline."""
+    idt = indptr.dtype
+    n_rows = indptr.shape[0] - 1
+    dim = int(np.prod(x.shape[1:]))
+    if out is None:
+        out = np.zeros((n_rows,) + x.shape[1:], dtype=x.dtype)
+    else:
+        out[...] = 0
+    getattr(lib(), "oracle_spmm_copy_u_sum_csr_" + _sfx(x.dtype, idt))(
+        _i64(n_rows), _ptr(indptr), _ptr(indices), _ptr(x), _ptr(out), _i64(dim),
+        _nthreads(nthreads))
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# g-SDDMM
+# --------------------------------------------------------------------------- #
+def _sddmm_common(op, lhs, rhs):
+    fdt = (lhs if lhs is not None else rhs).dtype
+    squeeze = (lhs is None or lhs.ndim == 1) and (rhs is None or rhs.ndim == 1)
+    l, r = _prep_feat(lhs, fdt), _prep_feat(rhs, fdt)
+    use_l, use_r = op != "copy_rhs", op != "copy_lhs"
+    lshape = l.shape if use_l else r.shape
+    rshape = r.shape if use_r else l.shape
+    bc = BcastOff(op, lshape, rshape)
+    feat_shape = infer_broadcast_shape(op, lshape[1:], rshape[1:])
+    return fdt, squeeze, l, r, bc, feat_shape
+
+
+def sddmm_coo(op, row, col, eids, lhs, rhs, lhs_target="u", rhs_target="v", nthreads=None):
+    """``out[eid] = op(lhs[sel(lhs_target)], rhs[sel(rhs_target)])`` over COO edges
+    (row = source ids, col = destination ids)."""
+    row = np.ascontiguousarray(row)
+    idt = row.dtype
+    col = np.ascontiguousarray(col, dtype=idt)
+    eids = None if eids is None else np.ascontiguousarray(eids, dtype=idt)
+    fdt, squeeze, l, r, bc, feat_shape = _sddmm_common(op, lhs, rhs)
+    nnz = row.shape[0]
+    out = np.zeros((nnz,) + feat_shape, dtype=fdt)
+    getattr(lib(), "oracle_sddmm_coo_" + _sfx(fdt, idt))(
+        OPS[op], _i64(nnz), _ptr(row), _ptr(col), _ptr(eids), _ptr(l), _ptr(r),
+        _ptr(out), _i64(bc.out_len), _i64(bc.lhs_len), _i64(bc.rhs_len),
+        _i64(bc.reduce_size), _ptr(bc.lhs_offset), _ptr(bc.rhs_offset),
+        TARGETS[lhs_target], TARGETS[rhs_target], _nthreads(nthreads))
+    return out.reshape(-1) if squeeze else out
+
+
+def sddmm_csr(op, indptr, indices, eids, lhs, rhs, lhs_target="u", rhs_target="v", nthreads=None):
+    """CSR flavour; rows are SOURCE nodes here (see kernels_impl.inc note)."""
+    indptr = np.ascontiguousarray(indptr)
+    idt = indptr.dtype
+    indices = np.ascontiguousarray(indices, dtype=idt)
+    eids = None if eids is None else np.ascontiguousarray(eids, dtype=idt)
+    fdt, squeeze, l, r, bc, feat_shape = _sddmm_common(op, lhs, rhs)
+    nnz = indices.shape[0]
+    out = np.zeros((nnz,) + feat_shape, dtype=fdt)
+    getattr(lib(), "oracle_sddmm_csr_" + _sfx(fdt, idt))(
+        OPS[op], _i64(indptr.shape[0] - 1), _ptr(indptr), _ptr(indices), _ptr(eids),
+        _ptr(l), _ptr(r), _ptr(out), _i64(bc.out_len), _i64(bc.lhs_len),
+        _i64(bc.rhs_len), _i64(bc.reduce_size), _ptr(bc.lhs_offset),
+        _ptr(bc.rhs_offset), TARGETS[lhs_target], TARGETS[rhs_target],
+        _nthreads(nthreads))
+    return out.reshape(-1) if squeeze else out
+
+
+# --------------------------------------------------------------------------- #
+# edge softmax
+# --------------------------------------------------------------------------- #
+def edge_softmax_fwd(indptr, eids, score, nthreads=None):
+    indptr = np.ascontiguousarray(indptr)
+    idt = indptr.dtype
+    eids = None if eids is None else np.ascontiguousarray(eids, dtype=idt)
+    s = np.ascontiguousarray(score)
+    dim = int(np.prod(s.shape[1:])) if s.ndim > 1 else 1
+    out = np.zeros_like(s)
+    getattr(lib(), "oracle_edge_softmax_fwd_" + _sfx(s.dtype, idt))(
+        _i64(indptr.shape[0] - 1), _ptr(indptr), _ptr(eids), _ptr(s), _ptr(out),
+        _i64(dim), _nthreads(nthreads))
+    return out
+
+
+def edge_softmax_bwd(indptr, eids, out, sds, nthreads=None):
+    indptr = np.ascontiguousarray(indptr)
+    idt = indptr.dtype
+    eids = None if eids is None else np.ascontiguousarray(eids, dtype=idt)
+    o = np.ascontiguousarray(out)
+    s = np.ascontiguousarray(sds, dtype=o.dtype)
+    dim = int(np.prod(o.shape[1:])) if o.ndim > 1 else 1
+    back = np.zeros_like(o)
+    getattr(lib(), "oracle_edge_softmax_bwd_" + _sfx(o.dtype, idt))(
+        _i64(indptr.shape[0] - 1), _ptr(indptr), _ptr(eids), _ptr(o), _ptr(s),
+        _ptr(back), _i64(dim), _nthreads(nthreads))
+    return back

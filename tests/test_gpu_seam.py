@@ -1,0 +1,424 @@
+"""GPU parity tests of the graph-free C seam (dgla_*) against the CPU oracle.
+
+Modelled on the reference's operator tests (tests/python/common/ops/test_ops.py:87-299):
+same graphs (rand_graph(30,100), rand_bipartite(30,40,300)), the same broadcast shape pairs,
+every op x reducer x idtype x dtype; plus the edge cases the merge-path kernel has to survive
+(rows longer than a unit, isolated nodes, empty graphs, star graphs).
+
+Bar: arg_u / arg_e and max/min values bit-exact; fp32 sums within 1e-5 relative (the
+north-star tolerance), fp64 within 1e-12.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests.graphgen import coo_to_csc, coo_to_csr, synth_csr
+
+pytestmark = pytest.mark.gpu
+
+SPMM_SHAPES = [  # tests/python/common/ops/test_ops.py:93-100
+    ((1, 2, 1, 3, 1), (4, 1, 3, 1, 1)),
+    ((5, 3, 1, 7), (1, 3, 7, 1)),
+    ((1, 3, 1), (4, 1, 3)),
+    ((3, 3), (1, 3)),
+    ((1,), (3,)),
+    ((3,), (1,)),
+    ((1,), (1,)),
+    ((), ()),
+]
+SDDMM_SHAPES = [  # test_ops.py:102-108
+    ((1, 2, 1, 3, 1), (4, 1, 3, 1, 1)),
+    ((5, 3, 1, 7), (1, 3, 7, 7)),
+    ((1, 3, 3), (4, 1, 3)),
+    ((3,), (3,)),
+    ((1,), (1,)),
+]
+
+
+def rand_graph(n_src, n_dst, n_edges, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, n_src, n_edges), rng.integers(0, n_dst, n_edges)
+
+
+GRAPHS = {
+    "homo": lambda: (30, 30) + rand_graph(30, 30, 100, 1),          # dgl.rand_graph(30, 100)
+    "bipartite": lambda: (30, 40) + rand_graph(30, 40, 300, 2),     # dgl.rand_bipartite(..,30,..,40,300)
+}
+
+
+def _tol(dtype):
+    return dict(rtol=1e-5, atol=1e-6) if dtype == np.float32 else dict(rtol=1e-12, atol=1e-12)
+
+
+def run_spmm(dev, op, reduce, n_src, n_dst, src, dst, ufeat, efeat, idtype, use_eids=True,
+             accumulate_into=None):
+    from dgl_amd import _capi
+
+    indptr, indices, eids = coo_to_csc(src, dst, n_dst, idtype)
+    if not use_eids:
+        # positions as edge ids: permute efeat on the host so both sides see the same data
+        if efeat is not None:
+            efeat = efeat[eids]
+        eids = None
+    ref, ref_u, ref_e = oracle.spmm_csr(op, reduce, indptr, indices, eids, ufeat, efeat)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    csr = _capi.make_csr(t(indptr), t(indices), t(eids), n_src)
+    keep = (t(indptr), t(indices), t(eids))
+    csr = _capi.make_csr(keep[0], keep[1], keep[2], n_src)
+    tu, te = t(ufeat), t(efeat)
+    out = torch.full(ref.shape, 7.0, dtype=(tu if tu is not None else te).dtype, device=dev)
+    if accumulate_into is not None:
+        out = t(accumulate_into.astype(ref.dtype))
+    tidt = torch.int32 if idtype == np.int32 else torch.int64
+    arg_u = torch.full(ref.shape, -5, dtype=tidt, device=dev) if reduce != "sum" else None
+    arg_e = torch.full(ref.shape, -5, dtype=tidt, device=dev) if reduce != "sum" else None
+    nbytes = _capi.spmm_csr_workspace_bytes(op, reduce, csr, out.dtype, tu, te, out)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    _capi.spmm_csr(op, reduce, csr, tu, te, out, arg_u, arg_e, ws,
+                   accumulate=accumulate_into is not None)
+    # second call re-using the cached plan must give identical bits
+    out2 = out.clone() if accumulate_into is None else t(accumulate_into.astype(ref.dtype))
+    _capi.spmm_csr(op, reduce, csr, tu, te, out2, arg_u, arg_e, ws,
+                   accumulate=accumulate_into is not None, plan_valid=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    return out.cpu().numpy(), (None if arg_u is None else arg_u.cpu().numpy()), \
+        (None if arg_e is None else arg_e.cpu().numpy()), ref, ref_u, ref_e
+
+
+def check_spmm(res, reduce, dtype):
+    out, au, ae, ref, ref_u, ref_e = res
+    if reduce == "sum":
+        np.testing.assert_allclose(out, ref, **_tol(dtype))
+    else:
+        # max/min pick one of the candidates: must be the same bits, and the same edge
+        np.testing.assert_array_equal(out, ref)
+        if ref_u is not None:
+            np.testing.assert_array_equal(au, ref_u)
+        if ref_e is not None:
+            np.testing.assert_array_equal(ae, ref_e)
+
+
+@pytest.mark.parametrize("gname", list(GRAPHS))
+@pytest.mark.parametrize("shp", SPMM_SHAPES)
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "div", "copy_lhs", "copy_rhs"])
+@pytest.mark.parametrize("reduce", ["sum", "min", "max"])
+@pytest.mark.parametrize("idtype", [np.int32, np.int64])
+def test_spmm_matrix(dev, gname, shp, op, reduce, idtype):
+    n_src, n_dst, src, dst = GRAPHS[gname]()
+    rng = np.random.default_rng(12345)
+    dtype = np.float32
+    u = (rng.random((n_src,) + shp[0]) + 1).astype(dtype)
+    e = (rng.random((len(src),) + shp[1]) + 1).astype(dtype)
+    res = run_spmm(dev, op, reduce, n_src, n_dst, src, dst,
+                   u if op != "copy_rhs" else None, e if op != "copy_lhs" else None, idtype)
+    check_spmm(res, reduce, dtype)
+
+
+@pytest.mark.parametrize("op", ["mul", "copy_lhs", "copy_rhs", "add"])
+@pytest.mark.parametrize("reduce", ["sum", "max", "min"])
+@pytest.mark.parametrize("feat", [(100,), (8, 16), (4,), (1,), (33,), (300,), (260,)])
+def test_spmm_f64_and_widths(dev, op, reduce, feat):
+    """fp64 and feature widths that hit every access path: 16-byte lanes (100, 128, 4),
+    element-wise lanes (1, 33), more than one 64-lane chunk (300, 260)."""
+    n_src, n_dst, src, dst = GRAPHS["bipartite"]()
+    rng = np.random.default_rng(7)
+    for dtype in (np.float32, np.float64):
+        u = (rng.random((n_src,) + feat) + 1).astype(dtype)
+        e = (rng.random((len(src),) + feat) + 1).astype(dtype)
+        res = run_spmm(dev, op, reduce, n_src, n_dst, src, dst,
+                       u if op != "copy_rhs" else None, e if op != "copy_lhs" else None, np.int32)
+        check_spmm(res, reduce, dtype)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "max", "min"])
+@pytest.mark.parametrize("use_eids", [True, False])
+def test_spmm_gat_broadcast(dev, reduce, use_eids):
+    """u_mul_e with (N,H,D) x (E,H,1) — the GATConv pattern (gatconv.py:346), and scalar e."""
+    n_src, n_dst, src, dst = GRAPHS["homo"]()
+    rng = np.random.default_rng(3)
+    for ushape, eshape in (((8, 16), (8, 1)), ((64,), (1,)), ((4, 8), (1, 1))):
+        u = (rng.random((n_src,) + ushape) + 1).astype(np.float32)
+        e = (rng.random((len(src),) + eshape) + 1).astype(np.float32)
+        res = run_spmm(dev, "mul", reduce, n_src, n_dst, src, dst, u, e, np.int32, use_eids)
+        check_spmm(res, reduce, np.float32)
+
+
+def _edge_case_graphs():
+    rng = np.random.default_rng(99)
+    cases = {}
+    # star: 900 leaves -> node 0 (tests/python/common/ops/test_ops.py:193-216)
+    cases["star900"] = (901, 901, np.arange(1, 901), np.zeros(900, dtype=np.int64))
+    # one row far longer than a 512-item unit, plus isolated nodes before and after it
+    src = rng.integers(0, 50, 3000)
+    dst = np.full(3000, 20)
+    cases["long_row"] = (50, 60, src, dst)
+    # many isolated destination nodes (more row-end items than edges), edges at the end
+    cases["isolated"] = (10, 2000, rng.integers(0, 10, 40), rng.integers(1990, 2000, 40))
+    # mixture: a few heavy rows among light ones, unit boundaries fall inside rows
+    dst = np.concatenate([rng.integers(0, 300, 2000), np.full(700, 7), np.full(1300, 150)])
+    cases["mixed"] = (200, 300, rng.integers(0, 200, len(dst)), dst)
+    # exact multiples of the unit size
+    cases["exact512"] = (16, 256, rng.integers(0, 16, 256), np.arange(256))
+    cases["no_edges"] = (5, 7, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
+    cases["single"] = (1, 1, np.zeros(1, dtype=np.int64), np.zeros(1, dtype=np.int64))
+    return cases
+
+
+@pytest.mark.parametrize("name", list(_edge_case_graphs()))
+@pytest.mark.parametrize("reduce", ["sum", "max", "min"])
+@pytest.mark.parametrize("op", ["copy_lhs", "mul"])
+@pytest.mark.parametrize("feat", [100, 8, 1])
+def test_spmm_edge_cases(dev, name, reduce, op, feat):
+    n_src, n_dst, src, dst = _edge_case_graphs()[name]
+    rng = np.random.default_rng(5)
+    u = (rng.random((n_src, feat)) + 1).astype(np.float32)
+    e = (rng.random((len(src), feat)) + 1).astype(np.float32)
+    if len(src) == 0:
+        e = np.zeros((0, feat), np.float32)
+    res = run_spmm(dev, op, reduce, n_src, n_dst, src, dst, u, e if op == "mul" else None,
+                   np.int64)
+    check_spmm(res, reduce, np.float32)
+
+
+def test_spmm_ties_pick_first_position(dev):
+    """All candidates equal: arg must be the first edge in CSR order (strict compare,
+    src/array/cpu/spmm_binary_ops.h:121,137), also across unit / lane-group boundaries."""
+    n_src, n_dst = 40, 3
+    src = np.tile(np.arange(40), 50)          # 2000 edges into 3 rows, long rows
+    dst = np.repeat(np.arange(3), [1200, 1, 799])
+    u = np.ones((n_src, 100), np.float32)
+    for reduce in ("max", "min"):
+        res = run_spmm(dev, "copy_lhs", reduce, n_src, n_dst, src, dst, u, None, np.int32)
+        check_spmm(res, reduce, np.float32)
+
+
+def test_spmm_nan_never_wins(dev):
+    n_src, n_dst, src, dst = GRAPHS["homo"]()
+    rng = np.random.default_rng(8)
+    u = (rng.random((n_src, 12)) + 1).astype(np.float32)
+    u[::3, ::2] = np.nan
+    for reduce in ("max", "min"):
+        res = run_spmm(dev, "copy_lhs", reduce, n_src, n_dst, src, dst, u, None, np.int32)
+        check_spmm(res, reduce, np.float32)
+
+
+def test_spmm_accumulate_flag(dev):
+    """DGLA_ACCUMULATE: out += result (the reference's contract, spmm.cuh:528-534)."""
+    n_src, n_dst, src, dst = _edge_case_graphs()["mixed"]
+    rng = np.random.default_rng(11)
+    u = (rng.random((n_src, 100)) + 1).astype(np.float32)
+    base = rng.random((n_dst, 100)).astype(np.float32)
+    out, _, _, ref, _, _ = run_spmm(dev, "copy_lhs", "sum", n_src, n_dst, src, dst, u, None,
+                                    np.int32, accumulate_into=base)
+    np.testing.assert_allclose(out, ref + base, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tdtype,rtol,atol", [(torch.float16, 1e-3, 0.5), (torch.bfloat16, 4e-3, 2.0)])
+def test_spmm_half(dev, tdtype, rtol, atol):
+    """test_ops.py:184-223: star graph 900 -> 1, feat 32, fp16 / bf16 inputs, fp32 accumulate."""
+    from dgl_amd import _capi
+
+    n = 901
+    src, dst = np.arange(1, 901), np.zeros(900, dtype=np.int64)
+    indptr, indices, eids = coo_to_csc(src, dst, n, np.int32)
+    rng = np.random.default_rng(4)
+    u32 = (rng.random((n, 32)) + 1).astype(np.float32)
+    e32 = (rng.random((900, 32)) + 1).astype(np.float32)
+    tu = torch.from_numpy(u32).to(dev).to(tdtype)
+    te = torch.from_numpy(e32).to(dev).to(tdtype)
+    ti = [torch.from_numpy(a).to(dev) for a in (indptr, indices, eids)]
+    csr = _capi.make_csr(ti[0], ti[1], ti[2], n)
+    for op, uu, ee in (("copy_lhs", tu, None), ("mul", tu, te)):
+        out = torch.empty((n, 32), dtype=tdtype, device=dev)
+        ws = torch.empty(max(_capi.spmm_csr_workspace_bytes(op, "sum", csr, tdtype, uu, ee, out), 1),
+                         dtype=torch.uint8, device=dev)
+        _capi.spmm_csr(op, "sum", csr, uu, ee, out, None, None, ws)
+        # oracle on the rounded inputs, accumulating in fp32/fp64
+        ref, _, _ = oracle.spmm_csr(op, "sum", indptr, indices, eids,
+                                    tu.float().cpu().numpy().astype(np.float64),
+                                    None if ee is None else te.float().cpu().numpy().astype(np.float64))
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=rtol, atol=atol)
+
+
+# --------------------------------------------------------------------------------------
+# SDDMM
+# --------------------------------------------------------------------------------------
+def run_sddmm(dev, fmt, op, n_src, n_dst, src, dst, lhs, rhs, lt, rt, idtype, dtype):
+    from dgl_amd import _capi
+
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    if fmt == "coo":
+        row, col = src.astype(idtype), dst.astype(idtype)
+        ref = oracle.sddmm_coo(op, row, col, None, lhs, rhs, lt, rt)
+        keep = (t(row), t(col))
+        sp = _capi.make_coo(keep[0], keep[1], None, n_src, n_dst)
+    else:
+        indptr, indices, eids = coo_to_csr(src, dst, n_src, idtype)
+        ref = oracle.sddmm_csr(op, indptr, indices, eids, lhs, rhs, lt, rt)
+        keep = (t(indptr), t(indices), t(eids))
+        sp = _capi.make_csr(keep[0], keep[1], keep[2], n_dst)
+    tl, tr = t(lhs), t(rhs)
+    out = torch.full(ref.shape, -3.0, dtype=torch.float32 if dtype == np.float32 else torch.float64,
+                     device=dev)
+    fn = _capi.sddmm_coo if fmt == "coo" else _capi.sddmm_csr
+    fn(op, sp, tl, tr, out, _capi.TARGETS[lt], _capi.TARGETS[rt])
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), ref
+
+
+@pytest.mark.parametrize("gname", list(GRAPHS))
+@pytest.mark.parametrize("fmt", ["coo", "csr"])
+@pytest.mark.parametrize("shp", SDDMM_SHAPES)
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "div", "dot", "copy_lhs", "copy_rhs"])
+@pytest.mark.parametrize("lt", ["u", "v", "e"])
+@pytest.mark.parametrize("rt", ["u", "v", "e"])
+def test_sddmm_matrix(dev, gname, fmt, shp, op, lt, rt):
+    n_src, n_dst, src, dst = GRAPHS[gname]()
+    rng = np.random.default_rng(12345)
+    n = {"u": n_src, "v": n_dst, "e": len(src)}
+    dtype = np.float32
+    lhs = (rng.random((n[lt],) + shp[0]) + 1).astype(dtype)
+    rhs = (rng.random((n[rt],) + shp[1]) + 1).astype(dtype)
+    if op == "dot" and shp[0][-1:] != shp[1][-1:]:
+        pytest.skip("dot needs equal last dims")
+    out, ref = run_sddmm(dev, fmt, op, n_src, n_dst, src, dst,
+                         lhs if op != "copy_rhs" else None, rhs if op != "copy_lhs" else None,
+                         lt, rt, np.int32, dtype)
+    if op == "dot":
+        np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-6)
+    else:
+        np.testing.assert_array_equal(out, ref)  # one rounding per element: bit-exact
+
+
+@pytest.mark.parametrize("hd", [(8, 32), (8, 8), (1, 128), (4, 64), (3, 20), (2, 256), (16, 4)])
+@pytest.mark.parametrize("idtype", [np.int32, np.int64])
+def test_sddmm_dot_heads(dev, hd, idtype):
+    """u_dot_v with (N,H,D): fast shuffle path (D/4 power of two) and general path."""
+    n_src, n_dst, src, dst = GRAPHS["bipartite"]()
+    rng = np.random.default_rng(2)
+    for dtype in (np.float32, np.float64):
+        lhs = (rng.random((n_src,) + hd) - 0.5).astype(dtype)
+        rhs = (rng.random((n_dst,) + hd) - 0.5).astype(dtype)
+        for fmt in ("coo", "csr"):
+            out, ref = run_sddmm(dev, fmt, "dot", n_src, n_dst, src, dst, lhs, rhs, "u", "v",
+                                 idtype, dtype)
+            np.testing.assert_allclose(out, ref, rtol=1e-5 if dtype == np.float32 else 1e-12,
+                                       atol=1e-6 if dtype == np.float32 else 1e-12)
+
+
+# --------------------------------------------------------------------------------------
+# COO SpMM, edge softmax, errors
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("op", ["copy_lhs", "mul", "add", "copy_rhs"])
+@pytest.mark.parametrize("reduce", ["sum", "max", "min"])
+def test_spmm_coo(dev, op, reduce):
+    from dgl_amd import _capi
+
+    n_src, n_dst, src, dst = GRAPHS["bipartite"]()
+    rng = np.random.default_rng(6)
+    for shp in (((5,), (5,)), ((3, 4), (3, 1))):
+        u = (rng.random((n_src,) + shp[0]) + 1).astype(np.float32)
+        e = (rng.random((len(src),) + shp[1]) + 1).astype(np.float32)
+        uu = u if op != "copy_rhs" else None
+        ee = e if op != "copy_lhs" else None
+        row, col = src.astype(np.int32), dst.astype(np.int32)
+        ref, ru, re_ = oracle.spmm_coo(op, reduce, row, col, None, n_dst, uu, ee)
+        t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+        keep = (t(row), t(col))
+        coo = _capi.make_coo(keep[0], keep[1], None, n_src, n_dst)
+        out = torch.full(ref.shape, 9.0, device=dev)
+        au = torch.full(ref.shape, -1, dtype=torch.int32, device=dev) if reduce != "sum" else None
+        ae = torch.full(ref.shape, -1, dtype=torch.int32, device=dev) if reduce != "sum" else None
+        _capi.spmm_coo(op, reduce, coo, t(uu), t(ee), out, au, ae)
+        if reduce == "sum":  # atomics: order differs, tolerance only
+            np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+        else:
+            np.testing.assert_array_equal(out.cpu().numpy(), ref)
+            if ru is not None:
+                np.testing.assert_array_equal(au.cpu().numpy(), ru)
+            if re_ is not None:
+                np.testing.assert_array_equal(ae.cpu().numpy(), re_)
+
+
+@pytest.mark.parametrize("heads", [1, 4, 8])
+def test_edge_softmax_fused(dev, heads):
+    from dgl_amd import _capi
+
+    n_src, n_dst, src, dst = _edge_case_graphs()["mixed"]
+    indptr, indices, eids = coo_to_csc(src, dst, n_dst, np.int32)
+    rng = np.random.default_rng(1)
+    score = rng.standard_normal((len(src), heads, 1)).astype(np.float32) * 3
+    grad = rng.standard_normal((len(src), heads, 1)).astype(np.float32)
+    ref = oracle.edge_softmax_fwd(indptr, eids, score)
+    ref_b = oracle.edge_softmax_bwd(indptr, eids, ref, ref * grad)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    keep = (t(indptr), t(indices), t(eids))
+    csr = _capi.make_csr(keep[0], keep[1], keep[2], n_src)
+    out = torch.empty_like(t(score))
+    _capi.edge_softmax_forward(csr, t(score), out)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-7)
+    back = torch.empty_like(out)
+    _capi.edge_softmax_backward(csr, t(ref), t(ref * grad), back)
+    np.testing.assert_allclose(back.cpu().numpy(), ref_b, rtol=1e-5, atol=1e-6)
+
+
+def test_errors_are_reported(dev):
+    from dgl_amd import DGLAMDError, _capi
+
+    n_src, n_dst, src, dst = GRAPHS["homo"]()
+    indptr, indices, eids = coo_to_csc(src, dst, n_dst, np.int32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    keep = (t(indptr), t(indices), t(eids))
+    csr = _capi.make_csr(keep[0], keep[1], keep[2], n_src)
+    u = torch.ones((n_src, 4), device=dev)
+    out = torch.empty((n_dst, 4), device=dev)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    with pytest.raises(DGLAMDError, match="Unsupported SpMM binary operator"):
+        _capi.spmm_csr("pow", "sum", csr, u, None, out, None, None, ws)
+    with pytest.raises(DGLAMDError, match="Unsupported SpMM reducer"):
+        _capi.spmm_csr("copy_lhs", "prod", csr, u, None, out, None, None, ws)
+    with pytest.raises(DGLAMDError, match="first dimension"):
+        _capi.spmm_csr("copy_lhs", "sum", csr, u[:-1].contiguous(), None, out, None, None, ws)
+    with pytest.raises(DGLAMDError, match="workspace"):
+        _capi.spmm_csr("copy_lhs", "sum", csr, u, None, out, None, None, ws[:8])
+    with pytest.raises(DGLAMDError, match="arg_u is required"):
+        _capi.spmm_csr("copy_lhs", "max", csr, u, None, out, None, None, ws)
+
+
+def test_scaled_c2_properties(dev):
+    """Scaled-down headline config (N/16, E/16, F=100) at full kernel geometry: result vs the
+    oracle, plus size-independent properties used at full size by bench.py: linearity
+    (A(x+y) = Ax + Ay within fp32 tolerance) and the column-sum identity
+    sum_r out[r] == sum_c outdeg[c] * x[c]."""
+    from dgl_amd import _capi
+    from tests.graphgen import C2_EDGES, C2_NODES
+
+    n, e, f = C2_NODES // 16, C2_EDGES // 16, 100
+    g = synth_csr(n, n, e, "U", device=dev)
+    torch.manual_seed(12345)
+    x = torch.rand(n, f, device=dev) + 1
+    csr = _capi.make_csr(g["indptr"], g["indices"], None, n)
+    out = torch.empty(n, f, device=dev)
+    ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, x.dtype, x, None, out),
+                     dtype=torch.uint8, device=dev)
+    _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws)
+    ref = oracle.copy_u_sum_csr(g["indptr"].cpu().numpy(), g["indices"].cpu().numpy(), x.cpu().numpy())
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    # max with args, bit exact
+    au = torch.empty(n, f, dtype=torch.int32, device=dev)
+    ae = torch.empty(n, f, dtype=torch.int32, device=dev)
+    outm = torch.empty(n, f, device=dev)
+    wsm = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "max", csr, x.dtype, x, None, outm),
+                      dtype=torch.uint8, device=dev)
+    _capi.spmm_csr("copy_lhs", "max", csr, x, None, outm, au, ae, wsm)
+    r, ru, _ = oracle.spmm_csr("copy_lhs", "max", g["indptr"].cpu().numpy(),
+                               g["indices"].cpu().numpy(), None, x.cpu().numpy(), None)
+    np.testing.assert_array_equal(outm.cpu().numpy(), r)
+    np.testing.assert_array_equal(au.cpu().numpy(), ru)
+    # column-sum identity in fp64
+    outdeg = torch.bincount(g["indices"].long(), minlength=n).double()
+    lhs = out.double().sum(0)
+    rhs = (outdeg[:, None] * x.double()).sum(0)
+    assert torch.allclose(lhs, rhs, rtol=1e-6)

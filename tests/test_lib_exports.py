@@ -1,0 +1,71 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/dgl_amd.h
+declares, the registry lists the reference's global names, and the product package never
+touches the oracle."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "dgl_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:dgla_|DGL)[A-Za-z_0-9]+)\s*\(", hdr)))
+
+
+def test_every_declared_symbol_is_exported():
+    from dgl_amd import _lib
+
+    names = _declared_functions()
+    assert "dgla_spmm_csr" in names and "DGLFuncCall" in names and len(names) >= 18
+    for n in names:
+        assert hasattr(_lib.LIB, n), "libdgl_amd.so does not export " + n
+
+
+def test_registry_lists_reference_names():
+    from dgl_amd import _lib
+
+    n = ctypes.c_int()
+    arr = ctypes.POINTER(ctypes.c_char_p)()
+    assert _lib.LIB.DGLFuncListGlobalNames(ctypes.byref(n), ctypes.byref(arr)) == 0
+    names = {arr[i].decode() for i in range(n.value)}
+    for want in ("sparse._CAPI_DGLKernelSpMM", "sparse._CAPI_DGLKernelSDDMM",
+                 "sparse._CAPI_DGLKernelEdge_softmax_forward",
+                 "sparse._CAPI_DGLKernelEdge_softmax_backward"):
+        assert want in names
+    h = ctypes.c_void_p()
+    assert _lib.LIB.DGLFuncGetGlobal(b"sparse._CAPI_DGLKernelSpMM", ctypes.byref(h)) == 0 and h.value
+    assert _lib.LIB.DGLFuncGetGlobal(b"no.such.function", ctypes.byref(h)) == 0 and not h.value
+
+
+def test_errors_cross_the_abi_as_strings():
+    from dgl_amd import _lib
+
+    # a call with a NULL csr must fail with -1 and a message, not crash
+    rc = _lib.LIB.dgla_spmm_csr(b"copy_lhs", b"sum", None, 0, None, None, None, None, None, None,
+                                0, 0, None)
+    assert rc == -1 and b"null" in _lib.LIB.dgla_last_error()
+    _lib.LIB.DGLAPISetLastError(b"hello")
+    _lib.LIB.DGLGetLastError.restype = ctypes.c_char_p
+    assert _lib.LIB.DGLGetLastError() == b"hello"
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "dgl_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cuh")):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
+                assert "liboracle" not in src, f
+
+
+def test_cpu_tensor_is_refused():
+    import pytest
+    import torch
+
+    from dgl_amd import DGLAMDError, _capi
+
+    with pytest.raises(DGLAMDError, match="no CPU fallback|ROCm GPU"):
+        _capi.make_csr(torch.zeros(3, dtype=torch.int32), torch.zeros(2, dtype=torch.int32), None, 2)
