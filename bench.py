@@ -63,21 +63,28 @@ def cpu_baseline(g, x, budget_s=12.0):
     indptr = g["indptr"].cpu().numpy()
     indices = g["indices"].cpu().numpy()
     xh = x.cpu().numpy()
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
     out = np.zeros_like(xh)
     t0 = time.perf_counter()
-    oracle.copy_u_sum_csr(indptr, indices, xh, cores, out)  # warm-up (page faults, OMP pool)
+    oracle.copy_u_sum_csr(indptr, indices, xh, ncpu, out)  # warm-up (page faults, OMP pool)
     warm = time.perf_counter() - t0
-    reps = max(1, min(10, int(budget_s / max(warm, 1e-3))))
-    times = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        oracle.copy_u_sum_csr(indptr, indices, xh, cores, out)
-        times.append(time.perf_counter() - t0)
-    best = min(times)
+    # the gather is memory-bound: on a many-core host fewer threads than hardware threads can
+    # win, so sweep a few counts and keep the fastest (its thread count is reported as `cores`)
+    best, cores, reps = None, ncpu, 0
+    t_start = time.perf_counter()
+    for th in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4)}, reverse=True):
+        for _ in range(2):
+            t0 = time.perf_counter()
+            oracle.copy_u_sum_csr(indptr, indices, xh, th, out)
+            dt = time.perf_counter() - t0
+            reps += 1
+            if best is None or dt < best:
+                best, cores = dt, th
+        if time.perf_counter() - t_start > budget_s:
+            break
     return {
         "value": g["nnz"] / best, "unit": "edges/s", "cores": cores, "kind": "port",
-        "sample": "full workload (%d edges, F=%d), best of %d passes after 1 warm-up; "
+        "sample": "full workload (%d edges, F=%d), best of %d passes (thread-count sweep) after 1 warm-up; "
                   "oracle.copy_u_sum_csr = C/OpenMP restatement of DGL SpMMSumCsrNaive "
                   "(libxsmm JIT unavailable)" % (g["nnz"], x.shape[1], reps),
     }, out

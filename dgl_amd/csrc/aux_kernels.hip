@@ -7,20 +7,36 @@ namespace dgla {
 // Streaming copy: 16 bytes per lane, grid-stride.  bench.py uses it to measure the HBM
 // peak the roofline fraction is quoted against (MI355X_MICROARCH.md: 6.29 TB/s float4 copy).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restrict__ src,
-                                                          uint4* __restrict__ dst, size_t n) {
-  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
-  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += stride)
-    dst[i] = src[i];
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+__global__ __launch_bounds__(256) void stream_copy_kernel(const u32x4* __restrict__ src,
+                                                          u32x4* __restrict__ dst, size_t n) {
+  // 4 independent 16-byte loads per lane in flight, then 4 stores; blocks walk the array
+  // in 16 KiB tiles.
+  constexpr int U = 4;
+  const size_t tile = static_cast<size_t>(blockDim.x) * U;
+  const size_t stride = static_cast<size_t>(gridDim.x) * tile;
+  for (size_t base = blockIdx.x * tile + threadIdx.x; base < n; base += stride) {
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = base + static_cast<size_t>(u) * blockDim.x;
+      if (i < n) v[u] = __builtin_nontemporal_load(src + i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = base + static_cast<size_t>(u) * blockDim.x;
+      if (i < n) __builtin_nontemporal_store(v[u], dst + i);
+    }
+  }
 }
 
 int launch_stream_copy(void* dst, const void* src, size_t bytes, hipStream_t stream) {
   const size_t n = bytes / 16;
   if (n == 0) return 0;
-  size_t blocks = (n + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  size_t blocks = (n + 1023) / 1024;
+  if (blocks > 256 * 8) blocks = 256 * 8;
   hipLaunchKernelGGL(stream_copy_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                     stream, static_cast<const uint4*>(src), static_cast<uint4*>(dst), n);
+                     stream, static_cast<const u32x4*>(src), static_cast<u32x4*>(dst), n);
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
 }
