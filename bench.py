@@ -35,6 +35,32 @@ def algorithmic_bytes(n_rows, n_edges, feat, s=4, i=4):
     return n_edges * (feat * s + i) + (n_rows + 1) * i + n_rows * feat * s
 
 
+def pmc_traffic(kernel_substr="spmm_csr_merge_kernel"):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    of this same command (profiles/<round>/pmc_FETCH_SIZE.csv, pmc_WRITE_SIZE.csv; collected by
+    tools_profile.sh in separate --pmc runs).  Units/corrections per MI355X_MICROARCH.md §HBM:
+    both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced
+    reads (calibrated here on the 4 GiB stream_copy_kernel: FETCH_SIZE*1024 = 2.147e9 for
+    4.295e9 bytes read; WRITE_SIZE*1024 = 4.295e9 exact), so reads are doubled."""
+    import csv
+    import glob
+
+    dirs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*")))
+    if not dirs:
+        return None, None
+    vals = {}
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        path = os.path.join(dirs[-1], "pmc_%s.csv" % name)
+        if not os.path.exists(path):
+            return None, None
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+             if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == name]
+        if not v:
+            return None, None
+        vals[name] = sum(v) / len(v)
+    return 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024, os.path.relpath(dirs[-1], ROOT)
+
+
 def measure_copy_peak(dev, nbytes=4 << 30, iters=5):
     from dgl_amd import _capi
 
@@ -204,12 +230,17 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
                 "kernel": "spmm_csr_merge_kernel<int,float,VEC=4,copy_lhs,sum>",
                 "kernel_avg_ms": kern_avg, "kernel_min_ms": float(np.min(kern_ms)),
                 "algorithmic_bytes_per_launch": b_alg,
             },
         }
+
+    if rank == 0 and args.scale == 1 and args.variant == "U":
+        t, src = pmc_traffic()
+        result["roofline"]["traffic"] = t
+        result["roofline"]["traffic_source"] = src
 
     # ---- extras on rank 0, outside the timed region ----------------------------------
     if rank == 0 and world == 1:

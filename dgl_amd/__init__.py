@@ -8,3 +8,11 @@ from . import _lib  # noqa: F401  (raises ImportError if libdgl_amd.so has not b
 from ._lib import DGLAMDError
 
 __version__ = "0.1.0"
+
+from . import function  # noqa: E402,F401
+from . import ops  # noqa: E402,F401
+from .heterograph import (DGLGraph, create_block, graph, heterograph, rand_bipartite,  # noqa: E402,F401
+                          rand_graph, reverse)
+from .ops import edge_softmax  # noqa: E402,F401
+
+DGLError = DGLAMDError

@@ -1,0 +1,164 @@
+"""Python binding of the registry layer of libdgl_amd.so (``DGLFuncGetGlobal`` /
+``DGLFuncCall``), i.e. the same calling convention python/dgl/_ffi/_ctypes/function.py uses
+against libdgl.so: arguments are packed into ``DGLValue[]`` + type codes, NDArrays travel as
+``DGLArray*`` handles, errors come back as -1 + ``DGLGetLastError()``.
+
+Tensors are NOT copied and no DLPack capsule is needed: a ``DGLArray`` struct is filled
+straight from the torch tensor (pointer, shape, dtype, device_type = kDGLROCM = 10).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import LIB
+
+# type codes, include/dgl/runtime/c_runtime_api.h:66-91
+kObjectInt, kObjectFloat, kHandle, kNull, kArrayHandle, kObjectHandle, kStr = 0, 2, 3, 4, 7, 8, 11
+kDGLROCM = 10
+
+
+class DGLValue(ctypes.Union):
+    _fields_ = [("v_int64", ctypes.c_int64), ("v_float64", ctypes.c_double),
+                ("v_handle", ctypes.c_void_p), ("v_str", ctypes.c_char_p)]
+
+
+class DGLContext(ctypes.Structure):
+    _fields_ = [("device_type", ctypes.c_int32), ("device_id", ctypes.c_int32)]
+
+
+class DGLDataType(ctypes.Structure):
+    _fields_ = [("code", ctypes.c_uint8), ("bits", ctypes.c_uint8), ("lanes", ctypes.c_uint16)]
+
+
+class DGLArray(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("ctx", DGLContext), ("ndim", ctypes.c_int32),
+                ("dtype", DGLDataType), ("shape", ctypes.POINTER(ctypes.c_int64)),
+                ("strides", ctypes.POINTER(ctypes.c_int64)), ("byte_offset", ctypes.c_uint64)]
+
+
+_DT = {
+    torch.float32: (2, 32), torch.float64: (2, 64), torch.float16: (2, 16),
+    torch.bfloat16: (4, 16), torch.int32: (0, 32), torch.int64: (0, 64), torch.uint8: (1, 8),
+}
+
+LIB.DGLGetLastError.restype = ctypes.c_char_p
+LIB.DGLFuncGetGlobal.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+LIB.DGLFuncCall.argtypes = [ctypes.c_void_p, ctypes.POINTER(DGLValue), ctypes.POINTER(ctypes.c_int),
+                            ctypes.c_int, ctypes.POINTER(DGLValue), ctypes.POINTER(ctypes.c_int)]
+LIB.DGLSetStream.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+
+
+class NDArray:
+    """A borrowed view of a torch tensor as a ``DGLArray``.  ``unsqueeze`` views a 1-D
+    feature as (n, 1) (python/dgl/_sparse_ops.py:208-217)."""
+
+    __slots__ = ("tensor", "_shape", "arr")
+
+    def __init__(self, t, unsqueeze=False):
+        if not t.is_cuda:
+            raise _lib.DGLAMDError("dgl_amd: tensors must live on a ROCm GPU (no CPU fallback)")
+        if not t.is_contiguous():
+            raise _lib.DGLAMDError("dgl_amd: tensors handed to the kernels must be contiguous")
+        self.tensor = t
+        shape = tuple(t.shape)
+        if unsqueeze and len(shape) == 1:
+            shape = (shape[0], 1)
+        self._shape = (ctypes.c_int64 * max(len(shape), 1))(*shape)
+        code, bits = _DT[t.dtype]
+        self.arr = DGLArray(t.data_ptr(), DGLContext(kDGLROCM, t.device.index or 0), len(shape),
+                            DGLDataType(code, bits, 1), self._shape, None, 0)
+
+
+def _pack(args):
+    n = len(args)
+    values = (DGLValue * max(n, 1))()
+    codes = (ctypes.c_int * max(n, 1))()
+    keep = []
+    for i, a in enumerate(args):
+        if a is None:
+            values[i].v_handle = None
+            codes[i] = kNull
+        elif isinstance(a, NDArray):
+            values[i].v_handle = ctypes.cast(ctypes.pointer(a.arr), ctypes.c_void_p)
+            codes[i] = kArrayHandle
+            keep.append(a)
+        elif isinstance(a, bool) or isinstance(a, int):
+            values[i].v_int64 = int(a)
+            codes[i] = kObjectInt
+        elif isinstance(a, float):
+            values[i].v_float64 = a
+            codes[i] = kObjectFloat
+        elif isinstance(a, str):
+            b = a.encode("utf-8")
+            keep.append(b)
+            values[i].v_str = b
+            codes[i] = kStr
+        elif isinstance(a, ObjectHandle):
+            values[i].v_handle = a.handle
+            codes[i] = kObjectHandle
+        else:
+            raise TypeError("cannot pass %r through the FFI" % type(a))
+    return values, codes, n, keep
+
+
+class ObjectHandle:
+    """Opaque object living on the C++ side (the unit-graph handle)."""
+
+    __slots__ = ("handle",)
+
+    def __init__(self, handle):
+        self.handle = handle
+
+
+class Function:
+    """A registered global function (python/dgl/_ffi/function.py:Function)."""
+
+    __slots__ = ("name", "handle")
+
+    def __init__(self, name, handle):
+        self.name, self.handle = name, handle
+
+    def __call__(self, *args):
+        values, codes, n, keep = _pack(args)
+        ret, ret_code = DGLValue(), ctypes.c_int(kNull)
+        rc = LIB.DGLFuncCall(self.handle, values, codes, n, ctypes.byref(ret), ctypes.byref(ret_code))
+        del keep
+        if rc != 0:
+            raise _lib.DGLAMDError(LIB.DGLGetLastError().decode("utf-8", "replace"))
+        if ret_code.value == kNull:
+            return None
+        if ret_code.value == kObjectInt:
+            return ret.v_int64
+        if ret_code.value == kObjectFloat:
+            return ret.v_float64
+        if ret_code.value in (kObjectHandle, kHandle):
+            return ObjectHandle(ret.v_handle)
+        raise _lib.DGLAMDError("unsupported FFI return type code %d" % ret_code.value)
+
+
+_cache = {}
+
+
+def get_global_func(name):
+    f = _cache.get(name)
+    if f is None:
+        h = ctypes.c_void_p()
+        LIB.DGLFuncGetGlobal(name.encode(), ctypes.byref(h))
+        if not h.value:
+            raise _lib.DGLAMDError("global function %s is not registered" % name)
+        f = _cache[name] = Function(name, h.value)
+    return f
+
+
+def list_global_func_names():
+    n = ctypes.c_int()
+    arr = ctypes.POINTER(ctypes.c_char_p)()
+    LIB.DGLFuncListGlobalNames(ctypes.byref(n), ctypes.byref(arr))
+    return [arr[i].decode() for i in range(n.value)]
+
+
+def use_current_stream(device):
+    """Queue the following kernel calls of this thread on PyTorch's current stream of
+    `device` (reference: tensoradapter CUDACurrentStream, src/runtime/cuda/cuda_device_api.cc:362-367)."""
+    LIB.DGLSetStream(kDGLROCM, device.index or 0, torch.cuda.current_stream(device).cuda_stream)

@@ -65,7 +65,15 @@ static int parse_reduce(const char* s) {
   return -1;
 }
 
-static bool present(const dgla_tensor* t) { return t && t->data != nullptr; }
+// An operand is absent when the descriptor is NULL or has no dimensions; an EMPTY tensor
+// (0 rows, data may be NULL) is present.
+static bool present(const dgla_tensor* t) {
+  if (!t || t->ndim <= 0 || !t->shape) return false;
+  if (t->data) return true;
+  for (int i = 0; i < t->ndim; ++i)
+    if (t->shape[i] == 0) return true;
+  return false;
+}
 
 static int64_t feat_len(const dgla_tensor* t) {
   int64_t n = 1;

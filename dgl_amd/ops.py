@@ -1,0 +1,216 @@
+"""Operator API of the hot path: the ``dgl.ops`` surface for g-SpMM / g-SDDMM / edge softmax.
+
+Same names, argument meaning and semantics as python/dgl/ops/spmm.py (``gspmm`` :39-116 and
+the generated ``u_mul_e_sum`` ... ``copy_e_mean`` aliases :224-241), python/dgl/ops/sddmm.py
+(``gsddmm`` :40-98, ``u_add_v`` ... ``copy_e`` :146-207) and python/dgl/ops/edge_softmax.py
+(:12).  ``g`` is a :class:`dgl_amd.heterograph.DGLGraph`.
+"""
+import sys
+
+import torch
+
+from . import autograd as _F
+from ._lib import DGLAMDError
+
+__all__ = ["gspmm", "gsddmm", "edge_softmax", "copy_u", "copy_v", "copy_e"]
+
+
+def _reshape_for_broadcast(op, lhs, rhs):
+    """Pad the shorter feature shape with 1s right after the node/edge axis so both operands
+    have the same rank (ops/spmm.py:13-36); `dot` keeps the last (reduced) axis aligned."""
+    ls, rs = lhs.shape, rhs.shape
+    if len(ls) == len(rs):
+        return lhs, rhs
+    if len(ls) < len(rs):
+        lhs = lhs.reshape((ls[0],) + (1,) * (len(rs) - len(ls)) + tuple(ls[1:]))
+    else:
+        rhs = rhs.reshape((rs[0],) + (1,) * (len(ls) - len(rs)) + tuple(rs[1:]))
+    return lhs, rhs
+
+
+def gspmm(g, op, reduce_op, lhs_data, rhs_data):
+    r"""Generalized SpMM: messages ``op(lhs[src], rhs[edge])`` reduced into destination nodes.
+
+    op in {add, sub, mul, div, copy_lhs, copy_rhs}; reduce_op in {sum, max, min, mean}.
+    For graphs with several relations pass tuples/dicts as the reference does (lhs indexed by
+    source node type, rhs by edge type)."""
+    if op not in ("add", "sub", "mul", "div", "copy_lhs", "copy_rhs"):
+        raise DGLAMDError("Unsupported SpMM binary operator: {}".format(op))
+    if reduce_op not in ("sum", "max", "min", "mean"):
+        raise DGLAMDError("Unsupported SpMM reducer: {}".format(reduce_op))
+    gidx = g._graph
+    if gidx.number_of_etypes() == 1:
+        if op not in ("copy_lhs", "copy_rhs"):
+            lhs_data, rhs_data = _reshape_for_broadcast(op, lhs_data, rhs_data)
+        ret = _F.gspmm(gidx, op, "sum" if reduce_op == "mean" else reduce_op, lhs_data, rhs_data)
+    else:
+        lhs_t = _to_type_tuple(g, lhs_data, "ntype") if op != "copy_rhs" else ()
+        rhs_t = _to_type_tuple(g, rhs_data, "etype") if op != "copy_lhs" else ()
+        if op not in ("copy_lhs", "copy_rhs"):
+            lhs_t, rhs_t = list(lhs_t), list(rhs_t)
+            for et in range(gidx.number_of_etypes()):
+                s, _ = gidx.metagraph.find_edge(et)
+                if lhs_t[s] is not None and rhs_t[et] is not None:
+                    lhs_t[s], rhs_t[et] = _reshape_for_broadcast(op, lhs_t[s], rhs_t[et])
+        ret = _F.gspmm_hetero(gidx, op, "sum" if reduce_op == "mean" else reduce_op,
+                              len(lhs_t), *(tuple(lhs_t) + tuple(rhs_t)))
+    if reduce_op == "mean":
+        # mean = sum / clamp(in_degree, 1)  (ops/spmm.py:109-114)
+        def div(x, deg):
+            shp = (x.shape[0],) + (1,) * (x.dim() - 1)
+            return x / deg.to(x.dtype).clamp(min=1).reshape(shp)
+
+        if gidx.number_of_etypes() == 1:
+            ret = div(ret, g.in_degrees())
+        else:
+            raise DGLAMDError("Reduce op 'mean' is not supported on graphs with several relations "
+                              "(python/dgl/heterograph.py:5133-5138).")
+    return ret
+
+
+def gsddmm(g, op, lhs_data, rhs_data, lhs_target="u", rhs_target="v"):
+    r"""Generalized SDDMM: ``out[e] = op(lhs[target_l(e)], rhs[target_r(e)])``.
+
+    op in {add, sub, mul, div, dot, copy_lhs, copy_rhs}; targets in {u, v, e}."""
+    if op not in ("add", "sub", "mul", "div", "dot", "copy_lhs", "copy_rhs"):
+        raise DGLAMDError("Unsupported SDDMM binary operator: {}".format(op))
+    if lhs_target not in "uve" or rhs_target not in "uve":
+        raise DGLAMDError("targets must be one of 'u', 'v', 'e'")
+    gidx = g._graph
+    if gidx.number_of_etypes() == 1:
+        if op not in ("copy_lhs", "copy_rhs"):
+            lhs_data, rhs_data = _reshape_for_broadcast(op, lhs_data, rhs_data)
+        return _F.gsddmm(gidx, op, lhs_data, rhs_data, lhs_target, rhs_target)
+    kind = lambda t: "etype" if t == "e" else "ntype"
+    lhs_t = _to_type_tuple(g, lhs_data, kind(lhs_target)) if op != "copy_rhs" else ()
+    rhs_t = _to_type_tuple(g, rhs_data, kind(rhs_target)) if op != "copy_lhs" else ()
+    return _F.gsddmm_hetero(gidx, op, len(lhs_t), lhs_target, rhs_target,
+                            *(tuple(lhs_t) + tuple(rhs_t)))
+
+
+def _to_type_tuple(g, data, kind):
+    """dict keyed by type name (or tuple/list already in type-id order) -> tuple in id order."""
+    if isinstance(data, (tuple, list)):
+        return tuple(data)
+    n = len(g.ntypes) if kind == "ntype" else len(g.canonical_etypes)
+    out = [None] * n
+    for k, v in data.items():
+        idx = g.get_ntype_id(k) if kind == "ntype" else g.get_etype_id(k)
+        out[idx] = v
+    return tuple(out)
+
+
+def edge_softmax(graph, logits, eids=None, norm_by="dst"):
+    r"""Softmax of edge scores over the edges that share a destination (or source) node
+    (python/dgl/ops/edge_softmax.py:12-140)."""
+    if norm_by not in ("dst", "src"):
+        raise DGLAMDError("norm_by must be 'dst' or 'src'")
+    gidx = graph._graph
+    if eids is not None and not isinstance(eids, torch.Tensor):
+        eids = torch.as_tensor(eids)
+    if gidx.number_of_etypes() == 1:
+        return _F.edge_softmax(gidx, logits, eids, norm_by)
+    # several relations: the normaliser runs over ALL incoming edges of a node regardless of
+    # relation (EdgeSoftmax_hetero, sparse.py:750-850): concatenate per destination type
+    if eids is not None:
+        raise DGLAMDError("eids is not supported on graphs with several relations")
+    scores = _to_type_tuple(graph, logits, "etype")
+    outs = [None] * gidx.number_of_etypes()
+    by_nt = {}
+    for et in range(gidx.number_of_etypes()):
+        s, d = gidx.metagraph.find_edge(et)
+        if scores[et] is not None:
+            by_nt.setdefault(d if norm_by == "dst" else s, []).append(et)
+    from .graph_index import GraphIndex, Relation
+
+    for nt, ets in by_nt.items():
+        rows, cols, offs = [], [], [0]
+        for et in ets:
+            r, c, old = gidx.relations[et].coo()
+            if old is not None:
+                raise DGLAMDError("edge_softmax needs COO in edge-id order")
+            rows.append(r if norm_by == "dst" else c)
+            cols.append(c if norm_by == "dst" else r)
+            offs.append(offs[-1] + r.shape[0])
+        # source ids of different relations may collide; they are irrelevant for the softmax
+        rel = Relation(int(max(int(x.max()) + 1 if x.numel() else 1 for x in rows)),
+                       gidx.num_nodes(nt), torch.cat(rows), torch.cat(cols),
+                       idtype=gidx.dtype, device=gidx.ctx)
+        sub = GraphIndex([rel.num_src, rel.num_dst], [(0, 1)], [rel])
+        res = _F.edge_softmax(sub, torch.cat([scores[et] for et in ets]), None, "dst")
+        for i, et in enumerate(ets):
+            outs[et] = res[offs[i]:offs[i + 1]]
+    if isinstance(logits, dict):
+        return {graph.canonical_etypes[et]: o for et, o in enumerate(outs) if o is not None}
+    return tuple(outs)
+
+
+# ---- generated aliases -----------------------------------------------------------------
+def _make_spmm(binary, reduce_op):
+    name = "u_{}_e_{}".format(binary, reduce_op)
+
+    def f(g, x, y):
+        return gspmm(g, binary, reduce_op, x, y)
+
+    f.__name__ = name
+    f.__doc__ = "Generalized SpMM: message = u {} e, reducer = {} (ops/spmm.py:119-170).".format(
+        binary, reduce_op)
+    return name, f
+
+
+def _make_copy_spmm(which, reduce_op):
+    name = "copy_{}_{}".format(which, reduce_op)
+    op = "copy_lhs" if which == "u" else "copy_rhs"
+
+    def f(g, x):
+        return gspmm(g, op, reduce_op, x if which == "u" else None, None if which == "u" else x)
+
+    f.__name__ = name
+    f.__doc__ = "Generalized SpMM: message = copy_{}, reducer = {} (ops/spmm.py:173-221).".format(
+        which, reduce_op)
+    return name, f
+
+
+def _make_sddmm(lhs, binary, rhs):
+    name = "{}_{}_{}".format(lhs, binary, rhs)
+
+    def f(g, x, y):
+        return gsddmm(g, binary, x, y, lhs_target=lhs, rhs_target=rhs)
+
+    f.__name__ = name
+    f.__doc__ = "Generalized SDDMM: out[e] = {} {} {} (ops/sddmm.py:101-143).".format(lhs, binary, rhs)
+    return name, f
+
+
+_mod = sys.modules[__name__]
+for _b in ("add", "sub", "mul", "div"):
+    for _r in ("sum", "max", "min", "mean"):
+        _n, _f = _make_spmm(_b, _r)
+        setattr(_mod, _n, _f)
+        __all__.append(_n)
+for _w in ("u", "e"):
+    for _r in ("sum", "max", "min", "mean"):
+        _n, _f = _make_copy_spmm(_w, _r)
+        setattr(_mod, _n, _f)
+        __all__.append(_n)
+for _l in "uve":
+    for _r in "uve":
+        for _b in ("add", "sub", "mul", "div", "dot"):
+            _n, _f = _make_sddmm(_l, _b, _r)
+            setattr(_mod, _n, _f)
+            __all__.append(_n)
+
+
+def copy_u(g, x):
+    """Edge feature = source node feature (ops/sddmm.py:146-165)."""
+    return gsddmm(g, "copy_lhs", x, None)
+
+
+def copy_v(g, x):
+    """Edge feature = destination node feature (ops/sddmm.py:168-187)."""
+    return gsddmm(g, "copy_rhs", None, x)
+
+
+def copy_e(g, x):
+    """Identity on edge features (ops/sddmm.py:190-207)."""
+    return x

@@ -1,0 +1,266 @@
+"""Shape inference, output allocation and the FFI call sites of the hot path.
+
+Host-side mirror of python/dgl/_sparse_ops.py (``_gspmm`` :156-265, ``_gsddmm`` :482-565,
+hetero variants :268-433,568-638, ``_edge_softmax_forward/backward`` :720-800): same
+argument meaning, dtype rules, 1-D feature handling, return values and error messages —
+the arithmetic happens in libdgl_amd.so behind ``sparse._CAPI_DGLKernel*``.
+"""
+import torch
+
+from . import _ffi
+from ._lib import DGLAMDError
+
+_TARGET = {"u": 0, "e": 1, "v": 2, 0: 0, 1: 1, 2: 2}
+
+
+def infer_broadcast_shape(op, shp1, shp2):
+    """Feature shape of ``op(lhs, rhs)`` (python/dgl/_sparse_ops.py:10-60)."""
+    shp1, shp2 = tuple(shp1), tuple(shp2)
+    if op == "copy_lhs":
+        return shp1
+    if op == "copy_rhs":
+        return shp2
+    n = max(len(shp1), len(shp2))
+    a, b = (1,) * (n - len(shp1)) + shp1, (1,) * (n - len(shp2)) + shp2
+    for x, y in zip(a, b):
+        if x != y and x != 1 and y != 1:
+            raise DGLAMDError("Feature shapes {} and {} are not valid for broadcasting.".format(shp1, shp2))
+    out = tuple(max(x, y) for x, y in zip(a, b))
+    return out[:-1] + (1,) if op == "dot" else out
+
+
+def _nd(t):
+    return None if t is None else _ffi.NDArray(t, unsqueeze=True)
+
+
+def _check_pair(u, e, use_u, use_e, what):
+    if use_u and use_e and u.dtype != e.dtype:
+        raise DGLAMDError(
+            "The node features' data type {} doesn't match edge features' data type {}, "
+            "please convert them to the same type.".format(u.dtype, e.dtype) if what == "spmm" else
+            "The left operand's data type {} doesn't match the right operand's data type {}, "
+            "please convert them to the same type.".format(u.dtype, e.dtype))
+
+
+def _call(name, rel, fmt, *args):
+    dev = rel.device
+    _ffi.use_current_stream(dev)
+    return _ffi.get_global_func(name)(rel.handle(fmt), *args)
+
+
+def _spmm_format(rel):
+    # aten::SpMM: SelectFormat(0, CSC_CODE) — CSC (built on demand) unless the graph is
+    # restricted to COO (src/array/kernel.cc:26-43)
+    if rel.allowed("csc"):
+        return "csc"
+    if rel.allowed("coo"):
+        return "coo"
+    raise DGLAMDError("SpMM only supports CSC and COO formats")
+
+
+def _sddmm_format(rel):
+    # aten::SDDMM: SelectFormat(0, COO_CODE) — COO preferred, else CSR (kernel.cc:230-247)
+    if rel.allowed("coo"):
+        return "coo"
+    if rel.allowed("csr"):
+        return "csr"
+    raise DGLAMDError("SDDMM only supports CSR and COO formats")
+
+
+def _gspmm(gidx, op, reduce_op, u, e, accumulate_into=None):
+    """out[v] = reduce_{(u,e,v)} op(u_feat, e_feat).  Returns ``(out, (arg_u, arg_e))``."""
+    if gidx.number_of_etypes() != 1:
+        raise DGLAMDError("We only support gspmm on graph with one edge type")
+    use_u, use_e = op != "copy_rhs", op != "copy_lhs"
+    _check_pair(u, e, use_u, use_e, "spmm")
+    rel = gidx.relations[0]
+    expand_u = expand_e = False
+    if use_u:
+        if u.dim() == 1:
+            u, expand_u = u.unsqueeze(-1), True
+    if use_e:
+        if e.dim() == 1:
+            e, expand_e = e.unsqueeze(-1), True
+    ref = u if use_u else e
+    dtype, dev = ref.dtype, ref.device
+    u_shp = tuple(u.shape) if use_u else (0,)
+    e_shp = tuple(e.shape) if use_e else (0,)
+    s, d = gidx.metagraph.find_edge(0)
+    v_shp = (gidx.num_nodes(d),) + infer_broadcast_shape(op, u_shp[1:], e_shp[1:])
+    use_cmp = reduce_op in ("max", "min")
+    n_edges = gidx.num_edges(0)
+    if accumulate_into is not None:
+        v = accumulate_into
+    elif n_edges == 0:
+        v = torch.zeros(v_shp, dtype=dtype, device=dev)   # _sparse_ops.py:238: kernel is not called
+    else:
+        v = torch.empty(v_shp, dtype=dtype, device=dev)   # every row is written by the kernel
+    arg_u = arg_e = None
+    if use_cmp:
+        mk = torch.zeros if n_edges == 0 else torch.empty
+        if use_u:
+            arg_u = mk(v_shp, dtype=rel.idtype, device=dev)
+        if use_e:
+            arg_e = mk(v_shp, dtype=rel.idtype, device=dev)
+    if n_edges > 0 and v.numel() > 0:
+        fmt = _spmm_format(rel)
+        uu = u.contiguous() if use_u else None
+        ee = e.contiguous() if use_e else None
+        args = (op, reduce_op, _nd(uu), _nd(ee), _nd(v), _nd(arg_u), _nd(arg_e))
+        if fmt == "csc":
+            nbytes = _call("sparse._CAPI_DGLKernelSpMMWorkspaceBytes", rel, fmt, *args)
+            rel.ensure_workspace(nbytes)
+        name = "sparse._CAPI_DGLKernelSpMM" if accumulate_into is None else \
+            "sparse._CAPI_DGLKernelSpMMAccumulate"
+        _call(name, rel, fmt, *args)
+    # 1-D inputs give 1-D outputs (_sparse_ops.py:258-264)
+    if (expand_u or not use_u) and (expand_e or not use_e):
+        v = v.squeeze(-1)
+        arg_u = None if arg_u is None else arg_u.squeeze(-1)
+        arg_e = None if arg_e is None else arg_e.squeeze(-1)
+    return v, (arg_u, arg_e)
+
+
+def _gsddmm(gidx, op, lhs, rhs, lhs_target="u", rhs_target="v"):
+    """out[e] = op(lhs[target], rhs[target]) for every edge."""
+    if gidx.number_of_etypes() != 1:
+        raise DGLAMDError("We only support gsddmm on graph with one edge type")
+    use_l, use_r = op != "copy_rhs", op != "copy_lhs"
+    _check_pair(lhs, rhs, use_l, use_r, "sddmm")
+    rel = gidx.relations[0]
+    expand_l = expand_r = False
+    if use_l and lhs.dim() == 1:
+        lhs, expand_l = lhs.unsqueeze(-1), True
+    if use_r and rhs.dim() == 1:
+        rhs, expand_r = rhs.unsqueeze(-1), True
+    ref = lhs if use_l else rhs
+    l_shp = tuple(lhs.shape) if use_l else (0,)
+    r_shp = tuple(rhs.shape) if use_r else (0,)
+    n_edges = gidx.num_edges(0)
+    out_shp = (n_edges,) + infer_broadcast_shape(op, l_shp[1:], r_shp[1:])
+    out = torch.empty(out_shp, dtype=ref.dtype, device=ref.device)
+    if n_edges > 0 and out.numel() > 0:
+        fmt = _sddmm_format(rel)
+        _call("sparse._CAPI_DGLKernelSDDMM", rel, fmt, op,
+              _nd(lhs.contiguous() if use_l else None), _nd(rhs.contiguous() if use_r else None),
+              _nd(out), _TARGET[lhs_target], _TARGET[rhs_target])
+    if (expand_l or not use_l) and (expand_r or not use_r):
+        out = out.squeeze(-1)
+    return out
+
+
+def _edge_softmax_forward(gidx, e, op="copy_rhs"):
+    """Fused softmax of edge scores over the incoming edges of each destination node
+    (python/dgl/_sparse_ops.py:720-758; CPU-only in the reference)."""
+    if gidx.number_of_etypes() != 1:
+        raise DGLAMDError("We only support edge_softmax on graph with one edge type")
+    rel = gidx.relations[0]
+    expand = e.dim() == 1
+    if expand:
+        e = e.unsqueeze(-1)
+    e = e.contiguous()
+    out = torch.empty_like(e)
+    if gidx.num_edges(0) > 0 and e.numel() > 0:
+        _call("sparse._CAPI_DGLKernelEdge_softmax_forward", rel, "csc", op, None, _nd(e), _nd(out))
+    return out.squeeze(-1) if expand else out
+
+
+def _edge_softmax_backward(gidx, out, sds):
+    """grad_score = sds - out * sum_dst(sds)   (python/dgl/_sparse_ops.py:761-800)."""
+    rel = gidx.relations[0]
+    expand = out.dim() == 1
+    if expand:
+        out, sds = out.unsqueeze(-1), sds.unsqueeze(-1)
+    out, sds = out.contiguous(), sds.contiguous()
+    back = torch.empty_like(out)
+    if gidx.num_edges(0) > 0 and out.numel() > 0:
+        _call("sparse._CAPI_DGLKernelEdge_softmax_backward", rel, "csc", "copy_rhs", _nd(out),
+              _nd(sds), _nd(back), None)
+    return back.squeeze(-1) if expand else back
+
+
+# ---------------------------------------------------------------------------------------
+# Heterogeneous graphs: one kernel launch per relation on the same stream, results of the
+# relations that share a destination node type reduced into one buffer — the structure of
+# SpMMCsrHetero (src/array/cuda/spmm_hetero.cu:26-200).
+# ---------------------------------------------------------------------------------------
+def _gspmm_hetero(gidx, op, reduce_op, u_len, u_and_e_tuple):
+    """Returns ``(out_per_dst_ntype, (arg_u, arg_e, arg_u_ntype, arg_e_etype))`` like
+    python/dgl/_sparse_ops.py:268-433.  ``u`` is indexed by source node type, ``e`` by edge
+    type, outputs by destination node type."""
+    u_tuple, e_tuple = u_and_e_tuple[:u_len], u_and_e_tuple[u_len:]
+    use_u, use_e = op != "copy_rhs", op != "copy_lhs"
+    n_nt, n_et = gidx.number_of_ntypes(), gidx.number_of_etypes()
+    outs = [None] * n_nt
+    arg_u, arg_e = [None] * n_nt, [None] * n_nt
+    arg_u_nt, arg_e_et = [None] * n_nt, [None] * n_nt
+    use_cmp = reduce_op in ("max", "min")
+    feat_shape = {}
+    for et in range(n_et):
+        s, d = gidx.metagraph.find_edge(et)
+        u = u_tuple[s] if use_u else None
+        e = e_tuple[et] if use_e else None
+        if (use_u and u is None) or (use_e and e is None):
+            continue
+        sub = gidx.get_relation_graph(et)
+        o_feat = infer_broadcast_shape(op, tuple(u.shape[1:]) if use_u else (),
+                                       tuple(e.shape[1:]) if use_e else ())
+        if d in feat_shape and feat_shape[d] != o_feat:
+            # src/array/kernel.cc:194-199: relations reducing into one node type must agree
+            raise DGLAMDError("The feature shape of relation {} does not match others.".format(et))
+        feat_shape[d] = o_feat
+        if not use_cmp:
+            if outs[d] is None:
+                ref = u if use_u else e
+                o_shp = (gidx.num_nodes(d),) + infer_broadcast_shape(
+                    op, tuple(u.shape[1:]) if use_u else (), tuple(e.shape[1:]) if use_e else ())
+                if ref.dim() == 1:
+                    o_shp = (gidx.num_nodes(d),)
+                if gidx.num_edges(et) > 0:
+                    outs[d], _ = _gspmm(sub, op, reduce_op, u, e)          # first relation writes
+                else:
+                    outs[d] = torch.zeros(o_shp, dtype=ref.dtype, device=ref.device)
+            elif gidx.num_edges(et) > 0:
+                acc = outs[d] if outs[d].dim() > 1 else outs[d].unsqueeze(-1)
+                _gspmm(sub, op, reduce_op, u, e, accumulate_into=acc)     # later ones add
+        else:
+            o, (au, ae) = _gspmm(sub, op, reduce_op, u, e)
+            if outs[d] is None:
+                outs[d], arg_u[d], arg_e[d] = o, au, ae
+                has = gidx.relations[et].in_degrees() > 0
+                has = has.view((-1,) + (1,) * (o.dim() - 1)).expand_as(o)
+                # node/edge type of the winner, -1 where no edge arrived (spmm_hetero.cu:87-117)
+                if use_u:
+                    arg_u_nt[d] = torch.where(has, torch.full_like(au, s), torch.full_like(au, -1))
+                if use_e:
+                    arg_e_et[d] = torch.where(has, torch.full_like(ae, et), torch.full_like(ae, -1))
+            else:
+                # running max/min across relations: a later relation wins only if strictly
+                # better (SpMMCmpCsrHeteroKernel seeds from the current output, spmm.cuh:552-606)
+                better = (o > outs[d]) if reduce_op == "max" else (o < outs[d])
+                outs[d] = torch.where(better, o, outs[d])
+                if use_u:
+                    arg_u[d] = torch.where(better, au, arg_u[d])
+                    arg_u_nt[d] = torch.where(better, torch.full_like(au, s), arg_u_nt[d])
+                if use_e:
+                    arg_e[d] = torch.where(better, ae, arg_e[d])
+                    arg_e_et[d] = torch.where(better, torch.full_like(ae, et), arg_e_et[d])
+    return tuple(outs), (arg_u, arg_e, arg_u_nt, arg_e_et)
+
+
+def _gsddmm_hetero(gidx, op, lhs_len, lhs_target, rhs_target, lhs_and_rhs_tuple):
+    """Per-relation SDDMM (python/dgl/_sparse_ops.py:568-638): operands indexed by node type
+    for 'u' / 'v' targets and by edge type for 'e'; output indexed by edge type."""
+    lhs_tuple, rhs_tuple = lhs_and_rhs_tuple[:lhs_len], lhs_and_rhs_tuple[lhs_len:]
+    use_l, use_r = op != "copy_rhs", op != "copy_lhs"
+    outs = []
+    for et in range(gidx.number_of_etypes()):
+        s, d = gidx.metagraph.find_edge(et)
+        pick = lambda tup, tgt: tup[{"u": s, "v": d, "e": et}[tgt]]
+        l = pick(lhs_tuple, lhs_target) if use_l else None
+        r = pick(rhs_tuple, rhs_target) if use_r else None
+        if (use_l and l is None) or (use_r and r is None):
+            outs.append(None)
+            continue
+        outs.append(_gsddmm(gidx.get_relation_graph(et), op, l, r, lhs_target, rhs_target))
+    return tuple(outs)
