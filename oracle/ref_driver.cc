@@ -1,0 +1,341 @@
+// oracle/_ref driver — TEST INFRASTRUCTURE ONLY (never linked into or called by dgl_amd).
+//
+// Plain-pointer C entry points around the REFERENCE's own CPU g-SpMM / g-SDDMM code, which
+// oracle/Makefile compiles from the files where they lie under /root/reference:
+//     src/array/cpu/spmm.cc  (+ spmm.h, spmm_binary_ops.h)   SpMMCsr / SpMMCoo / Edge_softmax_*
+//     src/array/cpu/sddmm.cc (+ sddmm.h, ../selector.h)      SDDMMCsr / SDDMMCoo
+//     src/bcast.cc                                           CalcBcastOff
+// Nothing of the reference is copied into this repository.  The empty third_party/dmlc-core
+// submodule is replaced by the from-scratch headers in oracle/ref_shim/dmlc/.  libxsmm is
+// absent (empty submodule), so USE_LIBXSMM is undefined and the reference takes its naive
+// path (spmm.h:144-160) — the same arithmetic in plain CSR-position order.
+//
+// What this file adds of its own: (1) NDArray views over caller memory (an
+// NDArray::Container whose dl_tensor points at the caller's buffer; the public struct is
+// declared in include/dgl/runtime/ndarray.h:410-480), (2) the two out-of-line NDArray
+// members the kernels call, NumElements() / GetSize(), and NDArray::Empty (used by
+// aten::NullArray and the hetero accumulators) as a plain host allocation — their home,
+// src/runtime/ndarray.cc, drags in the device API and tensor adapter and is not compiled —
+// and (3) the
+// idtype x dtype switch that src/array/kernel.cc:20-44,224-248 performs with ATEN_* macros.
+#include <dgl/array.h>
+#include <dgl/bcast.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// Declarations of the reference templates (src/array/kernel_decl.h:23-87 declares the same;
+// the definitions and explicit instantiations live in the .cc files listed above).
+namespace dgl {
+namespace aten {
+template <int XPU, typename IdType, typename DType>
+void SpMMCsr(const std::string& op, const std::string& reduce, const BcastOff& bcast,
+             const CSRMatrix& csr, NDArray ufeat, NDArray efeat, NDArray out,
+             std::vector<NDArray> out_aux);
+template <int XPU, typename IdType, typename DType>
+void SpMMCoo(const std::string& op, const std::string& reduce, const BcastOff& bcast,
+             const COOMatrix& coo, NDArray ufeat, NDArray efeat, NDArray out,
+             std::vector<NDArray> out_aux);
+template <int XPU, typename IdType, typename DType>
+void SDDMMCsr(const std::string& op, const BcastOff& bcast, const CSRMatrix& csr, NDArray lhs,
+              NDArray rhs, NDArray out, int lhs_target, int rhs_target);
+template <int XPU, typename IdType, typename DType>
+void SDDMMCoo(const std::string& op, const BcastOff& bcast, const COOMatrix& coo, NDArray lhs,
+              NDArray rhs, NDArray out, int lhs_target, int rhs_target);
+template <int XPU, typename IdType, typename DType>
+void Edge_softmax_csr_forward(const std::string& op, const BcastOff& bcast,
+                              const CSRMatrix& csr, NDArray ufeat, NDArray efeat, NDArray out);
+template <int XPU, typename IdType, typename DType>
+void Edge_softmax_csr_backward(const std::string& op, const BcastOff& bcast,
+                               const CSRMatrix& csr, NDArray out, NDArray sds,
+                               NDArray back_out);
+}  // namespace aten
+
+namespace runtime {
+// src/runtime/ndarray.cc:119-128 (not compiled, see header comment).
+int64_t NDArray::NumElements() const {
+  if (data_->dl_tensor.ndim == 0) return 0;
+  int64_t n = 1;
+  for (int i = 0; i < data_->dl_tensor.ndim; ++i) n *= data_->dl_tensor.shape[i];
+  return n;
+}
+size_t NDArray::GetSize() const {
+  const DGLArray& t = data_->dl_tensor;
+  return static_cast<size_t>(NumElements()) * ((t.dtype.bits * t.dtype.lanes + 7) / 8);
+}
+}  // namespace runtime
+}  // namespace dgl
+
+namespace {
+using dgl::runtime::NDArray;
+
+struct View : NDArray::Container {
+  int64_t shape_store[8];
+  void* owned = nullptr;
+};
+void view_deleter(NDArray::Container* c) {
+  View* v = static_cast<View*>(c);
+  free(v->owned);
+  delete v;
+}
+}  // namespace
+
+namespace dgl {
+namespace runtime {
+// Host-only stand-in for src/runtime/ndarray.cc:206-225 (device API not compiled).
+NDArray NDArray::Empty(std::vector<int64_t> shape, DGLDataType dtype, DGLContext ctx) {
+  View* v = new View();
+  int64_t n = 1;
+  for (size_t i = 0; i < shape.size(); ++i) {
+    v->shape_store[i] = shape[i];
+    n *= shape[i];
+  }
+  const size_t bytes = static_cast<size_t>(n) * ((dtype.bits * dtype.lanes + 7) / 8);
+  v->owned = bytes ? aligned_alloc(64, (bytes + 63) / 64 * 64) : nullptr;
+  v->dl_tensor.data = v->owned;
+  v->dl_tensor.ctx = ctx;
+  v->dl_tensor.ndim = static_cast<int>(shape.size());
+  v->dl_tensor.dtype = dtype;
+  v->dl_tensor.shape = v->shape_store;
+  v->dl_tensor.strides = nullptr;
+  v->dl_tensor.byte_offset = 0;
+  v->deleter = view_deleter;
+  return NDArray(v);
+}
+}  // namespace runtime
+}  // namespace dgl
+
+namespace {
+
+// code: 0 = int, 2 = float, 4 = bfloat (c_runtime_api.h DGLDataTypeCode)
+NDArray make_view(void* data, int ndim, const int64_t* shape, uint8_t code, uint8_t bits) {
+  View* v = new View();
+  v->dl_tensor.data = data;
+  v->dl_tensor.ctx.device_type = kDGLCPU;
+  v->dl_tensor.ctx.device_id = 0;
+  v->dl_tensor.ndim = ndim;
+  v->dl_tensor.dtype.code = code;
+  v->dl_tensor.dtype.bits = bits;
+  v->dl_tensor.dtype.lanes = 1;
+  for (int i = 0; i < ndim; ++i) v->shape_store[i] = shape[i];
+  v->dl_tensor.shape = v->shape_store;
+  v->dl_tensor.strides = nullptr;
+  v->dl_tensor.byte_offset = 0;
+  v->deleter = view_deleter;
+  return NDArray(v);
+}
+
+// "absent operand" = empty int64 array, IsNullArray <=> shape[0] == 0
+// (include/dgl/aten/array_ops.h:28-37, python/dgl/ndarray.py:309-312)
+NDArray null_array() {
+  const int64_t z = 0;
+  return make_view(nullptr, 1, &z, 0, 64);
+}
+
+NDArray id_view(const void* p, int64_t n, int idbits) {
+  if (p == nullptr) return null_array();
+  return make_view(const_cast<void*>(p), 1, &n, 0, static_cast<uint8_t>(idbits));
+}
+
+struct Feat {
+  void* data;
+  int32_t ndim;
+  const int64_t* shape;
+};
+
+// dtype: 0 f32, 1 f64, 3 bf16 (codes of include/dgl_amd.h; fp16 has no CPU kernels in the
+// reference: ATEN_FLOAT_TYPE_SWITCH_16BITS on CPU offers bf16 only, aten/macro.h:137-166)
+NDArray feat_view(const Feat* f, int dtype) {
+  if (f == nullptr || f->data == nullptr) return null_array();
+  if (dtype == 0) return make_view(f->data, f->ndim, f->shape, 2, 32);
+  if (dtype == 1) return make_view(f->data, f->ndim, f->shape, 2, 64);
+  return make_view(f->data, f->ndim, f->shape, 4, 16);
+}
+
+thread_local std::string g_err;
+
+template <typename F>
+int guarded(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+#define REF_TYPE_SWITCH(idbits, dtype, IdType, DType, ...)          \
+  do {                                                              \
+    if ((idbits) == 32) {                                           \
+      typedef int32_t IdType;                                       \
+      REF_DTYPE_SWITCH(dtype, DType, __VA_ARGS__);                  \
+    } else {                                                        \
+      typedef int64_t IdType;                                       \
+      REF_DTYPE_SWITCH(dtype, DType, __VA_ARGS__);                  \
+    }                                                               \
+  } while (0)
+#define REF_DTYPE_SWITCH(dtype, DType, ...)   \
+  do {                                        \
+    if ((dtype) == 0) {                       \
+      typedef float DType;                    \
+      { __VA_ARGS__ }                         \
+    } else if ((dtype) == 1) {                \
+      typedef double DType;                   \
+      { __VA_ARGS__ }                         \
+    } else {                                  \
+      typedef BFloat16 DType;                 \
+      { __VA_ARGS__ }                         \
+    }                                         \
+  } while (0)
+
+dgl::aten::CSRMatrix make_csr(int64_t num_rows, int64_t num_cols, int64_t nnz, int idbits,
+                              const void* indptr, const void* indices, const void* eids) {
+  dgl::aten::CSRMatrix csr;
+  csr.num_rows = num_rows;
+  csr.num_cols = num_cols;
+  csr.indptr = id_view(indptr, num_rows + 1, idbits);
+  csr.indices = id_view(indices, nnz, idbits);
+  if (nnz == 0) csr.indices = make_view(nullptr, 1, &nnz, 0, static_cast<uint8_t>(idbits));
+  csr.data = id_view(eids, nnz, idbits);
+  return csr;
+}
+
+dgl::aten::COOMatrix make_coo(int64_t num_rows, int64_t num_cols, int64_t nnz, int idbits,
+                              const void* row, const void* col, const void* eids) {
+  dgl::aten::COOMatrix coo;
+  coo.num_rows = num_rows;
+  coo.num_cols = num_cols;
+  coo.row = make_view(const_cast<void*>(row), 1, &nnz, 0, static_cast<uint8_t>(idbits));
+  coo.col = make_view(const_cast<void*>(col), 1, &nnz, 0, static_cast<uint8_t>(idbits));
+  coo.data = id_view(eids, nnz, idbits);
+  return coo;
+}
+}  // namespace
+
+extern "C" {
+
+const char* ref_last_error() { return g_err.c_str(); }
+
+// BcastOff of (op, lhs, rhs) as the reference computes it; offsets may be NULL.
+// Returns use_bcast; fills lens[4] = {lhs_len, rhs_len, out_len, reduce_size}.
+int ref_calc_bcast_off(const char* op, const Feat* lhs, const Feat* rhs, int64_t* lens,
+                       int64_t* lhs_off, int64_t* rhs_off, int64_t off_cap) {
+  int use = -1;
+  guarded([&] {
+    dgl::BcastOff b = dgl::CalcBcastOff(op, feat_view(lhs, 0), feat_view(rhs, 0));
+    lens[0] = b.lhs_len;
+    lens[1] = b.rhs_len;
+    lens[2] = b.out_len;
+    lens[3] = b.reduce_size;
+    if (b.use_bcast && lhs_off && rhs_off) {
+      for (size_t i = 0; i < b.lhs_offset.size() && static_cast<int64_t>(i) < off_cap; ++i) {
+        lhs_off[i] = b.lhs_offset[i];
+        rhs_off[i] = b.rhs_offset[i];
+      }
+    }
+    use = b.use_bcast ? 1 : 0;
+  });
+  return use;
+}
+
+// aten::CSRSpMM semantics (src/array/kernel.cc:20-44 -> SpMMCsr<kDGLCPU>).  `out` must be
+// pre-zeroed by the caller exactly as python/dgl/_sparse_ops.py:227 does.
+int ref_spmm_csr(const char* op, const char* reduce, int idbits, int dtype, int64_t num_rows,
+                 int64_t num_cols, int64_t nnz, const void* indptr, const void* indices,
+                 const void* eids, const Feat* ufeat, const Feat* efeat, const Feat* out,
+                 void* arg_u, void* arg_e) {
+  return guarded([&] {
+    NDArray U = feat_view(ufeat, dtype), E = feat_view(efeat, dtype), O = feat_view(out, dtype);
+    const dgl::BcastOff bcast = dgl::CalcBcastOff(op, U, E);
+    const auto csr = make_csr(num_rows, num_cols, nnz, idbits, indptr, indices, eids);
+    Feat au{arg_u, out->ndim, out->shape}, ae{arg_e, out->ndim, out->shape};
+    std::vector<NDArray> aux = {
+        arg_u ? make_view(arg_u, out->ndim, out->shape, 0, static_cast<uint8_t>(idbits)) : null_array(),
+        arg_e ? make_view(arg_e, out->ndim, out->shape, 0, static_cast<uint8_t>(idbits)) : null_array()};
+    (void)au;
+    (void)ae;
+    REF_TYPE_SWITCH(idbits, dtype, IdType, DType, {
+      dgl::aten::SpMMCsr<kDGLCPU, IdType, DType>(op, reduce, bcast, csr, U, E, O, aux);
+    });
+  });
+}
+
+int ref_spmm_coo(const char* op, const char* reduce, int idbits, int dtype, int64_t num_src,
+                 int64_t num_dst, int64_t nnz, const void* row, const void* col,
+                 const void* eids, const Feat* ufeat, const Feat* efeat, const Feat* out,
+                 void* arg_u, void* arg_e) {
+  return guarded([&] {
+    NDArray U = feat_view(ufeat, dtype), E = feat_view(efeat, dtype), O = feat_view(out, dtype);
+    const dgl::BcastOff bcast = dgl::CalcBcastOff(op, U, E);
+    const auto coo = make_coo(num_src, num_dst, nnz, idbits, row, col, eids);
+    std::vector<NDArray> aux = {
+        arg_u ? make_view(arg_u, out->ndim, out->shape, 0, static_cast<uint8_t>(idbits)) : null_array(),
+        arg_e ? make_view(arg_e, out->ndim, out->shape, 0, static_cast<uint8_t>(idbits)) : null_array()};
+    REF_TYPE_SWITCH(idbits, dtype, IdType, DType, {
+      dgl::aten::SpMMCoo<kDGLCPU, IdType, DType>(op, reduce, bcast, coo, U, E, O, aux);
+    });
+  });
+}
+
+// aten::CSRSDDMM / COOSDDMM semantics (src/array/kernel.cc:224-248).
+int ref_sddmm_csr(const char* op, int idbits, int dtype, int64_t num_rows, int64_t num_cols,
+                  int64_t nnz, const void* indptr, const void* indices, const void* eids,
+                  const Feat* lhs, const Feat* rhs, const Feat* out, int lhs_target,
+                  int rhs_target) {
+  return guarded([&] {
+    NDArray L = feat_view(lhs, dtype), R = feat_view(rhs, dtype), O = feat_view(out, dtype);
+    const dgl::BcastOff bcast = dgl::CalcBcastOff(op, L, R);
+    const auto csr = make_csr(num_rows, num_cols, nnz, idbits, indptr, indices, eids);
+    REF_TYPE_SWITCH(idbits, dtype, IdType, DType, {
+      dgl::aten::SDDMMCsr<kDGLCPU, IdType, DType>(op, bcast, csr, L, R, O, lhs_target, rhs_target);
+    });
+  });
+}
+
+int ref_sddmm_coo(const char* op, int idbits, int dtype, int64_t num_src, int64_t num_dst,
+                  int64_t nnz, const void* row, const void* col, const void* eids,
+                  const Feat* lhs, const Feat* rhs, const Feat* out, int lhs_target,
+                  int rhs_target) {
+  return guarded([&] {
+    NDArray L = feat_view(lhs, dtype), R = feat_view(rhs, dtype), O = feat_view(out, dtype);
+    const dgl::BcastOff bcast = dgl::CalcBcastOff(op, L, R);
+    const auto coo = make_coo(num_src, num_dst, nnz, idbits, row, col, eids);
+    REF_TYPE_SWITCH(idbits, dtype, IdType, DType, {
+      dgl::aten::SDDMMCoo<kDGLCPU, IdType, DType>(op, bcast, coo, L, R, O, lhs_target, rhs_target);
+    });
+  });
+}
+
+// _CAPI_DGLKernelEdge_softmax_forward / _backward (src/array/kernel.cc:312-346,542-561):
+// op is always "copy_rhs"; ufeat is the null array.
+int ref_edge_softmax_forward(int idbits, int dtype, int64_t num_rows, int64_t num_cols,
+                             int64_t nnz, const void* indptr, const void* indices,
+                             const void* eids, const Feat* score, const Feat* out) {
+  return guarded([&] {
+    NDArray U = null_array(), E = feat_view(score, dtype), O = feat_view(out, dtype);
+    const dgl::BcastOff bcast = dgl::CalcBcastOff("copy_rhs", U, E);
+    const auto csr = make_csr(num_rows, num_cols, nnz, idbits, indptr, indices, eids);
+    REF_TYPE_SWITCH(idbits, dtype, IdType, DType, {
+      dgl::aten::Edge_softmax_csr_forward<kDGLCPU, IdType, DType>("copy_rhs", bcast, csr, U, E, O);
+    });
+  });
+}
+
+int ref_edge_softmax_backward(int idbits, int dtype, int64_t num_rows, int64_t num_cols,
+                              int64_t nnz, const void* indptr, const void* indices,
+                              const void* eids, const Feat* out, const Feat* sds,
+                              const Feat* back) {
+  return guarded([&] {
+    NDArray O = feat_view(out, dtype), S = feat_view(sds, dtype), B = feat_view(back, dtype);
+    const dgl::BcastOff bcast = dgl::CalcBcastOff("copy_rhs", O, S);
+    const auto csr = make_csr(num_rows, num_cols, nnz, idbits, indptr, indices, eids);
+    REF_TYPE_SWITCH(idbits, dtype, IdType, DType, {
+      dgl::aten::Edge_softmax_csr_backward<kDGLCPU, IdType, DType>("copy_rhs", bcast, csr, O, S, B);
+    });
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+"""Golden fixtures: outputs of the reference's own CPU kernels (tests/golden/make_golden.py),
+committed so they travel to machines without /root/reference.
+
+ * CPU (`-m "not gpu"`): the oracle restatement reproduces every fixture bit for bit, and the
+   regenerated inputs equal the stored ones (the generator is deterministic).
+ * GPU (`-m gpu`): the HIP kernels, called through the C ABI, against the same fixtures —
+   arg_u / arg_e and max/min values bit-exact, element-wise SDDMM bit-exact, fp32 sums / dots /
+   softmax within 1e-5 relative (north-star tolerance), fp64 within 1e-12.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.golden_cases import all_cases, run_case
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                      "reference_cpu_outputs.npz")
+CASES = all_cases(full=False)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN)
+
+
+def _outputs(golden, name):
+    pre = name + "/out/"
+    return {k[len(pre):]: golden[k] for k in golden.files if k.startswith(pre)}
+
+
+def test_fixture_inputs_are_reproducible(golden):
+    for c in CASES:
+        for k, v in c.items():
+            if isinstance(v, np.ndarray):
+                np.testing.assert_array_equal(v, golden["%s/in/%s" % (c["name"], k)], err_msg=c["name"])
+
+
+@pytest.mark.parametrize("c", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_reproduces_reference_outputs(golden, c):
+    want = _outputs(golden, c["name"])
+    got = run_case(oracle, c)
+    assert set(k for k, v in got.items() if v is not None) == set(want)
+    for k, v in want.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape
+        np.testing.assert_array_equal(got[k], v, err_msg="%s/%s" % (c["name"], k))
+
+
+# ------------------------------------------------------------------------------------------
+def _gpu_run(dev, c):
+    import torch
+
+    from dgl_amd import _capi
+
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    k = c["kind"]
+    if k == "spmm_csr":
+        ip, ix, ei = t(c["indptr"]), t(c["indices"]), t(c["eids"])
+        csr = _capi.make_csr(ip, ix, ei, c["n_src"])
+        u, e = t(c["ufeat"]), t(c["efeat"])
+        shape = (c["n_dst"],) + oracle.infer_broadcast_shape(
+            c["op"], (u if u is not None else e).shape[1:], (e if e is not None else u).shape[1:])
+        fdt = (u if u is not None else e).dtype
+        out = torch.full(shape, 3.0, dtype=fdt, device=dev)
+        au = ae = None
+        if c["reduce"] != "sum":
+            au = torch.full(shape, -9, dtype=ip.dtype, device=dev)
+            ae = torch.full(shape, -9, dtype=ip.dtype, device=dev)
+        ws = torch.empty(max(1, _capi.spmm_csr_workspace_bytes(c["op"], c["reduce"], csr, fdt, u, e, out)),
+                         dtype=torch.uint8, device=dev)
+        _capi.spmm_csr(c["op"], c["reduce"], csr, u, e, out, au, ae, ws)
+        res = {"out": out}
+        if au is not None and c["op"] != "copy_rhs":
+            res["arg_u"] = au
+        if ae is not None and c["op"] != "copy_lhs":
+            res["arg_e"] = ae
+        return {k2: v.cpu().numpy() for k2, v in res.items()}
+    if k == "spmm_coo":
+        row, col, ei = t(c["row"]), t(c["col"]), t(c["eids"])
+        coo = _capi.make_coo(row, col, ei, c["n_src"], c["n_dst"])
+        u, e = t(c["ufeat"]), t(c["efeat"])
+        shape = (c["n_dst"],) + oracle.infer_broadcast_shape(
+            c["op"], (u if u is not None else e).shape[1:], (e if e is not None else u).shape[1:])
+        fdt = (u if u is not None else e).dtype
+        out = torch.full(shape, 3.0, dtype=fdt, device=dev)
+        au = ae = None
+        if c["reduce"] != "sum":
+            au = torch.full(shape, -9, dtype=row.dtype, device=dev)
+            ae = torch.full(shape, -9, dtype=row.dtype, device=dev)
+        _capi.spmm_coo(c["op"], c["reduce"], coo, u, e, out, au, ae)
+        res = {"out": out}
+        if au is not None and c["op"] != "copy_rhs":
+            res["arg_u"] = au
+        if ae is not None and c["op"] != "copy_lhs":
+            res["arg_e"] = ae
+        return {k2: v.cpu().numpy() for k2, v in res.items()}
+    if k in ("sddmm_coo", "sddmm_csr"):
+        lhs, rhs = t(c["lhs"]), t(c["rhs"])
+        a = lhs if lhs is not None else rhs
+        b = rhs if rhs is not None else lhs
+        if k == "sddmm_coo":
+            g = _capi.make_coo(t(c["row"]), t(c["col"]), t(c["eids"]), c["n_src"], c["n_dst"])
+            nnz = len(c["row"])
+        else:
+            keep = (t(c["indptr"]), t(c["indices"]), t(c["eids"]))
+            g = _capi.make_csr(keep[0], keep[1], keep[2], c["n_dst"])
+            nnz = len(c["indices"])
+        shape = (nnz,) + oracle.infer_broadcast_shape(c["op"], a.shape[1:], b.shape[1:])
+        out = torch.full(shape, 3.0, dtype=a.dtype, device=dev)
+        fn = _capi.sddmm_coo if k == "sddmm_coo" else _capi.sddmm_csr
+        fn(c["op"], g, lhs, rhs, out, _capi.TARGETS[c["lhs_target"]], _capi.TARGETS[c["rhs_target"]])
+        return {"out": out.cpu().numpy()}
+    if k == "edge_softmax":
+        keep = (t(c["indptr"]), t(c["indices"]), t(c["eids"]))
+        csr = _capi.make_csr(keep[0], keep[1], keep[2], int(c["indices"].max()) + 1)
+        score = t(c["score"])
+        out = torch.empty_like(score)
+        _capi.edge_softmax_forward(csr, score, out)
+        sds = out * t(c["grad"])
+        back = torch.empty_like(score)
+        _capi.edge_softmax_backward(csr, out, sds, back)
+        return {"out": out.cpu().numpy(), "back": back.cpu().numpy()}
+    raise ValueError(k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", CASES, ids=[c["name"] for c in CASES])
+def test_gpu_matches_reference_outputs(dev, golden, c):
+    want = _outputs(golden, c["name"])
+    got = _gpu_run(dev, c)
+    assert set(got) == set(want), (set(got), set(want))
+    exact_values = (c["kind"].startswith("spmm") and c["reduce"] != "sum") or \
+        (c["kind"].startswith("sddmm") and c["op"] != "dot")
+    for k, v in want.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape, k
+        if k in ("arg_u", "arg_e") or exact_values:
+            np.testing.assert_array_equal(got[k], v, err_msg="%s/%s" % (c["name"], k))
+        else:
+            tol = 1e-5 if v.dtype == np.float32 else 1e-12
+            extra = 0.0
+            if c["kind"].startswith("spmm") and v.dtype == np.float32:
+                # the reference's own sequential fp32 sum carries up to deg * 2^-24 of rounding
+                deg = np.diff(c["indptr"]).max() if "indptr" in c else np.bincount(c["col"]).max()
+                extra = 2 * deg * 2.0 ** -24
+            np.testing.assert_allclose(got[k], v, rtol=tol + extra, atol=1e-6 if v.dtype == np.float32 else 1e-12,
+                                       err_msg="%s/%s" % (c["name"], k))
