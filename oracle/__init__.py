@@ -7,10 +7,12 @@ The arithmetic lives in ``oracle.c`` / ``kernels_impl.inc`` (plain C + OpenMP re
 ``src/array/cpu/{spmm.h,spmm.cc,sddmm.h,spmm_binary_ops.h}`` of the reference); this
 module is the numpy front end plus the broadcast bookkeeping of ``src/bcast.cc``.
 
-Parity status: the reference cannot be built or imported here and stores no golden
-vectors, so the oracle is pinned by the reference's closed-form test cases and by
-independent implementations (scipy / torch scatter / dense) — see oracle.c header and
-``tests/test_oracle_known_answers.py``.
+Parity status: PINNED to the reference build.  ``oracle.ref`` wraps
+``oracle/_ref/libdglref.so`` — the reference's own CPU kernels compiled from
+/root/reference by ``oracle/Makefile`` — and ``tests/test_oracle_vs_reference.py`` demands
+bit equality with this restatement over an exhaustive sweep; the reference build's outputs
+are committed as ``tests/golden/reference_cpu_outputs.npz``.  See the oracle.c header for
+what remains unpinned (libxsmm / cuSPARSE summation order).
 """
 import ctypes
 import os

@@ -126,7 +126,9 @@ def calc_bcast_off(op, lhs_shape, rhs_shape):
             "rhs_offset": ro[:n].copy() if use else None}
 
 
-def spmm_csr(op, reduce, indptr, indices, eids, ufeat, efeat, num_cols=None, bf16=False):
+def spmm_csr(op, reduce, indptr, indices, eids, ufeat, efeat, num_cols=None, bf16=False, out=None):
+    """`out` (optional): a pre-ZEROED array to write into, so a timing loop measures the
+    kernel alone (the reference's Python caller allocates it, _sparse_ops.py:227)."""
     indptr = np.ascontiguousarray(indptr)
     idt = indptr.dtype
     indices = np.ascontiguousarray(indices, dtype=idt)
@@ -138,7 +140,9 @@ def spmm_csr(op, reduce, indptr, indices, eids, ufeat, efeat, num_cols=None, bf1
     n_rows = indptr.shape[0] - 1
     if num_cols is None:
         num_cols = u.shape[0] if use_l and u is not None else (int(indices.max()) + 1 if indices.size else 0)
-    out = np.zeros((n_rows,) + fshape, dtype=fdt)
+    if out is None:
+        out = np.zeros((n_rows,) + fshape, dtype=fdt)
+    assert out.shape == (n_rows,) + fshape and out.dtype == fdt and out.flags.c_contiguous
     argu = arge = None
     if reduce != "sum":
         argu = np.zeros(out.shape, dtype=idt)
