@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""Per-kernel microbenchmarks of the hot path beyond the headline (bench.py): every kernel
+family at the BASELINE.json config shapes, each with its algorithmic bytes and the achieved
+fraction of the HBM peak.  Runs on one MI355X:  python benchmarks/bench_ops.py [--only C3]
+
+Prints one JSON line per (config, op).  Algorithmic-byte models:
+  SpMM   E*(F_l*s [+ W_row*s] + i [+ i if eid map]) + (N+1)*i + N*F_out*s
+  SDDMM  E*(lhs_row + rhs_row + out_row)*s + 2*E*i            (COO: row + col)
+  edge_softmax fwd  E*H*s read + E*H*s written + (N+1)*i (+ E*i eid map)
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from dgl_amd import _capi  # noqa: E402
+from tests.graphgen import C2_EDGES, C2_FEAT, C2_NODES, synth_csr  # noqa: E402
+
+PEAK = 8000.0
+
+
+def timeit(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for k in range(reps):
+        fn()
+        ev[k + 1].record()
+    torch.cuda.synchronize()
+    ts = [ev[k].elapsed_time(ev[k + 1]) for k in range(reps)]
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def emit(cfg, op, e, ms, ms_min, nbytes, **kw):
+    r = {"config": cfg, "op": op, "edges": e, "ms_median": round(ms, 4), "ms_min": round(ms_min, 4),
+         "edges_per_s": e / (ms * 1e-3), "alg_bytes": nbytes,
+         "achieved_GBps": nbytes / (ms * 1e-3) / 1e9, "frac_of_8TBps": nbytes / (ms * 1e-3) / 1e9 / PEAK}
+    r.update(kw)
+    print(json.dumps(r), flush=True)
+
+
+def spmm_bytes(n_rows, e, f_l, f_out, s, i, w_row=0, eid=False):
+    return e * (f_l * s + w_row * s + i + (i if eid else 0)) + (n_rows + 1) * i + n_rows * f_out * s
+
+
+def run_spmm(cfg, name, g, op, red, u, w, fo, dev, eid=False):
+    n = g["num_rows"]
+    csr = _capi.make_csr(g["indptr"], g["indices"], g["eids"] if eid else None, g["num_cols"])
+    out = torch.empty((n,) + tuple(fo), device=dev, dtype=(u if u is not None else w).dtype)
+    idt = g["indptr"].dtype
+    au = torch.empty(out.shape, dtype=idt, device=dev) if red != "sum" else None
+    ae = torch.empty(out.shape, dtype=idt, device=dev) if red != "sum" else None
+    ws = torch.empty(max(1, _capi.spmm_csr_workspace_bytes(op, red, csr, out.dtype, u, w, out)),
+                     dtype=torch.uint8, device=dev)
+    _capi.spmm_csr(op, red, csr, u, w, out, au, ae, ws)
+    ms, mn = timeit(lambda: _capi.spmm_csr(op, red, csr, u, w, out, au, ae, ws, plan_valid=True))
+    s = out.element_size()
+    i = g["indptr"].element_size()
+    f_l = 0 if u is None else int(np.prod(u.shape[1:]))
+    w_row = 0 if w is None else int(np.prod(w.shape[1:]))
+    f_out = int(np.prod(fo))
+    nb = spmm_bytes(n, g["nnz"], f_l, f_out, s, i, w_row, eid and w is not None)
+    if red != "sum":
+        nb += n * f_out * i * ((u is not None) + (w is not None))
+    emit(cfg, name, g["nnz"], ms, mn, nb, dtype=str(out.dtype), idtype=str(idt))
+    return out
+
+
+def coo_of(g, dev):
+    deg = (g["indptr"][1:] - g["indptr"][:-1]).long()
+    dst = torch.repeat_interleave(torch.arange(g["num_rows"], device=dev), deg).to(g["indices"].dtype)
+    return g["indices"], dst  # row = src, col = dst
+
+
+def c2(dev, args):
+    n, e, f = C2_NODES // args.scale, C2_EDGES // args.scale, C2_FEAT
+    g = synth_csr(n, n, e, "U", device=dev, with_eids=True)
+    torch.manual_seed(1)
+    x = torch.rand(n, f, device=dev) + 1
+    w1 = torch.rand(e, 1, device=dev) + 1
+    run_spmm("C2", "copy_u_sum", g, "copy_lhs", "sum", x, None, (f,), dev)
+    run_spmm("C2", "copy_u_max(+arg_u)", g, "copy_lhs", "max", x, None, (f,), dev)
+    run_spmm("C2", "u_mul_e_sum(scalar e, eid map)", g, "mul", "sum", x, w1, (f,), dev, eid=True)
+    run_spmm("C2", "u_mul_e_sum(scalar e, no map)", g, "mul", "sum", x, w1, (f,), dev, eid=False)
+    xh = x.to(torch.bfloat16)
+    # F=100 bf16 rows are 200 B: 8-byte aligned only -> exercises the narrow access path
+    run_spmm("C2", "copy_u_sum bf16", g, "copy_lhs", "sum", xh, None, (f,), dev)
+    del x, xh, w1
+    # gather rate vs working-set size of X (same E, fewer distinct columns): where does the
+    # Infinity Cache (256 MB) / L2 (8 x 4 MB) start to serve the gathers?
+    for ncols in (n // 4, n // 16, n // 64, n // 256):
+        gg = synth_csr(n, max(ncols, 64), e, "U", device=dev)
+        xx = torch.rand(max(ncols, 64), f, device=dev) + 1
+        run_spmm("C2", "copy_u_sum, X=%d rows (%.0f MB)" % (xx.shape[0], xx.numel() * 4 / 1e6),
+                 gg, "copy_lhs", "sum", xx, None, (f,), dev)
+        del gg, xx
+
+
+def c3(dev, args):
+    # ogbn-arxiv-shaped + reverse edges + self loops ~ 2.5 M edges, 8 heads
+    n, e, h = 169_343, 2_501_829, 8
+    g = synth_csr(n, n, e, "U", device=dev, with_eids=True)
+    row, col = coo_of(g, dev)
+    coo = _capi.make_coo(row, col, g["eids"], n, n)
+    s, i = 4, 4
+    torch.manual_seed(2)
+    for d in (8, 32, 64):
+        el = torch.rand(n, h, 1, device=dev)
+        er = torch.rand(n, h, 1, device=dev)
+        ft = torch.rand(n, h, d, device=dev)
+        out = torch.empty(e, h, 1, device=dev)
+        if d == 8:
+            ms, mn = timeit(lambda: _capi.sddmm_coo("add", coo, el, er, out, 0, 2))
+            emit("C3", "sddmm u_add_v (H=8)", e, ms, mn, e * (3 * h * s + 3 * i))
+        ms, mn = timeit(lambda: _capi.sddmm_coo("dot", coo, ft, ft, out, 0, 2))
+        emit("C3", "sddmm u_dot_v (H=8,D=%d)" % d, e, ms, mn, e * (2 * h * d * s + h * s + 3 * i))
+        if d == 8:
+            csr = _capi.make_csr(g["indptr"], g["indices"], g["eids"], n)
+            a = torch.empty_like(out)
+            ms, mn = timeit(lambda: _capi.edge_softmax_forward(csr, out, a))
+            emit("C3", "edge_softmax fwd (H=8)", e, ms, mn, e * (2 * h * s + i) + (n + 1) * i)
+            sds = a * out
+            back = torch.empty_like(out)
+            ms, mn = timeit(lambda: _capi.edge_softmax_backward(csr, a, sds, back))
+            emit("C3", "edge_softmax bwd (H=8)", e, ms, mn, e * (3 * h * s + i) + (n + 1) * i)
+        a = torch.rand(e, h, 1, device=dev)
+        run_spmm("C3", "u_mul_e_sum (H=8,D=%d)x(H,1)" % d, g, "mul", "sum", ft, a, (h, d), dev, eid=True)
+
+
+def c5(dev, args):
+    # R-GCN: 8 relations x 12.5 M edges on 10 M nodes, F=256, bf16; per-relation SpMM accumulating
+    n, e, f, r = 10_000_000 // args.scale, 12_500_000 // args.scale, 256, 8
+    torch.manual_seed(3)
+    x = (torch.rand(n, f, device=dev) + 1).to(torch.bfloat16)
+    out = torch.zeros(n, f, device=dev, dtype=torch.bfloat16)
+    rel = []
+    for k in range(r):
+        g = synth_csr(n, n, e, "U", seed=100 + k, device=dev)
+        csr = _capi.make_csr(g["indptr"], g["indices"], None, n)
+        ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, x.dtype, x, None, out),
+                         dtype=torch.uint8, device=dev)
+        _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, accumulate=True)
+        rel.append((g, csr, ws))
+
+    def step():
+        out.zero_()
+        for g, csr, ws in rel:
+            _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, accumulate=True,
+                           plan_valid=True)
+
+    ms, mn = timeit(step, reps=5, warm=2)
+    s, i = 2, 4
+    nb = r * (e * (f * s + i) + (n + 1) * i + 2 * n * f * s) + n * f * s
+    emit("C5", "hetero copy_u_sum, 8 relations accumulate, bf16 F=256", r * e, ms, mn, nb)
+    g, csr, ws = rel[0]
+    o1 = torch.empty_like(out)
+    ms, mn = timeit(lambda: _capi.spmm_csr("copy_lhs", "sum", csr, x, None, o1, None, None, ws, plan_valid=True), reps=5)
+    emit("C5", "one relation copy_u_sum bf16 F=256 (write)", e, ms, mn, e * (f * s + i) + (n + 1) * i + n * f * s)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--scale", type=int, default=1)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5)):
+        if args.only and name not in args.only.split(","):
+            continue
+        fn(dev, args)
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

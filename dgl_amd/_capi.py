@@ -131,6 +131,13 @@ def stream_copy(dst, src):
                                     src.numel() * src.element_size(), _stream(dst)))
 
 
+def stream_copy_variant(dst, src, variant):
+    _require_gpu(dst)
+    check_call(LIB.dgla_stream_copy_variant(dst.data_ptr(), src.data_ptr(),
+                                            src.numel() * src.element_size(), int(variant),
+                                            _stream(dst)))
+
+
 def set_profile_events(before, after):
     """Record two torch.cuda.Event objects around the merge kernel of the next spmm_csr calls
     of this thread (None, None disables).  The events must have been recorded once already so

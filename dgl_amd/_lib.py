@@ -78,6 +78,8 @@ LIB.dgla_spmm_set_profile_events.restype = c_int
 LIB.dgla_spmm_set_profile_events.argtypes = [c_void_p, c_void_p]
 LIB.dgla_stream_copy.restype = c_int
 LIB.dgla_stream_copy.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
+LIB.dgla_stream_copy_variant.restype = c_int
+LIB.dgla_stream_copy_variant.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_void_p]
 
 DGLA_ACCUMULATE = 1
 DGLA_PLAN_VALID = 2

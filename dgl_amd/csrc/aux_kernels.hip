@@ -8,35 +8,69 @@ namespace dgla {
 // peak the roofline fraction is quoted against (MI355X_MICROARCH.md: 6.29 TB/s float4 copy).
 // ---------------------------------------------------------------------------------------
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+// MODE 0: copy with non-temporal loads and stores; 1: copy with default cache policy;
+// 2: read only (xor-reduce, one 16-byte store per lane at the end) — the read-side peak, which
+// is what a gather-dominated kernel (97 % reads) is really up against.
+template <int U, int MODE>
 __global__ __launch_bounds__(256) void stream_copy_kernel(const u32x4* __restrict__ src,
                                                           u32x4* __restrict__ dst, size_t n) {
-  // 4 independent 16-byte loads per lane in flight, then 4 stores; blocks walk the array
-  // in 16 KiB tiles.
-  constexpr int U = 4;
+  // U independent 16-byte loads per lane in flight, then U stores; blocks walk the array in
+  // 256 * U * 16-byte tiles, grid-strided.
   const size_t tile = static_cast<size_t>(blockDim.x) * U;
   const size_t stride = static_cast<size_t>(gridDim.x) * tile;
+  u32x4 acc = {0u, 0u, 0u, 0u};
   for (size_t base = blockIdx.x * tile + threadIdx.x; base < n; base += stride) {
     u32x4 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t i = base + static_cast<size_t>(u) * blockDim.x;
-      if (i < n) v[u] = __builtin_nontemporal_load(src + i);
+      if (i < n) {
+        if constexpr (MODE == 1)
+          v[u] = src[i];
+        else
+          v[u] = __builtin_nontemporal_load(src + i);
+      } else {
+        v[u] = acc;
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t i = base + static_cast<size_t>(u) * blockDim.x;
-      if (i < n) __builtin_nontemporal_store(v[u], dst + i);
+      if constexpr (MODE == 2) {
+        acc ^= v[u];
+      } else if (i < n) {
+        if constexpr (MODE == 1)
+          dst[i] = v[u];
+        else
+          __builtin_nontemporal_store(v[u], dst + i);
+      }
     }
   }
+  if constexpr (MODE == 2) dst[blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x] = acc;
 }
 
-int launch_stream_copy(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+// variant = MODE + 4 * (blocks-per-CU selector) + 16 * (unroll selector); 0 is the default
+// used for the roofline denominator, the others exist for benchmarks/bench_peak.py.
+int launch_stream_copy(void* dst, const void* src, size_t bytes, int variant, hipStream_t stream) {
   const size_t n = bytes / 16;
   if (n == 0) return 0;
-  size_t blocks = (n + 1023) / 1024;
-  if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL(stream_copy_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                     stream, static_cast<const u32x4*>(src), static_cast<u32x4*>(dst), n);
+  const int mode = variant & 3;
+  const int bpc = 1 << (((variant >> 2) & 3) + 2);  // 4, 8, 16, 32 blocks per CU
+  const int usel = (variant >> 4) & 1;               // 0: U = 4, 1: U = 8
+  const size_t tile = 256 * static_cast<size_t>(usel ? 8 : 4);
+  size_t blocks = (n + tile - 1) / tile;
+  if (blocks > static_cast<size_t>(256 * bpc)) blocks = 256 * bpc;
+  const dim3 g(static_cast<unsigned>(blocks)), b(256);
+  const u32x4* s = static_cast<const u32x4*>(src);
+  u32x4* d = static_cast<u32x4*>(dst);
+#define DGLA_COPY(UU, MM) hipLaunchKernelGGL((stream_copy_kernel<UU, MM>), g, b, 0, stream, s, d, n)
+  if (usel) {
+    if (mode == 0) DGLA_COPY(8, 0); else if (mode == 1) DGLA_COPY(8, 1); else DGLA_COPY(8, 2);
+  } else {
+    if (mode == 0) DGLA_COPY(4, 0); else if (mode == 1) DGLA_COPY(4, 1); else DGLA_COPY(4, 2);
+  }
+#undef DGLA_COPY
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
 }

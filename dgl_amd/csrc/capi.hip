@@ -34,7 +34,7 @@ int launch_sddmm_f32(const SddmmLaunch&);
 int launch_sddmm_f64(const SddmmLaunch&);
 int launch_sddmm_f16(const SddmmLaunch&);
 int launch_sddmm_bf16(const SddmmLaunch&);
-int launch_stream_copy(void*, const void*, size_t, hipStream_t);
+int launch_stream_copy(void*, const void*, size_t, int, hipStream_t);
 int launch_spmm_coo(const CooView&, int, int, int, const void*, const void*, void*, void*, void*,
                     int64_t, int64_t, int64_t, bool, const BcastDims&, hipStream_t);
 int launch_edge_softmax(const CsrView&, int, const void*, const void*, void*, int64_t, bool,
@@ -454,7 +454,12 @@ int dgla_spmm_set_profile_events(void* before, void* after) {
 }
 
 int dgla_stream_copy(void* dst, const void* src, size_t bytes, void* hip_stream) {
-  return launch_stream_copy(dst, src, bytes, static_cast<hipStream_t>(hip_stream));
+  return launch_stream_copy(dst, src, bytes, 1 << 2, static_cast<hipStream_t>(hip_stream));
+}
+
+int dgla_stream_copy_variant(void* dst, const void* src, size_t bytes, int variant,
+                             void* hip_stream) {
+  return launch_stream_copy(dst, src, bytes, variant, static_cast<hipStream_t>(hip_stream));
 }
 
 }  // extern "C"

@@ -142,6 +142,12 @@ int dgla_spmm_set_profile_events(void* before, void* after);
 /* Measured-peak helper used by bench.py: streams `bytes` from src to dst with 16-byte
  * lane accesses (the "float4 copy" the HBM roofline is quoted against). */
 int dgla_stream_copy(void* dst, const void* src, size_t bytes, void* hip_stream);
+/* Same with an explicit kernel variant (benchmarks/bench_peak.py): bits 0-1 = 0 copy with
+ * non-temporal accesses, 1 copy with default cache policy, 2 read-only (dst receives one
+ * 16-byte value per lane of the grid: needs >= 32 MiB); bits 2-3 = log2(blocks per CU) - 2;
+ * bit 4 = 8 instead of 4 loads in flight per lane. */
+int dgla_stream_copy_variant(void* dst, const void* src, size_t bytes, int variant,
+                             void* hip_stream);
 
 /* ======================================================================================
  * (2) Registry layer — same names and layouts as include/dgl/runtime/c_runtime_api.h.

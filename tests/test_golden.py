@@ -100,7 +100,8 @@ def _gpu_run(dev, c):
         a = lhs if lhs is not None else rhs
         b = rhs if rhs is not None else lhs
         if k == "sddmm_coo":
-            g = _capi.make_coo(t(c["row"]), t(c["col"]), t(c["eids"]), c["n_src"], c["n_dst"])
+            keep = (t(c["row"]), t(c["col"]), t(c["eids"]))  # the struct only borrows pointers
+            g = _capi.make_coo(keep[0], keep[1], keep[2], c["n_src"], c["n_dst"])
             nnz = len(c["row"])
         else:
             keep = (t(c["indptr"]), t(c["indices"]), t(c["eids"]))
