@@ -93,10 +93,22 @@ def c2(dev, args):
     xh = x.to(torch.bfloat16)
     # F=100 bf16 rows are 200 B: 8-byte aligned only -> exercises the narrow access path
     run_spmm("C2", "copy_u_sum bf16", g, "copy_lhs", "sum", xh, None, (f,), dev)
-    del x, xh, w1
+    # SDDMM at products scale: u_dot_v over F=100 (D=100: 25 of 32 lanes per edge), u_add_v
+    row, col = coo_of(g, dev)
+    coo = _capi.make_coo(row, col, None, n, n)
+    oe = torch.empty(e, 1, device=dev)
+    ms, mn = timeit(lambda: _capi.sddmm_coo("dot", coo, x, x, oe, 0, 2), reps=5)
+    emit("C2", "sddmm u_dot_v (D=100)", e, ms, mn, e * (2 * f * 4 + 4 + 8))
+    del oe
+    if args.big:
+        of = torch.empty(e, f, device=dev)
+        ms, mn = timeit(lambda: _capi.sddmm_coo("add", coo, x, x, of, 0, 2), reps=3)
+        emit("C2", "sddmm u_add_v (F=100)", e, ms, mn, e * (3 * f * 4 + 8))
+        del of
+    del x, xh, w1, row, col
     # gather rate vs working-set size of X (same E, fewer distinct columns): where does the
     # Infinity Cache (256 MB) / L2 (8 x 4 MB) start to serve the gathers?
-    for ncols in (n // 4, n // 16, n // 64, n // 256):
+    for ncols in (() if args.no_sweep else (n // 4, n // 16, n // 64, n // 256)):
         gg = synth_csr(n, max(ncols, 64), e, "U", device=dev)
         xx = torch.rand(max(ncols, 64), f, device=dev) + 1
         run_spmm("C2", "copy_u_sum, X=%d rows (%.0f MB)" % (xx.shape[0], xx.numel() * 4 / 1e6),
@@ -170,6 +182,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--scale", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="also ops whose output is E x F (25 GB)")
+    ap.add_argument("--no-sweep", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for name, fn in (("C2", c2), ("C3", c3), ("C5", c5)):

@@ -1,4 +1,4 @@
-// Auxiliary gfx950 kernels: COO g-SpMM (atomics), fused edge softmax, streaming copy.
+// Auxiliary gfx950 kernels: COO g-SpMM (atomics), streaming copy.
 #include "common.h"
 
 namespace dgla {
@@ -303,111 +303,6 @@ int launch_spmm_coo(const CooView& coo, int op, int red, int dtype, const void* 
                             : spmm_coo_op<int64_t, double>(p, op, red, stream);
   // the reference refuses half types on this path as well (spmm.cuh:633-641)
   last_error() = "SpMM on COO does not support fp16/bf16 features; use the CSR format";
-  return -1;
-}
-
-// ---------------------------------------------------------------------------------------
-// Fused edge softmax on the in-edge CSR (rows = destination nodes).
-// One lane group of LPE >= dim lanes per row; three sweeps over the row's edges
-// (max, exp + sum, normalise).  Same arithmetic as Edge_softmax_csr_forward /
-// _backward (src/array/cpu/spmm.h:484-570), which the reference never ported to GPU.
-// ---------------------------------------------------------------------------------------
-template <typename Idx, typename DT>
-__global__ __launch_bounds__(256) void edge_softmax_fwd_kernel(
-    const Idx* __restrict__ indptr, const Idx* __restrict__ eids, const DT* __restrict__ score,
-    DT* __restrict__ out, int64_t num_rows, int dim, int log2_lpe) {
-  using A = typename Acc<DT>::type;
-  const int lpe = 1 << log2_lpe;
-  const int lg = threadIdx.x & (lpe - 1);
-  const int64_t gpb = blockDim.x >> log2_lpe;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * gpb;
-  for (int64_t r = blockIdx.x * gpb + (threadIdx.x >> log2_lpe); r < num_rows; r += stride) {
-    const int64_t s = indptr[r], e = indptr[r + 1];
-    for (int k = lg; k < dim; k += lpe) {
-      A mx = -static_cast<A>(__builtin_huge_valf());
-      for (int64_t j = s; j < e; ++j) {
-        const int64_t eid = eids ? static_cast<int64_t>(eids[j]) : j;
-        const A v = to_acc<DT>(score[eid * dim + k]);
-        mx = mx > v ? mx : v;
-      }
-      A sum = A(0);
-      for (int64_t j = s; j < e; ++j) {
-        const int64_t eid = eids ? static_cast<int64_t>(eids[j]) : j;
-        const A ex = static_cast<A>(exp(static_cast<A>(to_acc<DT>(score[eid * dim + k]) - mx)));
-        sum += ex;
-      }
-      for (int64_t j = s; j < e; ++j) {
-        const int64_t eid = eids ? static_cast<int64_t>(eids[j]) : j;
-        const A ex = static_cast<A>(exp(static_cast<A>(to_acc<DT>(score[eid * dim + k]) - mx)));
-        out[eid * dim + k] = from_acc<DT>(ex / sum);
-      }
-    }
-  }
-}
-
-template <typename Idx, typename DT>
-__global__ __launch_bounds__(256) void edge_softmax_bwd_kernel(
-    const Idx* __restrict__ indptr, const Idx* __restrict__ eids, const DT* __restrict__ out,
-    const DT* __restrict__ sds, DT* __restrict__ back, int64_t num_rows, int dim, int log2_lpe) {
-  using A = typename Acc<DT>::type;
-  const int lpe = 1 << log2_lpe;
-  const int lg = threadIdx.x & (lpe - 1);
-  const int64_t gpb = blockDim.x >> log2_lpe;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * gpb;
-  for (int64_t r = blockIdx.x * gpb + (threadIdx.x >> log2_lpe); r < num_rows; r += stride) {
-    const int64_t s = indptr[r], e = indptr[r + 1];
-    for (int k = lg; k < dim; k += lpe) {
-      A sum = A(0);
-      for (int64_t j = s; j < e; ++j) {
-        const int64_t eid = eids ? static_cast<int64_t>(eids[j]) : j;
-        sum += to_acc<DT>(sds[eid * dim + k]);
-      }
-      for (int64_t j = s; j < e; ++j) {
-        const int64_t eid = eids ? static_cast<int64_t>(eids[j]) : j;
-        back[eid * dim + k] =
-            from_acc<DT>(to_acc<DT>(sds[eid * dim + k]) - sum * to_acc<DT>(out[eid * dim + k]));
-      }
-    }
-  }
-}
-
-template <typename Idx, typename DT>
-static int edge_softmax_run(const CsrView& csr, const void* a, const void* b, void* c, int dim,
-                            bool backward, hipStream_t s) {
-  int l2 = 0;
-  while ((1 << l2) < dim && l2 < 6) ++l2;
-  const int64_t gpb = 256 >> l2;
-  int64_t blocks = (csr.num_rows + gpb - 1) / gpb;
-  if (blocks > 256 * 64) blocks = 256 * 64;
-  if (blocks < 1) blocks = 1;
-  if (!backward)
-    hipLaunchKernelGGL((edge_softmax_fwd_kernel<Idx, DT>), dim3(static_cast<unsigned>(blocks)),
-                       dim3(256), 0, s, static_cast<const Idx*>(csr.indptr),
-                       static_cast<const Idx*>(csr.eids), static_cast<const DT*>(a),
-                       static_cast<DT*>(c), csr.num_rows, dim, l2);
-  else
-    hipLaunchKernelGGL((edge_softmax_bwd_kernel<Idx, DT>), dim3(static_cast<unsigned>(blocks)),
-                       dim3(256), 0, s, static_cast<const Idx*>(csr.indptr),
-                       static_cast<const Idx*>(csr.eids), static_cast<const DT*>(a),
-                       static_cast<const DT*>(b), static_cast<DT*>(c), csr.num_rows, dim, l2);
-  DGLA_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-int launch_edge_softmax(const CsrView& csr, int dtype, const void* a, const void* b, void* c,
-                        int64_t dim, bool backward, hipStream_t s) {
-  const int d = static_cast<int>(dim);
-#define DGLA_ES(DT)                                                              \
-  return csr.idbits == 32 ? edge_softmax_run<int32_t, DT>(csr, a, b, c, d, backward, s) \
-                          : edge_softmax_run<int64_t, DT>(csr, a, b, c, d, backward, s)
-  switch (dtype) {
-    case kF32: DGLA_ES(float);
-    case kF64: DGLA_ES(double);
-    case kF16: DGLA_ES(f16_t);
-    case kBF16: DGLA_ES(bf16_t);
-  }
-#undef DGLA_ES
-  last_error() = "unsupported dtype";
   return -1;
 }
 

@@ -110,8 +110,10 @@ __global__ __launch_bounds__(256) void sddmm_elementwise_kernel(const SddmmParam
   }
 }
 
-// dot, fast path: no broadcast, D % VEC == 0, D / VEC a power of two <= 64.
-// A lane group covers `heads_per_pass` heads at a time; lanes of one head reduce by shuffle.
+// dot, fast path: no broadcast.  A lane group covers `heads_per_pass` heads at a time; the
+// lph = 2^log2_lph lanes of one head stride over its D elements VEC at a time (D need not be
+// a power of two or a multiple of lph * VEC: F = 100 -> 25 of 32 lanes live) and finish with
+// xor-shuffles.
 template <typename Idx, typename DT, int VEC, bool CSR>
 __global__ __launch_bounds__(256) void sddmm_dot_kernel(const SddmmParams<Idx> p) {
   using A = typename Acc<DT>::type;
@@ -147,13 +149,16 @@ __global__ __launch_bounds__(256) void sddmm_dot_kernel(const SddmmParams<Idx> p
     const int64_t rrow = sddmm_select<Idx>(p.rhs_target, src, eid, dst);
     for (int h0 = 0; h0 < H; h0 += heads_per_pass) {
       const int h = h0 + (lg >> p.log2_lph);
-      const int d0 = (lg & (lph - 1)) * VEC;
       A part = A(0);
       if (live && h < H) {
-        const V lv = *reinterpret_cast<const V*>(L + lrow * p.lhs_len + h * D + d0);
-        const V rv = *reinterpret_cast<const V*>(Rr + rrow * p.rhs_len + h * D + d0);
+        const DT* lp = L + lrow * p.lhs_len + static_cast<int64_t>(h) * D;
+        const DT* rp = Rr + rrow * p.rhs_len + static_cast<int64_t>(h) * D;
+        for (int d0 = (lg & (lph - 1)) * VEC; d0 < D; d0 += lph * VEC) {
+          const V lv = *reinterpret_cast<const V*>(lp + d0);
+          const V rv = *reinterpret_cast<const V*>(rp + d0);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) part += to_acc<DT>(lv.v[v]) * to_acc<DT>(rv.v[v]);
+          for (int v = 0; v < VEC; ++v) part += to_acc<DT>(lv.v[v]) * to_acc<DT>(rv.v[v]);
+        }
       }
       for (int m = lph >> 1; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
       if (live && h < H && (lg & (lph - 1)) == 0) O[eid * H + h] = from_acc<DT>(part);
@@ -249,8 +254,6 @@ inline bool sddmm_vec_ok(const SddmmLaunch& L) {
   if (L.bcast != kBcNone) return false;
   if (L.op == kDot) {
     if (L.reduce_size % full) return false;
-    const int64_t lph = L.reduce_size / full;
-    if (lph > 64 || (lph & (lph - 1))) return false;
     if (L.lhs_len % full || L.rhs_len % full) return false;
     return aligned(L.lhs) && aligned(L.rhs);
   }
@@ -295,24 +298,25 @@ inline int launch_sddmm_fmt(const SddmmLaunch& L) {
   const bool vec = sddmm_vec_ok<DT>(L);
   if (L.op == kDot) {
     SddmmParams<Idx> p = make_sddmm_params<Idx>(L);
-    if (vec) {
-      const int64_t lph = L.reduce_size / full;
+    if (L.bcast == kBcNone) {
+      // lanes per head: enough to cover D with one access each, a power of two, <= 64
+      const int64_t per = vec ? full : 1;
+      int64_t lph = (L.reduce_size + per - 1) / per;
+      if (lph > 64) lph = 64;
       p.log2_lph = ceil_log2(lph);
-      int64_t lanes = lph * L.out_len;
+      int64_t lanes = (int64_t(1) << p.log2_lph) * L.out_len;
       if (lanes > 64) lanes = 64;
       p.log2_lpe = ceil_log2(lanes);
-      if (p.log2_lpe < p.log2_lph) p.log2_lpe = p.log2_lph;
       const int64_t gpb = 256 >> p.log2_lpe;
-      hipLaunchKernelGGL((sddmm_dot_kernel<Idx, DT, full, CSR>), dim3(sddmm_grid(p.nnz, gpb)),
-                         dim3(256), 0, L.stream, p);
+      const dim3 grid(sddmm_grid(p.nnz, gpb));
+      if (vec)
+        hipLaunchKernelGGL((sddmm_dot_kernel<Idx, DT, full, CSR>), grid, dim3(256), 0, L.stream, p);
+      else
+        hipLaunchKernelGGL((sddmm_dot_kernel<Idx, DT, 1, CSR>), grid, dim3(256), 0, L.stream, p);
     } else {
       const unsigned grid = sddmm_grid(p.nnz * p.out_len, 256);
-      if (L.bcast == kBcGeneral)
-        hipLaunchKernelGGL((sddmm_dot_general_kernel<Idx, DT, kBcGeneral, CSR>), dim3(grid),
-                           dim3(256), 0, L.stream, p);
-      else
-        hipLaunchKernelGGL((sddmm_dot_general_kernel<Idx, DT, kBcNone, CSR>), dim3(grid),
-                           dim3(256), 0, L.stream, p);
+      hipLaunchKernelGGL((sddmm_dot_general_kernel<Idx, DT, kBcGeneral, CSR>), dim3(grid),
+                         dim3(256), 0, L.stream, p);
     }
     DGLA_CHECK_HIP(hipGetLastError());
     return 0;

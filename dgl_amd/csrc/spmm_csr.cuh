@@ -592,19 +592,40 @@ inline int launch_spmm_op(const SpmmLaunch& L, const SpmmGeometry& g) {
   return -1;
 }
 
-// Chooses the access width: 16-byte lane accesses when every row start is 16-byte
-// aligned and the operand layout allows it, else element-wise.
+// Chooses the access width: 16-byte lane accesses when every row start is 16-byte aligned
+// and the operand layout allows it, else 8-byte accesses under the same test (bf16 / fp16
+// rows of F % 4 == 0 elements such as F = 100, fp32 rows of even length), else element-wise.
+template <typename DT>
+inline bool spmm_vec_fits(const SpmmLaunch& L, int vec) {
+  const uintptr_t mask = sizeof(DT) * vec - 1;
+  auto aligned = [mask](const void* p) { return (reinterpret_cast<uintptr_t>(p) & mask) == 0; };
+  if (L.out_len % vec) return false;
+  if (!aligned(L.out)) return false;
+  if (op_uses_lhs(L.op) && (L.lhs_len % vec || !aligned(L.ufeat))) return false;
+  if (op_uses_rhs(L.op) && L.bcast == kBcNone && (L.rhs_len % vec || !aligned(L.efeat))) return false;
+  if (L.bcast == kBcRhsGroup && L.rhs_group % vec) return false;
+  return true;
+}
+
 template <typename DT>
 inline int spmm_pick_vec(const SpmmLaunch& L) {
   constexpr int full = 16 / sizeof(DT);
+  constexpr int half = full / 2;
   if (L.bcast == kBcGeneral) return 1;
-  auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  if (L.out_len % full) return 1;
-  if (!aligned(L.out)) return 1;
-  if (op_uses_lhs(L.op) && (L.lhs_len % full || !aligned(L.ufeat))) return 1;
-  if (op_uses_rhs(L.op) && L.bcast == kBcNone && (L.rhs_len % full || !aligned(L.efeat))) return 1;
-  if (L.bcast == kBcRhsGroup && L.rhs_group % full) return 1;
-  return full;
+  if (spmm_vec_fits<DT>(L, full)) return full;
+  if (half > 1 && spmm_vec_fits<DT>(L, half)) return half;
+  return 1;
+}
+
+template <typename Idx, typename DT>
+inline int launch_spmm_vec(const SpmmLaunch& L, const SpmmGeometry& g, int vec) {
+  constexpr int full = 16 / sizeof(DT);
+  constexpr int half = full / 2;
+  if (vec == full) return launch_spmm_op<Idx, DT, full>(L, g);
+  if constexpr (half > 1) {
+    if (vec == half) return launch_spmm_op<Idx, DT, half>(L, g);
+  }
+  return launch_spmm_op<Idx, DT, 1>(L, g);
 }
 
 template <typename DT>
@@ -617,24 +638,23 @@ inline int launch_spmm_csr_typed(const SpmmLaunch& L) {
     last_error() = "SpMM workspace too small: need " + std::to_string(g.total) + " bytes";
     return -1;
   }
-  constexpr int full = 16 / sizeof(DT);
   if (L.csr.idbits == 32) {
     if (launch_plan<int32_t>(L, g)) return -1;
-    return vec == 1 ? launch_spmm_op<int32_t, DT, 1>(L, g) : launch_spmm_op<int32_t, DT, full>(L, g);
+    return launch_spmm_vec<int32_t, DT>(L, g, vec);
   } else {
     if (launch_plan<int64_t>(L, g)) return -1;
-    return vec == 1 ? launch_spmm_op<int64_t, DT, 1>(L, g) : launch_spmm_op<int64_t, DT, full>(L, g);
+    return launch_spmm_vec<int64_t, DT>(L, g, vec);
   }
 }
 
-// Upper bound over both access widths, so the answer does not depend on pointer alignment
+// Upper bound over all access widths, so the answer does not depend on pointer alignment
 // and one allocation serves every later call on this (graph, feature width).
 template <typename DT>
 inline size_t spmm_csr_workspace_typed(const SpmmLaunch& L) {
   using A = typename Acc<DT>::type;
   constexpr int full = 16 / sizeof(DT);
   size_t best = 0;
-  for (int vec : {1, full}) {
+  for (int vec : {1, full / 2 > 1 ? full / 2 : 1, full}) {
     const size_t t = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
                                    L.csr.idbits / 8, L.red != kSum)
                          .total;

@@ -433,3 +433,103 @@ def test_scaled_c2_properties(dev):
     lhs = out.double().sum(0)
     rhs = (outdeg[:, None] * x.double()).sum(0)
     assert torch.allclose(lhs, rhs, rtol=1e-6)
+
+
+# --------------------------------------------------------------------------------------
+# Access-width paths added after the first profile: 8-byte lanes (bf16/fp16 rows of
+# F % 4 == 0, fp32 rows of even length), generalised dot lanes, edge-softmax lane groups
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tdtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("feat", [100, 36, 6, 10, 260])
+@pytest.mark.parametrize("op,reduce", [("copy_lhs", "sum"), ("mul", "sum"), ("copy_lhs", "max"),
+                                       ("add", "min")])
+def test_spmm_8byte_lanes(dev, tdtype, feat, op, reduce):
+    """F=100 in bf16 is a 200-byte row (8-byte aligned only); F=6/10 fp32 rows are 8-byte
+    aligned.  Values: sums against the oracle in fp64 on the rounded inputs; max/min pick an
+    input (or one rounded op result) so they must match the oracle run in the same storage
+    precision exactly, and so must arg_u / arg_e."""
+    from dgl_amd import _capi
+
+    n_src, n_dst, src, dst = GRAPHS["bipartite"]()
+    indptr, indices, eids = coo_to_csc(src, dst, n_dst, np.int32)
+    rng = np.random.default_rng(feat)
+    tu = torch.from_numpy((rng.random((n_src, feat)) + 1).astype(np.float32)).to(dev).to(tdtype)
+    te = torch.from_numpy((rng.random((len(src), feat)) + 1).astype(np.float32)).to(dev).to(tdtype)
+    uu = tu if op != "copy_rhs" else None
+    ee = te if op != "copy_lhs" else None
+    ti = [torch.from_numpy(a).to(dev) for a in (indptr, indices, eids)]
+    csr = _capi.make_csr(ti[0], ti[1], ti[2], n_src)
+    out = torch.empty((n_dst, feat), dtype=tdtype, device=dev)
+    au = torch.full((n_dst, feat), -3, dtype=torch.int32, device=dev) if reduce != "sum" else None
+    ae = torch.full((n_dst, feat), -3, dtype=torch.int32, device=dev) if reduce != "sum" else None
+    ws = torch.empty(max(_capi.spmm_csr_workspace_bytes(op, reduce, csr, tdtype, uu, ee, out), 1),
+                     dtype=torch.uint8, device=dev)
+    _capi.spmm_csr(op, reduce, csr, uu, ee, out, au, ae, ws)
+    f64 = lambda t: None if t is None else t.float().cpu().numpy().astype(np.float64)
+    ref, ru, re_ = oracle.spmm_csr(op, reduce, indptr, indices, eids, f64(uu), f64(ee))
+    got = out.float().cpu().numpy()
+    if reduce == "sum":
+        tol = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1e-2}[tdtype]
+        np.testing.assert_allclose(got, ref, rtol=tol, atol=tol)
+    else:
+        # round the fp64 op result to storage precision the way the kernel does
+        want = torch.from_numpy(ref).to(tdtype).float().numpy()
+        if op == "copy_lhs":
+            np.testing.assert_array_equal(got, want)
+            np.testing.assert_array_equal(au.cpu().numpy(), ru)
+        else:
+            np.testing.assert_allclose(got, want, rtol={torch.float32: 1e-6}.get(tdtype, 1e-2))
+
+
+@pytest.mark.parametrize("hd", [(1, 100), (2, 50), (1, 7), (3, 33), (1, 300), (5, 12)])
+def test_sddmm_dot_any_width(dev, hd):
+    """dot over D that is neither a power of two nor a multiple of the vector width."""
+    n_src, n_dst, src, dst = GRAPHS["homo"]()
+    rng = np.random.default_rng(3)
+    for dtype in (np.float32, np.float64):
+        lhs = (rng.random((n_src,) + hd) - 0.5).astype(dtype)
+        rhs = (rng.random((n_dst,) + hd) - 0.5).astype(dtype)
+        for fmt in ("coo", "csr"):
+            out, ref = run_sddmm(dev, fmt, "dot", n_src, n_dst, src, dst, lhs, rhs, "u", "v",
+                                 np.int32, dtype)
+            np.testing.assert_allclose(out, ref, rtol=1e-5 if dtype == np.float32 else 1e-12,
+                                       atol=1e-6 if dtype == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("n_dst,n_edges,dim", [
+    (2000, 3000, 1),      # mean degree 1-2: 64 rows per wave
+    (500, 12000, 8),      # mean degree 24: 8 heads x 8 edge slots = one row per wave
+    (40, 30000, 4),       # rows of ~750 edges: far beyond the register cache
+    (300, 9000, 70),      # dim > 64: feature loop
+    (1000, 16000, 3),     # non power-of-two dim: idle feature lanes
+])
+@pytest.mark.parametrize("idtype", [np.int32, np.int64])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_edge_softmax_geometries(dev, n_dst, n_edges, dim, idtype, dtype):
+    from dgl_amd import _capi
+
+    rng = np.random.default_rng(n_edges)
+    src = rng.integers(0, 50, n_edges)
+    dst = np.minimum((rng.random(n_edges) ** 2 * n_dst).astype(np.int64), n_dst - 1)  # skewed
+    indptr, indices, eids = coo_to_csc(src, dst, n_dst, idtype)
+    score = (rng.standard_normal((n_edges, dim)) * 4).astype(dtype)
+    grad = rng.standard_normal((n_edges, dim)).astype(dtype)
+    ref = oracle.edge_softmax_fwd(indptr, eids, score)
+    ref_b = oracle.edge_softmax_bwd(indptr, eids, ref, ref * grad)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    keep = (t(indptr), t(indices), t(eids))
+    csr = _capi.make_csr(keep[0], keep[1], keep[2], 50)
+    ts = t(score)
+    out = torch.full_like(ts, 7.0)
+    _capi.edge_softmax_forward(csr, ts, out)
+    tol = dict(rtol=2e-5, atol=1e-7) if dtype == np.float32 else dict(rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, **tol)
+    back = torch.full_like(ts, 7.0)
+    _capi.edge_softmax_backward(csr, t(ref), t(ref * grad), back)
+    np.testing.assert_allclose(back.cpu().numpy(), ref_b, rtol=tol["rtol"] * 10, atol=1e-6 if dtype == np.float32 else 1e-13)
+    # softmax rows sum to one (size-independent property)
+    rows = np.repeat(np.arange(n_dst), np.diff(indptr))
+    sums = np.zeros((n_dst, dim))
+    np.add.at(sums, rows, out.cpu().numpy()[eids].astype(np.float64))
+    nz = np.diff(indptr) > 0
+    np.testing.assert_allclose(sums[nz], 1.0, rtol=1e-5)
