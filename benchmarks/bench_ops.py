@@ -138,11 +138,21 @@ def c3(dev, args):
             csr = _capi.make_csr(g["indptr"], g["indices"], g["eids"], n)
             a = torch.empty_like(out)
             ms, mn = timeit(lambda: _capi.edge_softmax_forward(csr, out, a))
-            emit("C3", "edge_softmax fwd (H=8)", e, ms, mn, e * (2 * h * s + i) + (n + 1) * i)
+            emit("C3", "edge_softmax fwd (H=8) lane-group kernel", e, ms, mn, e * (2 * h * s + i) + (n + 1) * i)
             sds = a * out
             back = torch.empty_like(out)
             ms, mn = timeit(lambda: _capi.edge_softmax_backward(csr, a, sds, back))
-            emit("C3", "edge_softmax bwd (H=8)", e, ms, mn, e * (3 * h * s + i) + (n + 1) * i)
+            emit("C3", "edge_softmax bwd (H=8) lane-group kernel", e, ms, mn, e * (3 * h * s + i) + (n + 1) * i)
+            ws = torch.empty(_capi.edge_softmax_workspace_bytes(csr, out.dtype, h), dtype=torch.uint8, device=dev)
+            _capi.edge_softmax_forward(csr, out, a, ws)
+            ms, mn = timeit(lambda: _capi.edge_softmax_forward(csr, out, a, ws, plan_valid=True))
+            emit("C3", "edge_softmax fwd (H=8) merge-path", e, ms, mn, e * (2 * h * s + i) + (n + 1) * i)
+            ms, mn = timeit(lambda: _capi.edge_softmax_backward(csr, a, sds, back, ws, plan_valid=True))
+            emit("C3", "edge_softmax bwd (H=8) merge-path", e, ms, mn, e * (3 * h * s + i) + (n + 1) * i)
+            # identity edge-id map (COO already sorted by destination): sequential score rows
+            csr0 = _capi.make_csr(g["indptr"], g["indices"], None, n)
+            ms, mn = timeit(lambda: _capi.edge_softmax_forward(csr0, out, a, ws, plan_valid=True))
+            emit("C3", "edge_softmax fwd (H=8) merge-path, eid = position", e, ms, mn, e * (2 * h * s) + (n + 1) * i)
         a = torch.rand(e, h, 1, device=dev)
         run_spmm("C3", "u_mul_e_sum (H=8,D=%d)x(H,1)" % d, g, "mul", "sum", ft, a, (h, d), dev, eid=True)
 

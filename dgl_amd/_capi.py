@@ -110,19 +110,32 @@ def sddmm_csr(op, csr, lhs, rhs, out, lhs_target, rhs_target):
                                   lhs_target, rhs_target, _stream(out)))
 
 
-def edge_softmax_forward(csr, score, out):
+def edge_softmax_workspace_bytes(csr, dtype, dim):
+    return LIB.dgla_edge_softmax_workspace_bytes(ctypes.byref(csr), _DTYPES[dtype], int(dim))
+
+
+def _ws_args(workspace, plan_valid):
+    return (_ptr(workspace), 0 if workspace is None else workspace.numel() * workspace.element_size(),
+            _lib.DGLA_PLAN_VALID if plan_valid else 0)
+
+
+def edge_softmax_forward(csr, score, out, workspace=None, plan_valid=False):
+    """`workspace` (uint8 tensor of edge_softmax_workspace_bytes) selects the degree-balanced
+    merge-path kernels; None runs the scratch-free lane-group kernel."""
     keep = []
     ts, to = _tensor(score, keep), _tensor(out, keep)
     check_call(LIB.dgla_edge_softmax_forward(ctypes.byref(csr), _DTYPES[out.dtype],
-                                             ctypes.byref(ts), ctypes.byref(to), _stream(out)))
+                                             ctypes.byref(ts), ctypes.byref(to),
+                                             *_ws_args(workspace, plan_valid), _stream(out)))
 
 
-def edge_softmax_backward(csr, out, sds, back):
+def edge_softmax_backward(csr, out, sds, back, workspace=None, plan_valid=False):
     keep = []
     to, ts, tb = _tensor(out, keep), _tensor(sds, keep), _tensor(back, keep)
     check_call(LIB.dgla_edge_softmax_backward(ctypes.byref(csr), _DTYPES[out.dtype],
                                               ctypes.byref(to), ctypes.byref(ts),
-                                              ctypes.byref(tb), _stream(back)))
+                                              ctypes.byref(tb), *_ws_args(workspace, plan_valid),
+                                              _stream(back)))
 
 
 def stream_copy(dst, src):

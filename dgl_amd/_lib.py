@@ -70,10 +70,13 @@ LIB.dgla_sddmm_csr.restype = c_int
 LIB.dgla_sddmm_csr.argtypes = [c_char_p, P(CSR), c_int, P(Tensor), P(Tensor), P(Tensor), c_int,
                                c_int, c_void_p]
 LIB.dgla_edge_softmax_forward.restype = c_int
-LIB.dgla_edge_softmax_forward.argtypes = [P(CSR), c_int, P(Tensor), P(Tensor), c_void_p]
+LIB.dgla_edge_softmax_forward.argtypes = [P(CSR), c_int, P(Tensor), P(Tensor), c_void_p, c_size_t,
+                                          c_uint32, c_void_p]
+LIB.dgla_edge_softmax_workspace_bytes.restype = c_size_t
+LIB.dgla_edge_softmax_workspace_bytes.argtypes = [P(CSR), c_int, c_int64]
 LIB.dgla_edge_softmax_backward.restype = c_int
 LIB.dgla_edge_softmax_backward.argtypes = [P(CSR), c_int, P(Tensor), P(Tensor), P(Tensor),
-                                           c_void_p]
+                                           c_void_p, c_size_t, c_uint32, c_void_p]
 LIB.dgla_spmm_set_profile_events.restype = c_int
 LIB.dgla_spmm_set_profile_events.argtypes = [c_void_p, c_void_p]
 LIB.dgla_stream_copy.restype = c_int

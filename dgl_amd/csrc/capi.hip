@@ -38,7 +38,8 @@ int launch_stream_copy(void*, const void*, size_t, int, hipStream_t);
 int launch_spmm_coo(const CooView&, int, int, int, const void*, const void*, void*, void*, void*,
                     int64_t, int64_t, int64_t, bool, const BcastDims&, hipStream_t);
 int launch_edge_softmax(const CsrView&, int, const void*, const void*, void*, int64_t, bool,
-                        hipStream_t);
+                        void*, size_t, bool, hipStream_t);
+size_t edge_softmax_workspace_bytes(int64_t, int64_t, int, int64_t);
 
 static int fail(const std::string& msg) {
   last_error() = msg;
@@ -419,8 +420,14 @@ int dgla_sddmm_csr(const char* op, const dgla_csr* csr, dgla_dtype dtype, const 
                       hip_stream);
 }
 
+size_t dgla_edge_softmax_workspace_bytes(const dgla_csr* csr, dgla_dtype dtype, int64_t dim) {
+  if (!csr) return 0;
+  return edge_softmax_workspace_bytes(csr->num_rows, csr->nnz, dtype, dim);
+}
+
 int dgla_edge_softmax_forward(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* score,
-                              const dgla_tensor* out, void* hip_stream) {
+                              const dgla_tensor* out, void* workspace, size_t workspace_bytes,
+                              uint32_t flags, void* hip_stream) {
   CsrView v;
   if (fill_csr(csr, &v)) return -1;
   if (!present(score) || !present(out)) return csr->nnz == 0 ? 0 : fail("score / out is null");
@@ -428,11 +435,13 @@ int dgla_edge_softmax_forward(const dgla_csr* csr, dgla_dtype dtype, const dgla_
   if (feat_len(score) != feat_len(out)) return fail("score and out shapes differ");
   if (csr->nnz == 0 || feat_len(score) == 0) return 0;
   return launch_edge_softmax(v, dtype, score->data, nullptr, out->data, feat_len(score), false,
+                             workspace, workspace_bytes, (flags & DGLA_PLAN_VALID) != 0,
                              static_cast<hipStream_t>(hip_stream));
 }
 
 int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* out,
-                               const dgla_tensor* sds, const dgla_tensor* back, void* hip_stream) {
+                               const dgla_tensor* sds, const dgla_tensor* back, void* workspace,
+                               size_t workspace_bytes, uint32_t flags, void* hip_stream) {
   CsrView v;
   if (fill_csr(csr, &v)) return -1;
   if (!present(out) || !present(sds) || !present(back))
@@ -444,6 +453,7 @@ int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla
     return fail("out, sds and back shapes differ");
   if (csr->nnz == 0 || feat_len(out) == 0) return 0;
   return launch_edge_softmax(v, dtype, out->data, sds->data, back->data, feat_len(out), true,
+                             workspace, workspace_bytes, (flags & DGLA_PLAN_VALID) != 0,
                              static_cast<hipStream_t>(hip_stream));
 }
 

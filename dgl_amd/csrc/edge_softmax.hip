@@ -151,6 +151,484 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
   }
 }
 
+// =========================================================================================
+// Merge-path variant (dim <= 16, caller-provided workspace): degree-balanced.
+//
+// The lane-group kernel above gives one row to one lane group, so a 10k-edge hub row is
+// walked serially by 4-64 lanes while the rest of the chip idles (measured on the
+// ogbn-arxiv-shaped graph: 0.53 ms for 80 MB of scores).  Here the CSR is cut by merge path
+// into units of kEsmItems items (edges + row ends) exactly like the SpMM; one wavefront per
+// unit:
+//   1. stage the unit's row ends and edge ids in LDS, then gather all its scores into LDS
+//      with independent loads (one HBM round trip for the whole unit);
+//   2. one lane per (segment, feature) reduces its segment out of LDS; a segment is a row,
+//      or the part of a row inside this unit;
+//   3. rows that lie entirely inside the unit are finished and written (read once, written
+//      once); a row that straddles units leaves (max, sum) per part in the workspace and its
+//      edges un-normalised;
+//   4. a fix-up kernel, one 64-lane block per unit, merges the parts of each straddling row
+//      ((m, s) pairs combine as S = sum_i s_i * exp(m_i - M)) and rescales its own unit's
+//      edges, so even a hub row is handled by as many blocks as it has units.
+// =========================================================================================
+constexpr int kEsmItems = 256;
+
+template <typename Idx>
+struct EsmParams {
+  const Idx* indptr;
+  const Idx* eids;
+  int64_t num_rows, nnz, num_units;
+  const int64_t* plan;  // [num_units + 1]
+  const void* a;
+  const void* b;
+  void* c;
+  int dim, log2_hp;
+  int wave_lds_bytes;
+  int64_t* carry_row;  // [num_units] row continued in the next unit, or -1
+  void* carry_stat;    // [num_units, 2 * dim] accumulators: (m | s) forward, (sum | -) backward
+  void* tail_stat;     // [num_units, 2 * dim]
+};
+
+template <typename Idx>
+__global__ void esm_plan_kernel(const Idx* __restrict__ indptr, int64_t num_rows, int64_t nnz,
+                                int64_t num_units, int64_t* __restrict__ plan) {
+  // plan[w] = largest i in [0, N] with indptr[i] + i <= w * kEsmItems (see spmm_csr.cuh)
+  const int64_t w = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (w > num_units) return;
+  int64_t d = w * kEsmItems;
+  const int64_t total = num_rows + nnz;
+  if (d > total) d = total;
+  int64_t lo = 0, hi = num_rows;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (static_cast<int64_t>(indptr[mid]) + mid <= d)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  plan[w] = lo;
+}
+
+struct EsmUnit {
+  int64_t i0, j0;
+  int R, nE;
+};
+
+template <typename Idx>
+__device__ __forceinline__ EsmUnit esm_unit(const EsmParams<Idx>& p, int64_t w) {
+  EsmUnit u;
+  const int64_t total = p.num_rows + p.nnz;
+  const int64_t d0 = w * kEsmItems;
+  int64_t d1 = d0 + kEsmItems;
+  if (d1 > total) d1 = total;
+  u.i0 = p.plan[w];
+  const int64_t i1 = p.plan[w + 1];
+  u.j0 = d0 - u.i0;
+  u.R = static_cast<int>(i1 - u.i0);
+  u.nE = static_cast<int>((d1 - i1) - u.j0);
+  return u;
+}
+
+template <typename A, bool PRECISE>
+__device__ __forceinline__ A esm_expx(A x) {
+  if constexpr (PRECISE)
+    return static_cast<A>(exp(static_cast<double>(x)));
+  else
+    return esm_exp<A>(x);
+}
+
+template <typename Idx, typename DT, bool BWD, bool PRECISE>
+__global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams<Idx> p) {
+  using A = typename Acc<DT>::type;
+  extern __shared__ __align__(16) unsigned char esm_smem[];
+  const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * wpb + wib;
+  const int hp = 1 << p.log2_hp, dim = p.dim;
+  unsigned char* base = esm_smem + static_cast<size_t>(wib) * p.wave_lds_bytes;
+  A* val = reinterpret_cast<A*>(base);                               // [kEsmItems * hp]
+  A* val2 = val + (BWD ? kEsmItems * hp : 0);                        // backward: out values
+  int64_t* eid = reinterpret_cast<int64_t*>(val2 + kEsmItems * hp);  // [kEsmItems]
+  int* rend = reinterpret_cast<int*>(eid + kEsmItems);               // [kEsmItems + 2]
+  const DT* __restrict__ pa = static_cast<const DT*>(p.a);
+  const DT* __restrict__ pb = static_cast<const DT*>(p.b);
+  DT* __restrict__ pc = static_cast<DT*>(p.c);
+
+  EsmUnit u{0, 0, 0, 0};
+  int first = 0;
+  if (w < p.num_units) {
+    u = esm_unit<Idx>(p, w);
+    // ---- stage row ends and edge ids: kEsmItems / 64 = 4 independent loads per lane issued
+    // back to back (addresses clamped, not predicated), one HBM round trip ---------------
+    constexpr int KS = kEsmItems / 64;
+    const int items = u.R + u.nE;
+    if (items > 0) {
+      int64_t itemv[KS];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        int it = lane + 64 * k;
+        if (it >= items) it = items - 1;
+        if (it < u.nE)
+          itemv[k] = p.eids ? static_cast<int64_t>(p.eids[u.j0 + it]) : u.j0 + it;
+        else
+          itemv[k] = static_cast<int64_t>(p.indptr[u.i0 + 1 + (it - u.nE)]) - u.j0;
+      }
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        const int it = lane + 64 * k;
+        if (it < u.nE)
+          eid[it] = itemv[k];
+        else if (it < items)
+          rend[it - u.nE + 1] = static_cast<int>(itemv[k]);
+      }
+    }
+    const int64_t f = static_cast<int64_t>(p.indptr[u.i0]) - u.j0;
+    first = f < 0 ? -1 : static_cast<int>(f);
+    if (lane == 0) rend[0] = first;
+  }
+  __syncthreads();
+  if (w < p.num_units) {
+    // ---- gather the unit's values into LDS: UG loads in flight per lane ----------------
+    constexpr int UG = BWD ? 8 : 16;
+    const int total = u.nE << p.log2_hp;
+    const int h = lane & (hp - 1);  // 64 is a multiple of hp: the same feature every step
+    if (h < dim) {
+      for (int base = lane; base < total; base += 64 * UG) {
+        A tv[UG];
+        A tv2[BWD ? UG : 1];
+#pragma unroll
+        for (int k = 0; k < UG; ++k) {
+          int idx = base + 64 * k;
+          if (idx >= total) idx = base;  // clamp: a valid element, not stored
+          const int64_t off = eid[idx >> p.log2_hp] * dim + h;
+          if constexpr (BWD) {
+            tv[k] = to_acc<DT>(pb[off]);   // sds
+            tv2[k] = to_acc<DT>(pa[off]);  // out
+          } else {
+            tv[k] = to_acc<DT>(pa[off]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < UG; ++k) {
+          const int idx = base + 64 * k;
+          if (idx < total) {
+            val[idx] = tv[k];
+            if constexpr (BWD) val2[idx] = tv2[k];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // segment bounds shared by the reduce and the write pass
+  const int tail_end = (first < 0 && u.R > 0) ? rend[1] : 0;          // edges [0, tail_end) belong to a row begun earlier
+  int carry_begin = u.nE;                                              // edges [carry_begin, nE) continue in the next unit
+  if (w < p.num_units) {
+    const int cb = rend[u.R] < 0 ? 0 : rend[u.R];
+    if (cb < u.nE) carry_begin = cb;
+    const bool has_carry = carry_begin < u.nE;
+    if (lane == 0) p.carry_row[w] = has_carry ? u.i0 + u.R : int64_t(-1);
+    // ---- reduce ---------------------------------------------------------------------------
+    // Segments of up to kBig edges: one lane per (segment, feature), serial over LDS.
+    // Longer ones (at most kEsmItems / kBig per unit) are found with a ballot and reduced by
+    // the whole wave: the es lane groups stride over the segment, xor-shuffles combine them.
+    constexpr int kBig = 24;
+    const int nseg = u.R + (has_carry ? 1 : 0);
+    const int h = lane & (hp - 1);
+    const int g = lane >> p.log2_hp;
+    const int es = 64 >> p.log2_hp;
+    auto seg_bounds = [&](int sg, int* t0, int* t1, bool* partial, A** stat) {
+      const bool is_carry = sg == u.R;
+      const bool is_tail = sg == 0 && first < 0 && !is_carry;
+      int a0 = rend[sg] < 0 ? 0 : rend[sg];
+      if (is_carry) a0 = carry_begin;
+      *t0 = a0;
+      *t1 = is_carry ? u.nE : rend[sg + 1];
+      *partial = is_carry || is_tail;
+      *stat = static_cast<A*>(is_carry ? p.carry_stat : p.tail_stat) + w * 2 * dim;
+    };
+    // (a) short segments
+    for (int sg = g; sg < nseg; sg += es) {
+      int t0, t1;
+      bool partial;
+      A* stat;
+      seg_bounds(sg, &t0, &t1, &partial, &stat);
+      if (t1 - t0 > kBig || h >= dim) continue;
+      if constexpr (BWD) {
+        A sum = A(0);
+        for (int t = t0; t < t1; ++t) sum += val[(t << p.log2_hp) + h];
+        if (partial) {
+          stat[h] = sum;
+        } else {
+          for (int t = t0; t < t1; ++t) {
+            const int i = (t << p.log2_hp) + h;
+            val[i] = val[i] - sum * val2[i];
+          }
+        }
+      } else {
+        A mx = -static_cast<A>(__builtin_huge_valf());
+        for (int t = t0; t < t1; ++t) {
+          const A x = val[(t << p.log2_hp) + h];
+          mx = mx > x ? mx : x;
+        }
+        A sum = A(0);
+        for (int t = t0; t < t1; ++t) {
+          const int i = (t << p.log2_hp) + h;
+          const A ex = esm_expx<A, PRECISE>(val[i] - mx);
+          val[i] = ex;
+          sum += ex;
+        }
+        if (partial) {
+          stat[h] = mx;
+          stat[dim + h] = sum;
+        } else {
+          for (int t = t0; t < t1; ++t) {
+            const int i = (t << p.log2_hp) + h;
+            val[i] = val[i] / sum;
+          }
+        }
+      }
+    }
+    // (b) long segments, whole wave each (wave-uniform control flow)
+    for (int sbase = 0; sbase < nseg; sbase += 64) {
+      const int sg_l = sbase + lane;
+      bool big = false;
+      if (sg_l < nseg) {
+        int t0, t1;
+        bool partial;
+        A* stat;
+        seg_bounds(sg_l, &t0, &t1, &partial, &stat);
+        big = t1 - t0 > kBig;
+      }
+      unsigned long long mask = __ballot(big);
+      while (mask) {
+        const int bit = __ffsll(static_cast<long long>(mask)) - 1;
+        mask &= mask - 1;
+        int t0, t1;
+        bool partial;
+        A* stat;
+        seg_bounds(sbase + bit, &t0, &t1, &partial, &stat);
+        const bool hok = h < dim;
+        if constexpr (BWD) {
+          A sum = A(0);
+          if (hok)
+            for (int t = t0 + g; t < t1; t += es) sum += val[(t << p.log2_hp) + h];
+          sum = group_reduce_sum<A>(sum, hp, 64);
+          if (partial) {
+            if (hok && g == 0) stat[h] = sum;
+          } else if (hok) {
+            for (int t = t0 + g; t < t1; t += es) {
+              const int i = (t << p.log2_hp) + h;
+              val[i] = val[i] - sum * val2[i];
+            }
+          }
+        } else {
+          A mx = -static_cast<A>(__builtin_huge_valf());
+          if (hok)
+            for (int t = t0 + g; t < t1; t += es) {
+              const A x = val[(t << p.log2_hp) + h];
+              mx = mx > x ? mx : x;
+            }
+          mx = group_reduce_max<A>(mx, hp, 64);
+          A sum = A(0);
+          if (hok)
+            for (int t = t0 + g; t < t1; t += es) {
+              const int i = (t << p.log2_hp) + h;
+              const A ex = esm_expx<A, PRECISE>(val[i] - mx);
+              val[i] = ex;
+              sum += ex;
+            }
+          sum = group_reduce_sum<A>(sum, hp, 64);
+          if (partial) {
+            if (hok && g == 0) {
+              stat[h] = mx;
+              stat[dim + h] = sum;
+            }
+          } else if (hok) {
+            for (int t = t0 + g; t < t1; t += es) {
+              const int i = (t << p.log2_hp) + h;
+              val[i] = val[i] / sum;
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (w < p.num_units) {
+    // ---- write: complete rows are final; parts of straddling rows are written
+    // un-normalised (forward) or left to the fix-up (backward) ---------------------------
+    const int total = u.nE << p.log2_hp;
+    for (int idx = lane; idx < total; idx += 64) {
+      const int t = idx >> p.log2_hp, h = idx & (hp - 1);
+      if (h >= dim) continue;
+      const bool partial = t < tail_end || t >= carry_begin;
+      if (BWD && partial) continue;
+      pc[eid[t] * dim + h] = from_acc<DT>(val[idx]);
+    }
+  }
+}
+
+template <typename Idx, typename DT, bool BWD, bool PRECISE>
+__global__ __launch_bounds__(64) void edge_softmax_fixup_kernel(const EsmParams<Idx> p) {
+  using A = typename Acc<DT>::type;
+  const int64_t w = blockIdx.x;
+  const int dim = p.dim, hp = 1 << p.log2_hp;
+  const EsmUnit u = esm_unit<Idx>(p, w);
+  const int64_t f = static_cast<int64_t>(p.indptr[u.i0]) - u.j0;
+  const A* cs = static_cast<const A*>(p.carry_stat);
+  const A* ts = static_cast<const A*>(p.tail_stat);
+  const DT* __restrict__ pa = static_cast<const DT*>(p.a);
+  const DT* __restrict__ pb = static_cast<const DT*>(p.b);
+  DT* __restrict__ pc = static_cast<DT*>(p.c);
+  const int lane = threadIdx.x;
+  const int h = lane & (hp - 1);
+  const int es = 64 >> p.log2_hp;
+
+  // part: 0 = this unit's carry segment, 1 = this unit's tail segment
+  for (int part = 0; part < 2; ++part) {
+    int64_t row, sa, s2;  // run of carries [sa, s2) plus the tail held by unit s2
+    int t0, t1;
+    if (part == 0) {
+      row = p.carry_row[w];
+      if (row < 0) continue;
+      sa = w;
+      while (sa > 0 && p.carry_row[sa - 1] == row) --sa;
+      s2 = w + 1;
+      while (s2 < p.num_units && p.carry_row[s2] == row) ++s2;
+      const int64_t cb = static_cast<int64_t>(p.indptr[u.i0 + u.R]) - u.j0;
+      t0 = cb < 0 ? 0 : static_cast<int>(cb);
+      t1 = u.nE;
+    } else {
+      if (!(f < 0 && u.R > 0)) continue;
+      row = u.i0;
+      s2 = w;
+      sa = w;
+      while (sa > 0 && p.carry_row[sa - 1] == row) --sa;
+      t0 = 0;
+      t1 = static_cast<int>(static_cast<int64_t>(p.indptr[u.i0 + 1]) - u.j0);
+    }
+    if (h >= dim) continue;
+    if constexpr (BWD) {
+      A sum = A(0);
+      for (int64_t q = sa; q < s2; ++q) sum += cs[q * 2 * dim + h];
+      sum += ts[s2 * 2 * dim + h];
+      for (int t = t0 + (lane >> p.log2_hp); t < t1; t += es) {
+        const int64_t j = u.j0 + t;
+        const int64_t off = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + h;
+        pc[off] = from_acc<DT>(to_acc<DT>(pb[off]) - sum * to_acc<DT>(pa[off]));
+      }
+    } else {
+      A M = ts[s2 * 2 * dim + h];
+      for (int64_t q = sa; q < s2; ++q) {
+        const A m = cs[q * 2 * dim + h];
+        M = M > m ? M : m;
+      }
+      A S = A(0);
+      for (int64_t q = sa; q < s2; ++q)
+        S += cs[q * 2 * dim + dim + h] * esm_expx<A, PRECISE>(cs[q * 2 * dim + h] - M);
+      {
+        const A s_t = ts[s2 * 2 * dim + dim + h];
+        if (s_t > A(0)) S += s_t * esm_expx<A, PRECISE>(ts[s2 * 2 * dim + h] - M);
+      }
+      const A mine = part == 0 ? cs[w * 2 * dim + h] : ts[w * 2 * dim + h];
+      const A scale = esm_expx<A, PRECISE>(mine - M) / S;
+      for (int t = t0 + (lane >> p.log2_hp); t < t1; t += es) {
+        const int64_t j = u.j0 + t;
+        const int64_t off = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + h;
+        pc[off] = from_acc<DT>(to_acc<DT>(pc[off]) * scale);
+      }
+    }
+  }
+}
+
+struct EsmGeometry {
+  int log2_hp;
+  int64_t num_units;
+  size_t off_plan, off_carry_row, off_carry_stat, off_tail_stat, total;
+};
+
+static size_t esm_align(size_t x) { return (x + 255) / 256 * 256; }
+
+static EsmGeometry esm_geometry(int64_t num_rows, int64_t nnz, int dim, size_t acc_bytes) {
+  EsmGeometry g;
+  g.log2_hp = 0;
+  while ((1 << g.log2_hp) < dim) ++g.log2_hp;
+  g.num_units = (num_rows + nnz + kEsmItems - 1) / kEsmItems;
+  size_t off = 0;
+  g.off_plan = off;
+  off = esm_align(off + sizeof(int64_t) * (g.num_units + 1));
+  g.off_carry_row = off;
+  off = esm_align(off + sizeof(int64_t) * g.num_units);
+  g.off_carry_stat = off;
+  off = esm_align(off + acc_bytes * g.num_units * 2 * dim);
+  g.off_tail_stat = off;
+  off = esm_align(off + acc_bytes * g.num_units * 2 * dim);
+  g.total = off;
+  return g;
+}
+
+constexpr int kEsmMaxDim = 16;
+
+template <typename Idx, typename DT>
+static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void* b, void* c,
+                                  int dim, bool backward, void* ws, bool plan_valid,
+                                  hipStream_t s) {
+  using A = typename Acc<DT>::type;
+  const EsmGeometry g = esm_geometry(csr.num_rows, csr.nnz, dim, sizeof(A));
+  char* wsp = static_cast<char*>(ws);
+  EsmParams<Idx> p;
+  p.indptr = static_cast<const Idx*>(csr.indptr);
+  p.eids = static_cast<const Idx*>(csr.eids);
+  p.num_rows = csr.num_rows;
+  p.nnz = csr.nnz;
+  p.num_units = g.num_units;
+  p.plan = reinterpret_cast<const int64_t*>(wsp + g.off_plan);
+  p.a = a;
+  p.b = b;
+  p.c = c;
+  p.dim = dim;
+  p.log2_hp = g.log2_hp;
+  p.carry_row = reinterpret_cast<int64_t*>(wsp + g.off_carry_row);
+  p.carry_stat = wsp + g.off_carry_stat;
+  p.tail_stat = wsp + g.off_tail_stat;
+  const int hp = 1 << g.log2_hp;
+  const size_t per_wave = sizeof(A) * kEsmItems * hp * (backward ? 2 : 1) +
+                          sizeof(int64_t) * kEsmItems + sizeof(int) * (kEsmItems + 2) + 8;
+  p.wave_lds_bytes = static_cast<int>((per_wave + 15) / 16 * 16);
+  int wpb = static_cast<int>((64 * 1024) / p.wave_lds_bytes);
+  if (wpb > 4) wpb = 4;
+  if (wpb < 1) wpb = 1;
+  if (!plan_valid) {
+    const int64_t n = g.num_units + 1;
+    hipLaunchKernelGGL((esm_plan_kernel<Idx>), dim3(static_cast<unsigned>((n + 255) / 256)),
+                       dim3(256), 0, s, p.indptr, csr.num_rows, csr.nnz, g.num_units,
+                       reinterpret_cast<int64_t*>(wsp + g.off_plan));
+  }
+  const unsigned blocks = static_cast<unsigned>((g.num_units + wpb - 1) / wpb);
+  const size_t lds = static_cast<size_t>(p.wave_lds_bytes) * wpb;
+  constexpr bool kPrecise = sizeof(DT) == 8;
+  if (backward) {
+    hipLaunchKernelGGL((edge_softmax_merge_kernel<Idx, DT, true, kPrecise>), dim3(blocks),
+                       dim3(64 * wpb), lds, s, p);
+    hipLaunchKernelGGL((edge_softmax_fixup_kernel<Idx, DT, true, kPrecise>),
+                       dim3(static_cast<unsigned>(g.num_units)), dim3(64), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((edge_softmax_merge_kernel<Idx, DT, false, kPrecise>), dim3(blocks),
+                       dim3(64 * wpb), lds, s, p);
+    hipLaunchKernelGGL((edge_softmax_fixup_kernel<Idx, DT, false, kPrecise>),
+                       dim3(static_cast<unsigned>(g.num_units)), dim3(64), 0, s, p);
+  }
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+size_t edge_softmax_workspace_bytes(int64_t num_rows, int64_t nnz, int dtype, int64_t dim) {
+  // lane-group kernel (no scratch) beyond what one wave's LDS slice holds: 16 features with
+  // 4-byte accumulators, 8 with fp64 (2 x 256 x hp x 8 B for the backward pass <= 64 KiB)
+  if (dim < 1 || dim > (dtype == kF64 ? kEsmMaxDim / 2 : kEsmMaxDim)) return 0;
+  return esm_geometry(num_rows, nnz, static_cast<int>(dim), dtype == kF64 ? 8 : 4).total;
+}
+
 template <typename Idx, typename DT>
 static int edge_softmax_run(const CsrView& csr, const void* a, const void* b, void* c, int dim,
                             bool backward, hipStream_t s) {
@@ -184,10 +662,17 @@ static int edge_softmax_run(const CsrView& csr, const void* a, const void* b, vo
 }
 
 int launch_edge_softmax(const CsrView& csr, int dtype, const void* a, const void* b, void* c,
-                        int64_t dim, bool backward, hipStream_t s) {
+                        int64_t dim, bool backward, void* ws, size_t ws_bytes, bool plan_valid,
+                        hipStream_t s) {
   const int d = static_cast<int>(dim);
-#define DGLA_ES(DT)                                                              \
-  return csr.idbits == 32 ? edge_softmax_run<int32_t, DT>(csr, a, b, c, d, backward, s) \
+  const size_t need = edge_softmax_workspace_bytes(csr.num_rows, csr.nnz, dtype, dim);
+  const bool merge = need > 0 && ws != nullptr && ws_bytes >= need;
+#define DGLA_ES(DT)                                                                          \
+  if (merge)                                                                                 \
+    return csr.idbits == 32                                                                  \
+               ? edge_softmax_merge_run<int32_t, DT>(csr, a, b, c, d, backward, ws, plan_valid, s) \
+               : edge_softmax_merge_run<int64_t, DT>(csr, a, b, c, d, backward, ws, plan_valid, s); \
+  return csr.idbits == 32 ? edge_softmax_run<int32_t, DT>(csr, a, b, c, d, backward, s)     \
                           : edge_softmax_run<int64_t, DT>(csr, a, b, c, d, backward, s)
   switch (dtype) {
     case kF32: DGLA_ES(float);

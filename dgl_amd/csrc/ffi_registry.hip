@@ -160,6 +160,10 @@ struct UnitGraph {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   bool plan_valid = false;
+  // scratch of the merge-path edge softmax on `csc` (its own plan: units of 256 items)
+  void* esm_ws = nullptr;
+  size_t esm_ws_bytes = 0;
+  bool esm_plan_valid = false;
 };
 
 static int idbits_of(const DGLArray* t, int* bits) {
@@ -222,7 +226,7 @@ static int set_format(const FfiArgs& a, int which) {
     const int64_t rows = which == 1 ? g->num_src : g->num_dst;
     if (x->shape[0] != rows + 1) return ffi_fail("indptr must have num_rows + 1 entries");
     (which == 1 ? g->csr : g->csc) = f;
-    if (which == 2) g->plan_valid = false;
+    if (which == 2) g->plan_valid = g->esm_plan_valid = false;
   }
   g->num_edges = f.nnz;
   return 0;
@@ -270,6 +274,19 @@ static Registrar r_ws("dgl_amd._CAPI_UnitGraphSetWorkspace", [](const FfiArgs& a
   g->ws = null_array(w) ? nullptr : data_ptr(w);
   g->ws_bytes = null_array(w) ? 0 : static_cast<size_t>(w->shape[0]) * ((w->dtype.bits + 7) / 8);
   g->plan_valid = false;
+  *rtc = kNull;
+  return 0;
+});
+
+static Registrar r_ws2("dgl_amd._CAPI_UnitGraphSetSoftmaxWorkspace",
+                       [](const FfiArgs& a, DGLValue*, int* rtc) {
+  void* h;
+  DGLArray* w;
+  if (get_handle(a, 0, &h) || get_array(a, 1, &w)) return -1;
+  UnitGraph* g = static_cast<UnitGraph*>(h);
+  g->esm_ws = null_array(w) ? nullptr : data_ptr(w);
+  g->esm_ws_bytes = null_array(w) ? 0 : static_cast<size_t>(w->shape[0]) * ((w->dtype.bits + 7) / 8);
+  g->esm_plan_valid = false;
   *rtc = kNull;
   return 0;
 });
@@ -412,6 +429,15 @@ static Registrar r_sddmm("sparse._CAPI_DGLKernelSDDMM", [](const FfiArgs& a, DGL
   return ffi_fail("SDDMM only supports CSR and COO formats");  // kernel.cc:245
 });
 
+// Will this call run the merge-path kernels (and so leave a valid plan in g->esm_ws)?
+static bool esm_uses_workspace(const UnitGraph* g, const dgla_csr& csc, dgla_dtype dt,
+                               const DGLArray* t) {
+  int64_t dim = 1;
+  for (int i = 1; i < t->ndim; ++i) dim *= t->shape[i];
+  const size_t need = dgla_edge_softmax_workspace_bytes(&csc, dt, dim);
+  return need > 0 && g->esm_ws != nullptr && g->esm_ws_bytes >= need;
+}
+
 static int edge_softmax_ffi(const FfiArgs& a, bool backward) {
   void* h;
   const char* op;
@@ -431,14 +457,39 @@ static int edge_softmax_ffi(const FfiArgs& a, bool backward) {
     // (g, op, U(null), E = score, V = out)
     if (null_array(y) || null_array(z)) return g->num_edges == 0 ? 0 : ffi_fail("score / out missing");
     if (float_dtype(y, &dt)) return -1;
-    return dgla_edge_softmax_forward(&csc, dt, &ty.t, &tz.t, tls_stream);
+    const bool merge = esm_uses_workspace(g, csc, dt, y);
+    const int rc = dgla_edge_softmax_forward(&csc, dt, &ty.t, &tz.t, g->esm_ws, g->esm_ws_bytes,
+                                             g->esm_plan_valid ? DGLA_PLAN_VALID : 0, tls_stream);
+    if (rc == 0 && merge) g->esm_plan_valid = true;  // the plan was (re)built in esm_ws
+    return rc;
   }
   // (g, op, out, sds, back_out, ufeat(null))
   if (null_array(x) || null_array(y) || null_array(z))
     return g->num_edges == 0 ? 0 : ffi_fail("out / sds / back missing");
   if (float_dtype(x, &dt)) return -1;
-  return dgla_edge_softmax_backward(&csc, dt, &tx.t, &ty.t, &tz.t, tls_stream);
+  const bool merge = esm_uses_workspace(g, csc, dt, x);
+  const int rc = dgla_edge_softmax_backward(&csc, dt, &tx.t, &ty.t, &tz.t, g->esm_ws,
+                                            g->esm_ws_bytes,
+                                            g->esm_plan_valid ? DGLA_PLAN_VALID : 0, tls_stream);
+  if (rc == 0 && merge) g->esm_plan_valid = true;
+  return rc;
 }
+
+// (g, dim, dtype_bits) -> bytes of scratch the merge-path softmax wants (0: none needed)
+static Registrar r_esw("sparse._CAPI_DGLKernelEdge_softmaxWorkspaceBytes",
+                       [](const FfiArgs& a, DGLValue* ret, int* rtc) {
+  void* h;
+  int64_t dim, bits;
+  if (get_handle(a, 0, &h) || get_int(a, 1, &dim) || get_int(a, 2, &bits)) return -1;
+  UnitGraph* g = static_cast<UnitGraph*>(h);
+  *rtc = kObjectInt;
+  ret->v_int64 = 0;
+  if (!g->csc.present) return 0;
+  const dgla_csr csc = csr_of(g, g->csc, true);
+  ret->v_int64 = static_cast<int64_t>(
+      dgla_edge_softmax_workspace_bytes(&csc, bits == 64 ? DGLA_F64 : DGLA_F32, dim));
+  return 0;
+});
 static Registrar r_esf("sparse._CAPI_DGLKernelEdge_softmax_forward",
                        [](const FfiArgs& a, DGLValue*, int* rtc) {
   *rtc = kNull;

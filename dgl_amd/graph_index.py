@@ -38,6 +38,7 @@ class Relation:
         self.formats = tuple(formats)
         self._handle = None
         self._ws = None
+        self._esm_ws = None
         self._set = set()
         self._rev = None
         self._degs = {}
@@ -131,6 +132,13 @@ class Relation:
             _ffi.get_global_func("dgl_amd._CAPI_UnitGraphSetWorkspace")(
                 self._handle, _ffi.NDArray(self._ws))
 
+    def ensure_softmax_workspace(self, nbytes):
+        """Scratch of the merge-path edge softmax (own plan, kept valid between calls)."""
+        if nbytes and (self._esm_ws is None or self._esm_ws.numel() < nbytes):
+            self._esm_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            _ffi.get_global_func("dgl_amd._CAPI_UnitGraphSetSoftmaxWorkspace")(
+                self._handle, _ffi.NDArray(self._esm_ws))
+
     def __del__(self):
         try:
             if self._handle is not None:
@@ -148,7 +156,7 @@ class Relation:
             r._coo = None if self._coo is None else (self._coo[1], self._coo[0], self._coo[2])
             r._csr, r._csc = self._csc, self._csr
             r.formats = tuple({"csr": "csc", "csc": "csr", "coo": "coo"}[f] for f in self.formats)
-            r._handle, r._ws, r._set, r._degs = None, None, set(), {}
+            r._handle, r._ws, r._esm_ws, r._set, r._degs = None, None, None, set(), {}
             r._rev = self
             self._rev = r
         return self._rev

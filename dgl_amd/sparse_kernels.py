@@ -149,6 +149,17 @@ def _gsddmm(gidx, op, lhs, rhs, lhs_target="u", rhs_target="v"):
     return out
 
 
+def _softmax_scratch(rel, t):
+    """Give the graph handle the scratch the degree-balanced softmax kernels want (the
+    reference would take it from the tensoradapter's workspace pool)."""
+    dim = 1
+    for d in t.shape[1:]:
+        dim *= int(d)
+    nbytes = _call("sparse._CAPI_DGLKernelEdge_softmaxWorkspaceBytes", rel, "csc", dim,
+                   64 if t.dtype == torch.float64 else 32)
+    rel.ensure_softmax_workspace(nbytes)
+
+
 def _edge_softmax_forward(gidx, e, op="copy_rhs"):
     """Fused softmax of edge scores over the incoming edges of each destination node
     (python/dgl/_sparse_ops.py:720-758; CPU-only in the reference)."""
@@ -161,6 +172,7 @@ def _edge_softmax_forward(gidx, e, op="copy_rhs"):
     e = e.contiguous()
     out = torch.empty_like(e)
     if gidx.num_edges(0) > 0 and e.numel() > 0:
+        _softmax_scratch(rel, e)
         _call("sparse._CAPI_DGLKernelEdge_softmax_forward", rel, "csc", op, None, _nd(e), _nd(out))
     return out.squeeze(-1) if expand else out
 
@@ -174,6 +186,7 @@ def _edge_softmax_backward(gidx, out, sds):
     out, sds = out.contiguous(), sds.contiguous()
     back = torch.empty_like(out)
     if gidx.num_edges(0) > 0 and out.numel() > 0:
+        _softmax_scratch(rel, out)
         _call("sparse._CAPI_DGLKernelEdge_softmax_backward", rel, "csc", "copy_rhs", _nd(out),
               _nd(sds), _nd(back), None)
     return back.squeeze(-1) if expand else back

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DGLA_ABI_VERSION 1
+#define DGLA_ABI_VERSION 2
 
 /* Feature element types (DGLDataType {code,bits}: float32/64, float16, bfloat16 —
  * ATEN_FLOAT_TYPE_SWITCH_16BITS, include/dgl/aten/macro.h:137-166). */
@@ -127,12 +127,19 @@ int dgla_sddmm_csr(const char* op, const dgla_csr* csr, dgla_dtype dtype,
  * src/array/kernel.cc:542-561; GPU is a TODO at kernel.cc:313,331 and runs 5 kernels,
  * python/dgl/backend/pytorch/sparse.py:709-713).
  *   score / out / grad tensors: [nnz, ...] indexed by edge id.
+ *   workspace  optional device scratch of dgla_edge_softmax_workspace_bytes() bytes: with it
+ *              (and a feature length <= 16) the degree-balanced merge-path kernels run and
+ *              hub rows cost no more than any other 256 edges; without it (NULL / 0) a
+ *              row-per-lane-group kernel needing no scratch is used.  DGLA_PLAN_VALID in
+ *              `flags`: the workspace still holds the plan of an earlier call on this csr.
  */
+size_t dgla_edge_softmax_workspace_bytes(const dgla_csr* csr, dgla_dtype dtype, int64_t dim);
 int dgla_edge_softmax_forward(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* score,
-                              const dgla_tensor* out, void* hip_stream);
+                              const dgla_tensor* out, void* workspace, size_t workspace_bytes,
+                              uint32_t flags, void* hip_stream);
 int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* out,
-                               const dgla_tensor* sds, const dgla_tensor* back,
-                               void* hip_stream);
+                               const dgla_tensor* sds, const dgla_tensor* back, void* workspace,
+                               size_t workspace_bytes, uint32_t flags, void* hip_stream);
 
 /* Benchmark hook: when both are non-NULL (hipEvent_t), the calling thread's next
  * dgla_spmm_csr calls record `before` / `after` on the launch stream around the dominant

@@ -116,12 +116,20 @@ def _gpu_run(dev, c):
         keep = (t(c["indptr"]), t(c["indices"]), t(c["eids"]))
         csr = _capi.make_csr(keep[0], keep[1], keep[2], int(c["indices"].max()) + 1)
         score = t(c["score"])
-        out = torch.empty_like(score)
-        _capi.edge_softmax_forward(csr, score, out)
-        sds = out * t(c["grad"])
-        back = torch.empty_like(score)
-        _capi.edge_softmax_backward(csr, out, sds, back)
-        return {"out": out.cpu().numpy(), "back": back.cpu().numpy()}
+        dim = int(np.prod(score.shape[1:]))
+        ws = torch.empty(_capi.edge_softmax_workspace_bytes(csr, score.dtype, dim), dtype=torch.uint8,
+                         device=dev)
+        res = {}
+        for tag, w in (("", None), ("_merge", ws)):   # lane-group kernel, then merge-path pair
+            out = torch.empty_like(score)
+            _capi.edge_softmax_forward(csr, score, out, w)
+            sds = out * t(c["grad"])
+            back = torch.empty_like(score)
+            _capi.edge_softmax_backward(csr, out, sds, back, w, plan_valid=w is not None)
+            res["out" + tag], res["back" + tag] = out.cpu().numpy(), back.cpu().numpy()
+        assert np.allclose(res["out"], res["out_merge"], rtol=1e-5, atol=1e-7)
+        assert np.allclose(res["back"], res["back_merge"], rtol=1e-4, atol=1e-6)
+        return {"out": res["out_merge"], "back": res["back_merge"]}
     raise ValueError(k)
 
 

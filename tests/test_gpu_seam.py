@@ -354,7 +354,8 @@ def test_spmm_coo(dev, op, reduce):
 
 
 @pytest.mark.parametrize("heads", [1, 4, 8])
-def test_edge_softmax_fused(dev, heads):
+@pytest.mark.parametrize("merge", [False, True])
+def test_edge_softmax_fused(dev, heads, merge):
     from dgl_amd import _capi
 
     n_src, n_dst, src, dst = _edge_case_graphs()["mixed"]
@@ -368,10 +369,12 @@ def test_edge_softmax_fused(dev, heads):
     keep = (t(indptr), t(indices), t(eids))
     csr = _capi.make_csr(keep[0], keep[1], keep[2], n_src)
     out = torch.empty_like(t(score))
-    _capi.edge_softmax_forward(csr, t(score), out)
+    ws = torch.empty(_capi.edge_softmax_workspace_bytes(csr, out.dtype, heads), dtype=torch.uint8,
+                     device=dev) if merge else None
+    _capi.edge_softmax_forward(csr, t(score), out, ws)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-7)
     back = torch.empty_like(out)
-    _capi.edge_softmax_backward(csr, t(ref), t(ref * grad), back)
+    _capi.edge_softmax_backward(csr, t(ref), t(ref * grad), back, ws, plan_valid=merge)
     np.testing.assert_allclose(back.cpu().numpy(), ref_b, rtol=1e-5, atol=1e-6)
 
 
@@ -502,10 +505,16 @@ def test_sddmm_dot_any_width(dev, hd):
     (40, 30000, 4),       # rows of ~750 edges: far beyond the register cache
     (300, 9000, 70),      # dim > 64: feature loop
     (1000, 16000, 3),     # non power-of-two dim: idle feature lanes
+    (3, 20000, 8),        # three hub rows spanning ~25 merge units each
+    (5000, 200, 2),       # almost all rows empty
+    (700, 40000, 16),     # widest merge-path case
 ])
 @pytest.mark.parametrize("idtype", [np.int32, np.int64])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_edge_softmax_geometries(dev, n_dst, n_edges, dim, idtype, dtype):
+@pytest.mark.parametrize("merge", [False, True])
+def test_edge_softmax_geometries(dev, n_dst, n_edges, dim, idtype, dtype, merge):
+    """merge=True hands the kernels a workspace: the degree-balanced merge-path pair runs
+    (for dim <= 16; fp64: <= 8), otherwise the scratch-free lane-group kernel."""
     from dgl_amd import _capi
 
     rng = np.random.default_rng(n_edges)
@@ -514,18 +523,30 @@ def test_edge_softmax_geometries(dev, n_dst, n_edges, dim, idtype, dtype):
     indptr, indices, eids = coo_to_csc(src, dst, n_dst, idtype)
     score = (rng.standard_normal((n_edges, dim)) * 4).astype(dtype)
     grad = rng.standard_normal((n_edges, dim)).astype(dtype)
-    ref = oracle.edge_softmax_fwd(indptr, eids, score)
-    ref_b = oracle.edge_softmax_bwd(indptr, eids, ref, ref * grad)
+    # exact reference: the oracle in fp64 on the same inputs (the reference's own fp32 loop
+    # carries ~degree * 2^-24 of rounding in its sequential sums; rows here reach 7k edges)
+    ref = oracle.edge_softmax_fwd(indptr, eids, score.astype(np.float64)).astype(dtype)
+    ref_b = oracle.edge_softmax_bwd(indptr, eids, ref.astype(np.float64),
+                                    ref.astype(np.float64) * grad).astype(dtype)
     t = lambda a: torch.from_numpy(a).to(dev)
     keep = (t(indptr), t(indices), t(eids))
     csr = _capi.make_csr(keep[0], keep[1], keep[2], 50)
     ts = t(score)
+    ws = None
+    if merge:
+        nbytes = _capi.edge_softmax_workspace_bytes(csr, ts.dtype, dim)
+        assert (nbytes > 0) == (dim <= (8 if dtype == np.float64 else 16))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
     out = torch.full_like(ts, 7.0)
-    _capi.edge_softmax_forward(csr, ts, out)
+    _capi.edge_softmax_forward(csr, ts, out, ws)
     tol = dict(rtol=2e-5, atol=1e-7) if dtype == np.float32 else dict(rtol=1e-11, atol=1e-14)
     np.testing.assert_allclose(out.cpu().numpy(), ref, **tol)
+    if merge:  # cached plan: identical bits
+        out2 = torch.full_like(ts, 5.0)
+        _capi.edge_softmax_forward(csr, ts, out2, ws, plan_valid=True)
+        assert torch.equal(out, out2)
     back = torch.full_like(ts, 7.0)
-    _capi.edge_softmax_backward(csr, t(ref), t(ref * grad), back)
+    _capi.edge_softmax_backward(csr, t(ref), t(ref * grad), back, ws, plan_valid=merge)
     np.testing.assert_allclose(back.cpu().numpy(), ref_b, rtol=tol["rtol"] * 10, atol=1e-6 if dtype == np.float32 else 1e-13)
     # softmax rows sum to one (size-independent property)
     rows = np.repeat(np.arange(n_dst), np.diff(indptr))
