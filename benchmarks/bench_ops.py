@@ -182,6 +182,20 @@ def c5(dev, args):
     s, i = 2, 4
     nb = r * (e * (f * s + i) + (n + 1) * i + 2 * n * f * s) + n * f * s
     emit("C5", "hetero copy_u_sum, 8 relations accumulate, bf16 F=256", r * e, ms, mn, nb)
+    # the same reduction as ONE launch over the row-wise stacked CSR (dgla_spmm_csr_stacked)
+    from dgl_amd.graph_index import stack_csc
+    indptr, indices, eids, relid = stack_csc([(g["indptr"], g["indices"], None) for g, _, _ in rel], n,
+                                             torch.int32)
+    scsr = _capi.make_csr(indptr, indices, eids, n)
+    xs = [x] * r
+    sws = torch.empty(_capi.spmm_csr_stacked_workspace_bytes("copy_lhs", scsr, x, None, out),
+                      dtype=torch.uint8, device=dev)
+    tabs = _capi.spmm_csr_stacked("copy_lhs", scsr, relid, xs, None, out, sws)
+    ms, mn = timeit(lambda: _capi.spmm_csr_stacked("copy_lhs", scsr, relid, xs, None, out, sws,
+                                                   u_table=tabs[0], plan_valid=True), reps=5, warm=2)
+    nb1 = r * e * (f * s + i + 1) + (n + 1) * i + n * f * s
+    emit("C5", "hetero copy_u_sum, 8 relations in ONE stacked launch, bf16 F=256", r * e, ms, mn, nb1)
+    del indptr, indices, eids, relid, sws
     g, csr, ws = rel[0]
     o1 = torch.empty_like(out)
     ms, mn = timeit(lambda: _capi.spmm_csr("copy_lhs", "sum", csr, x, None, o1, None, None, ws, plan_valid=True), reps=5)

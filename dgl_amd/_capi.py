@@ -86,6 +86,43 @@ def spmm_csr(op, reduce, csr, ufeat, efeat, out, arg_u=None, arg_e=None, workspa
         _stream(out)))
 
 
+def pointer_table(tensors, device):
+    """Device array of the tensors' data pointers (int64), as dgla_spmm_csr_stacked wants."""
+    return torch.tensor([0 if t is None else t.data_ptr() for t in tensors], dtype=torch.int64,
+                        device=device)
+
+
+def spmm_csr_stacked_workspace_bytes(op, csr, ufeat0, efeat0, out):
+    keep = []
+    tu, te, to = _tensor(ufeat0, keep), _tensor(efeat0, keep), _tensor(out, keep)
+    return LIB.dgla_spmm_csr_stacked_workspace_bytes(op.encode(), ctypes.byref(csr),
+                                                     _DTYPES[out.dtype], ctypes.byref(tu),
+                                                     ctypes.byref(te), ctypes.byref(to))
+
+
+def spmm_csr_stacked(op, csr, rel, ufeats, efeats, out, workspace, u_table=None, e_table=None,
+                     accumulate=False, plan_valid=False):
+    """Fused sum over several relations (SpMMCsrHetero in one launch).  `csr` is the stacked
+    matrix, `rel` the uint8 relation id per stacked edge, `ufeats` / `efeats` lists with one
+    tensor per relation (or None when the operator does not read that side)."""
+    keep = []
+    u0 = None if ufeats is None else ufeats[0]
+    e0 = None if efeats is None else efeats[0]
+    tu, te, to = _tensor(u0, keep), _tensor(e0, keep), _tensor(out, keep)
+    if u_table is None and ufeats is not None:
+        u_table = pointer_table(ufeats, out.device)
+    if e_table is None and efeats is not None:
+        e_table = pointer_table(efeats, out.device)
+    n_rel = len(ufeats if ufeats is not None else efeats)
+    flags = (_lib.DGLA_ACCUMULATE if accumulate else 0) | (_lib.DGLA_PLAN_VALID if plan_valid else 0)
+    check_call(LIB.dgla_spmm_csr_stacked(
+        op.encode(), ctypes.byref(csr), rel.data_ptr(), n_rel, _DTYPES[out.dtype], ctypes.byref(tu),
+        ctypes.byref(te), _ptr(u_table), _ptr(e_table), ctypes.byref(to), _ptr(workspace),
+        0 if workspace is None else workspace.numel() * workspace.element_size(), flags,
+        _stream(out)))
+    return u_table, e_table
+
+
 def spmm_coo(op, reduce, coo, ufeat, efeat, out, arg_u=None, arg_e=None):
     keep = []
     tu, te, to = _tensor(ufeat, keep), _tensor(efeat, keep), _tensor(out, keep)

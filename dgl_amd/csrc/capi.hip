@@ -327,6 +327,72 @@ int dgla_spmm_csr(const char* op, const char* reduce, const dgla_csr* csr, dgla_
   return fail("unsupported feature dtype");
 }
 
+// Shapes are taken from relation 0's operands; every relation must use the same feature
+// shape (src/array/kernel.cc:194-199).  The first dimensions of ufeat0 / efeat0 are not
+// comparable with the stacked matrix (each relation has its own node and edge counts), so
+// they are aligned with it before the common checks.
+static int build_stacked_launch(const char* op, const dgla_csr* csr, dgla_dtype dtype,
+                                const dgla_tensor* ufeat0, const dgla_tensor* efeat0,
+                                const dgla_tensor* out, SpmmLaunch* L) {
+  if (!csr) return fail("csr is null");
+  dgla_csr c = *csr;
+  const int opc = parse_op(op, false);
+  if (opc < 0) return fail(std::string("Unsupported SpMM binary operator: ") + (op ? op : "(null)"));
+  if (op_uses_lhs(opc) && present(ufeat0)) c.num_cols = ufeat0->shape[0];
+  dgla_tensor e0{nullptr, 0, nullptr};
+  std::vector<int64_t> eshape;
+  if (op_uses_rhs(opc)) {
+    if (!present(efeat0)) return fail("operator needs the edge feature (efeat)");
+    eshape.assign(efeat0->shape, efeat0->shape + efeat0->ndim);
+    eshape[0] = c.nnz;
+    e0 = dgla_tensor{efeat0->data, efeat0->ndim, eshape.data()};
+  }
+  return build_spmm_launch(op, "sum", &c, dtype, ufeat0, &e0, out, L);
+}
+
+size_t dgla_spmm_csr_stacked_workspace_bytes(const char* op, const dgla_csr* csr,
+                                             dgla_dtype dtype, const dgla_tensor* ufeat0,
+                                             const dgla_tensor* efeat0, const dgla_tensor* out) {
+  SpmmLaunch L{};
+  if (build_stacked_launch(op, csr, dtype, ufeat0, efeat0, out, &L)) return 0;
+  switch (dtype) {
+    case DGLA_F32: return spmm_csr_workspace_f32(L);
+    case DGLA_F64: return spmm_csr_workspace_f64(L);
+    case DGLA_F16: return spmm_csr_workspace_f16(L);
+    case DGLA_BF16: return spmm_csr_workspace_bf16(L);
+  }
+  return 0;
+}
+
+int dgla_spmm_csr_stacked(const char* op, const dgla_csr* csr, const void* rel, int num_rel,
+                          dgla_dtype dtype, const dgla_tensor* ufeat0, const dgla_tensor* efeat0,
+                          const void* const* ufeat_ptrs, const void* const* efeat_ptrs,
+                          const dgla_tensor* out, void* workspace, size_t workspace_bytes,
+                          uint32_t flags, void* hip_stream) {
+  if (!rel) return fail("rel is null");
+  if (num_rel < 1 || num_rel > 256) return fail("num_rel must be in [1, 256]");
+  SpmmLaunch L{};
+  if (build_stacked_launch(op, csr, dtype, ufeat0, efeat0, out, &L)) return -1;
+  if (op_uses_lhs(L.op) && !ufeat_ptrs) return fail("ufeat_ptrs is null");
+  if (op_uses_rhs(L.op) && !efeat_ptrs) return fail("efeat_ptrs is null");
+  L.rel = rel;
+  L.ufeat_tab = ufeat_ptrs;
+  L.efeat_tab = efeat_ptrs;
+  L.accumulate = (flags & DGLA_ACCUMULATE) != 0;
+  L.plan_valid = (flags & DGLA_PLAN_VALID) != 0;
+  L.workspace = workspace;
+  L.workspace_bytes = workspace_bytes;
+  L.stream = static_cast<hipStream_t>(hip_stream);
+  if (csr->num_rows == 0 || L.out_len == 0) return 0;
+  switch (dtype) {
+    case DGLA_F32: return launch_spmm_csr_f32(L);
+    case DGLA_F64: return launch_spmm_csr_f64(L);
+    case DGLA_F16: return launch_spmm_csr_f16(L);
+    case DGLA_BF16: return launch_spmm_csr_bf16(L);
+  }
+  return fail("unsupported feature dtype");
+}
+
 int dgla_spmm_coo(const char* op_s, const char* red_s, const dgla_coo* coo, dgla_dtype dtype,
                   const dgla_tensor* ufeat, const dgla_tensor* efeat, const dgla_tensor* out,
                   void* arg_u, void* arg_e, void* hip_stream) {

@@ -143,6 +143,12 @@ struct SpmmLaunch {
   int bcast;      // Bcast
   int rhs_group;  // kBcRhsGroup: consecutive outputs sharing one rhs element
   BcastDims bdims;
+  // Stacked multi-relation form (dgla_spmm_csr_stacked): the CSR is the row-wise
+  // concatenation of several relations; rel[j] names the relation of edge j and
+  // ufeat_tab / efeat_tab (device arrays of device pointers) hold each relation's operands.
+  const void* rel;               // uint8 [nnz] or nullptr (single relation)
+  const void* const* ufeat_tab;  // [num_rel]
+  const void* const* efeat_tab;  // [num_rel]
   bool accumulate;  // out += result (reference semantics, spmm.cuh:528-534) vs out = result
   bool plan_valid;  // workspace already holds the merge plan of this CSR
   void* workspace;

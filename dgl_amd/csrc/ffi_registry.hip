@@ -390,6 +390,63 @@ static Registrar r_spmm_acc("sparse._CAPI_DGLKernelSpMMAccumulate",
   return rc;
 });
 
+// Fused sum over the relations sharing one destination node type (SpMMCsrHetero,
+// src/array/kernel.cc:173-221 / spmm_hetero.cu:26-200, in ONE launch).
+//   (g_stacked, op, U0, E0, Utab, Etab, V, rel [, want_bytes])
+// g_stacked: unit graph whose CSC is the row-wise concatenation of the relations' CSCs
+// (dgl_amd/graph_index.py:stack_csc); U0 / E0: relation 0's operands (shapes); Utab / Etab:
+// int64 arrays of each relation's operand device pointers; rel: uint8 relation id per edge.
+static int spmm_stacked_ffi(const FfiArgs& a, DGLValue* ret, int* rtc, bool want_bytes) {
+  void* h;
+  const char* op;
+  DGLArray *U0, *E0, *Ut, *Et, *V, *rel;
+  if (get_handle(a, 0, &h) || get_str(a, 1, &op) || get_array(a, 2, &U0) || get_array(a, 3, &E0) ||
+      get_array(a, 4, &Ut) || get_array(a, 5, &Et) || get_array(a, 6, &V) || get_array(a, 7, &rel))
+    return -1;
+  UnitGraph* g = static_cast<UnitGraph*>(h);
+  if (!g->csc.present) return ffi_fail("stacked SpMM needs the CSC format");
+  if (null_array(V)) return ffi_fail("out array is empty");
+  dgla_dtype dt;
+  if (float_dtype(V, &dt)) return -1;
+  for (const DGLArray* t : {U0, E0}) {
+    dgla_dtype d;
+    if (null_array(t)) continue;
+    if (!on_gpu(t)) return ffi_fail("operand is not on the GPU device of the graph");
+    if (check_contiguous(t, "operand") || float_dtype(t, &d)) return -1;
+    if (d != dt) return ffi_fail("operand and output dtypes differ");
+  }
+  TensorArg u, e, v;
+  to_tensor(U0, &u);
+  to_tensor(E0, &e);
+  to_tensor(V, &v);
+  const dgla_csr csc = csr_of(g, g->csc, true);
+  if (want_bytes) {
+    *rtc = kObjectInt;
+    last_error().clear();
+    ret->v_int64 = static_cast<int64_t>(
+        dgla_spmm_csr_stacked_workspace_bytes(op, &csc, dt, &u.t, &e.t, &v.t));
+    return last_error().empty() ? 0 : -1;
+  }
+  *rtc = kNull;
+  if (null_array(rel) || rel->dtype.bits != 8) return ffi_fail("rel must be a uint8 array");
+  const int64_t n_rel = !null_array(Ut) ? Ut->shape[0] : (!null_array(Et) ? Et->shape[0] : 0);
+  const int rc = dgla_spmm_csr_stacked(
+      op, &csc, data_ptr(rel), static_cast<int>(n_rel), dt, &u.t, &e.t,
+      null_array(Ut) ? nullptr : static_cast<const void* const*>(data_ptr(Ut)),
+      null_array(Et) ? nullptr : static_cast<const void* const*>(data_ptr(Et)), &v.t, g->ws,
+      g->ws_bytes, g->plan_valid ? DGLA_PLAN_VALID : 0, tls_stream);
+  if (rc == 0) g->plan_valid = true;
+  return rc;
+}
+static Registrar r_stk("sparse._CAPI_DGLKernelSpMMStacked",
+                       [](const FfiArgs& a, DGLValue* ret, int* rtc) {
+  return spmm_stacked_ffi(a, ret, rtc, false);
+});
+static Registrar r_stkw("sparse._CAPI_DGLKernelSpMMStackedWorkspaceBytes",
+                        [](const FfiArgs& a, DGLValue* ret, int* rtc) {
+  return spmm_stacked_ffi(a, ret, rtc, true);
+});
+
 static Registrar r_sddmm("sparse._CAPI_DGLKernelSDDMM", [](const FfiArgs& a, DGLValue*, int* rtc) {
   *rtc = kNull;
   void* h;

@@ -43,6 +43,10 @@ struct SpmmParams {
   int rhs_group;  // kBcRhsGroup
   BcastDims bd;   // kBcGeneral
   int accumulate;
+  // stacked multi-relation form (MULTI kernels only)
+  const uint8_t* rel;
+  const void* const* xtab;
+  const void* const* wtab;
   // fix-up workspace, one slot per lane group: slot = wave * G + group
   int64_t* carry_row;  // row id of the slot's carry-out, or -1
   void* carry_val;     // [slots, out_len] accumulator type: head part of a straddling row
@@ -99,7 +103,12 @@ __device__ __forceinline__ typename Acc<DT>::type round_to_storage(typename Acc<
     return v;
 }
 
-template <typename Idx, typename DT, int VEC, int OP, int RED, int BC, int U, bool ACCUM>
+// MULTI: the CSR is a row-wise concatenation of several relations (SpMMCsrHetero's sum over
+// relations sharing a destination type, src/array/cuda/spmm_hetero.cu:150-158, fused into
+// one launch): every edge carries its relation id, and the relation's operand base pointers
+// are staged in LDS next to the column ids, so the gather loop reads (column, base) pairs.
+template <typename Idx, typename DT, int VEC, int OP, int RED, int BC, int U, bool ACCUM,
+          bool MULTI = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
     const SpmmParams<Idx> p) {
   using A = typename Acc<DT>::type;
@@ -111,6 +120,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   __shared__ int s_cols[kWavesPerBlock][kWaveItems];
   __shared__ int s_rend[kWavesPerBlock][kWaveItems + 2];
   __shared__ Idx s_eid[UR ? kWavesPerBlock : 1][UR ? kWaveItems : 1];
+  __shared__ const DT* s_xb[(MULTI && UL) ? kWavesPerBlock : 1][(MULTI && UL) ? kWaveItems : 1];
+  __shared__ const DT* s_wb[(MULTI && UR) ? kWavesPerBlock : 1][(MULTI && UR) ? kWaveItems : 1];
 
   const int wib = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
@@ -138,12 +149,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
     if (items > 0) {
       Idx itemv[kWaveItems / 64];
       Idx eidv[kWaveItems / 64];
+      uint8_t relv[MULTI ? kWaveItems / 64 : 1];
 #pragma unroll
       for (int k = 0; k < kWaveItems / 64; ++k) {
         int it = lane + 64 * k;
         if (it >= items) it = items - 1;
         const Idx* src = it < nE ? p.indices + (j0 + it) : p.indptr + (i0 + 1 + (it - nE));
         itemv[k] = *src;
+        if constexpr (MULTI) relv[k] = it < nE ? p.rel[j0 + it] : uint8_t(0);
         if constexpr (UR) {
           if (has_eid) {
             const int ie = it < nE ? it : (nE > 0 ? nE - 1 : 0);
@@ -158,6 +171,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
         if (it < nE) {
           s_cols[wib][it] = static_cast<int>(itemv[k]);
           if constexpr (UR) s_eid[wib][it] = has_eid ? eidv[k] : static_cast<Idx>(j0 + it);
+          if constexpr (MULTI && UL) s_xb[wib][it] = static_cast<const DT*>(p.xtab[relv[k]]);
+          if constexpr (MULTI && UR) s_wb[wib][it] = static_cast<const DT*>(p.wtab[relv[k]]);
         } else if (it < items) {
           s_rend[wib][it - nE + 1] = static_cast<int>(static_cast<int64_t>(itemv[k]) - j0);
         }
@@ -225,11 +240,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
       if (ee >= e_e) ee = e_e - 1;  // clamp: re-load a valid edge, ignored when reducing
       if constexpr (UL) {
         const int64_t c = cols[ee];
-        b.x[u] = *reinterpret_cast<const XV*>(X + c * lhs_len);
+        const DT* xb = X;
+        if constexpr (MULTI) xb = s_xb[wib][ee] + lo_off;
+        b.x[u] = *reinterpret_cast<const XV*>(xb + c * lhs_len);
       }
       if constexpr (UR) {
         const int64_t eid = static_cast<int64_t>(eidl[ee]);
-        b.w[u] = *reinterpret_cast<const WV*>(Wt + eid * rhs_len);
+        const DT* wb = Wt;
+        if constexpr (MULTI) wb = s_wb[wib][ee] + ro_off;
+        b.w[u] = *reinterpret_cast<const WV*>(wb + eid * rhs_len);
       }
     }
   };
@@ -511,6 +530,9 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.rhs_group = L.rhs_group > 0 ? L.rhs_group : 1;
   p.bd = L.bdims;
   p.accumulate = L.accumulate ? 1 : 0;
+  p.rel = static_cast<const uint8_t*>(L.rel);
+  p.xtab = L.ufeat_tab;
+  p.wtab = L.efeat_tab;
   p.carry_row = reinterpret_cast<int64_t*>(ws + g.off_carry_row);
   p.carry_val = ws + g.off_carry_val;
   p.tail_val = ws + g.off_tail_val;
@@ -531,7 +553,21 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
       static_cast<unsigned>((g.num_waves + kWavesPerBlock - 1) / kWavesPerBlock);
   const ProfileEvents pe = profile_events();
   if (pe.before) DGLA_CHECK_HIP(hipEventRecord(pe.before, L.stream));
-  if constexpr (RED == kSum) {
+  if (L.rel != nullptr) {
+    // stacked multi-relation launch: the operator subset the fused hetero path uses
+    if constexpr (RED == kSum && (OP == kCopyLhs || OP == kCopyRhs || OP == kMul) &&
+                  BC != kBcGeneral) {
+      if (L.accumulate)
+        hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, true, true>),
+                           dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
+      else
+        hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false, true>),
+                           dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
+    } else {
+      last_error() = "stacked SpMM supports copy_lhs / copy_rhs / mul with reduce sum only";
+      return -1;
+    }
+  } else if constexpr (RED == kSum) {
     if (L.accumulate)
       hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, true>),
                          dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);

@@ -184,6 +184,36 @@ class Relation:
         return r
 
 
+def stack_csc(cscs, num_rows, idtype):
+    """Row-wise concatenation of several in-edge CSRs over the same destination nodes: row r
+    lists relation 0's edges into r, then relation 1's, ...  Returns
+    ``(indptr, indices, eids, rel)`` with ``eids`` = relation-local edge id and ``rel`` = uint8
+    relation index of every stacked position.  Done once per (graph, relation set) with torch
+    primitives and cached, like the reference's lazily built CSC (unit_graph.cc:1418-1450)."""
+    dev = cscs[0][0].device
+    degs = [(ip[1:] - ip[:-1]).long() for ip, _, _ in cscs]
+    total = torch.stack(degs).sum(0)
+    indptr = torch.zeros(num_rows + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(total, 0, out=indptr[1:])
+    nnz = int(indptr[-1])
+    indices = torch.empty(nnz, dtype=idtype, device=dev)
+    eids = torch.empty(nnz, dtype=idtype, device=dev)
+    rel = torch.empty(nnz, dtype=torch.uint8, device=dev)
+    before = torch.zeros(num_rows, dtype=torch.int64, device=dev)
+    rows = torch.arange(num_rows, device=dev)
+    for k, ((ip, ix, ei), deg) in enumerate(zip(cscs, degs)):
+        n_k = int(ix.shape[0])
+        if n_k == 0:
+            continue
+        r = torch.repeat_interleave(rows, deg)
+        pos = (indptr[:-1] + before)[r] + (torch.arange(n_k, device=dev) - ip.long()[r])
+        indices[pos] = ix
+        eids[pos] = ei if ei is not None else torch.arange(n_k, dtype=idtype, device=dev)
+        rel[pos] = k
+        before += deg
+    return indptr.to(idtype), indices, eids, rel
+
+
 class MetaGraph:
     def __init__(self, edges):
         self.edges = list(edges)  # etype id -> (src ntype id, dst ntype id)
@@ -200,6 +230,21 @@ class GraphIndex:
         self.metagraph = MetaGraph(meta_edges)
         self.relations = list(relations)
         self._rev = None
+        self._stacked = {}
+
+    def stacked(self, etypes):
+        """(Relation over the stacked CSC, uint8 rel array) for relations `etypes`, which must
+        share their destination node type; built on first use and cached."""
+        key = tuple(etypes)
+        if key not in self._stacked:
+            d = self.metagraph.find_edge(key[0])[1]
+            rels = [self.relations[et] for et in key]
+            n = self._num_nodes[d]
+            indptr, indices, eids, rel = stack_csc([r.csc() for r in rels], n, rels[0].idtype)
+            stk = Relation(max(r.num_src for r in rels), n, csc=(indptr, indices, eids),
+                           idtype=rels[0].idtype, device=rels[0].device, formats=("csc",))
+            self._stacked[key] = (stk, rel)
+        return self._stacked[key]
 
     def number_of_etypes(self):
         return len(self.relations)

@@ -209,8 +209,11 @@ def _gspmm_hetero(gidx, op, reduce_op, u_len, u_and_e_tuple):
     arg_u_nt, arg_e_et = [None] * n_nt, [None] * n_nt
     use_cmp = reduce_op in ("max", "min")
     feat_shape = {}
+    fused = _fused_hetero_sum(gidx, op, reduce_op, u_tuple, e_tuple, outs)
     for et in range(n_et):
         s, d = gidx.metagraph.find_edge(et)
+        if d in fused:
+            continue
         u = u_tuple[s] if use_u else None
         e = e_tuple[et] if use_e else None
         if (use_u and u is None) or (use_e and e is None):
@@ -259,6 +262,64 @@ def _gspmm_hetero(gidx, op, reduce_op, u_len, u_and_e_tuple):
                     arg_e[d] = torch.where(better, ae, arg_e[d])
                     arg_e_et[d] = torch.where(better, torch.full_like(ae, et), arg_e_et[d])
     return tuple(outs), (arg_u, arg_e, arg_u_nt, arg_e_et)
+
+
+_FUSED_OPS = ("copy_lhs", "copy_rhs", "mul")
+
+
+def _fused_hetero_sum(gidx, op, reduce_op, u_tuple, e_tuple, outs):
+    """Destination node types whose relations are reduced by ONE stacked launch
+    (sparse._CAPI_DGLKernelSpMMStacked) instead of the reference's per-relation accumulate
+    loop.  Fills ``outs[d]`` for those types and returns their set; everything it does not
+    take (max/min, other operators, mixed shapes, COO-only graphs, a single relation) is left
+    to the sequential path."""
+    done = set()
+    if reduce_op != "sum" or op not in _FUSED_OPS:
+        return done
+    use_u, use_e = op != "copy_rhs", op != "copy_lhs"
+    by_dst = {}
+    for et in range(gidx.number_of_etypes()):
+        s, d = gidx.metagraph.find_edge(et)
+        u = u_tuple[s] if use_u else None
+        e = e_tuple[et] if use_e else None
+        if (use_u and u is None) or (use_e and e is None) or gidx.num_edges(et) == 0:
+            continue
+        by_dst.setdefault(d, []).append((et, u, e))
+    for d, items in by_dst.items():
+        if len(items) < 2 or len(items) > 255:
+            continue
+        us = [u for _, u, _ in items]
+        es = [e for _, _, e in items]
+        ref = us[0] if use_u else es[0]
+        same = lambda ts: all(t.shape[1:] == ts[0].shape[1:] and t.dtype == ts[0].dtype and
+                              t.dim() >= 2 for t in ts)
+        if (use_u and not same(us)) or (use_e and not same(es)):
+            continue
+        if use_u and use_e and us[0].dtype != es[0].dtype:
+            continue
+        if not all(gidx.relations[et].allowed("csc") for et, _, _ in items):
+            continue
+        # only the broadcast forms the stacked kernels implement: equal shapes or (..,H,D)x(..,H,1)
+        if use_u and use_e:
+            a, b = tuple(us[0].shape[1:]), tuple(es[0].shape[1:])
+            if a != b and not (len(a) == len(b) and a[:-1] == b[:-1] and b[-1] == 1):
+                continue
+        stk, rel = gidx.stacked([et for et, _, _ in items])
+        o_feat = infer_broadcast_shape(op, tuple(us[0].shape[1:]) if use_u else (),
+                                       tuple(es[0].shape[1:]) if use_e else ())
+        v = torch.empty((gidx.num_nodes(d),) + o_feat, dtype=ref.dtype, device=ref.device)
+        us_c = [u.contiguous() for u in us] if use_u else None
+        es_c = [e.contiguous() for e in es] if use_e else None
+        table = lambda ts: None if ts is None else _nd(torch.tensor(
+            [t.data_ptr() for t in ts], dtype=torch.int64, device=ref.device))
+        args = (op, _nd(us_c[0]) if use_u else None, _nd(es_c[0]) if use_e else None,
+                table(us_c), table(es_c), _nd(v), _ffi.NDArray(rel))
+        nbytes = _call("sparse._CAPI_DGLKernelSpMMStackedWorkspaceBytes", stk, "csc", *args)
+        stk.ensure_workspace(nbytes)
+        _call("sparse._CAPI_DGLKernelSpMMStacked", stk, "csc", *args)
+        outs[d] = v
+        done.add(d)
+    return done
 
 
 def _gsddmm_hetero(gidx, op, lhs_len, lhs_target, rhs_target, lhs_and_rhs_tuple):

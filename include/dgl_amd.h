@@ -97,6 +97,31 @@ size_t dgla_spmm_csr_workspace_bytes(const char* op, const char* reduce, const d
                                      const dgla_tensor* efeat, const dgla_tensor* out);
 
 /*
+ * Multi-relation g-SpMM with reduce = sum in ONE launch.  Replaces the per-relation loop of
+ * SpMMCsrHetero<kDGLCUDA,...> (src/array/cuda/spmm_hetero.cu:26-200), which launches one
+ * accumulating kernel per edge type and so re-reads and re-writes the destination buffer
+ * once per relation.
+ *   csr         row-wise concatenation ("stack") of the in-edge CSRs of all relations that
+ *               share the destination node type: row r lists relation 0's edges into r, then
+ *               relation 1's, ...; `data` maps a stacked position to the relation-local edge id.
+ *   rel         uint8 [nnz]: relation index of every stacked edge, in [0, num_rel)
+ *   ufeat0 / efeat0   relation 0's operands (feature shapes are taken from them; all
+ *               relations must agree, src/array/kernel.cc:194-199)
+ *   ufeat_ptrs / efeat_ptrs   DEVICE arrays of num_rel device pointers: each relation's
+ *               source-node / edge feature tensor (NULL when the operator does not use it)
+ *   op          "copy_lhs" | "copy_rhs" | "mul"
+ * Workspace as for dgla_spmm_csr (same byte count for the stacked csr).
+ */
+size_t dgla_spmm_csr_stacked_workspace_bytes(const char* op, const dgla_csr* csr,
+                                             dgla_dtype dtype, const dgla_tensor* ufeat0,
+                                             const dgla_tensor* efeat0, const dgla_tensor* out);
+int dgla_spmm_csr_stacked(const char* op, const dgla_csr* csr, const void* rel, int num_rel,
+                          dgla_dtype dtype, const dgla_tensor* ufeat0, const dgla_tensor* efeat0,
+                          const void* const* ufeat_ptrs, const void* const* efeat_ptrs,
+                          const dgla_tensor* out, void* workspace, size_t workspace_bytes,
+                          uint32_t flags, void* hip_stream);
+
+/*
  * g-SpMM on COO (edge-parallel with device atomics).  Replaces aten::COOSpMM
  * (array.cc:1170-1190) -> SpMMCoo<kDGLCUDA,...> (spmm.cu:80-106, spmm.cuh:624-682).
  * `out` (and arg_*) are fully written by the call.  fp16 / bf16 are refused like the
