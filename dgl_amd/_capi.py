@@ -196,3 +196,53 @@ def set_profile_events(before, after):
         LIB.dgla_spmm_set_profile_events(None, None)
     else:
         LIB.dgla_spmm_set_profile_events(before.cuda_event, after.cuda_event)
+
+
+def set_tuning(flags):
+    """Process-wide tuning bits of the CSR SpMM (include/dgl_amd.h: DGLA_TUNE_*); results are
+    bit-identical under every setting."""
+    check_call(LIB.dgla_set_tuning(int(flags)))
+
+
+def get_tuning():
+    return int(LIB.dgla_get_tuning())
+
+
+def segment_reduce(reduce, feat, offsets, out, arg=None, workspace=None, plan_valid=False):
+    """out[i] = reduce(feat[offsets[i]:offsets[i+1]]) (dgla_segment_reduce).  `workspace` may
+    be None (stream-ordered scratch inside the call) or a uint8 tensor of
+    segment_reduce_workspace_bytes() that also caches the merge plan of `offsets`."""
+    keep = []
+    tf, to = _tensor(feat, keep), _tensor(out, keep)
+    _require_gpu(offsets)
+    check_call(LIB.dgla_segment_reduce(
+        reduce.encode(), _idbits(offsets), _DTYPES[out.dtype], ctypes.byref(tf),
+        offsets.data_ptr(), offsets.shape[0] - 1, ctypes.byref(to), _ptr(arg), _ptr(workspace),
+        0 if workspace is None else workspace.numel() * workspace.element_size(),
+        _lib.DGLA_PLAN_VALID if plan_valid else 0, _stream(out)))
+
+
+def segment_reduce_workspace_bytes(reduce, feat, offsets, out):
+    keep = []
+    tf, to = _tensor(feat, keep), _tensor(out, keep)
+    return LIB.dgla_segment_reduce_workspace_bytes(reduce.encode(), _idbits(offsets),
+                                                   _DTYPES[out.dtype], ctypes.byref(tf),
+                                                   offsets.shape[0] - 1, ctypes.byref(to))
+
+
+def scatter_add(feat, idx, out):
+    """out[idx[i]] += feat[i] (dgla_scatter_add; `out` is not zeroed)."""
+    keep = []
+    tf, to = _tensor(feat, keep), _tensor(out, keep)
+    _require_gpu(idx)
+    check_call(LIB.dgla_scatter_add(_idbits(idx), _DTYPES[out.dtype], ctypes.byref(tf),
+                                    idx.data_ptr(), ctypes.byref(to), _stream(out)))
+
+
+def backward_segment_cmp(feat, arg, out):
+    """out[arg[i, k], k] = feat[i, k] where arg >= 0 (dgla_backward_segment_cmp)."""
+    keep = []
+    tf, to = _tensor(feat, keep), _tensor(out, keep)
+    _require_gpu(arg)
+    check_call(LIB.dgla_backward_segment_cmp(_idbits(arg), _DTYPES[out.dtype], ctypes.byref(tf),
+                                             arg.data_ptr(), ctypes.byref(to), _stream(out)))

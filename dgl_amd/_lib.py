@@ -86,6 +86,19 @@ LIB.dgla_edge_softmax_backward.argtypes = [P(CSR), c_int, P(Tensor), P(Tensor), 
                                            c_void_p, c_size_t, c_uint32, c_void_p]
 LIB.dgla_spmm_set_profile_events.restype = c_int
 LIB.dgla_spmm_set_profile_events.argtypes = [c_void_p, c_void_p]
+LIB.dgla_segment_reduce_workspace_bytes.restype = c_size_t
+LIB.dgla_segment_reduce_workspace_bytes.argtypes = [c_char_p, c_int, c_int, P(Tensor), c_int64,
+                                                    P(Tensor)]
+LIB.dgla_segment_reduce.restype = c_int
+LIB.dgla_segment_reduce.argtypes = [c_char_p, c_int, c_int, P(Tensor), c_void_p, c_int64, P(Tensor),
+                                    c_void_p, c_void_p, c_size_t, c_uint32, c_void_p]
+LIB.dgla_scatter_add.restype = c_int
+LIB.dgla_scatter_add.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
+LIB.dgla_backward_segment_cmp.restype = c_int
+LIB.dgla_backward_segment_cmp.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
+LIB.dgla_set_tuning.restype = c_int
+LIB.dgla_set_tuning.argtypes = [c_uint32]
+LIB.dgla_get_tuning.restype = c_uint32
 LIB.dgla_stream_copy.restype = c_int
 LIB.dgla_stream_copy.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
 LIB.dgla_stream_copy_variant.restype = c_int
@@ -93,6 +106,7 @@ LIB.dgla_stream_copy_variant.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_
 
 DGLA_ACCUMULATE = 1
 DGLA_PLAN_VALID = 2
+DGLA_TUNE_XCD, DGLA_TUNE_NT_OUT, DGLA_TUNE_NT_IDX, DGLA_TUNE_SPLIT = 1, 2, 4, 8
 
 
 def check_call(ret):

@@ -16,6 +16,11 @@ std::string& last_error() {
   return err;
 }
 
+uint32_t& tuning_flags() {
+  static uint32_t flags = kDefaultTuning;
+  return flags;
+}
+
 ProfileEvents& profile_events() {
   static thread_local ProfileEvents pe;
   return pe;
@@ -273,6 +278,7 @@ static int build_spmm_launch(const char* op_s, const char* red_s, const dgla_csr
   L->bcast = bc.mode;
   L->rhs_group = bc.rhs_group;
   L->bdims = bc.dims;
+  L->tune = tuning_flags();
   return 0;
 }
 
@@ -522,6 +528,13 @@ int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla
                              workspace, workspace_bytes, (flags & DGLA_PLAN_VALID) != 0,
                              static_cast<hipStream_t>(hip_stream));
 }
+
+int dgla_set_tuning(uint32_t flags) {
+  tuning_flags() = flags;
+  return 0;
+}
+
+uint32_t dgla_get_tuning(void) { return tuning_flags(); }
 
 int dgla_spmm_set_profile_events(void* before, void* after) {
   profile_events().before = static_cast<hipEvent_t>(before);

@@ -149,6 +149,8 @@ struct SpmmLaunch {
   const void* rel;               // uint8 [nnz] or nullptr (single relation)
   const void* const* ufeat_tab;  // [num_rel]
   const void* const* efeat_tab;  // [num_rel]
+  int arg_empty;    // arg value of an output element no edge won: 0 (g-SpMM), -1 (segment reduce)
+  uint32_t tune;    // kTune* bits, from dgla_set_tuning()
   bool accumulate;  // out += result (reference semantics, spmm.cuh:528-534) vs out = result
   bool plan_valid;  // workspace already holds the merge plan of this CSR
   void* workspace;
@@ -171,6 +173,19 @@ struct SddmmLaunch {
   BcastDims bdims;
   hipStream_t stream;
 };
+
+// Tuning bits of the CSR SpMM (dgla_set_tuning / dgla_get_tuning).  None changes a result bit.
+enum Tune : uint32_t {
+  kTuneXcd = 1u,    // XCD-contiguous unit order (one contiguous eighth of the merge path per L2)
+  kTuneNtOut = 2u,  // non-temporal stores of finished output rows
+  kTuneNtIdx = 4u,  // non-temporal loads of the index streams (indices / indptr / eids)
+  kTuneSplit = 8u,  // split-row re-layout of ufeat when rows are not a whole number of 128-B lines
+};
+// Default: XCD-contiguous order (measured on C2: variant L -3 % time, variant U neutral); the
+// non-temporal bits are neutral and split-row trades a 0.49 ms copy for a 0.51 ms faster gather
+// on variant U but loses on variant L (profiles/r1/tune_ab.jsonl) -> opt-in.
+constexpr uint32_t kDefaultTuning = 1u;
+uint32_t& tuning_flags();
 
 // Merge-path geometry of the CSR SpMM (see spmm_csr.cuh).
 constexpr int kWaveItems = 512;     // rows + edges handled by one wavefront

@@ -558,6 +558,90 @@ static Registrar r_esb("sparse._CAPI_DGLKernelEdge_softmax_backward",
   return edge_softmax_ffi(a, true);
 });
 
+// ---- segment reduce family (src/array/kernel.cc:658-708) -------------------------------------
+static int seg_arrays_ok(std::initializer_list<const DGLArray*> arrs) {
+  for (const DGLArray* t : arrs) {
+    if (!t || t->ndim == 0) continue;
+    if (!on_gpu(t)) return ffi_fail("array is not on a GPU device");
+    if (check_contiguous(t, "array")) return -1;
+  }
+  return 0;
+}
+
+// (str op, NDArray feat, NDArray offsets, NDArray out, NDArray arg)
+static Registrar r_segred("sparse._CAPI_DGLKernelSegmentReduce",
+                          [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  const char* op;
+  DGLArray *feat, *offsets, *out, *arg;
+  if (get_str(a, 0, &op) || get_array(a, 1, &feat) || get_array(a, 2, &offsets) ||
+      get_array(a, 3, &out) || get_array(a, 4, &arg))
+    return -1;
+  if (!feat || !offsets || !out || out->ndim == 0) return ffi_fail("feat / offsets / out is required");
+  if (seg_arrays_ok({feat, offsets, out, arg})) return -1;
+  // CheckCtx / CheckContiguous as the reference lambda; dtype rules of SegmentReduceDispatch
+  dgla_dtype dt, df;
+  int bits;
+  if (float_dtype(out, &dt) || float_dtype(feat, &df) || idbits_of(offsets, &bits)) return -1;
+  if (dt != df) return ffi_fail("feat and out dtypes differ");
+  if (offsets->ndim != 1 || offsets->shape[0] != out->shape[0] + 1)
+    return ffi_fail("offsets must have out.shape[0] + 1 entries");
+  const bool cmp = strcmp(op, "sum") != 0;
+  if (cmp) {
+    int abits;
+    if (null_array(arg) && out->shape[0] > 0 ) return ffi_fail("arg is required for max/min");
+    if (!null_array(arg) && (idbits_of(arg, &abits) || abits != bits))
+      return ffi_fail("arg dtype must equal the offsets dtype");
+  }
+  TensorArg tf, to;
+  tf.shape.assign(feat->shape, feat->shape + feat->ndim);
+  tf.t = dgla_tensor{data_ptr(feat), feat->ndim, tf.shape.data()};
+  to.shape.assign(out->shape, out->shape + out->ndim);
+  to.t = dgla_tensor{data_ptr(out), out->ndim, to.shape.data()};
+  return dgla_segment_reduce(op, bits, dt, &tf.t, data_ptr(offsets), out->shape[0], &to.t,
+                             null_array(arg) ? nullptr : data_ptr(arg), nullptr, 0, 0, tls_stream);
+});
+
+// (NDArray feat, NDArray idx, NDArray out)
+static Registrar r_scatter("sparse._CAPI_DGLKernelScatterAdd",
+                           [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  DGLArray *feat, *idx, *out;
+  if (get_array(a, 0, &feat) || get_array(a, 1, &idx) || get_array(a, 2, &out)) return -1;
+  if (!feat || !idx || !out) return ffi_fail("feat / idx / out is required");
+  if (null_array(feat)) return 0;
+  if (seg_arrays_ok({feat, idx, out})) return -1;
+  dgla_dtype dt, df;
+  int bits;
+  if (float_dtype(out, &dt) || float_dtype(feat, &df) || idbits_of(idx, &bits)) return -1;
+  if (dt != df) return ffi_fail("feat and out dtypes differ");
+  if (idx->ndim != 1 || idx->shape[0] != feat->shape[0])
+    return ffi_fail("idx must have one entry per row of feat");
+  TensorArg tf, to;
+  to_tensor(feat, &tf);
+  to_tensor(out, &to);
+  return dgla_scatter_add(bits, dt, &tf.t, data_ptr(idx), &to.t, tls_stream);
+});
+
+// (NDArray feat, NDArray arg, NDArray out)
+static Registrar r_bwdseg("sparse._CAPI_DGLKernelBwdSegmentCmp",
+                          [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  DGLArray *feat, *arg, *out;
+  if (get_array(a, 0, &feat) || get_array(a, 1, &arg) || get_array(a, 2, &out)) return -1;
+  if (!feat || !arg || !out) return ffi_fail("feat / arg / out is required");
+  if (null_array(feat)) return 0;
+  if (seg_arrays_ok({feat, arg, out})) return -1;
+  dgla_dtype dt, df;
+  int bits;
+  if (float_dtype(out, &dt) || float_dtype(feat, &df) || idbits_of(arg, &bits)) return -1;
+  if (dt != df) return ffi_fail("feat and out dtypes differ");
+  TensorArg tf, to;
+  to_tensor(feat, &tf);
+  to_tensor(out, &to);
+  return dgla_backward_segment_cmp(bits, dt, &tf.t, data_ptr(arg), &to.t, tls_stream);
+});
+
 }  // namespace dgla
 
 using namespace dgla;

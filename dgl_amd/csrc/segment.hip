@@ -1,0 +1,301 @@
+// Segment reduce / scatter add / backward of segment max-min for gfx950.
+//
+// Reference: src/array/cuda/segment_reduce.cuh:30-113 (SegmentReduceKernel, ScatterAddKernel,
+// BackwardSegmentCmpKernel), src/array/cpu/segment_reduce.h:27-187, registered at
+// src/array/kernel.cc:658-708.
+//
+//  * segment reduce IS a g-SpMM: offsets are a CSR indptr whose "edges" are the rows of
+//    `feat` in place (copy_rhs, edge id == position), so it runs on the merge-path kernel of
+//    spmm_csr.cuh — one wavefront per 512 items whatever the segment lengths — instead of
+//    the reference's one-block-per-segment loop.  Only difference from g-SpMM: arg of an
+//    element nothing won is -1 (segment_reduce.cuh:39, cpu/segment_reduce.h:66), not 0.
+//  * scatter add: out[idx[i], :] += feat[i, :] with hardware float atomics, 16-byte row
+//    pieces per lane (the reference: one scalar atomic per thread).
+//  * backward of segment max/min: out[arg[i, k], k] = feat[i, k] where arg >= 0; every
+//    (row, k) is written at most once, so plain stores.
+#include "../../include/dgl_amd.h"
+
+#include <cstring>
+
+#include "common.h"
+
+namespace dgla {
+
+int launch_spmm_csr_f32(const SpmmLaunch&);
+int launch_spmm_csr_f64(const SpmmLaunch&);
+int launch_spmm_csr_f16(const SpmmLaunch&);
+int launch_spmm_csr_bf16(const SpmmLaunch&);
+size_t spmm_csr_workspace_f32(const SpmmLaunch&);
+size_t spmm_csr_workspace_f64(const SpmmLaunch&);
+size_t spmm_csr_workspace_f16(const SpmmLaunch&);
+size_t spmm_csr_workspace_bf16(const SpmmLaunch&);
+
+namespace {
+
+int sfail(const std::string& m) {
+  last_error() = m;
+  return -1;
+}
+
+int64_t row_len(const dgla_tensor* t) {
+  int64_t n = 1;
+  for (int i = 1; i < t->ndim; ++i) n *= t->shape[i];
+  return n;
+}
+
+// ---- scatter add ----------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void atomic_add_elem(T* p, T v) {
+  atomicAdd(p, v);  // fp32 / fp64: hardware atomics (-munsafe-fp-atomics)
+}
+// 16-bit storage: compare-and-swap on the enclosing aligned 32-bit word
+template <typename T>
+__device__ __forceinline__ void atomic_add_16(T* p, float v) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  uint32_t* word = reinterpret_cast<uint32_t*>(a & ~uintptr_t(3));
+  const int shift = (a & 2) ? 16 : 0;
+  uint32_t old = *word;
+  while (true) {
+    T cur;
+    const uint16_t bits = static_cast<uint16_t>(old >> shift);
+    __builtin_memcpy(&cur, &bits, 2);
+    const T nv = from_acc<T>(to_acc<T>(cur) + v);
+    uint16_t nb;
+    __builtin_memcpy(&nb, &nv, 2);
+    const uint32_t want = (old & ~(0xffffu << shift)) | (static_cast<uint32_t>(nb) << shift);
+    const uint32_t seen = atomicCAS(word, old, want);
+    if (seen == old) break;
+    old = seen;
+  }
+}
+template <>
+__device__ __forceinline__ void atomic_add_elem<f16_t>(f16_t* p, f16_t v) {
+  atomic_add_16<f16_t>(p, to_acc<f16_t>(v));
+}
+template <>
+__device__ __forceinline__ void atomic_add_elem<bf16_t>(bf16_t* p, bf16_t v) {
+  atomic_add_16<bf16_t>(p, to_acc<bf16_t>(v));
+}
+
+// One lane per VEC consecutive features of one input row; rows of a workgroup are
+// consecutive so the feat reads are fully coalesced.
+template <typename Idx, typename DT, int VEC>
+__global__ __launch_bounds__(256) void scatter_add_kernel(const DT* __restrict__ feat,
+                                                          const Idx* __restrict__ idx,
+                                                          DT* __restrict__ out, int64_t n,
+                                                          int dim, int lanes_per_row) {
+  const int64_t total = n * lanes_per_row;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < total;
+       t += stride) {
+    const int64_t row = t / lanes_per_row;
+    const int k = static_cast<int>(t - row * lanes_per_row) * VEC;
+    const int64_t dst = static_cast<int64_t>(idx[row]);
+    const VecT<DT, VEC> v = *reinterpret_cast<const VecT<DT, VEC>*>(feat + row * dim + k);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) atomic_add_elem<DT>(out + dst * dim + k + j, v.v[j]);
+  }
+}
+
+template <typename Idx, typename DT>
+int run_scatter_add(const void* feat, const void* idx, void* out, int64_t n, int64_t dim,
+                    hipStream_t s) {
+  constexpr int full = 16 / sizeof(DT);
+  const bool vec_ok = dim % full == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0;
+  const int vec = vec_ok ? full : 1;
+  const int lanes = static_cast<int>(dim / vec);
+  int64_t blocks = (n * lanes + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  if (blocks < 1) blocks = 1;
+  if (vec_ok)
+    hipLaunchKernelGGL((scatter_add_kernel<Idx, DT, full>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(256), 0, s, static_cast<const DT*>(feat), static_cast<const Idx*>(idx),
+                       static_cast<DT*>(out), n, static_cast<int>(dim), lanes);
+  else
+    hipLaunchKernelGGL((scatter_add_kernel<Idx, DT, 1>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(256), 0, s, static_cast<const DT*>(feat), static_cast<const Idx*>(idx),
+                       static_cast<DT*>(out), n, static_cast<int>(dim), lanes);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- backward of segment max / min ------------------------------------------------------
+template <typename Idx, typename DT>
+__global__ __launch_bounds__(256) void bwd_segment_cmp_kernel(const DT* __restrict__ feat,
+                                                              const Idx* __restrict__ arg,
+                                                              DT* __restrict__ out,
+                                                              int64_t total, int dim) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < total;
+       t += stride) {
+    const int64_t w = static_cast<int64_t>(arg[t]);
+    if (w >= 0) out[w * dim + (t % dim)] = feat[t];
+  }
+}
+
+template <typename Idx, typename DT>
+int run_bwd_segment_cmp(const void* feat, const void* arg, void* out, int64_t n, int64_t dim,
+                        hipStream_t s) {
+  const int64_t total = n * dim;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((bwd_segment_cmp_kernel<Idx, DT>), dim3(static_cast<unsigned>(blocks)),
+                     dim3(256), 0, s, static_cast<const DT*>(feat), static_cast<const Idx*>(arg),
+                     static_cast<DT*>(out), total, static_cast<int>(dim));
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+#define DGLA_IDX_DTYPE_SWITCH(idbits, dtype, FN, ...)                                   \
+  do {                                                                                  \
+    if ((idbits) == 32) {                                                               \
+      switch (dtype) {                                                                  \
+        case DGLA_F32: return FN<int32_t, float>(__VA_ARGS__);                          \
+        case DGLA_F64: return FN<int32_t, double>(__VA_ARGS__);                         \
+        case DGLA_F16: return FN<int32_t, f16_t>(__VA_ARGS__);                          \
+        case DGLA_BF16: return FN<int32_t, bf16_t>(__VA_ARGS__);                        \
+      }                                                                                 \
+    } else {                                                                            \
+      switch (dtype) {                                                                  \
+        case DGLA_F32: return FN<int64_t, float>(__VA_ARGS__);                          \
+        case DGLA_F64: return FN<int64_t, double>(__VA_ARGS__);                         \
+        case DGLA_F16: return FN<int64_t, f16_t>(__VA_ARGS__);                          \
+        case DGLA_BF16: return FN<int64_t, bf16_t>(__VA_ARGS__);                        \
+      }                                                                                 \
+    }                                                                                   \
+  } while (0)
+
+int build_segment_launch(const char* reduce, int idbits, dgla_dtype dtype,
+                         const dgla_tensor* feat, const void* offsets, int64_t num_segments,
+                         const dgla_tensor* out, SpmmLaunch* L) {
+  int red = -1;
+  if (reduce && !strcmp(reduce, "sum")) red = kSum;
+  if (reduce && !strcmp(reduce, "max")) red = kMax;
+  if (reduce && !strcmp(reduce, "min")) red = kMin;
+  if (red < 0)
+    return sfail(std::string("Unsupported reduce function ") + (reduce ? reduce : "(null)"));
+  if (idbits != 32 && idbits != 64) return sfail("idtype must be int32 or int64");
+  if (dtype < DGLA_F32 || dtype > DGLA_BF16) return sfail("unsupported feature dtype");
+  if (!feat || !out || feat->ndim < 1 || out->ndim < 1 || !feat->shape || !out->shape)
+    return sfail("feat / out is null");
+  if (feat->ndim != out->ndim) return sfail("feat and out must have the same number of dimensions");
+  if (out->shape[0] != num_segments) return sfail("out has a different number of rows than segments");
+  if (row_len(feat) != row_len(out)) return sfail("feat and out have different feature shapes");
+  if (num_segments > 0 && !offsets) return sfail("offsets is null");
+  if (row_len(out) > 0x7fffffffLL / 4) return sfail("feature length too large");
+  L->csr.num_rows = num_segments;
+  L->csr.num_cols = 0;
+  L->csr.nnz = feat->shape[0];
+  L->csr.idbits = idbits;
+  L->csr.indptr = offsets;
+  L->csr.indices = nullptr;
+  L->csr.eids = nullptr;
+  L->op = kCopyRhs;
+  L->red = red;
+  L->dtype = dtype;
+  L->ufeat = nullptr;
+  L->efeat = feat->data;
+  L->out = out->data;
+  L->out_len = L->lhs_len = L->rhs_len = row_len(out);
+  L->bcast = kBcNone;
+  L->rhs_group = 1;
+  L->arg_empty = -1;
+  L->tune = tuning_flags() & ~static_cast<uint32_t>(kTuneSplit);
+  return 0;
+}
+
+}  // namespace
+}  // namespace dgla
+
+using namespace dgla;
+
+extern "C" {
+
+size_t dgla_segment_reduce_workspace_bytes(const char* reduce, int idtype_bits, dgla_dtype dtype,
+                                           const dgla_tensor* feat, int64_t num_segments,
+                                           const dgla_tensor* out) {
+  SpmmLaunch L{};
+  static const int64_t dummy = 0;
+  if (build_segment_launch(reduce, idtype_bits, dtype, feat, &dummy, num_segments, out, &L)) return 0;
+  switch (dtype) {
+    case DGLA_F32: return spmm_csr_workspace_f32(L);
+    case DGLA_F64: return spmm_csr_workspace_f64(L);
+    case DGLA_F16: return spmm_csr_workspace_f16(L);
+    case DGLA_BF16: return spmm_csr_workspace_bf16(L);
+  }
+  return 0;
+}
+
+int dgla_segment_reduce(const char* reduce, int idtype_bits, dgla_dtype dtype,
+                        const dgla_tensor* feat, const void* offsets, int64_t num_segments,
+                        const dgla_tensor* out, void* arg, void* workspace,
+                        size_t workspace_bytes, uint32_t flags, void* hip_stream) {
+  SpmmLaunch L{};
+  if (build_segment_launch(reduce, idtype_bits, dtype, feat, offsets, num_segments, out, &L))
+    return -1;
+  if (L.red != kSum && !arg) return sfail("arg is required for max/min");
+  if (num_segments == 0 || L.out_len == 0) return 0;
+  L.arg_u = nullptr;
+  L.arg_e = arg;
+  L.accumulate = false;
+  L.plan_valid = (flags & DGLA_PLAN_VALID) != 0;
+  L.stream = static_cast<hipStream_t>(hip_stream);
+  // scratch: the caller's, or a stream-ordered allocation released after the launches
+  void* owned = nullptr;
+  if (!workspace) {
+    const size_t need = dgla_segment_reduce_workspace_bytes(reduce, idtype_bits, dtype, feat,
+                                                            num_segments, out);
+    DGLA_CHECK_HIP(hipMallocAsync(&owned, need ? need : 256, L.stream));
+    workspace = owned;
+    workspace_bytes = need;
+    L.plan_valid = false;
+  }
+  L.workspace = workspace;
+  L.workspace_bytes = workspace_bytes;
+  int rc = -1;
+  switch (dtype) {
+    case DGLA_F32: rc = launch_spmm_csr_f32(L); break;
+    case DGLA_F64: rc = launch_spmm_csr_f64(L); break;
+    case DGLA_F16: rc = launch_spmm_csr_f16(L); break;
+    case DGLA_BF16: rc = launch_spmm_csr_bf16(L); break;
+  }
+  if (owned) {
+    const hipError_t e = hipFreeAsync(owned, L.stream);
+    if (e != hipSuccess && rc == 0) return sfail(std::string("hipFreeAsync: ") + hipGetErrorString(e));
+  }
+  return rc;
+}
+
+int dgla_scatter_add(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat, const void* idx,
+                     const dgla_tensor* out, void* hip_stream) {
+  if (idtype_bits != 32 && idtype_bits != 64) return sfail("idtype must be int32 or int64");
+  if (dtype < DGLA_F32 || dtype > DGLA_BF16) return sfail("unsupported feature dtype");
+  if (!feat || !out || feat->ndim < 1 || out->ndim < 1 || !feat->shape || !out->shape)
+    return sfail("feat / out is null");
+  if (row_len(feat) != row_len(out)) return sfail("feat and out have different feature shapes");
+  const int64_t n = feat->shape[0], dim = row_len(out);
+  if (n == 0 || dim == 0) return 0;
+  if (!feat->data || !out->data || !idx) return sfail("feat / idx / out data is null");
+  if (dim > 0x7fffffffLL / 4) return sfail("feature length too large");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DGLA_IDX_DTYPE_SWITCH(idtype_bits, dtype, run_scatter_add, feat->data, idx, out->data, n, dim, s);
+  return sfail("unsupported feature dtype");
+}
+
+int dgla_backward_segment_cmp(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat,
+                              const void* arg, const dgla_tensor* out, void* hip_stream) {
+  if (idtype_bits != 32 && idtype_bits != 64) return sfail("idtype must be int32 or int64");
+  if (dtype < DGLA_F32 || dtype > DGLA_BF16) return sfail("unsupported feature dtype");
+  if (!feat || !out || feat->ndim < 1 || out->ndim < 1 || !feat->shape || !out->shape)
+    return sfail("feat / out is null");
+  if (row_len(feat) != row_len(out)) return sfail("feat and out have different feature shapes");
+  const int64_t n = feat->shape[0], dim = row_len(out);
+  if (n == 0 || dim == 0) return 0;
+  if (!feat->data || !out->data || !arg) return sfail("feat / arg / out data is null");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  DGLA_IDX_DTYPE_SWITCH(idtype_bits, dtype, run_bwd_segment_cmp, feat->data, arg, out->data, n, dim, s);
+  return sfail("unsupported feature dtype");
+}
+
+}  // extern "C"

@@ -22,6 +22,8 @@
 //    results are run-to-run deterministic and arg-max / arg-min ties resolve to the lowest
 //    CSR position exactly like the reference's sequential loop (functor.cuh:246-254).
 #pragma once
+#include <algorithm>
+
 #include "common.h"
 
 namespace dgla {
@@ -43,6 +45,13 @@ struct SpmmParams {
   int rhs_group;  // kBcRhsGroup
   BcastDims bd;   // kBcGeneral
   int accumulate;
+  int arg_empty;  // arg_u / arg_e of an output element no edge won: 0 (g-SpMM) or -1 (segment reduce)
+  uint32_t tune;  // kTune* bits (common.h)
+  // split-row layout of ufeat (kTuneSplit, see spmm_split_rows_kernel): features
+  // [0, split_main) of every row live in `ufeat` with pitch split_main, the rest in `utail`
+  // with pitch split_tail.  split_main == 0: plain layout.
+  const void* utail;
+  int split_main, split_tail;
   // stacked multi-relation form (MULTI kernels only)
   const uint8_t* rel;
   const void* const* xtab;
@@ -80,6 +89,48 @@ __global__ void spmm_merge_plan_kernel(const Idx* __restrict__ indptr, int64_t n
       hi = mid - 1;
   }
   plan[w] = lo;
+}
+
+// Non-temporal store of one lane access (16 / 8 / 4 / 2 bytes).
+template <typename DT, int VEC>
+__device__ __forceinline__ void store_nt(DT* dst, const VecT<DT, VEC>& v) {
+  constexpr int B = sizeof(DT) * VEC;
+  if constexpr (B == 16) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(*reinterpret_cast<const u4*>(&v), reinterpret_cast<u4*>(dst));
+  } else if constexpr (B == 8) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(*reinterpret_cast<const u2*>(&v), reinterpret_cast<u2*>(dst));
+  } else if constexpr (B == 4) {
+    __builtin_nontemporal_store(*reinterpret_cast<const uint32_t*>(&v), reinterpret_cast<uint32_t*>(dst));
+  } else {
+    *reinterpret_cast<VecT<DT, VEC>*>(dst) = v;
+  }
+}
+
+// Split-row re-layout (kTuneSplit).  A feature row of RB bytes that is not a multiple of the
+// 128-byte L2 line straddles ceil-ish(RB / 128) + 1 lines when gathered (F = 100 fp32: 400 B
+// -> always 4 lines = 512 B of fabric traffic per edge).  Copying X once per call into a
+// line-aligned MAIN array (pitch = RB rounded down to 128 B) and a dense TAIL array (pitch =
+// the remainder, small enough to live in L2 / Infinity Cache) turns the gather into
+// RB_main / 128 full lines plus one cached access: 2 N RB bytes of streaming traffic buy
+// 128 B x E of gather traffic.  One thread moves one 16-byte piece.
+typedef uint32_t piece16_t __attribute__((ext_vector_type(4)));
+template <int PIECE_BYTES>  // template only so that the header can live in several objects
+__global__ __launch_bounds__(256) void spmm_split_rows_kernel(
+    const piece16_t* __restrict__ x, piece16_t* __restrict__ main_out,
+    piece16_t* __restrict__ tail_out, int64_t num_rows, int pieces, int main_pieces) {
+  const int64_t total = num_rows * pieces;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t r = i / pieces;
+    const int j = static_cast<int>(i - r * pieces);
+    const piece16_t v = __builtin_nontemporal_load(x + i);
+    if (j < main_pieces)
+      main_out[r * main_pieces + j] = v;
+    else
+      tail_out[r * (pieces - main_pieces) + (j - main_pieces)] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -125,8 +176,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
 
   const int wib = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  const int64_t w = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wib;
+  // XCD-contiguous unit order: the dispatcher deals workgroups round-robin over the 8 XCDs
+  // (block b -> XCD b % 8), so consecutive units -- neighbouring destination rows, whose
+  // neighbour sets overlap on any graph with locality -- would land in 8 different L2s.
+  // Remapped, XCD x walks one contiguous eighth of the merge path and its 4 MiB L2 holds one
+  // window of X instead of a copy of everybody's.  Pure index math: correct under any placement.
+  unsigned blk = blockIdx.x;
+  if ((p.tune & kTuneXcd) && gridDim.y == 1) {
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u;
+    const unsigned x = blk & 7u, i = blk >> 3;
+    blk = x * q + (x < r ? x : r) + i;
+  }
+  const int64_t w = static_cast<int64_t>(blk) * kWavesPerBlock + wib;
   const bool has_eid = p.eids != nullptr;
+  const bool nt_idx = (p.tune & kTuneNtIdx) != 0;
 
   int64_t i0 = 0, j0 = 0;
   int R = 0, nE = 0;
@@ -154,13 +217,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
       for (int k = 0; k < kWaveItems / 64; ++k) {
         int it = lane + 64 * k;
         if (it >= items) it = items - 1;
-        const Idx* src = it < nE ? p.indices + (j0 + it) : p.indptr + (i0 + 1 + (it - nE));
-        itemv[k] = *src;
+        // column ids are only needed to gather ufeat rows (and to name arg_u): copy_rhs /
+        // segment reduce never reads them (p.indices may be NULL there)
+        const Idx* src = p.indptr + (i0 + 1 + (it < nE ? 0 : it - nE));
+        if constexpr (UL) src = it < nE ? p.indices + (j0 + it) : src;
+        itemv[k] = nt_idx ? __builtin_nontemporal_load(src) : *src;  // read-once stream
         if constexpr (MULTI) relv[k] = it < nE ? p.rel[j0 + it] : uint8_t(0);
         if constexpr (UR) {
           if (has_eid) {
             const int ie = it < nE ? it : (nE > 0 ? nE - 1 : 0);
-            eidv[k] = nE > 0 ? p.eids[j0 + ie] : Idx(0);
+            eidv[k] = nE > 0 ? p.eids[j0 + ie] : static_cast<Idx>(p.arg_empty);
           }
         }
       }
@@ -225,7 +291,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   if constexpr (BC == kBcGeneral) bcast_offsets(p.bd, k0, &lo_off, &ro_off);
   const DT* __restrict__ X = static_cast<const DT*>(p.ufeat) + lo_off;
   const DT* __restrict__ Wt = static_cast<const DT*>(p.efeat) + ro_off;
-  const int64_t lhs_len = p.lhs_len, rhs_len = p.rhs_len;
+  int64_t lhs_len = p.lhs_len;
+  const int64_t rhs_len = p.rhs_len;
+  if (p.split_main > 0) {  // split-row layout: this lane's piece lives in the main or the tail array
+    if (lo_off < p.split_main) {
+      lhs_len = p.split_main;
+    } else {
+      X = static_cast<const DT*>(p.utail) + (lo_off - p.split_main);
+      lhs_len = p.split_tail;
+    }
+  }
 
   using XV = VecT<DT, VEC>;
   using WV = VecT<DT, RV>;
@@ -282,8 +357,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           const int bi = best[v];
-          if constexpr (UL) p.tail_argu[slot * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : Idx(0);
-          if constexpr (UR) p.tail_arge[slot * F + k0 + v] = bi >= 0 ? eidl[bi] : Idx(0);
+          if constexpr (UL) p.tail_argu[slot * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : static_cast<Idx>(p.arg_empty);
+          if constexpr (UR) p.tail_arge[slot * F + k0 + v] = bi >= 0 ? eidl[bi] : static_cast<Idx>(p.arg_empty);
         }
       }
       first_is_tail = false;
@@ -298,13 +373,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
 #pragma unroll
         for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(acc[v]);
       }
-      *reinterpret_cast<VecT<DT, VEC>*>(o) = ov;
+      if (p.tune & kTuneNtOut)
+        store_nt(o, ov);  // written once, never re-read by this launch: keep X in the caches
+      else
+        *reinterpret_cast<VecT<DT, VEC>*>(o) = ov;
       if constexpr (ARG) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           const int bi = best[v];
-          if constexpr (UL) p.arg_u[row * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : Idx(0);
-          if constexpr (UR) p.arg_e[row * F + k0 + v] = bi >= 0 ? eidl[bi] : Idx(0);
+          if constexpr (UL) p.arg_u[row * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : static_cast<Idx>(p.arg_empty);
+          if constexpr (UR) p.arg_e[row * F + k0 + v] = bi >= 0 ? eidl[bi] : static_cast<Idx>(p.arg_empty);
         }
       }
     }
@@ -380,8 +458,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         const int bi = best[v];
-        if constexpr (UL) p.carry_argu[slot * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : Idx(0);
-        if constexpr (UR) p.carry_arge[slot * F + k0 + v] = bi >= 0 ? eidl[bi] : Idx(0);
+        if constexpr (UL) p.carry_argu[slot * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : static_cast<Idx>(p.arg_empty);
+        if constexpr (UR) p.carry_arge[slot * F + k0 + v] = bi >= 0 ? eidl[bi] : static_cast<Idx>(p.arg_empty);
       }
     }
   }
@@ -454,12 +532,29 @@ struct SpmmGeometry {
   int64_t num_waves, num_slots;
   size_t off_plan, off_carry_row, off_carry_val, off_tail_val, off_carry_argu,
       off_carry_arge, off_tail_argu, off_tail_arge, total;
+  // split-row layout (0 = not used): bytes of a row kept in the main / tail array
+  int split_main_bytes, split_tail_bytes;
+  size_t off_split_main, off_split_tail;
 };
+
+// Shape-only eligibility of the split-row layout: 16-byte lane accesses cover the row in one
+// chunk, the row is longer than one 128-byte line and not a whole number of lines.
+inline bool spmm_split_shape_ok(const SpmmLaunch& L, size_t elem_bytes) {
+  if (!(L.tune & kTuneSplit) || L.rel != nullptr || !op_uses_lhs(L.op)) return false;
+  if (L.bcast == kBcGeneral || L.lhs_len != L.out_len) return false;
+  const int64_t rb = L.lhs_len * static_cast<int64_t>(elem_bytes);
+  if (rb % 16 || rb > 1024 || rb < 128 || rb % 128 == 0) return false;
+  // pays off only when rows are re-read (average in-degree) and X does not fit the caches
+  if (L.csr.nnz < 4 * L.csr.num_cols) return false;
+  if (L.csr.num_cols * rb < (int64_t(64) << 20)) return false;
+  return true;
+}
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len, int vec,
-                                  size_t acc_bytes, int idbytes, bool with_arg) {
+                                  size_t acc_bytes, int idbytes, bool with_arg,
+                                  int64_t split_rows = 0, int64_t split_row_bytes = 0) {
   SpmmGeometry g;
   g.vec = vec;
   int64_t lanes = (out_len + vec - 1) / vec;
@@ -488,6 +583,16 @@ inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len
     g.off_tail_argu = off + 2 * a;
     g.off_tail_arge = off + 3 * a;
     off += 4 * a;
+  }
+  g.split_main_bytes = g.split_tail_bytes = 0;
+  g.off_split_main = g.off_split_tail = off;
+  if (split_rows > 0) {
+    g.split_main_bytes = static_cast<int>(split_row_bytes / 128 * 128);
+    g.split_tail_bytes = static_cast<int>(split_row_bytes - g.split_main_bytes);
+    g.off_split_main = off;
+    off = align_up(off + static_cast<size_t>(split_rows) * g.split_main_bytes, 256);
+    g.off_split_tail = off;
+    off = align_up(off + static_cast<size_t>(split_rows) * g.split_tail_bytes, 256);
   }
   g.total = off;
   return g;
@@ -530,6 +635,16 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.rhs_group = L.rhs_group > 0 ? L.rhs_group : 1;
   p.bd = L.bdims;
   p.accumulate = L.accumulate ? 1 : 0;
+  p.arg_empty = L.arg_empty;
+  p.tune = L.tune;
+  p.utail = nullptr;
+  p.split_main = p.split_tail = 0;
+  if (g.split_main_bytes > 0) {
+    p.ufeat = ws + g.off_split_main;
+    p.utail = ws + g.off_split_tail;
+    p.split_main = g.split_main_bytes / static_cast<int>(sizeof(DT));
+    p.split_tail = g.split_tail_bytes / static_cast<int>(sizeof(DT));
+  }
   p.rel = static_cast<const uint8_t*>(L.rel);
   p.xtab = L.ufeat_tab;
   p.wtab = L.efeat_tab;
@@ -551,6 +666,18 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
   const SpmmParams<Idx> p = make_params<Idx, DT>(L, g);
   const unsigned blocks =
       static_cast<unsigned>((g.num_waves + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (g.split_main_bytes > 0) {
+    char* ws = static_cast<char*>(L.workspace);
+    const int pieces = (g.split_main_bytes + g.split_tail_bytes) / 16;
+    const int64_t total = L.csr.num_cols * pieces;
+    const unsigned sblocks = static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 256 * 64));
+    hipLaunchKernelGGL(spmm_split_rows_kernel<16>, dim3(sblocks), dim3(256), 0, L.stream,
+                       static_cast<const piece16_t*>(L.ufeat),
+                       reinterpret_cast<piece16_t*>(ws + g.off_split_main),
+                       reinterpret_cast<piece16_t*>(ws + g.off_split_tail), L.csr.num_cols, pieces,
+                       g.split_main_bytes / 16);
+    DGLA_CHECK_HIP(hipGetLastError());
+  }
   const ProfileEvents pe = profile_events();
   if (pe.before) DGLA_CHECK_HIP(hipEventRecord(pe.before, L.stream));
   if (L.rel != nullptr) {
@@ -668,8 +795,16 @@ template <typename DT>
 inline int launch_spmm_csr_typed(const SpmmLaunch& L) {
   using A = typename Acc<DT>::type;
   const int vec = spmm_pick_vec<DT>(L);
-  const SpmmGeometry g = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
-                                       L.csr.idbits / 8, L.red != kSum);
+  SpmmGeometry g = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
+                                 L.csr.idbits / 8, L.red != kSum);
+  if (vec * sizeof(DT) == 16 && g.chunks == 1 && spmm_split_shape_ok(L, sizeof(DT))) {
+    // same carve-up plus the two re-laid-out copies of X; used only if the caller's workspace
+    // has room (dgla_spmm_csr_workspace_bytes accounts for it), else the plain layout runs
+    const SpmmGeometry gs = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
+                                          L.csr.idbits / 8, L.red != kSum, L.csr.num_cols,
+                                          L.lhs_len * static_cast<int64_t>(sizeof(DT)));
+    if (L.workspace && L.workspace_bytes >= gs.total) g = gs;
+  }
   if (L.workspace_bytes < g.total || (g.total && !L.workspace)) {
     last_error() = "SpMM workspace too small: need " + std::to_string(g.total) + " bytes";
     return -1;
@@ -690,9 +825,11 @@ inline size_t spmm_csr_workspace_typed(const SpmmLaunch& L) {
   using A = typename Acc<DT>::type;
   constexpr int full = 16 / sizeof(DT);
   size_t best = 0;
+  const bool split = spmm_split_shape_ok(L, sizeof(DT));
   for (int vec : {1, full / 2 > 1 ? full / 2 : 1, full}) {
     const size_t t = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
-                                   L.csr.idbits / 8, L.red != kSum)
+                                   L.csr.idbits / 8, L.red != kSum, split ? L.csr.num_cols : 0,
+                                   L.lhs_len * static_cast<int64_t>(sizeof(DT)))
                          .total;
     if (t > best) best = t;
   }

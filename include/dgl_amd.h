@@ -166,6 +166,49 @@ int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla
                                const dgla_tensor* sds, const dgla_tensor* back, void* workspace,
                                size_t workspace_bytes, uint32_t flags, void* hip_stream);
 
+/* ---- segment reduce / scatter add ----------------------------------------
+ * Replace SegmentReduce / ScatterAdd / BackwardSegmentCmp<kDGLCUDA,…>
+ * (src/array/kernel_decl.h, kernels src/array/cuda/segment_reduce.cuh:30-113; registered as
+ * sparse._CAPI_DGLKernelSegmentReduce / ScatterAdd / BwdSegmentCmp, src/array/kernel.cc:658-708).
+ *
+ * dgla_segment_reduce: out[i, :] = reduce_{j in [offsets[i], offsets[i+1])} feat[j, :],
+ *   reduce in {"sum","max","min"}; offsets has num_segments + 1 entries of idtype_bits;
+ *   `arg` (idtype, shape of out; required for max/min) receives the winning row j, or -1 for
+ *   an element nothing won (empty segment).  Empty segments give 0 / -inf / +inf like the
+ *   reference.  `workspace` may be NULL: scratch is then taken from the stream-ordered HIP
+ *   allocator for the duration of the call.
+ * dgla_scatter_add: out[idx[i], :] += feat[i, :]   (atomic; out is NOT zeroed)
+ * dgla_backward_segment_cmp: out[arg[i, k], k] = feat[i, k] wherever arg[i, k] >= 0 */
+size_t dgla_segment_reduce_workspace_bytes(const char* reduce, int idtype_bits, dgla_dtype dtype,
+                                           const dgla_tensor* feat, int64_t num_segments,
+                                           const dgla_tensor* out);
+int dgla_segment_reduce(const char* reduce, int idtype_bits, dgla_dtype dtype,
+                        const dgla_tensor* feat, const void* offsets, int64_t num_segments,
+                        const dgla_tensor* out, void* arg, void* workspace,
+                        size_t workspace_bytes, uint32_t flags, void* hip_stream);
+int dgla_scatter_add(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat, const void* idx,
+                     const dgla_tensor* out, void* hip_stream);
+int dgla_backward_segment_cmp(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat,
+                              const void* arg, const dgla_tensor* out, void* hip_stream);
+
+/* Process-wide tuning bits of the CSR SpMM.  None of them changes a result bit; they select
+ * memory-system behaviour and exist so that a benchmark can A/B them on the GPU:
+ *   DGLA_TUNE_XCD     units visit the merge path in XCD-contiguous order (block b runs on XCD
+ *                     b % 8, so each XCD's L2 sees one contiguous eighth of the rows)
+ *   DGLA_TUNE_NT_OUT  finished output rows are stored non-temporally
+ *   DGLA_TUNE_NT_IDX  indices / indptr / eids are loaded non-temporally (read-once streams)
+ *   DGLA_TUNE_SPLIT   when a ufeat row is not a whole number of 128-byte lines (F = 100 fp32:
+ *                     400 B = 4 lines touched per gather) the call first copies ufeat into a
+ *                     line-aligned main array + a dense tail array inside the workspace and
+ *                     gathers from those (3 lines + one cached access per edge)
+ * The reference has no counterpart (its kernels take no hints). */
+#define DGLA_TUNE_XCD 1u
+#define DGLA_TUNE_NT_OUT 2u
+#define DGLA_TUNE_NT_IDX 4u
+#define DGLA_TUNE_SPLIT 8u
+int dgla_set_tuning(uint32_t flags);
+uint32_t dgla_get_tuning(void);
+
 /* Benchmark hook: when both are non-NULL (hipEvent_t), the calling thread's next
  * dgla_spmm_csr calls record `before` / `after` on the launch stream around the dominant
  * (merge) kernel only, so its duration can be read with hipEventElapsedTime.  NULL disables. */

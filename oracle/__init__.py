@@ -335,3 +335,45 @@ def edge_softmax_bwd(indptr, eids, out, sds, nthreads=None):
         _i64(indptr.shape[0] - 1), _ptr(indptr), _ptr(eids), _ptr(o), _ptr(s),
         _ptr(back), _i64(dim), _nthreads(nthreads))
     return back
+
+
+# --------------------------------------------------------------------------- #
+# segment reduce / scatter add (src/array/cpu/segment_reduce.h)
+# --------------------------------------------------------------------------- #
+def segment_reduce(reduce, feat, offsets, nthreads=None):
+    """Returns ``(out, arg)``; ``arg`` is None for sum.  Shapes as
+    python/dgl/_sparse_ops.py:641-676 (_segment_reduce) produces them."""
+    assert reduce in ("sum", "max", "min")
+    offsets = np.ascontiguousarray(offsets)
+    idt = offsets.dtype
+    f = np.ascontiguousarray(feat)
+    n = offsets.shape[0] - 1
+    dim = int(np.prod(f.shape[1:])) if f.ndim > 1 else 1
+    out = np.zeros((n,) + f.shape[1:], dtype=f.dtype)
+    arg = None if reduce == "sum" else np.zeros(out.shape, dtype=idt)
+    getattr(lib(), "oracle_segment_reduce_" + _sfx(f.dtype, idt))(
+        {"sum": -1, "max": 1, "min": 0}[reduce], _i64(n), _ptr(offsets), _ptr(f), _ptr(out),
+        _ptr(arg), _i64(dim), _nthreads(nthreads))
+    return out, arg
+
+
+def scatter_add(feat, idx, out):
+    """In place: ``out[idx[i]] += feat[i]`` for i ascending."""
+    idx = np.ascontiguousarray(idx)
+    f = np.ascontiguousarray(feat, dtype=out.dtype)
+    assert out.flags.c_contiguous
+    dim = int(np.prod(out.shape[1:])) if out.ndim > 1 else 1
+    getattr(lib(), "oracle_scatter_add_" + _sfx(out.dtype, idx.dtype))(
+        _i64(f.shape[0]), _ptr(idx), _ptr(f), _ptr(out), _i64(dim))
+    return out
+
+
+def backward_segment_cmp(feat, arg, out):
+    """In place: ``out[arg[i, k], k] = feat[i, k]`` where ``arg >= 0``."""
+    arg = np.ascontiguousarray(arg)
+    f = np.ascontiguousarray(feat, dtype=out.dtype)
+    assert out.flags.c_contiguous
+    dim = int(np.prod(out.shape[1:])) if out.ndim > 1 else 1
+    getattr(lib(), "oracle_bwd_segment_cmp_" + _sfx(out.dtype, arg.dtype))(
+        _i64(f.shape[0]), _ptr(arg), _ptr(f), _ptr(out), _i64(dim))
+    return out

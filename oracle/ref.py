@@ -277,3 +277,42 @@ def edge_softmax_bwd(indptr, eids, out, sds, indices=None, bf16=False):
                                            _i64(indices.shape[0]), _ptr(indptr), _ptr(indices),
                                            _ptr(eids), _fp(f1), _fp(f2), _fp(f3)))
     return back.reshape(np.shape(out))
+
+
+# --------------------------------------------------------------------------- #
+# segment reduce family (src/array/cpu/segment_reduce.cc)
+# --------------------------------------------------------------------------- #
+def segment_reduce(reduce, feat, offsets):
+    offsets = np.ascontiguousarray(offsets)
+    idt = offsets.dtype
+    f = np.ascontiguousarray(feat)
+    n = offsets.shape[0] - 1
+    out = np.zeros((n,) + f.shape[1:], dtype=f.dtype)
+    arg = None if reduce == "sum" else np.zeros(out.shape, dtype=idt)
+    ff, k1 = _feat(f)
+    of, k2 = _feat(out)
+    _check(lib().ref_segment_reduce(reduce.encode(), idt.itemsize * 8, _dcode(out), _i64(n),
+                                    _ptr(offsets), _fp(ff), _fp(of), _ptr(arg)))
+    return out, arg
+
+
+def scatter_add(feat, idx, out):
+    idx = np.ascontiguousarray(idx)
+    f = np.ascontiguousarray(feat, dtype=out.dtype)
+    assert out.flags.c_contiguous
+    ff, k1 = _feat(f)
+    of, k2 = _feat(out)
+    _check(lib().ref_scatter_add(idx.dtype.itemsize * 8, _dcode(out), _i64(f.shape[0]), _ptr(idx),
+                                 _fp(ff), _fp(of)))
+    return out
+
+
+def backward_segment_cmp(feat, arg, out):
+    arg = np.ascontiguousarray(arg)
+    f = np.ascontiguousarray(feat, dtype=out.dtype)
+    assert out.flags.c_contiguous
+    ff, k1 = _feat(f)
+    of, k2 = _feat(out)
+    _check(lib().ref_backward_segment_cmp(arg.dtype.itemsize * 8, _dcode(out), _fp(ff), _ptr(arg),
+                                          _fp(of)))
+    return out

@@ -5,6 +5,7 @@
 //     src/array/cpu/spmm.cc  (+ spmm.h, spmm_binary_ops.h)   SpMMCsr / SpMMCoo / Edge_softmax_*
 //     src/array/cpu/sddmm.cc (+ sddmm.h, ../selector.h)      SDDMMCsr / SDDMMCoo
 //     src/bcast.cc                                           CalcBcastOff
+//     src/array/cpu/segment_reduce.cc (+ segment_reduce.h)   SegmentReduce / ScatterAdd / BackwardSegmentCmp
 // Nothing of the reference is copied into this repository.  The empty third_party/dmlc-core
 // submodule is replaced by the from-scratch headers in oracle/ref_shim/dmlc/.  libxsmm is
 // absent (empty submodule), so USE_LIBXSMM is undefined and the reference takes its naive
@@ -51,6 +52,13 @@ template <int XPU, typename IdType, typename DType>
 void Edge_softmax_csr_backward(const std::string& op, const BcastOff& bcast,
                                const CSRMatrix& csr, NDArray out, NDArray sds,
                                NDArray back_out);
+// src/array/cpu/segment_reduce.cc:18-57 (declared in src/array/kernel_decl.h)
+template <int XPU, typename IdType, typename DType>
+void SegmentReduce(const std::string& op, NDArray feat, NDArray offsets, NDArray out, NDArray arg);
+template <int XPU, typename IdType, typename DType>
+void ScatterAdd(NDArray feat, NDArray idx, NDArray out);
+template <int XPU, typename IdType, typename DType>
+void BackwardSegmentCmp(NDArray feat, NDArray arg, NDArray out);
 }  // namespace aten
 
 namespace runtime {
@@ -334,6 +342,47 @@ int ref_edge_softmax_backward(int idbits, int dtype, int64_t num_rows, int64_t n
     const auto csr = make_csr(num_rows, num_cols, nnz, idbits, indptr, indices, eids);
     REF_TYPE_SWITCH(idbits, dtype, IdType, DType, {
       dgl::aten::Edge_softmax_csr_backward<kDGLCPU, IdType, DType>("copy_rhs", bcast, csr, O, S, B);
+    });
+  });
+}
+
+// SegmentReduce<kDGLCPU> (src/array/cpu/segment_reduce.cc:18-35).  For "sum" `out` must be
+// pre-zeroed by the caller (python/dgl/_sparse_ops.py:665 allocates F.zeros); max/min fill it.
+int ref_segment_reduce(const char* op, int idbits, int dtype, int64_t num_segments,
+                       const void* offsets, const Feat* feat, const Feat* out, void* arg) {
+  return guarded([&] {
+    NDArray F = feat_view(feat, dtype), O = feat_view(out, dtype);
+    NDArray Off = id_view(offsets, num_segments + 1, idbits);
+    NDArray A = arg ? make_view(arg, out->ndim, out->shape, 0, static_cast<uint8_t>(idbits))
+                    : null_array();
+    if (dtype != 0 && dtype != 1) throw std::runtime_error("segment reduce: f32 / f64 only");
+    REF_TYPE_SWITCH(idbits, dtype, IdType, DType, {
+      dgl::aten::SegmentReduce<kDGLCPU, IdType, DType>(op, F, Off, O, A);
+    });
+  });
+}
+
+int ref_scatter_add(int idbits, int dtype, int64_t n, const void* idx, const Feat* feat,
+                    const Feat* out) {
+  return guarded([&] {
+    NDArray F = feat_view(feat, dtype), O = feat_view(out, dtype);
+    NDArray I = id_view(idx, n, idbits);
+    if (dtype != 0 && dtype != 1) throw std::runtime_error("scatter add: f32 / f64 only");
+    REF_TYPE_SWITCH(idbits, dtype, IdType, DType, {
+      dgl::aten::ScatterAdd<kDGLCPU, IdType, DType>(F, I, O);
+    });
+  });
+}
+
+int ref_backward_segment_cmp(int idbits, int dtype, const Feat* feat, const void* arg,
+                             const Feat* out) {
+  return guarded([&] {
+    NDArray F = feat_view(feat, dtype), O = feat_view(out, dtype);
+    NDArray A = make_view(const_cast<void*>(arg), feat->ndim, feat->shape, 0,
+                          static_cast<uint8_t>(idbits));
+    if (dtype != 0 && dtype != 1) throw std::runtime_error("backward segment cmp: f32 / f64 only");
+    REF_TYPE_SWITCH(idbits, dtype, IdType, DType, {
+      dgl::aten::BackwardSegmentCmp<kDGLCPU, IdType, DType>(F, A, O);
     });
   });
 }

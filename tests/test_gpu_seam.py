@@ -554,3 +554,60 @@ def test_edge_softmax_geometries(dev, n_dst, n_edges, dim, idtype, dtype, merge)
     np.add.at(sums, rows, out.cpu().numpy()[eids].astype(np.float64))
     nz = np.diff(indptr) > 0
     np.testing.assert_allclose(sums[nz], 1.0, rtol=1e-5)
+
+
+# --------------------------------------------------------------------------------------
+# Tuning bits (dgla_set_tuning): XCD-contiguous order, non-temporal streams, split-row layout.
+# They only steer the memory system: every setting must give the SAME BITS as flags = 0.
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("feat,tdtype", [(100, torch.float32), (36, torch.float32),
+                                         (100, torch.bfloat16), (200, torch.float16),
+                                         (50, torch.float64)])
+@pytest.mark.parametrize("op,reduce", [("copy_lhs", "sum"), ("mul", "sum"), ("copy_lhs", "max")])
+def test_spmm_tuning_bits_do_not_change_results(dev, feat, tdtype, op, reduce):
+    from dgl_amd import _capi
+
+    # large enough that the split-row layout is eligible for 400-byte rows
+    # (N_src * row bytes >= 64 MiB, E >= 4 N_src); columns != rows to catch mix-ups
+    n_dst, n_src, e = 50_000, 180_000, 800_000
+    g = synth_csr(n_dst, n_src, e, "U", seed=77, device=dev, with_eids=True)
+    torch.manual_seed(5)
+    x = (torch.rand(n_src, feat, device=dev) + 1).to(tdtype)
+    w = (torch.rand(e, 1, device=dev) + 1).to(tdtype) if op == "mul" else None
+    csr = _capi.make_csr(g["indptr"], g["indices"], g["eids"], n_src)
+    results = {}
+    default = _capi.get_tuning()
+    try:
+        for flags in (0, 1, 2, 4, 8, 15):
+            _capi.set_tuning(flags)
+            assert _capi.get_tuning() == flags
+            out = torch.full((n_dst, feat), -3.0, dtype=tdtype, device=dev)
+            au = torch.full((n_dst, feat), -9, dtype=torch.int32, device=dev) if reduce != "sum" else None
+            ae = None
+            ws = torch.empty(_capi.spmm_csr_workspace_bytes(op, reduce, csr, x.dtype, x, w, out),
+                             dtype=torch.uint8, device=dev)
+            _capi.spmm_csr(op, reduce, csr, x, w, out, au, ae, ws)
+            # second call with the cached plan (and, for split, a fresh re-layout of X)
+            _capi.spmm_csr(op, reduce, csr, x, w, out, au, ae, ws, plan_valid=True)
+            torch.cuda.synchronize()
+            results[flags] = (out.clone(), None if au is None else au.clone(), ws.numel())
+    finally:
+        _capi.set_tuning(default)
+    base = results[0]
+    for flags, (o, a, _) in results.items():
+        assert torch.equal(o.view(torch.uint8), base[0].view(torch.uint8)), "flags=%d" % flags
+        if a is not None:
+            assert torch.equal(a, base[1]), "flags=%d" % flags
+    row_bytes = feat * x.element_size()
+    if row_bytes % 128 and row_bytes >= 128 and row_bytes % 16 == 0 and row_bytes * n_src >= 64 << 20:
+        assert results[8][2] >= results[0][2] + n_src * row_bytes  # the re-laid-out copy of X
+    # and the shared result is the right one
+    host = [t.cpu().numpy() for t in (g["indptr"], g["indices"], g["eids"])]
+    if tdtype in (torch.float32, torch.float64):
+        ref, ru, _ = oracle.spmm_csr(op, reduce, host[0], host[1], host[2], x.cpu().numpy(),
+                                     None if w is None else w.cpu().numpy())
+        if reduce == "sum":
+            np.testing.assert_allclose(base[0].cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+        else:
+            np.testing.assert_array_equal(base[0].cpu().numpy(), ref)
+            np.testing.assert_array_equal(base[1].cpu().numpy(), ru)
