@@ -96,6 +96,9 @@ LIB.dgla_scatter_add.restype = c_int
 LIB.dgla_scatter_add.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
 LIB.dgla_backward_segment_cmp.restype = c_int
 LIB.dgla_backward_segment_cmp.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
+LIB.dgla_partition_kway.restype = c_int
+LIB.dgla_partition_kway.argtypes = [c_int, c_int64, c_void_p, c_void_p, c_int, ctypes.c_double, c_int,
+                                    ctypes.c_uint64, c_void_p, c_void_p]
 LIB.dgla_set_tuning.restype = c_int
 LIB.dgla_set_tuning.argtypes = [c_uint32]
 LIB.dgla_get_tuning.restype = c_uint32

@@ -610,6 +610,7 @@ static Registrar r_scatter("sparse._CAPI_DGLKernelScatterAdd",
   if (get_array(a, 0, &feat) || get_array(a, 1, &idx) || get_array(a, 2, &out)) return -1;
   if (!feat || !idx || !out) return ffi_fail("feat / idx / out is required");
   if (null_array(feat)) return 0;
+  if (null_array(out)) return ffi_fail("out is empty but feat is not");
   if (seg_arrays_ok({feat, idx, out})) return -1;
   dgla_dtype dt, df;
   int bits;
@@ -630,7 +631,7 @@ static Registrar r_bwdseg("sparse._CAPI_DGLKernelBwdSegmentCmp",
   DGLArray *feat, *arg, *out;
   if (get_array(a, 0, &feat) || get_array(a, 1, &arg) || get_array(a, 2, &out)) return -1;
   if (!feat || !arg || !out) return ffi_fail("feat / arg / out is required");
-  if (null_array(feat)) return 0;
+  if (null_array(feat) || null_array(out)) return 0;  // nothing to scatter / nowhere to write
   if (seg_arrays_ok({feat, arg, out})) return -1;
   dgla_dtype dt, df;
   int bits;

@@ -137,3 +137,80 @@ def shard_csr(indptr, indices, eids, bounds, rank):
         "n_local": hi - lo, "n_halo": base - (hi - lo), "requests": requests,
         "row_range": (lo, hi),
     }
+
+
+# ---------------------------------------------------------------------------------------
+# Node-cut partitioning (the reference: metis_partition_assignment + reshuffle,
+# python/dgl/partition.py:278-397, python/dgl/distributed/partition.py reshuffle=True)
+# ---------------------------------------------------------------------------------------
+def partition_assignment(indptr, indices, k, balance_edges=True, imbalance=0.03, seed=0):
+    """Part id of every node of a square graph given as a CSR (rows = destination nodes), from
+    the native multilevel partitioner in libdgl_amd.so (csrc/partition.cc), which stands where
+    METIS stands in the reference.  Host-side preprocessing: tensors are taken on the CPU.
+
+    Returns ``(node_part int64[N], stats)`` with ``stats`` = cut edges, cut fraction,
+    heaviest / average part weight and the number of multilevel levels."""
+    import ctypes
+
+    from ._lib import LIB, check_call
+
+    ip = indptr.detach().cpu().contiguous()
+    ix = indices.detach().cpu().to(ip.dtype).contiguous()
+    n = ip.numel() - 1
+    bits = {torch.int32: 32, torch.int64: 64}[ip.dtype]
+    part = torch.empty(n, dtype=torch.int64)
+    st = (ctypes.c_int64 * 4)()
+    check_call(LIB.dgla_partition_kway(bits, n, ip.data_ptr(), ix.data_ptr(), int(k),
+                                       float(imbalance), 1 if balance_edges else 0, int(seed),
+                                       part.data_ptr(), ctypes.cast(st, ctypes.c_void_p)))
+    nnz = max(int(ix.numel()), 1)
+    stats = {"cut_edges": int(st[0]), "cut_fraction": int(st[0]) / nnz,
+             "max_part_weight": int(st[1]), "avg_part_weight": int(st[2]), "levels": int(st[3])}
+    return part, stats
+
+
+def reshuffle(node_part, k):
+    """Relabelling that makes every part a contiguous id range (reshuffle=True in the
+    reference): returns ``(orig_id, new_id, bounds)`` with ``orig_id[new] = old``,
+    ``new_id[old] = new`` and ``bounds`` the ``k + 1`` range boundaries.  Stable inside a
+    part, so node order within a part is preserved."""
+    node_part = node_part.cpu()
+    orig_id = torch.argsort(node_part, stable=True)
+    new_id = torch.empty_like(orig_id)
+    new_id[orig_id] = torch.arange(orig_id.numel(), dtype=orig_id.dtype)
+    counts = torch.bincount(node_part, minlength=k)
+    bounds = torch.zeros(k + 1, dtype=torch.int64)
+    bounds[1:] = torch.cumsum(counts, 0)
+    return orig_id, new_id, bounds
+
+
+def relabel_csr(indptr, indices, eids, orig_id, new_id):
+    """The same square graph with node ``old`` renamed ``new_id[old]`` (rows reordered, column
+    ids renamed and re-sorted inside each row; edge ids follow their edges).  Internal only:
+    results are mapped back with ``orig_id``."""
+    indptr, indices = indptr.cpu().long(), indices.cpu().long()
+    deg = indptr[1:] - indptr[:-1]
+    new_deg = deg[orig_id]
+    new_indptr = torch.zeros_like(indptr)
+    new_indptr[1:] = torch.cumsum(new_deg, 0)
+    # gather the old rows in the new order
+    starts = indptr[:-1][orig_id]
+    pos = torch.repeat_interleave(starts - new_indptr[:-1], new_deg) + torch.arange(int(new_indptr[-1]))
+    cols = new_id[indices[pos]]
+    e = pos if eids is None else eids.cpu().long()[pos]
+    rows = torch.repeat_interleave(torch.arange(orig_id.numel()), new_deg)
+    order = torch.argsort(rows * orig_id.numel() + cols, stable=True)
+    return new_indptr, cols[order], e[order]
+
+
+def halo_fraction(indptr, indices, bounds):
+    """Fraction of stored edges whose column is owned by another part and, per part, the number
+    of distinct remote rows it has to pull (the per-step exchange volume in rows)."""
+    indptr, indices = indptr.cpu().long(), indices.cpu().long()
+    k = bounds.numel() - 1
+    rows = torch.repeat_interleave(torch.arange(indptr.numel() - 1), indptr[1:] - indptr[:-1])
+    row_part = torch.searchsorted(bounds[1:], rows, right=True)
+    col_part = torch.searchsorted(bounds[1:], indices, right=True)
+    remote = row_part != col_part
+    halo_rows = [int(torch.unique(indices[remote & (row_part == p)]).numel()) for p in range(k)]
+    return float(remote.float().mean()) if indices.numel() else 0.0, halo_rows

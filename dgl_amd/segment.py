@@ -56,7 +56,7 @@ def _bwd_segment_cmp(feat, arg, m):
     (python/dgl/_sparse_ops.py:733-760)."""
     feat = feat.contiguous()
     out = torch.zeros((m,) + tuple(feat.shape[1:]), dtype=feat.dtype, device=feat.device)
-    if feat.numel():
+    if feat.numel() and out.numel():
         _call("sparse._CAPI_DGLKernelBwdSegmentCmp", feat, _nd(feat), _nd(arg.contiguous()), _nd(out))
     return out
 

@@ -191,6 +191,19 @@ int dgla_scatter_add(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat,
 int dgla_backward_segment_cmp(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat,
                               const void* arg, const dgla_tensor* out, void* hip_stream);
 
+/* ---- k-way node-cut partitioner (host code) ---------------------------------
+ * Stands where METIS stands in the reference: metis_partition_assignment
+ * (python/dgl/partition.py:278-397 -> _CAPI_DGLMetisPartition_Hetero).  Multilevel
+ * size-constrained label propagation (csrc/partition.cc).  The CSR (HOST pointers, rows =
+ * destination nodes, square) is symmetrised internally like the reference does.
+ *   imbalance      allowed excess of a part's weight over the average, e.g. 0.03
+ *   balance_edges  vertex weight = 1 + in-degree instead of 1 (the reference's flag)
+ *   out_part       [num_nodes] int64, the part of every node
+ *   stats          optional [4]: cut edges, heaviest part weight, average part weight, levels */
+int dgla_partition_kway(int idtype_bits, int64_t num_nodes, const void* indptr,
+                        const void* indices, int num_parts, double imbalance, int balance_edges,
+                        uint64_t seed, int64_t* out_part, int64_t* stats);
+
 /* Process-wide tuning bits of the CSR SpMM.  None of them changes a result bit; they select
  * memory-system behaviour and exist so that a benchmark can A/B them on the GPU:
  *   DGLA_TUNE_XCD     units visit the merge path in XCD-contiguous order (block b runs on XCD

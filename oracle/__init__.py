@@ -137,7 +137,10 @@ def _prep_feat(x, dtype):
 
 
 def _nthreads(n):
-    return int(n) if n else (os.cpu_count() or 1)
+    # default: at most 8 threads.  Nearly every caller is a parity test on a graph of a few
+    # hundred edges, where waking a 64-256 thread team costs far more than the kernel; the
+    # timed CPU baseline (bench.py) passes its thread count explicitly.
+    return int(n) if n else max(1, min((os.cpu_count() or 2) // 2, 8))
 
 
 def _i64(v):

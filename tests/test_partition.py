@@ -1,0 +1,103 @@
+"""The native k-way partitioner (csrc/partition.cc; stands where METIS stands in the
+reference, python/dgl/partition.py:278-397) and the relabelling that turns its answer into the
+contiguous row ranges the sharded SpMM uses.  Host code: runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from dgl_amd.parallel import (halo_fraction, partition_assignment, partition_rows, relabel_csr,
+                              reshuffle, shard_csr)
+from tests.graphgen import coo_to_csc
+
+
+def planted(k, per, deg, p_in, seed, shuffle=True):
+    """k communities of `per` nodes; every node draws `deg` in-neighbours, a fraction p_in of
+    them from its own community; node ids shuffled so that ranges carry no information."""
+    rng = np.random.default_rng(seed)
+    n = k * per
+    comm = np.repeat(np.arange(k), per)
+    dst = np.repeat(np.arange(n), deg)
+    inside = rng.random(n * deg) < p_in
+    src = np.where(inside, comm[dst] * per + rng.integers(0, per, n * deg), rng.integers(0, n, n * deg))
+    perm = rng.permutation(n) if shuffle else np.arange(n)
+    src, dst = perm[src], perm[dst]
+    truth = np.empty(n, dtype=np.int64)
+    truth[perm] = comm
+    indptr, indices, _ = coo_to_csc(src, dst, n, np.int64)
+    return torch.from_numpy(indptr), torch.from_numpy(indices), truth
+
+
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+def test_recovers_planted_communities(idtype):
+    k = 8
+    indptr, indices, truth = planted(k, 1500, 12, 0.9, seed=1)
+    part, st = partition_assignment(indptr.to(idtype), indices.to(idtype), k, imbalance=0.05, seed=3)
+    assert part.shape == (k * 1500,) and int(part.min()) == 0 and int(part.max()) == k - 1
+    # planted cut: ~10 % of the edges leave their community (+ the share of random edges that
+    # happen to land inside): a contiguous split of the shuffled ids would cut 87.5 %
+    rows = np.repeat(np.arange(len(truth)), np.diff(indptr.numpy()))
+    planted_cut = float((truth[rows] != truth[indices.numpy()]).mean())
+    assert 0.05 < planted_cut < 0.12
+    assert st["cut_fraction"] <= 1.25 * planted_cut, st
+    assert st["max_part_weight"] <= 1.06 * st["avg_part_weight"] + 20, st
+    # stats agree with a recount
+    p = part.numpy()
+    sym_cut = (p[rows] != p[indices.numpy()]).sum()
+    assert sym_cut >= st["cut_edges"] * 0.99  # merged parallel edges count once per pair weight
+    # deterministic
+    part2, _ = partition_assignment(indptr.to(idtype), indices.to(idtype), k, imbalance=0.05, seed=3)
+    assert torch.equal(part, part2)
+
+
+def test_degenerate_inputs():
+    # one part, more parts than nodes with edges, isolated nodes, self loops only
+    indptr = torch.tensor([0, 1, 2, 2, 3], dtype=torch.int64)
+    indices = torch.tensor([0, 0, 3], dtype=torch.int64)
+    part, st = partition_assignment(indptr, indices, 1)
+    assert torch.equal(part, torch.zeros(4, dtype=torch.int64)) and st["cut_edges"] == 0
+    part, st = partition_assignment(indptr, indices, 3, imbalance=0.5)
+    assert part.numel() == 4 and 0 <= int(part.min()) and int(part.max()) < 3
+    empty, _ = partition_assignment(torch.zeros(1, dtype=torch.int64), torch.zeros(0, dtype=torch.int64), 4)
+    assert empty.numel() == 0
+
+
+def test_partitioned_spmm_equals_unpartitioned():
+    """partition -> reshuffle -> relabel -> shard per rank -> oracle SpMM per shard with halo
+    rows filled from the owners -> map back: equals the SpMM of the original graph."""
+    k = 4
+    indptr, indices, _ = planted(k, 300, 8, 0.85, seed=5)
+    n = indptr.numel() - 1
+    rng = np.random.default_rng(0)
+    x = rng.random((n, 6))
+    full, _, _ = oracle.spmm_csr("copy_lhs", "sum", indptr.numpy(), indices.numpy(), None, x, None)
+    part, st = partition_assignment(indptr, indices, k, seed=1)
+    orig_id, new_id, bounds = reshuffle(part, k)
+    assert torch.equal(new_id[orig_id], torch.arange(n)) and int(bounds[-1]) == n
+    ip2, ix2, e2 = relabel_csr(indptr, indices, None, orig_id, new_id)
+    # e2 names the original edge position of every relabelled edge
+    assert torch.equal(torch.sort(e2)[0], torch.arange(indices.numel()))
+    x2 = x[orig_id.numpy()]
+    out2 = np.zeros_like(x2)
+    for r in range(k):
+        sh = shard_csr(ip2, ix2, None, bounds, r)
+        lo, hi = sh["row_range"]
+        xl = np.zeros((sh["n_local"] + sh["n_halo"], x.shape[1]))
+        xl[: sh["n_local"]] = x2[lo:hi]
+        off = sh["n_local"]
+        for p in sorted(sh["requests"]):
+            rows = sh["requests"][p].numpy() + int(bounds[p])
+            xl[off: off + len(rows)] = x2[rows]
+            off += len(rows)
+        loc, _, _ = oracle.spmm_csr("copy_lhs", "sum", sh["indptr"].numpy(), sh["indices"].numpy(),
+                                    None, xl, None)
+        out2[lo:hi] = loc
+    back = np.empty_like(out2)
+    back[orig_id.numpy()] = out2
+    np.testing.assert_allclose(back, full, rtol=1e-12)
+    # the partitioner's cut is what the halo exchange pays for: far below the naive split
+    frac, halo_rows = halo_fraction(ip2, ix2, bounds)
+    naive = partition_rows(indptr, k)
+    naive_frac, naive_rows = halo_fraction(indptr, indices, naive)
+    assert frac < 0.5 * naive_frac and sum(halo_rows) < sum(naive_rows)
+    assert abs(frac - st["cut_fraction"]) < 0.05

@@ -74,6 +74,20 @@ def test_docstring_example():
     assert out[1, 0] == -np.inf and arg[1, 0] == -1 and arg[3, 0] == 9 and arg.dtype == np.int32
 
 
+def _assert_sum_close(got, want, c):
+    """The features are standard normal, so segment sums cancel: the error of ANY summation
+    order is bounded by n * eps * sum|x| (not by a multiple of the result).  Bar: within
+    (1e-5 + 2 n eps) * sum|x| of the reference value, n = longest segment — for positive data
+    this is the north-star's 1e-5 relative."""
+    f64 = c["feat"].astype(np.float64)
+    mag, _ = oracle.segment_reduce("sum", np.abs(f64), c["offsets"])
+    longest = int(np.diff(c["offsets"]).max()) if len(c["offsets"]) > 1 else 0
+    eps = 2.0 ** -24 if c["feat"].dtype == np.float32 else 2.0 ** -53
+    bound = (1e-5 * (eps / 2.0 ** -24) + 2 * longest * eps) * mag + 1e-30
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    assert (err <= bound).all(), (c["name"], float((err / bound).max()))
+
+
 # ---- GPU ---------------------------------------------------------------------------------
 def _gpu_run(dev, c, via):
     from dgl_amd import _capi
@@ -127,9 +141,7 @@ def test_gpu_matches_reference_outputs(dev, golden, c, via):
     for k, v in want.items():
         assert got[k].dtype == v.dtype and got[k].shape == v.shape, k
         if c["kind"] == "segment_reduce" and c["reduce"] == "sum":
-            longest = int(np.diff(c["offsets"]).max()) if len(c["offsets"]) > 1 else 0
-            np.testing.assert_allclose(got[k], v, rtol=1e-5 + 2 * longest * 2.0 ** -24, atol=1e-5,
-                                       err_msg=c["name"])
+            _assert_sum_close(got[k], v, c)
         else:  # max/min values, args, scattered gradients, exact-by-construction scatter sums
             np.testing.assert_array_equal(got[k], v, err_msg="%s/%s" % (c["name"], k))
 
@@ -148,8 +160,7 @@ def test_gpu_full_sweep_vs_oracle(dev, reduce, dtype, idtype):
         got = _gpu_run(dev, c, "seam")
         if reduce == "sum":
             exact = run_case(oracle, dict(c, feat=c["feat"].astype(np.float64)))["out"]
-            np.testing.assert_allclose(got["out"], exact, rtol=1e-5 if dtype == np.float32 else 1e-12,
-                                       atol=1e-5 if dtype == np.float32 else 1e-12, err_msg=c["name"])
+            _assert_sum_close(got["out"], exact, c)
         else:
             for k in ("out", "arg", "back"):
                 np.testing.assert_array_equal(got[k], want[k], err_msg="%s/%s" % (c["name"], k))
