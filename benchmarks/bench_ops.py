@@ -202,6 +202,44 @@ def c5(dev, args):
     emit("C5", "one relation copy_u_sum bf16 F=256 (write)", e, ms, mn, e * (f * s + i) + (n + 1) * i + n * f * s)
 
 
+def seg(dev, args):
+    """Segment reduce / scatter add at readout-like shapes: F = 100 fp32.
+    (a) 62 M rows in 2.4 M segments of C2's degree sequence (= copy_e SpMM of C2),
+    (b) the same rows in 64 huge segments (graph readout over a batch of 64 graphs),
+    (c) scatter add of 62 M rows into 2.4 M rows is skipped unless --big (24.7 GB in)
+    Algorithmic bytes: rows*F*s read + segments*F*s written + (segments+1)*i."""
+    from tests.graphgen import lognormal_degrees
+
+    rows = C2_EDGES // args.scale // 4      # 15.5 M rows x 400 B = 6.2 GB
+    f = 100
+    torch.manual_seed(3)
+    feat = torch.rand(rows, f, device=dev)
+    for label, nseg in (("C2-like degree sequence", C2_NODES // args.scale // 4), ("64 equal segments", 64)):
+        if nseg == 64:
+            lens = np.full(64, rows // 64, dtype=np.int64)
+            lens[-1] += rows - lens.sum()
+        else:
+            lens = lognormal_degrees(nseg, rows)
+        off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)])).to(dev)
+        for red in ("sum", "max"):
+            out = torch.empty(nseg, f, device=dev)
+            arg = torch.empty(nseg, f, dtype=torch.int64, device=dev) if red == "max" else None
+            ws = torch.empty(max(1, _capi.segment_reduce_workspace_bytes(red, feat, off, out)),
+                             dtype=torch.uint8, device=dev)
+            _capi.segment_reduce(red, feat, off, out, arg, ws)
+            ms, mn = timeit(lambda: _capi.segment_reduce(red, feat, off, out, arg, ws, plan_valid=True))
+            nb = rows * f * 4 + nseg * f * 4 + (nseg + 1) * 8 + (nseg * f * 8 if red == "max" else 0)
+            emit("SEG", "segment_reduce %s, %d rows -> %d segments (%s), F=100 fp32" % (red, rows, nseg, label),
+                 rows, ms, mn, nb)
+    # scatter add: rows -> nseg random targets (atomics)
+    nseg = C2_NODES // args.scale // 4
+    idx = torch.randint(0, nseg, (rows,), device=dev)
+    acc = torch.zeros(nseg, f, device=dev)
+    ms, mn = timeit(lambda: _capi.scatter_add(feat, idx, acc), reps=5)
+    emit("SEG", "scatter_add %d rows -> %d rows (random idx, fp32 atomics), F=100" % (rows, nseg), rows, ms, mn,
+         rows * (f * 4 * 2 + 8))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -210,7 +248,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5)):
+    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("SEG", seg)):
         if args.only and name not in args.only.split(","):
             continue
         fn(dev, args)

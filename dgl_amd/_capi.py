@@ -246,3 +246,43 @@ def backward_segment_cmp(feat, arg, out):
     _require_gpu(arg)
     check_call(LIB.dgla_backward_segment_cmp(_idbits(arg), _DTYPES[out.dtype], ctypes.byref(tf),
                                              arg.data_ptr(), ctypes.byref(to), _stream(out)))
+
+
+def _mm_check(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        _require_gpu(t)
+        if not t.is_contiguous():
+            raise _lib.DGLAMDError("matrices handed to segment_mm / gather_mm must be contiguous")
+
+
+def segment_mm(a, b, c, seglen, b_trans=False):
+    """c[rows of r] = a[rows of r] @ b[r]  (or @ b[r].T when b_trans); `seglen` may be a CPU or
+    GPU int32/int64 tensor (dgla_segment_mm)."""
+    _mm_check(a, b, c)
+    k = a.shape[1]
+    n = c.shape[1]
+    check_call(LIB.dgla_segment_mm(_idbits(seglen), _DTYPES[a.dtype], a.data_ptr(), b.data_ptr(),
+                                   c.data_ptr(), seglen.data_ptr(), 0 if seglen.is_cuda else 1,
+                                   a.shape[0], seglen.shape[0], k, n, 1 if b_trans else 0, None, 0,
+                                   _stream(a)))
+
+
+def segment_mm_backward_b(a, dc, db, seglen):
+    """db[r] = a[rows of r].T @ dc[rows of r] (dgla_segment_mm_backward_b)."""
+    _mm_check(a, dc, db)
+    check_call(LIB.dgla_segment_mm_backward_b(
+        _idbits(seglen), _DTYPES[a.dtype], a.data_ptr(), dc.data_ptr(), db.data_ptr(),
+        seglen.data_ptr(), 0 if seglen.is_cuda else 1, a.shape[0], seglen.shape[0], a.shape[1],
+        dc.shape[1], None, 0, _stream(a)))
+
+
+def gather_mm(a, b, c, idx_a=None, idx_b=None, idx_c=None):
+    """c[idx_c[i]] = a[idx_a[i]] @ b[idx_b[i]] (dgla_gather_mm); absent index = identity."""
+    _mm_check(a, b, c, idx_a, idx_b, idx_c)
+    ref = next(t for t in (idx_a, idx_b, idx_c) if t is not None)
+    rows = ref.shape[0]
+    check_call(LIB.dgla_gather_mm(_idbits(ref), _DTYPES[a.dtype], a.data_ptr(), b.data_ptr(),
+                                  c.data_ptr(), _ptr(idx_a), _ptr(idx_b), _ptr(idx_c), rows,
+                                  a.shape[1], b.shape[-1], _stream(a)))

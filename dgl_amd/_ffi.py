@@ -16,6 +16,7 @@ from ._lib import LIB
 # type codes, include/dgl/runtime/c_runtime_api.h:66-91
 kObjectInt, kObjectFloat, kHandle, kNull, kArrayHandle, kObjectHandle, kStr = 0, 2, 3, 4, 7, 8, 11
 kDGLROCM = 10
+kDGLCPU = 1
 
 
 class DGLValue(ctypes.Union):
@@ -55,8 +56,10 @@ class NDArray:
 
     __slots__ = ("tensor", "_shape", "arr")
 
-    def __init__(self, t, unsqueeze=False):
-        if not t.is_cuda:
+    def __init__(self, t, unsqueeze=False, host_ok=False):
+        # host_ok: small integer side inputs the reference itself keeps in host memory
+        # (segment_mm's seglen, python/dgl/ops/gather_mm.py:57) travel as kDGLCPU arrays
+        if not t.is_cuda and not (host_ok and not t.dtype.is_floating_point):
             raise _lib.DGLAMDError("dgl_amd: tensors must live on a ROCm GPU (no CPU fallback)")
         if not t.is_contiguous():
             raise _lib.DGLAMDError("dgl_amd: tensors handed to the kernels must be contiguous")
@@ -66,8 +69,9 @@ class NDArray:
             shape = (shape[0], 1)
         self._shape = (ctypes.c_int64 * max(len(shape), 1))(*shape)
         code, bits = _DT[t.dtype]
-        self.arr = DGLArray(t.data_ptr(), DGLContext(kDGLROCM, t.device.index or 0), len(shape),
-                            DGLDataType(code, bits, 1), self._shape, None, 0)
+        ctx = DGLContext(kDGLROCM, t.device.index or 0) if t.is_cuda else DGLContext(kDGLCPU, 0)
+        self.arr = DGLArray(t.data_ptr(), ctx, len(shape), DGLDataType(code, bits, 1), self._shape,
+                            None, 0)
 
 
 def _pack(args):

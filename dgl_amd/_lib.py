@@ -96,6 +96,18 @@ LIB.dgla_scatter_add.restype = c_int
 LIB.dgla_scatter_add.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
 LIB.dgla_backward_segment_cmp.restype = c_int
 LIB.dgla_backward_segment_cmp.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
+LIB.dgla_segment_mm_workspace_bytes.restype = c_size_t
+LIB.dgla_segment_mm_workspace_bytes.argtypes = [c_int, c_int64, c_int64, c_int64]
+LIB.dgla_segment_mm.restype = c_int
+LIB.dgla_segment_mm.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                                c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]
+LIB.dgla_segment_mm_backward_b.restype = c_int
+LIB.dgla_segment_mm_backward_b.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_int64, c_int64, c_int64, c_int64, c_void_p, c_size_t,
+                                           c_void_p]
+LIB.dgla_gather_mm.restype = c_int
+LIB.dgla_gather_mm.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_int64, c_int64, c_int64, c_void_p]
 LIB.dgla_partition_kway.restype = c_int
 LIB.dgla_partition_kway.argtypes = [c_int, c_int64, c_void_p, c_void_p, c_int, ctypes.c_double, c_int,
                                     ctypes.c_uint64, c_void_p, c_void_p]

@@ -643,6 +643,106 @@ static Registrar r_bwdseg("sparse._CAPI_DGLKernelBwdSegmentCmp",
   return dgla_backward_segment_cmp(bits, dt, &tf.t, data_ptr(arg), &to.t, tls_stream);
 });
 
+// ---- segment / gather mm (src/array/kernel.cc:501-540) ---------------------------------------
+static int mm_dims(const DGLArray* t, int want_ndim, const char* name) {
+  if (!t || t->ndim != want_ndim)
+    return ffi_fail(std::string(name) + " must be a " + std::to_string(want_ndim) + "-D array");
+  if (!on_gpu(t)) return ffi_fail(std::string(name) + " is not on a GPU device");
+  return check_contiguous(t, name);
+}
+
+// (NDArray A, NDArray B, NDArray C, NDArray seglen_A, bool A_trans, bool B_trans)
+static Registrar r_segmm("sparse._CAPI_DGLKernelSEGMENTMM",
+                         [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  DGLArray *A, *B, *C, *seglen;
+  int64_t a_trans, b_trans;
+  if (get_array(a, 0, &A) || get_array(a, 1, &B) || get_array(a, 2, &C) ||
+      get_array(a, 3, &seglen) || get_int(a, 4, &a_trans) || get_int(a, 5, &b_trans))
+    return -1;
+  if (mm_dims(A, 2, "A") || mm_dims(B, 3, "B") || mm_dims(C, 2, "C")) return -1;
+  if (!seglen || seglen->ndim != 1) return ffi_fail("seglen_A must be a 1-D array");
+  if (a_trans) return ffi_fail("segment_mm: A_trans is not supported (the reference never sets it)");
+  dgla_dtype dt, db, dc;
+  int bits;
+  if (float_dtype(A, &dt) || float_dtype(B, &db) || float_dtype(C, &dc) || idbits_of(seglen, &bits))
+    return -1;
+  if (dt != db || dt != dc) return ffi_fail("A, B and C dtypes differ");
+  // kernel.cc:47-66 checks
+  if (seglen->shape[0] != B->shape[0]) return ffi_fail("segment_mm expects len(seglen_A) == B.shape[0]");
+  const int64_t k = A->shape[1];
+  const int64_t n = C->shape[1];
+  if (C->shape[0] != A->shape[0]) return ffi_fail("segment_mm expects C.shape[0] == A.shape[0]");
+  if (b_trans ? (B->shape[2] != k || B->shape[1] != n) : (B->shape[1] != k || B->shape[2] != n))
+    return ffi_fail("segment_mm expects A.shape[1] == B.shape[1] (B.shape[2] with B_trans) and C to match");
+  const int on_host = on_gpu(seglen) ? 0 : 1;
+  return dgla_segment_mm(bits, dt, data_ptr(A), data_ptr(B), data_ptr(C), data_ptr(seglen), on_host,
+                         A->shape[0], B->shape[0], k, n, b_trans ? 1 : 0, nullptr, 0, tls_stream);
+});
+
+// (NDArray A, NDArray dC, NDArray dB, NDArray seglen)
+static Registrar r_segmm_b("sparse._CAPI_DGLKernelSEGMENTMMBackwardB",
+                           [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  DGLArray *A, *dC, *dB, *seglen;
+  if (get_array(a, 0, &A) || get_array(a, 1, &dC) || get_array(a, 2, &dB) || get_array(a, 3, &seglen))
+    return -1;
+  if (mm_dims(A, 2, "A") || mm_dims(dC, 2, "dC") || mm_dims(dB, 3, "dB")) return -1;
+  if (!seglen || seglen->ndim != 1) return ffi_fail("seglen must be a 1-D array");
+  dgla_dtype dt, d2, d3;
+  int bits;
+  if (float_dtype(A, &dt) || float_dtype(dC, &d2) || float_dtype(dB, &d3) || idbits_of(seglen, &bits))
+    return -1;
+  if (dt != d2 || dt != d3) return ffi_fail("A, dC and dB dtypes differ");
+  if (A->shape[0] != dC->shape[0]) return ffi_fail("segment_mm backward expects A and dC to have the same rows");
+  if (seglen->shape[0] != dB->shape[0] || dB->shape[1] != A->shape[1] || dB->shape[2] != dC->shape[1])
+    return ffi_fail("segment_mm backward expects dB of shape (len(seglen), A.shape[1], dC.shape[1])");
+  return dgla_segment_mm_backward_b(bits, dt, data_ptr(A), data_ptr(dC), data_ptr(dB), data_ptr(seglen),
+                                    on_gpu(seglen) ? 0 : 1, A->shape[0], dB->shape[0], A->shape[1],
+                                    dC->shape[1], nullptr, 0, tls_stream);
+});
+
+static int gather_mm_ffi(const FfiArgs& a, bool scatter) {
+  DGLArray *A, *B, *C, *ia, *ib, *ic = nullptr;
+  if (get_array(a, 0, &A) || get_array(a, 1, &B) || get_array(a, 2, &C) || get_array(a, 3, &ia) ||
+      get_array(a, 4, &ib))
+    return -1;
+  if (scatter && get_array(a, 5, &ic)) return -1;
+  if (mm_dims(A, 2, "A") || mm_dims(B, 3, "B") || mm_dims(C, 2, "C")) return -1;
+  dgla_dtype dt, d2, d3;
+  if (float_dtype(A, &dt) || float_dtype(B, &d2) || float_dtype(C, &d3)) return -1;
+  if (dt != d2 || dt != d3) return ffi_fail("A, B and C dtypes differ");
+  int bits = 0;
+  int64_t rows = -1;
+  for (DGLArray* t : {ia, ib, ic}) {
+    if (null_array(t)) continue;
+    int b;
+    if (!on_gpu(t)) return ffi_fail("index arrays must be on the GPU");
+    if (idbits_of(t, &b)) return -1;
+    if (bits && b != bits) return ffi_fail("index arrays must share one dtype");
+    if (rows >= 0 && t->shape[0] != rows) return ffi_fail("index arrays must have the same length");
+    bits = b;
+    rows = t->shape[0];
+  }
+  if (rows < 0) return ffi_fail("gather_mm needs at least one index array");
+  if (A->shape[1] != B->shape[1]) return ffi_fail("gather_mm expects A.shape[1] == B.shape[1]");
+  if (C->shape[1] != B->shape[2]) return ffi_fail("gather_mm expects C.shape[1] == B.shape[2]");
+  auto ptr = [](DGLArray* t) { return null_array(t) ? nullptr : data_ptr(t); };
+  return dgla_gather_mm(bits, dt, data_ptr(A), data_ptr(B), data_ptr(C), ptr(ia), ptr(ib), ptr(ic),
+                        rows, A->shape[1], B->shape[2], tls_stream);
+}
+// (NDArray A, NDArray B, NDArray C, NDArray idx_a, NDArray idx_b)
+static Registrar r_gmm("sparse._CAPI_DGLKernelGATHERMM", [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  return gather_mm_ffi(a, false);
+});
+// (NDArray A, NDArray B, NDArray C, NDArray idx_a, NDArray idx_b, NDArray idx_c), B 3-D
+static Registrar r_gmms("sparse._CAPI_DGLKernelGATHERMMSCATTER",
+                        [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  return gather_mm_ffi(a, true);
+});
+
 }  // namespace dgla
 
 using namespace dgla;

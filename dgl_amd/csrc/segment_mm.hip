@@ -1,0 +1,656 @@
+// Segment / gather matrix multiply for gfx950: the per-relation dense
+// transform next to the g-SpMM in R-GCN / HGT (nn/pytorch/linear.py:208-210 TypedLinear).
+//
+// Reference: src/array/cuda/gather_mm.cu — SegmentMM :201-246 (a host loop issuing one cuBLAS
+// GEMM per relation), SegmentMMBackwardB :248-291 (same), GatherMM / GatherMMScatter :293-360
+// (one warp per row, scalar FMAs); registered at src/array/kernel.cc:501-540.
+//
+// MI355X-first design: ONE grouped-GEMM launch for all relations.
+//  * A tiny plan kernel turns the segment lengths into a table of 128-row tiles
+//    (tile -> relation, first row); every workgroup of the main kernel looks its tile up with
+//    a binary search, so a relation with 3 rows and one with 30 M rows share the launch and
+//    nothing is serialised on the host.
+//  * 256 threads = 4 wavefronts in a 2 x 2 grid, 128 x 128 output tile, each wave 64 x 64 =
+//    2 x 2 MFMA tiles of 32 x 32: v_mfma_f32_32x32x16_{bf16,f16} for 16-bit storage (fp32
+//    accumulate, as cuBLAS does for the reference: CUBLAS_COMPUTE_32F), v_mfma_f32_32x32x2_f32
+//    for fp32 (exact fp32 FMA chain, no TF32-like rounding).  fp64 takes a plain FMA kernel.
+//  * Both operands are staged through LDS K-contiguous (64-byte row payload, 80-byte pitch), so
+//    every MFMA fragment is one ds_read_b128 (16-bit) / ds_read_b32 (fp32).  The weight operand
+//    is needed K-contiguous per output column: for C = A . B[r] the (small) weights are
+//    transposed once per call into scratch, for C = A . B[r]^T (the backward w.r.t. A) they
+//    already are.  Global accesses are 16-byte pieces; the next K-slab is fetched into
+//    registers while the current one is multiplied.
+//  * Weight-gradient dB[r] = A_r^T . dC_r contracts over the rows of a segment: the same
+//    MFMA loop with both operands transposed on their way into LDS, split over 2048-row
+//    slabs whose fp32 partial tiles are added with hardware float atomics.
+#include "../../include/dgl_amd.h"
+
+#include <cstring>
+
+#include "common.h"
+
+namespace dgla {
+namespace {
+
+int mfail(const std::string& m) {
+  last_error() = m;
+  return -1;
+}
+
+constexpr int BM = 128, BN = 128;
+constexpr int kRowBytes = 64;   // K-slab payload per tile row
+constexpr int kPitch = 80;      // LDS row pitch in bytes (64 + 16 pad)
+constexpr int kSlabRows = 2048; // rows per split-K slab of the weight-gradient kernel
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- plan: tiles per relation ---------------------------------------------------------
+// plan[0 .. R]        exclusive prefix of ceil(len / rows_per_tile)
+// plan[R+1 .. 2R+1]   exclusive prefix of len (row offsets)
+template <typename Idx>
+__global__ void segment_plan_kernel(const Idx* __restrict__ seglen, int64_t num_rel,
+                                    int rows_per_tile, int64_t* __restrict__ plan) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int64_t t = 0, r0 = 0;
+  for (int64_t r = 0; r < num_rel; ++r) {
+    plan[r] = t;
+    plan[num_rel + 1 + r] = r0;
+    const int64_t len = static_cast<int64_t>(seglen[r]);
+    t += (len + rows_per_tile - 1) / rows_per_tile;
+    r0 += len;
+  }
+  plan[num_rel] = t;
+  plan[2 * num_rel + 1] = r0;
+}
+
+__device__ __forceinline__ int64_t find_segment(const int64_t* __restrict__ tile_off,
+                                                int64_t num_rel, int64_t t) {
+  // largest r with tile_off[r] <= t  (tile_off is non-decreasing; empty relations repeat)
+  int64_t lo = 0, hi = num_rel - 1;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (tile_off[mid] <= t)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  return lo;
+}
+
+// ---- weight transpose: Bt[r][n][k] = B[r][k][n] -----------------------------------------
+template <typename DT>
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const DT* __restrict__ b,
+                                                               DT* __restrict__ bt, int K, int N) {
+  __shared__ DT tile[32][33];
+  const int64_t base = static_cast<int64_t>(blockIdx.z) * K * N;
+  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8)
+    if (k0 + i < K && n0 + tx < N) tile[i][tx] = b[base + static_cast<int64_t>(k0 + i) * N + n0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (n0 + i < N && k0 + tx < K) bt[base + static_cast<int64_t>(n0 + i) * K + k0 + tx] = tile[tx][i];
+}
+
+// ---- MFMA fragment helpers ----------------------------------------------------------------
+template <typename DT>
+struct Mma;  // KE: elements of K per 64-byte slab row; one slab = KE / KSTEP MFMA steps
+
+template <>
+struct Mma<float> {
+  static constexpr int KE = 16, KSTEP = 2;
+  __device__ static __forceinline__ void step(const char* sa, const char* sb, int s, int khalf,
+                                              f32x16& acc) {
+    const float a = *reinterpret_cast<const float*>(sa + (s * 2 + khalf) * 4);
+    const float b = *reinterpret_cast<const float*>(sb + (s * 2 + khalf) * 4);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+};
+template <>
+struct Mma<f16_t> {
+  static constexpr int KE = 32, KSTEP = 16;
+  __device__ static __forceinline__ void step(const char* sa, const char* sb, int s, int khalf,
+                                              f32x16& acc) {
+    const h16x8 a = *reinterpret_cast<const h16x8*>(sa + (s * 16 + khalf * 8) * 2);
+    const h16x8 b = *reinterpret_cast<const h16x8*>(sb + (s * 16 + khalf * 8) * 2);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+  }
+};
+template <>
+struct Mma<bf16_t> {
+  static constexpr int KE = 32, KSTEP = 16;
+  __device__ static __forceinline__ void step(const char* sa, const char* sb, int s, int khalf,
+                                              f32x16& acc) {
+    const b16x8 a = *reinterpret_cast<const b16x8*>(sa + (s * 16 + khalf * 8) * 2);
+    const b16x8 b = *reinterpret_cast<const b16x8*>(sb + (s * 16 + khalf * 8) * 2);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+};
+
+// One 16-byte piece of a K-contiguous operand row: `valid` elements starting at `src`
+// (0 <= valid <= E); vector load when the piece is whole and aligned, else element-wise.
+template <typename DT>
+__device__ __forceinline__ u32x4 load_piece(const DT* src, int valid, bool vec_ok) {
+  constexpr int E = 16 / sizeof(DT);
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (valid >= E && vec_ok) {
+    v = *reinterpret_cast<const u32x4*>(src);
+  } else if (valid > 0) {
+    DT tmp[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) tmp[j] = j < valid ? src[j] : DT{};
+    __builtin_memcpy(&v, tmp, 16);
+  }
+  return v;
+}
+
+struct MmParams {
+  const void* a;    // [M, K] rows grouped by relation
+  const void* bt;   // [R, N, K]  (K contiguous)
+  void* c;          // [M, N]
+  const int64_t* plan;
+  int64_t num_rel;
+  int K, N;
+  int vec_a, vec_b;  // 16-byte loads allowed (alignment + K % E == 0)
+};
+
+// ---- forward: C_r = A_r . Bt_r^T ----------------------------------------------------------
+template <typename DT>
+__global__ __launch_bounds__(256) void segment_mm_kernel(const MmParams p) {
+  using M = Mma<DT>;
+  constexpr int KE = M::KE;            // K elements per slab
+  constexpr int E = 16 / sizeof(DT);   // elements per 16-byte piece
+  __shared__ __attribute__((aligned(16))) char sA[BM * kPitch];
+  __shared__ __attribute__((aligned(16))) char sB[BN * kPitch];
+
+  const int64_t tile = blockIdx.y;
+  const int64_t* tile_off = p.plan;
+  const int64_t* row_off = p.plan + p.num_rel + 1;
+  if (tile >= tile_off[p.num_rel]) return;
+  const int64_t rel = find_segment(tile_off, p.num_rel, tile);
+  const int64_t row0 = row_off[rel] + (tile - tile_off[rel]) * BM;
+  const int64_t row_end = row_off[rel + 1];
+  const int n0 = blockIdx.x * BN;
+  const int K = p.K, N = p.N;
+
+  const DT* __restrict__ A = static_cast<const DT*>(p.a);
+  const DT* __restrict__ Bt = static_cast<const DT*>(p.bt) + rel * static_cast<int64_t>(N) * K;
+  DT* __restrict__ C = static_cast<DT*>(p.c);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // the two 16-byte pieces of each operand this thread moves per slab
+  const int pr0 = tid >> 2, pc = tid & 3;  // rows pr0 and pr0 + 64, 16-byte chunk pc
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto fetch = [&](int k0, u32x4 (&ra)[2], u32x4 (&rb)[2]) {
+    const int kk = k0 + pc * E;
+    const int valid = K - kk;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = pr0 + 64 * h;
+      const int64_t ar = row0 + r;
+      ra[h] = load_piece<DT>(A + ar * K + kk, ar < row_end ? valid : 0, p.vec_a != 0);
+      const int bn = n0 + r;
+      rb[h] = load_piece<DT>(Bt + static_cast<int64_t>(bn) * K + kk, bn < N ? valid : 0,
+                             p.vec_b != 0);
+    }
+  };
+  auto stash = [&](const u32x4 (&ra)[2], const u32x4 (&rb)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = pr0 + 64 * h;
+      *reinterpret_cast<u32x4*>(sA + r * kPitch + pc * 16) = ra[h];
+      *reinterpret_cast<u32x4*>(sB + r * kPitch + pc * 16) = rb[h];
+    }
+  };
+
+  u32x4 ra[2], rb[2];
+  fetch(0, ra, rb);
+  for (int k0 = 0; k0 < K; k0 += KE) {
+    __syncthreads();  // previous slab fully consumed
+    stash(ra, rb);
+    __syncthreads();
+    if (k0 + KE < K) fetch(k0 + KE, ra, rb);  // in flight while this slab is multiplied
+    const int lrow = lane & 31, khalf = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < KE / M::KSTEP; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const char* sa = sA + (wm * 64 + i * 32 + lrow) * kPitch;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const char* sb = sB + (wn * 64 + j * 32 + lrow) * kPitch;
+          M::step(sa, sb, s, khalf, acc[i][j]);
+        }
+      }
+    }
+  }
+
+  // C/D layout of the 32x32 MFMAs: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + col_l;
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+        if (row < row_end) C[row * N + col] = from_acc<DT>(acc[i][j][r]);
+      }
+    }
+}
+
+// fp64 (and any shape the MFMA path does not take): one thread per output element.
+template <typename DT>
+__global__ __launch_bounds__(256) void segment_mm_plain_kernel(const MmParams p, int64_t M) {
+  using A_ = typename Acc<DT>::type;
+  const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (idx >= M * p.N) return;
+  const int64_t row = idx / p.N;
+  const int col = static_cast<int>(idx - row * p.N);
+  const int64_t* row_off = p.plan + p.num_rel + 1;
+  int64_t lo = 0, hi = p.num_rel - 1;  // largest r with row_off[r] <= row
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (row_off[mid] <= row)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  if (row >= row_off[p.num_rel]) return;  // rows beyond sum(seglen) are left untouched
+  const DT* a = static_cast<const DT*>(p.a) + row * p.K;
+  const DT* b = static_cast<const DT*>(p.bt) + (lo * p.N + col) * static_cast<int64_t>(p.K);
+  A_ acc = 0;
+  for (int k = 0; k < p.K; ++k) acc += to_acc<DT>(a[k]) * to_acc<DT>(b[k]);
+  static_cast<DT*>(p.c)[idx] = from_acc<DT>(acc);
+}
+
+// ---- weight gradient: dB_r[i][j] = sum_{rows m of r} A[m][i] * dC[m][j] -------------------
+struct MmBwdParams {
+  const void* a;   // [M, D1]
+  const void* dc;  // [M, D2]
+  float* acc;      // [R, D1, D2] fp32, zeroed
+  const int64_t* plan;  // slab table: rows_per_tile = kSlabRows
+  int64_t num_rel;
+  int D1, D2;
+};
+
+template <typename DT>
+__global__ __launch_bounds__(256) void segment_mm_bwd_b_kernel(const MmBwdParams p) {
+  using M = Mma<DT>;
+  constexpr int KE = M::KE;
+  __shared__ __attribute__((aligned(16))) char sA[BM * kPitch];
+  __shared__ __attribute__((aligned(16))) char sB[BN * kPitch];
+
+  const int64_t slab = blockIdx.z;
+  const int64_t* slab_off = p.plan;
+  const int64_t* row_off = p.plan + p.num_rel + 1;
+  if (slab >= slab_off[p.num_rel]) return;
+  const int64_t rel = find_segment(slab_off, p.num_rel, slab);
+  const int64_t m0 = row_off[rel] + (slab - slab_off[rel]) * kSlabRows;
+  int64_t m1 = m0 + kSlabRows;
+  if (m1 > row_off[rel + 1]) m1 = row_off[rel + 1];
+  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+  const int D1 = p.D1, D2 = p.D2;
+  const DT* __restrict__ A = static_cast<const DT*>(p.a);
+  const DT* __restrict__ dC = static_cast<const DT*>(p.dc);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposing stage: slab rows m (the contraction index) become the K-contiguous LDS axis.
+  // Thread t handles feature column (t & 127) of operand (t >> 7 ? dC : A) for all KE rows.
+  const int which = tid >> 7, f = tid & 127;
+  const DT* src = which ? dC : A;
+  const int width = which ? D2 : D1;
+  const int fcol = (which ? j0 : i0) + f;
+  char* dst = (which ? sB : sA) + f * kPitch;
+  for (int64_t m = m0; m < m1; m += KE) {
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < KE; ++kk) {
+      DT v{};
+      if (m + kk < m1 && fcol < width) v = src[(m + kk) * width + fcol];
+      *reinterpret_cast<DT*>(dst + kk * sizeof(DT)) = v;
+    }
+    __syncthreads();
+    const int lrow = lane & 31, khalf = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < KE / M::KSTEP; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const char* sa = sA + (wm * 64 + i * 32 + lrow) * kPitch;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          M::step(sa, sB + (wn * 64 + j * 32 + lrow) * kPitch, s, khalf, acc[i][j]);
+      }
+  }
+  float* out = p.acc + rel * static_cast<int64_t>(D1) * D2;
+  const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = j0 + wn * 64 + j * 32 + col_l;
+      if (col >= D2) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+        if (row < D1) atomicAdd(out + static_cast<int64_t>(row) * D2 + col, acc[i][j][r]);
+      }
+    }
+}
+
+template <typename DT>
+__global__ void convert_from_f32_kernel(const float* __restrict__ src, DT* __restrict__ dst,
+                                        int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride)
+    dst[i] = from_acc<DT>(src[i]);
+}
+
+// fp64 weight gradient: one thread per (relation, i, j), sequential over the rows.
+__global__ __launch_bounds__(256) void segment_mm_bwd_b_f64_kernel(const double* __restrict__ a,
+                                                                  const double* __restrict__ dc,
+                                                                  double* __restrict__ db,
+                                                                  const int64_t* __restrict__ plan,
+                                                                  int64_t num_rel, int D1, int D2) {
+  const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (idx >= num_rel * D1 * D2) return;
+  const int64_t rel = idx / (static_cast<int64_t>(D1) * D2);
+  const int ij = static_cast<int>(idx - rel * D1 * D2);
+  const int i = ij / D2, j = ij - i * D2;
+  const int64_t* row_off = plan + num_rel + 1;
+  double acc = 0;
+  for (int64_t m = row_off[rel]; m < row_off[rel + 1]; ++m) acc += a[m * D1 + i] * dc[m * D2 + j];
+  db[idx] = acc;
+}
+
+// ---- gather mm: C[idx_c[i]] (+)= A[idx_a[i]] . B[idx_b[i]]  (GatherMMScatterKernel) --------
+// One wavefront per row; used for the small shapes the Python layer keeps on this path
+// (python/dgl/ops/gather_mm.py:39-60: D1, D2 <= 8 and N <= 1e6), everything else is sorted and
+// sent through segment_mm.
+template <typename Idx, typename DT>
+__global__ __launch_bounds__(256) void gather_mm_kernel(const DT* __restrict__ a,
+                                                        const DT* __restrict__ b,
+                                                        DT* __restrict__ c,
+                                                        const Idx* __restrict__ idx_a,
+                                                        const Idx* __restrict__ idx_b,
+                                                        const Idx* __restrict__ idx_c,
+                                                        int64_t num_rows, int K, int N,
+                                                        int scatter_add) {
+  using A_ = typename Acc<DT>::type;
+  const int64_t row = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= num_rows) return;
+  const int64_t ra = idx_a ? static_cast<int64_t>(idx_a[row]) : row;
+  const int64_t rb = idx_b ? static_cast<int64_t>(idx_b[row]) : row;
+  const int64_t rc = idx_c ? static_cast<int64_t>(idx_c[row]) : row;
+  const DT* ar = a + ra * K;
+  const DT* br = b + rb * static_cast<int64_t>(K) * N;
+  for (int n = lane; n < N; n += 64) {
+    A_ acc = 0;
+    for (int k = 0; k < K; ++k) acc += to_acc<DT>(ar[k]) * to_acc<DT>(br[static_cast<int64_t>(k) * N + n]);
+    c[rc * N + n] = from_acc<DT>(acc);
+  }
+  (void)scatter_add;
+}
+
+// ---- host side ------------------------------------------------------------------------------
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct MmScratch {
+  size_t off_plan, off_bt, off_acc, total;
+};
+
+MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool need_bt,
+                     bool need_acc) {
+  MmScratch s;
+  size_t off = 0;
+  s.off_plan = off;
+  off = align256(off + sizeof(int64_t) * (2 * num_rel + 2) + /* staged seglen */ 8 * num_rel);
+  s.off_bt = off;
+  if (need_bt) off = align256(off + static_cast<size_t>(num_rel) * K * N * elem);
+  s.off_acc = off;
+  if (need_acc) off = align256(off + static_cast<size_t>(num_rel) * K * N * sizeof(float));
+  s.total = off;
+  return s;
+}
+
+int stage_plan(int idbits, const void* seglen, int seglen_on_host, int64_t num_rel,
+               int rows_per_tile, char* ws, const MmScratch& sc, hipStream_t s) {
+  int64_t* plan = reinterpret_cast<int64_t*>(ws + sc.off_plan);
+  const void* dev_seglen = seglen;
+  if (seglen_on_host) {
+    // the reference hands seglen over in host memory (it loops over it on the CPU,
+    // gather_mm.cu:221-246); stage it behind the plan
+    void* stage = plan + 2 * num_rel + 2;
+    DGLA_CHECK_HIP(hipMemcpyAsync(stage, seglen, static_cast<size_t>(idbits / 8) * num_rel,
+                                  hipMemcpyHostToDevice, s));
+    dev_seglen = stage;
+  }
+  if (idbits == 32)
+    hipLaunchKernelGGL(segment_plan_kernel<int32_t>, dim3(1), dim3(64), 0, s,
+                       static_cast<const int32_t*>(dev_seglen), num_rel, rows_per_tile, plan);
+  else
+    hipLaunchKernelGGL(segment_plan_kernel<int64_t>, dim3(1), dim3(64), 0, s,
+                       static_cast<const int64_t*>(dev_seglen), num_rel, rows_per_tile, plan);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename DT>
+int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, int64_t N,
+                   int64_t num_rel, bool b_trans, char* ws, const MmScratch& sc, hipStream_t s) {
+  // Bt = [R, N, K]: the weights with the contraction axis contiguous
+  const void* bt = b;
+  if (!b_trans) {
+    // b: [R, K, N]
+    DT* dst = reinterpret_cast<DT*>(ws + sc.off_bt);
+    hipLaunchKernelGGL((transpose_weights_kernel<DT>),
+                       dim3((N + 31) / 32, (K + 31) / 32, static_cast<unsigned>(num_rel)), dim3(256),
+                       0, s, static_cast<const DT*>(b), dst, static_cast<int>(K), static_cast<int>(N));
+    bt = dst;
+  }
+  MmParams p;
+  p.a = a;
+  p.bt = bt;
+  p.c = c;
+  p.plan = reinterpret_cast<const int64_t*>(ws + sc.off_plan);
+  p.num_rel = num_rel;
+  p.K = static_cast<int>(K);
+  p.N = static_cast<int>(N);
+  constexpr int E = 16 / sizeof(DT);
+  p.vec_a = (K % E == 0 && aligned16(a)) ? 1 : 0;
+  p.vec_b = (K % E == 0 && aligned16(bt)) ? 1 : 0;
+  if constexpr (sizeof(DT) == 8) {
+    const int64_t total = M * N;
+    hipLaunchKernelGGL((segment_mm_plain_kernel<DT>), dim3(static_cast<unsigned>((total + 255) / 256)),
+                       dim3(256), 0, s, p, M);
+  } else {
+    const int64_t max_tiles = (M + BM - 1) / BM + num_rel;
+    if (max_tiles > 0x7fffffffLL) return mfail("segment_mm: too many row tiles");
+    // N tiles on x (fastest): the blocks sharing a row tile run together and re-read it from L2
+    hipLaunchKernelGGL((segment_mm_kernel<DT>),
+                       dim3(static_cast<unsigned>((N + BN - 1) / BN), static_cast<unsigned>(max_tiles)),
+                       dim3(256), 0, s, p);
+  }
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename DT>
+int run_segment_mm_bwd_b(const void* a, const void* dc, void* db, int64_t M, int64_t D1, int64_t D2,
+                         int64_t num_rel, char* ws, const MmScratch& sc, hipStream_t s) {
+  const int64_t* plan = reinterpret_cast<const int64_t*>(ws + sc.off_plan);
+  const int64_t out_elems = num_rel * D1 * D2;
+  if constexpr (sizeof(DT) == 8) {
+    hipLaunchKernelGGL(segment_mm_bwd_b_f64_kernel, dim3(static_cast<unsigned>((out_elems + 255) / 256)),
+                       dim3(256), 0, s, static_cast<const double*>(a), static_cast<const double*>(dc),
+                       static_cast<double*>(db), plan, num_rel, static_cast<int>(D1),
+                       static_cast<int>(D2));
+  } else {
+    float* acc = std::is_same<DT, float>::value ? static_cast<float*>(db)
+                                                : reinterpret_cast<float*>(ws + sc.off_acc);
+    DGLA_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(float) * out_elems, s));
+    MmBwdParams p;
+    p.a = a;
+    p.dc = dc;
+    p.acc = acc;
+    p.plan = plan;
+    p.num_rel = num_rel;
+    p.D1 = static_cast<int>(D1);
+    p.D2 = static_cast<int>(D2);
+    const int64_t max_slabs = (M + kSlabRows - 1) / kSlabRows + num_rel;
+    if (max_slabs > 65535) return mfail("segment_mm backward: more than 65535 row slabs (" +
+                                        std::to_string(max_slabs) + "); split the call");
+    hipLaunchKernelGGL((segment_mm_bwd_b_kernel<DT>),
+                       dim3(static_cast<unsigned>((D2 + BN - 1) / BN), static_cast<unsigned>((D1 + BM - 1) / BM),
+                            static_cast<unsigned>(max_slabs)),
+                       dim3(256), 0, s, p);
+    if (!std::is_same<DT, float>::value)
+      hipLaunchKernelGGL((convert_from_f32_kernel<DT>), dim3(static_cast<unsigned>(std::min<int64_t>((out_elems + 255) / 256, 4096))),
+                         dim3(256), 0, s, acc, static_cast<DT*>(db), out_elems);
+  }
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename Idx, typename DT>
+int run_gather_mm(const void* a, const void* b, void* c, const void* ia, const void* ib,
+                  const void* ic, int64_t rows, int64_t K, int64_t N, hipStream_t s) {
+  const int64_t blocks = (rows * 64 + 255) / 256;
+  if (blocks > 0x7fffffffLL) return mfail("gather_mm: too many rows");
+  hipLaunchKernelGGL((gather_mm_kernel<Idx, DT>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s,
+                     static_cast<const DT*>(a), static_cast<const DT*>(b), static_cast<DT*>(c),
+                     static_cast<const Idx*>(ia), static_cast<const Idx*>(ib),
+                     static_cast<const Idx*>(ic), rows, static_cast<int>(K), static_cast<int>(N), 0);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int check_mm_common(int idbits, dgla_dtype dtype, int64_t M, int64_t K, int64_t N, int64_t R) {
+  if (idbits != 32 && idbits != 64) return mfail("idtype must be int32 or int64");
+  if (dtype < DGLA_F32 || dtype > DGLA_BF16) return mfail("unsupported feature dtype");
+  if (M < 0 || K < 0 || N < 0 || R < 0) return mfail("negative dimension");
+  if (K > 0x3fffffff || N > 0x3fffffff) return mfail("feature dimension too large");
+  return 0;
+}
+
+}  // namespace
+}  // namespace dgla
+
+using namespace dgla;
+
+extern "C" {
+
+size_t dgla_segment_mm_workspace_bytes(dgla_dtype dtype, int64_t num_rel, int64_t d1, int64_t d2) {
+  const size_t elem = dtype == DGLA_F64 ? 8 : (dtype == DGLA_F32 ? 4 : 2);
+  return mm_scratch(num_rel, d1, d2, elem, true, true).total;
+}
+
+int dgla_segment_mm(int idtype_bits, dgla_dtype dtype, const void* a, const void* b, void* c,
+                    const void* seglen, int seglen_on_host, int64_t num_rows, int64_t num_rel,
+                    int64_t k, int64_t n, int b_trans, void* workspace, size_t workspace_bytes,
+                    void* hip_stream) {
+  if (check_mm_common(idtype_bits, dtype, num_rows, k, n, num_rel)) return -1;
+  if (num_rows == 0 || n == 0 || num_rel == 0) return 0;
+  if (!a || !b || !c || !seglen) return mfail("segment_mm: null operand");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const size_t elem = dtype == DGLA_F64 ? 8 : (dtype == DGLA_F32 ? 4 : 2);
+  const MmScratch sc = mm_scratch(num_rel, k, n, elem, !b_trans, false);
+  void* owned = nullptr;
+  if (!workspace || workspace_bytes < sc.total) {
+    DGLA_CHECK_HIP(hipMallocAsync(&owned, sc.total, s));
+    workspace = owned;
+  }
+  char* ws = static_cast<char*>(workspace);
+  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, BM, ws, sc, s);
+  if (rc == 0) {
+    switch (dtype) {
+      case DGLA_F32: rc = run_segment_mm<float>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, ws, sc, s); break;
+      case DGLA_F64: rc = run_segment_mm<double>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, ws, sc, s); break;
+      case DGLA_F16: rc = run_segment_mm<f16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, ws, sc, s); break;
+      case DGLA_BF16: rc = run_segment_mm<bf16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, ws, sc, s); break;
+    }
+  }
+  if (owned) (void)hipFreeAsync(owned, s);
+  return rc;
+}
+
+int dgla_segment_mm_backward_b(int idtype_bits, dgla_dtype dtype, const void* a, const void* dc,
+                               void* db, const void* seglen, int seglen_on_host,
+                               int64_t num_rows, int64_t num_rel, int64_t d1, int64_t d2,
+                               void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (check_mm_common(idtype_bits, dtype, num_rows, d1, d2, num_rel)) return -1;
+  if (num_rel == 0 || d1 == 0 || d2 == 0) return 0;
+  if (!db || !seglen || (num_rows > 0 && (!a || !dc))) return mfail("segment_mm backward: null operand");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const size_t elem = dtype == DGLA_F64 ? 8 : (dtype == DGLA_F32 ? 4 : 2);
+  const MmScratch sc = mm_scratch(num_rel, d1, d2, elem, false, elem == 2);
+  void* owned = nullptr;
+  if (!workspace || workspace_bytes < sc.total) {
+    DGLA_CHECK_HIP(hipMallocAsync(&owned, sc.total, s));
+    workspace = owned;
+  }
+  char* ws = static_cast<char*>(workspace);
+  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, kSlabRows, ws, sc, s);
+  if (rc == 0) {
+    switch (dtype) {
+      case DGLA_F32: rc = run_segment_mm_bwd_b<float>(a, dc, db, num_rows, d1, d2, num_rel, ws, sc, s); break;
+      case DGLA_F64: rc = run_segment_mm_bwd_b<double>(a, dc, db, num_rows, d1, d2, num_rel, ws, sc, s); break;
+      case DGLA_F16: rc = run_segment_mm_bwd_b<f16_t>(a, dc, db, num_rows, d1, d2, num_rel, ws, sc, s); break;
+      case DGLA_BF16: rc = run_segment_mm_bwd_b<bf16_t>(a, dc, db, num_rows, d1, d2, num_rel, ws, sc, s); break;
+    }
+  }
+  if (owned) (void)hipFreeAsync(owned, s);
+  return rc;
+}
+
+int dgla_gather_mm(int idtype_bits, dgla_dtype dtype, const void* a, const void* b, void* c,
+                   const void* idx_a, const void* idx_b, const void* idx_c, int64_t num_rows,
+                   int64_t k, int64_t n, void* hip_stream) {
+  if (check_mm_common(idtype_bits, dtype, num_rows, k, n, 0)) return -1;
+  if (num_rows == 0 || n == 0) return 0;
+  if (!a || !b || !c) return mfail("gather_mm: null operand");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+#define DGLA_GMM(IDX)                                                                             \
+  switch (dtype) {                                                                                \
+    case DGLA_F32: return run_gather_mm<IDX, float>(a, b, c, idx_a, idx_b, idx_c, num_rows, k, n, s);   \
+    case DGLA_F64: return run_gather_mm<IDX, double>(a, b, c, idx_a, idx_b, idx_c, num_rows, k, n, s);  \
+    case DGLA_F16: return run_gather_mm<IDX, f16_t>(a, b, c, idx_a, idx_b, idx_c, num_rows, k, n, s);   \
+    case DGLA_BF16: return run_gather_mm<IDX, bf16_t>(a, b, c, idx_a, idx_b, idx_c, num_rows, k, n, s); \
+  }
+  if (idtype_bits == 32) {
+    DGLA_GMM(int32_t)
+  } else {
+    DGLA_GMM(int64_t)
+  }
+#undef DGLA_GMM
+  return mfail("unsupported feature dtype");
+}
+
+}  // extern "C"

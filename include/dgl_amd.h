@@ -191,6 +191,36 @@ int dgla_scatter_add(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat,
 int dgla_backward_segment_cmp(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat,
                               const void* arg, const dgla_tensor* out, void* hip_stream);
 
+/* ---- segment / gather matrix multiply --------------------------------------
+ * Replace SegmentMM / SegmentMMBackwardB / GatherMM / GatherMMScatter<kDGLCUDA,…>
+ * (src/array/cuda/gather_mm.cu:201-360; registered as sparse._CAPI_DGLKernelSEGMENTMM,
+ * …SEGMENTMMBackwardB, …GATHERMM, …GATHERMMSCATTER, src/array/kernel.cc:501-540).
+ * All matrices row-major and contiguous; `seglen` has num_rel entries of idtype_bits and may
+ * live in HOST memory (seglen_on_host = 1, as the reference passes it) or on the device.
+ *
+ * dgla_segment_mm:  for every relation r with rows [o_r, o_r + seglen[r]) of A:
+ *     b_trans == 0:  C[rows] = A[rows] (m x k) . B[r] (k x n),  B is [num_rel, k, n]
+ *     b_trans != 0:  C[rows] = A[rows] (m x k) . B[r]^T,        B is [num_rel, n, k]
+ *   ONE grouped launch on the MFMA units (fp32 accumulate; fp64 on the vector ALUs).  Rows
+ *   beyond sum(seglen) are not written.
+ * dgla_segment_mm_backward_b:  dB[r] (d1 x d2) = A[rows_r]^T (d1 x m) . dC[rows_r] (m x d2);
+ *   relations without rows get zeros.
+ * dgla_gather_mm:  C[idx_c ? idx_c[i] : i] = A[idx_a ? idx_a[i] : i] (1 x k) . B[idx_b ? idx_b[i] : i]
+ *   (k x n), one wavefront per row (the small-shape path of dgl.ops.gather_mm).
+ * `workspace` may be NULL (stream-ordered scratch for the duration of the call). */
+size_t dgla_segment_mm_workspace_bytes(dgla_dtype dtype, int64_t num_rel, int64_t d1, int64_t d2);
+int dgla_segment_mm(int idtype_bits, dgla_dtype dtype, const void* a, const void* b, void* c,
+                    const void* seglen, int seglen_on_host, int64_t num_rows, int64_t num_rel,
+                    int64_t k, int64_t n, int b_trans, void* workspace, size_t workspace_bytes,
+                    void* hip_stream);
+int dgla_segment_mm_backward_b(int idtype_bits, dgla_dtype dtype, const void* a, const void* dc,
+                               void* db, const void* seglen, int seglen_on_host,
+                               int64_t num_rows, int64_t num_rel, int64_t d1, int64_t d2,
+                               void* workspace, size_t workspace_bytes, void* hip_stream);
+int dgla_gather_mm(int idtype_bits, dgla_dtype dtype, const void* a, const void* b, void* c,
+                   const void* idx_a, const void* idx_b, const void* idx_c, int64_t num_rows,
+                   int64_t k, int64_t n, void* hip_stream);
+
 /* ---- k-way node-cut partitioner (host code) ---------------------------------
  * Stands where METIS stands in the reference: metis_partition_assignment
  * (python/dgl/partition.py:278-397 -> _CAPI_DGLMetisPartition_Hetero).  Multilevel

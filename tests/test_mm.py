@@ -1,0 +1,172 @@
+"""segment_mm / gather_mm on the MFMA units.
+
+The reference's CPU path for these operators is a per-segment ``torch`` matmul
+(python/dgl/backend/pytorch/sparse.py:1173-1195; the C++ CPU kernels are LOG(FATAL) stubs,
+src/array/cpu/gather_mm.cc:16-45), and its GPU path is cuBLAS: neither fixes a summation
+order, so parity here is tolerance-based exactly like the reference's own tests
+(tests/python/common/ops/test_ops.py:302-383: per-segment matmul, rtol/atol 1e-4 fp32, 2e-2
+fp16 / bf16) — "parity unpinned" at the bit level, stated in DESIGN.md.  The oracle is the
+exact product in fp64 (numpy) of the SAME stored inputs; bounds are condition-aware:
+|err| <= tol * sum_k |a_ik| |b_kj|.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# accumulator epsilon and the half-ulp of the final store, per storage type
+ACC_EPS = {torch.float32: 2.0 ** -24, torch.float64: 2.0 ** -53, torch.float16: 2.0 ** -24,
+           torch.bfloat16: 2.0 ** -24}
+STORE_EPS = {torch.float32: 0.0, torch.float64: 0.0, torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}
+
+
+def _exact_segment_mm(a, b, seglen, b_trans=False):
+    a64, b64 = a.double().cpu().numpy(), b.double().cpu().numpy()
+    n_out = b64.shape[1] if b_trans else b64.shape[2]
+    out = np.zeros((a64.shape[0], n_out))
+    mag = np.zeros_like(out)
+    off = 0
+    for r, m in enumerate(int(v) for v in seglen):
+        w = b64[r].T if b_trans else b64[r]
+        out[off:off + m] = a64[off:off + m] @ w
+        mag[off:off + m] = np.abs(a64[off:off + m]) @ np.abs(w)
+        off += m
+    return out, mag
+
+
+def _close(got, want, mag, dtype, k, what=""):
+    """|err| <= 4 sqrt(k) eps_acc * sum|a||b|  (random-walk growth of an fp32 / fp64 dot product of
+    length k in ANY order; the worst case would be k eps) + one rounding of the stored result."""
+    err = np.abs(got.double().cpu().numpy() - want)
+    bound = 4 * np.sqrt(max(k, 1)) * ACC_EPS[dtype] * mag + 1.01 * STORE_EPS[dtype] * np.abs(want) + 1e-30
+    assert (err <= bound).all(), (what, float((err / bound).max()))
+
+
+SEGLENS = {
+    "docstring": [10, 5, 0, 3],                       # python/dgl/ops/segment.py:109-113
+    "tile_edges": [128, 1, 127, 129, 0, 0, 256, 3],   # around the 128-row tile size
+    "one_big": [1000],
+    "many_small": [3, 0, 1, 7, 2, 0, 0, 5, 1, 1, 9, 4],
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16, torch.float64])
+@pytest.mark.parametrize("kind", list(SEGLENS))
+@pytest.mark.parametrize("d1,d2", [(16, 32), (256, 256), (100, 36), (7, 130), (33, 1)])
+@pytest.mark.parametrize("seglen_dev", ["cpu", "gpu"])
+def test_segment_mm_forward(dev, dtype, kind, d1, d2, seglen_dev):
+    from dgl_amd import mm
+
+    seglen = torch.tensor(SEGLENS[kind], dtype=torch.int64)
+    n, r = int(seglen.sum()), len(seglen)
+    g = torch.Generator().manual_seed(d1 * 1000 + d2)
+    a = (torch.rand(n, d1, generator=g) - 0.3).to(dtype).to(dev)
+    b = (torch.rand(r, d1, d2, generator=g) - 0.6).to(dtype).to(dev)   # asymmetric on purpose
+    sl = seglen.to(dev) if seglen_dev == "gpu" else seglen
+    c = torch.full((n, d2), 7.0, dtype=dtype, device=dev)
+    mm._segment_mm(a, b, c, sl)
+    want, mag = _exact_segment_mm(a, b, seglen)
+    _close(c, want, mag, dtype, d1, "fwd")
+    # transposed weights: the A-gradient form  dA = dC . B^T
+    da = torch.full((n, d1), 7.0, dtype=dtype, device=dev)
+    mm._segment_mm(c, b, da, sl, b_trans=True)
+    want, mag = _exact_segment_mm(c, b, seglen, b_trans=True)
+    _close(da, want, mag, dtype, d2, "b_trans")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16, torch.float64])
+@pytest.mark.parametrize("kind", ["docstring", "tile_edges", "many_small", "long"])
+@pytest.mark.parametrize("d1,d2", [(16, 32), (130, 70), (256, 256), (5, 3)])
+def test_segment_mm_backward_b(dev, dtype, kind, d1, d2):
+    from dgl_amd import mm
+
+    seglen = torch.tensor(SEGLENS[kind] if kind != "long" else [5000, 0, 2049, 1], dtype=torch.int64)
+    n, r = int(seglen.sum()), len(seglen)
+    g = torch.Generator().manual_seed(d1 * 77 + d2)
+    a = (torch.rand(n, d1, generator=g) - 0.3).to(dtype).to(dev)
+    dc = (torch.rand(n, d2, generator=g) - 0.6).to(dtype).to(dev)
+    db = torch.full((r, d1, d2), 7.0, dtype=dtype, device=dev)
+    mm._segment_mm_backward_B(a, dc, db, seglen)
+    a64, c64 = a.double().cpu().numpy(), dc.double().cpu().numpy()
+    off = 0
+    for i, m in enumerate(int(v) for v in seglen):
+        want = a64[off:off + m].T @ c64[off:off + m]
+        mag = np.abs(a64[off:off + m]).T @ np.abs(c64[off:off + m])
+        _close(db[i], want, mag, dtype, m, "rel %d" % i)
+        off += m
+
+
+def test_mfma_layout_identity(dev):
+    """A = I against an ASYMMETRIC B: a row/column swap or a wrong lane -> k mapping cannot pass."""
+    from dgl_amd import mm
+
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
+        k = 160
+        a = torch.eye(k, dtype=dtype, device=dev)
+        b = (torch.arange(k * 192, device=dev).reshape(1, k, 192) % 251).to(dtype)
+        c = torch.empty(k, 192, dtype=dtype, device=dev)
+        mm._segment_mm(a, b, c, torch.tensor([k]))
+        assert torch.equal(c, b[0]), dtype
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_api_segment_mm_matches_torch_with_grads(dev, dtype):
+    """tests/python/common/ops/test_ops.py:302-342 (test_segment_mm)."""
+    import dgl_amd
+
+    torch.manual_seed(1)
+    a = torch.randn(100, 32, device=dev, dtype=dtype).requires_grad_(True)
+    b = torch.randn(4, 32, 48, device=dev, dtype=dtype).requires_grad_(True)
+    seglen = torch.tensor([10, 15, 8, 67])
+    c = dgl_amd.segment_mm(a, b, seglen)
+    dc = torch.randn_like(c)
+    c.backward(dc)
+    a2, b2 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    parts, off = [], 0
+    for i, m in enumerate(seglen.tolist()):
+        parts.append(a2[off:off + m] @ b2[i])
+        off += m
+    c2 = torch.cat(parts)
+    c2.backward(dc)
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    assert torch.allclose(c, c2, **tol)
+    assert torch.allclose(a.grad, a2.grad, **tol)
+    assert torch.allclose(b.grad, b2.grad, **(tol if dtype == torch.float32 else dict(rtol=3e-2, atol=8e-2)))
+
+
+@pytest.mark.parametrize("d1,d2", [(4, 6), (8, 8), (32, 16)])
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+def test_api_gather_mm_matches_bmm_with_grads(dev, d1, d2, idtype):
+    """tests/python/common/ops/test_ops.py:345-383 (test_gather_mm_idx_b); (32, 16) takes the
+    sort + segment_mm route, the small shapes the per-row kernel."""
+    import dgl_amd
+
+    torch.manual_seed(2)
+    n, r = 300, 5
+    a = torch.randn(n, d1, device=dev).requires_grad_(True)
+    b = torch.randn(r, d1, d2, device=dev).requires_grad_(True)
+    idx = torch.randint(0, r, (n,), device=dev).to(idtype)
+    c = dgl_amd.gather_mm(a, b, idx_b=idx)
+    dc = torch.randn_like(c)
+    c.backward(dc)
+    a2, b2 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    c2 = torch.bmm(a2.unsqueeze(1), b2[idx.long()]).squeeze(1)
+    c2.backward(dc)
+    assert torch.allclose(c, c2, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(a.grad, a2.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(b.grad, b2.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_errors(dev):
+    import dgl_amd
+    from dgl_amd._lib import DGLAMDError
+
+    a = torch.ones(4, 3, device=dev)
+    b = torch.ones(2, 5, 6, device=dev)
+    with pytest.raises(DGLAMDError, match="A.shape\\[1\\] == B.shape\\[1\\]"):
+        dgl_amd.segment_mm(a, b, torch.tensor([2, 2]))
+    with pytest.raises(ValueError, match="3D"):
+        dgl_amd.segment_mm(a, torch.ones(3, 6, device=dev), torch.tensor([4]))
+    with pytest.raises(DGLAMDError, match="len\\(seglen_A\\)"):
+        dgl_amd.segment_mm(a, torch.ones(2, 3, 6, device=dev), torch.tensor([4]))
