@@ -240,6 +240,55 @@ def seg(dev, args):
          rows * (f * 4 * 2 + 8))
 
 
+def mm(dev, args):
+    """segment_mm at the R-GCN shape of config 5: 8 relations, D1 = D2 = 256,
+    10 M rows split evenly, bf16 / fp16 / fp32; forward, A-gradient (b_trans) and weight
+    gradient.  Reports TFLOP/s (2 M K N) next to the algorithmic bytes (A + C once, weights
+    once): the transform is memory-bound above ~650 TFLOP/s in bf16."""
+    rows, r, k, n = 10_000_000 // args.scale, 8, 256, 256
+    seglen = torch.full((r,), rows // r, dtype=torch.int64)
+    seglen[-1] += rows - int(seglen.sum())
+    sl = seglen.to(dev)
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        torch.manual_seed(0)
+        a = (torch.rand(rows, k, device=dev) - 0.5).to(dt)
+        b = (torch.rand(r, k, n, device=dev) - 0.5).to(dt)
+        c = torch.empty(rows, n, device=dev, dtype=dt)
+        s = a.element_size()
+        flops = 2.0 * rows * k * n
+        nb = rows * (k + n) * s + r * k * n * s
+        for name, fn in (
+                ("segment_mm fwd", lambda: _capi.segment_mm(a, b, c, sl)),
+                ("segment_mm dA (b_trans)", lambda: _capi.segment_mm(c, b, a, sl, b_trans=True)),
+                ("segment_mm dB", lambda: _capi.segment_mm_backward_b(a, c, b, sl))):
+            ms, mn = timeit(fn, reps=5, warm=2)
+            emit("MM", "%s, %d rows x %d x %d, %d relations, %s" % (name, rows, k, n, r, str(dt)), rows, ms, mn,
+                 nb, tflops=flops / (ms * 1e-3) / 1e12)
+        # what the reference does: one GEMM per relation through the vendor library (hipBLASLt via torch)
+        off = [0] + torch.cumsum(seglen, 0).tolist()
+        ms, mn = timeit(lambda: [torch.mm(a[off[i]:off[i + 1]], b[i], out=c[off[i]:off[i + 1]]) for i in range(r)],
+                        reps=5, warm=2)
+        emit("MM", "per-relation torch.mm loop (vendor GEMM; the reference's structure), %s" % str(dt), rows, ms,
+             mn, nb, tflops=flops / (ms * 1e-3) / 1e12)
+        del a, b, c
+    # many small relations (the case the grouped launch exists for): 512 relations, 1 M rows
+    rows, r = 1_000_000 // args.scale, 512
+    lens = np.random.default_rng(0).multinomial(rows, np.ones(r) / r)
+    seglen = torch.from_numpy(lens)
+    sl = seglen.to(dev)
+    a = (torch.rand(rows, k, device=dev) - 0.5).to(torch.bfloat16)
+    b = (torch.rand(r, k, n, device=dev) - 0.5).to(torch.bfloat16)
+    c = torch.empty(rows, n, device=dev, dtype=torch.bfloat16)
+    flops, nb = 2.0 * rows * k * n, rows * (k + n) * 2 + r * k * n * 2
+    ms, mn = timeit(lambda: _capi.segment_mm(a, b, c, sl), reps=5, warm=2)
+    emit("MM", "segment_mm fwd, %d rows, 512 relations (~%d rows each), bf16" % (rows, rows // r), rows, ms, mn, nb,
+         tflops=flops / (ms * 1e-3) / 1e12)
+    off = [0] + torch.cumsum(seglen, 0).tolist()
+    ms, mn = timeit(lambda: [torch.mm(a[off[i]:off[i + 1]], b[i], out=c[off[i]:off[i + 1]]) for i in range(r)],
+                    reps=5, warm=2)
+    emit("MM", "per-relation torch.mm loop, 512 relations, bf16", rows, ms, mn, nb, tflops=flops / (ms * 1e-3) / 1e12)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -248,7 +297,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("SEG", seg)):
+    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("SEG", seg), ("MM", mm)):
         if args.only and name not in args.only.split(","):
             continue
         fn(dev, args)

@@ -81,15 +81,10 @@ __device__ __forceinline__ T from_acc(typename Acc<T>::type v) {
 }
 template <>
 __device__ __forceinline__ bf16_t from_acc<bf16_t>(float f) {
-  // round-to-nearest-even; NaN stays NaN
-  uint32_t u = __float_as_uint(f);
+  // round-to-nearest-even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 (one instruction)
+  const __bf16 h = static_cast<__bf16>(f);
   bf16_t r;
-  if ((u & 0x7fffffffu) > 0x7f800000u) {
-    r.bits = static_cast<uint16_t>((u >> 16) | 0x40);
-  } else {
-    u += 0x7fffu + ((u >> 16) & 1u);
-    r.bits = static_cast<uint16_t>(u >> 16);
-  }
+  __builtin_memcpy(&r.bits, &h, 2);
   return r;
 }
 

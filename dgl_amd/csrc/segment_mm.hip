@@ -14,7 +14,7 @@
 //    2 x 2 MFMA tiles of 32 x 32: v_mfma_f32_32x32x16_{bf16,f16} for 16-bit storage (fp32
 //    accumulate, as cuBLAS does for the reference: CUBLAS_COMPUTE_32F), v_mfma_f32_32x32x2_f32
 //    for fp32 (exact fp32 FMA chain, no TF32-like rounding).  fp64 takes a plain FMA kernel.
-//  * Both operands are staged through LDS K-contiguous (64-byte row payload, 80-byte pitch), so
+//  * Both operands are staged through LDS K-contiguous (128-byte row payload, 144-byte pitch), so
 //    every MFMA fragment is one ds_read_b128 (16-bit) / ds_read_b32 (fp32).  The weight operand
 //    is needed K-contiguous per output column: for C = A . B[r] the (small) weights are
 //    transposed once per call into scratch, for C = A . B[r]^T (the backward w.r.t. A) they
@@ -25,6 +25,7 @@
 //    slabs whose fp32 partial tiles are added with hardware float atomics.
 #include "../../include/dgl_amd.h"
 
+#include <algorithm>
 #include <cstring>
 
 #include "common.h"
@@ -37,9 +38,9 @@ int mfail(const std::string& m) {
   return -1;
 }
 
-constexpr int BM = 128, BN = 128;
-constexpr int kRowBytes = 64;   // K-slab payload per tile row
-constexpr int kPitch = 80;      // LDS row pitch in bytes (64 + 16 pad)
+constexpr int BM = 128;
+constexpr int kFwdSlab = 128;   // forward: bytes of K per tile row and slab (pitch + 16: conflict-free ds_read_b128)
+constexpr int kBwdSlab = 64;    // weight gradient: 64-byte slabs
 constexpr int kSlabRows = 2048; // rows per split-K slab of the weight-gradient kernel
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -65,6 +66,14 @@ __global__ void segment_plan_kernel(const Idx* __restrict__ seglen, int64_t num_
   }
   plan[num_rel] = t;
   plan[2 * num_rel + 1] = r0;
+}
+
+// Values that are the same in every lane (derived from blockIdx and the plan): tell the compiler,
+// so they live in scalar registers instead of costing two VGPRs each.
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32));
+  return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
 __device__ __forceinline__ int64_t find_segment(const int64_t* __restrict__ tile_off,
@@ -98,11 +107,11 @@ __global__ __launch_bounds__(256) void transpose_weights_kernel(const DT* __rest
 
 // ---- MFMA fragment helpers ----------------------------------------------------------------
 template <typename DT>
-struct Mma;  // KE: elements of K per 64-byte slab row; one slab = KE / KSTEP MFMA steps
+struct Mma;  // KSTEP: K elements consumed by one MFMA
 
 template <>
 struct Mma<float> {
-  static constexpr int KE = 16, KSTEP = 2;
+  static constexpr int KSTEP = 2;
   __device__ static __forceinline__ void step(const char* sa, const char* sb, int s, int khalf,
                                               f32x16& acc) {
     const float a = *reinterpret_cast<const float*>(sa + (s * 2 + khalf) * 4);
@@ -112,7 +121,7 @@ struct Mma<float> {
 };
 template <>
 struct Mma<f16_t> {
-  static constexpr int KE = 32, KSTEP = 16;
+  static constexpr int KSTEP = 16;
   __device__ static __forceinline__ void step(const char* sa, const char* sb, int s, int khalf,
                                               f32x16& acc) {
     const h16x8 a = *reinterpret_cast<const h16x8*>(sa + (s * 16 + khalf * 8) * 2);
@@ -122,7 +131,7 @@ struct Mma<f16_t> {
 };
 template <>
 struct Mma<bf16_t> {
-  static constexpr int KE = 32, KSTEP = 16;
+  static constexpr int KSTEP = 16;
   __device__ static __forceinline__ void step(const char* sa, const char* sb, int s, int khalf,
                                               f32x16& acc) {
     const b16x8 a = *reinterpret_cast<const b16x8*>(sa + (s * 16 + khalf * 8) * 2);
@@ -156,100 +165,162 @@ struct MmParams {
   int64_t num_rel;
   int K, N;
   int vec_a, vec_b;  // 16-byte loads allowed (alignment + K % E == 0)
+  int vec_c;         // 16-byte stores of C rows allowed (alignment + N % E == 0)
+  int64_t n_tiles;   // ceil(N / BN)
 };
 
 // ---- forward: C_r = A_r . Bt_r^T ----------------------------------------------------------
-template <typename DT>
-__global__ __launch_bounds__(256) void segment_mm_kernel(const MmParams p) {
+// TBN = 256 (used when N > 128): one workgroup owns 128 rows x 256 columns, so for N <= 256
+// every element of A — the operand that comes from HBM; the weights sit in L2 — is read
+// exactly once.  TBN = 128 keeps narrow outputs from wasting half of the MFMA work.
+// XCD-aware tile order for N > TBN: workgroup L runs on XCD L % 8 (round-robin dispatch); the
+// n-tiles of one row tile go to workgroups L, L + 8, ... of the SAME XCD, which re-read the A
+// tile from that XCD's L2.  Index math only: any placement is correct.
+template <typename DT, int TBN, bool VEC>  // VEC: A, Bt and C rows are 16-byte aligned and whole pieces
+__global__ __launch_bounds__(256, 2) void segment_mm_kernel(const MmParams p) {
   using M = Mma<DT>;
-  constexpr int KE = M::KE;            // K elements per slab
-  constexpr int E = 16 / sizeof(DT);   // elements per 16-byte piece
-  __shared__ __attribute__((aligned(16))) char sA[BM * kPitch];
-  __shared__ __attribute__((aligned(16))) char sB[BN * kPitch];
+  constexpr int KE = kFwdSlab / sizeof(DT);  // K elements per slab
+  constexpr int E = 16 / sizeof(DT);         // elements per 16-byte piece
+  constexpr int kPitch = kFwdSlab + 16;
+  constexpr int PPR = kFwdSlab / 16;         // 16-byte pieces per tile row
+  constexpr int RSTEP = 256 / PPR;           // tile rows covered by one pass of the 256 threads
+  constexpr int PA = BM / RSTEP, PB = TBN / RSTEP;  // pieces per thread: A tile, weight tile
+  constexpr int NJ = TBN / 64;               // 32-column MFMA tiles per wave
+  constexpr int kCPitch = TBN * 2 + 16;      // 16-bit epilogue staging: pitch of a C row
+  static_assert(sizeof(DT) != 2 || 64 * kCPitch <= (BM + TBN) * kPitch, "half a C tile must fit");
+  __shared__ __attribute__((aligned(16))) char smem[(BM + TBN) * kPitch];
+  char* sA = smem;
+  char* sB = smem + BM * kPitch;
 
-  const int64_t tile = blockIdx.y;
   const int64_t* tile_off = p.plan;
   const int64_t* row_off = p.plan + p.num_rel + 1;
+  const int K = p.K, N = p.N;
+  const int64_t L = blockIdx.x;
+  const int64_t j = L >> 3;
+  const int64_t tile = (j / p.n_tiles) * 8 + (L & 7);
+  const int n0 = static_cast<int>(j % p.n_tiles) * TBN;
   if (tile >= tile_off[p.num_rel]) return;
   const int64_t rel = find_segment(tile_off, p.num_rel, tile);
   const int64_t row0 = row_off[rel] + (tile - tile_off[rel]) * BM;
   const int64_t row_end = row_off[rel + 1];
-  const int n0 = blockIdx.x * BN;
-  const int K = p.K, N = p.N;
 
   const DT* __restrict__ A = static_cast<const DT*>(p.a);
   const DT* __restrict__ Bt = static_cast<const DT*>(p.bt) + rel * static_cast<int64_t>(N) * K;
   DT* __restrict__ C = static_cast<DT*>(p.c);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  // the two 16-byte pieces of each operand this thread moves per slab
-  const int pr0 = tid >> 2, pc = tid & 3;  // rows pr0 and pr0 + 64, 16-byte chunk pc
+  const int wm = wave >> 1, wn = wave & 1;      // wave tile: rows wm * 64 .., cols wn * (TBN / 2) ..
+  const int pr0 = tid / PPR, pc = tid % PPR;    // piece h: tile row pr0 + h * RSTEP, chunk pc
+  const int lrow = lane & 31, khalf = lane >> 5;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-  auto fetch = [&](int k0, u32x4 (&ra)[2], u32x4 (&rb)[2]) {
+  auto fetch = [&](int k0, u32x4 (&ra)[PA], u32x4 (&rb)[PB]) {
     const int kk = k0 + pc * E;
     const int valid = K - kk;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = pr0 + 64 * h;
-      const int64_t ar = row0 + r;
-      ra[h] = load_piece<DT>(A + ar * K + kk, ar < row_end ? valid : 0, p.vec_a != 0);
-      const int bn = n0 + r;
-      rb[h] = load_piece<DT>(Bt + static_cast<int64_t>(bn) * K + kk, bn < N ? valid : 0,
-                             p.vec_b != 0);
+    for (int h = 0; h < PA; ++h) {
+      const int64_t ar = row0 + pr0 + RSTEP * h;
+      ra[h] = load_piece<DT>(A + ar * K + kk, ar < row_end ? valid : 0, VEC);
+    }
+#pragma unroll
+    for (int h = 0; h < PB; ++h) {
+      const int bn = n0 + pr0 + RSTEP * h;
+      rb[h] = load_piece<DT>(Bt + static_cast<int64_t>(bn) * K + kk, bn < N ? valid : 0, VEC);
     }
   };
-  auto stash = [&](const u32x4 (&ra)[2], const u32x4 (&rb)[2]) {
+  auto stash = [&](const u32x4 (&ra)[PA], const u32x4 (&rb)[PB]) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = pr0 + 64 * h;
-      *reinterpret_cast<u32x4*>(sA + r * kPitch + pc * 16) = ra[h];
-      *reinterpret_cast<u32x4*>(sB + r * kPitch + pc * 16) = rb[h];
-    }
+    for (int h = 0; h < PA; ++h)
+      *reinterpret_cast<u32x4*>(sA + (pr0 + RSTEP * h) * kPitch + pc * 16) = ra[h];
+#pragma unroll
+    for (int h = 0; h < PB; ++h)
+      *reinterpret_cast<u32x4*>(sB + (pr0 + RSTEP * h) * kPitch + pc * 16) = rb[h];
   };
 
-  u32x4 ra[2], rb[2];
+  u32x4 ra[PA], rb[PB];
   fetch(0, ra, rb);
   for (int k0 = 0; k0 < K; k0 += KE) {
     __syncthreads();  // previous slab fully consumed
     stash(ra, rb);
     __syncthreads();
     if (k0 + KE < K) fetch(k0 + KE, ra, rb);  // in flight while this slab is multiplied
-    const int lrow = lane & 31, khalf = lane >> 5;
-#pragma unroll
-    for (int s = 0; s < KE / M::KSTEP; ++s) {
+    auto kstep = [&](int s) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const char* sa = sA + (wm * 64 + i * 32 + lrow) * kPitch;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const char* sb = sB + (wn * 64 + j * 32 + lrow) * kPitch;
-          M::step(sa, sb, s, khalf, acc[i][j]);
+        for (int jj = 0; jj < NJ; ++jj) {
+          const char* sb = sB + (wn * (TBN / 2) + jj * 32 + lrow) * kPitch;
+          M::step(sa, sb, s, khalf, acc[i][jj]);
         }
       }
+    };
+    // 16-bit fragments are 4 VGPRs each: keep one k-step of them live (the fully unrolled
+    // form hoists every LDS read of the slab and costs a wave of occupancy); fp32 fragments
+    // are one VGPR, so four k-steps are unrolled to keep LDS reads ahead of the MFMAs.
+    if constexpr (sizeof(DT) == 2) {
+#pragma unroll 1
+      for (int s = 0; s < KE / M::KSTEP; ++s) kstep(s);
+    } else {
+#pragma unroll 4
+      for (int s = 0; s < KE / M::KSTEP; ++s) kstep(s);
     }
   }
 
   // C/D layout of the 32x32 MFMAs: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+  const int rbase = 4 * khalf;
+  if constexpr (sizeof(DT) == 2 && VEC) {
+    {
+      // 16-bit results: a lane owns ONE column, so direct stores would be 2 bytes wide.  Stage
+      // the tile in LDS, 64 rows at a time (the waves of one wm), and write 16-byte row pieces.
+      constexpr int CPR = TBN * 2 / 16;  // 16-byte pieces per C row
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        __syncthreads();  // operands (or the previous half) no longer needed
+        if (wm == half) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                const int col = wn * (TBN / 2) + jj * 32 + lrow;
+                *reinterpret_cast<DT*>(smem + row * kCPitch + col * 2) = from_acc<DT>(acc[i][jj][r]);
+              }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 64 * CPR / 256; ++h) {
+          const int pidx = tid + 256 * h;
+          const int row = pidx / CPR, chunk = pidx % CPR;
+          const int64_t grow = row0 + half * 64 + row;
+          const int col = n0 + chunk * 8;
+          if (grow < row_end && col < N)  // N % 8 == 0 here: a piece is all in or all out
+            *reinterpret_cast<u32x4*>(C + grow * N + col) =
+                *reinterpret_cast<const u32x4*>(smem + row * kCPitch + chunk * 16);
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + col_l;
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int col = n0 + wn * (TBN / 2) + jj * 32 + lrow;
       if (col >= N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-        if (row < row_end) C[row * N + col] = from_acc<DT>(acc[i][j][r]);
+        if (row < row_end) C[row * N + col] = from_acc<DT>(acc[i][jj][r]);
       }
     }
 }
@@ -279,6 +350,8 @@ __global__ __launch_bounds__(256) void segment_mm_plain_kernel(const MmParams p,
   static_cast<DT*>(p.c)[idx] = from_acc<DT>(acc);
 }
 
+constexpr int BN = 128;  // weight-gradient tile width
+
 // ---- weight gradient: dB_r[i][j] = sum_{rows m of r} A[m][i] * dC[m][j] -------------------
 struct MmBwdParams {
   const void* a;   // [M, D1]
@@ -287,12 +360,15 @@ struct MmBwdParams {
   const int64_t* plan;  // slab table: rows_per_tile = kSlabRows
   int64_t num_rel;
   int D1, D2;
+  int vec_a, vec_dc;  // 16-byte loads allowed (row pitch and base 16-byte aligned)
 };
 
 template <typename DT>
 __global__ __launch_bounds__(256) void segment_mm_bwd_b_kernel(const MmBwdParams p) {
   using M = Mma<DT>;
-  constexpr int KE = M::KE;
+  constexpr int KE = kBwdSlab / sizeof(DT);  // slab rows (contraction index) per step
+  constexpr int E = 16 / sizeof(DT);
+  constexpr int kPitch = kBwdSlab + 16;
   __shared__ __attribute__((aligned(16))) char sA[BM * kPitch];
   __shared__ __attribute__((aligned(16))) char sB[BN * kPitch];
 
@@ -306,8 +382,6 @@ __global__ __launch_bounds__(256) void segment_mm_bwd_b_kernel(const MmBwdParams
   if (m1 > row_off[rel + 1]) m1 = row_off[rel + 1];
   const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
   const int D1 = p.D1, D2 = p.D2;
-  const DT* __restrict__ A = static_cast<const DT*>(p.a);
-  const DT* __restrict__ dC = static_cast<const DT*>(p.dc);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -319,23 +393,51 @@ __global__ __launch_bounds__(256) void segment_mm_bwd_b_kernel(const MmBwdParams
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // transposing stage: slab rows m (the contraction index) become the K-contiguous LDS axis.
-  // Thread t handles feature column (t & 127) of operand (t >> 7 ? dC : A) for all KE rows.
-  const int which = tid >> 7, f = tid & 127;
-  const DT* src = which ? dC : A;
+  // Transposing stage: the slab rows (contraction index) become the K-contiguous LDS axis.
+  // Threads 0-127 move the A part, 128-255 the dC part.  Inside a part, thread u = (cgrp, kk):
+  // it loads 16-byte pieces of slab row kk (E consecutive features) and writes each element to
+  // LDS row `feature`, byte kk * sizeof(DT).  Lanes of a wavefront differ in kk first, so one
+  // ds_write covers consecutive bytes of ONE LDS row: no bank conflicts; the strided 16-byte
+  // global reads of a wave touch each 128-byte line completely over its 128 / 16 pieces.
+  const int which = tid >> 7, u = tid & 127;
+  const DT* __restrict__ src = static_cast<const DT*>(which ? p.dc : p.a);
   const int width = which ? D2 : D1;
-  const int fcol = (which ? j0 : i0) + f;
-  char* dst = (which ? sB : sA) + f * kPitch;
+  const int f0 = which ? j0 : i0;
+  char* sT = which ? sB : sA;
+  const int kk = u % KE, cgrp = u / KE;
+  constexpr int CGRPS = 128 / KE;            // chunk groups among the 128 threads of a part
+  constexpr int CHUNKS = 128 / E;            // 16-byte chunks per 128 features
+  constexpr int CPT = CHUNKS / CGRPS;        // chunks per thread
+  const bool vec_ok = (which ? p.vec_dc : p.vec_a) != 0;
+
+  u32x4 regs[CPT];
+  auto fetch = [&](int64_t m) {
+    const int64_t row = m + kk;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int f = f0 + (cgrp + c * CGRPS) * E;
+      regs[c] = load_piece<DT>(src + row * width + f, row < m1 ? width - f : 0, vec_ok);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int fl = (cgrp + c * CGRPS) * E;
+      DT tmp[E];
+      __builtin_memcpy(tmp, &regs[c], 16);
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        *reinterpret_cast<DT*>(sT + (fl + e) * kPitch + kk * sizeof(DT)) = tmp[e];
+    }
+  };
+
+  fetch(m0);
+  const int lrow = lane & 31, khalf = lane >> 5;
   for (int64_t m = m0; m < m1; m += KE) {
     __syncthreads();
-#pragma unroll 4
-    for (int kk = 0; kk < KE; ++kk) {
-      DT v{};
-      if (m + kk < m1 && fcol < width) v = src[(m + kk) * width + fcol];
-      *reinterpret_cast<DT*>(dst + kk * sizeof(DT)) = v;
-    }
+    stash();
     __syncthreads();
-    const int lrow = lane & 31, khalf = lane >> 5;
+    if (m + KE < m1) fetch(m + KE);
 #pragma unroll
     for (int s = 0; s < KE / M::KSTEP; ++s)
 #pragma unroll
@@ -462,6 +564,17 @@ int stage_plan(int idbits, const void* seglen, int seglen_on_host, int64_t num_r
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int mm_num_cus() {
+  static int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;  // MI355X
+    return n;
+  }();
+  return cus;
+}
+
 template <typename DT>
 int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, int64_t N,
                    int64_t num_rel, bool b_trans, char* ws, const MmScratch& sc, hipStream_t s) {
@@ -486,17 +599,28 @@ int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, 
   constexpr int E = 16 / sizeof(DT);
   p.vec_a = (K % E == 0 && aligned16(a)) ? 1 : 0;
   p.vec_b = (K % E == 0 && aligned16(bt)) ? 1 : 0;
+  p.vec_c = (N % E == 0 && aligned16(c)) ? 1 : 0;
+  p.n_tiles = 1;
   if constexpr (sizeof(DT) == 8) {
     const int64_t total = M * N;
     hipLaunchKernelGGL((segment_mm_plain_kernel<DT>), dim3(static_cast<unsigned>((total + 255) / 256)),
                        dim3(256), 0, s, p, M);
   } else {
-    const int64_t max_tiles = (M + BM - 1) / BM + num_rel;
-    if (max_tiles > 0x7fffffffLL) return mfail("segment_mm: too many row tiles");
-    // N tiles on x (fastest): the blocks sharing a row tile run together and re-read it from L2
-    hipLaunchKernelGGL((segment_mm_kernel<DT>),
-                       dim3(static_cast<unsigned>((N + BN - 1) / BN), static_cast<unsigned>(max_tiles)),
-                       dim3(256), 0, s, p);
+    const int64_t max_tiles = ((M + BM - 1) / BM + num_rel + 7) / 8 * 8;  // whole groups of 8 XCDs
+    const bool wide = N > 128;
+    p.n_tiles = wide ? (N + 255) / 256 : 1;
+    const int64_t blocks = max_tiles * p.n_tiles;
+    if (blocks > 0x7fffffffLL) return mfail("segment_mm: too many tiles");
+    const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+    const bool vec = p.vec_a && p.vec_b && p.vec_c;
+    if (wide && vec)
+      hipLaunchKernelGGL((segment_mm_kernel<DT, 256, true>), grid, block, 0, s, p);
+    else if (wide)
+      hipLaunchKernelGGL((segment_mm_kernel<DT, 256, false>), grid, block, 0, s, p);
+    else if (vec)
+      hipLaunchKernelGGL((segment_mm_kernel<DT, 128, true>), grid, block, 0, s, p);
+    else
+      hipLaunchKernelGGL((segment_mm_kernel<DT, 128, false>), grid, block, 0, s, p);
   }
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
@@ -524,6 +648,9 @@ int run_segment_mm_bwd_b(const void* a, const void* dc, void* db, int64_t M, int
     p.num_rel = num_rel;
     p.D1 = static_cast<int>(D1);
     p.D2 = static_cast<int>(D2);
+    constexpr int E = 16 / sizeof(DT);
+    p.vec_a = (D1 % E == 0 && aligned16(a)) ? 1 : 0;
+    p.vec_dc = (D2 % E == 0 && aligned16(dc)) ? 1 : 0;
     const int64_t max_slabs = (M + kSlabRows - 1) / kSlabRows + num_rel;
     if (max_slabs > 65535) return mfail("segment_mm backward: more than 65535 row slabs (" +
                                         std::to_string(max_slabs) + "); split the call");
