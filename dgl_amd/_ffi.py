@@ -48,6 +48,7 @@ LIB.DGLFuncGetGlobal.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p
 LIB.DGLFuncCall.argtypes = [ctypes.c_void_p, ctypes.POINTER(DGLValue), ctypes.POINTER(ctypes.c_int),
                             ctypes.c_int, ctypes.POINTER(DGLValue), ctypes.POINTER(ctypes.c_int)]
 LIB.DGLSetStream.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+LIB.DGLObjectFree.argtypes = [ctypes.c_void_p]
 
 
 class NDArray:
@@ -74,12 +75,42 @@ class NDArray:
                             None, 0)
 
 
+class _Boxed:
+    """A List<Value> made for the duration of one call (convert_to_object,
+    python/dgl/_ffi/object_generic.py:27-59): released with DGLObjectFree afterwards."""
+
+    __slots__ = ("handle", "parts", "keep")
+
+    def __init__(self, seq):
+        self.keep = list(seq)
+        self.parts = []
+        for x in self.keep:
+            if x is None:
+                self.parts.append(None)
+            else:
+                self.parts.append(get_global_func("_Value")(x))
+        self.handle = get_global_func("_List")(*self.parts).handle
+
+    def free(self):
+        LIB.DGLObjectFree(ctypes.c_void_p(self.handle))
+        for p in self.parts:
+            if p is not None:
+                LIB.DGLObjectFree(ctypes.c_void_p(p.handle))
+        self.parts, self.handle = [], None
+
+
 def _pack(args):
     n = len(args)
     values = (DGLValue * max(n, 1))()
     codes = (ctypes.c_int * max(n, 1))()
     keep = []
     for i, a in enumerate(args):
+        if isinstance(a, (list, tuple)):
+            a = _Boxed(a)
+            keep.append(a)
+            values[i].v_handle = a.handle
+            codes[i] = kObjectHandle
+            continue
         if a is None:
             values[i].v_handle = None
             codes[i] = kNull
@@ -127,6 +158,9 @@ class Function:
         values, codes, n, keep = _pack(args)
         ret, ret_code = DGLValue(), ctypes.c_int(kNull)
         rc = LIB.DGLFuncCall(self.handle, values, codes, n, ctypes.byref(ret), ctypes.byref(ret_code))
+        for k in keep:
+            if isinstance(k, _Boxed):
+                k.free()
         del keep
         if rc != 0:
             raise _lib.DGLAMDError(LIB.DGLGetLastError().decode("utf-8", "replace"))

@@ -152,7 +152,13 @@ struct SparseFmt {
   int64_t nnz = 0;
 };
 
+// Every object handed to Python as an opaque handle starts with a tag, so a function that is
+// given the wrong kind of handle fails with a message instead of reading garbage.
+constexpr uint32_t kMagicUnit = 0x554e4954u, kMagicList = 0x4c495354u, kMagicValue = 0x56414c55u,
+                   kMagicHetero = 0x48455445u;
+
 struct UnitGraph {
+  uint32_t magic = kMagicUnit;
   int64_t num_src = 0, num_dst = 0, num_edges = 0;
   int idbits = 64;
   SparseFmt coo, csr /*rows = src*/, csc /*rows = dst*/;
@@ -743,11 +749,411 @@ static Registrar r_gmms("sparse._CAPI_DGLKernelGATHERMMSCATTER",
   return gather_mm_ffi(a, true);
 });
 
+
+// =========================================================================================
+// Lists of values and the heterograph handle: what sparse._CAPI_DGLKernelSpMMHetero /
+// SDDMMHetero need (src/array/kernel.cc:563-601,628-656).  The reference boxes Python lists
+// as List<Value> objects through `_List` / `_Value` (python/dgl/_ffi/object_generic.py:27-59,
+// src/api/api_container.cc); the same two global names exist here with the same meaning.
+// =========================================================================================
+struct ObjValue {
+  uint32_t magic = kMagicValue;
+  DGLValue v;
+  int tc = kNull;
+};
+struct ObjList {
+  uint32_t magic = kMagicList;
+  std::vector<ObjValue> items;
+};
+struct HeteroGraphObj {
+  uint32_t magic = kMagicHetero;
+  int num_ntypes = 0;
+  std::vector<UnitGraph*> rel;  // borrowed: the unit graphs outlive this object
+  std::vector<int> src, dst;    // metagraph: etype -> (src ntype, dst ntype)
+};
+
+static uint32_t magic_of(const void* h) { return h ? *static_cast<const uint32_t*>(h) : 0; }
+
+static Registrar r_value("_Value", [](const FfiArgs& a, DGLValue* ret, int* rtc) {
+  if (a.n != 1) return ffi_fail("_Value takes one argument");
+  ObjValue* o = new ObjValue();
+  o->v = a.v[0];
+  o->tc = a.tc[0];
+  ret->v_handle = o;
+  *rtc = kObjectHandle;
+  return 0;
+});
+
+static Registrar r_list("_List", [](const FfiArgs& a, DGLValue* ret, int* rtc) {
+  ObjList* l = new ObjList();
+  for (int i = 0; i < a.n; ++i) {
+    ObjValue it;
+    it.v = a.v[i];
+    it.tc = a.tc[i];
+    // a boxed value is unboxed: the list holds (value, type code) pairs
+    if ((a.tc[i] == kObjectHandle || a.tc[i] == kHandle) && magic_of(a.v[i].v_handle) == kMagicValue) {
+      const ObjValue* b = static_cast<const ObjValue*>(a.v[i].v_handle);
+      it.v = b->v;
+      it.tc = b->tc;
+    }
+    l->items.push_back(it);
+  }
+  ret->v_handle = l;
+  *rtc = kObjectHandle;
+  return 0;
+});
+
+static int get_list(const FfiArgs& a, int i, const ObjList** out) {
+  void* h = nullptr;
+  if (i < a.n && a.tc[i] == kNull) {
+    static const ObjList empty;
+    *out = &empty;
+    return 0;
+  }
+  if (get_handle(a, i, &h) || magic_of(h) != kMagicList)
+    return ffi_fail("argument " + std::to_string(i) + ": expected a list (see _List)");
+  *out = static_cast<const ObjList*>(h);
+  return 0;
+}
+
+// i-th entry as an NDArray; absent (short list, None) -> nullptr
+static int list_array(const ObjList* l, size_t i, DGLArray** out) {
+  *out = nullptr;
+  if (i >= l->items.size() || l->items[i].tc == kNull) return 0;
+  if (!is_array(l->items[i].tc)) return ffi_fail("list entry " + std::to_string(i) + " is not an NDArray");
+  *out = static_cast<DGLArray*>(l->items[i].v.v_handle);
+  return 0;
+}
+
+// (num_ntypes, unit_graph_0, src_ntype_0, dst_ntype_0, unit_graph_1, ...)
+static Registrar r_hg_create("dgl_amd._CAPI_HeteroGraphCreate",
+                             [](const FfiArgs& a, DGLValue* ret, int* rtc) {
+  int64_t nt;
+  if (get_int(a, 0, &nt)) return -1;
+  if ((a.n - 1) % 3) return ffi_fail("expected (num_ntypes, [unit graph, src ntype, dst ntype] ...)");
+  HeteroGraphObj* hg = new HeteroGraphObj();
+  hg->num_ntypes = static_cast<int>(nt);
+  for (int i = 1; i < a.n; i += 3) {
+    void* h;
+    int64_t s, d;
+    if (get_handle(a, i, &h) || get_int(a, i + 1, &s) || get_int(a, i + 2, &d) ||
+        magic_of(h) != kMagicUnit || s < 0 || s >= nt || d < 0 || d >= nt) {
+      delete hg;
+      return ffi_fail("bad relation " + std::to_string((i - 1) / 3));
+    }
+    hg->rel.push_back(static_cast<UnitGraph*>(h));
+    hg->src.push_back(static_cast<int>(s));
+    hg->dst.push_back(static_cast<int>(d));
+  }
+  ret->v_handle = hg;
+  *rtc = kObjectHandle;
+  return 0;
+});
+
+// ---- device helpers of the hetero max / min path -------------------------------------------
+template <typename T>
+__global__ void hetero_fill_kernel(T* p, int64_t n, T v) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+// Running max / min across relations: relation `etype` (source node type `src`) replaces the
+// current winner only where it is STRICTLY better — SpMMCmpCsrHeteroKernel seeds its compare
+// from the current output (src/array/cuda/spmm.cuh:552-606), so earlier relations win ties.
+template <typename DT, typename Idx, bool MAX>
+__global__ void hetero_cmp_combine_kernel(DT* __restrict__ out, const DT* __restrict__ cand,
+                                          Idx* __restrict__ arg_u, const Idx* __restrict__ cand_u,
+                                          Idx* __restrict__ arg_e, const Idx* __restrict__ cand_e,
+                                          Idx* __restrict__ arg_u_nt, Idx* __restrict__ arg_e_et,
+                                          Idx src, Idx etype, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) {
+    const auto cur = to_acc<DT>(out[i]);
+    const auto c = to_acc<DT>(cand[i]);
+    if (MAX ? (cur < c) : (cur > c)) {
+      out[i] = cand[i];
+      if (arg_u) arg_u[i] = cand_u[i];
+      if (arg_e) arg_e[i] = cand_e[i];
+      if (arg_u_nt) arg_u_nt[i] = src;
+      if (arg_e_et) arg_e_et[i] = etype;
+    }
+  }
+}
+
+static unsigned hgrid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return static_cast<unsigned>(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+template <typename DT>
+static DT storage_identity(bool is_max, bool half16) {
+  const float inf = __builtin_huge_valf();
+  const float v = half16 ? (is_max ? -65504.f : 65504.f) : (is_max ? -inf : inf);
+  return static_cast<DT>(v);
+}
+
+template <typename DT, typename Idx>
+static int hetero_combine(bool is_max, void* out, const void* cand, void* au, const void* cu, void* ae,
+                          const void* ce, void* unt, void* eet, int src, int et, int64_t n) {
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(hgrid(n)), dim3(256), 0, tls_stream, static_cast<DT*>(out),
+                       static_cast<const DT*>(cand), static_cast<Idx*>(au), static_cast<const Idx*>(cu),
+                       static_cast<Idx*>(ae), static_cast<const Idx*>(ce), static_cast<Idx*>(unt),
+                       static_cast<Idx*>(eet), static_cast<Idx>(src), static_cast<Idx>(et), n);
+  };
+  if (is_max)
+    launch(hetero_cmp_combine_kernel<DT, Idx, true>);
+  else
+    launch(hetero_cmp_combine_kernel<DT, Idx, false>);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static size_t dtype_bytes(dgla_dtype d) { return d == DGLA_F64 ? 8 : (d == DGLA_F32 ? 4 : 2); }
+
+static int fill_identity(dgla_dtype dt, void* p, int64_t n, bool is_max) {
+  switch (dt) {
+    case DGLA_F32:
+      hipLaunchKernelGGL(hetero_fill_kernel<float>, dim3(hgrid(n)), dim3(256), 0, tls_stream,
+                         static_cast<float*>(p), n, storage_identity<float>(is_max, false));
+      break;
+    case DGLA_F64:
+      hipLaunchKernelGGL(hetero_fill_kernel<double>, dim3(hgrid(n)), dim3(256), 0, tls_stream,
+                         static_cast<double*>(p), n, storage_identity<double>(is_max, false));
+      break;
+    case DGLA_F16:
+      hipLaunchKernelGGL(hetero_fill_kernel<f16_t>, dim3(hgrid(n)), dim3(256), 0, tls_stream,
+                         static_cast<f16_t*>(p), n, storage_identity<f16_t>(is_max, true));
+      break;
+    case DGLA_BF16: {
+      bf16_t v;
+      v.bits = is_max ? 0xff80 : 0x7f80;  // -inf / +inf
+      hipLaunchKernelGGL(hetero_fill_kernel<bf16_t>, dim3(hgrid(n)), dim3(256), 0, tls_stream,
+                         static_cast<bf16_t*>(p), n, v);
+      break;
+    }
+  }
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static int fill_index(int bits, void* p, int64_t n, int64_t v) {
+  if (bits == 32)
+    hipLaunchKernelGGL(hetero_fill_kernel<int32_t>, dim3(hgrid(n)), dim3(256), 0, tls_stream,
+                       static_cast<int32_t*>(p), n, static_cast<int32_t>(v));
+  else
+    hipLaunchKernelGGL(hetero_fill_kernel<int64_t>, dim3(hgrid(n)), dim3(256), 0, tls_stream,
+                       static_cast<int64_t*>(p), n, v);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static int64_t numel(const DGLArray* t) {
+  int64_t n = 1;
+  for (int i = 0; i < t->ndim; ++i) n *= t->shape[i];
+  return n;
+}
+
+// One relation's g-SpMM on a unit graph into caller-provided output / arg buffers.
+static int spmm_unit(UnitGraph* g, const char* op, const char* reduce, dgla_dtype dt, const dgla_tensor* u,
+                     const dgla_tensor* e, const dgla_tensor* v, void* arg_u, void* arg_e, bool accumulate) {
+  if (g->csc.present) {
+    const dgla_csr csc = csr_of(g, g->csc, true);
+    const size_t need = dgla_spmm_csr_workspace_bytes(op, reduce, &csc, dt, u, e, v);
+    void* ws = g->ws;
+    size_t ws_bytes = g->ws_bytes;
+    void* owned = nullptr;
+    uint32_t flags = accumulate ? DGLA_ACCUMULATE : 0;
+    if (need > ws_bytes) {  // graph scratch not (yet) attached: stream-ordered allocation
+      DGLA_CHECK_HIP(hipMallocAsync(&owned, need, tls_stream));
+      ws = owned;
+      ws_bytes = need;
+    } else if (g->plan_valid) {
+      flags |= DGLA_PLAN_VALID;
+    }
+    const int rc = dgla_spmm_csr(op, reduce, &csc, dt, u, e, v, arg_u, arg_e, ws, ws_bytes, flags, tls_stream);
+    if (owned)
+      (void)hipFreeAsync(owned, tls_stream);
+    else if (rc == 0)
+      g->plan_valid = true;
+    return rc;
+  }
+  if (g->coo.present) {
+    if (accumulate) return ffi_fail("accumulating SpMM needs the CSC format");  // kernel.cc:212-217
+    const dgla_coo coo = coo_of(g);
+    return dgla_spmm_coo(op, reduce, &coo, dt, u, e, v, arg_u, arg_e, tls_stream);
+  }
+  return ffi_fail("SpMM only supports CSC and COO formats");
+}
+
+// (hg, op, reduce, List U [by src ntype], List E [by etype], List V [by dst ntype],
+//  List ArgU, List ArgE, List ArgU_ntype, List ArgE_etype [all by dst ntype])
+// V arrives zero-filled; relations whose V entry is absent are skipped (the Python layer
+// routes those destination types through the fused stacked launch instead).
+static Registrar r_spmm_hetero("sparse._CAPI_DGLKernelSpMMHetero",
+                               [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  void* h;
+  const char *op, *reduce;
+  const ObjList *LU, *LE, *LV, *LAU, *LAE, *LUT, *LET;
+  if (get_handle(a, 0, &h) || get_str(a, 1, &op) || get_str(a, 2, &reduce) || get_list(a, 3, &LU) ||
+      get_list(a, 4, &LE) || get_list(a, 5, &LV) || get_list(a, 6, &LAU) || get_list(a, 7, &LAE) ||
+      get_list(a, 8, &LUT) || get_list(a, 9, &LET))
+    return -1;
+  if (magic_of(h) != kMagicHetero) return ffi_fail("argument 0: expected a heterograph handle");
+  HeteroGraphObj* hg = static_cast<HeteroGraphObj*>(h);
+  const bool is_sum = !strcmp(reduce, "sum"), is_max = !strcmp(reduce, "max");
+  if (!is_sum && !is_max && strcmp(reduce, "min")) return ffi_fail(std::string("Unsupported SpMM reducer: ") + reduce);
+  const bool use_u = strcmp(op, "copy_rhs") != 0, use_e = strcmp(op, "copy_lhs") != 0;
+  const size_t n_et = hg->rel.size();
+
+  // feature shape agreement between the relations reducing into one node type
+  // (src/array/kernel.cc:194-199, spmm_hetero.cu:61-81)
+  std::vector<bool> initialised(hg->num_ntypes, false);
+  for (size_t et = 0; et < n_et; ++et) {
+    UnitGraph* g = hg->rel[et];
+    const int s = hg->src[et], d = hg->dst[et];
+    DGLArray *U, *E, *V, *AU, *AE, *UT, *ET;
+    if (list_array(LU, s, &U) || list_array(LE, et, &E) || list_array(LV, d, &V) ||
+        list_array(LAU, d, &AU) || list_array(LAE, d, &AE) || list_array(LUT, d, &UT) ||
+        list_array(LET, d, &ET))
+      return -1;
+    if (null_array(V)) continue;                               // not ours (see above)
+    if ((use_u && null_array(U)) || (use_e && null_array(E))) continue;  // relation carries no message
+    dgla_dtype dt;
+    if (float_dtype(V, &dt)) return -1;
+    for (const DGLArray* t : {U, E, V, AU, AE}) {
+      if (null_array(t)) continue;
+      if (!on_gpu(t)) return ffi_fail("array is not on the GPU device of the graph");
+      if (check_contiguous(t, "array")) return -1;
+    }
+    const int64_t n_out = numel(V);
+    TensorArg tu, te, tv;
+    to_tensor(use_u ? U : nullptr, &tu);
+    to_tensor(use_e ? E : nullptr, &te);
+    to_tensor(V, &tv);
+    if (is_sum) {
+      if (g->num_edges == 0) continue;
+      // V is zero-filled by the caller; every relation adds (spmm_hetero.cu:150-158)
+      if (spmm_unit(g, op, reduce, dt, &tu.t, &te.t, &tv.t, nullptr, nullptr, true)) return -1;
+      continue;
+    }
+    // ---- max / min ----
+    if (!initialised[d]) {
+      initialised[d] = true;
+      if (fill_identity(dt, data_ptr(V), n_out, is_max)) return -1;    // spmm_hetero.cu:87-99
+      if (!null_array(UT) && fill_index(g->idbits, data_ptr(UT), n_out, -1)) return -1;  // :100-117
+      if (!null_array(ET) && fill_index(g->idbits, data_ptr(ET), n_out, -1)) return -1;
+    }
+    if (g->num_edges == 0) continue;
+    if (use_u && null_array(AU)) return ffi_fail("Arg_U is required for max/min");
+    if (use_e && null_array(AE)) return ffi_fail("Arg_E is required for max/min");
+    // candidate of this relation into scratch, then the strict running compare
+    const size_t vb = static_cast<size_t>(n_out) * dtype_bytes(dt);
+    const size_t ib = static_cast<size_t>(n_out) * (g->idbits / 8);
+    const size_t off_u = (vb + 255) / 256 * 256, off_e = off_u + (ib + 255) / 256 * 256;
+    char* tmp = nullptr;
+    DGLA_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&tmp), off_e + ib + 256, tls_stream));
+    TensorArg tc = tv;
+    tc.t.shape = tc.shape.data();
+    tc.t.data = tmp;
+    int rc = spmm_unit(g, op, reduce, dt, &tu.t, &te.t, &tc.t, use_u ? tmp + off_u : nullptr,
+                       use_e ? tmp + off_e : nullptr, false);
+    if (rc == 0) {
+      void* au = use_u ? data_ptr(AU) : nullptr;
+      void* ae = use_e ? data_ptr(AE) : nullptr;
+      void* ut = (use_u && !null_array(UT)) ? data_ptr(UT) : nullptr;
+      void* et_p = (use_e && !null_array(ET)) ? data_ptr(ET) : nullptr;
+#define DGLA_HCOMB(DT_)                                                                               \
+  rc = g->idbits == 32                                                                                \
+           ? hetero_combine<DT_, int32_t>(is_max, data_ptr(V), tmp, au, tmp + off_u, ae, tmp + off_e, \
+                                          ut, et_p, hg->src[et], static_cast<int>(et), n_out)         \
+           : hetero_combine<DT_, int64_t>(is_max, data_ptr(V), tmp, au, tmp + off_u, ae, tmp + off_e, \
+                                          ut, et_p, hg->src[et], static_cast<int>(et), n_out)
+      switch (dt) {
+        case DGLA_F32: DGLA_HCOMB(float); break;
+        case DGLA_F64: DGLA_HCOMB(double); break;
+        case DGLA_F16: DGLA_HCOMB(f16_t); break;
+        case DGLA_BF16: DGLA_HCOMB(bf16_t); break;
+      }
+#undef DGLA_HCOMB
+    }
+    (void)hipFreeAsync(tmp, tls_stream);
+    if (rc) return rc;
+  }
+  return 0;
+});
+
+// (hg, op, List lhs, List rhs, List out [by etype], int lhs_target, int rhs_target): operands
+// indexed by node type for u / v targets and by edge type for e (src/array/kernel.cc:249-290).
+static Registrar r_sddmm_hetero("sparse._CAPI_DGLKernelSDDMMHetero",
+                                [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  void* h;
+  const char* op;
+  const ObjList *LL, *LR, *LO;
+  int64_t lt, rt;
+  if (get_handle(a, 0, &h) || get_str(a, 1, &op) || get_list(a, 2, &LL) || get_list(a, 3, &LR) ||
+      get_list(a, 4, &LO) || get_int(a, 5, &lt) || get_int(a, 6, &rt))
+    return -1;
+  if (magic_of(h) != kMagicHetero) return ffi_fail("argument 0: expected a heterograph handle");
+  if (lt < 0 || lt > 2 || rt < 0 || rt > 2) return ffi_fail("targets must be 0 (u), 1 (e) or 2 (v)");
+  HeteroGraphObj* hg = static_cast<HeteroGraphObj*>(h);
+  for (size_t et = 0; et < hg->rel.size(); ++et) {
+    UnitGraph* g = hg->rel[et];
+    const size_t pick[3] = {static_cast<size_t>(hg->src[et]), et, static_cast<size_t>(hg->dst[et])};
+    DGLArray *lhs, *rhs, *out;
+    if (list_array(LL, pick[lt], &lhs) || list_array(LR, pick[rt], &rhs) || list_array(LO, et, &out))
+      return -1;
+    if (null_array(out) || g->num_edges == 0) continue;
+    const bool use_l = strcmp(op, "copy_rhs") != 0, use_r = strcmp(op, "copy_lhs") != 0;
+    if ((use_l && null_array(lhs)) || (use_r && null_array(rhs))) continue;
+    dgla_dtype dt;
+    if (float_dtype(out, &dt)) return -1;
+    for (const DGLArray* t : {lhs, rhs, out}) {
+      if (null_array(t)) continue;
+      if (!on_gpu(t)) return ffi_fail("array is not on the GPU device of the graph");
+      if (check_contiguous(t, "array")) return -1;
+    }
+    TensorArg l, r, o;
+    to_tensor(use_l ? lhs : nullptr, &l);
+    to_tensor(use_r ? rhs : nullptr, &r);
+    to_tensor(out, &o);
+    int rc;
+    if (g->coo.present) {
+      const dgla_coo coo = coo_of(g);
+      rc = dgla_sddmm_coo(op, &coo, dt, &l.t, &r.t, &o.t, static_cast<int>(lt), static_cast<int>(rt), tls_stream);
+    } else if (g->csr.present) {
+      const dgla_csr csr = csr_of(g, g->csr, false);
+      rc = dgla_sddmm_csr(op, &csr, dt, &l.t, &r.t, &o.t, static_cast<int>(lt), static_cast<int>(rt), tls_stream);
+    } else {
+      return ffi_fail("SDDMM only supports CSR and COO formats");
+    }
+    if (rc) return rc;
+  }
+  return 0;
+});
+
 }  // namespace dgla
 
 using namespace dgla;
 
 extern "C" {
+
+// Frees any object handle made by this library (the reference: DGLObjectFree,
+// include/dgl/runtime/c_object_api.h).  Unit graphs borrowed by a heterograph handle must
+// outlive it.
+int DGLObjectFree(void* handle) {
+  switch (magic_of(handle)) {
+    case kMagicValue: delete static_cast<ObjValue*>(handle); return 0;
+    case kMagicList: delete static_cast<ObjList*>(handle); return 0;
+    case kMagicHetero: delete static_cast<HeteroGraphObj*>(handle); return 0;
+    case kMagicUnit: delete static_cast<UnitGraph*>(handle); return 0;
+    case 0: return 0;
+  }
+  last_error() = "DGLObjectFree: not an object of this library";
+  return -1;
+}
 
 const char* DGLGetLastError(void) { return last_error().c_str(); }
 void DGLAPISetLastError(const char* msg) { last_error() = msg ? msg : ""; }

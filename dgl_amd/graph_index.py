@@ -231,6 +231,8 @@ class GraphIndex:
         self.relations = list(relations)
         self._rev = None
         self._stacked = {}
+        self._hetero_handle = None
+        self._hetero_fmts = None
 
     def stacked(self, etypes):
         """(Relation over the stacked CSC, uint8 rel array) for relations `etypes`, which must
@@ -245,6 +247,27 @@ class GraphIndex:
                            idtype=rels[0].idtype, device=rels[0].device, formats=("csc",))
             self._stacked[key] = (stk, rel)
         return self._stacked[key]
+
+    def hetero_handle(self, fmts):
+        """Heterograph handle (dgl_amd._CAPI_HeteroGraphCreate) over the relations' unit-graph
+        handles, with format ``fmts[et]`` registered for relation ``et`` — what the reference's
+        HeteroGraphRef argument gives its C++ side: NumEdgeTypes, meta_graph()->FindEdge and the
+        per-relation matrices (src/array/kernel.cc:563-601)."""
+        handles = [r.handle(f) for r, f in zip(self.relations, fmts)]
+        if self._hetero_handle is None:
+            flat = []
+            for h, (s, d) in zip(handles, self.metagraph.edges):
+                flat += [h, int(s), int(d)]
+            self._hetero_handle = _ffi.get_global_func("dgl_amd._CAPI_HeteroGraphCreate")(
+                len(self._num_nodes), *flat)
+        return self._hetero_handle
+
+    def __del__(self):
+        try:
+            if self._hetero_handle is not None:
+                _ffi.LIB.DGLObjectFree(self._hetero_handle.handle)
+        except Exception:  # interpreter shutdown
+            pass
 
     def number_of_etypes(self):
         return len(self.relations)

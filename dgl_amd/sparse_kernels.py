@@ -200,67 +200,87 @@ def _edge_softmax_backward(gidx, out, sds):
 def _gspmm_hetero(gidx, op, reduce_op, u_len, u_and_e_tuple):
     """Returns ``(out_per_dst_ntype, (arg_u, arg_e, arg_u_ntype, arg_e_etype))`` like
     python/dgl/_sparse_ops.py:268-433.  ``u`` is indexed by source node type, ``e`` by edge
-    type, outputs by destination node type."""
+    type, outputs by destination node type.
+
+    Destination types whose relations can be summed by one stacked launch take that route
+    (``_fused_hetero_sum``); everything else goes through ``sparse._CAPI_DGLKernelSpMMHetero``
+    with the reference's argument lists: the per-relation loop, the accumulate-into-``V``
+    contract for sum and the strict running compare with node / edge type tracking for
+    max / min all live on the C++ side (csrc/ffi_registry.hip ≙ spmm_hetero.cu:26-200)."""
     u_tuple, e_tuple = u_and_e_tuple[:u_len], u_and_e_tuple[u_len:]
     use_u, use_e = op != "copy_rhs", op != "copy_lhs"
     n_nt, n_et = gidx.number_of_ntypes(), gidx.number_of_etypes()
     outs = [None] * n_nt
+    use_cmp = reduce_op in ("max", "min")
+    fused = _fused_hetero_sum(gidx, op, reduce_op, u_tuple, e_tuple, outs)
+
+    list_u, list_e, list_v = [None] * n_nt, [None] * n_et, [None] * n_nt
     arg_u, arg_e = [None] * n_nt, [None] * n_nt
     arg_u_nt, arg_e_et = [None] * n_nt, [None] * n_nt
-    use_cmp = reduce_op in ("max", "min")
+    squeeze = [False] * n_nt
     feat_shape = {}
-    fused = _fused_hetero_sum(gidx, op, reduce_op, u_tuple, e_tuple, outs)
+    fmts = ["coo"] * n_et
+    todo = False
     for et in range(n_et):
         s, d = gidx.metagraph.find_edge(et)
+        rel = gidx.relations[et]
+        fmts[et] = "csc" if rel.allowed("csc") else ("coo" if rel.allowed("coo") else "csr")
         if d in fused:
             continue
         u = u_tuple[s] if use_u else None
         e = e_tuple[et] if use_e else None
         if (use_u and u is None) or (use_e and e is None):
             continue
-        sub = gidx.get_relation_graph(et)
+        _check_pair(u, e, use_u, use_e, "spmm")
+        expand_u = expand_e = False
+        if use_u and u.dim() == 1:
+            u, expand_u = u.unsqueeze(-1), True
+        if use_e and e.dim() == 1:
+            e, expand_e = e.unsqueeze(-1), True
         o_feat = infer_broadcast_shape(op, tuple(u.shape[1:]) if use_u else (),
                                        tuple(e.shape[1:]) if use_e else ())
         if d in feat_shape and feat_shape[d] != o_feat:
             # src/array/kernel.cc:194-199: relations reducing into one node type must agree
             raise DGLAMDError("The feature shape of relation {} does not match others.".format(et))
         feat_shape[d] = o_feat
-        if not use_cmp:
-            if outs[d] is None:
-                ref = u if use_u else e
-                o_shp = (gidx.num_nodes(d),) + infer_broadcast_shape(
-                    op, tuple(u.shape[1:]) if use_u else (), tuple(e.shape[1:]) if use_e else ())
-                if ref.dim() == 1:
-                    o_shp = (gidx.num_nodes(d),)
-                if gidx.num_edges(et) > 0:
-                    outs[d], _ = _gspmm(sub, op, reduce_op, u, e)          # first relation writes
-                else:
-                    outs[d] = torch.zeros(o_shp, dtype=ref.dtype, device=ref.device)
-            elif gidx.num_edges(et) > 0:
-                acc = outs[d] if outs[d].dim() > 1 else outs[d].unsqueeze(-1)
-                _gspmm(sub, op, reduce_op, u, e, accumulate_into=acc)     # later ones add
-        else:
-            o, (au, ae) = _gspmm(sub, op, reduce_op, u, e)
-            if outs[d] is None:
-                outs[d], arg_u[d], arg_e[d] = o, au, ae
-                has = gidx.relations[et].in_degrees() > 0
-                has = has.view((-1,) + (1,) * (o.dim() - 1)).expand_as(o)
-                # node/edge type of the winner, -1 where no edge arrived (spmm_hetero.cu:87-117)
+        ref = u if use_u else e
+        if use_u:
+            list_u[s] = u.contiguous()
+        if use_e:
+            list_e[et] = e.contiguous()
+        if list_v[d] is None:
+            v_shp = (gidx.num_nodes(d),) + o_feat
+            list_v[d] = torch.zeros(v_shp, dtype=ref.dtype, device=ref.device)  # _sparse_ops.py:351
+            squeeze[d] = (expand_u or not use_u) and (expand_e or not use_e)
+            if use_cmp:
                 if use_u:
-                    arg_u_nt[d] = torch.where(has, torch.full_like(au, s), torch.full_like(au, -1))
+                    arg_u[d] = torch.zeros(v_shp, dtype=rel.idtype, device=ref.device)
+                    arg_u_nt[d] = torch.zeros(v_shp, dtype=rel.idtype, device=ref.device)
                 if use_e:
-                    arg_e_et[d] = torch.where(has, torch.full_like(ae, et), torch.full_like(ae, -1))
-            else:
-                # running max/min across relations: a later relation wins only if strictly
-                # better (SpMMCmpCsrHeteroKernel seeds from the current output, spmm.cuh:552-606)
-                better = (o > outs[d]) if reduce_op == "max" else (o < outs[d])
-                outs[d] = torch.where(better, o, outs[d])
-                if use_u:
-                    arg_u[d] = torch.where(better, au, arg_u[d])
-                    arg_u_nt[d] = torch.where(better, torch.full_like(au, s), arg_u_nt[d])
-                if use_e:
-                    arg_e[d] = torch.where(better, ae, arg_e[d])
-                    arg_e_et[d] = torch.where(better, torch.full_like(ae, et), arg_e_et[d])
+                    arg_e[d] = torch.zeros(v_shp, dtype=rel.idtype, device=ref.device)
+                    arg_e_et[d] = torch.zeros(v_shp, dtype=rel.idtype, device=ref.device)
+        if gidx.num_edges(et) > 0 and list_v[d].numel() > 0:
+            todo = True
+            if fmts[et] == "csc":  # attach scratch to the relation so that its merge plan is cached
+                args = (op, reduce_op, _nd(list_u[s] if use_u else None),
+                        _nd(list_e[et] if use_e else None), _nd(list_v[d]), _nd(arg_u[d]), _nd(arg_e[d]))
+                rel.ensure_workspace(_call("sparse._CAPI_DGLKernelSpMMWorkspaceBytes", rel, "csc", *args))
+    if todo:
+        if fmts and any(f == "csr" for f in fmts):
+            raise DGLAMDError("SpMM only supports CSC and COO formats")
+        nd = lambda ts: [_nd(t) for t in ts]
+        _ffi.use_current_stream(gidx.ctx)
+        _ffi.get_global_func("sparse._CAPI_DGLKernelSpMMHetero")(
+            gidx.hetero_handle(fmts), op, reduce_op, nd(list_u), nd(list_e), nd(list_v),
+            nd(arg_u), nd(arg_e), nd(arg_u_nt), nd(arg_e_et))
+    for d in range(n_nt):
+        if d in fused or list_v[d] is None:
+            continue
+        if squeeze[d]:  # 1-D inputs give 1-D outputs (_sparse_ops.py:424-430)
+            list_v[d] = list_v[d].squeeze(-1)
+            for lst in (arg_u, arg_e, arg_u_nt, arg_e_et):
+                lst[d] = None if lst[d] is None else lst[d].squeeze(-1)
+        outs[d] = list_v[d]
     return tuple(outs), (arg_u, arg_e, arg_u_nt, arg_e_et)
 
 
@@ -323,18 +343,51 @@ def _fused_hetero_sum(gidx, op, reduce_op, u_tuple, e_tuple, outs):
 
 
 def _gsddmm_hetero(gidx, op, lhs_len, lhs_target, rhs_target, lhs_and_rhs_tuple):
-    """Per-relation SDDMM (python/dgl/_sparse_ops.py:568-638): operands indexed by node type
-    for 'u' / 'v' targets and by edge type for 'e'; output indexed by edge type."""
+    """Per-relation SDDMM (python/dgl/_sparse_ops.py:568-638) through
+    ``sparse._CAPI_DGLKernelSDDMMHetero``: operands indexed by node type for 'u' / 'v' targets
+    and by edge type for 'e'; output indexed by edge type."""
     lhs_tuple, rhs_tuple = lhs_and_rhs_tuple[:lhs_len], lhs_and_rhs_tuple[lhs_len:]
     use_l, use_r = op != "copy_rhs", op != "copy_lhs"
-    outs = []
-    for et in range(gidx.number_of_etypes()):
+    n_et = gidx.number_of_etypes()
+    outs = [None] * n_et
+    squeeze = [False] * n_et
+    prep = {}
+
+    def operand(tup, idx, side):
+        t = tup[idx]
+        if t is None:
+            return None, False
+        key = (side, idx)
+        if key not in prep:
+            ex = t.dim() == 1
+            prep[key] = ((t.unsqueeze(-1) if ex else t).contiguous(), ex)
+        return prep[key]
+
+    fmts, todo = [], False
+    for et in range(n_et):
         s, d = gidx.metagraph.find_edge(et)
-        pick = lambda tup, tgt: tup[{"u": s, "v": d, "e": et}[tgt]]
-        l = pick(lhs_tuple, lhs_target) if use_l else None
-        r = pick(rhs_tuple, rhs_target) if use_r else None
+        rel = gidx.relations[et]
+        fmts.append("coo" if rel.allowed("coo") else ("csr" if rel.allowed("csr") else "csc"))
+        pick = lambda tgt: {"u": s, "v": d, "e": et}[tgt]
+        l, ex_l = operand(lhs_tuple, pick(lhs_target), "l") if use_l else (None, False)
+        r, ex_r = operand(rhs_tuple, pick(rhs_target), "r") if use_r else (None, False)
         if (use_l and l is None) or (use_r and r is None):
-            outs.append(None)
             continue
-        outs.append(_gsddmm(gidx.get_relation_graph(et), op, l, r, lhs_target, rhs_target))
-    return tuple(outs)
+        _check_pair(l, r, use_l, use_r, "sddmm")
+        ref = l if use_l else r
+        o_feat = infer_broadcast_shape(op, tuple(l.shape[1:]) if use_l else (),
+                                       tuple(r.shape[1:]) if use_r else ())
+        outs[et] = torch.empty((gidx.num_edges(et),) + o_feat, dtype=ref.dtype, device=ref.device)
+        squeeze[et] = (ex_l or not use_l) and (ex_r or not use_r)
+        if fmts[-1] == "csc":
+            raise DGLAMDError("SDDMM only supports CSR and COO formats")
+        todo = todo or outs[et].numel() > 0
+    if todo:
+        n_l = len(lhs_tuple)
+        n_r = len(rhs_tuple)
+        lst = lambda side, n: [_nd(prep[(side, i)][0]) if (side, i) in prep else None for i in range(n)]
+        _ffi.use_current_stream(gidx.ctx)
+        _ffi.get_global_func("sparse._CAPI_DGLKernelSDDMMHetero")(
+            gidx.hetero_handle(fmts), op, lst("l", n_l), lst("r", n_r), [_nd(o) for o in outs],
+            _TARGET[lhs_target], _TARGET[rhs_target])
+    return tuple(None if o is None else (o.squeeze(-1) if sq else o) for o, sq in zip(outs, squeeze))

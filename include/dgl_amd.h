@@ -335,6 +335,11 @@ int DGLFuncGetGlobal(const char* name, DGLFunctionHandle* out);
 int DGLFuncCall(DGLFunctionHandle func, DGLValue* args, int* type_codes, int num_args,
                 DGLValue* ret_val, int* ret_type_code);
 int DGLFuncFree(DGLFunctionHandle func);
+/* include/dgl/runtime/c_object_api.h: DGLObjectFree — releases an object handle returned by a
+ * registry function: the List<Value> / Value boxes of the global functions `_List` / `_Value`
+ * (how the reference passes Python lists, python/dgl/_ffi/object_generic.py:27-59), the
+ * heterograph handle of dgl_amd._CAPI_HeteroGraphCreate, a unit-graph handle. */
+int DGLObjectFree(void* handle);
 /* c_runtime_api.h: DGLSetStream — the stream kernels of this thread are queued on. */
 int DGLSetStream(int device_type, int device_id, void* stream);
 int DGLGetStream(int device_type, int device_id, void** stream);

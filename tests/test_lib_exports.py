@@ -31,8 +31,13 @@ def test_registry_lists_reference_names():
     assert _lib.LIB.DGLFuncListGlobalNames(ctypes.byref(n), ctypes.byref(arr)) == 0
     names = {arr[i].decode() for i in range(n.value)}
     for want in ("sparse._CAPI_DGLKernelSpMM", "sparse._CAPI_DGLKernelSDDMM",
+                 "sparse._CAPI_DGLKernelSpMMHetero", "sparse._CAPI_DGLKernelSDDMMHetero",
                  "sparse._CAPI_DGLKernelEdge_softmax_forward",
-                 "sparse._CAPI_DGLKernelEdge_softmax_backward"):
+                 "sparse._CAPI_DGLKernelEdge_softmax_backward",
+                 "sparse._CAPI_DGLKernelSegmentReduce", "sparse._CAPI_DGLKernelScatterAdd",
+                 "sparse._CAPI_DGLKernelBwdSegmentCmp", "sparse._CAPI_DGLKernelSEGMENTMM",
+                 "sparse._CAPI_DGLKernelSEGMENTMMBackwardB", "sparse._CAPI_DGLKernelGATHERMM",
+                 "sparse._CAPI_DGLKernelGATHERMMSCATTER", "_List", "_Value"):
         assert want in names
     h = ctypes.c_void_p()
     assert _lib.LIB.DGLFuncGetGlobal(b"sparse._CAPI_DGLKernelSpMM", ctypes.byref(h)) == 0 and h.value
@@ -69,3 +74,26 @@ def test_cpu_tensor_is_refused():
 
     with pytest.raises(DGLAMDError, match="no CPU fallback|ROCm GPU"):
         _capi.make_csr(torch.zeros(3, dtype=torch.int32), torch.zeros(2, dtype=torch.int32), None, 2)
+
+
+def test_list_objects_and_handle_tags():
+    """`_List` / `_Value` box Python lists the way the reference's FFI does; handles carry a type
+    tag, so a wrong handle is an error message, not a crash."""
+    import pytest
+
+    from dgl_amd import _ffi, _lib
+
+    v = _ffi.get_global_func("_Value")(7)
+    lst = _ffi.get_global_func("_List")(v, None, 3)
+    assert v.handle and lst.handle
+    # a list where a heterograph handle is expected
+    f = _ffi.get_global_func("sparse._CAPI_DGLKernelSDDMMHetero")
+    with pytest.raises(_lib.DGLAMDError, match="heterograph handle"):
+        f(lst, "add", [], [], [], 0, 2)
+    # an int where a list is expected
+    with pytest.raises(_lib.DGLAMDError, match="expected a list"):
+        f(lst, "add", 1, [], [], 0, 2)
+    for h in (lst, v):
+        assert _lib.LIB.DGLObjectFree(ctypes.c_void_p(h.handle)) == 0
+    bogus = (ctypes.c_uint32 * 4)(123, 0, 0, 0)
+    assert _lib.LIB.DGLObjectFree(ctypes.cast(bogus, ctypes.c_void_p)) == -1
