@@ -48,6 +48,12 @@ def _call(name, rel, fmt, *args):
     return _ffi.get_global_func(name)(rel.handle(fmt), *args)
 
 
+def _call_hetero(name, gidx, fmts, *args):
+    """A registry function that takes the heterograph handle (the reference's HeteroGraphRef)."""
+    _ffi.use_current_stream(gidx.ctx)
+    return _ffi.get_global_func(name)(gidx.hetero_handle(fmts), *args)
+
+
 def _spmm_format(rel):
     # aten::SpMM: SelectFormat(0, CSC_CODE) — CSC (built on demand) unless the graph is
     # restricted to COO (src/array/kernel.cc:26-43)
@@ -269,10 +275,8 @@ def _gspmm_hetero(gidx, op, reduce_op, u_len, u_and_e_tuple):
         if fmts and any(f == "csr" for f in fmts):
             raise DGLAMDError("SpMM only supports CSC and COO formats")
         nd = lambda ts: [_nd(t) for t in ts]
-        _ffi.use_current_stream(gidx.ctx)
-        _ffi.get_global_func("sparse._CAPI_DGLKernelSpMMHetero")(
-            gidx.hetero_handle(fmts), op, reduce_op, nd(list_u), nd(list_e), nd(list_v),
-            nd(arg_u), nd(arg_e), nd(arg_u_nt), nd(arg_e_et))
+        _call_hetero("sparse._CAPI_DGLKernelSpMMHetero", gidx, fmts, op, reduce_op, nd(list_u),
+                     nd(list_e), nd(list_v), nd(arg_u), nd(arg_e), nd(arg_u_nt), nd(arg_e_et))
     for d in range(n_nt):
         if d in fused or list_v[d] is None:
             continue
@@ -386,8 +390,6 @@ def _gsddmm_hetero(gidx, op, lhs_len, lhs_target, rhs_target, lhs_and_rhs_tuple)
         n_l = len(lhs_tuple)
         n_r = len(rhs_tuple)
         lst = lambda side, n: [_nd(prep[(side, i)][0]) if (side, i) in prep else None for i in range(n)]
-        _ffi.use_current_stream(gidx.ctx)
-        _ffi.get_global_func("sparse._CAPI_DGLKernelSDDMMHetero")(
-            gidx.hetero_handle(fmts), op, lst("l", n_l), lst("r", n_r), [_nd(o) for o in outs],
-            _TARGET[lhs_target], _TARGET[rhs_target])
+        _call_hetero("sparse._CAPI_DGLKernelSDDMMHetero", gidx, fmts, op, lst("l", n_l), lst("r", n_r),
+                     [_nd(o) for o in outs], _TARGET[lhs_target], _TARGET[rhs_target])
     return tuple(None if o is None else (o.squeeze(-1) if sq else o) for o, sq in zip(outs, squeeze))

@@ -110,11 +110,19 @@ def test_hetero_update_all_uses_one_launch_and_matches_loop(dev, msg, monkeypatc
         calls.append(name)
         return real_call(name, *a)
 
+    real_hetero = sparse_kernels._call_hetero
+
+    def spy_hetero(name, *a):
+        calls.append(name)
+        return real_hetero(name, *a)
+
     monkeypatch.setattr(sparse_kernels, "_call", spy)
+    monkeypatch.setattr(sparse_kernels, "_call_hetero", spy_hetero)
     g.update_all(mfunc, fn.sum("m", "o"))
     fused = {nt: g.nodes[nt].data["o"].clone() for nt in ("user", "item")}
     assert calls.count("sparse._CAPI_DGLKernelSpMMStacked") == 1       # user: 3 relations, 1 launch
-    assert calls.count("sparse._CAPI_DGLKernelSpMM") == 1              # item: single relation
+    assert calls.count("sparse._CAPI_DGLKernelSpMMHetero") == 1        # item: the reference's loop
+    assert calls.count("sparse._CAPI_DGLKernelSpMM") == 0
     monkeypatch.setattr(sparse_kernels, "_FUSED_OPS", ())
     g.update_all(mfunc, fn.sum("m", "o"))
     for nt in fused:
