@@ -286,3 +286,18 @@ def gather_mm(a, b, c, idx_a=None, idx_b=None, idx_c=None):
     check_call(LIB.dgla_gather_mm(_idbits(ref), _DTYPES[a.dtype], a.data_ptr(), b.data_ptr(),
                                   c.data_ptr(), _ptr(idx_a), _ptr(idx_b), _ptr(idx_c), rows,
                                   a.shape[1], b.shape[-1], _stream(a)))
+
+
+def coo_to_csr(row, col, eids, num_rows):
+    """(indptr, indices, eids_out) of the CSR that compresses `row` (dgla_coo_to_csr): stable,
+    so COO order is kept inside every row; `eids_out[i]` = edge id of CSR position i."""
+    _require_gpu(row)
+    bits = _idbits(row)
+    nnz = row.shape[0]
+    indptr = torch.empty(num_rows + 1, dtype=row.dtype, device=row.device)
+    indices = torch.empty(nnz, dtype=row.dtype, device=row.device)
+    eids_out = torch.empty(nnz, dtype=row.dtype, device=row.device)
+    check_call(LIB.dgla_coo_to_csr(bits, int(num_rows), nnz, _ptr(row), _ptr(col), _ptr(eids),
+                                   indptr.data_ptr(), _ptr(indices), _ptr(eids_out), None, 0,
+                                   _stream(row)))
+    return indptr, indices, eids_out

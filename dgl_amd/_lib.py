@@ -108,6 +108,11 @@ LIB.dgla_segment_mm_backward_b.argtypes = [c_int, c_int, c_void_p, c_void_p, c_v
 LIB.dgla_gather_mm.restype = c_int
 LIB.dgla_gather_mm.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int64, c_int64, c_int64, c_void_p]
+LIB.dgla_coo_to_csr_workspace_bytes.restype = c_size_t
+LIB.dgla_coo_to_csr_workspace_bytes.argtypes = [c_int, c_int64, c_int64]
+LIB.dgla_coo_to_csr.restype = c_int
+LIB.dgla_coo_to_csr.argtypes = [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_size_t, c_void_p]
 LIB.dgla_partition_kway.restype = c_int
 LIB.dgla_partition_kway.argtypes = [c_int, c_int64, c_void_p, c_void_p, c_int, ctypes.c_double, c_int,
                                     ctypes.c_uint64, c_void_p, c_void_p]

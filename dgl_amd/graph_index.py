@@ -68,6 +68,12 @@ class Relation:
     def _compress(self, major, minor, eids, n_major):
         # stable sort by the major index keeps edge-id order inside each row, which fixes the
         # CSR position order (and therefore arg-max/min tie-breaking) deterministically
+        if major.is_cuda:
+            # native path: one radix sort + one fused gather / indptr kernel (csrc/coo2csr.hip
+            # ≙ aten::COOToCSR<kDGLCUDA>, src/array/cuda/coo2csr.cu:28-110)
+            from . import _capi
+            return _capi.coo_to_csr(major.contiguous(), minor.contiguous(),
+                                    None if eids is None else eids.contiguous(), n_major)
         order = torch.argsort(major, stable=True)
         counts = torch.bincount(major.long(), minlength=n_major)
         indptr = torch.zeros(n_major + 1, dtype=self.idtype, device=self.device)

@@ -221,6 +221,21 @@ int dgla_gather_mm(int idtype_bits, dgla_dtype dtype, const void* a, const void*
                    const void* idx_a, const void* idx_b, const void* idx_c, int64_t num_rows,
                    int64_t k, int64_t n, void* hip_stream);
 
+/* ---- COO -> CSR / CSC materialisation -----------------------------------
+ * Replaces aten::COOToCSR<kDGLCUDA> (src/array/cuda/coo2csr.cu:28-110 = COOSort by row +
+ * cusparseXcoo2csr), which UnitGraph::GetInCSR / GetOutCSR run on first use
+ * (src/graph/unit_graph.cc:1418-1450).  Stable: edges keep their COO order inside a row.
+ *   row / col   [nnz] of idtype_bits: the major index (compressed) and the minor one; pass
+ *               (dst, src) for the in-edge CSR ("CSC"), (src, dst) for the out-edge CSR
+ *   eids        optional [nnz] edge ids of the COO entries (NULL: position)
+ *   indptr      out [num_rows + 1];  indices, eids_out: out [nnz] — eids_out[i] is the edge id
+ *               of CSR position i (the reference's csr.data)
+ * `workspace` may be NULL (stream-ordered scratch for the duration of the call). */
+size_t dgla_coo_to_csr_workspace_bytes(int idtype_bits, int64_t num_rows, int64_t nnz);
+int dgla_coo_to_csr(int idtype_bits, int64_t num_rows, int64_t nnz, const void* row, const void* col,
+                    const void* eids, void* indptr, void* indices, void* eids_out, void* workspace,
+                    size_t workspace_bytes, void* hip_stream);
+
 /* ---- k-way node-cut partitioner (host code) ---------------------------------
  * Stands where METIS stands in the reference: metis_partition_assignment
  * (python/dgl/partition.py:278-397 -> _CAPI_DGLMetisPartition_Hetero).  Multilevel
