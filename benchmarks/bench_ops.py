@@ -289,6 +289,55 @@ def mm(dev, args):
     emit("MM", "per-relation torch.mm loop, 512 relations, bf16", rows, ms, mn, nb, tflops=flops / (ms * 1e-3) / 1e12)
 
 
+def sample(dev, args):
+    """Mini-batch path of config 4 on the C2-shaped graph: uniform neighbour
+    sampling, block construction and the block SpMM, for the usual 1 024-seed batch with
+    fanouts (15, 10) and for a 256 k-seed layer.  Algorithmic bytes of the sampler: per seed
+    2 indptr entries + per pick one column id, one edge id (read) and two ids written."""
+    import dgl_amd as dgl
+    import dgl_amd.function as fn
+
+    n, e = C2_NODES // args.scale, C2_EDGES // args.scale
+    gs = synth_csr(n, n, e, "U", device=dev, idtype=torch.int64)
+    csr = _capi.make_csr(gs["indptr"], gs["indices"], None, n)
+    torch.manual_seed(0)
+    i = 8
+    for n_seeds, fanout in ((1024, 10), (262144, 15)):
+        seeds = torch.randperm(n, device=dev)[:n_seeds].contiguous()
+        ms, mn = timeit(lambda: _capi.sample_neighbors(csr, seeds, fanout, False, 1), reps=10, warm=3)
+        indptr, src, eids = _capi.sample_neighbors(csr, seeds, fanout, False, 1)
+        picks = int(indptr[-1])
+        emit("SAMPLE", "sample_neighbors %d seeds, fanout %d (%d picks; includes output allocation)" % (n_seeds, fanout, picks),
+             picks, ms, mn, n_seeds * 3 * i + picks * 4 * i)
+        node_map = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        ms, mn = timeit(lambda: _capi.to_block(seeds, src[:picks], node_map), reps=10, warm=3)
+        emit("SAMPLE", "to_block %d seeds + %d sampled sources (sort + renumber + 1 read-back)" % (n_seeds, picks), picks,
+             ms, mn, picks * 4 * i)
+    # whole 2-layer sample_blocks + SAGE-mean forward on the blocks, F = 100
+    rel_g = dgl.graph((gs["indices"], torch.repeat_interleave(torch.arange(n, device=dev), (gs["indptr"][1:] - gs["indptr"][:-1]))),
+                      num_nodes=n, device=dev)
+    rel_g._graph.relations[0]._csc = (gs["indptr"], gs["indices"], None)
+    sampler = dgl.NeighborSampler([15, 10], seed=1)
+    feat = torch.rand(n, 100, device=dev)
+    seeds = torch.randperm(n, device=dev)[:1024].contiguous()
+
+    def step():
+        inp, out, blocks = sampler.sample_blocks(rel_g, seeds)
+        h = feat[inp]
+        for blk in blocks:
+            with blk.local_scope():
+                blk.srcdata["h"] = h
+                blk.update_all(fn.copy_u("h", "m"), fn.mean("m", "n"))
+                h = blk.dstdata["n"]
+        return h
+
+    ms, mn = timeit(step, reps=10, warm=3)
+    inp, _, blocks = sampler.sample_blocks(rel_g, seeds)
+    tot = sum(b.num_edges() for b in blocks)
+    emit("SAMPLE", "1024-seed batch end to end: sample_blocks(15,10) + feature gather (%d rows) + 2 x copy_u/mean, F=100"
+         % inp.shape[0], tot, ms, mn, inp.shape[0] * 400 * 2 + tot * 408)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -297,7 +346,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("SEG", seg), ("MM", mm)):
+    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("SEG", seg), ("MM", mm), ("SAMPLE", sample)):
         if args.only and name not in args.only.split(","):
             continue
         fn(dev, args)

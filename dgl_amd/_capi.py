@@ -301,3 +301,40 @@ def coo_to_csr(row, col, eids, num_rows):
                                    indptr.data_ptr(), _ptr(indices), _ptr(eids_out), None, 0,
                                    _stream(row)))
     return indptr, indices, eids_out
+
+
+def sample_neighbors(csr, seeds, fanout, replace=False, rng_seed=0):
+    """Uniform in-neighbour sampling over the in-edge CSR `csr` (dgla_sample_neighbors):
+    returns ``(indptr, src, eids)`` — a CSR over the seeds with GLOBAL source / edge ids."""
+    _require_gpu(seeds)
+    n = seeds.shape[0]
+    dev, dt = seeds.device, seeds.dtype
+    indptr = torch.empty(n + 1, dtype=dt, device=dev)
+    st = _stream(seeds)
+    if fanout < 0:  # all neighbours: sizes first
+        check_call(LIB.dgla_sample_neighbors(ctypes.byref(csr), seeds.data_ptr(), n, fanout, 0, rng_seed,
+                                             indptr.data_ptr(), None, None, None, 0, st))
+        cap = int(indptr[-1])
+    else:
+        cap = n * fanout
+    src = torch.empty(cap, dtype=dt, device=dev)
+    eids = torch.empty(cap, dtype=dt, device=dev)
+    check_call(LIB.dgla_sample_neighbors(ctypes.byref(csr), seeds.data_ptr(), n, fanout, 1 if replace else 0,
+                                         rng_seed, indptr.data_ptr(), _ptr(src), _ptr(eids), None, 0, st))
+    return indptr, src, eids
+
+
+def to_block(seeds, src, node_map):
+    """Block-local renumbering of `src` (dgla_to_block).  Returns ``(local_src, src_nodes,
+    num_src)``; reading ``num_src`` back is the one host synchronisation of block building
+    (the reference synchronises at the same place, cuda_to_block.cu)."""
+    _require_gpu(src)
+    n, nnz = seeds.shape[0], src.shape[0]
+    dev, dt = seeds.device, seeds.dtype
+    local = torch.empty(nnz, dtype=dt, device=dev)
+    src_nodes = torch.empty(n + nnz, dtype=dt, device=dev)
+    num = torch.empty(1, dtype=torch.int64, device=dev)
+    check_call(LIB.dgla_to_block(_idbits(seeds), seeds.data_ptr(), n, _ptr(src), nnz, node_map.data_ptr(),
+                                 _ptr(local), src_nodes.data_ptr(), num.data_ptr(), None, 0, _stream(seeds)))
+    k = int(num.item())
+    return local, src_nodes[:k], k

@@ -1,0 +1,337 @@
+// Uniform neighbour sampling and block construction on the device: the two
+// steps in front of the g-SpMM in mini-batch GraphSAGE (BASELINE config 4).
+//
+// Reference: CSRRowWiseSamplingUniform<kDGLCUDA> (src/array/cuda/rowwise_sampling.cu:43-330:
+// degree kernel + prefix sum + one warp per row, reservoir "algorithm R" with atomics in the
+// without-replacement case) behind dgl.sampling.sample_neighbors
+// (python/dgl/sampling/neighbor.py:222-395), and ToBlock<kDGLCUDA>
+// (src/graph/transform/cuda/cuda_to_block.cu + cuda_map_edges.cuh: an ordered device hash table
+// that renumbers the source nodes) behind dgl.to_block.
+//
+// MI355X-first choices:
+//  * Sampling without replacement is Floyd's subset algorithm run by ONE LANE per seed row:
+//    exactly `fanout` distinct positions in O(fanout) draws, no atomics, no retries, and the
+//    same picks whatever the launch geometry (counter-based generator keyed by (seed, row,
+//    draw)) — a run is reproducible from its seed, which the reference's per-block Philox
+//    streams are not across geometries.  64 independent rows per wavefront keep the lanes busy
+//    for fanouts of 5-25; the gathers of the picked neighbours are the only memory traffic.
+//  * Renumbering uses a dense node -> local id map instead of a hash table: with 288 GB of HBM
+//    a 4-byte entry per node is affordable even for papers100M (444 MB) and turns every
+//    lookup into one load.  The map lives in caller-owned scratch, is all -1 between calls and
+//    is cleaned by touching only the entries the call used.  Local ids are deterministic:
+//    seeds first in the given order (the block's destination nodes are its first source
+//    nodes, dgl.to_block's include_dst_in_src), then the other sampled nodes by ascending id.
+#include "../../include/dgl_amd.h"
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "common.h"
+
+namespace dgla {
+namespace {
+
+int sfail(const std::string& m) {
+  last_error() = m;
+  return -1;
+}
+
+constexpr int kMaxFanout = 128;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// uniform integer in [0, n) from the (seed, row, draw) counter: multiply-high reduction
+__device__ __forceinline__ uint64_t draw(uint64_t seed, uint64_t row, uint32_t k, uint64_t n) {
+  const uint64_t r = mix64(mix64(seed ^ (row * 0xD1B54A32D192ED03ull)) + k);
+  return __umul64hi(r, n);
+}
+
+template <typename Idx>
+__global__ __launch_bounds__(256) void sample_count_kernel(const Idx* __restrict__ indptr,
+                                                           const Idx* __restrict__ seeds,
+                                                           int64_t num_seeds, int fanout, int replace,
+                                                           Idx* __restrict__ counts) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i > num_seeds) return;
+  if (i == num_seeds) {
+    counts[i] = 0;  // so that an exclusive scan over num_seeds + 1 entries ends with the total
+    return;
+  }
+  const int64_t r = static_cast<int64_t>(seeds[i]);
+  const int64_t deg = static_cast<int64_t>(indptr[r + 1]) - static_cast<int64_t>(indptr[r]);
+  int64_t c = deg < fanout ? deg : fanout;
+  if (replace) c = deg == 0 ? 0 : fanout;
+  if (fanout < 0) c = deg;  // fanout = -1: all neighbours (neighbor.py:259-261)
+  counts[i] = static_cast<Idx>(c);
+}
+
+template <typename Idx>
+__global__ __launch_bounds__(256) void sample_pick_kernel(const Idx* __restrict__ indptr,
+                                                          const Idx* __restrict__ indices,
+                                                          const Idx* __restrict__ eids,
+                                                          const Idx* __restrict__ seeds,
+                                                          int64_t num_seeds, int fanout, int replace,
+                                                          uint64_t rng_seed,
+                                                          const Idx* __restrict__ out_indptr,
+                                                          Idx* __restrict__ out_src,
+                                                          Idx* __restrict__ out_eids) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= num_seeds) return;
+  const int64_t r = static_cast<int64_t>(seeds[i]);
+  const int64_t start = static_cast<int64_t>(indptr[r]);
+  const int64_t deg = static_cast<int64_t>(indptr[r + 1]) - start;
+  const int64_t o = static_cast<int64_t>(out_indptr[i]);
+  auto emit = [&](int64_t slot, int64_t pos) {
+    out_src[o + slot] = indices[start + pos];
+    out_eids[o + slot] = eids ? eids[start + pos] : static_cast<Idx>(start + pos);
+  };
+  if (fanout < 0 || (!replace && deg <= fanout)) {  // the whole neighbourhood, in CSR order
+    for (int64_t k = 0; k < deg; ++k) emit(k, k);
+    return;
+  }
+  if (deg == 0) return;
+  if (replace) {
+    for (int k = 0; k < fanout; ++k) emit(k, static_cast<int64_t>(draw(rng_seed, r, k, deg)));
+    return;
+  }
+  // Floyd: for j = deg - fanout .. deg - 1: t = U[0, j]; take t unless already taken, else j
+  int64_t chosen[kMaxFanout];
+  int n = 0;
+  for (int64_t j = deg - fanout; j < deg; ++j) {
+    int64_t t = static_cast<int64_t>(draw(rng_seed, r, static_cast<uint32_t>(n), j + 1));
+    bool dup = false;
+    for (int q = 0; q < n; ++q) dup = dup || chosen[q] == t;
+    if (dup) t = j;
+    chosen[n] = t;
+    emit(n, t);
+    ++n;
+  }
+}
+
+// ---- to_block -------------------------------------------------------------------------------
+template <typename Idx>
+__global__ __launch_bounds__(256) void scatter_seed_ids_kernel(const Idx* __restrict__ seeds,
+                                                               int64_t num_seeds,
+                                                               int32_t* __restrict__ node_map,
+                                                               Idx* __restrict__ src_nodes) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= num_seeds) return;
+  node_map[seeds[i]] = static_cast<int32_t>(i);
+  src_nodes[i] = seeds[i];
+}
+
+// flag[i] = sorted[i] starts a run of a node that is not a seed (gets a fresh local id)
+template <typename Idx>
+__global__ __launch_bounds__(256) void flag_new_nodes_kernel(const Idx* __restrict__ sorted, int64_t n,
+                                                             const int32_t* __restrict__ node_map,
+                                                             int32_t* __restrict__ flag) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i > n) return;
+  if (i == n) {
+    flag[i] = 0;
+    return;
+  }
+  const bool first = i == 0 || sorted[i] != sorted[i - 1];
+  flag[i] = (first && node_map[sorted[i]] < 0) ? 1 : 0;
+}
+
+template <typename Idx>
+__global__ __launch_bounds__(256) void assign_new_ids_kernel(const Idx* __restrict__ sorted, int64_t n,
+                                                             const int32_t* __restrict__ flag,
+                                                             const int32_t* __restrict__ rank,
+                                                             int64_t num_seeds,
+                                                             int32_t* __restrict__ node_map,
+                                                             Idx* __restrict__ src_nodes,
+                                                             int64_t* __restrict__ num_src_out) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i > n) return;
+  if (i == n) {
+    *num_src_out = num_seeds + rank[n];  // rank is the exclusive scan: rank[n] = number of new nodes
+    return;
+  }
+  if (flag[i]) {
+    const int64_t id = num_seeds + rank[i];
+    node_map[sorted[i]] = static_cast<int32_t>(id);
+    src_nodes[id] = sorted[i];
+  }
+}
+
+template <typename Idx>
+__global__ __launch_bounds__(256) void relabel_kernel(const Idx* __restrict__ src, int64_t n,
+                                                      const int32_t* __restrict__ node_map,
+                                                      Idx* __restrict__ local_src) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) local_src[i] = static_cast<Idx>(node_map[src[i]]);
+}
+
+// put the map back to all -1: only the entries of this block's source nodes were touched
+template <typename Idx>
+__global__ __launch_bounds__(256) void reset_map_kernel(const Idx* __restrict__ src_nodes,
+                                                        const int64_t* __restrict__ num_src,
+                                                        int64_t capacity, int32_t* __restrict__ node_map) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < capacity && i < *num_src) node_map[src_nodes[i]] = -1;
+}
+
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+unsigned grid1(int64_t n) { return static_cast<unsigned>((n + 255) / 256 < 1 ? 1 : (n + 255) / 256); }
+
+template <typename Idx>
+size_t scan_temp_bytes(int64_t n) {
+  size_t b = 0;
+  (void)rocprim::exclusive_scan(nullptr, b, static_cast<const Idx*>(nullptr), static_cast<Idx*>(nullptr),
+                                Idx(0), static_cast<size_t>(n), rocprim::plus<Idx>(), nullptr);
+  return b;
+}
+
+template <typename Idx>
+size_t sort_keys_temp_bytes(int64_t n) {
+  size_t b = 0;
+  (void)rocprim::radix_sort_keys(nullptr, b, static_cast<const Idx*>(nullptr), static_cast<Idx*>(nullptr),
+                                 static_cast<size_t>(n), 0, sizeof(Idx) * 8, nullptr);
+  return b;
+}
+
+template <typename Idx>
+int run_sample(const dgla_csr* csc, const void* seeds, int64_t num_seeds, int fanout, int replace,
+               uint64_t rng_seed, void* out_indptr, void* out_src, void* out_eids, char* ws, hipStream_t s) {
+  // counts -> exclusive scan in place of out_indptr (num_seeds + 1 entries)
+  Idx* counts = reinterpret_cast<Idx*>(ws);
+  void* temp = ws + align256(sizeof(Idx) * (num_seeds + 1));
+  size_t temp_bytes = scan_temp_bytes<Idx>(num_seeds + 1);
+  hipLaunchKernelGGL(sample_count_kernel<Idx>, dim3(grid1(num_seeds + 1)), dim3(256), 0, s,
+                     static_cast<const Idx*>(csc->indptr), static_cast<const Idx*>(seeds), num_seeds,
+                     fanout, replace, counts);
+  DGLA_CHECK_HIP(rocprim::exclusive_scan(temp, temp_bytes, static_cast<const Idx*>(counts),
+                                         static_cast<Idx*>(out_indptr), Idx(0),
+                                         static_cast<size_t>(num_seeds + 1), rocprim::plus<Idx>(), s));
+  if (out_src)
+    hipLaunchKernelGGL(sample_pick_kernel<Idx>, dim3(grid1(num_seeds)), dim3(256), 0, s,
+                       static_cast<const Idx*>(csc->indptr), static_cast<const Idx*>(csc->indices),
+                       static_cast<const Idx*>(csc->data), static_cast<const Idx*>(seeds), num_seeds, fanout,
+                       replace, rng_seed, static_cast<const Idx*>(out_indptr), static_cast<Idx*>(out_src),
+                       static_cast<Idx*>(out_eids));
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename Idx>
+int run_to_block(const void* seeds, int64_t num_seeds, const void* src, int64_t nnz, int32_t* node_map,
+                 void* local_src, void* src_nodes, int64_t* num_src_out, char* ws, hipStream_t s) {
+  const size_t a_sorted = align256(sizeof(Idx) * (nnz + 1));
+  const size_t a_flag = align256(sizeof(int32_t) * (nnz + 1));
+  Idx* sorted = reinterpret_cast<Idx*>(ws);
+  int32_t* flag = reinterpret_cast<int32_t*>(ws + a_sorted);
+  int32_t* rank = reinterpret_cast<int32_t*>(ws + a_sorted + a_flag);
+  void* temp = ws + a_sorted + 2 * a_flag;
+  hipLaunchKernelGGL(scatter_seed_ids_kernel<Idx>, dim3(grid1(num_seeds)), dim3(256), 0, s,
+                     static_cast<const Idx*>(seeds), num_seeds, node_map, static_cast<Idx*>(src_nodes));
+  if (nnz > 0) {
+    size_t tb = sort_keys_temp_bytes<Idx>(nnz);
+    DGLA_CHECK_HIP(rocprim::radix_sort_keys(temp, tb, static_cast<const Idx*>(src), sorted,
+                                            static_cast<size_t>(nnz), 0, sizeof(Idx) * 8, s));
+  }
+  hipLaunchKernelGGL(flag_new_nodes_kernel<Idx>, dim3(grid1(nnz + 1)), dim3(256), 0, s, sorted, nnz, node_map,
+                     flag);
+  size_t tb2 = 0;
+  (void)rocprim::exclusive_scan(nullptr, tb2, static_cast<const int32_t*>(flag), rank, int32_t(0),
+                                static_cast<size_t>(nnz + 1), rocprim::plus<int32_t>(), s);
+  DGLA_CHECK_HIP(rocprim::exclusive_scan(temp, tb2, static_cast<const int32_t*>(flag), rank, int32_t(0),
+                                         static_cast<size_t>(nnz + 1), rocprim::plus<int32_t>(), s));
+  hipLaunchKernelGGL(assign_new_ids_kernel<Idx>, dim3(grid1(nnz + 1)), dim3(256), 0, s, sorted, nnz, flag, rank,
+                     num_seeds, node_map, static_cast<Idx*>(src_nodes), num_src_out);
+  if (nnz > 0)
+    hipLaunchKernelGGL(relabel_kernel<Idx>, dim3(grid1(nnz)), dim3(256), 0, s, static_cast<const Idx*>(src), nnz,
+                       node_map, static_cast<Idx*>(local_src));
+  hipLaunchKernelGGL(reset_map_kernel<Idx>, dim3(grid1(num_seeds + nnz)), dim3(256), 0, s,
+                     static_cast<const Idx*>(src_nodes), num_src_out, num_seeds + nnz, node_map);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename Idx>
+size_t to_block_ws(int64_t nnz) {
+  size_t scan_b = 0;
+  (void)rocprim::exclusive_scan(nullptr, scan_b, static_cast<const int32_t*>(nullptr),
+                                static_cast<int32_t*>(nullptr), int32_t(0), static_cast<size_t>(nnz + 1),
+                                rocprim::plus<int32_t>(), nullptr);
+  const size_t sort_b = nnz > 0 ? sort_keys_temp_bytes<Idx>(nnz) : 0;
+  return align256(sizeof(Idx) * (nnz + 1)) + 2 * align256(sizeof(int32_t) * (nnz + 1)) +
+         align256(scan_b > sort_b ? scan_b : sort_b);
+}
+
+}  // namespace
+}  // namespace dgla
+
+using namespace dgla;
+
+extern "C" {
+
+size_t dgla_sample_neighbors_workspace_bytes(int idtype_bits, int64_t num_seeds) {
+  const size_t ib = idtype_bits / 8;
+  const size_t scan = idtype_bits == 32 ? scan_temp_bytes<int32_t>(num_seeds + 1)
+                                        : scan_temp_bytes<int64_t>(num_seeds + 1);
+  return align256(ib * (num_seeds + 1)) + align256(scan);
+}
+
+int dgla_sample_neighbors(const dgla_csr* csc, const void* seeds, int64_t num_seeds, int fanout,
+                          int replace, uint64_t rng_seed, void* out_indptr, void* out_src,
+                          void* out_eids, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!csc || !csc->indptr) return sfail("csc is null");
+  if (csc->idtype_bits != 32 && csc->idtype_bits != 64) return sfail("idtype must be int32 or int64");
+  if (num_seeds < 0) return sfail("negative number of seeds");
+  if (fanout > kMaxFanout) return sfail("fanout larger than " + std::to_string(kMaxFanout) + " is not supported");
+  if (fanout == 0 || fanout < -1) return sfail("fanout must be positive, or -1 for all neighbours");
+  if (!out_indptr) return sfail("out_indptr is null");
+  if (num_seeds > 0 && !seeds) return sfail("seeds is null");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const size_t need = dgla_sample_neighbors_workspace_bytes(csc->idtype_bits, num_seeds);
+  void* owned = nullptr;
+  if (!workspace || workspace_bytes < need) {
+    DGLA_CHECK_HIP(hipMallocAsync(&owned, need, s));
+    workspace = owned;
+  }
+  const int rc = csc->idtype_bits == 32
+                     ? run_sample<int32_t>(csc, seeds, num_seeds, fanout, replace, rng_seed, out_indptr,
+                                           out_src, out_eids, static_cast<char*>(workspace), s)
+                     : run_sample<int64_t>(csc, seeds, num_seeds, fanout, replace, rng_seed, out_indptr,
+                                           out_src, out_eids, static_cast<char*>(workspace), s);
+  if (owned) (void)hipFreeAsync(owned, s);
+  return rc;
+}
+
+size_t dgla_to_block_workspace_bytes(int idtype_bits, int64_t nnz) {
+  return idtype_bits == 32 ? to_block_ws<int32_t>(nnz) : to_block_ws<int64_t>(nnz);
+}
+
+int dgla_to_block(int idtype_bits, const void* seeds, int64_t num_seeds, const void* src, int64_t nnz,
+                  void* node_map, void* local_src, void* src_nodes, int64_t* num_src_out,
+                  void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (idtype_bits != 32 && idtype_bits != 64) return sfail("idtype must be int32 or int64");
+  if (num_seeds < 0 || nnz < 0) return sfail("negative size");
+  if (!node_map || !src_nodes || !num_src_out) return sfail("node_map / src_nodes / num_src_out is null");
+  if ((num_seeds > 0 && !seeds) || (nnz > 0 && (!src || !local_src))) return sfail("input arrays are null");
+  if (num_seeds + nnz > 0x7fffffffLL) return sfail("a block with more than 2^31-1 source nodes is not supported");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const size_t need = dgla_to_block_workspace_bytes(idtype_bits, nnz);
+  void* owned = nullptr;
+  if (!workspace || workspace_bytes < need) {
+    DGLA_CHECK_HIP(hipMallocAsync(&owned, need, s));
+    workspace = owned;
+  }
+  const int rc = idtype_bits == 32
+                     ? run_to_block<int32_t>(seeds, num_seeds, src, nnz, static_cast<int32_t*>(node_map), local_src,
+                                             src_nodes, num_src_out, static_cast<char*>(workspace), s)
+                     : run_to_block<int64_t>(seeds, num_seeds, src, nnz, static_cast<int32_t*>(node_map), local_src,
+                                             src_nodes, num_src_out, static_cast<char*>(workspace), s);
+  if (owned) (void)hipFreeAsync(owned, s);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+"""Uniform neighbour sampling and message-flow blocks for mini-batch training.
+
+Mirror of ``dgl.sampling.sample_neighbors`` (python/dgl/sampling/neighbor.py:222-395, uniform /
+single relation / edge_dir='in'), ``dgl.to_block`` (python/dgl/transforms/functional.py) and
+``dgl.dataloading.NeighborSampler.sample_blocks`` (python/dgl/dataloading/neighbor_sampler.py):
+the steps that run in front of the g-SpMM for every mini-batch of GraphSAGE (BASELINE config 4).
+The kernels are in csrc/sampling.hip; the blocks come out with their in-edge CSR already
+built (rows = seeds), i.e. in the format the SpMM consumes — no COO round trip.
+"""
+import torch
+
+from . import _capi
+from .graph_index import GraphIndex, Relation
+from .heterograph import DGLGraph
+
+NID = "_ID"   # dgl.NID / dgl.EID
+EID = "_ID"
+
+
+def _csc_of(g):
+    rel = g._graph.relations[0]
+    indptr, indices, eids = rel.csc()
+    return rel, _capi.make_csr(indptr, indices, eids, rel.num_src), (indptr, indices, eids)
+
+
+def _node_map(g, device):
+    """Per-graph dense node -> local-id scratch (int32, all -1 between calls)."""
+    m = getattr(g, "_sampling_node_map", None)
+    if m is None or m.device != device:
+        m = torch.full((g.num_nodes(),), -1, dtype=torch.int32, device=device)
+        g._sampling_node_map = m
+    return m
+
+
+def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, seed=0):
+    """Frontier graph on the nodes of `g` holding, for every node in `nodes`, ``fanout`` of its
+    inbound edges picked uniformly (all of them when it has fewer, or ``fanout == -1``).
+    ``edata[dgl.EID]`` carries the original edge ids."""
+    if edge_dir != "in" or prob is not None:
+        raise NotImplementedError("dgl_amd.sampling: uniform sampling of inbound edges only")
+    if len(g.canonical_etypes) != 1:
+        raise NotImplementedError("dgl_amd.sampling: single-relation graphs only")
+    rel, csr, keep = _csc_of(g)
+    nodes = nodes.to(device=rel.device, dtype=rel.idtype).contiguous()
+    indptr, src, eids = _capi.sample_neighbors(csr, nodes, int(fanout), replace, int(seed))
+    n_e = int(indptr[-1])
+    dst = torch.repeat_interleave(nodes, (indptr[1:] - indptr[:-1]).long())
+    r = Relation(rel.num_src, rel.num_dst, src[:n_e].contiguous(), dst, idtype=rel.idtype, device=rel.device)
+    out = DGLGraph(GraphIndex([g.num_nodes()], [(0, 0)], [r]), ["_N"], [("_N", "_E", "_N")])
+    out.edata[EID] = eids[:n_e]
+    return out
+
+
+def _make_block(indptr, local_src, num_src, num_dst, idtype, device):
+    rel = Relation(num_src, num_dst, csc=(indptr, local_src, None), idtype=idtype, device=device)
+    blk = DGLGraph(GraphIndex([num_src, num_dst], [(0, 1)], [rel]), ["_N", "_N"], [("_N", "_E", "_N")],
+                   src_ntypes=[0], dst_ntypes=[1])
+    blk.is_block = True
+    return blk
+
+
+class NeighborSampler:
+    """``NeighborSampler([15, 10])``: one block per layer, built from the output nodes inwards
+    (neighbor_sampler.py: sample_blocks).  ``sample_blocks(g, seed_nodes)`` returns
+    ``(input_nodes, output_nodes, blocks)``; ``blocks[i].srcdata[dgl.NID]`` /
+    ``dstdata[dgl.NID]`` / ``edata[dgl.EID]`` hold the original ids."""
+
+    def __init__(self, fanouts, replace=False, seed=0):
+        self.fanouts = [int(f) for f in fanouts]
+        self.replace = bool(replace)
+        self.seed = int(seed)
+        self._calls = 0
+
+    def sample_blocks(self, g, seed_nodes):
+        rel, csr, keep = _csc_of(g)
+        dev, idt = rel.device, rel.idtype
+        node_map = _node_map(g, dev)
+        seeds = seed_nodes.to(device=dev, dtype=idt).contiguous()
+        output_nodes = seeds
+        blocks = []
+        for layer, fanout in enumerate(reversed(self.fanouts)):
+            rng = (self.seed * 1000003 + self._calls) * 64 + layer
+            indptr, src, eids = _capi.sample_neighbors(csr, seeds, fanout, self.replace, rng)
+            n_e = int(indptr[-1])   # one read-back per layer (sizes the block)
+            local, src_nodes, num_src = _capi.to_block(seeds, src[:n_e], node_map)
+            blk = _make_block(indptr, local, num_src, seeds.shape[0], idt, dev)
+            blk.srcdata[NID] = src_nodes
+            blk.dstdata[NID] = seeds
+            blk.edata[EID] = eids[:n_e]
+            blocks.insert(0, blk)
+            seeds = src_nodes
+        self._calls += 1
+        return seeds, output_nodes, blocks

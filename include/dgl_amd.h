@@ -236,6 +236,31 @@ int dgla_coo_to_csr(int idtype_bits, int64_t num_rows, int64_t nnz, const void* 
                     const void* eids, void* indptr, void* indices, void* eids_out, void* workspace,
                     size_t workspace_bytes, void* hip_stream);
 
+/* ---- uniform neighbour sampling and block construction -------------------
+ * Replace CSRRowWiseSamplingUniform<kDGLCUDA> (src/array/cuda/rowwise_sampling.cu:43-330, behind
+ * dgl.sampling.sample_neighbors) and ToBlock<kDGLCUDA> (src/graph/transform/cuda/cuda_to_block.cu,
+ * behind dgl.to_block) for the uniform, single-relation case of mini-batch GraphSAGE.
+ *
+ * dgla_sample_neighbors: for every seed (a row of the in-edge CSR `csc`) picks min(deg, fanout)
+ *   in-neighbours uniformly without replacement (fanout with replacement when `replace`;
+ *   fanout = -1: all).  Output is itself a CSR over the seeds: out_indptr [num_seeds + 1],
+ *   out_src (GLOBAL source ids) and out_eids (edge ids) of out_indptr[num_seeds] entries —
+ *   allocate num_seeds * fanout (or call once with out_src == NULL to get out_indptr only, for
+ *   fanout = -1).  The picks depend only on (rng_seed, seed node): reproducible.
+ * dgla_to_block: renumbers `src` (global ids, nnz entries) into block-local ids with the seeds
+ *   first in the given order and the remaining nodes by ascending id.  `node_map` is caller-owned
+ *   int32 scratch with one entry per node of the graph, all -1 on entry and again on exit;
+ *   src_nodes [>= num_seeds + nnz] receives the global id of every local source node,
+ *   *num_src_out (device memory) their number. */
+size_t dgla_sample_neighbors_workspace_bytes(int idtype_bits, int64_t num_seeds);
+int dgla_sample_neighbors(const dgla_csr* csc, const void* seeds, int64_t num_seeds, int fanout,
+                          int replace, uint64_t rng_seed, void* out_indptr, void* out_src,
+                          void* out_eids, void* workspace, size_t workspace_bytes, void* hip_stream);
+size_t dgla_to_block_workspace_bytes(int idtype_bits, int64_t nnz);
+int dgla_to_block(int idtype_bits, const void* seeds, int64_t num_seeds, const void* src, int64_t nnz,
+                  void* node_map, void* local_src, void* src_nodes, int64_t* num_src_out,
+                  void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* ---- k-way node-cut partitioner (host code) ---------------------------------
  * Stands where METIS stands in the reference: metis_partition_assignment
  * (python/dgl/partition.py:278-397 -> _CAPI_DGLMetisPartition_Hetero).  Multilevel

@@ -1,0 +1,152 @@
+"""Uniform neighbour sampling + block construction.
+
+Random picks cannot be bit-compared with the reference's Philox streams; what the reference's
+own tests check are the properties below (tests/python/common/sampling/test_sampling.py:
+_test_sample_neighbors — picked edges are edges of the graph, per-node counts, no repetition
+without replacement; tests/python/common/transforms/test_to_block.py — dst nodes first, induced
+ids map back) — checked here exactly (integer work), plus reproducibility from the seed, a
+chi-square test of uniformity, and end-to-end equality of a 2-layer mean-SAGE forward on the
+sampled blocks with a dense evaluation over the same sampled edges."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(dev, idtype, n=3000, e=60000, seed=0):
+    import dgl_amd as dgl
+
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, e)
+    dst = np.minimum((rng.random(e) ** 3 * n).astype(np.int64), n - 1)   # skewed in-degrees, some 0
+    g = dgl.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n, idtype=idtype, device=dev)
+    return g, src, dst
+
+
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("fanout,replace", [(5, False), (15, False), (1, False), (128, False), (10, True), (-1, False)])
+def test_sample_neighbors_properties(dev, idtype, fanout, replace):
+    from dgl_amd import _capi
+    from dgl_amd.sampling import _csc_of
+
+    g, src, dst = _graph(dev, idtype)
+    rel, csr, (ip, ix, ei) = _csc_of(g)
+    seeds = torch.from_numpy(np.random.default_rng(1).permutation(3000)[:700]).to(dev).to(idtype)
+    indptr, s, e = _capi.sample_neighbors(csr, seeds, fanout, replace, 42)
+    indptr_h, s_h, e_h = indptr.cpu().numpy(), s.cpu().numpy(), e.cpu().numpy()
+    indeg = np.bincount(dst, minlength=3000)
+    for i, v in enumerate(seeds.cpu().numpy()):
+        lo, hi = indptr_h[i], indptr_h[i + 1]
+        want = indeg[v] if fanout < 0 else (min(indeg[v], fanout) if not replace else (fanout if indeg[v] else 0))
+        assert hi - lo == want
+        # every pick is an in-edge of v, and (src, eid) are consistent with the COO
+        assert (dst[e_h[lo:hi]] == v).all() and (src[e_h[lo:hi]] == s_h[lo:hi]).all()
+        if not replace:
+            assert len(set(e_h[lo:hi].tolist())) == hi - lo
+    assert indptr_h[-1] <= len(s_h)
+    # reproducible from the seed, different under another seed
+    indptr2, s2, e2 = _capi.sample_neighbors(csr, seeds, fanout, replace, 42)
+    n_e = int(indptr_h[-1])
+    assert torch.equal(indptr, indptr2) and torch.equal(e[:n_e], e2[:n_e])
+    if 0 < fanout < 20:
+        _, _, e3 = _capi.sample_neighbors(csr, seeds, fanout, replace, 43)
+        assert not torch.equal(e[:n_e], e3[:n_e])
+    if fanout < 0:   # the whole neighbourhood in CSC order: bit-exact
+        ip_h, ei_h = ip.cpu().numpy(), ei.cpu().numpy()
+        for i, v in enumerate(seeds.cpu().numpy()[:50]):
+            np.testing.assert_array_equal(e_h[indptr_h[i]:indptr_h[i + 1]], ei_h[ip_h[v]:ip_h[v + 1]])
+
+
+def test_sampling_is_uniform(dev):
+    """One node with 40 in-neighbours, fanout 4, 6 000 independent draws: every neighbour is
+    picked ~600 times (chi-square with 39 dof, p ~ 1e-6 bound 90)."""
+    import dgl_amd as dgl
+    from dgl_amd import _capi
+    from dgl_amd.sampling import _csc_of
+
+    n = 6000
+    src = torch.arange(1, 41).repeat(n)                   # the same 40 sources into every node
+    dst = torch.repeat_interleave(torch.arange(n), 40)
+    g = dgl.graph((src, dst), num_nodes=n, device=dev)
+    _, csr, _ = _csc_of(g)
+    seeds = torch.arange(n, device=dev)
+    indptr, s, _ = _capi.sample_neighbors(csr, seeds, 4, False, 7)
+    counts = torch.bincount(s[: int(indptr[-1])], minlength=41)[1:].double().cpu().numpy()
+    assert counts.sum() == n * 4
+    chi2 = ((counts - 600.0) ** 2 / 600.0).sum()
+    assert chi2 < 90, chi2
+    # with replacement
+    indptr, s, _ = _capi.sample_neighbors(csr, seeds, 4, True, 8)
+    counts = torch.bincount(s[: int(indptr[-1])], minlength=41)[1:].double().cpu().numpy()
+    assert ((counts - 600.0) ** 2 / 600.0).sum() < 90
+
+
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+def test_to_block_renumbering(dev, idtype):
+    from dgl_amd import _capi
+
+    rng = np.random.default_rng(3)
+    n = 5000
+    seeds = torch.from_numpy(rng.permutation(n)[:300]).to(dev).to(idtype)
+    src = torch.from_numpy(rng.integers(0, n, 4000)).to(dev).to(idtype)
+    node_map = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    local, src_nodes, k = _capi.to_block(seeds, src, node_map)
+    assert torch.equal(src_nodes[:300], seeds)                        # destination nodes come first
+    assert torch.equal(src_nodes[local.long()], src)                  # ids map back
+    assert k == len(set(seeds.tolist()) | set(src.tolist()))          # every node once
+    rest = src_nodes[300:]
+    assert bool((rest[1:] > rest[:-1]).all())                         # others by ascending id
+    assert int((node_map != -1).sum()) == 0                           # scratch is clean again
+    # no sampled edges at all
+    local, src_nodes, k = _capi.to_block(seeds, src[:0], node_map)
+    assert k == 300 and local.numel() == 0
+
+
+def test_two_layer_sage_on_sampled_blocks_matches_dense(dev):
+    import dgl_amd as dgl
+    import dgl_amd.function as fn
+
+    g, src, dst = _graph(dev, torch.int64, n=2000, e=50000, seed=5)
+    torch.manual_seed(0)
+    feat = torch.randn(2000, 32, device=dev)
+    w = [torch.randn(32, 16, device=dev), torch.randn(32, 16, device=dev),
+         torch.randn(16, 8, device=dev), torch.randn(16, 8, device=dev)]
+    sampler = dgl.NeighborSampler([15, 10], seed=3)
+    seeds = torch.arange(0, 2000, 7, device=dev)
+    input_nodes, output_nodes, blocks = sampler.sample_blocks(g, seeds)
+    assert torch.equal(output_nodes, seeds) and len(blocks) == 2
+    assert torch.equal(blocks[0].srcdata[dgl.NID], input_nodes)
+    assert torch.equal(blocks[1].dstdata[dgl.NID], seeds)
+    assert torch.equal(blocks[0].dstdata[dgl.NID], blocks[1].srcdata[dgl.NID])
+
+    def layer(blk, h, ws, wn):
+        with blk.local_scope():
+            blk.srcdata["h"] = h
+            blk.update_all(fn.copy_u("h", "m"), fn.mean("m", "n"))
+            return h[: blk.num_dst_nodes()] @ ws + blk.dstdata["n"] @ wn
+
+    h = feat[input_nodes]
+    h = torch.relu(layer(blocks[0], h, w[0], w[1]))
+    out = layer(blocks[1], h, w[2], w[3])
+
+    # dense evaluation over exactly the sampled edges (original ids from EID)
+    def dense_layer(blk, h_full_by_node, ws, wn):
+        eid = blk.edata[dgl.EID].long()
+        s_t = torch.from_numpy(src).to(dev)[eid]
+        d_t = torch.from_numpy(dst).to(dev)[eid]
+        dn = blk.dstdata[dgl.NID].long()
+        agg = torch.zeros(2000, h_full_by_node.shape[1], device=dev).index_add_(0, d_t, h_full_by_node[s_t])
+        deg = torch.bincount(d_t, minlength=2000).clamp(min=1).unsqueeze(-1)
+        res = torch.zeros(2000, ws.shape[1], device=dev)
+        res[dn] = h_full_by_node[dn] @ ws + (agg / deg)[dn] @ wn
+        return res
+
+    h1 = torch.relu(dense_layer(blocks[0], feat, w[0], w[1]))
+    want = dense_layer(blocks[1], h1, w[2], w[3])[seeds]
+    assert torch.allclose(out, want, rtol=1e-4, atol=1e-4)
+    # a second call draws a different sample, the same sampler state reproduces the first
+    _, _, b2 = sampler.sample_blocks(g, seeds)
+    assert not torch.equal(b2[1].edata[dgl.EID], blocks[1].edata[dgl.EID])
+    _, _, b3 = dgl.NeighborSampler([15, 10], seed=3).sample_blocks(g, seeds)
+    assert torch.equal(b3[1].edata[dgl.EID], blocks[1].edata[dgl.EID])
