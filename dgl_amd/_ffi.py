@@ -200,3 +200,50 @@ def use_current_stream(device):
     """Queue the following kernel calls of this thread on PyTorch's current stream of
     `device` (reference: tensoradapter CUDACurrentStream, src/runtime/cuda/cuda_device_api.cc:362-367)."""
     LIB.DGLSetStream(kDGLROCM, device.index or 0, torch.cuda.current_stream(device).cuda_stream)
+
+
+# ---- DLPack hand-over (python/dgl/_ffi/_ctypes/ndarray.py:28-45) ---------------------------------
+LIB.DGLArrayFromDLPack.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+LIB.DGLArrayToDLPack.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+LIB.DGLArrayFree.argtypes = [ctypes.c_void_p]
+ctypes.pythonapi.PyCapsule_GetPointer.restype = ctypes.c_void_p
+ctypes.pythonapi.PyCapsule_GetPointer.argtypes = [ctypes.py_object, ctypes.c_char_p]
+ctypes.pythonapi.PyCapsule_SetName.argtypes = [ctypes.py_object, ctypes.c_char_p]
+ctypes.pythonapi.PyCapsule_New.restype = ctypes.py_object
+ctypes.pythonapi.PyCapsule_New.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p]
+
+
+class OwnedArray:
+    """An array made by ``DGLArrayFromDLPack`` from a ``torch.utils.dlpack.to_dlpack`` capsule:
+    the library owns the DLManagedTensor and releases it in ``DGLArrayFree``.  Usable wherever
+    an ``NDArray`` argument is (the handle points at a ``DGLArray``)."""
+
+    def __init__(self, capsule):
+        ptr = ctypes.pythonapi.PyCapsule_GetPointer(capsule, b"dltensor")
+        h = ctypes.c_void_p()
+        if LIB.DGLArrayFromDLPack(ptr, ctypes.byref(h)) != 0:
+            raise _lib.DGLAMDError(LIB.DGLGetLastError().decode("utf-8", "replace"))
+        ctypes.pythonapi.PyCapsule_SetName(capsule, b"used_dltensor")  # consumed, as the reference does
+        self.handle = h.value
+        self.arr = ctypes.cast(h, ctypes.POINTER(DGLArray)).contents
+
+    def to_dlpack(self):
+        out = ctypes.c_void_p()
+        if LIB.DGLArrayToDLPack(self.handle, ctypes.byref(out), 0) != 0:
+            raise _lib.DGLAMDError(LIB.DGLGetLastError().decode("utf-8", "replace"))
+        return ctypes.pythonapi.PyCapsule_New(out, b"dltensor", None)
+
+    def free(self):
+        if self.handle:
+            LIB.DGLArrayFree(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def from_dlpack(capsule):
+    return OwnedArray(capsule)

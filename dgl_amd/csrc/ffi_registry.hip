@@ -16,6 +16,7 @@
 // graph engine owns the index arrays; here PyTorch does and the handle only borrows pointers).
 #include "../../include/dgl_amd.h"
 
+#include <atomic>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -1139,6 +1140,93 @@ static Registrar r_sddmm_hetero("sparse._CAPI_DGLKernelSDDMMHetero",
 using namespace dgla;
 
 extern "C" {
+
+// ---- DLPack hand-over (src/runtime/dlpack_convert.cc:57-140) -----------------------------------
+namespace {
+constexpr uint32_t kMagicArray = 0x41525259u;
+struct ArrayContainer {     // like NDArray::Container: the DGLArray comes first, so the handle
+  DGLArray dl_tensor;       // can be read as a DGLArray* (python/dgl/_ffi/ndarray.py:200-212)
+  uint32_t magic;
+  DLManagedTensor* owned;   // the tensor this array was made from (its deleter frees the memory)
+  std::atomic<int> refs;
+};
+void array_unref(ArrayContainer* c) {
+  if (c->refs.fetch_sub(1) == 1) {
+    if (c->owned && c->owned->deleter) c->owned->deleter(c->owned);
+    delete c;
+  }
+}
+void dlpack_view_deleter(DLManagedTensor* t) {
+  array_unref(static_cast<ArrayContainer*>(t->manager_ctx));
+  delete t;
+}
+}  // namespace
+
+int DGLArrayFromDLPack(DLManagedTensor* from, void** out) {
+  if (!from || !out) {
+    last_error() = "DGLArrayFromDLPack: null argument";
+    return -1;
+  }
+  ArrayContainer* c = new ArrayContainer();
+  c->dl_tensor.data = from->dl_tensor.data;
+  c->dl_tensor.ctx.device_type = from->dl_tensor.device.device_type;  // kDLROCM == kDGLROCM == 10
+  c->dl_tensor.ctx.device_id = from->dl_tensor.device.device_id;
+  c->dl_tensor.ndim = from->dl_tensor.ndim;
+  c->dl_tensor.dtype.code = from->dl_tensor.dtype.code;
+  c->dl_tensor.dtype.bits = from->dl_tensor.dtype.bits;
+  c->dl_tensor.dtype.lanes = from->dl_tensor.dtype.lanes;
+  c->dl_tensor.shape = from->dl_tensor.shape;
+  c->dl_tensor.strides = from->dl_tensor.strides;
+  c->dl_tensor.byte_offset = from->dl_tensor.byte_offset;
+  c->magic = kMagicArray;
+  c->owned = from;
+  c->refs = 1;
+  *out = &c->dl_tensor;
+  return 0;
+}
+
+int DGLArrayToDLPack(void* from, DLManagedTensor** out, int alignment) {
+  ArrayContainer* c = static_cast<ArrayContainer*>(from);
+  if (!c || !out || c->magic != kMagicArray) {
+    last_error() = "DGLArrayToDLPack: not an array made by DGLArrayFromDLPack";
+    return -1;
+  }
+  if (alignment > 0 && (reinterpret_cast<uintptr_t>(c->dl_tensor.data) + c->dl_tensor.byte_offset) % alignment) {
+    last_error() = "DGLArrayToDLPack: data is not aligned as requested";  // dlpack_convert.cc:131-137
+    return -1;
+  }
+  DLManagedTensor* t = new DLManagedTensor();
+  t->dl_tensor.data = c->dl_tensor.data;
+  t->dl_tensor.device.device_type = c->dl_tensor.ctx.device_type;
+  t->dl_tensor.device.device_id = c->dl_tensor.ctx.device_id;
+  t->dl_tensor.ndim = c->dl_tensor.ndim;
+  t->dl_tensor.dtype.code = c->dl_tensor.dtype.code;
+  t->dl_tensor.dtype.bits = c->dl_tensor.dtype.bits;
+  t->dl_tensor.dtype.lanes = c->dl_tensor.dtype.lanes;
+  t->dl_tensor.shape = c->dl_tensor.shape;
+  t->dl_tensor.strides = c->dl_tensor.strides;
+  t->dl_tensor.byte_offset = c->dl_tensor.byte_offset;
+  t->manager_ctx = c;
+  t->deleter = dlpack_view_deleter;
+  c->refs.fetch_add(1);
+  *out = t;
+  return 0;
+}
+
+int DGLArrayFree(void* handle) {
+  ArrayContainer* c = static_cast<ArrayContainer*>(handle);
+  if (!c) return 0;
+  if (c->magic != kMagicArray) {
+    last_error() = "DGLArrayFree: not an array made by DGLArrayFromDLPack";
+    return -1;
+  }
+  array_unref(c);
+  return 0;
+}
+
+void DGLDLManagedTensorCallDeleter(DLManagedTensor* t) {
+  if (t && t->deleter) t->deleter(t);
+}
 
 // Frees any object handle made by this library (the reference: DGLObjectFree,
 // include/dgl/runtime/c_object_api.h).  Unit graphs borrowed by a heterograph handle must

@@ -375,6 +375,43 @@ int DGLFuncGetGlobal(const char* name, DGLFunctionHandle* out);
 int DGLFuncCall(DGLFunctionHandle func, DGLValue* args, int* type_codes, int num_args,
                 DGLValue* ret_val, int* ret_type_code);
 int DGLFuncFree(DGLFunctionHandle func);
+
+/* DLPack hand-over (include/dgl/runtime/dlpack_convert.h:60-80, src/runtime/dlpack_convert.cc:
+ * 57-140; the reference's Python wraps every tensor this way, backend/pytorch/tensor.py:432-435).
+ * DGLArrayFromDLPack takes ownership of `from` (its deleter runs when the array is freed) and
+ * returns a handle that points at a DGLArray — the first member of the array's container, as
+ * with NDArray::Container.  device_type travels unchanged: PyTorch-ROCm exports kDLROCM = 10 =
+ * kDGLROCM.  DGLArrayToDLPack shares the memory and keeps the array alive until the consumer
+ * calls the returned tensor's deleter. */
+#ifndef DLPACK_DLPACK_H_
+typedef struct {
+  int32_t device_type;
+  int32_t device_id;
+} DLDevice;
+typedef struct {
+  uint8_t code;
+  uint8_t bits;
+  uint16_t lanes;
+} DLDataType;
+typedef struct {
+  void* data;
+  DLDevice device;
+  int32_t ndim;
+  DLDataType dtype;
+  int64_t* shape;
+  int64_t* strides;
+  uint64_t byte_offset;
+} DLTensor;
+typedef struct DLManagedTensor {
+  DLTensor dl_tensor;
+  void* manager_ctx;
+  void (*deleter)(struct DLManagedTensor* self);
+} DLManagedTensor;
+#endif
+int DGLArrayFromDLPack(DLManagedTensor* from, void** out /* DGLArrayHandle* */);
+int DGLArrayToDLPack(void* from /* DGLArrayHandle */, DLManagedTensor** out, int alignment);
+int DGLArrayFree(void* handle /* DGLArrayHandle made by DGLArrayFromDLPack */);
+void DGLDLManagedTensorCallDeleter(DLManagedTensor* dltensor);
 /* include/dgl/runtime/c_object_api.h: DGLObjectFree — releases an object handle returned by a
  * registry function: the List<Value> / Value boxes of the global functions `_List` / `_Value`
  * (how the reference passes Python lists, python/dgl/_ffi/object_generic.py:27-59), the

@@ -97,3 +97,36 @@ def test_list_objects_and_handle_tags():
         assert _lib.LIB.DGLObjectFree(ctypes.c_void_p(h.handle)) == 0
     bogus = (ctypes.c_uint32 * 4)(123, 0, 0, 0)
     assert _lib.LIB.DGLObjectFree(ctypes.cast(bogus, ctypes.c_void_p)) == -1
+
+
+def test_dlpack_round_trip_shares_memory_and_releases_owner():
+    """torch -> to_dlpack -> DGLArrayFromDLPack -> (fields) -> DGLArrayToDLPack -> torch: one
+    buffer throughout; the producer's deleter runs exactly when the last holder lets go
+    (src/runtime/dlpack_convert.cc:57-140; CPU tensor: no GPU needed)."""
+    import gc
+    import weakref
+
+    import torch
+    from torch.utils import dlpack
+
+    from dgl_amd import _ffi
+
+    t = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    alive = weakref.ref(t.untyped_storage())
+    arr = _ffi.from_dlpack(dlpack.to_dlpack(t))
+    a = arr.arr
+    assert a.ndim == 2 and a.shape[0] == 3 and a.shape[1] == 4
+    assert a.dtype.code == 2 and a.dtype.bits == 32 and a.ctx.device_type == 1   # kDLCPU
+    assert a.data == t.data_ptr()
+    back = dlpack.from_dlpack(arr.to_dlpack())
+    assert back.data_ptr() == t.data_ptr() and torch.equal(back, t)
+    back[0, 0] = 99.0
+    assert float(t[0, 0]) == 99.0
+    ptr = t.data_ptr()
+    del t
+    arr.free()            # the array lets go; `back` still holds the memory through its capsule
+    gc.collect()
+    assert back.data_ptr() == ptr and float(back[0, 0]) == 99.0 and alive() is not None
+    del back
+    gc.collect()
+    assert alive() is None
