@@ -338,6 +338,46 @@ def sample(dev, args):
          % inp.shape[0], tot, ms, mn, inp.shape[0] * 400 * 2 + tot * 408)
 
 
+def gat_graph(dev, args):
+    """Config 3 as a whole layer (GATConv forward: u_add_v -> leaky_relu -> edge softmax ->
+    u_mul_e + sum, H = 8, D = 8 / 32) on the ogbn-arxiv-shaped graph: eager launches through the
+    Python operator API vs ONE hipGraph replay of the same launches (tests/test_hip_graph.py)."""
+    import dgl_amd as dgl
+    import dgl_amd.function as fn
+
+    n, e = 169_343, 2_501_829
+    g = dgl.rand_graph(n, e, device=dev, seed=1, idtype=torch.int32)
+    for d in (8, 32):
+        ft = torch.randn(n, 8, d, device=dev)
+        el = torch.randn(n, 8, 1, device=dev)
+        er = torch.randn(n, 8, 1, device=dev)
+
+        def layer():
+            with g.local_scope():
+                g.srcdata.update({"ft": ft, "el": el})
+                g.dstdata.update({"er": er})
+                g.apply_edges(fn.u_add_v("el", "er", "e"))
+                sc = torch.nn.functional.leaky_relu(g.edata.pop("e"), 0.2)
+                g.edata["a"] = dgl.edge_softmax(g, sc)
+                g.update_all(fn.u_mul_e("ft", "a", "m"), fn.sum("m", "o"))
+                return g.dstdata["o"]
+
+        layer()
+        ms, mn = timeit(layer, reps=20, warm=5)
+        nb = e * (8 * 4 * 6 + 8 * d * 4 + 3 * 4) + n * 8 * d * 4
+        emit("GAT", "GATConv forward H=8 D=%d, eager (5 launches + torch glue)" % d, e, ms, mn, nb)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            layer()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            layer()
+        ms, mn = timeit(graph.replay, reps=20, warm=5)
+        emit("GAT", "GATConv forward H=8 D=%d, one hipGraph replay" % d, e, ms, mn, nb)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -346,7 +386,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("SEG", seg), ("MM", mm), ("SAMPLE", sample)):
+    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("SEG", seg), ("MM", mm), ("SAMPLE", sample), ("GAT", gat_graph)):
         if args.only and name not in args.only.split(","):
             continue
         fn(dev, args)
