@@ -476,47 +476,51 @@ __global__ __launch_bounds__(64) void spmm_csr_fixup_kernel(const SpmmParams<Idx
   using A = typename Acc<DT>::type;
   constexpr bool UL = op_uses_lhs(OP), UR = op_uses_rhs(OP);
   constexpr bool ARG = RED != kSum;
-  const int64_t s = blockIdx.x;
-  const int64_t row = p.carry_row[s];
-  if (row < 0) return;
-  if (s > 0 && p.carry_row[s - 1] == row) return;
-  int64_t s2 = s + 1;
-  while (s2 < num_slots && p.carry_row[s2] == row) ++s2;
-  // slot s2 holds the tail (the group in which the row ends); it always exists because a
-  // row with a carry has its row-end item in a later slot.
-  const int F = p.out_len;
-  const A* cv = static_cast<const A*>(p.carry_val);
-  const A* tv = static_cast<const A*>(p.tail_val);
-  DT* out = static_cast<DT*>(p.out);
-  for (int k = threadIdx.x; k < F; k += 64) {
-    A acc = cv[s * F + k];
-    Idx au = 0, ae = 0;
-    if constexpr (ARG) {
-      if constexpr (UL) au = p.carry_argu[s * F + k];
-      if constexpr (UR) ae = p.carry_arge[s * F + k];
-    }
-    auto combine = [&](A val, const Idx* pu, const Idx* pe, int64_t idx) {
-      if constexpr (RED == kSum) {
-        acc += val;
-      } else {
-        const bool take = (RED == kMax) ? (acc < val) : (acc > val);
-        if (take) {
-          acc = val;
-          if constexpr (UL) au = pu[idx];
-          if constexpr (UR) ae = pe[idx];
-        }
+  // grid-stride over the slots: one block per slot would need num_slots * 64 threads, which
+  // passes HIP's 2^32 threads-per-launch limit for narrow features on billion-edge graphs
+  // (tests/test_gpu_large.py)
+  for (int64_t s = blockIdx.x; s < num_slots; s += gridDim.x) {
+    const int64_t row = p.carry_row[s];
+    if (row < 0) continue;
+    if (s > 0 && p.carry_row[s - 1] == row) continue;
+    int64_t s2 = s + 1;
+    while (s2 < num_slots && p.carry_row[s2] == row) ++s2;
+    // slot s2 holds the tail (the group in which the row ends); it always exists because a
+    // row with a carry has its row-end item in a later slot.
+    const int F = p.out_len;
+    const A* cv = static_cast<const A*>(p.carry_val);
+    const A* tv = static_cast<const A*>(p.tail_val);
+    DT* out = static_cast<DT*>(p.out);
+    for (int k = threadIdx.x; k < F; k += 64) {
+      A acc = cv[s * F + k];
+      Idx au = 0, ae = 0;
+      if constexpr (ARG) {
+        if constexpr (UL) au = p.carry_argu[s * F + k];
+        if constexpr (UR) ae = p.carry_arge[s * F + k];
       }
-    };
-    for (int64_t q = s + 1; q < s2; ++q) combine(cv[q * F + k], p.carry_argu, p.carry_arge, q * F + k);
-    combine(tv[s2 * F + k], p.tail_argu, p.tail_arge, s2 * F + k);
-    const int64_t o = row * F + k;
-    if (p.accumulate)
-      out[o] = from_acc<DT>(to_acc<DT>(out[o]) + acc);
-    else
-      out[o] = from_acc<DT>(acc);
-    if constexpr (ARG) {
-      if constexpr (UL) p.arg_u[o] = au;
-      if constexpr (UR) p.arg_e[o] = ae;
+      auto combine = [&](A val, const Idx* pu, const Idx* pe, int64_t idx) {
+        if constexpr (RED == kSum) {
+          acc += val;
+        } else {
+          const bool take = (RED == kMax) ? (acc < val) : (acc > val);
+          if (take) {
+            acc = val;
+            if constexpr (UL) au = pu[idx];
+            if constexpr (UR) ae = pe[idx];
+          }
+        }
+      };
+      for (int64_t q = s + 1; q < s2; ++q) combine(cv[q * F + k], p.carry_argu, p.carry_arge, q * F + k);
+      combine(tv[s2 * F + k], p.tail_argu, p.tail_arge, s2 * F + k);
+      const int64_t o = row * F + k;
+      if (p.accumulate)
+        out[o] = from_acc<DT>(to_acc<DT>(out[o]) + acc);
+      else
+        out[o] = from_acc<DT>(acc);
+      if constexpr (ARG) {
+        if constexpr (UL) p.arg_u[o] = au;
+        if constexpr (UR) p.arg_e[o] = ae;
+      }
     }
   }
 }
@@ -708,8 +712,8 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
   DGLA_CHECK_HIP(hipGetLastError());
   if (pe.after) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
   hipLaunchKernelGGL((spmm_csr_fixup_kernel<Idx, DT, OP, RED>),
-                     dim3(static_cast<unsigned>(g.num_slots)), dim3(64), 0, L.stream, p,
-                     g.num_slots);
+                     dim3(static_cast<unsigned>(std::min<int64_t>(g.num_slots, int64_t(1) << 24))),
+                     dim3(64), 0, L.stream, p, g.num_slots);
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
 }
