@@ -90,6 +90,36 @@ def c2(dev, args):
     run_spmm("C2", "copy_u_max(+arg_u)", g, "copy_lhs", "max", x, None, (f,), dev)
     run_spmm("C2", "u_mul_e_sum(scalar e, eid map)", g, "mul", "sum", x, w1, (f,), dev, eid=True)
     run_spmm("C2", "u_mul_e_sum(scalar e, no map)", g, "mul", "sum", x, w1, (f,), dev, eid=False)
+    # API level ("kernel-only and API-level"): the same reduction through the operator
+    # API — output allocation, shape inference, FFI packing, registry call — and through
+    # DGLGraph.update_all with the result stored in the node frame; plus one autograd step
+    import dgl_amd as dgl
+    import dgl_amd.function as fn
+    from dgl_amd.graph_index import GraphIndex, Relation
+    from dgl_amd.heterograph import DGLGraph
+
+    rel = Relation(n, n, csc=(g["indptr"], g["indices"], None), idtype=g["indptr"].dtype, device=dev)
+    dg = DGLGraph(GraphIndex([n], [(0, 0)], [rel]), ["_N"], [("_N", "_E", "_N")])
+    ms, mn = timeit(lambda: dgl.ops.copy_u_sum(dg, x))
+    emit("C2", "copy_u_sum through dgl.ops.copy_u_sum (API level)", e, ms, mn, spmm_bytes(n, e, f, f, 4, 4))
+    dg.ndata["h"] = x
+
+    def ua():
+        dg.update_all(fn.copy_u("h", "m"), fn.sum("m", "o"))
+
+    ms, mn = timeit(ua)
+    emit("C2", "copy_u_sum through DGLGraph.update_all (API level)", e, ms, mn, spmm_bytes(n, e, f, f, 4, 4))
+    xg = x.clone().requires_grad_(True)
+
+    def fwd_bwd():
+        xg.grad = None
+        dgl.ops.copy_u_sum(dg, xg).sum().backward()
+
+    fwd_bwd()  # builds the reverse graph's CSC once (not timed, like the forward CSC)
+    ms, mn = timeit(fwd_bwd, reps=5)
+    emit("C2", "copy_u_sum forward + backward (autograd: SpMM on the reverse graph)", 2 * e, ms, mn,
+         2 * spmm_bytes(n, e, f, f, 4, 4))
+    del dg, rel, xg
     xh = x.to(torch.bfloat16)
     # F=100 bf16 rows are 200 B: 8-byte aligned only -> exercises the narrow access path
     run_spmm("C2", "copy_u_sum bf16", g, "copy_lhs", "sum", xh, None, (f,), dev)
