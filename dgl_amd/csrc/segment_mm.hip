@@ -41,7 +41,7 @@ int mfail(const std::string& m) {
 constexpr int BM = 128;
 constexpr int kFwdSlab = 128;   // forward: bytes of K per tile row and slab (pitch + 16: conflict-free ds_read_b128)
 constexpr int kBwdSlab = 64;    // weight gradient: 64-byte slabs
-constexpr int kSlabRows = 2048; // rows per split-K slab of the weight-gradient kernel
+constexpr int kMinSlabRows = 2048;  // rows per split-K slab of the weight-gradient kernel (lower bound)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -357,10 +357,12 @@ struct MmBwdParams {
   const void* a;   // [M, D1]
   const void* dc;  // [M, D2]
   float* acc;      // [R, D1, D2] fp32, zeroed
-  const int64_t* plan;  // slab table: rows_per_tile = kSlabRows
+  const int64_t* plan;  // slab table: rows_per_tile = slab_rows
   int64_t num_rel;
   int D1, D2;
   int vec_a, vec_dc;  // 16-byte loads allowed (row pitch and base 16-byte aligned)
+  int tiles_i, tiles_j;  // ceil(D1 / 128), ceil(D2 / 128)
+  int64_t slab_rows;     // rows per split-K slab
 };
 
 template <typename DT>
@@ -372,15 +374,23 @@ __global__ __launch_bounds__(256) void segment_mm_bwd_b_kernel(const MmBwdParams
   __shared__ __attribute__((aligned(16))) char sA[BM * kPitch];
   __shared__ __attribute__((aligned(16))) char sB[BN * kPitch];
 
-  const int64_t slab = blockIdx.z;
+  // 1-D grid, XCD-aware: the (D1 / 128) x (D2 / 128) output tiles of one row slab go to
+  // CONSECUTIVE workgroups of the same XCD (workgroup L runs on XCD L % 8), so the slab's rows
+  // of A and dC (2 x 1 MB for 256-wide bf16 features) come from HBM once and from that
+  // XCD's L2 for the other tiles.
+  const int64_t L = blockIdx.x;
+  const int64_t jd = L >> 3;
+  const int tiles = p.tiles_i * p.tiles_j;
+  const int64_t slab = (jd / tiles) * 8 + (L & 7);
+  const int tile = static_cast<int>(jd % tiles);
   const int64_t* slab_off = p.plan;
   const int64_t* row_off = p.plan + p.num_rel + 1;
   if (slab >= slab_off[p.num_rel]) return;
   const int64_t rel = find_segment(slab_off, p.num_rel, slab);
-  const int64_t m0 = row_off[rel] + (slab - slab_off[rel]) * kSlabRows;
-  int64_t m1 = m0 + kSlabRows;
+  const int64_t m0 = row_off[rel] + (slab - slab_off[rel]) * p.slab_rows;
+  int64_t m1 = m0 + p.slab_rows;
   if (m1 > row_off[rel + 1]) m1 = row_off[rel + 1];
-  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+  const int i0 = (tile / p.tiles_j) * BM, j0 = (tile % p.tiles_j) * BN;
   const int D1 = p.D1, D2 = p.D2;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -626,6 +636,18 @@ int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, 
   return 0;
 }
 
+// Rows per split-K slab: every slab ends in one fp32 atomic add per output element, and the
+// atomics (not the MFMAs) bound the kernel when slabs are short (2048-row slabs: 320 M atomics
+// = 4.0 ms of a 4.0 ms launch at 10 M rows).  Long slabs cut them; enough slabs must remain to
+// fill the chip: aim at ~4 workgroups per slot of (CUs x 3 resident workgroups).
+int64_t bwd_slab_rows(int64_t M, int64_t D1, int64_t D2) {
+  const int64_t tiles = ((D1 + BM - 1) / BM) * ((D2 + 127) / 128);
+  const int64_t want_blocks = int64_t(mm_num_cus()) * 3 * 4;
+  int64_t rows = (M * tiles + want_blocks - 1) / want_blocks;
+  rows = (rows + 31) / 32 * 32;
+  return rows < kMinSlabRows ? kMinSlabRows : rows;
+}
+
 template <typename DT>
 int run_segment_mm_bwd_b(const void* a, const void* dc, void* db, int64_t M, int64_t D1, int64_t D2,
                          int64_t num_rel, char* ws, const MmScratch& sc, hipStream_t s) {
@@ -651,13 +673,14 @@ int run_segment_mm_bwd_b(const void* a, const void* dc, void* db, int64_t M, int
     constexpr int E = 16 / sizeof(DT);
     p.vec_a = (D1 % E == 0 && aligned16(a)) ? 1 : 0;
     p.vec_dc = (D2 % E == 0 && aligned16(dc)) ? 1 : 0;
-    const int64_t max_slabs = (M + kSlabRows - 1) / kSlabRows + num_rel;
-    if (max_slabs > 65535) return mfail("segment_mm backward: more than 65535 row slabs (" +
-                                        std::to_string(max_slabs) + "); split the call");
-    hipLaunchKernelGGL((segment_mm_bwd_b_kernel<DT>),
-                       dim3(static_cast<unsigned>((D2 + BN - 1) / BN), static_cast<unsigned>((D1 + BM - 1) / BM),
-                            static_cast<unsigned>(max_slabs)),
-                       dim3(256), 0, s, p);
+    p.tiles_i = static_cast<int>((D1 + BM - 1) / BM);
+    p.tiles_j = static_cast<int>((D2 + BN - 1) / BN);
+    p.slab_rows = bwd_slab_rows(M, D1, D2);
+    const int64_t max_slabs = ((M + p.slab_rows - 1) / p.slab_rows + num_rel + 7) / 8 * 8;
+    const int64_t blocks = max_slabs * p.tiles_i * p.tiles_j;
+    if (blocks >= (int64_t(1) << 24)) return mfail("segment_mm backward: too many tiles (" +
+                                                   std::to_string(blocks) + "); split the call");
+    hipLaunchKernelGGL((segment_mm_bwd_b_kernel<DT>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
     if (!std::is_same<DT, float>::value)
       hipLaunchKernelGGL((convert_from_f32_kernel<DT>), dim3(static_cast<unsigned>(std::min<int64_t>((out_elems + 255) / 256, 4096))),
                          dim3(256), 0, s, acc, static_cast<DT*>(db), out_elems);
@@ -744,7 +767,7 @@ int dgla_segment_mm_backward_b(int idtype_bits, dgla_dtype dtype, const void* a,
     workspace = owned;
   }
   char* ws = static_cast<char*>(workspace);
-  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, kSlabRows, ws, sc, s);
+  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, static_cast<int>(bwd_slab_rows(num_rows, d1, d2)), ws, sc, s);
   if (rc == 0) {
     switch (dtype) {
       case DGLA_F32: rc = run_segment_mm_bwd_b<float>(a, dc, db, num_rows, d1, d2, num_rel, ws, sc, s); break;
