@@ -307,6 +307,7 @@ def sample_neighbors(csr, seeds, fanout, replace=False, rng_seed=0):
     """Uniform in-neighbour sampling over the in-edge CSR `csr` (dgla_sample_neighbors):
     returns ``(indptr, src, eids)`` — a CSR over the seeds with GLOBAL source / edge ids."""
     _require_gpu(seeds)
+    rng_seed = int(rng_seed) & 0xFFFFFFFFFFFFFFFF
     n = seeds.shape[0]
     dev, dt = seeds.device, seeds.dtype
     indptr = torch.empty(n + 1, dtype=dt, device=dev)
