@@ -316,3 +316,21 @@ def backward_segment_cmp(feat, arg, out):
     _check(lib().ref_backward_segment_cmp(arg.dtype.itemsize * 8, _dcode(out), _fp(ff), _ptr(arg),
                                           _fp(of)))
     return out
+
+
+def coo_to_csr(row, col, data, num_rows, num_cols=None):
+    """aten::impl::COOToCSR<kDGLCPU> (src/array/cpu/spmat_op_impl_coo.cc:747-764): returns
+    ``(indptr, indices, data)`` with ``data`` = edge id of every CSR position."""
+    row = np.ascontiguousarray(row)
+    idt = row.dtype
+    col = np.ascontiguousarray(col, dtype=idt)
+    data = None if data is None else np.ascontiguousarray(data, dtype=idt)
+    if num_cols is None:
+        num_cols = int(col.max()) + 1 if col.size else 0
+    nnz = row.shape[0]
+    indptr = np.zeros(num_rows + 1, dtype=idt)
+    indices = np.zeros(nnz, dtype=idt)
+    out = np.zeros(nnz, dtype=idt)
+    _check(lib().ref_coo_to_csr(idt.itemsize * 8, _i64(num_rows), _i64(num_cols), _i64(nnz), _ptr(row),
+                                _ptr(col), _ptr(data), _ptr(indptr), _ptr(indices), _ptr(out)))
+    return indptr, indices, out

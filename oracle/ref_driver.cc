@@ -6,6 +6,7 @@
 //     src/array/cpu/sddmm.cc (+ sddmm.h, ../selector.h)      SDDMMCsr / SDDMMCoo
 //     src/bcast.cc                                           CalcBcastOff
 //     src/array/cpu/segment_reduce.cc (+ segment_reduce.h)   SegmentReduce / ScatterAdd / BackwardSegmentCmp
+//     src/array/cpu/spmat_op_impl_coo.cc                     COOToCSR (tsl::robin_map shimmed, ref_shim/tsl/)
 // Nothing of the reference is copied into this repository.  The empty third_party/dmlc-core
 // submodule is replaced by the from-scratch headers in oracle/ref_shim/dmlc/.  libxsmm is
 // absent (empty submodule), so USE_LIBXSMM is undefined and the reference takes its naive
@@ -22,7 +23,9 @@
 #include <dgl/array.h>
 #include <dgl/bcast.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <ostream>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -59,6 +62,11 @@ template <int XPU, typename IdType, typename DType>
 void ScatterAdd(NDArray feat, NDArray idx, NDArray out);
 template <int XPU, typename IdType, typename DType>
 void BackwardSegmentCmp(NDArray feat, NDArray arg, NDArray out);
+namespace impl {
+// src/array/cpu/spmat_op_impl_coo.cc:747-764 (declared in src/array/array_op.h)
+template <DGLDeviceType XPU, typename IdType>
+CSRMatrix COOToCSR(COOMatrix coo);
+}  // namespace impl
 }  // namespace aten
 
 namespace runtime {
@@ -112,8 +120,40 @@ NDArray NDArray::Empty(std::vector<int64_t> shape, DGLDataType dtype, DGLContext
   v->deleter = view_deleter;
   return NDArray(v);
 }
+// Host-only stand-in for src/runtime/ndarray.cc:286-294 (device API not compiled).
+template <typename T>
+NDArray NDArray::FromVector(const std::vector<T>& vec, DGLContext ctx) {
+  DGLDataType dt;
+  dt.code = 0;
+  dt.bits = sizeof(T) * 8;
+  dt.lanes = 1;
+  NDArray ret = NDArray::Empty({static_cast<int64_t>(vec.size())}, dt, ctx);
+  if (!vec.empty()) std::memcpy(ret->data, vec.data(), vec.size() * sizeof(T));
+  return ret;
+}
+template NDArray NDArray::FromVector<int32_t>(const std::vector<int32_t>&, DGLContext);
+template NDArray NDArray::FromVector<int64_t>(const std::vector<int64_t>&, DGLContext);
 }  // namespace runtime
+
+namespace aten {
+// Host-only stand-in for aten::Full (src/array/array.cc:54-66 -> cpu impl: allocate + fill).
+IdArray Full(int64_t val, int64_t length, uint8_t nbits, DGLContext ctx) {
+  DGLDataType dt;
+  dt.code = 0;
+  dt.bits = nbits;
+  dt.lanes = 1;
+  IdArray ret = runtime::NDArray::Empty({length}, dt, ctx);
+  if (nbits == 32)
+    std::fill_n(static_cast<int32_t*>(ret->data), length, static_cast<int32_t>(val));
+  else
+    std::fill_n(static_cast<int64_t*>(ret->data), length, val);
+  return ret;
+}
+}  // namespace aten
 }  // namespace dgl
+
+// only reached on a failing CHECK in the reference (include/dgl/aten/array_ops.h declares it)
+std::ostream& operator<<(std::ostream& os, dgl::runtime::NDArray) { return os << "<NDArray>"; }
 
 namespace {
 
@@ -384,6 +424,29 @@ int ref_backward_segment_cmp(int idbits, int dtype, const Feat* feat, const void
     REF_TYPE_SWITCH(idbits, dtype, IdType, DType, {
       dgl::aten::BackwardSegmentCmp<kDGLCPU, IdType, DType>(F, A, O);
     });
+  });
+}
+
+// aten::impl::COOToCSR<kDGLCPU> (src/array/cpu/spmat_op_impl_coo.cc:747-764): chooses between
+// its sorted / small / sparse / dense algorithms itself.  `data` may be NULL (edge id = position).
+int ref_coo_to_csr(int idbits, int64_t num_rows, int64_t num_cols, int64_t nnz, const void* row,
+                   const void* col, const void* data, void* indptr, void* indices, void* data_out) {
+  return guarded([&] {
+    dgl::aten::COOMatrix coo = make_coo(num_rows, num_cols, nnz, idbits, row, col, data);
+    coo.row_sorted = coo.col_sorted = false;
+    dgl::aten::CSRMatrix csr = idbits == 32 ? dgl::aten::impl::COOToCSR<kDGLCPU, int32_t>(coo)
+                                            : dgl::aten::impl::COOToCSR<kDGLCPU, int64_t>(coo);
+    const size_t ib = idbits / 8;
+    std::memcpy(indptr, csr.indptr->data, ib * (num_rows + 1));
+    if (nnz) std::memcpy(indices, csr.indices->data, ib * nnz);
+    if (dgl::aten::IsNullArray(csr.data)) {  // "no data" = position
+      for (int64_t i = 0; i < nnz; ++i) {
+        if (idbits == 32) static_cast<int32_t*>(data_out)[i] = static_cast<int32_t>(i);
+        else static_cast<int64_t*>(data_out)[i] = i;
+      }
+    } else if (nnz) {
+      std::memcpy(data_out, csr.data->data, ib * nnz);
+    }
   });
 }
 

@@ -1,21 +1,62 @@
 """COO -> CSR / CSC on the device against the definition the reference's
 conversion satisfies (aten::COOToCSR, src/array/cuda/coo2csr.cu:28-110): rows compressed,
 edges in COO order inside a row, `data` = original edge id of every position.  Integer work:
-bit-exact against a numpy stable argsort."""
+bit-exact.  The definition itself is pinned to the reference: its own COOToCSR<kDGLCPU>
+(src/array/cpu/spmat_op_impl_coo.cc, built in place into oracle/_ref) equals it on every case,
+and its outputs are committed as tests/golden/reference_coo2csr_outputs.npz."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+from oracle import ref
+from tests.coo_cases import all_cases, stable_definition as _expect
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_coo2csr_outputs.npz")
 
 
-def _expect(row, col, eids, n):
-    order = np.argsort(row, kind="stable")
-    indptr = np.zeros(n + 1, dtype=row.dtype)
-    np.add.at(indptr, row + 1, 1)
-    return np.cumsum(indptr).astype(row.dtype), col[order], (order if eids is None else eids[order]).astype(row.dtype)
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref/libdglref.so not built")
+def test_reference_build_equals_the_stable_definition():
+    """Pins the definition the GPU path is held to: the reference's own COOToCSR<kDGLCPU> (all
+    four of its algorithms: sorted / small / sparse / dense, chosen by shape) returns exactly
+    the stable compression, bit for bit, for both id widths and with explicit edge ids."""
+    for threads in (1, 4):
+        ref.set_num_threads(threads)
+        for c in all_cases():
+            got = ref.coo_to_csr(c["row"], c["col"], c["eids"], c["num_rows"], c["num_cols"])
+            want = _expect(c["row"], c["col"], c["eids"], c["num_rows"])
+            for g, w in zip(got, want):
+                np.testing.assert_array_equal(g, w, err_msg=c["name"])
+    ref.set_num_threads(os.cpu_count() or 1)
 
 
+def test_golden_fixture_matches_the_definition():
+    gold = np.load(GOLDEN)
+    n = 0
+    for c in all_cases():
+        if c["name"] + "/out/indptr" not in gold.files:
+            continue
+        want = _expect(c["row"], c["col"], c["eids"], c["num_rows"])
+        for k, w in zip(("indptr", "indices", "eids"), want):
+            np.testing.assert_array_equal(gold["%s/out/%s" % (c["name"], k)], w)
+        n += 1
+    assert n >= 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", [c for c in all_cases() if c["row"].size <= 5000], ids=lambda c: c["name"])
+def test_gpu_matches_reference_outputs(dev, c):
+    from dgl_amd import _capi
+
+    gold = np.load(GOLDEN)
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    ip, ix, ei = _capi.coo_to_csr(t(c["row"]), t(c["col"]), t(c["eids"]), c["num_rows"])
+    for k, g in (("indptr", ip), ("indices", ix), ("eids", ei)):
+        np.testing.assert_array_equal(g.cpu().numpy(), gold["%s/out/%s" % (c["name"], k)], err_msg=k)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("idtype", [np.int32, np.int64])
 @pytest.mark.parametrize("n,m,e", [(1, 1, 0), (5, 7, 0), (1, 1, 1), (30, 40, 300), (1000, 10, 50000),
                                    (3, 100000, 200000), (70000, 70000, 1), (1 << 17, 333, 1 << 20)])
@@ -38,6 +79,7 @@ def test_coo_to_csr_bit_exact(dev, idtype, n, m, e, with_eids):
     np.testing.assert_array_equal(ei.cpu().numpy(), wei)
 
 
+@pytest.mark.gpu
 def test_graph_formats_are_built_natively_and_round_trip(dev):
     """The DGLGraph shim builds CSR / CSC through the native path; COO -> CSC -> COO keeps
     every edge, and the conversion runs on the current stream."""
