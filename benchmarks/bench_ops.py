@@ -301,6 +301,31 @@ def mm(dev, args):
         emit("MM", "per-relation torch.mm loop (vendor GEMM; the reference's structure), %s" % str(dt), rows, ms,
              mn, nb, tflops=flops / (ms * 1e-3) / 1e12)
         del a, b, c
+    # gather_mm on unsorted rows (HGT-style typed linear): the permutation is read inside the
+    # kernels vs the reference's structure (two index_select copies around a segment_mm)
+    rows = 10_000_000 // args.scale
+    a = (torch.rand(rows, k, device=dev) - 0.5).to(torch.bfloat16)
+    b = (torch.rand(r, k, n, device=dev) - 0.5).to(torch.bfloat16)
+    idx = torch.randint(0, r, (rows,), device=dev)
+    perm = torch.sort(idx, stable=True)[1].contiguous()
+    sl = torch.bincount(idx, minlength=r)
+    c = torch.empty(rows, n, device=dev, dtype=torch.bfloat16)
+    flops, nb = 2.0 * rows * k * n, rows * (k + n) * 2 + r * k * n * 2
+    ms, mn = timeit(lambda: _capi.segment_mm(a, b, c, sl, row_index=perm), reps=5, warm=2)
+    emit("MM", "gather_mm core, 10 M unsorted rows: segment_mm reading through the permutation, bf16", rows, ms, mn,
+         nb, tflops=flops / (ms * 1e-3) / 1e12)
+    rev = torch.empty_like(perm)
+    rev[perm] = torch.arange(rows, device=dev)
+    cs = torch.empty_like(c)
+
+    def ref_structure():
+        _capi.segment_mm(torch.index_select(a, 0, perm), b, cs, sl)
+        return torch.index_select(cs, 0, rev)
+
+    ms, mn = timeit(ref_structure, reps=5, warm=2)
+    emit("MM", "gather_mm core, reference structure: index_select + segment_mm + index_select, bf16", rows, ms, mn,
+         nb, tflops=flops / (ms * 1e-3) / 1e12)
+    del a, b, c, cs, idx, perm, rev
     # many small relations (the case the grouped launch exists for): 512 relations, 1 M rows
     rows, r = 1_000_000 // args.scale, 512
     lens = np.random.default_rng(0).multinomial(rows, np.ones(r) / r)

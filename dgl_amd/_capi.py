@@ -257,25 +257,30 @@ def _mm_check(*ts):
             raise _lib.DGLAMDError("matrices handed to segment_mm / gather_mm must be contiguous")
 
 
-def segment_mm(a, b, c, seglen, b_trans=False):
+def segment_mm(a, b, c, seglen, b_trans=False, row_index=None):
     """c[rows of r] = a[rows of r] @ b[r]  (or @ b[r].T when b_trans); `seglen` may be a CPU or
-    GPU int32/int64 tensor (dgla_segment_mm)."""
-    _mm_check(a, b, c)
+    GPU int32/int64 tensor (dgla_segment_mm).  With `row_index` (int64, GPU) the logical row r
+    lives at physical row row_index[r] of both a and c (dgla_segment_mm_indexed)."""
+    _mm_check(a, b, c, row_index)
+    if row_index is not None and row_index.dtype != torch.int64:
+        raise _lib.DGLAMDError("row_index must be int64")
     k = a.shape[1]
     n = c.shape[1]
-    check_call(LIB.dgla_segment_mm(_idbits(seglen), _DTYPES[a.dtype], a.data_ptr(), b.data_ptr(),
-                                   c.data_ptr(), seglen.data_ptr(), 0 if seglen.is_cuda else 1,
-                                   a.shape[0], seglen.shape[0], k, n, 1 if b_trans else 0, None, 0,
-                                   _stream(a)))
+    check_call(LIB.dgla_segment_mm_indexed(
+        _idbits(seglen), _DTYPES[a.dtype], a.data_ptr(), b.data_ptr(), c.data_ptr(), seglen.data_ptr(),
+        0 if seglen.is_cuda else 1, _ptr(row_index), a.shape[0], seglen.shape[0], k, n,
+        1 if b_trans else 0, None, 0, _stream(a)))
 
 
-def segment_mm_backward_b(a, dc, db, seglen):
-    """db[r] = a[rows of r].T @ dc[rows of r] (dgla_segment_mm_backward_b)."""
-    _mm_check(a, dc, db)
-    check_call(LIB.dgla_segment_mm_backward_b(
+def segment_mm_backward_b(a, dc, db, seglen, row_index=None):
+    """db[r] = a[rows of r].T @ dc[rows of r] (dgla_segment_mm_backward_b[_indexed])."""
+    _mm_check(a, dc, db, row_index)
+    if row_index is not None and row_index.dtype != torch.int64:
+        raise _lib.DGLAMDError("row_index must be int64")
+    check_call(LIB.dgla_segment_mm_backward_b_indexed(
         _idbits(seglen), _DTYPES[a.dtype], a.data_ptr(), dc.data_ptr(), db.data_ptr(),
-        seglen.data_ptr(), 0 if seglen.is_cuda else 1, a.shape[0], seglen.shape[0], a.shape[1],
-        dc.shape[1], None, 0, _stream(a)))
+        seglen.data_ptr(), 0 if seglen.is_cuda else 1, _ptr(row_index), a.shape[0], seglen.shape[0],
+        a.shape[1], dc.shape[1], None, 0, _stream(a)))
 
 
 def gather_mm(a, b, c, idx_a=None, idx_b=None, idx_c=None):

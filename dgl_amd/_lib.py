@@ -105,6 +105,13 @@ LIB.dgla_segment_mm_backward_b.restype = c_int
 LIB.dgla_segment_mm_backward_b.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                            c_int64, c_int64, c_int64, c_int64, c_void_p, c_size_t,
                                            c_void_p]
+LIB.dgla_segment_mm_indexed.restype = c_int
+LIB.dgla_segment_mm_indexed.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                        c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]
+LIB.dgla_segment_mm_backward_b_indexed.restype = c_int
+LIB.dgla_segment_mm_backward_b_indexed.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                   c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                                   c_size_t, c_void_p]
 LIB.dgla_gather_mm.restype = c_int
 LIB.dgla_gather_mm.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int64, c_int64, c_int64, c_void_p]

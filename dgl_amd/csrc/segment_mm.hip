@@ -166,6 +166,7 @@ struct MmParams {
   int K, N;
   int vec_a, vec_b;  // 16-byte loads allowed (alignment + K % E == 0)
   int vec_c;         // 16-byte stores of C rows allowed (alignment + N % E == 0)
+  const int64_t* row_index;  // optional: logical row r of A and C lives at physical row row_index[r]
   int64_t n_tiles;   // ceil(N / BN)
 };
 
@@ -227,7 +228,9 @@ __global__ __launch_bounds__(256, 2) void segment_mm_kernel(const MmParams p) {
 #pragma unroll
     for (int h = 0; h < PA; ++h) {
       const int64_t ar = row0 + pr0 + RSTEP * h;
-      ra[h] = load_piece<DT>(A + ar * K + kk, ar < row_end ? valid : 0, VEC);
+      const bool in = ar < row_end;
+      const int64_t pr = (in && p.row_index) ? p.row_index[ar] : ar;
+      ra[h] = load_piece<DT>(A + pr * K + kk, in ? valid : 0, VEC);
     }
 #pragma unroll
     for (int h = 0; h < PB; ++h) {
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void segment_mm_kernel(const MmParams p) {
           const int64_t grow = row0 + half * 64 + row;
           const int col = n0 + chunk * 8;
           if (grow < row_end && col < N)  // N % 8 == 0 here: a piece is all in or all out
-            *reinterpret_cast<u32x4*>(C + grow * N + col) =
+            *reinterpret_cast<u32x4*>(C + (p.row_index ? p.row_index[grow] : grow) * N + col) =
                 *reinterpret_cast<const u32x4*>(smem + row * kCPitch + chunk * 16);
         }
       }
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void segment_mm_kernel(const MmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-        if (row < row_end) C[row * N + col] = from_acc<DT>(acc[i][jj][r]);
+        if (row < row_end) C[(p.row_index ? p.row_index[row] : row) * N + col] = from_acc<DT>(acc[i][jj][r]);
       }
     }
 }
@@ -343,11 +346,12 @@ __global__ __launch_bounds__(256) void segment_mm_plain_kernel(const MmParams p,
       hi = mid - 1;
   }
   if (row >= row_off[p.num_rel]) return;  // rows beyond sum(seglen) are left untouched
-  const DT* a = static_cast<const DT*>(p.a) + row * p.K;
+  const int64_t prow = p.row_index ? p.row_index[row] : row;
+  const DT* a = static_cast<const DT*>(p.a) + prow * p.K;
   const DT* b = static_cast<const DT*>(p.bt) + (lo * p.N + col) * static_cast<int64_t>(p.K);
   A_ acc = 0;
   for (int k = 0; k < p.K; ++k) acc += to_acc<DT>(a[k]) * to_acc<DT>(b[k]);
-  static_cast<DT*>(p.c)[idx] = from_acc<DT>(acc);
+  static_cast<DT*>(p.c)[prow * p.N + col] = from_acc<DT>(acc);
 }
 
 constexpr int BN = 128;  // weight-gradient tile width
@@ -363,6 +367,7 @@ struct MmBwdParams {
   int vec_a, vec_dc;  // 16-byte loads allowed (row pitch and base 16-byte aligned)
   int tiles_i, tiles_j;  // ceil(D1 / 128), ceil(D2 / 128)
   int64_t slab_rows;     // rows per split-K slab
+  const int64_t* row_index;  // optional: logical row r of A and dC lives at physical row row_index[r]
 };
 
 template <typename DT>
@@ -423,10 +428,11 @@ __global__ __launch_bounds__(256) void segment_mm_bwd_b_kernel(const MmBwdParams
   u32x4 regs[CPT];
   auto fetch = [&](int64_t m) {
     const int64_t row = m + kk;
+    const int64_t prow = (row < m1 && p.row_index) ? p.row_index[row] : row;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       const int f = f0 + (cgrp + c * CGRPS) * E;
-      regs[c] = load_piece<DT>(src + row * width + f, row < m1 ? width - f : 0, vec_ok);
+      regs[c] = load_piece<DT>(src + prow * width + f, row < m1 ? width - f : 0, vec_ok);
     }
   };
   auto stash = [&]() {
@@ -487,7 +493,8 @@ __global__ __launch_bounds__(256) void segment_mm_bwd_b_f64_kernel(const double*
                                                                   const double* __restrict__ dc,
                                                                   double* __restrict__ db,
                                                                   const int64_t* __restrict__ plan,
-                                                                  int64_t num_rel, int D1, int D2) {
+                                                                  int64_t num_rel, int D1, int D2,
+                                                                  const int64_t* __restrict__ row_index) {
   const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (idx >= num_rel * D1 * D2) return;
   const int64_t rel = idx / (static_cast<int64_t>(D1) * D2);
@@ -495,7 +502,10 @@ __global__ __launch_bounds__(256) void segment_mm_bwd_b_f64_kernel(const double*
   const int i = ij / D2, j = ij - i * D2;
   const int64_t* row_off = plan + num_rel + 1;
   double acc = 0;
-  for (int64_t m = row_off[rel]; m < row_off[rel + 1]; ++m) acc += a[m * D1 + i] * dc[m * D2 + j];
+  for (int64_t m = row_off[rel]; m < row_off[rel + 1]; ++m) {
+    const int64_t pm = row_index ? row_index[m] : m;
+    acc += a[pm * D1 + i] * dc[pm * D2 + j];
+  }
   db[idx] = acc;
 }
 
@@ -587,7 +597,8 @@ int mm_num_cus() {
 
 template <typename DT>
 int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, int64_t N,
-                   int64_t num_rel, bool b_trans, char* ws, const MmScratch& sc, hipStream_t s) {
+                   int64_t num_rel, bool b_trans, const int64_t* row_index, char* ws,
+                   const MmScratch& sc, hipStream_t s) {
   // Bt = [R, N, K]: the weights with the contraction axis contiguous
   const void* bt = b;
   if (!b_trans) {
@@ -610,6 +621,7 @@ int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, 
   p.vec_a = (K % E == 0 && aligned16(a)) ? 1 : 0;
   p.vec_b = (K % E == 0 && aligned16(bt)) ? 1 : 0;
   p.vec_c = (N % E == 0 && aligned16(c)) ? 1 : 0;
+  p.row_index = row_index;
   p.n_tiles = 1;
   if constexpr (sizeof(DT) == 8) {
     const int64_t total = M * N;
@@ -650,14 +662,15 @@ int64_t bwd_slab_rows(int64_t M, int64_t D1, int64_t D2) {
 
 template <typename DT>
 int run_segment_mm_bwd_b(const void* a, const void* dc, void* db, int64_t M, int64_t D1, int64_t D2,
-                         int64_t num_rel, char* ws, const MmScratch& sc, hipStream_t s) {
+                         int64_t num_rel, const int64_t* row_index, char* ws, const MmScratch& sc,
+                         hipStream_t s) {
   const int64_t* plan = reinterpret_cast<const int64_t*>(ws + sc.off_plan);
   const int64_t out_elems = num_rel * D1 * D2;
   if constexpr (sizeof(DT) == 8) {
     hipLaunchKernelGGL(segment_mm_bwd_b_f64_kernel, dim3(static_cast<unsigned>((out_elems + 255) / 256)),
                        dim3(256), 0, s, static_cast<const double*>(a), static_cast<const double*>(dc),
                        static_cast<double*>(db), plan, num_rel, static_cast<int>(D1),
-                       static_cast<int>(D2));
+                       static_cast<int>(D2), row_index);
   } else {
     float* acc = std::is_same<DT, float>::value ? static_cast<float*>(db)
                                                 : reinterpret_cast<float*>(ws + sc.off_acc);
@@ -676,6 +689,7 @@ int run_segment_mm_bwd_b(const void* a, const void* dc, void* db, int64_t M, int
     p.tiles_i = static_cast<int>((D1 + BM - 1) / BM);
     p.tiles_j = static_cast<int>((D2 + BN - 1) / BN);
     p.slab_rows = bwd_slab_rows(M, D1, D2);
+    p.row_index = row_index;
     const int64_t max_slabs = ((M + p.slab_rows - 1) / p.slab_rows + num_rel + 7) / 8 * 8;
     const int64_t blocks = max_slabs * p.tiles_i * p.tiles_j;
     if (blocks >= (int64_t(1) << 24)) return mfail("segment_mm backward: too many tiles (" +
@@ -722,10 +736,10 @@ size_t dgla_segment_mm_workspace_bytes(dgla_dtype dtype, int64_t num_rel, int64_
   return mm_scratch(num_rel, d1, d2, elem, true, true).total;
 }
 
-int dgla_segment_mm(int idtype_bits, dgla_dtype dtype, const void* a, const void* b, void* c,
-                    const void* seglen, int seglen_on_host, int64_t num_rows, int64_t num_rel,
-                    int64_t k, int64_t n, int b_trans, void* workspace, size_t workspace_bytes,
-                    void* hip_stream) {
+int dgla_segment_mm_indexed(int idtype_bits, dgla_dtype dtype, const void* a, const void* b, void* c,
+                            const void* seglen, int seglen_on_host, const int64_t* row_index,
+                            int64_t num_rows, int64_t num_rel, int64_t k, int64_t n, int b_trans,
+                            void* workspace, size_t workspace_bytes, void* hip_stream) {
   if (check_mm_common(idtype_bits, dtype, num_rows, k, n, num_rel)) return -1;
   if (num_rows == 0 || n == 0 || num_rel == 0) return 0;
   if (!a || !b || !c || !seglen) return mfail("segment_mm: null operand");
@@ -741,20 +755,29 @@ int dgla_segment_mm(int idtype_bits, dgla_dtype dtype, const void* a, const void
   int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, BM, ws, sc, s);
   if (rc == 0) {
     switch (dtype) {
-      case DGLA_F32: rc = run_segment_mm<float>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, ws, sc, s); break;
-      case DGLA_F64: rc = run_segment_mm<double>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, ws, sc, s); break;
-      case DGLA_F16: rc = run_segment_mm<f16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, ws, sc, s); break;
-      case DGLA_BF16: rc = run_segment_mm<bf16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, ws, sc, s); break;
+      case DGLA_F32: rc = run_segment_mm<float>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
+      case DGLA_F64: rc = run_segment_mm<double>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
+      case DGLA_F16: rc = run_segment_mm<f16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
+      case DGLA_BF16: rc = run_segment_mm<bf16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
     }
   }
   if (owned) (void)hipFreeAsync(owned, s);
   return rc;
 }
 
-int dgla_segment_mm_backward_b(int idtype_bits, dgla_dtype dtype, const void* a, const void* dc,
-                               void* db, const void* seglen, int seglen_on_host,
-                               int64_t num_rows, int64_t num_rel, int64_t d1, int64_t d2,
-                               void* workspace, size_t workspace_bytes, void* hip_stream) {
+int dgla_segment_mm(int idtype_bits, dgla_dtype dtype, const void* a, const void* b, void* c,
+                    const void* seglen, int seglen_on_host, int64_t num_rows, int64_t num_rel,
+                    int64_t k, int64_t n, int b_trans, void* workspace, size_t workspace_bytes,
+                    void* hip_stream) {
+  return dgla_segment_mm_indexed(idtype_bits, dtype, a, b, c, seglen, seglen_on_host, nullptr, num_rows,
+                                 num_rel, k, n, b_trans, workspace, workspace_bytes, hip_stream);
+}
+
+int dgla_segment_mm_backward_b_indexed(int idtype_bits, dgla_dtype dtype, const void* a, const void* dc,
+                                       void* db, const void* seglen, int seglen_on_host,
+                                       const int64_t* row_index, int64_t num_rows, int64_t num_rel,
+                                       int64_t d1, int64_t d2, void* workspace, size_t workspace_bytes,
+                                       void* hip_stream) {
   if (check_mm_common(idtype_bits, dtype, num_rows, d1, d2, num_rel)) return -1;
   if (num_rel == 0 || d1 == 0 || d2 == 0) return 0;
   if (!db || !seglen || (num_rows > 0 && (!a || !dc))) return mfail("segment_mm backward: null operand");
@@ -770,14 +793,23 @@ int dgla_segment_mm_backward_b(int idtype_bits, dgla_dtype dtype, const void* a,
   int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, static_cast<int>(bwd_slab_rows(num_rows, d1, d2)), ws, sc, s);
   if (rc == 0) {
     switch (dtype) {
-      case DGLA_F32: rc = run_segment_mm_bwd_b<float>(a, dc, db, num_rows, d1, d2, num_rel, ws, sc, s); break;
-      case DGLA_F64: rc = run_segment_mm_bwd_b<double>(a, dc, db, num_rows, d1, d2, num_rel, ws, sc, s); break;
-      case DGLA_F16: rc = run_segment_mm_bwd_b<f16_t>(a, dc, db, num_rows, d1, d2, num_rel, ws, sc, s); break;
-      case DGLA_BF16: rc = run_segment_mm_bwd_b<bf16_t>(a, dc, db, num_rows, d1, d2, num_rel, ws, sc, s); break;
+      case DGLA_F32: rc = run_segment_mm_bwd_b<float>(a, dc, db, num_rows, d1, d2, num_rel, row_index, ws, sc, s); break;
+      case DGLA_F64: rc = run_segment_mm_bwd_b<double>(a, dc, db, num_rows, d1, d2, num_rel, row_index, ws, sc, s); break;
+      case DGLA_F16: rc = run_segment_mm_bwd_b<f16_t>(a, dc, db, num_rows, d1, d2, num_rel, row_index, ws, sc, s); break;
+      case DGLA_BF16: rc = run_segment_mm_bwd_b<bf16_t>(a, dc, db, num_rows, d1, d2, num_rel, row_index, ws, sc, s); break;
     }
   }
   if (owned) (void)hipFreeAsync(owned, s);
   return rc;
+}
+
+int dgla_segment_mm_backward_b(int idtype_bits, dgla_dtype dtype, const void* a, const void* dc,
+                               void* db, const void* seglen, int seglen_on_host,
+                               int64_t num_rows, int64_t num_rel, int64_t d1, int64_t d2,
+                               void* workspace, size_t workspace_bytes, void* hip_stream) {
+  return dgla_segment_mm_backward_b_indexed(idtype_bits, dtype, a, dc, db, seglen, seglen_on_host, nullptr,
+                                            num_rows, num_rel, d1, d2, workspace, workspace_bytes,
+                                            hip_stream);
 }
 
 int dgla_gather_mm(int idtype_bits, dgla_dtype dtype, const void* a, const void* b, void* c,

@@ -115,6 +115,45 @@ class GATHERMM(torch.autograd.Function):
         return A_grad, B_grad, None
 
 
+class GATHERMM_SORTED(torch.autograd.Function):
+    """``c[i] = a[i] @ b[idx_b[i]]`` for large inputs: rows are visited grouped by relation through
+    a permutation (``dgla_segment_mm_indexed``) instead of being copied into sorted order and back
+    (the reference's two ``index_select`` passes, python/dgl/ops/gather_mm.py:44-60).  Forward,
+    A-gradient and weight gradient all run on the grouped MFMA kernels."""
+
+    @staticmethod
+    def forward(ctx, A, B, idx_b):
+        from . import _capi
+
+        if B.dim() != 3:
+            raise ValueError("Expected dimension of B is 3. Got " + str(B.dim()))
+        A, B = A.contiguous(), B.contiguous()
+        perm, seglen = _sort_by_relation(idx_b, B.shape[0])
+        perm = perm.long().contiguous()
+        C = torch.empty((A.shape[0], B.shape[2]), device=A.device, dtype=A.dtype)
+        if C.numel():
+            _capi.segment_mm(A, B, C, seglen, row_index=perm)
+        ctx.backward_cache = A, B, perm, seglen
+        return C
+
+    @staticmethod
+    def backward(ctx, dZ):
+        from . import _capi
+
+        A, B, perm, seglen = ctx.backward_cache
+        dZ = dZ.contiguous()
+        A_grad = B_grad = None
+        if ctx.needs_input_grad[0]:
+            A_grad = torch.empty(A.shape, device=A.device, dtype=A.dtype)
+            if A_grad.numel():
+                _capi.segment_mm(dZ, B, A_grad, seglen, b_trans=True, row_index=perm)
+        if ctx.needs_input_grad[1]:
+            B_grad = torch.empty(B.shape, device=B.device, dtype=B.dtype)
+            if B_grad.numel():
+                _capi.segment_mm_backward_b(A, dZ, B_grad, seglen, row_index=perm)
+        return A_grad, B_grad, None
+
+
 def segment_mm(a, b, seglen_a):
     """``a[0:s0] @ b[0], a[s0:s0+s1] @ b[1], ...`` stacked (python/dgl/ops/segment.py:106-136).
     ``a``: (N, D1), ``b``: (R, D1, D2), ``seglen_a``: (R,) integer tensor on the CPU (as in
@@ -126,13 +165,13 @@ def segment_mm(a, b, seglen_a):
 
 def gather_mm(a, b, *, idx_b):
     """``c[i] = a[i] @ b[idx_b[i]]`` (python/dgl/ops/gather_mm.py:8-62).  Like the reference,
-    large problems are sorted by relation and run as one segment_mm; here the sort stays on
+    large problems are grouped by relation and run on the segment_mm kernels; here the grouping
+    is a permutation the kernels read through — no sorted copies of ``a`` and ``c`` — and stays on
     the device (no ``.cpu()`` synchronisation: seglen is consumed on the GPU)."""
     N, D1 = a.shape
     R, _, D2 = b.shape
     if N > 1000000 or D1 > 8 or D2 > 8:
-        perm, seglen = _sort_by_relation(idx_b, R)
-        rev = torch.empty_like(perm)
-        rev[perm] = torch.arange(perm.numel(), device=perm.device)
-        return torch.index_select(segment_mm(torch.index_select(a, 0, perm), b, seglen), 0, rev)
+        if len(idx_b) != N:
+            raise DGLAMDError("gather_mm expects one relation index per row of a")
+        return GATHERMM_SORTED.apply(a, b, idx_b)
     return GATHERMM.apply(a, b, idx_b)

@@ -217,6 +217,19 @@ int dgla_segment_mm_backward_b(int idtype_bits, dgla_dtype dtype, const void* a,
                                void* db, const void* seglen, int seglen_on_host,
                                int64_t num_rows, int64_t num_rel, int64_t d1, int64_t d2,
                                void* workspace, size_t workspace_bytes, void* hip_stream);
+/* The same two operators over rows that are NOT stored grouped by relation: logical row r (the
+ * order `seglen` describes) lives at physical row row_index[r] of A and of C (forward) / of A and
+ * dC (weight gradient).  This is dgl.ops.gather_mm for large inputs without its two
+ * index_select copies (python/dgl/ops/gather_mm.py:44-60): sort idx_b once, pass the permutation. */
+int dgla_segment_mm_indexed(int idtype_bits, dgla_dtype dtype, const void* a, const void* b, void* c,
+                            const void* seglen, int seglen_on_host, const int64_t* row_index,
+                            int64_t num_rows, int64_t num_rel, int64_t k, int64_t n, int b_trans,
+                            void* workspace, size_t workspace_bytes, void* hip_stream);
+int dgla_segment_mm_backward_b_indexed(int idtype_bits, dgla_dtype dtype, const void* a, const void* dc,
+                                       void* db, const void* seglen, int seglen_on_host,
+                                       const int64_t* row_index, int64_t num_rows, int64_t num_rel,
+                                       int64_t d1, int64_t d2, void* workspace, size_t workspace_bytes,
+                                       void* hip_stream);
 int dgla_gather_mm(int idtype_bits, dgla_dtype dtype, const void* a, const void* b, void* c,
                    const void* idx_a, const void* idx_b, const void* idx_c, int64_t num_rows,
                    int64_t k, int64_t n, void* hip_stream);
