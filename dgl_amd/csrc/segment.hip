@@ -9,8 +9,10 @@
 //    spmm_csr.cuh — one wavefront per 512 items whatever the segment lengths — instead of
 //    the reference's one-block-per-segment loop.  Only difference from g-SpMM: arg of an
 //    element nothing won is -1 (segment_reduce.cuh:39, cpu/segment_reduce.h:66), not 0.
-//  * scatter add: out[idx[i], :] += feat[i, :] with hardware float atomics, 16-byte row
-//    pieces per lane (the reference: one scalar atomic per thread).
+//  * scatter add: out[idx[i], :] += feat[i, :].  Small inputs: hardware float atomics, 16-byte
+//    row pieces per lane (the reference: one scalar atomic per thread).  Large inputs: no
+//    atomics — rows are grouped by target with one radix sort and summed by the merge-path
+//    kernel reading through the permutation (deterministic, several times faster).
 //  * backward of segment max/min: out[arg[i, k], k] = feat[i, k] where arg >= 0; every
 //    (row, k) is written at most once, so plain stores.
 #include "../../include/dgl_amd.h"
@@ -205,6 +207,69 @@ int build_segment_launch(const char* reduce, int idbits, dgla_dtype dtype,
   return 0;
 }
 
+// Large scatter adds do not use atomics at all: grouping the rows by target (one stable radix
+// sort of (idx, position) + the fused compress kernel of coo2csr.hip) turns the operation into
+// a segment sum whose "edges" are read through the permutation — the merge-path g-SpMM kernel
+// with copy_rhs / sum / accumulate.  15.5 M rows x 100 fp32 into 612 k targets: 23.2 ms with
+// hardware atomics (67 G atomics/s), a few ms sorted; and the result no longer depends on
+// the order in which atomics land (rows of one target are added in input order).
+constexpr int64_t kScatterSortMinElems = int64_t(1) << 20;
+
+size_t align_256(size_t x) { return (x + 255) / 256 * 256; }
+
+int scatter_add_sorted(int idbits, dgla_dtype dtype, const dgla_tensor* feat, const void* idx,
+                       const dgla_tensor* out, hipStream_t s) {
+  const int64_t n = feat->shape[0], rows = out->shape[0];
+  const size_t ib = idbits / 8;
+  SpmmLaunch L{};
+  L.csr.num_rows = rows;
+  L.csr.num_cols = 0;
+  L.csr.nnz = n;
+  L.csr.idbits = idbits;
+  L.op = kCopyRhs;
+  L.red = kSum;
+  L.dtype = dtype;
+  L.efeat = feat->data;
+  L.out = out->data;
+  L.out_len = L.lhs_len = L.rhs_len = row_len(out);
+  L.bcast = kBcNone;
+  L.rhs_group = 1;
+  L.accumulate = true;  // out += ...: scatter add keeps what out already holds
+  L.tune = tuning_flags() & ~static_cast<uint32_t>(kTuneSplit);
+  L.stream = s;
+  size_t spmm_ws = 0;
+  switch (dtype) {
+    case DGLA_F32: spmm_ws = spmm_csr_workspace_f32(L); break;
+    case DGLA_F64: spmm_ws = spmm_csr_workspace_f64(L); break;
+    case DGLA_F16: spmm_ws = spmm_csr_workspace_f16(L); break;
+    case DGLA_BF16: spmm_ws = spmm_csr_workspace_bf16(L); break;
+  }
+  const size_t sort_ws = dgla_coo_to_csr_workspace_bytes(idbits, rows, n);
+  const size_t off_indptr = 0, off_junk = align_256(ib * (rows + 1)), off_eids = off_junk + align_256(ib * n),
+               off_sort = off_eids + align_256(ib * n), off_spmm = off_sort + align_256(sort_ws),
+               total = off_spmm + align_256(spmm_ws);
+  char* ws = nullptr;
+  DGLA_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&ws), total, s));
+  // rows = targets, "columns" are not needed (written to scratch), eids_out = input rows in target order
+  int rc = dgla_coo_to_csr(idbits, rows, n, idx, idx, nullptr, ws + off_indptr, ws + off_junk, ws + off_eids,
+                           ws + off_sort, sort_ws, s);
+  if (rc == 0) {
+    L.csr.indptr = ws + off_indptr;
+    L.csr.indices = nullptr;
+    L.csr.eids = ws + off_eids;
+    L.workspace = ws + off_spmm;
+    L.workspace_bytes = spmm_ws;
+    switch (dtype) {
+      case DGLA_F32: rc = launch_spmm_csr_f32(L); break;
+      case DGLA_F64: rc = launch_spmm_csr_f64(L); break;
+      case DGLA_F16: rc = launch_spmm_csr_f16(L); break;
+      case DGLA_BF16: rc = launch_spmm_csr_bf16(L); break;
+    }
+  }
+  (void)hipFreeAsync(ws, s);
+  return rc;
+}
+
 }  // namespace
 }  // namespace dgla
 
@@ -279,6 +344,8 @@ int dgla_scatter_add(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat,
   if (!feat->data || !out->data || !idx) return sfail("feat / idx / out data is null");
   if (dim > 0x7fffffffLL / 4) return sfail("feature length too large");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const int64_t out_rows = out->shape[0];
+  if (n * dim >= kScatterSortMinElems && out_rows > 0) return scatter_add_sorted(idtype_bits, dtype, feat, idx, out, s);
   DGLA_IDX_DTYPE_SWITCH(idtype_bits, dtype, run_scatter_add, feat->data, idx, out->data, n, dim, s);
   return sfail("unsupported feature dtype");
 }

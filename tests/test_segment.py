@@ -255,3 +255,34 @@ def test_errors(dev):
         _capi.segment_reduce("max", feat, off, out)
     with pytest.raises(DGLAMDError, match="different feature shapes"):
         _capi.segment_reduce("sum", feat, off, torch.empty(2, 4, device=dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("tdtype,dim", [(torch.float32, 8), (torch.float32, 100), (torch.float64, 5), (torch.bfloat16, 16)])
+def test_gpu_scatter_add_sorted_path(dev, idtype, tdtype, dim):
+    """Above 2^20 elements scatter add groups the rows by target and sums them with the merge-path
+    kernel (no atomics): exact for exactly representable inputs, keeps what `out` already held,
+    leaves untouched targets alone, and is reproducible bit for bit."""
+    from dgl_amd import _capi
+
+    n = (1 << 20) // dim + 4097
+    m = 3001
+    g = torch.Generator().manual_seed(dim)
+    idx = torch.randint(0, m, (n,), generator=g)
+    idx[idx == 7] = 8                                   # an untouched target
+    idx[: n // 4] = 11                                  # a hub target
+    x = torch.randint(-4, 5, (n, dim), generator=g).to(tdtype)
+    base = torch.randint(-2, 3, (m, dim), generator=g).to(tdtype)
+    out = base.clone().to(dev)
+    _capi.scatter_add(x.to(dev), idx.to(idtype).to(dev), out)
+    want = base.double().clone().index_add_(0, idx, x.double())   # .double() aliases an fp64 base
+    if tdtype == torch.bfloat16:
+        # the hub sums exceed bf16's exact-integer range: compare after the same final rounding
+        assert torch.equal(out.cpu(), want.to(torch.bfloat16))
+    else:
+        assert torch.equal(out.cpu().double(), want)
+    assert torch.equal(out[7].cpu(), base[7])
+    out2 = base.clone().to(dev)
+    _capi.scatter_add(x.to(dev), idx.to(idtype).to(dev), out2)
+    assert torch.equal(out.view(torch.uint8), out2.view(torch.uint8))
