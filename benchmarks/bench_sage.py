@@ -1,0 +1,136 @@
+#!/usr/bin/env python
+"""Mini-batch GraphSAGE end to end (BASELINE.json configs[3] mechanics on the C2-shaped graph):
+NeighborSampler(15, 10) -> feature gather -> 2 x SAGE-mean (copy_u + mean through update_all,
+dense part in torch) -> cross-entropy -> backward (g-SpMM on the reversed blocks) -> SGD.
+
+    python benchmarks/bench_sage.py [--batch 1024] [--steps 50]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 benchmarks/bench_sage.py
+
+MI355X-first data placement: the whole graph AND the whole feature matrix are replicated on
+every GPU (ogbn-products: 0.5 GB of CSC + 1 GB of features; even papers100M — 13 GB of CSC,
+28 GB of bf16 features — fits the 288 GB of one MI355X several times over), so mini-batch
+training shards by SEED NODES only and the one collective per step is the gradient all-reduce
+(the reference shards features with METIS partitions and pulls halo rows per batch because
+its target GPUs cannot hold them).  Prints one JSON line: seeds/s and sampled edges/s over
+all ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from tests.graphgen import C2_EDGES, C2_NODES, synth_csr  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scale", type=int, default=1)
+    ap.add_argument("--hidden", type=int, default=256)
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import dgl_amd as dgl
+    import dgl_amd.function as fn
+    from dgl_amd.graph_index import GraphIndex, Relation
+    from dgl_amd.heterograph import DGLGraph
+
+    n, e, f, classes = C2_NODES // args.scale, C2_EDGES // args.scale, 100, 47
+    gs = synth_csr(n, n, e, "L", seed=20250824, device=dev, idtype=torch.int64)   # same graph on every rank
+    rel = Relation(n, n, csc=(gs["indptr"], gs["indices"], None), idtype=torch.int64, device=dev)
+    g = DGLGraph(GraphIndex([n], [(0, 0)], [rel]), ["_N"], [("_N", "_E", "_N")])
+    torch.manual_seed(0)
+    feat = torch.rand(n, f, device=dev)
+    labels = torch.randint(0, classes, (n,), device=dev)
+    params = [torch.randn(f, args.hidden, device=dev) * 0.05, torch.randn(f, args.hidden, device=dev) * 0.05,
+              torch.randn(args.hidden, classes, device=dev) * 0.05, torch.randn(args.hidden, classes, device=dev) * 0.05]
+    for p in params:
+        p.requires_grad_(True)
+    sampler = dgl.NeighborSampler([15, 10], seed=1 + rank)
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)
+
+    def sage(blk, h, ws, wn):
+        with blk.local_scope():
+            blk.srcdata["h"] = h
+            blk.update_all(fn.copy_u("h", "m"), fn.mean("m", "n"))
+            return h[: blk.num_dst_nodes()] @ ws + blk.dstdata["n"] @ wn
+
+    edges = [0]
+
+    def step():
+        seeds = torch.randint(0, n, (args.batch,), device=dev, generator=gen).unique()
+        inp, out, blocks = sampler.sample_blocks(g, seeds)
+        edges[0] += sum(b.num_edges() for b in blocks)
+        h = feat[inp]
+        h = torch.relu(sage(blocks[0], h, params[0], params[1]))
+        logits = sage(blocks[1], h, params[2], params[3])
+        loss = torch.nn.functional.cross_entropy(logits, labels[out.long()])
+        grads = torch.autograd.grad(loss, params)
+        if dist is not None:
+            flat = torch.cat([gr.reshape(-1) for gr in grads])
+            dist.all_reduce(flat)
+            flat /= world
+            off, synced = 0, []
+            for gr in grads:
+                synced.append(flat[off:off + gr.numel()].view_as(gr))
+                off += gr.numel()
+            grads = synced
+        with torch.no_grad():
+            for p, gr in zip(params, grads):
+                p -= 0.1 * gr
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    edges[0] = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt, float(edges[0])], device=dev, dtype=torch.float64)
+        tm = t.clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, tot_edges = float(tm[0]), float(t[1])
+    else:
+        tot_edges = float(edges[0])
+    if rank == 0:
+        print(json.dumps({
+            "workload": "2-layer GraphSAGE-mean mini-batch training step, fanouts (15, 10), batch %d per GPU, "
+                        "graph N=%d E=%d (variant L), F=%d -> %d -> %d, fp32; graph + features replicated per GPU"
+                        % (args.batch, n, e, f, args.hidden, classes),
+            "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
+            "seeds_per_s": args.batch * world * args.steps / dt,
+            "sampled_edges_per_s": tot_edges / dt, "final_loss": float(loss.detach())}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
