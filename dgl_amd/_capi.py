@@ -73,12 +73,13 @@ def spmm_csr_workspace_bytes(op, reduce, csr, dtype, ufeat, efeat, out):
 
 
 def spmm_csr(op, reduce, csr, ufeat, efeat, out, arg_u=None, arg_e=None, workspace=None,
-             accumulate=False, plan_valid=False):
+             accumulate=False, plan_valid=False, mean=False):
     """out = g-SpMM over `csr` (rows = destination nodes).  `workspace` is a uint8 tensor of
     at least spmm_csr_workspace_bytes(); it also caches the merge plan between calls."""
     keep = []
     tu, te, to = _tensor(ufeat, keep), _tensor(efeat, keep), _tensor(out, keep)
-    flags = (_lib.DGLA_ACCUMULATE if accumulate else 0) | (_lib.DGLA_PLAN_VALID if plan_valid else 0)
+    flags = (_lib.DGLA_ACCUMULATE if accumulate else 0) | (_lib.DGLA_PLAN_VALID if plan_valid else 0) | \
+        (_lib.DGLA_MEAN if mean else 0)
     check_call(LIB.dgla_spmm_csr(
         op.encode(), reduce.encode(), ctypes.byref(csr), _DTYPES[out.dtype], ctypes.byref(tu),
         ctypes.byref(te), ctypes.byref(to), _ptr(arg_u), _ptr(arg_e), _ptr(workspace),

@@ -95,6 +95,55 @@ class GSpMM(torch.autograd.Function):
         return None, None, None, dX, dY
 
 
+class GSpMMMean(torch.autograd.Function):
+    """``mean`` reducer with the division fused into the SpMM kernel (the reference composes
+    ``gspmm(.., 'sum', ..) / clamp(in_degrees, 1)``, python/dgl/ops/spmm.py:109-114, i.e. one
+    more pass over the output; forward values are identical).  Backward: the incoming gradient
+    is divided by the same degrees, then flows through the sum reducer's backward."""
+
+    @staticmethod
+    def forward(ctx, gidx, op, X, Y, in_deg):
+        out, _ = _gspmm(gidx, op, "sum", X, Y, mean=True)
+        ref = X if X is not None else Y
+        ctx.meta = (gidx, op, None if X is None else X.shape, None if Y is None else Y.shape,
+                    _last_dim_is_reduced(X, Y))
+        need_dx = X is not None and X.requires_grad
+        need_dy = Y is not None and Y.requires_grad
+        kx, ky, _ = _keep_for_spmm_backward(op, "sum", need_dx, need_dy)
+        ctx.save_for_backward(X if kx else None, Y if ky else None, in_deg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dZ):
+        gidx, op, x_shape, y_shape, reduce_last = ctx.meta
+        X, Y, in_deg = ctx.saved_tensors
+        den = in_deg.to(dZ.dtype).clamp(min=1).reshape((dZ.shape[0],) + (1,) * (dZ.dim() - 1))
+        dZ = (dZ / den).contiguous()
+        dX = dY = None
+        if op != "copy_rhs" and ctx.needs_input_grad[2]:
+            rev = gidx.reverse()
+            dX = gspmm(rev, "mul", "sum", dZ, Y) if op == "mul" else gspmm(rev, "copy_lhs", "sum", dZ, None)
+            dX = _reduce_grad(dX, x_shape)
+        if op != "copy_lhs" and ctx.needs_input_grad[3]:
+            if op == "mul":
+                dY = gsddmm(gidx, "dot" if reduce_last else "mul", X, dZ)
+            else:
+                dY = gsddmm(gidx, "copy_rhs", X, dZ)
+            dY = _reduce_grad(dY, y_shape)
+        return None, None, dX, dY, None
+
+
+def gspmm_mean(gidx, op, lhs_data, rhs_data, in_deg):
+    """Single-relation ``mean`` g-SpMM on a graph whose CSC format is allowed."""
+    if op == "sub":
+        op, rhs_data = "add", -rhs_data
+    if op == "div":
+        op, rhs_data = "mul", 1.0 / rhs_data
+    lhs_data, rhs_data = _autocast(lhs_data, rhs_data)
+    with torch.autocast("cuda", enabled=False):
+        return GSpMMMean.apply(gidx, op, lhs_data, rhs_data, in_deg)
+
+
 class GSDDMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gidx, op, X, Y, lhs_target, rhs_target):

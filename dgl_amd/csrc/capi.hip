@@ -319,6 +319,9 @@ int dgla_spmm_csr(const char* op, const char* reduce, const dgla_csr* csr, dgla_
   L.arg_u = arg_u;
   L.arg_e = arg_e;
   L.accumulate = (flags & DGLA_ACCUMULATE) != 0;
+  L.mean = (flags & DGLA_MEAN) != 0;
+  if (L.mean && (L.red != kSum || L.accumulate))
+    return fail("DGLA_MEAN is defined for reduce == sum without DGLA_ACCUMULATE");
   L.plan_valid = (flags & DGLA_PLAN_VALID) != 0;
   L.workspace = workspace;
   L.workspace_bytes = workspace_bytes;

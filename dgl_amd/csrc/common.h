@@ -146,6 +146,7 @@ struct SpmmLaunch {
   const void* const* efeat_tab;  // [num_rel]
   int arg_empty;    // arg value of an output element no edge won: 0 (g-SpMM), -1 (segment reduce)
   uint32_t tune;    // kTune* bits, from dgla_set_tuning()
+  bool mean;        // reduce == sum: store sum / max(in_degree, 1)  (the `mean` reducer, fused)
   bool accumulate;  // out += result (reference semantics, spmm.cuh:528-534) vs out = result
   bool plan_valid;  // workspace already holds the merge plan of this CSR
   void* workspace;

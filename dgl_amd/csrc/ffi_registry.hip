@@ -380,6 +380,23 @@ static Registrar r_spmm("sparse._CAPI_DGLKernelSpMM", [](const FfiArgs& a, DGLVa
   return ffi_fail("SpMM only supports CSC and COO formats");  // kernel.cc:41
 });
 
+// reduce "sum" followed by / clamp(in_degree, 1), fused (the `mean` reducer of dgl.ops.gspmm,
+// python/dgl/ops/spmm.py:109-114): same arguments as SpMM, reduce must be "sum".
+static Registrar r_spmm_mean("sparse._CAPI_DGLKernelSpMMMean",
+                             [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  SpmmCall c;
+  if (unpack_spmm(a, &c)) return -1;
+  UnitGraph* g = c.g;
+  if (!g->csc.present) return ffi_fail("SpMMMean needs the CSC format");
+  const dgla_csr csc = csr_of(g, g->csc, true);
+  const uint32_t flags = (g->plan_valid ? DGLA_PLAN_VALID : 0) | DGLA_MEAN;
+  const int rc = dgla_spmm_csr(c.op, c.reduce, &csc, c.dtype, &c.u.t, &c.e.t, &c.v.t, nullptr,
+                               nullptr, g->ws, g->ws_bytes, flags, tls_stream);
+  if (rc == 0) g->plan_valid = true;
+  return rc;
+});
+
 // Same as above but `out += result` — what the reference's per-relation loop relies on
 // (src/array/cuda/spmm_hetero.cu:150-158, spmm.cuh:528-534).
 static Registrar r_spmm_acc("sparse._CAPI_DGLKernelSpMMAccumulate",

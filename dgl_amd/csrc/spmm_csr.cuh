@@ -46,6 +46,7 @@ struct SpmmParams {
   BcastDims bd;   // kBcGeneral
   int accumulate;
   int arg_empty;  // arg_u / arg_e of an output element no edge won: 0 (g-SpMM) or -1 (segment reduce)
+  int mean;       // reduce == sum only: divide every row by max(its edge count, 1) before storing
   uint32_t tune;  // kTune* bits (common.h)
   // split-row layout of ufeat (kTuneSplit, see spmm_split_rows_kernel): features
   // [0, split_main) of every row live in `ufeat` with pitch split_main, the rest in `utail`
@@ -369,6 +370,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
         ov = *reinterpret_cast<VecT<DT, VEC>*>(o);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(to_acc<DT>(ov.v[v]) + acc[v]);
+      } else if (RED == kSum && p.mean) {
+        // fused `mean` (python/dgl/ops/spmm.py:109-114: sum, then / clamp(in_degree, 1)): a row
+        // written here lies wholly inside this group, so `cnt` is its in-degree.  Same two
+        // roundings as the reference: the sum to the storage type, then the quotient.
+        // the reference casts the degree to the feature dtype before dividing (`F.astype(deg,
+        // F.dtype(ret))`): in 16-bit storage a degree above 256 (bf16) / 2048 (fp16) is rounded
+        const A den = round_to_storage<DT>(static_cast<A>(cnt > 1 ? cnt : 1));
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(round_to_storage<DT>(acc[v]) / den);
       } else {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(acc[v]);
@@ -513,6 +523,10 @@ __global__ __launch_bounds__(64) void spmm_csr_fixup_kernel(const SpmmParams<Idx
       for (int64_t q = s + 1; q < s2; ++q) combine(cv[q * F + k], p.carry_argu, p.carry_arge, q * F + k);
       combine(tv[s2 * F + k], p.tail_argu, p.tail_arge, s2 * F + k);
       const int64_t o = row * F + k;
+      if (RED == kSum && p.mean) {
+        const int64_t deg = static_cast<int64_t>(p.indptr[row + 1]) - static_cast<int64_t>(p.indptr[row]);
+        acc = round_to_storage<DT>(acc) / round_to_storage<DT>(static_cast<A>(deg > 1 ? deg : 1));
+      }
       if (p.accumulate)
         out[o] = from_acc<DT>(to_acc<DT>(out[o]) + acc);
       else
@@ -640,6 +654,7 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.bd = L.bdims;
   p.accumulate = L.accumulate ? 1 : 0;
   p.arg_empty = L.arg_empty;
+  p.mean = L.mean ? 1 : 0;
   p.tune = L.tune;
   p.utail = nullptr;
   p.split_main = p.split_tail = 0;

@@ -42,6 +42,9 @@ def gspmm(g, op, reduce_op, lhs_data, rhs_data):
     if gidx.number_of_etypes() == 1:
         if op not in ("copy_lhs", "copy_rhs"):
             lhs_data, rhs_data = _reshape_for_broadcast(op, lhs_data, rhs_data)
+        if reduce_op == "mean" and gidx.relations[0].allowed("csc"):
+            # the division by clamp(in_degree, 1) happens inside the kernel (DGLA_MEAN)
+            return _F.gspmm_mean(gidx, op, lhs_data, rhs_data, g.in_degrees())
         ret = _F.gspmm(gidx, op, "sum" if reduce_op == "mean" else reduce_op, lhs_data, rhs_data)
     else:
         lhs_t = _to_type_tuple(g, lhs_data, "ntype") if op != "copy_rhs" else ()

@@ -73,8 +73,10 @@ def _sddmm_format(rel):
     raise DGLAMDError("SDDMM only supports CSR and COO formats")
 
 
-def _gspmm(gidx, op, reduce_op, u, e, accumulate_into=None):
-    """out[v] = reduce_{(u,e,v)} op(u_feat, e_feat).  Returns ``(out, (arg_u, arg_e))``."""
+def _gspmm(gidx, op, reduce_op, u, e, accumulate_into=None, mean=False):
+    """out[v] = reduce_{(u,e,v)} op(u_feat, e_feat).  Returns ``(out, (arg_u, arg_e))``.
+    ``mean=True`` (with reduce_op 'sum' on a CSC-capable graph) divides every row by
+    max(in-degree, 1) inside the kernel."""
     if gidx.number_of_etypes() != 1:
         raise DGLAMDError("We only support gspmm on graph with one edge type")
     use_u, use_e = op != "copy_rhs", op != "copy_lhs"
@@ -118,6 +120,9 @@ def _gspmm(gidx, op, reduce_op, u, e, accumulate_into=None):
             rel.ensure_workspace(nbytes)
         name = "sparse._CAPI_DGLKernelSpMM" if accumulate_into is None else \
             "sparse._CAPI_DGLKernelSpMMAccumulate"
+        if mean:
+            assert reduce_op == "sum" and accumulate_into is None and fmt == "csc"
+            name = "sparse._CAPI_DGLKernelSpMMMean"
         _call(name, rel, fmt, *args)
     # 1-D inputs give 1-D outputs (_sparse_ops.py:258-264)
     if (expand_u or not use_u) and (expand_e or not use_e):

@@ -44,6 +44,11 @@ typedef enum { DGLA_F32 = 0, DGLA_F64 = 1, DGLA_F16 = 2, DGLA_BF16 = 3 } dgla_dt
                               read of `out`).  Only meaningful for reduce == "sum". */
 #define DGLA_PLAN_VALID 2u /* `workspace` still holds the merge plan built by an earlier
                               call on the SAME csr (indptr contents, num_rows, nnz). */
+#define DGLA_MEAN 4u       /* reduce == "sum" only: every output row is divided by
+                              max(in-degree, 1) before it is stored — the `mean` reducer of
+                              dgl.ops.gspmm (python/dgl/ops/spmm.py:109-114: sum, then
+                              / clamp(in_degrees, 1)) without the second pass over `out`;
+                              same two roundings as the reference's sum-then-divide. */
 
 /* CSRMatrix (include/dgl/aten/csr.h:40-49).  For SpMM the rows are DESTINATION nodes
  * (the in-edge CSR / "CSC", src/array/kernel.cc:20-44); for SDDMM rows are SOURCE nodes. */

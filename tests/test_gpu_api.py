@@ -419,3 +419,44 @@ def test_hetero_update_all_max_tracks_relations(dev):
     c = g.get_ntype_id("c")
     assert torch.equal(au[c].cpu(), torch.tensor([[1, 0], [2, 2], [1, 1]], dtype=au[c].dtype))
     assert torch.equal(ant[c].cpu(), torch.tensor([[0, 1], [0, 0], [1, 1]], dtype=ant[c].dtype))
+
+
+@pytest.mark.parametrize("tdtype", [torch.float32, torch.float64, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("op", ["copy_lhs", "mul", "copy_rhs"])
+def test_fused_mean_equals_sum_then_divide(dev, tdtype, op):
+    """reduce 'mean' divides inside the kernel (DGLA_MEAN); values must be the bits the
+    reference's composition produces — sum in the storage type, then / clamp(in_degree, 1)
+    (python/dgl/ops/spmm.py:109-114) — including rows longer than a merge unit, isolated
+    nodes, and the gradient."""
+    import dgl_amd as dgl
+
+    rng = np.random.default_rng(3)
+    n_src, n_dst, e = 400, 300, 9000
+    src = rng.integers(0, n_src, e)
+    dst = np.minimum((rng.random(e) ** 3 * n_dst).astype(np.int64), n_dst - 1)   # hub rows + empties
+    g = dgl.heterograph({("a", "r", "b"): (torch.from_numpy(src), torch.from_numpy(dst))},
+                        {"a": n_src, "b": n_dst}, device=dev)
+    torch.manual_seed(0)
+    x = (torch.rand(n_src, 4, 8, device=dev) + 0.5).to(tdtype)
+    w = (torch.rand(e, 4, 1, device=dev) + 0.5).to(tdtype)
+    lhs = None if op == "copy_rhs" else x.clone().requires_grad_(True)
+    rhs = None if op == "copy_lhs" else w.clone().requires_grad_(True)
+    got = dgl.ops.gspmm(g, op, "mean", lhs, rhs)
+    lhs2 = None if lhs is None else lhs.detach().clone().requires_grad_(True)
+    rhs2 = None if rhs is None else rhs.detach().clone().requires_grad_(True)
+    s = dgl.ops.gspmm(g, op, "sum", lhs2, rhs2)
+    deg = g.in_degrees().to(tdtype).clamp(min=1).reshape(-1, 1, 1)
+    want = s / deg
+    assert got.dtype == want.dtype and got.shape == want.shape
+    assert torch.equal(got.view(torch.int16 if got.element_size() == 2 else
+                                (torch.int32 if got.element_size() == 4 else torch.int64)),
+                       want.view(torch.int16 if got.element_size() == 2 else
+                                 (torch.int32 if got.element_size() == 4 else torch.int64)))
+    if tdtype in (torch.float32, torch.float64):
+        wgt = torch.rand_like(got)
+        ins = [t for t in (lhs, rhs) if t is not None]
+        ins2 = [t for t in (lhs2, rhs2) if t is not None]
+        g1 = torch.autograd.grad((got * wgt).sum(), ins)
+        g2 = torch.autograd.grad((want * wgt).sum(), ins2)
+        for a, b in zip(g1, g2):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
