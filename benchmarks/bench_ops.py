@@ -261,12 +261,12 @@ def seg(dev, args):
             nb = rows * f * 4 + nseg * f * 4 + (nseg + 1) * 8 + (nseg * f * 8 if red == "max" else 0)
             emit("SEG", "segment_reduce %s, %d rows -> %d segments (%s), F=100 fp32" % (red, rows, nseg, label),
                  rows, ms, mn, nb)
-    # scatter add: rows -> nseg random targets (atomics)
+    # scatter add: rows -> nseg random targets
     nseg = C2_NODES // args.scale // 4
     idx = torch.randint(0, nseg, (rows,), device=dev)
     acc = torch.zeros(nseg, f, device=dev)
     ms, mn = timeit(lambda: _capi.scatter_add(feat, idx, acc), reps=5)
-    emit("SEG", "scatter_add %d rows -> %d rows (random idx, fp32 atomics), F=100" % (rows, nseg), rows, ms, mn,
+    emit("SEG", "scatter_add %d rows -> %d rows (random idx; sorted, atomic-free path), F=100" % (rows, nseg), rows, ms, mn,
          rows * (f * 4 * 2 + 8))
 
 
