@@ -150,7 +150,7 @@ def _i64(v):
 # --------------------------------------------------------------------------- #
 # g-SpMM
 # --------------------------------------------------------------------------- #
-def spmm_csr(op, reduce, indptr, indices, eids, ufeat, efeat, nthreads=None):
+def spmm_csr(op, reduce, indptr, indices, eids, ufeat, efeat, nthreads=None, out=None):
     """``out[r] = reduce_{j in row r} op(ufeat[indices[j]], efeat[eid(j)])``.
 
     Returns ``(out, arg_u, arg_e)`` (args are None for sum / for the unused side), with
@@ -170,7 +170,12 @@ def spmm_csr(op, reduce, indptr, indices, eids, ufeat, efeat, nthreads=None):
     bc = BcastOff(op, lshape, rshape)
     n_rows = indptr.shape[0] - 1
     oshape = (n_rows,) + infer_broadcast_shape(op, lshape[1:], rshape[1:])
-    out = np.zeros(oshape, dtype=fdt)
+    if out is None:
+        out = np.zeros(oshape, dtype=fdt)
+    else:
+        # accumulate into the caller's buffer: `out[k] += ...` continues from what it holds, as the
+        # reference's kernel does with its pre-zeroed / partially summed output (spmm.h:60-70)
+        assert reduce == "sum" and out.shape == oshape and out.dtype == fdt and out.flags.c_contiguous
     assert int(np.prod(oshape[1:])) == bc.out_len
     L = lib()
     sfx = _sfx(fdt, idt)
@@ -380,3 +385,57 @@ def backward_segment_cmp(feat, arg, out):
     getattr(lib(), "oracle_bwd_segment_cmp_" + _sfx(out.dtype, arg.dtype))(
         _i64(f.shape[0]), _ptr(arg), _ptr(f), _ptr(out), _i64(dim))
     return out
+
+
+# --------------------------------------------------------------------------- #
+# heterograph SpMM: the per-relation loop of SpMMCsrHetero (src/array/cpu/spmm.cc:45-150)
+# --------------------------------------------------------------------------- #
+def spmm_csr_hetero(op, reduce, rels, num_nodes, ufeats, efeats):
+    """Restates SpMMCsrHetero<kDGLCPU>: sum — every relation adds into the (zeroed) output of
+    its destination type (spmm.cc:55-69); max / min — outputs start at -inf / +inf, the
+    node- / edge-type trackers at -1 (spmm.cc:72-98), then the relations run IN ORDER through
+    SpMMCmpCsrHetero (spmm.h:341-408), whose compare is strict and seeded from the current
+    output: an earlier relation keeps ties.  Same signature / return as oracle.ref.spmm_csr_hetero."""
+    use_u, use_e = op != "copy_rhs", op != "copy_lhs"
+    n_nt = len(num_nodes)
+    outs = [None] * n_nt
+    au, ae, aut, aet = ([None] * n_nt for _ in range(4))
+    for et, r in enumerate(rels):
+        s, d = r["src"], r["dst"]
+        u = ufeats[s] if use_u else None
+        e = efeats[et] if use_e else None
+        if reduce == "sum":
+            # every relation's edges are added into the SAME running output, in relation order
+            # (spmm.cc:58-68): the rounding differs from summing per-relation totals
+            if outs[d] is None:
+                probe = spmm_csr(op, reduce, r["indptr"][:1].repeat(len(r["indptr"])), r["indices"][:0],
+                                 None if r["eids"] is None else r["eids"][:0], u,
+                                 None if e is None else e[:0])[0]
+                outs[d] = np.zeros(probe.shape if probe.ndim > 1 else (probe.shape[0], 1), dtype=probe.dtype)
+            spmm_csr(op, reduce, r["indptr"], r["indices"], r["eids"],
+                     None if u is None else (u if u.ndim > 1 else u.reshape(-1, 1)),
+                     None if e is None else (e if e.ndim > 1 else e.reshape(-1, 1)), out=outs[d])
+            continue
+        o, cu, ce = spmm_csr(op, reduce, r["indptr"], r["indices"], r["eids"], u, e)
+        if o.ndim == 1:
+            o = o.reshape(-1, 1)
+            cu = None if cu is None else cu.reshape(-1, 1)
+            ce = None if ce is None else ce.reshape(-1, 1)
+        if outs[d] is None:
+            outs[d] = np.full(o.shape, -np.inf if reduce == "max" else np.inf, dtype=o.dtype)
+            idt = np.asarray(r["indptr"]).dtype
+            if use_u:
+                au[d] = np.zeros(o.shape, dtype=idt)
+                aut[d] = np.full(o.shape, -1, dtype=idt)
+            if use_e:
+                ae[d] = np.zeros(o.shape, dtype=idt)
+                aet[d] = np.full(o.shape, -1, dtype=idt)
+        better = (outs[d] < o) if reduce == "max" else (outs[d] > o)
+        outs[d] = np.where(better, o, outs[d])
+        if use_u:
+            au[d] = np.where(better, cu, au[d])
+            aut[d] = np.where(better, s, aut[d]).astype(au[d].dtype)
+        if use_e:
+            ae[d] = np.where(better, ce, ae[d])
+            aet[d] = np.where(better, et, aet[d]).astype(ae[d].dtype)
+    return outs, au, ae, aut, aet

@@ -334,3 +334,62 @@ def coo_to_csr(row, col, data, num_rows, num_cols=None):
     _check(lib().ref_coo_to_csr(idt.itemsize * 8, _i64(num_rows), _i64(num_cols), _i64(nnz), _ptr(row),
                                 _ptr(col), _ptr(data), _ptr(indptr), _ptr(indices), _ptr(out)))
     return indptr, indices, out
+
+
+# --------------------------------------------------------------------------- #
+# heterograph SpMM (src/array/cpu/spmm.cc:45-150 SpMMCsrHetero)
+# --------------------------------------------------------------------------- #
+def spmm_csr_hetero(op, reduce, rels, num_nodes, ufeats, efeats):
+    """``rels``: list of dicts(indptr, indices, eids, src, dst) — one in-edge CSR per relation with
+    its (src, dst) node-type ids; ``ufeats`` per node type, ``efeats`` per relation (entries may
+    be None where unused).  Returns ``(outs, arg_u, arg_e, arg_u_ntype, arg_e_etype)`` per node
+    type (None where the type receives nothing / the array is not produced)."""
+    use_u, use_e = op != "copy_rhs", op != "copy_lhs"
+    n_et, n_nt = len(rels), len(num_nodes)
+    idt = np.asarray(rels[0]["indptr"]).dtype
+    any_feat = next(f for f in (list(ufeats) if use_u else []) + (list(efeats) if use_e else []) if f is not None)
+    fdt = any_feat.dtype
+    u = [None if (not use_u or f is None) else _prep(f) for f in (ufeats if use_u else [None] * n_nt)]
+    e = [None if (not use_e or f is None) else _prep(f) for f in (efeats if use_e else [None] * n_et)]
+    u0 = u[rels[0]["src"]] if use_u else None
+    e0 = e[0] if use_e else None
+    _, _, fshape = _shapes(op, u0, e0)
+    touched = {r["dst"] for r in rels}
+    outs = [np.zeros((num_nodes[nt],) + fshape, dtype=fdt) if nt in touched else None for nt in range(n_nt)]
+    cmp = reduce != "sum"
+    mk = lambda on: [np.zeros(o.shape, dtype=idt) if (o is not None and cmp and on) else None for o in outs]
+    au, ae, aut, aet = mk(use_u), mk(use_e), mk(use_u), mk(use_e)
+    I64 = ctypes.c_int64 * n_et
+    VP = ctypes.c_void_p * n_et
+    VPN = ctypes.c_void_p * n_nt
+    ips = [np.ascontiguousarray(r["indptr"], dtype=idt) for r in rels]
+    ixs = [np.ascontiguousarray(r["indices"], dtype=idt) for r in rels]
+    eis = [None if r["eids"] is None else np.ascontiguousarray(r["eids"], dtype=idt) for r in rels]
+    vp = lambda a: None if a is None else a.ctypes.data
+    feats_n, keep = (_Feat * n_nt)(), []
+    outs_n = (_Feat * n_nt)()
+    for nt in range(n_nt):
+        for arr, slot in ((u[nt], feats_n), (outs[nt], outs_n)):
+            if arr is None:
+                slot[nt] = _Feat(None, 0, None)
+            else:
+                f, k = _feat(arr)
+                slot[nt] = f
+                keep.append(k)
+    feats_e = (_Feat * n_et)()
+    for et in range(n_et):
+        if e[et] is None:
+            feats_e[et] = _Feat(None, 0, None)
+        else:
+            f, k = _feat(e[et])
+            feats_e[et] = f
+            keep.append(k)
+    I32 = ctypes.c_int32 * n_et
+    _check(lib().ref_spmm_csr_hetero(
+        op.encode(), reduce.encode(), idt.itemsize * 8, _dcode(any_feat if any_feat.ndim > 1 else _prep(any_feat)),
+        n_et, n_nt, I64(*[len(p) - 1 for p in ips]), I64(*[num_nodes[r["src"]] for r in rels]),
+        I64(*[len(x) for x in ixs]), VP(*[vp(p) for p in ips]), VP(*[vp(x) for x in ixs]),
+        VP(*[vp(x) for x in eis]), I32(*[r["src"] for r in rels]), I32(*[r["dst"] for r in rels]),
+        feats_n, feats_e, outs_n, VPN(*[vp(a) for a in au]), VPN(*[vp(a) for a in ae]),
+        VPN(*[vp(a) for a in aut]), VPN(*[vp(a) for a in aet])))
+    return outs, au, ae, aut, aet

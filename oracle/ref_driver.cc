@@ -55,6 +55,14 @@ template <int XPU, typename IdType, typename DType>
 void Edge_softmax_csr_backward(const std::string& op, const BcastOff& bcast,
                                const CSRMatrix& csr, NDArray out, NDArray sds,
                                NDArray back_out);
+// src/array/cpu/spmm.cc:45-150 (declared in src/array/kernel_decl.h:37-47)
+template <int XPU, typename IdType, typename DType>
+void SpMMCsrHetero(const std::string& op, const std::string& reduce, const BcastOff& bcast,
+                   const std::vector<CSRMatrix>& csr, const std::vector<NDArray>& ufeat,
+                   const std::vector<NDArray>& efeat, std::vector<NDArray>* out,
+                   std::vector<std::vector<NDArray>>* out_aux,
+                   const std::vector<dgl_type_t>& ufeat_node_tids,
+                   const std::vector<dgl_type_t>& out_node_tids);
 // src/array/cpu/segment_reduce.cc:18-57 (declared in src/array/kernel_decl.h)
 template <int XPU, typename IdType, typename DType>
 void SegmentReduce(const std::string& op, NDArray feat, NDArray offsets, NDArray out, NDArray arg);
@@ -246,7 +254,10 @@ dgl::aten::CSRMatrix make_csr(int64_t num_rows, int64_t num_cols, int64_t nnz, i
   csr.num_cols = num_cols;
   csr.indptr = id_view(indptr, num_rows + 1, idbits);
   csr.indices = id_view(indices, nnz, idbits);
-  if (nnz == 0) csr.indices = make_view(nullptr, 1, &nnz, 0, static_cast<uint8_t>(idbits));
+  // an empty relation: libdgl's zero-length arrays still carry a non-null data pointer, which the
+  // kernels CHECK (spmm.h:135) before looping zero times
+  static int64_t empty_storage[2] = {0, 0};
+  if (nnz == 0) csr.indices = make_view(empty_storage, 1, &nnz, 0, static_cast<uint8_t>(idbits));
   csr.data = id_view(eids, nnz, idbits);
   return csr;
 }
@@ -382,6 +393,47 @@ int ref_edge_softmax_backward(int idbits, int dtype, int64_t num_rows, int64_t n
     const auto csr = make_csr(num_rows, num_cols, nnz, idbits, indptr, indices, eids);
     REF_TYPE_SWITCH(idbits, dtype, IdType, DType, {
       dgl::aten::Edge_softmax_csr_backward<kDGLCPU, IdType, DType>("copy_rhs", bcast, csr, O, S, B);
+    });
+  });
+}
+
+// aten::SpMMHetero semantics for the CSC-capable case (src/array/kernel.cc:173-221 ->
+// SpMMCsrHetero<kDGLCPU>, spmm.cc:45-150).  Per relation: its in-edge CSR and (src, dst) node
+// type; per node type: ufeat, out and the four aux arrays (NULL entries allowed where the
+// operator / reducer does not use them); per relation: efeat.  `out` arrives zero-filled.
+int ref_spmm_csr_hetero(const char* op, const char* reduce, int idbits, int dtype, int num_etypes,
+                        int num_ntypes, const int64_t* num_rows, const int64_t* num_cols,
+                        const int64_t* nnz, const void* const* indptr, const void* const* indices,
+                        const void* const* eids, const int32_t* src_ntype, const int32_t* dst_ntype,
+                        const Feat* ufeat, const Feat* efeat, const Feat* out, void* const* arg_u,
+                        void* const* arg_e, void* const* arg_u_ntype, void* const* arg_e_etype) {
+  return guarded([&] {
+    std::vector<dgl::aten::CSRMatrix> csrs;
+    std::vector<dgl::dgl_type_t> u_tids, o_tids;
+    for (int et = 0; et < num_etypes; ++et) {
+      csrs.push_back(make_csr(num_rows[et], num_cols[et], nnz[et], idbits, indptr[et], indices[et], eids[et]));
+      u_tids.push_back(src_ntype[et]);
+      o_tids.push_back(dst_ntype[et]);
+    }
+    const bool use_u = std::string(op) != "copy_rhs", use_e = std::string(op) != "copy_lhs";
+    std::vector<NDArray> U, E, O;
+    std::vector<std::vector<NDArray>> aux(4);
+    for (int nt = 0; nt < num_ntypes; ++nt) {
+      if (use_u) U.push_back(feat_view(&ufeat[nt], dtype));
+      O.push_back(feat_view(&out[nt], dtype));
+      void* const* src[4] = {arg_u, arg_e, arg_u_ntype, arg_e_etype};
+      for (int a = 0; a < 4; ++a)
+        aux[a].push_back(src[a] && src[a][nt]
+                             ? make_view(src[a][nt], out[nt].ndim, out[nt].shape, 0, static_cast<uint8_t>(idbits))
+                             : null_array());
+    }
+    if (use_e)
+      for (int et = 0; et < num_etypes; ++et) E.push_back(feat_view(&efeat[et], dtype));
+    // the broadcast is taken from relation 0's operands, as kernel.cc:181-192 does
+    NDArray u0 = use_u ? U[u_tids[0]] : null_array(), e0 = use_e ? E[0] : null_array();
+    const dgl::BcastOff bcast = dgl::CalcBcastOff(op, u0, e0);
+    REF_TYPE_SWITCH(idbits, dtype, IdType, DType, {
+      dgl::aten::SpMMCsrHetero<kDGLCPU, IdType, DType>(op, reduce, bcast, csrs, U, E, &O, &aux, u_tids, o_tids);
     });
   });
 }
