@@ -433,6 +433,39 @@ def gat_graph(dev, args):
         emit("GAT", "GATConv forward H=8 D=%d, one hipGraph replay" % d, e, ms, mn, nb)
 
 
+def fmt(dev, args):
+    """COO -> CSC of the C2 graph: dgla_coo_to_csr (radix sort of (dst, position)
+    + one fused gather / indptr kernel) vs the same result from torch primitives (stable argsort,
+    bincount, cumsum, two gathers).  Algorithmic bytes: read row + col, write indices + eids +
+    indptr (the sort's own passes are overhead on top)."""
+    n, e = C2_NODES // args.scale, C2_EDGES // args.scale
+    for idt in (torch.int32, torch.int64):
+        g = synth_csr(n, n, e, "U", device=dev, idtype=idt)
+        src = g["indices"]
+        dst = torch.repeat_interleave(torch.arange(n, device=dev), (g["indptr"][1:] - g["indptr"][:-1]).long()).to(idt)
+        perm = torch.randperm(e, device=dev)
+        src, dst = src[perm].contiguous(), dst[perm].contiguous()   # an unsorted COO
+        del g, perm
+        i = 4 if idt == torch.int32 else 8
+        nb = e * i * 4 + (n + 1) * i
+        ms, mn = timeit(lambda: _capi.coo_to_csr(dst, src, None, n), reps=5, warm=2)
+        emit("FMT", "COO -> CSC, %d edges, %s ids: dgla_coo_to_csr" % (e, str(idt)), e, ms, mn, nb)
+
+        def torch_path():
+            order = torch.argsort(dst, stable=True)
+            counts = torch.bincount(dst.long(), minlength=n)
+            indptr = torch.zeros(n + 1, dtype=idt, device=dev)
+            indptr[1:] = torch.cumsum(counts, 0).to(idt)
+            return indptr, src[order], order.to(idt)
+
+        ms, mn = timeit(torch_path, reps=5, warm=2)
+        emit("FMT", "COO -> CSC, %d edges, %s ids: torch argsort + bincount + cumsum + gathers" % (e, str(idt)), e, ms,
+             mn, nb)
+        a, b = _capi.coo_to_csr(dst, src, None, n), torch_path()
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+        del src, dst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -441,7 +474,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("SEG", seg), ("MM", mm), ("SAMPLE", sample), ("GAT", gat_graph)):
+    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("SEG", seg), ("MM", mm), ("SAMPLE", sample), ("GAT", gat_graph), ("FMT", fmt)):
         if args.only and name not in args.only.split(","):
             continue
         fn(dev, args)
