@@ -14,6 +14,7 @@ from . import ops  # noqa: E402,F401
 from .heterograph import (DGLGraph, create_block, graph, heterograph, rand_bipartite,  # noqa: E402,F401
                           rand_graph, reverse)
 from . import sampling  # noqa: E402,F401
+from . import sparse  # noqa: E402,F401
 from .ops import edge_softmax  # noqa: E402,F401
 from .sampling import EID, NID, NeighborSampler  # noqa: E402,F401
 from .mm import gather_mm, segment_mm  # noqa: E402,F401
