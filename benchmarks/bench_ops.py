@@ -23,6 +23,7 @@ from dgl_amd import _capi  # noqa: E402
 from tests.graphgen import C2_EDGES, C2_FEAT, C2_NODES, synth_csr  # noqa: E402
 
 PEAK = 8000.0
+VERIFY = False
 
 
 def timeit(fn, reps=10, warm=3):
@@ -70,7 +71,24 @@ def run_spmm(cfg, name, g, op, red, u, w, fo, dev, eid=False):
     nb = spmm_bytes(n, g["nnz"], f_l, f_out, s, i, w_row, eid and w is not None)
     if red != "sum":
         nb += n * f_out * i * ((u is not None) + (w is not None))
-    emit(cfg, name, g["nnz"], ms, mn, nb, dtype=str(out.dtype), idtype=str(idt))
+    extra = {}
+    if VERIFY and out.dtype in (torch.float32, torch.float64):
+        # full-size parity against the CPU oracle (tests do this at 1/16 scale; bench.py for copy_u+sum)
+        import oracle
+
+        h = lambda t: None if t is None else t.cpu().numpy()
+        ref, ru, re_ = oracle.spmm_csr(op, red, h(g["indptr"]), h(g["indices"]), h(g["eids"]) if eid else None,
+                                      h(u), h(w), nthreads=min(64, os.cpu_count() or 1))
+        got = out.cpu().numpy().reshape(ref.shape)
+        if red == "sum":
+            extra["parity_max_rel_err_vs_oracle"] = float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30)))
+        else:
+            extra["parity_values_bit_exact"] = bool(np.array_equal(got, ref))
+            if ru is not None:
+                extra["parity_arg_u_bit_exact"] = bool(np.array_equal(au.cpu().numpy().reshape(ru.shape), ru))
+            if re_ is not None:
+                extra["parity_arg_e_bit_exact"] = bool(np.array_equal(ae.cpu().numpy().reshape(re_.shape), re_))
+    emit(cfg, name, g["nnz"], ms, mn, nb, dtype=str(out.dtype), idtype=str(idt), **extra)
     return out
 
 
@@ -472,7 +490,10 @@ def main():
     ap.add_argument("--scale", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="also ops whose output is E x F (25 GB)")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="check every fp32 SpMM result against the CPU oracle at full size")
     args = ap.parse_args()
+    global VERIFY
+    VERIFY = args.verify
     dev = torch.device("cuda:0")
     for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("SEG", seg), ("MM", mm), ("SAMPLE", sample), ("GAT", gat_graph), ("FMT", fmt)):
         if args.only and name not in args.only.split(","):
