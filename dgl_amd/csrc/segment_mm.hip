@@ -629,7 +629,7 @@ int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, 
                        dim3(256), 0, s, p, M);
   } else {
     const int64_t max_tiles = ((M + BM - 1) / BM + num_rel + 7) / 8 * 8;  // whole groups of 8 XCDs
-    const bool wide = N > 128;
+    const bool wide = N > 128;  // (fp32 too: 128-wide tiles measured 14.6 vs 11.6 ms at 10 M x 256 x 256)
     p.n_tiles = wide ? (N + 255) / 256 : 1;
     const int64_t blocks = max_tiles * p.n_tiles;
     if (blocks > 0x7fffffffLL) return mfail("segment_mm: too many tiles");
