@@ -16,7 +16,7 @@ from .heterograph import (DGLGraph, create_block, graph, heterograph, rand_bipar
 from . import sampling  # noqa: E402,F401
 from . import sparse  # noqa: E402,F401
 from .ops import edge_softmax  # noqa: E402,F401
-from .sampling import EID, NID, NeighborSampler  # noqa: E402,F401
+from .sampling import EID, NID, NeighborSampler, to_block  # noqa: E402,F401
 from .mm import gather_mm, segment_mm  # noqa: E402,F401
 from .segment import scatter_add, segment_reduce, segment_softmax  # noqa: E402,F401
 

@@ -36,16 +36,24 @@ def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, 
     """Frontier graph on the nodes of `g` holding, for every node in `nodes`, ``fanout`` of its
     inbound edges picked uniformly (all of them when it has fewer, or ``fanout == -1``).
     ``edata[dgl.EID]`` carries the original edge ids."""
-    if edge_dir != "in" or prob is not None:
-        raise NotImplementedError("dgl_amd.sampling: uniform sampling of inbound edges only")
+    if edge_dir not in ("in", "out"):
+        raise ValueError("edge_dir must be 'in' or 'out'")
+    if prob is not None:
+        raise NotImplementedError("dgl_amd.sampling: uniform sampling only")
     if len(g.canonical_etypes) != 1:
         raise NotImplementedError("dgl_amd.sampling: single-relation graphs only")
-    rel, csr, keep = _csc_of(g)
+    if edge_dir == "in":
+        rel, csr, keep = _csc_of(g)
+    else:  # outbound edges: the same kernel over the out-edge CSR (rows = source nodes)
+        rel = g._graph.relations[0]
+        keep = rel.csr()
+        csr = _capi.make_csr(keep[0], keep[1], keep[2], rel.num_dst)
     nodes = nodes.to(device=rel.device, dtype=rel.idtype).contiguous()
-    indptr, src, eids = _capi.sample_neighbors(csr, nodes, int(fanout), replace, int(seed))
+    indptr, nbr, eids = _capi.sample_neighbors(csr, nodes, int(fanout), replace, int(seed))
     n_e = int(indptr[-1])
-    dst = torch.repeat_interleave(nodes, (indptr[1:] - indptr[:-1]).long())
-    r = Relation(rel.num_src, rel.num_dst, src[:n_e].contiguous(), dst, idtype=rel.idtype, device=rel.device)
+    own = torch.repeat_interleave(nodes, (indptr[1:] - indptr[:-1]).long())
+    src, dst = (nbr[:n_e].contiguous(), own) if edge_dir == "in" else (own, nbr[:n_e].contiguous())
+    r = Relation(rel.num_src, rel.num_dst, src, dst, idtype=rel.idtype, device=rel.device)
     out = DGLGraph(GraphIndex([g.num_nodes()], [(0, 0)], [r]), ["_N"], [("_N", "_E", "_N")])
     out.edata[EID] = eids[:n_e]
     return out
@@ -56,6 +64,34 @@ def _make_block(indptr, local_src, num_src, num_dst, idtype, device):
     blk = DGLGraph(GraphIndex([num_src, num_dst], [(0, 1)], [rel]), ["_N", "_N"], [("_N", "_E", "_N")],
                    src_ntypes=[0], dst_ntypes=[1])
     blk.is_block = True
+    return blk
+
+
+def to_block(g, dst_nodes):
+    """``dgl.to_block`` for a homogeneous frontier graph (python/dgl/transforms/functional.py):
+    the block's destination nodes are ``dst_nodes`` in the given order and its source nodes start
+    with them (include_dst_in_src); ``srcdata / dstdata[dgl.NID]`` and ``edata[dgl.EID]`` map back
+    to ``g``.  Every edge of ``g`` must point at one of ``dst_nodes``."""
+    rel = g._graph.relations[0]
+    dev, idt = rel.device, rel.idtype
+    dst_nodes = dst_nodes.to(device=dev, dtype=idt).contiguous()
+    indptr, indices, eids = rel.csc()                       # rows = every node of g
+    deg = (indptr[1:] - indptr[:-1])[dst_nodes.long()]
+    if int(deg.sum()) != rel.num_edges:
+        raise ValueError("to_block: some edges of the frontier do not end in dst_nodes")
+    blk_ptr = torch.zeros(dst_nodes.shape[0] + 1, dtype=idt, device=dev)
+    blk_ptr[1:] = torch.cumsum(deg, 0)
+    # positions of the kept CSC entries, row by row in dst_nodes order
+    starts = indptr[:-1][dst_nodes.long()].long()
+    pos = torch.repeat_interleave(starts - blk_ptr[:-1].long(), deg.long()) + \
+        torch.arange(int(blk_ptr[-1]), device=dev)
+    src = indices[pos].contiguous()
+    local, src_nodes, num_src = _capi.to_block(dst_nodes, src, _node_map(g, dev))
+    blk = _make_block(blk_ptr, local, num_src, dst_nodes.shape[0], idt, dev)
+    blk.srcdata[NID] = src_nodes
+    blk.dstdata[NID] = dst_nodes
+    orig = eids[pos]
+    blk.edata[EID] = g.edata[EID][orig.long()] if EID in g.edata else orig
     return blk
 
 

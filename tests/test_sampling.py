@@ -150,3 +150,31 @@ def test_two_layer_sage_on_sampled_blocks_matches_dense(dev):
     assert not torch.equal(b2[1].edata[dgl.EID], blocks[1].edata[dgl.EID])
     _, _, b3 = dgl.NeighborSampler([15, 10], seed=3).sample_blocks(g, seeds)
     assert torch.equal(b3[1].edata[dgl.EID], blocks[1].edata[dgl.EID])
+
+
+def test_sample_neighbors_out_direction_and_to_block(dev):
+    """edge_dir='out' samples outbound edges through the out-edge CSR; dgl.to_block on the sampled
+    frontier gives the same block structure NeighborSampler builds (dst nodes first, ids map back)."""
+    import dgl_amd as dgl
+
+    g, src, dst = _graph(dev, torch.int64, n=1500, e=30000, seed=9)
+    seeds = torch.arange(0, 1500, 5, device=dev)
+    fo = dgl.sampling.sample_neighbors(g, seeds, 4, edge_dir="out", seed=5)
+    s, d = fo.edges()
+    eid = fo.edata[dgl.EID].long()
+    assert torch.equal(torch.from_numpy(src).to(dev)[eid], s) and torch.equal(torch.from_numpy(dst).to(dev)[eid], d)
+    outdeg = np.bincount(src, minlength=1500)
+    cnt = torch.bincount(s, minlength=1500).cpu().numpy()
+    assert (cnt[seeds.cpu().numpy()] == np.minimum(outdeg[seeds.cpu().numpy()], 4)).all() and cnt.sum() == len(s)
+    # inbound frontier -> block
+    fi = dgl.sampling.sample_neighbors(g, seeds, 6, seed=2)
+    blk = dgl.to_block(fi, seeds)
+    assert blk.num_dst_nodes() == seeds.numel() and torch.equal(blk.srcdata[dgl.NID][: seeds.numel()], seeds)
+    bs, bd = blk.edges()
+    fs, fd = fi.edges()
+    got = torch.stack([blk.srcdata[dgl.NID][bs.long()], blk.dstdata[dgl.NID][bd.long()], blk.edata[dgl.EID]])
+    want = torch.stack([fs, fd, fi.edata[dgl.EID]])
+    key = lambda t: t[:, torch.argsort(t[2])]
+    assert torch.equal(key(got), key(want))
+    with pytest.raises(ValueError, match="do not end in dst_nodes"):
+        dgl.to_block(fi, seeds[:10])
