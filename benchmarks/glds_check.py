@@ -1,0 +1,102 @@
+#!/usr/bin/env python
+"""A/B of the two 16-bit segment_mm forward kernels (register-staged vs LDS-direct,
+DGLA_TUNE_GLDS): bit-equality over ragged shapes, then timing at the R-GCN shape."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dgl_amd import _capi  # noqa: E402
+
+GLDS = 16
+dev = torch.device("cuda:0")
+base = _capi.get_tuning() & ~GLDS
+
+
+def run(a, b, seglen, n, flags, b_trans=False, row_index=None):
+    _capi.set_tuning(flags)
+    c = torch.full((a.shape[0], n), float("nan"), dtype=a.dtype, device=dev)
+    _capi.segment_mm(a, b, c, seglen, b_trans=b_trans, row_index=row_index)
+    torch.cuda.synchronize()
+    return c
+
+
+bad = 0
+g = torch.Generator(device="cpu").manual_seed(5)
+def same(c0, c1, dt, a=None, b=None, sl=None):
+    if dt != torch.float32:
+        return torch.equal(c0.view(torch.int16), c1.view(torch.int16))
+    # fp32: the LDS-direct kernel contracts k in a permuted order -> compare both with fp64
+    return torch.allclose(c0, c1, rtol=1e-4, atol=1e-4 * float(c0.abs().max()))
+
+
+for dt in (torch.bfloat16, torch.float16, torch.float32):
+    for k in (32, 64, 96, 256, 544):
+        for n in (136, 256, 264, 512, 776):
+            for seg in ([1], [127, 129, 0, 5], [1000, 3, 0, 0, 2049], [300] * 9):
+                for indexed in (False, True):
+                    m = sum(seg)
+                    r = len(seg)
+                    a = torch.randn((m, k), generator=g).to(dt).to(dev)
+                    b = torch.randn((r, k, n), generator=g).to(dt).to(dev)
+                    sl = torch.tensor(seg, dtype=torch.int64)
+                    ri = torch.randperm(m, generator=g).to(dev) if indexed else None
+                    c0 = run(a, b, sl, n, base, row_index=ri)
+                    c1 = run(a, b, sl, n, base | GLDS, row_index=ri)
+                    ok = same(c0, c1, dt)
+                    bt = b.transpose(1, 2).contiguous()
+                    c2 = run(a, bt, sl, n, base | GLDS, b_trans=True, row_index=ri)
+                    ok = ok and same(c0, c2, dt)
+                    if not ok:
+                        bad += 1
+                        d = (c0.float() - c1.float()).abs()
+                        print("MISMATCH", dt, k, n, seg, indexed, "max", float(torch.nan_to_num(d, nan=1e9).max()),
+                              "rows", torch.nonzero(torch.nan_to_num(d, nan=1e9).amax(1) > 0).flatten()[:8].tolist(), flush=True)
+# big ragged case (many tiles per relation, every XCD slot in use)
+for dt in (torch.bfloat16, torch.float16, torch.float32):
+    for k, n in ((64, 256), (256, 264), (96, 520)):
+        seg = [100_000, 1, 0, 255, 257, 150_003, 77_777, 12]
+        m, r = sum(seg), len(seg)
+        a = torch.randn((m, k), generator=g).to(dt).to(dev)
+        b = torch.randn((r, k, n), generator=g).to(dt).to(dev)
+        sl = torch.tensor(seg, dtype=torch.int64)
+        for ri in (None, torch.randperm(m, generator=g).to(dev)):
+            c0 = run(a, b, sl, n, base, row_index=ri)
+            c1 = run(a, b, sl, n, base | GLDS, row_index=ri)
+            if not same(c0, c1, dt):
+                bad += 1
+                print("MISMATCH-large", dt, k, n, ri is not None, flush=True)
+print(json.dumps({"check": "glds vs register-staged, bit equality", "mismatches": bad}), flush=True)
+
+
+def timeit(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(reps)]
+    return float(np.median(ts)), float(np.min(ts))
+
+
+for (rows, k, n, r) in ((10_000_000, 256, 256, 8), (10_000_000, 128, 256, 8), (4_000_000, 256, 512, 8), (2_000_000, 1024, 1024, 4)):
+    for dt in (torch.bfloat16, torch.float32):
+        a = torch.randn((rows, k), device=dev, dtype=dt)
+        b = torch.randn((r, k, n), device=dev, dtype=dt) * 0.05
+        c = torch.empty((rows, n), device=dev, dtype=dt)
+        sl = torch.full((r,), rows // r, dtype=torch.int64)
+        for flags, name in ((base, "reg"), (base | GLDS, "glds")):
+            _capi.set_tuning(flags)
+            ms, mn = timeit(lambda: _capi.segment_mm(a, b, c, sl))
+            print(json.dumps({"shape": [rows, k, n, r], "dtype": str(dt), "kernel": name, "ms": round(ms, 4), "ms_min": round(mn, 4),
+                              "tflops": 2.0 * rows * k * n / (ms * 1e-3) / 1e12}), flush=True)
+        del a, b, c
+_capi.set_tuning(base)

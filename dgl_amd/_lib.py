@@ -144,7 +144,7 @@ LIB.dgla_stream_copy_variant.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_
 DGLA_ACCUMULATE = 1
 DGLA_PLAN_VALID = 2
 DGLA_MEAN = 4
-DGLA_TUNE_XCD, DGLA_TUNE_NT_OUT, DGLA_TUNE_NT_IDX, DGLA_TUNE_SPLIT = 1, 2, 4, 8
+DGLA_TUNE_XCD, DGLA_TUNE_NT_OUT, DGLA_TUNE_NT_IDX, DGLA_TUNE_SPLIT, DGLA_TUNE_GLDS = 1, 2, 4, 8, 16
 
 
 def check_call(ret):

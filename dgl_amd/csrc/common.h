@@ -176,11 +176,13 @@ enum Tune : uint32_t {
   kTuneNtOut = 2u,  // non-temporal stores of finished output rows
   kTuneNtIdx = 4u,  // non-temporal loads of the index streams (indices / indptr / eids)
   kTuneSplit = 8u,  // split-row re-layout of ufeat when rows are not a whole number of 128-B lines
+  kTuneGlds = 16u,  // segment_mm: LDS-direct (global_load_lds) slab rings instead of register staging
 };
 // Default: XCD-contiguous order (measured on C2: variant L -3 % time, variant U neutral); the
 // non-temporal bits are neutral and split-row trades a 0.49 ms copy for a 0.51 ms faster gather
-// on variant U but loses on variant L (profiles/r1/tune_ab.jsonl) -> opt-in.
-constexpr uint32_t kDefaultTuning = 1u;
+// on variant U but loses on variant L (profiles/r1/tune_ab.jsonl) -> opt-in.  The LDS-direct
+// segment_mm loop is 23-34 % faster at every measured shape (profiles/r1/glds_ab.jsonl) -> on.
+constexpr uint32_t kDefaultTuning = 1u | 16u;
 uint32_t& tuning_flags();
 
 // Merge-path geometry of the CSR SpMM (see spmm_csr.cuh).

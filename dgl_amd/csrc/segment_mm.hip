@@ -48,6 +48,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- plan: tiles per relation ---------------------------------------------------------
 // plan[0 .. R]        exclusive prefix of ceil(len / rows_per_tile)
@@ -168,6 +169,7 @@ struct MmParams {
   int vec_c;         // 16-byte stores of C rows allowed (alignment + N % E == 0)
   const int64_t* row_index;  // optional: logical row r of A and C lives at physical row row_index[r]
   int64_t n_tiles;   // ceil(N / BN)
+  uint32_t tune;     // kTune* bits
 };
 
 // ---- forward: C_r = A_r . Bt_r^T ----------------------------------------------------------
@@ -326,6 +328,252 @@ __global__ __launch_bounds__(256, 2) void segment_mm_kernel(const MmParams p) {
         if (row < row_end) C[(p.row_index ? p.row_index[row] : row) * N + col] = from_acc<DT>(acc[i][jj][r]);
       }
     }
+}
+
+// ---- forward, LDS-direct variant (16-bit and fp32 storage, K a whole number of 64-byte slabs):
+// the default for those shapes.  Same tile and MFMAs as segment_mm_kernel<DT, TBN, true>, but
+// the operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, 180 instead of
+// 238 VGPRs) into two rings of 64-byte-per-row slabs: NA = 6 slots for A (the operand that
+// comes from HBM: 5 slabs = 40 KB per workgroup always in flight) and NB = 2 for the weights
+// (L2 hits: one slab of lead is enough).  80 KB of LDS per workgroup = 2 workgroups per CU.
+// The K-loop never drains the memory pipe: one raw s_barrier per slab with a counted
+// s_waitcnt vmcnt(n) that lets every load issued after the needed weight slab stay outstanding.
+// The register-staged kernel is latency-bound (69 % of wave time parked, profiles/r1/
+// pmc_segment_mm_bf16.json); measured on MI355X (profiles/r1/glds_ab.jsonl), 8 relations:
+//   10 M x 256 x 256 bf16   3.79 -> 2.58 ms (509 TFLOP/s; per-relation vendor GEMM loop 2.93)
+//   10 M x 128 x 256 bf16   2.76 -> 1.81 ms      2 M x 1024 x 1024 bf16  7.06 -> 4.99 ms (840 TF)
+//   10 M x 256 x 256 fp32  15.85 -> 12.2 ms      16-bit results bit-identical to the other kernel
+// Ring depths tried: one 3-deep ring for both operands 2.90 ms, (NA, NB) = (4, 3) 2.65 ms,
+// (6, 2) 2.58 ms; 256-row tiles with 512 threads (half the weight traffic, 1 workgroup per CU)
+// 3.07 ms; non-temporal A loads +13 % time.
+//  * LDS layout: rows x 64 B, no padding — the DMA writes lane l at base + 16 l, i.e. 16 rows
+//    x 4 chunks per instruction.  Bank conflicts are avoided by a chunk swizzle applied on the
+//    SOURCE side: physical chunk c of row r holds logical chunk c ^ ((r >> 2) & 3), so the 16
+//    lanes a ds_read_b128 serves together (rows 4a + b) hit 16 distinct 16-byte bank groups.
+//  * Rows past the end of a segment / of the weight matrix are clamped to the last valid row:
+//    their products land in accumulator rows / columns that are never stored.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
+
+constexpr int kGldsSlabBytes = 64;  // bytes of K per tile row and slab (32 16-bit / 16 fp32 elements)
+
+template <typename DT, int TBN, int BMT, int NA, int NB>  // BMT x TBN output tile, 2 * BMT threads
+__global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(const MmParams p) {
+  using M = Mma<DT>;
+  constexpr int ES = sizeof(DT);  // 2: 32x32x16 MFMAs, LDS-staged epilogue; 4: 32x32x2 MFMAs, direct stores
+  static_assert(ES == 2 || ES == 4, "16-bit and fp32 storage");
+  static_assert(NA >= NB && NB >= 2, "A ring at least as deep as the weight ring");
+  constexpr int NJ = TBN / 64;
+  constexpr int NT = 2 * BMT, NW = NT / 64;   // threads, waves (one wave per 64 x TBN/2 of C)
+  constexpr int kASlab = BMT * 64, kBSlab = TBN * 64;  // bytes of one slab of each operand
+  constexpr int nA = kASlab / 1024 / NW, nB = kBSlab / 1024 / NW;  // DMA instructions per wave and slab
+  static_assert(nA * NW * 1024 == kASlab && nB * NW * 1024 == kBSlab, "whole DMA instructions per wave");
+  constexpr int kBBase = NA * kASlab;
+  constexpr int kCPitch = TBN * 2 + 16;
+  static_assert(64 * kCPitch <= NA * kASlab + NB * kBSlab, "half a C tile must fit");
+  __shared__ __attribute__((aligned(1024))) char smem[NA * kASlab + NB * kBSlab];
+
+  const int64_t* tile_off = p.plan;
+  const int64_t* row_off = p.plan + p.num_rel + 1;
+  const int K = p.K, N = p.N;
+  const int64_t L = blockIdx.x;
+  const int64_t j = L >> 3;
+  const int64_t tile = (j / p.n_tiles) * 8 + (L & 7);
+  const int n0 = static_cast<int>(j % p.n_tiles) * TBN;
+  if (tile >= tile_off[p.num_rel]) return;
+  const int64_t rel = find_segment(tile_off, p.num_rel, tile);
+  const int64_t row0 = row_off[rel] + (tile - tile_off[rel]) * BMT;
+  const int64_t row_end = row_off[rel + 1];
+
+  const char* __restrict__ A = static_cast<const char*>(p.a);
+  const char* __restrict__ Bt = static_cast<const char*>(p.bt) + rel * static_cast<int64_t>(N) * K * ES;
+  DT* __restrict__ C = static_cast<DT*>(p.c);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = lane & 31, khalf = lane >> 5;
+
+  // Source of this lane for each of the wave's DMA instructions per slab: instruction q of an
+  // operand fills its tile rows 16 q .. 16 q + 15; the lane owns row 16 q + (lane >> 2),
+  // physical chunk lane & 3.
+  const int src_chunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const char* srcA[nA];
+  const char* srcB[nB];
+#pragma unroll
+  for (int i = 0; i < nA; ++i) {
+    int64_t ar = row0 + (wave * nA + i) * 16 + (lane >> 2);
+    if (ar >= row_end) ar = row_end - 1;
+    if (p.row_index) ar = p.row_index[ar];
+    srcA[i] = A + ar * K * ES + src_chunk * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < nB; ++i) {
+    int bn = n0 + (wave * nB + i) * 16 + (lane >> 2);
+    if (bn >= N) bn = N - 1;
+    srcB[i] = Bt + static_cast<int64_t>(bn) * K * ES + src_chunk * 16;
+  }
+  const bool nt_c = (p.tune & kTuneNtOut) != 0;
+  const int nslab = K * ES / kGldsSlabBytes;
+  auto issue_a = [&](int t) {  // slab t of A -> ring slot t % NA
+    if (t >= nslab) return;
+    char* dst = smem + (t % NA) * kASlab + wave * (nA * 1024);
+#pragma unroll
+    for (int i = 0; i < nA; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(srcA[i] + static_cast<int64_t>(t) * kGldsSlabBytes),
+                                       (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+  };
+  auto issue_b = [&](int t) {  // slab t of the weights -> ring slot t % NB
+    if (t >= nslab) return;
+    char* dst = smem + kBBase + (t % NB) * kBSlab + wave * (nB * 1024);
+#pragma unroll
+    for (int i = 0; i < nB; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(srcB[i] + static_cast<int64_t>(t) * kGldsSlabBytes),
+                                       (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+  };
+  // Iteration i (also the prologue iterations i < 0) issues [weights slab i + NB - 1, A slab
+  // i + NA - 1], so the loads of this wave still allowed in flight when slab t is needed are
+  // those issued after weights slab t: the A slab of that iteration and all of the NB - 2
+  // iterations after it.  vmcnt retires in order, so A slab t (issued earlier) is done too.
+  auto issued_a = [&](int i) { return (i + NA - 1 >= 0 && i + NA - 1 < nslab) ? nA : 0; };
+  auto issued_b = [&](int i) { return (i + NB - 1 >= 0 && i + NB - 1 < nslab) ? nB : 0; };
+  auto wait_for_slab = [&](int t) {
+    int allowed = issued_a(t - NB + 1);
+#pragma unroll
+    for (int i = 2; i < NB; ++i) allowed += issued_a(t - NB + i) + issued_b(t - NB + i);
+    switch (allowed) {  // s_waitcnt takes an immediate: vmcnt in bits 3:0 (values < 16)
+      case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+      case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
+      case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+      case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
+      case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+      case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
+      case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
+      case 7: __builtin_amdgcn_s_waitcnt(0x0F77); break;
+      case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
+      case 9: __builtin_amdgcn_s_waitcnt(0x0F79); break;
+      case 10: __builtin_amdgcn_s_waitcnt(0x0F7A); break;
+      case 11: __builtin_amdgcn_s_waitcnt(0x0F7B); break;
+      case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
+      default: __builtin_amdgcn_s_waitcnt(0x0F70); break;  // never looser than needed
+    }
+  };
+  static_assert(nA + (NB - 2) * (nA + nB) <= 12, "extend the vmcnt switch");
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+  // fragment addresses inside a slab (swizzled chunk per k-step)
+  const int swz = (lrow >> 2) & 3;
+  const int a_off = (wm * 64 + lrow) * 64;
+  const int b_off = kBBase + (wn * (TBN / 2) + lrow) * 64;
+
+#pragma unroll
+  for (int i = 1 - NA; i < 0; ++i) {  // prologue iterations
+    issue_b(i + NB - 1 >= 0 ? i + NB - 1 : nslab);
+    issue_a(i + NA - 1);
+  }
+  for (int t = 0; t < nslab; ++t) {
+    wait_for_slab(t);  // this wave's pieces of slab t have landed ...
+    __builtin_amdgcn_s_barrier();  // ... and everybody's; slab t - 1 has been consumed by all
+    issue_b(t + NB - 1);  // into the slots slab t - 1 was multiplied from
+    issue_a(t + NA - 1);
+    const char* bufa = smem + (t % NA) * kASlab;
+    const char* bufb = smem + (t % NB) * kBSlab;
+    if constexpr (ES == 2) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {  // two k-steps of 16 elements
+        const int chunk = ((s * 2 + khalf) ^ swz) * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const char* sa = bufa + a_off + i * 32 * 64 + chunk;
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) {
+            const char* sb = bufb + b_off + jj * 32 * 64 + chunk;
+            M::step(sa, sb, 0, 0, acc[i][jj]);
+          }
+        }
+      }
+    } else {
+      // fp32: a lane reads 4 consecutive k of its row in one ds_read_b128 (chunk 2u + khalf) and
+      // feeds them to 4 MFMAs; the MFMA's k = 0 / 1 halves are then k = 8u + j and 8u + 4 + j —
+      // the same permutation of the contraction index for both operands.
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int chunk = ((u * 2 + khalf) ^ swz) * 16;
+        f32x4 fa[2], fb[NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(bufa + a_off + i * 32 * 64 + chunk);
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) fb[jj] = *reinterpret_cast<const f32x4*>(bufb + b_off + jj * 32 * 64 + chunk);
+#pragma unroll
+        for (int jk = 0; jk < 4; ++jk)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+              acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][jk], fb[jj][jk], acc[i][jj], 0, 0, 0);
+      }
+    }
+  }
+
+  if constexpr (ES == 4) {
+    // fp32: a half-wave owns 32 consecutive columns of one row = one 128-byte line per store
+    const int rb = 4 * khalf;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int col = n0 + wn * (TBN / 2) + jj * 32 + lrow;
+        if (col >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rb;
+          if (row < row_end) C[(p.row_index ? p.row_index[row] : row) * N + col] = acc[i][jj][r];
+        }
+      }
+    return;
+  }
+
+  // epilogue: as in segment_mm_kernel (LDS-staged 16-byte row pieces)
+  const int rbase = 4 * khalf;
+  constexpr int CPR = TBN * 2 / 16;
+#pragma unroll
+  for (int half = 0; half < BMT / 64; ++half) {
+    __syncthreads();
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+            const int col = wn * (TBN / 2) + jj * 32 + lrow;
+            *reinterpret_cast<DT*>(smem + row * kCPitch + col * ES) = from_acc<DT>(acc[i][jj][r]);
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 64 * CPR / NT; ++h) {
+      const int pidx = tid + NT * h;
+      const int row = pidx / CPR, chunk = pidx % CPR;
+      const int64_t grow = row0 + half * 64 + row;
+      const int col = n0 + chunk * 8;
+      if (grow < row_end && col < N) {
+        u32x4* dstp = reinterpret_cast<u32x4*>(C + (p.row_index ? p.row_index[grow] : grow) * N + col);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * kCPitch + chunk * 16);
+        if (nt_c)
+          __builtin_nontemporal_store(v, dstp);
+        else
+          *dstp = v;
+      }
+    }
+  }
 }
 
 // fp64 (and any shape the MFMA path does not take): one thread per output element.
@@ -595,9 +843,22 @@ int mm_num_cus() {
   return cus;
 }
 
+// LDS-direct forward kernel: 16-bit storage, whole 16-byte pieces, K a multiple of the slab.
+bool glds_eligible(size_t elem, int64_t K, int64_t N, bool vec) {
+  return (elem == 2 || elem == 4) && vec && (K * elem) % kGldsSlabBytes == 0 && (tuning_flags() & kTuneGlds);
+}
+
+// Rows per forward tile: 256-row tiles (512 threads) halve the weight traffic L2 -> CU; taken
+// when the LDS-direct kernel runs, the output is wide and there are tiles enough to fill the chip.
+int fwd_rows_per_tile(size_t elem, const void* a, const void* b, const void* c, int64_t M, int64_t K,
+                      int64_t N, bool b_trans) {
+  const bool vec = K % 8 == 0 && N % 8 == 0 && aligned16(a) && aligned16(c) && (!b_trans || aligned16(b));
+  return BM;
+}
+
 template <typename DT>
 int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, int64_t N,
-                   int64_t num_rel, bool b_trans, const int64_t* row_index, char* ws,
+                   int64_t num_rel, bool b_trans, const int64_t* row_index, int rows_per_tile, char* ws,
                    const MmScratch& sc, hipStream_t s) {
   // Bt = [R, N, K]: the weights with the contraction axis contiguous
   const void* bt = b;
@@ -623,6 +884,7 @@ int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, 
   p.vec_c = (N % E == 0 && aligned16(c)) ? 1 : 0;
   p.row_index = row_index;
   p.n_tiles = 1;
+  p.tune = tuning_flags();
   if constexpr (sizeof(DT) == 8) {
     const int64_t total = M * N;
     hipLaunchKernelGGL((segment_mm_plain_kernel<DT>), dim3(static_cast<unsigned>((total + 255) / 256)),
@@ -635,6 +897,16 @@ int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, 
     if (blocks > 0x7fffffffLL) return mfail("segment_mm: too many tiles");
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
     const bool vec = p.vec_a && p.vec_b && p.vec_c;
+    {
+      if (glds_eligible(sizeof(DT), K, N, p.vec_a && p.vec_b && p.vec_c)) {
+        if (wide)
+          hipLaunchKernelGGL((segment_mm_glds_kernel<DT, 256, 128, 6, 2>), grid, block, 0, s, p);
+        else
+          hipLaunchKernelGGL((segment_mm_glds_kernel<DT, 128, 128, 6, 2>), grid, block, 0, s, p);
+        DGLA_CHECK_HIP(hipGetLastError());
+        return 0;
+      }
+    }
     if (wide && vec)
       hipLaunchKernelGGL((segment_mm_kernel<DT, 256, true>), grid, block, 0, s, p);
     else if (wide)
@@ -752,13 +1024,14 @@ int dgla_segment_mm_indexed(int idtype_bits, dgla_dtype dtype, const void* a, co
     workspace = owned;
   }
   char* ws = static_cast<char*>(workspace);
-  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, BM, ws, sc, s);
+  const int rpt = fwd_rows_per_tile(elem, a, b, c, num_rows, k, n, b_trans != 0);
+  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, rpt, ws, sc, s);
   if (rc == 0) {
     switch (dtype) {
-      case DGLA_F32: rc = run_segment_mm<float>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
-      case DGLA_F64: rc = run_segment_mm<double>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
-      case DGLA_F16: rc = run_segment_mm<f16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
-      case DGLA_BF16: rc = run_segment_mm<bf16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
+      case DGLA_F32: rc = run_segment_mm<float>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, rpt, ws, sc, s); break;
+      case DGLA_F64: rc = run_segment_mm<double>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, rpt, ws, sc, s); break;
+      case DGLA_F16: rc = run_segment_mm<f16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, rpt, ws, sc, s); break;
+      case DGLA_BF16: rc = run_segment_mm<bf16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, rpt, ws, sc, s); break;
     }
   }
   if (owned) (void)hipFreeAsync(owned, s);

@@ -302,11 +302,16 @@ int dgla_partition_kway(int idtype_bits, int64_t num_nodes, const void* indptr,
  *                     400 B = 4 lines touched per gather) the call first copies ufeat into a
  *                     line-aligned main array + a dense tail array inside the workspace and
  *                     gathers from those (3 lines + one cached access per edge)
+ *   DGLA_TUNE_GLDS    dgla_segment_mm / dgla_gather_mm, 16-bit and fp32 storage, K a whole number
+ *                     of 64-byte slabs: operands go global -> LDS directly (global_load_lds,
+ *                     slab rings) instead of through registers; 16-bit results bit-identical,
+ *                     fp32 contracts k in a permuted order (default on)
  * The reference has no counterpart (its kernels take no hints). */
 #define DGLA_TUNE_XCD 1u
 #define DGLA_TUNE_NT_OUT 2u
 #define DGLA_TUNE_NT_IDX 4u
 #define DGLA_TUNE_SPLIT 8u
+#define DGLA_TUNE_GLDS 16u
 int dgla_set_tuning(uint32_t flags);
 uint32_t dgla_get_tuning(void);
 

@@ -578,7 +578,7 @@ def test_spmm_tuning_bits_do_not_change_results(dev, feat, tdtype, op, reduce):
     results = {}
     default = _capi.get_tuning()
     try:
-        for flags in (0, 1, 2, 4, 8, 15):
+        for flags in (0, 1, 2, 4, 8, 15, 31):
             _capi.set_tuning(flags)
             assert _capi.get_tuning() == flags
             out = torch.full((n_dst, feat), -3.0, dtype=tdtype, device=dev)

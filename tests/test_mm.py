@@ -55,7 +55,8 @@ SEGLENS = {
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16, torch.float64])
 @pytest.mark.parametrize("kind", list(SEGLENS))
-@pytest.mark.parametrize("d1,d2", [(16, 32), (256, 256), (100, 36), (7, 130), (33, 1)])
+@pytest.mark.parametrize("d1,d2", [(16, 32), (256, 256), (100, 36), (7, 130), (33, 1), (32, 200),
+                                   (96, 128), (160, 264)])
 @pytest.mark.parametrize("seglen_dev", ["cpu", "gpu"])
 def test_segment_mm_forward(dev, dtype, kind, d1, d2, seglen_dev):
     from dgl_amd import mm
@@ -110,6 +111,46 @@ def test_mfma_layout_identity(dev):
         c = torch.empty(k, 192, dtype=dtype, device=dev)
         mm._segment_mm(a, b, c, torch.tensor([k]))
         assert torch.equal(c, b[0]), dtype
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("k", [16, 32, 64, 96, 256, 544])
+@pytest.mark.parametrize("n", [64, 136, 256, 264, 776])
+def test_lds_direct_kernel_matches_register_staged(dev, dtype, k, n):
+    """DGLA_TUNE_GLDS picks the global_load_lds K-loop when K is a whole number of 64-byte
+    slabs.  16-bit storage: same MFMAs in the same k order, so the BITS must equal the
+    register-staged kernel's; fp32: k is contracted in a permuted order, so agreement is to
+    rounding.  Ragged segments, clamped tail rows / columns, row-indexed (gather_mm) access."""
+    from dgl_amd import _capi
+    from dgl_amd._lib import DGLA_TUNE_GLDS
+
+    default = _capi.get_tuning()
+    assert default & DGLA_TUNE_GLDS, "LDS-direct kernel is the default"
+    g = torch.Generator().manual_seed(k * 31 + n)
+    try:
+        for seg in ([1], [127, 129, 0, 5], [1000, 3, 0, 0, 2049], [300] * 5):
+            m, r = sum(seg), len(seg)
+            a = torch.randn((m, k), generator=g).to(dtype).to(dev)
+            b = torch.randn((r, k, n), generator=g).to(dtype).to(dev)
+            bt = b.transpose(1, 2).contiguous()
+            sl = torch.tensor(seg, dtype=torch.int64)
+            for ri in (None, torch.randperm(m, generator=g).to(dev)):
+                got = []
+                for flags, w, tr in ((default & ~DGLA_TUNE_GLDS, b, False), (default, b, False), (default, bt, True)):
+                    _capi.set_tuning(flags)
+                    c = torch.full((m, n), float("nan"), dtype=dtype, device=dev)
+                    _capi.segment_mm(a, w, c, sl, b_trans=tr, row_index=ri)
+                    got.append(c)
+                assert not torch.isnan(got[0]).any()
+                for c in got[1:]:
+                    assert not torch.isnan(c).any()
+                    if dtype == torch.float32:
+                        mag = a.abs() @ b.abs().amax(0)  # >= sum_k |a||b| of every relation
+                        assert ((c - got[0]).abs() <= 8 * k ** 0.5 * 2.0 ** -24 * mag + 1e-30).all(), (seg, ri is not None)
+                    else:
+                        assert torch.equal(c.view(torch.int16), got[0].view(torch.int16)), (seg, ri is not None)
+    finally:
+        _capi.set_tuning(default)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
