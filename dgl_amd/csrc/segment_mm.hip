@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256, 2) void segment_mm_kernel(const MmParams p) {
 //   10 M x 256 x 256 fp32  15.85 -> 12.2 ms      16-bit results bit-identical to the other kernel
 // Ring depths tried: one 3-deep ring for both operands 2.90 ms, (NA, NB) = (4, 3) 2.65 ms,
 // (6, 2) 2.58 ms; 256-row tiles with 512 threads (half the weight traffic, 1 workgroup per CU)
-// 3.07 ms; non-temporal A loads +13 % time.
+// 3.07 ms; non-temporal A loads +13 % time; delaying every other workgroup of the first wave by
+// 16-160 k cycles (to de-phase the two workgroups of a CU) +-0.
 //  * LDS layout: rows x 64 B, no padding — the DMA writes lane l at base + 16 l, i.e. 16 rows
 //    x 4 chunks per instruction.  Bank conflicts are avoided by a chunk swizzle applied on the
 //    SOURCE side: physical chunk c of row r holds logical chunk c ^ ((r >> 2) & 3), so the 16
