@@ -100,3 +100,43 @@ for (rows, k, n, r) in ((10_000_000, 256, 256, 8), (10_000_000, 128, 256, 8), (4
                               "tflops": 2.0 * rows * k * n / (ms * 1e-3) / 1e12}), flush=True)
         del a, b, c
 _capi.set_tuning(base)
+
+# ---- weight gradient: LDS-direct (transposing LDS reads) vs register-staged --------------------
+bad = 0
+for dt in (torch.bfloat16, torch.float16):
+    for d1, d2 in ((8, 8), (64, 128), (256, 256), (136, 72), (520, 264)):
+        for seg in ([1], [127, 129, 0, 5], [5000, 3, 0, 0, 2049], [40000, 17]):
+            m, r = sum(seg), len(seg)
+            a = torch.randn((m, d1), generator=g).to(dt).to(dev)
+            dc = torch.randn((m, d2), generator=g).to(dt).to(dev)
+            sl = torch.tensor(seg, dtype=torch.int64)
+            outs = []
+            for flags in (base, base | GLDS):
+                _capi.set_tuning(flags)
+                db = torch.full((r, d1, d2), float("nan"), dtype=dt, device=dev)
+                _capi.segment_mm_backward_b(a, dc, db, sl)
+                torch.cuda.synchronize()
+                outs.append(db.float())
+            off, want = 0, torch.zeros((r, d1, d2), device=dev)
+            for i, n_ in enumerate(seg):
+                want[i] = a[off:off + n_].float().T @ dc[off:off + n_].float()
+                off += n_
+            tol = (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10) * want.abs().clamp_min(1.0) + 1e-3 * max(seg) ** 0.5
+            for name, o in zip(("reg", "glds"), outs):
+                if not bool(((o - want).abs() <= tol).all()):
+                    bad += 1
+                    print("MISMATCH dB", name, dt, d1, d2, seg, float((o - want).abs().max()), flush=True)
+print(json.dumps({"check": "weight gradient vs fp32 torch, both kernels", "mismatches": bad}), flush=True)
+for (rows, d1, d2, r) in ((10_000_000, 256, 256, 8), (10_000_000, 128, 256, 8), (4_000_000, 512, 512, 8)):
+    dt = torch.bfloat16
+    a = torch.randn((rows, d1), device=dev, dtype=dt)
+    dc = torch.randn((rows, d2), device=dev, dtype=dt)
+    db = torch.empty((r, d1, d2), device=dev, dtype=dt)
+    sl = torch.full((r,), rows // r, dtype=torch.int64)
+    for flags, name in ((base, "reg"), (base | GLDS, "glds")):
+        _capi.set_tuning(flags)
+        ms, mn = timeit(lambda: _capi.segment_mm_backward_b(a, dc, db, sl))
+        print(json.dumps({"dB shape": [rows, d1, d2, r], "kernel": name, "ms": round(ms, 4), "ms_min": round(mn, 4),
+                          "tflops": 2.0 * rows * d1 * d2 / (ms * 1e-3) / 1e12}), flush=True)
+    del a, dc, db
+_capi.set_tuning(base)

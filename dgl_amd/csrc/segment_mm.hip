@@ -921,6 +921,185 @@ int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, 
   return 0;
 }
 
+// ---- weight gradient, LDS-direct variant (16-bit storage, contiguous rows) ------------------
+// Same split-K slabs, 128 x 128 output tile and fp32 atomics as segment_mm_bwd_b_kernel, but the
+// operands are NOT transposed on their way into LDS: global_load_lds_dwordx4 copies 32 rows of
+// A and dC (256 bytes = 128 features each) per slab into a ring of NS 16 KB slots, and the MFMA
+// fragments — lane <-> feature, registers <-> consecutive contraction rows — are read with
+// ds_read_b64_tr_b16, gfx950's transposing LDS load.  Measured semantics (one 16-lane group):
+// lane l receives halfword (l & 3) at the addresses supplied by lanes (l >> 2) + 4 j, j = 0..3.
+// So lane s supplies row (s >> 2), feature quad (s & 3) of a 4-row x 16-feature block and
+// every lane gets ITS feature at 4 consecutive rows.  Contraction index of register j of the
+// j2-th read in MFMA k-half kh: row 16 kk + 8 j2 + 4 kh + j — the same on both operands.
+//  * LDS rows are unpadded (lane-linear DMA); the 32-byte unit holding features 16 u .. 16 u + 15
+//    of row r sits at physical unit u ^ (r & 7), applied to the per-lane SOURCE address and to
+//    the fragment reads, so the 8 rows one read touches fall into distinct bank groups.
+//  * Rows past the end of the slab read a zero page; feature chunks past the width are clamped
+//    (their outputs are never stored).
+__device__ __attribute__((aligned(256))) char g_mm_zero_page[256];
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int kBwdGldsRows = 32;  // contraction rows per ring slot
+
+template <typename DT>
+__device__ __forceinline__ void mfma16(const s16x4 alo, const s16x4 ahi, const s16x4 blo, const s16x4 bhi,
+                                       f32x16& acc) {
+  const s16x8 a = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+  const s16x8 b = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+  if constexpr (std::is_same<DT, bf16_t>::value)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, a), __builtin_bit_cast(b16x8, b), acc, 0, 0, 0);
+  else
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), acc, 0, 0, 0);
+}
+
+template <typename DT, int NS>
+__global__ __launch_bounds__(256, NS >= 4 ? 2 : (NS == 3 ? 3 : 4)) void segment_mm_bwd_b_glds_kernel(const MmBwdParams p) {
+  static_assert(sizeof(DT) == 2, "16-bit storage");
+  constexpr int kPart = kBwdGldsRows * 256;  // one operand of a slot: 32 rows x 128 features
+  constexpr int kSlot = 2 * kPart;
+  constexpr int kLoads = 4;                  // DMA instructions per wave and slot (2 per operand)
+  __shared__ __attribute__((aligned(1024))) char smem[NS * kSlot];
+
+  const int64_t L = blockIdx.x;
+  const int64_t jd = L >> 3;
+  const int tiles = p.tiles_i * p.tiles_j;
+  const int64_t slab = (jd / tiles) * 8 + (L & 7);
+  const int tile = static_cast<int>(jd % tiles);
+  const int64_t* slab_off = p.plan;
+  const int64_t* row_off = p.plan + p.num_rel + 1;
+  if (slab >= slab_off[p.num_rel]) return;
+  const int64_t rel = find_segment(slab_off, p.num_rel, slab);
+  const int64_t m0 = row_off[rel] + (slab - slab_off[rel]) * p.slab_rows;
+  int64_t m1 = m0 + p.slab_rows;
+  if (m1 > row_off[rel + 1]) m1 = row_off[rel + 1];
+  const int i0 = (tile / p.tiles_j) * BM, j0 = (tile % p.tiles_j) * BN;
+  const int D1 = p.D1, D2 = p.D2;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // DMA sources.  Instruction n (0, 1) of a wave covers slot rows 8 wave + 4 n .. + 3 of one
+  // operand: lane -> row + (lane >> 4), physical 16-byte chunk lane & 15.
+  const int l16 = lane & 15;
+  int drow[2];
+  int64_t offA[2], offC[2];  // byte offset of the lane's piece from the operand's row m0
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int r = 8 * wave + 4 * n + (lane >> 4);
+    drow[n] = r;
+    const int unit = (l16 >> 1) ^ (r & 7);
+    const int chunk = (unit << 1) | (l16 & 1);
+    int fa = i0 + chunk * 8, fc = j0 + chunk * 8;
+    if (fa >= D1) fa = D1 - 8;
+    if (fc >= D2) fc = D2 - 8;
+    offA[n] = (static_cast<int64_t>(r) * D1 + fa) * 2;
+    offC[n] = (static_cast<int64_t>(r) * D2 + fc) * 2;
+  }
+  const char* __restrict__ baseA = static_cast<const char*>(p.a) + m0 * D1 * 2;
+  const char* __restrict__ baseC = static_cast<const char*>(p.dc) + m0 * D2 * 2;
+  const int64_t rows = m1 - m0;
+  const int nsl = static_cast<int>((rows + kBwdGldsRows - 1) / kBwdGldsRows);
+  auto issue = [&](int t) {
+    if (t >= nsl) return;
+    char* dst = smem + (t % NS) * kSlot + wave * 2048;
+    const int64_t mrow = static_cast<int64_t>(t) * kBwdGldsRows;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const bool in = mrow + drow[n] < rows;
+      const char* sa = in ? baseA + mrow * D1 * 2 + offA[n] : g_mm_zero_page;
+      const char* sc = in ? baseC + mrow * D2 * 2 + offC[n] : g_mm_zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)sa, (lds_ptr_t)(dst + n * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)sc, (lds_ptr_t)(dst + kPart + n * 1024), 16, 0, 0);
+    }
+  };
+  auto wait_for_slot = [&](int t) {  // slots issued after slot t so far: t + 1 .. min(t + NS - 2, nsl - 1)
+    int later = nsl - 1 - t;
+    if (later > NS - 2) later = NS - 2;
+    switch (later) {
+      case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+      case 1: __builtin_amdgcn_s_waitcnt(0x0F70 | (1 * kLoads)); break;
+      case 2: __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * kLoads)); break;
+      case 3: __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * kLoads)); break;
+      default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    }
+  };
+  static_assert(NS >= 2 && NS <= 5, "vmcnt switch covers up to 3 slots in flight behind the needed one");
+
+  // fragment addresses: lane = (kh, ih, s): feature 16 ih + (its own), rows 4 kh + (s >> 2) + ...
+  const int s4 = lane & 15, ih = (lane >> 4) & 1, kh = lane >> 5;
+  const int r7 = 4 * kh + (s4 >> 2);
+  int fa_off[2], fb_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ua = ((wm * 2 + i) * 2 + ih) ^ r7;
+    const int ub = ((wn * 2 + i) * 2 + ih) ^ r7;
+    fa_off[i] = r7 * 256 + ua * 32 + 8 * (s4 & 3);
+    fb_off[i] = kPart + r7 * 256 + ub * 32 + 8 * (s4 & 3);
+  }
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_ptr_t)smem));
+
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i) issue(i);
+  for (int t = 0; t < nsl; ++t) {
+    wait_for_slot(t);
+    __builtin_amdgcn_s_barrier();
+    issue(t + NS - 1);
+    // The 8 transposing reads of one k-step and their lgkmcnt wait are ONE asm statement: with the
+    // builtin, hipcc (ROCm 7.2) cannot tell the reads from the in-flight LDS-DMA writes and puts
+    // s_waitcnt vmcnt(0) in front of them, which would drain the ring every iteration.
+    const uint32_t slot = lds_base + (t % NS) * kSlot;
+    const uint32_t pa0 = slot + fa_off[0], pa1 = slot + fa_off[1], pb0 = slot + fb_off[0], pb1 = slot + fb_off[1];
+    s16x4 a00, a01, a10, a11, b00, b01, b10, b11;
+#define DGLA_TR_READS(O0, O1)                                                                       \
+  asm volatile("ds_read_b64_tr_b16 %0, %8 offset:" #O0 "\n\t"                                        \
+               "ds_read_b64_tr_b16 %1, %8 offset:" #O1 "\n\t"                                        \
+               "ds_read_b64_tr_b16 %2, %9 offset:" #O0 "\n\t"                                        \
+               "ds_read_b64_tr_b16 %3, %9 offset:" #O1 "\n\t"                                        \
+               "ds_read_b64_tr_b16 %4, %10 offset:" #O0 "\n\t"                                       \
+               "ds_read_b64_tr_b16 %5, %10 offset:" #O1 "\n\t"                                       \
+               "ds_read_b64_tr_b16 %6, %11 offset:" #O0 "\n\t"                                       \
+               "ds_read_b64_tr_b16 %7, %11 offset:" #O1 "\n\t"                                       \
+               "s_waitcnt lgkmcnt(0)"                                                                \
+               : "=&v"(a00), "=&v"(a01), "=&v"(a10), "=&v"(a11), "=&v"(b00), "=&v"(b01), "=&v"(b10),  \
+                 "=&v"(b11)                                                                          \
+               : "v"(pa0), "v"(pa1), "v"(pb0), "v"(pb1)                                              \
+               : "memory")
+#define DGLA_TR_MFMAS()                          \
+  mfma16<DT>(a00, a01, b00, b01, acc[0][0]);     \
+  mfma16<DT>(a00, a01, b10, b11, acc[0][1]);     \
+  mfma16<DT>(a10, a11, b00, b01, acc[1][0]);     \
+  mfma16<DT>(a10, a11, b10, b11, acc[1][1])
+    DGLA_TR_READS(0, 2048);     // contraction rows 0-15 of the slot (j2 = 0, 1: rows + 0, + 8)
+    DGLA_TR_MFMAS();
+    DGLA_TR_READS(4096, 6144);  // rows 16-31
+    DGLA_TR_MFMAS();
+#undef DGLA_TR_READS
+#undef DGLA_TR_MFMAS
+  }
+
+  float* out = p.acc + rel * static_cast<int64_t>(D1) * D2;
+  const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = j0 + wn * 64 + j * 32 + col_l;
+      if (col >= D2) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+        if (row < D1) atomicAdd(out + static_cast<int64_t>(row) * D2 + col, acc[i][j][r]);
+      }
+    }
+}
+
 // Rows per split-K slab: every slab ends in one fp32 atomic add per output element, and the
 // atomics (not the MFMAs) bound the kernel when slabs are short (2048-row slabs: 320 M atomics
 // = 4.0 ms of a 4.0 ms launch at 10 M rows).  Long slabs cut them; enough slabs must remain to
@@ -967,7 +1146,22 @@ int run_segment_mm_bwd_b(const void* a, const void* dc, void* db, int64_t M, int
     const int64_t blocks = max_slabs * p.tiles_i * p.tiles_j;
     if (blocks >= (int64_t(1) << 24)) return mfail("segment_mm backward: too many tiles (" +
                                                    std::to_string(blocks) + "); split the call");
-    hipLaunchKernelGGL((segment_mm_bwd_b_kernel<DT>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+    bool direct = false;
+    if constexpr (sizeof(DT) == 2)
+      direct = p.vec_a && p.vec_dc && !row_index && D1 >= 8 && D2 >= 8 && (tuning_flags() & kTuneGlds);
+    if constexpr (sizeof(DT) == 2) {
+      // Ring depth against occupancy (10 M rows, bf16, profiles/r1/glds_ab.jsonl): with few output
+      // tiles per row slab, 5 slots x 2 workgroups per CU (128 KB in flight) wins — 256 x 256:
+      // 2.08 ms against 2.57 (3 x 3) / 2.78 (2 x 4) / 2.62 (register-staged); with many tiles the
+      // slab rows are re-read from L2 by the other tiles and co-residency wins — 512 x 512:
+      // 2.58 ms (2 x 4) against 2.86 (5 x 2) / 3.79 (register-staged).
+      if (direct && p.tiles_i * p.tiles_j >= 8)
+        hipLaunchKernelGGL((segment_mm_bwd_b_glds_kernel<DT, 2>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+      else if (direct)
+        hipLaunchKernelGGL((segment_mm_bwd_b_glds_kernel<DT, 5>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+    }
+    if (!direct)
+      hipLaunchKernelGGL((segment_mm_bwd_b_kernel<DT>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
     if (!std::is_same<DT, float>::value)
       hipLaunchKernelGGL((convert_from_f32_kernel<DT>), dim3(static_cast<unsigned>(std::min<int64_t>((out_elems + 255) / 256, 4096))),
                          dim3(256), 0, s, acc, static_cast<DT*>(db), out_elems);

@@ -305,7 +305,8 @@ int dgla_partition_kway(int idtype_bits, int64_t num_nodes, const void* indptr,
  *   DGLA_TUNE_GLDS    dgla_segment_mm / dgla_gather_mm, 16-bit and fp32 storage, K a whole number
  *                     of 64-byte slabs: operands go global -> LDS directly (global_load_lds,
  *                     slab rings) instead of through registers; 16-bit results bit-identical,
- *                     fp32 contracts k in a permuted order (default on)
+ *                     fp32 contracts k in a permuted order; the 16-bit weight gradient reads
+ *                     its fragments with transposing LDS loads (default on)
  * The reference has no counterpart (its kernels take no hints). */
 #define DGLA_TUNE_XCD 1u
 #define DGLA_TUNE_NT_OUT 2u

@@ -153,6 +153,40 @@ def test_lds_direct_kernel_matches_register_staged(dev, dtype, k, n):
         _capi.set_tuning(default)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d1,d2", [(8, 8), (64, 128), (256, 256), (136, 72), (520, 264)])
+def test_lds_direct_weight_gradient(dev, dtype, d1, d2):
+    """16-bit dB with contiguous rows and whole 16-byte pieces takes the LDS-direct kernel
+    (global_load_lds ring + transposing ds_read_b64_tr_b16 fragments; both ring depths are
+    reached: 520 x 264 has 15 tiles per slab).  Checked against the exact fp64 product and
+    against the register-staged kernel (DGLA_TUNE_GLDS off): slab tails read the zero page,
+    feature tails are clamped, empty relations stay zero."""
+    from dgl_amd import _capi
+    from dgl_amd._lib import DGLA_TUNE_GLDS
+
+    default = _capi.get_tuning()
+    g = torch.Generator().manual_seed(d1 * 13 + d2)
+    try:
+        for seg in ([1], [127, 129, 0, 5], [5000, 3, 0, 0, 2049], [40000, 17]):
+            m, r = sum(seg), len(seg)
+            a = (torch.rand(m, d1, generator=g) - 0.3).to(dtype).to(dev)
+            dc = (torch.rand(m, d2, generator=g) - 0.6).to(dtype).to(dev)
+            sl = torch.tensor(seg, dtype=torch.int64)
+            a64, c64 = a.double().cpu().numpy(), dc.double().cpu().numpy()
+            for flags in (default, default & ~DGLA_TUNE_GLDS):
+                _capi.set_tuning(flags)
+                db = torch.full((r, d1, d2), float("nan"), dtype=dtype, device=dev)
+                _capi.segment_mm_backward_b(a, dc, db, sl)
+                off = 0
+                for i, n_ in enumerate(seg):
+                    want = a64[off:off + n_].T @ c64[off:off + n_]
+                    mag = np.abs(a64[off:off + n_]).T @ np.abs(c64[off:off + n_])
+                    _close(db[i], want, mag, dtype, n_, "rel %d flags %d" % (i, flags))
+                    off += n_
+    finally:
+        _capi.set_tuning(default)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_api_segment_mm_matches_torch_with_grads(dev, dtype):
     """tests/python/common/ops/test_ops.py:302-342 (test_segment_mm)."""
