@@ -158,6 +158,39 @@ __device__ __forceinline__ u32x4 load_piece(const DT* src, int valid, bool vec_o
   return v;
 }
 
+// Direct stores of a wave's accumulators (C/D layout of the 32x32 MFMAs: col = lane & 31,
+// row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); a half-wave writes 32 consecutive
+// columns of one row.  Row-indexed output (INDEXED): the 16 physical rows of a 32-row block
+// are looked up TOGETHER before its stores.  A lookup per store costs a s_waitcnt vmcnt(0) in
+// front of every store — loads and stores share the counter, so each store would wait for the
+// one before it (measured on the fp32 forward: 15.9 -> 12.2 ms came from the K-loop, the
+// remaining 1.4 ms to the vendor GEMM from this).
+template <typename DT, int NJ, bool INDEXED>
+__device__ __forceinline__ void store_acc_direct(DT* __restrict__ C, const f32x16 (&acc)[2][NJ],
+                                                 const int64_t* __restrict__ row_index, int64_t row_base,
+                                                 int64_t row_end, int col_base, int N, int rbase) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int64_t pr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = row_base + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+      if constexpr (INDEXED)
+        pr[r] = row < row_end ? row_index[row] : -1;
+      else
+        pr[r] = row < row_end ? row : -1;
+    }
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int col = col_base + jj * 32;
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (pr[r] >= 0) C[pr[r] * N + col] = from_acc<DT>(acc[i][jj][r]);
+    }
+  }
+}
+
 struct MmParams {
   const void* a;    // [M, K] rows grouped by relation
   const void* bt;   // [R, N, K]  (K contiguous)
@@ -302,32 +335,29 @@ __global__ __launch_bounds__(256, 2) void segment_mm_kernel(const MmParams p) {
               }
         }
         __syncthreads();
+        int64_t prow[64 * CPR / 256];  // physical rows first (one wait), then the stores
+#pragma unroll
+        for (int h = 0; h < 64 * CPR / 256; ++h) {
+          const int64_t grow = row0 + half * 64 + (tid + 256 * h) / CPR;
+          prow[h] = grow < row_end ? (p.row_index ? p.row_index[grow] : grow) : -1;
+        }
 #pragma unroll
         for (int h = 0; h < 64 * CPR / 256; ++h) {
           const int pidx = tid + 256 * h;
           const int row = pidx / CPR, chunk = pidx % CPR;
-          const int64_t grow = row0 + half * 64 + row;
           const int col = n0 + chunk * 8;
-          if (grow < row_end && col < N)  // N % 8 == 0 here: a piece is all in or all out
-            *reinterpret_cast<u32x4*>(C + (p.row_index ? p.row_index[grow] : grow) * N + col) =
+          if (prow[h] >= 0 && col < N)  // N % 8 == 0 here: a piece is all in or all out
+            *reinterpret_cast<u32x4*>(C + prow[h] * N + col) =
                 *reinterpret_cast<const u32x4*>(smem + row * kCPitch + chunk * 16);
         }
       }
       return;
     }
   }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-      const int col = n0 + wn * (TBN / 2) + jj * 32 + lrow;
-      if (col >= N) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-        if (row < row_end) C[(p.row_index ? p.row_index[row] : row) * N + col] = from_acc<DT>(acc[i][jj][r]);
-      }
-    }
+  if (p.row_index)
+    store_acc_direct<DT, NJ, true>(C, acc, p.row_index, row0 + wm * 64, row_end, n0 + wn * (TBN / 2) + lrow, N, rbase);
+  else
+    store_acc_direct<DT, NJ, false>(C, acc, nullptr, row0 + wm * 64, row_end, n0 + wn * (TBN / 2) + lrow, N, rbase);
 }
 
 // ---- forward, LDS-direct variant (16-bit and fp32 storage, K a whole number of 64-byte slabs):
@@ -524,19 +554,10 @@ __global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(con
 
   if constexpr (ES == 4) {
     // fp32: a half-wave owns 32 consecutive columns of one row = one 128-byte line per store
-    const int rb = 4 * khalf;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) {
-        const int col = n0 + wn * (TBN / 2) + jj * 32 + lrow;
-        if (col >= N) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rb;
-          if (row < row_end) C[(p.row_index ? p.row_index[row] : row) * N + col] = acc[i][jj][r];
-        }
-      }
+    if (p.row_index)
+      store_acc_direct<DT, NJ, true>(C, acc, p.row_index, row0 + wm * 64, row_end, n0 + wn * (TBN / 2) + lrow, N, 4 * khalf);
+    else
+      store_acc_direct<DT, NJ, false>(C, acc, nullptr, row0 + wm * 64, row_end, n0 + wn * (TBN / 2) + lrow, N, 4 * khalf);
     return;
   }
 
@@ -559,14 +580,19 @@ __global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(con
           }
     }
     __syncthreads();
+    int64_t prow[64 * CPR / NT];  // physical rows first (one wait), then the stores
+#pragma unroll
+    for (int h = 0; h < 64 * CPR / NT; ++h) {
+      const int64_t grow = row0 + half * 64 + (tid + NT * h) / CPR;
+      prow[h] = grow < row_end ? (p.row_index ? p.row_index[grow] : grow) : -1;
+    }
 #pragma unroll
     for (int h = 0; h < 64 * CPR / NT; ++h) {
       const int pidx = tid + NT * h;
       const int row = pidx / CPR, chunk = pidx % CPR;
-      const int64_t grow = row0 + half * 64 + row;
       const int col = n0 + chunk * 8;
-      if (grow < row_end && col < N) {
-        u32x4* dstp = reinterpret_cast<u32x4*>(C + (p.row_index ? p.row_index[grow] : grow) * N + col);
+      if (prow[h] >= 0 && col < N) {
+        u32x4* dstp = reinterpret_cast<u32x4*>(C + prow[h] * N + col);
         const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * kCPitch + chunk * 16);
         if (nt_c)
           __builtin_nontemporal_store(v, dstp);
