@@ -35,7 +35,7 @@ def same(c0, c1, dt, a=None, b=None, sl=None):
 
 
 for dt in (torch.bfloat16, torch.float16, torch.float32):
-    for k in (32, 64, 96, 256, 544):
+    for k in (24, 32, 64, 100, 256, 544):
         for n in (136, 256, 264, 512, 776):
             for seg in ([1], [127, 129, 0, 5], [1000, 3, 0, 0, 2049], [300] * 9):
                 for indexed in (False, True):
@@ -87,7 +87,7 @@ def timeit(fn, reps=10, warm=3):
     return float(np.median(ts)), float(np.min(ts))
 
 
-for (rows, k, n, r) in ((10_000_000, 256, 256, 8), (10_000_000, 128, 256, 8), (4_000_000, 256, 512, 8), (2_000_000, 1024, 1024, 4)):
+for (rows, k, n, r) in ((10_000_000, 256, 256, 8), (10_000_000, 128, 256, 8), (10_000_000, 104, 256, 8), (4_000_000, 256, 512, 8), (2_000_000, 1024, 1024, 4)):
     for dt in (torch.bfloat16, torch.float32):
         a = torch.randn((rows, k), device=dev, dtype=dt)
         b = torch.randn((r, k, n), device=dev, dtype=dt) * 0.05

@@ -360,8 +360,8 @@ __global__ __launch_bounds__(256, 2) void segment_mm_kernel(const MmParams p) {
     store_acc_direct<DT, NJ, false>(C, acc, nullptr, row0 + wm * 64, row_end, n0 + wn * (TBN / 2) + lrow, N, rbase);
 }
 
-// ---- forward, LDS-direct variant (16-bit and fp32 storage, K a whole number of 64-byte slabs):
-// the default for those shapes.  Same tile and MFMAs as segment_mm_kernel<DT, TBN, true>, but
+// ---- forward, LDS-direct variant (16-bit and fp32 storage, operands in whole aligned 16-byte
+// pieces): the default for those shapes.  Same tile and MFMAs as segment_mm_kernel<DT, TBN, true>, but
 // the operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, 180 instead of
 // 238 VGPRs) into two rings of 64-byte-per-row slabs: NA = 6 slots for A (the operand that
 // comes from HBM: 5 slabs = 40 KB per workgroup always in flight) and NB = 2 for the weights
@@ -385,6 +385,9 @@ __global__ __launch_bounds__(256, 2) void segment_mm_kernel(const MmParams p) {
 //    their products land in accumulator rows / columns that are never stored.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
+
+// Source of DMA lanes that must contribute zeros (K tail of the last slab, rows past a slab end).
+__device__ __attribute__((aligned(256))) char g_mm_zero_page[256];
 
 constexpr int kGldsSlabBytes = 64;  // bytes of K per tile row and slab (32 16-bit / 16 fp32 elements)
 
@@ -444,22 +447,30 @@ __global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(con
     srcB[i] = Bt + static_cast<int64_t>(bn) * K * ES + src_chunk * 16;
   }
   const bool nt_c = (p.tune & kTuneNtOut) != 0;
-  const int nslab = K * ES / kGldsSlabBytes;
+  // K need not be a whole number of slabs: in the last slab, the lanes whose 16-byte chunk starts
+  // at or past the end of the row read the zero page instead (both operands).
+  const int kbytes = K * ES;
+  const int nslab = (kbytes + kGldsSlabBytes - 1) / kGldsSlabBytes;
+  const bool tail_zero = (nslab - 1) * kGldsSlabBytes + src_chunk * 16 >= kbytes;
   auto issue_a = [&](int t) {  // slab t of A -> ring slot t % NA
     if (t >= nslab) return;
     char* dst = smem + (t % NA) * kASlab + wave * (nA * 1024);
+    const bool zero = tail_zero && t == nslab - 1;
 #pragma unroll
     for (int i = 0; i < nA; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(srcA[i] + static_cast<int64_t>(t) * kGldsSlabBytes),
-                                       (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(
+          (gbl_ptr_t)(zero ? g_mm_zero_page : srcA[i] + static_cast<int64_t>(t) * kGldsSlabBytes),
+          (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
   };
   auto issue_b = [&](int t) {  // slab t of the weights -> ring slot t % NB
     if (t >= nslab) return;
     char* dst = smem + kBBase + (t % NB) * kBSlab + wave * (nB * 1024);
+    const bool zero = tail_zero && t == nslab - 1;
 #pragma unroll
     for (int i = 0; i < nB; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(srcB[i] + static_cast<int64_t>(t) * kGldsSlabBytes),
-                                       (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(
+          (gbl_ptr_t)(zero ? g_mm_zero_page : srcB[i] + static_cast<int64_t>(t) * kGldsSlabBytes),
+          (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
   };
   // Iteration i (also the prologue iterations i < 0) issues [weights slab i + NB - 1, A slab
   // i + NA - 1], so the loads of this wave still allowed in flight when slab t is needed are
@@ -871,16 +882,9 @@ int mm_num_cus() {
 }
 
 // LDS-direct forward kernel: 16-bit storage, whole 16-byte pieces, K a multiple of the slab.
-bool glds_eligible(size_t elem, int64_t K, int64_t N, bool vec) {
-  return (elem == 2 || elem == 4) && vec && (K * elem) % kGldsSlabBytes == 0 && (tuning_flags() & kTuneGlds);
-}
-
-// Rows per forward tile: 256-row tiles (512 threads) halve the weight traffic L2 -> CU; taken
-// when the LDS-direct kernel runs, the output is wide and there are tiles enough to fill the chip.
-int fwd_rows_per_tile(size_t elem, const void* a, const void* b, const void* c, int64_t M, int64_t K,
-                      int64_t N, bool b_trans) {
-  const bool vec = K % 8 == 0 && N % 8 == 0 && aligned16(a) && aligned16(c) && (!b_trans || aligned16(b));
-  return BM;
+// (whole 16-byte pieces of K in both operands; 16-bit results also leave as 16-byte pieces)
+bool glds_eligible(size_t elem, int64_t K, int64_t N, bool vec_ab, bool vec_c) {
+  return (elem == 2 || elem == 4) && vec_ab && (vec_c || elem == 4) && (tuning_flags() & kTuneGlds);
 }
 
 template <typename DT>
@@ -925,7 +929,7 @@ int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, 
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
     const bool vec = p.vec_a && p.vec_b && p.vec_c;
     {
-      if (glds_eligible(sizeof(DT), K, N, p.vec_a && p.vec_b && p.vec_c)) {
+      if (glds_eligible(sizeof(DT), K, N, p.vec_a && p.vec_b, p.vec_c != 0)) {
         if (wide)
           hipLaunchKernelGGL((segment_mm_glds_kernel<DT, 256, 128, 6, 2>), grid, block, 0, s, p);
         else
@@ -962,8 +966,6 @@ int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, 
 //    the fragment reads, so the 8 rows one read touches fall into distinct bank groups.
 //  * Rows past the end of the slab read a zero page; feature chunks past the width are clamped
 //    (their outputs are never stored).
-__device__ __attribute__((aligned(256))) char g_mm_zero_page[256];
-
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int kBwdGldsRows = 32;  // contraction rows per ring slot
 
@@ -1245,7 +1247,7 @@ int dgla_segment_mm_indexed(int idtype_bits, dgla_dtype dtype, const void* a, co
     workspace = owned;
   }
   char* ws = static_cast<char*>(workspace);
-  const int rpt = fwd_rows_per_tile(elem, a, b, c, num_rows, k, n, b_trans != 0);
+  const int rpt = BM;
   int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, rpt, ws, sc, s);
   if (rc == 0) {
     switch (dtype) {

@@ -302,8 +302,8 @@ int dgla_partition_kway(int idtype_bits, int64_t num_nodes, const void* indptr,
  *                     400 B = 4 lines touched per gather) the call first copies ufeat into a
  *                     line-aligned main array + a dense tail array inside the workspace and
  *                     gathers from those (3 lines + one cached access per edge)
- *   DGLA_TUNE_GLDS    dgla_segment_mm / dgla_gather_mm, 16-bit and fp32 storage, K a whole number
- *                     of 64-byte slabs: operands go global -> LDS directly (global_load_lds,
+ *   DGLA_TUNE_GLDS    dgla_segment_mm / dgla_gather_mm, 16-bit and fp32 storage, operands in
+ *                     whole aligned 16-byte pieces: operands go global -> LDS directly (global_load_lds,
  *                     slab rings) instead of through registers; 16-bit results bit-identical,
  *                     fp32 contracts k in a permuted order; the 16-bit weight gradient reads
  *                     its fragments with transposing LDS loads (default on)

@@ -114,11 +114,12 @@ def test_mfma_layout_identity(dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
-@pytest.mark.parametrize("k", [16, 32, 64, 96, 256, 544])
+@pytest.mark.parametrize("k", [8, 16, 24, 32, 64, 96, 100, 256, 544, 600])
 @pytest.mark.parametrize("n", [64, 136, 256, 264, 776])
 def test_lds_direct_kernel_matches_register_staged(dev, dtype, k, n):
-    """DGLA_TUNE_GLDS picks the global_load_lds K-loop when K is a whole number of 64-byte
-    slabs.  16-bit storage: same MFMAs in the same k order, so the BITS must equal the
+    """DGLA_TUNE_GLDS picks the global_load_lds K-loop whenever the operands are whole 16-byte
+    pieces (K % 8 == 0 for 16-bit, K % 4 == 0 for fp32; a K tail inside the last 64-byte slab
+    reads the zero page).  16-bit storage: same MFMAs in the same k order, so the BITS must equal the
     register-staged kernel's; fp32: k is contracted in a permuted order, so agreement is to
     rounding.  Ragged segments, clamped tail rows / columns, row-indexed (gather_mm) access."""
     from dgl_amd import _capi
