@@ -140,3 +140,37 @@ for (rows, d1, d2, r) in ((10_000_000, 256, 256, 8), (10_000_000, 128, 256, 8), 
                           "tflops": 2.0 * rows * d1 * d2 / (ms * 1e-3) / 1e12}), flush=True)
     del a, dc, db
 _capi.set_tuning(base)
+
+# ---- fp32 weight gradient ------------------------------------------------------------------
+bad = 0
+for d1, d2 in ((4, 4), (64, 128), (256, 256), (132, 76), (520, 264)):
+    for seg in ([1], [127, 129, 0, 5], [5000, 3, 0, 0, 2049], [40000, 17]):
+        m, r = sum(seg), len(seg)
+        a = torch.randn((m, d1), generator=g).to(dev)
+        dc = torch.randn((m, d2), generator=g).to(dev)
+        sl = torch.tensor(seg, dtype=torch.int64)
+        off, want = 0, torch.zeros((r, d1, d2), device=dev, dtype=torch.float64)
+        for i, n_ in enumerate(seg):
+            want[i] = a[off:off + n_].double().T @ dc[off:off + n_].double()
+            off += n_
+        for flags in (base, base | GLDS):
+            _capi.set_tuning(flags)
+            db = torch.full((r, d1, d2), float("nan"), device=dev)
+            _capi.segment_mm_backward_b(a, dc, db, sl)
+            torch.cuda.synchronize()
+            if not bool(((db.double() - want).abs() <= 1e-5 * want.abs() + 1e-4 * max(seg) ** 0.5).all()):
+                bad += 1
+                print("MISMATCH dB fp32", flags, d1, d2, seg, float((db.double() - want).abs().max()), flush=True)
+print(json.dumps({"check": "fp32 weight gradient vs fp64 torch, both kernels", "mismatches": bad}), flush=True)
+for (rows, d1, d2, r) in ((10_000_000, 256, 256, 8), (10_000_000, 128, 256, 8), (4_000_000, 512, 512, 8)):
+    a = torch.randn((rows, d1), device=dev)
+    dc = torch.randn((rows, d2), device=dev)
+    db = torch.empty((r, d1, d2), device=dev)
+    sl = torch.full((r,), rows // r, dtype=torch.int64)
+    for flags, name in ((base, "reg"), (base | GLDS, "glds")):
+        _capi.set_tuning(flags)
+        ms, mn = timeit(lambda: _capi.segment_mm_backward_b(a, dc, db, sl))
+        print(json.dumps({"dB fp32 shape": [rows, d1, d2, r], "kernel": name, "ms": round(ms, 4), "ms_min": round(mn, 4),
+                          "tflops": 2.0 * rows * d1 * d2 / (ms * 1e-3) / 1e12}), flush=True)
+    del a, dc, db
+_capi.set_tuning(base)

@@ -1128,6 +1128,131 @@ __global__ __launch_bounds__(256, NS >= 4 ? 2 : (NS == 3 ? 3 : 4)) void segment_
     }
 }
 
+// fp32 weight gradient, LDS-direct: no transposition is needed at all — the 32x32x2 MFMA takes
+// ONE contraction row per k-half, so lane (feature f, k-half kh) reads LDS[row 2 s + kh][f] with a
+// plain ds_read_b32 (32 consecutive features = 32 consecutive banks; unpadded, unswizzled rows).
+// 16 rows x 128 features of A and of dC per slot, NS slots, counted vmcnt as above.
+constexpr int kBwdGldsRowsF32 = 16;
+
+template <int NS>
+__global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_glds_f32_kernel(const MmBwdParams p) {
+  constexpr int kPart = kBwdGldsRowsF32 * 512;  // one operand of a slot: 16 rows x 128 features x 4 B
+  constexpr int kSlot = 2 * kPart;
+  constexpr int kLoads = 4;  // DMA instructions per wave and slot (2 per operand, 2 rows each)
+  __shared__ __attribute__((aligned(1024))) char smem[NS * kSlot];
+
+  const int64_t L = blockIdx.x;
+  const int64_t jd = L >> 3;
+  const int tiles = p.tiles_i * p.tiles_j;
+  const int64_t slab = (jd / tiles) * 8 + (L & 7);
+  const int tile = static_cast<int>(jd % tiles);
+  const int64_t* slab_off = p.plan;
+  const int64_t* row_off = p.plan + p.num_rel + 1;
+  if (slab >= slab_off[p.num_rel]) return;
+  const int64_t rel = find_segment(slab_off, p.num_rel, slab);
+  const int64_t m0 = row_off[rel] + (slab - slab_off[rel]) * p.slab_rows;
+  int64_t m1 = m0 + p.slab_rows;
+  if (m1 > row_off[rel + 1]) m1 = row_off[rel + 1];
+  const int i0 = (tile / p.tiles_j) * BM, j0 = (tile % p.tiles_j) * BN;
+  const int D1 = p.D1, D2 = p.D2;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // DMA: instruction n (0, 1) of a wave covers slot rows 4 wave + 2 n, + 1 of one operand;
+  // lane -> row + (lane >> 5), features 4 (lane & 31) .. + 3
+  int drow[2];
+  int64_t offA[2], offC[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int r = 4 * wave + 2 * n + (lane >> 5);
+    drow[n] = r;
+    int fa = i0 + (lane & 31) * 4, fc = j0 + (lane & 31) * 4;
+    if (fa >= D1) fa = D1 - 4;
+    if (fc >= D2) fc = D2 - 4;
+    offA[n] = (static_cast<int64_t>(r) * D1 + fa) * 4;
+    offC[n] = (static_cast<int64_t>(r) * D2 + fc) * 4;
+  }
+  const char* __restrict__ baseA = static_cast<const char*>(p.a) + m0 * D1 * 4;
+  const char* __restrict__ baseC = static_cast<const char*>(p.dc) + m0 * D2 * 4;
+  const int64_t rows = m1 - m0;
+  const int nsl = static_cast<int>((rows + kBwdGldsRowsF32 - 1) / kBwdGldsRowsF32);
+  auto issue = [&](int t) {
+    if (t >= nsl) return;
+    char* dst = smem + (t % NS) * kSlot + wave * 2048;
+    const int64_t mrow = static_cast<int64_t>(t) * kBwdGldsRowsF32;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const bool in = mrow + drow[n] < rows;
+      const char* sa = in ? baseA + mrow * D1 * 4 + offA[n] : g_mm_zero_page;
+      const char* sc = in ? baseC + mrow * D2 * 4 + offC[n] : g_mm_zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)sa, (lds_ptr_t)(dst + n * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)sc, (lds_ptr_t)(dst + kPart + n * 1024), 16, 0, 0);
+    }
+  };
+  auto wait_for_slot = [&](int t) {
+    int later = nsl - 1 - t;
+    if (later > NS - 2) later = NS - 2;
+    switch (later) {
+      case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+      case 1: __builtin_amdgcn_s_waitcnt(0x0F70 | (1 * kLoads)); break;
+      case 2: __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * kLoads)); break;
+      case 3: __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * kLoads)); break;
+      default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    }
+  };
+  static_assert(NS >= 2 && NS <= 5, "vmcnt switch covers up to 3 slots in flight behind the needed one");
+
+  const int f = lane & 31, kh = lane >> 5;
+  const int a_off = kh * 512 + (wm * 64 + f) * 4;
+  const int b_off = kPart + kh * 512 + (wn * 64 + f) * 4;
+
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i) issue(i);
+  for (int t = 0; t < nsl; ++t) {
+    wait_for_slot(t);
+    __builtin_amdgcn_s_barrier();
+    issue(t + NS - 1);
+    const char* slot = smem + (t % NS) * kSlot;
+#pragma unroll
+    for (int s2 = 0; s2 < kBwdGldsRowsF32 / 2; ++s2) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const float*>(slot + a_off + s2 * 1024 + i * 128);
+        b[i] = *reinterpret_cast<const float*>(slot + b_off + s2 * 1024 + i * 128);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  float* out = p.acc + rel * static_cast<int64_t>(D1) * D2;
+  const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = j0 + wn * 64 + j * 32 + col_l;
+      if (col >= D2) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+        if (row < D1) atomicAdd(out + static_cast<int64_t>(row) * D2 + col, acc[i][j][r]);
+      }
+    }
+}
+
 // Rows per split-K slab: every slab ends in one fp32 atomic add per output element, and the
 // atomics (not the MFMAs) bound the kernel when slabs are short (2048-row slabs: 320 M atomics
 // = 4.0 ms of a 4.0 ms launch at 10 M rows).  Long slabs cut them; enough slabs must remain to
@@ -1187,6 +1312,13 @@ int run_segment_mm_bwd_b(const void* a, const void* dc, void* db, int64_t M, int
         hipLaunchKernelGGL((segment_mm_bwd_b_glds_kernel<DT, 2>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
       else if (direct)
         hipLaunchKernelGGL((segment_mm_bwd_b_glds_kernel<DT, 5>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+    }
+    if constexpr (sizeof(DT) == 4) {
+      direct = p.vec_a && p.vec_dc && !row_index && D1 >= 4 && D2 >= 4 && (tuning_flags() & kTuneGlds);
+      if (direct && p.tiles_i * p.tiles_j >= 8)
+        hipLaunchKernelGGL((segment_mm_bwd_b_glds_f32_kernel<2>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+      else if (direct)
+        hipLaunchKernelGGL((segment_mm_bwd_b_glds_f32_kernel<5>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
     }
     if (!direct)
       hipLaunchKernelGGL((segment_mm_bwd_b_kernel<DT>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);

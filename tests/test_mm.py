@@ -154,12 +154,13 @@ def test_lds_direct_kernel_matches_register_staged(dev, dtype, k, n):
         _capi.set_tuning(default)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("d1,d2", [(8, 8), (64, 128), (256, 256), (136, 72), (520, 264)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("d1,d2", [(8, 8), (4, 12), (64, 128), (256, 256), (136, 72), (132, 76), (520, 264)])
 def test_lds_direct_weight_gradient(dev, dtype, d1, d2):
-    """16-bit dB with contiguous rows and whole 16-byte pieces takes the LDS-direct kernel
-    (global_load_lds ring + transposing ds_read_b64_tr_b16 fragments; both ring depths are
-    reached: 520 x 264 has 15 tiles per slab).  Checked against the exact fp64 product and
+    """dB with contiguous rows and whole 16-byte pieces takes the LDS-direct kernels
+    (global_load_lds ring; 16-bit: transposing ds_read_b64_tr_b16 fragments, fp32: plain
+    ds_read_b32; both ring depths are reached: 520 x 264 has 15 tiles per slab; (4, 12) and
+    (132, 76) are whole pieces only in fp32, so 16-bit takes the register-staged kernel there).  Checked against the exact fp64 product and
     against the register-staged kernel (DGLA_TUNE_GLDS off): slab tails read the zero page,
     feature tails are clamped, empty relations stay zero."""
     from dgl_amd import _capi
