@@ -889,7 +889,7 @@ bool glds_eligible(size_t elem, int64_t K, int64_t N, bool vec_ab, bool vec_c) {
 
 template <typename DT>
 int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, int64_t N,
-                   int64_t num_rel, bool b_trans, const int64_t* row_index, int rows_per_tile, char* ws,
+                   int64_t num_rel, bool b_trans, const int64_t* row_index, char* ws,
                    const MmScratch& sc, hipStream_t s) {
   // Bt = [R, N, K]: the weights with the contraction axis contiguous
   const void* bt = b;
@@ -1379,14 +1379,13 @@ int dgla_segment_mm_indexed(int idtype_bits, dgla_dtype dtype, const void* a, co
     workspace = owned;
   }
   char* ws = static_cast<char*>(workspace);
-  const int rpt = BM;
-  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, rpt, ws, sc, s);
+  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, BM, ws, sc, s);
   if (rc == 0) {
     switch (dtype) {
-      case DGLA_F32: rc = run_segment_mm<float>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, rpt, ws, sc, s); break;
-      case DGLA_F64: rc = run_segment_mm<double>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, rpt, ws, sc, s); break;
-      case DGLA_F16: rc = run_segment_mm<f16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, rpt, ws, sc, s); break;
-      case DGLA_BF16: rc = run_segment_mm<bf16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, rpt, ws, sc, s); break;
+      case DGLA_F32: rc = run_segment_mm<float>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
+      case DGLA_F64: rc = run_segment_mm<double>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
+      case DGLA_F16: rc = run_segment_mm<f16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
+      case DGLA_BF16: rc = run_segment_mm<bf16_t>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
     }
   }
   if (owned) (void)hipFreeAsync(owned, s);
