@@ -14,15 +14,17 @@
 //    2 x 2 MFMA tiles of 32 x 32: v_mfma_f32_32x32x16_{bf16,f16} for 16-bit storage (fp32
 //    accumulate, as cuBLAS does for the reference: CUBLAS_COMPUTE_32F), v_mfma_f32_32x32x2_f32
 //    for fp32 (exact fp32 FMA chain, no TF32-like rounding).  fp64 takes a plain FMA kernel.
-//  * Both operands are staged through LDS K-contiguous (128-byte row payload, 144-byte pitch), so
-//    every MFMA fragment is one ds_read_b128 (16-bit) / ds_read_b32 (fp32).  The weight operand
-//    is needed K-contiguous per output column: for C = A . B[r] the (small) weights are
-//    transposed once per call into scratch, for C = A . B[r]^T (the backward w.r.t. A) they
-//    already are.  Global accesses are 16-byte pieces; the next K-slab is fetched into
-//    registers while the current one is multiplied.
-//  * Weight-gradient dB[r] = A_r^T . dC_r contracts over the rows of a segment: the same
-//    MFMA loop with both operands transposed on their way into LDS, split over 2048-row
-//    slabs whose fp32 partial tiles are added with hardware float atomics.
+//  * Both operands are staged through LDS K-contiguous, so every MFMA fragment is one
+//    ds_read_b128.  The weight operand is needed K-contiguous per output column: for
+//    C = A . B[r] the (small) weights are transposed once per call into scratch, for
+//    C = A . B[r]^T (the backward w.r.t. A) they already are.
+//  * Default data path (operands in whole aligned 16-byte pieces): LDS-direct — global_load_lds
+//    DMA into slab rings with counted vmcnt, no VGPR staging (segment_mm_glds_kernel,
+//    segment_mm_bwd_b_glds_kernel with transposing LDS reads, …_f32_kernel).  General path (odd
+//    widths, unaligned or row-indexed weight gradient): register-staged kernels, 16-byte global
+//    pieces, next K-slab fetched into registers while the current one is multiplied.
+//  * Weight-gradient dB[r] = A_r^T . dC_r contracts over the rows of a segment: split over row
+//    slabs sized to the chip whose fp32 partial tiles are added with hardware float atomics.
 #include "../../include/dgl_amd.h"
 
 #include <algorithm>
