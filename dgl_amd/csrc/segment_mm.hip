@@ -10,8 +10,8 @@
 //    (tile -> relation, first row); every workgroup of the main kernel looks its tile up with
 //    a binary search, so a relation with 3 rows and one with 30 M rows share the launch and
 //    nothing is serialised on the host.
-//  * 256 threads = 4 wavefronts in a 2 x 2 grid, 128 x 128 output tile, each wave 64 x 64 =
-//    2 x 2 MFMA tiles of 32 x 32: v_mfma_f32_32x32x16_{bf16,f16} for 16-bit storage (fp32
+//  * 256 threads = 4 wavefronts in a 2 x 2 grid; forward: 128 x 256 output tile (128 x 128 when
+//    N <= 128), each wave 64 x 128 = 2 x 4 MFMA tiles of 32 x 32; weight gradient: 128 x 128: v_mfma_f32_32x32x16_{bf16,f16} for 16-bit storage (fp32
 //    accumulate, as cuBLAS does for the reference: CUBLAS_COMPUTE_32F), v_mfma_f32_32x32x2_f32
 //    for fp32 (exact fp32 FMA chain, no TF32-like rounding).  fp64 takes a plain FMA kernel.
 //  * Both operands are staged through LDS K-contiguous, so every MFMA fragment is one
