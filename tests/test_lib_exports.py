@@ -130,3 +130,27 @@ def test_dlpack_round_trip_shares_memory_and_releases_owner():
     del back
     gc.collect()
     assert alive() is None
+
+
+def test_tuning_constants_match_header_and_library_default():
+    """DGLA_TUNE_* in include/dgl_amd.h == the Python mirror; the library's default (XCD order +
+    LDS-direct segment_mm kernels) is what dgla_get_tuning() reports in a fresh process, and
+    dgla_set_tuning round-trips (no GPU needed: flags are host state)."""
+    import os
+    import re
+
+    from dgl_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "dgl_amd.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (DGLA_TUNE_\w+) (\d+)u", text)}
+    assert defs == {"DGLA_TUNE_XCD": 1, "DGLA_TUNE_NT_OUT": 2, "DGLA_TUNE_NT_IDX": 4, "DGLA_TUNE_SPLIT": 8,
+                    "DGLA_TUNE_GLDS": 16}
+    for name, value in defs.items():
+        assert getattr(_lib, name) == value
+    default = int(_lib.LIB.dgla_get_tuning())
+    assert default == _lib.DGLA_TUNE_XCD | _lib.DGLA_TUNE_GLDS
+    try:
+        assert _lib.LIB.dgla_set_tuning(5) == 0 and int(_lib.LIB.dgla_get_tuning()) == 5
+    finally:
+        _lib.LIB.dgla_set_tuning(default)
