@@ -3,15 +3,19 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (dgla_spmm_csr: merge kernel + fix-up kernel) over the
-whole synthetic graph: N = 2,449,029 rows, E = 61,859,140 edges, F = 100, fp32, int32 ids,
-column ids uniform ("variant U") with inputs resident in HBM.  Rank 0 prints
-ONE JSON line with edges/s, the HBM roofline of the dominant kernel and the CPU baseline.
+A "step" is one pass of the hot path (dgla_spmm_csr: split-row copy of X when the graph's
+locality probe wants it, merge kernel, fix-up kernel) over the whole synthetic graph:
+N = 2,449,029 rows, E = 61,859,140 edges, F = 100, fp32, int32 ids, column ids uniform
+("variant U") with inputs resident in HBM; X is treated as a NEW tensor on
+every step (nothing about it is cached between steps).  Rank 0 prints ONE JSON line with
+edges/s, the HBM roofline of the dominant kernel and the CPU baseline; `variants` adds the
+locality variant L and the static-feature mode, timed outside the K steps.
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns one
-C2-shaped partition (weak scaling) whose last `halo` columns are feature rows owned by the
-other ranks; each step first pulls them with one RCCL all_to_all_single and then runs the
-local SpMM.  value = total edges of all ranks / max-over-ranks time.
+With N > 1 (launched by torch.distributed.run, one rank per GPU) the SAME graph is partitioned
+over the ranks (strong scaling): node partition -> per-rank shard (own-column block +
+halo-column block) -> each step = halo all-to-all over RCCL overlapped with the own-column
+launch, then the halo-column launch (dgl_amd.parallel.ShardedSpMM).
+value = E / max-over-ranks time; cut fraction and halo rows per rank are in `config`.
 """
 import argparse
 import json
@@ -137,6 +141,103 @@ def cpu_baseline(g, x, budget_s=20.0):
     }, out
 
 
+def time_events(fn, reps):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for k in range(reps):
+        fn()
+        ev[k + 1].record()
+    torch.cuda.synchronize()
+    return [ev[k].elapsed_time(ev[k + 1]) for k in range(reps)]
+
+
+def merge_kernel_ms(fn, reps=5):
+    """Average duration of the merge kernel inside `fn` (ONE dgla_spmm_csr call), from the HIP
+    events the library records around it on the launch stream."""
+    from dgl_amd import _capi
+
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+             for _ in range(reps)]
+    for a, b in pairs:
+        a.record()
+        b.record()
+    torch.cuda.synchronize()
+    for a, b in pairs:
+        _capi.set_profile_events(a, b)
+        fn()
+    torch.cuda.synchronize()
+    _capi.set_profile_events(None, None)
+    return float(np.mean([a.elapsed_time(b) for a, b in pairs]))
+
+
+def single_gpu(args, dev, n, e, f):
+    """N = 1: one dgla_spmm_csr call per step over the whole graph (split-row copy of X when the
+    locality probe wants it + merge kernel + fix-up kernel), X treated as NEW on every step."""
+    from dgl_amd import _capi
+
+    g = synth_csr(n, n, e, args.variant, seed=20250824, device=dev)
+    torch.manual_seed(12345)
+    x = torch.rand(n, f, device=dev) + 1
+    out = torch.empty(n, f, device=dev)
+    csr = _capi.make_csr(g["indptr"], g["indices"], None, n)
+    ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, x.dtype, x, None, out),
+                     dtype=torch.uint8, device=dev)
+    plan_valid = [False]
+
+    def step():
+        _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws,
+                       plan_valid=plan_valid[0])
+        plan_valid[0] = True
+
+    ctx = {"g": g, "x": x, "out": out, "csr": csr, "ws": ws, "edges": e, "rows": n,
+           "alg_bytes": algorithmic_bytes(n, e, f), "profile_in_step": True}
+    return step, ctx
+
+
+def multi_gpu(args, dev, n, e, f, rank, world, dist, spmm=None):
+    """N > 1: STRONG scaling of the one graph.  Every rank builds the same graph and features
+    from the same seeds, rank 0 partitions the nodes (native k-way partitioner standing where
+    METIS stands in the reference; `--partitioner range` = contiguous edge-balanced ranges),
+    each rank cuts its own shard (own-column block + halo-column block) and the step is
+    ShardedSpMM.step: halo all-to-all over RCCL overlapped with the own-column launch, then the
+    halo-column launch accumulates."""
+    from dgl_amd.parallel import (ShardedSpMM, partition_assignment, partition_rows,
+                                  shard_from_partition)
+
+    g = synth_csr(n, n, e, args.variant, seed=20250824, device=dev)
+    torch.manual_seed(12345)
+    x_full = torch.rand(n, f, device=dev) + 1
+    t0 = time.perf_counter()
+    part = torch.empty(n, dtype=torch.int64, device=dev)
+    stats = {}
+    if rank == 0:
+        if args.partitioner == "kway":
+            p, stats = partition_assignment(g["indptr"], g["indices"], world, seed=1)
+            part.copy_(p)
+        else:
+            bounds = partition_rows(g["indptr"].cpu(), world)
+            part.copy_(torch.searchsorted(bounds[1:].contiguous(), torch.arange(n), right=True))
+    dist.broadcast(part, src=0)
+    t_part = time.perf_counter() - t0
+    sh = shard_from_partition(g["indptr"], g["indices"], part, world, rank)
+    op = ShardedSpMM(sh, (f,), x_full.dtype, dev, spmm=spmm)  # spmm=None: the library's kernels
+    x_loc = x_full[sh["rows"]].contiguous()
+    out = torch.empty(sh["n_local"], f, device=dev)
+
+    def step():
+        op.step(x_loc, out)
+
+    info = {"rank": rank, "rows": sh["n_local"], "edges": sh["nnz"], "cut_edges": sh["cut_edges"],
+            "halo_rows": sh["n_halo"], "halo_bytes": sh["n_halo"] * f * 4}
+    infos = [None] * world
+    dist.all_gather_object(infos, info)
+    ctx = {"g": g, "x": x_full, "out": out, "shard": sh, "op": op, "x_loc": x_loc, "edges": sh["nnz"],
+           "rows": sh["n_local"], "alg_bytes": algorithmic_bytes(sh["n_local"], sh["nnz"], f),
+           "profile_in_step": False, "infos": infos, "partition_s": t_part,
+           "partition_stats": stats}
+    return step, ctx
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,11 +245,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--variant", default="U", choices=["U", "L"])
     ap.add_argument("--scale", type=int, default=1, help="divide N and E (debug only)")
-    ap.add_argument("--halo-frac", type=float, default=0.1,
-                    help="N>1: fraction of a partition's columns that are remote feature rows")
+    ap.add_argument("--partitioner", default="kway", choices=["kway", "range"],
+                    help="N>1: node partitioner (kway = native multilevel, range = contiguous rows)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-peak", action="store_true")
-    ap.add_argument("--extra", action="store_true", help="also time variant L / int64 / API path")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the extra variant-L / static-feature timings of the N=1 line")
+    ap.add_argument("--extra", action="store_true", help="also time int64 ids")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,29 +273,10 @@ def main():
     n = C2_NODES // args.scale
     e = C2_EDGES // args.scale
     f = C2_FEAT
-    n_halo = 0
-    if world > 1:
-        from dgl_amd.parallel import HaloExchange
-
-        n_halo = int(n * args.halo_frac) // (world - 1) * (world - 1)
-    g = synth_csr(n, n + n_halo, e, args.variant, seed=20250824 + rank, device=dev)
-    torch.manual_seed(12345 + rank)
-    x = torch.empty(n + n_halo, f, device=dev)
-    x[:n] = torch.rand(n, f, device=dev) + 1
-    out = torch.empty(n, f, device=dev)
-    csr = _capi.make_csr(g["indptr"], g["indices"], None, n + n_halo)
-    ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, x.dtype, x, None, out),
-                     dtype=torch.uint8, device=dev)
-    halo = HaloExchange(n, n_halo, f, dev, seed=7 + rank) if world > 1 else None
-
-    plan_valid = [False]
-
-    def step():
-        if halo is not None:
-            halo.pull(x)  # fills x[n:] with rows owned by the peers (RCCL all-to-all)
-        _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws,
-                       plan_valid=plan_valid[0])
-        plan_valid[0] = True
+    if world == 1:
+        step, ctx = single_gpu(args, dev, n, e, f)
+    else:
+        step, ctx = multi_gpu(args, dev, n, e, f, rank, world, dist)
 
     for _ in range(max(args.warmup, 1)):
         step()
@@ -210,7 +294,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for a, b in k_ev:
-        _capi.set_profile_events(a, b)
+        if ctx["profile_in_step"]:
+            _capi.set_profile_events(a, b)
         step()
     torch.cuda.synchronize()
     if dist is not None:
@@ -223,21 +308,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    kern_ms = [a.elapsed_time(b) for a, b in k_ev]
-    kern_avg = float(np.mean(kern_ms))
+
+    # ---- dominant-kernel duration (HIP events on the launch stream) -------------------
+    if world == 1:
+        kern_ms = [a.elapsed_time(b) for a, b in k_ev]
+        kern_avg, kern_min = float(np.mean(kern_ms)), float(np.min(kern_ms))
+        kernel_name = "spmm_csr_merge_kernel<int,float,VEC=4,copy_lhs,sum>"
+    else:
+        # a step has two launches of the merge kernel (own-column block, halo-column block):
+        # time each alone, outside the timed region; the roofline is quoted on their sum
+        op, sh = ctx["op"], ctx["shard"]
+        t_loc = merge_kernel_ms(lambda: op.spmm("local", sh["local"], sh["n_local"], ctx["x_loc"],
+                                                ctx["out"], False))
+        t_halo = merge_kernel_ms(lambda: op.spmm("halo", sh["halo"], sh["n_halo"], op.halo,
+                                                 ctx["out"], True)) if sh["n_halo"] else 0.0
+        kern_avg = kern_min = t_loc + t_halo
+        kernel_name = "spmm_csr_merge_kernel<int,float,VEC=4,copy_lhs,sum> x2 (own-column + halo-column block)"
 
     result = None
     if rank == 0:
-        b_alg = algorithmic_bytes(n, e, f)
-        achieved = b_alg / (kern_avg * 1e-3) / 1e9
+        achieved = ctx["alg_bytes"] / (kern_avg * 1e-3) / 1e9
         result = {
             "metric": "edges/sec for g-SpMM copy_u+sum (feat=100); % HBM roofline",
-            "value": e * world / (ms_per_step * 1e-3),
+            "value": e / (ms_per_step * 1e-3),
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -245,23 +343,55 @@ def main():
                 "workload": "configs[1]: g-SpMM copy_u+sum on ogbn-products-shaped CSR "
                             "(N=%d rows, E=%d edges, feat=%d) fp32, int32 ids, variant %s"
                             % (n, e, f, args.variant),
-                "per_gpu_edges": e, "halo_rows_per_gpu": n_halo,
+                "step": "one dgla_spmm_csr call over the whole graph, X treated as new on every "
+                        "step (split-row copy of X when the locality probe wants it, merge kernel, "
+                        "fix-up kernel)" if world == 1 else
+                        "ShardedSpMM.step on every rank: pack + halo all-to-all (RCCL) overlapped "
+                        "with the own-column launch, then the halo-column launch accumulates",
                 "parallelism": "1 GPU" if world == 1 else
-                               "row partition per GPU + halo pull (all_to_all_single over RCCL)",
+                               "%d-way node partition (%s), destination rows + features sharded, "
+                               "halo pull by all_to_all_single over RCCL" % (world, args.partitioner),
+                "tuning_flags": _capi.get_tuning(),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
-                "kernel": "spmm_csr_merge_kernel<int,float,VEC=4,copy_lhs,sum>",
-                "kernel_avg_ms": kern_avg, "kernel_min_ms": float(np.min(kern_ms)),
-                "algorithmic_bytes_per_launch": b_alg,
+                "kernel": kernel_name,
+                "kernel_avg_ms": kern_avg, "kernel_min_ms": kern_min,
+                "algorithmic_bytes_per_launch": ctx["alg_bytes"],
             },
         }
+        if world > 1:
+            infos = ctx["infos"]
+            cut = sum(i["cut_edges"] for i in infos)
+            result["config"].update({
+                "cut_fraction": cut / e, "partition_seconds": ctx["partition_s"],
+                "per_rank": infos,
+                "halo_rows_max": max(i["halo_rows"] for i in infos),
+                "exchange_bytes_per_step_max_rank": max(i["halo_bytes"] for i in infos),
+            })
+            result["roofline"]["note"] = "rank 0's shard: its algorithmic bytes / its two merge launches"
 
-    if rank == 0 and args.scale == 1 and args.variant == "U":
+    if rank == 0 and world == 1 and args.scale == 1 and args.variant == "U":
         t, src = pmc_traffic()
         result["roofline"]["traffic"] = t
         result["roofline"]["traffic_source"] = src
+
+    # ---- N > 1: every rank checks its rows against the one-launch result on the whole graph
+    if world > 1:
+        sh = ctx["shard"]
+        g, xf = ctx["g"], ctx["x"]
+        full = torch.empty(n, f, device=dev)
+        csr = _capi.make_csr(g["indptr"], g["indices"], None, n)
+        ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, xf.dtype, xf, None, full),
+                         dtype=torch.uint8, device=dev)
+        _capi.spmm_csr("copy_lhs", "sum", csr, xf, None, full, None, None, ws)
+        ref = full[sh["rows"]]
+        err = ((ctx["out"] - ref).abs() / ref.abs().clamp_min(1e-30)).max()
+        dist.all_reduce(err, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            result["parity_max_rel_err_vs_single_gpu_launch"] = float(err)
+        del full, ws
 
     # ---- extras on rank 0, outside the timed region ----------------------------------
     if rank == 0 and world == 1:
@@ -272,11 +402,13 @@ def main():
                 result["roofline"]["frac_of_measured_peak"] = result["roofline"]["achieved"] / peak
             except Exception as ex:  # pragma: no cover
                 result["roofline"]["measured_copy_peak_error"] = repr(ex)
+        if not args.no_variants:
+            result["variants"] = variants(dev, ctx, n, e, f, args)
         if not args.no_cpu:
-            cb, ref = cpu_baseline(g, x)
+            cb, ref = cpu_baseline(ctx["g"], ctx["x"])
             result["cpu_baseline"] = cb
             # the full-size run doubles as a parity check against the oracle
-            err = (out.cpu().numpy() - ref) / np.maximum(np.abs(ref), 1e-30)
+            err = (ctx["out"].cpu().numpy() - ref) / np.maximum(np.abs(ref), 1e-30)
             result["parity_max_rel_err_vs_oracle"] = float(np.abs(err).max())
             del ref
         if args.extra:
@@ -286,6 +418,57 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def variants(dev, ctx, n, e, f, args, reps=10):
+    """Same kernel, other situations, timed outside the K steps (median of `reps` whole calls):
+    the locality variant L of the graph, and static features (the split-row copy of X kept
+    between calls: DGLA_SPLIT_KEEP / _VALID, what dgl_amd.static_features(x) selects)."""
+    from dgl_amd import _capi
+
+    res = {}
+    b_alg = algorithmic_bytes(n, e, f)
+
+    def line(ts, kern=None):
+        med = float(np.median(ts))
+        d = {"ms_per_call_median": med, "edges_per_s": e / (med * 1e-3)}
+        if kern is not None:
+            d["merge_kernel_ms"] = kern
+            d["roofline_frac"] = b_alg / (kern * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        return d
+
+    def run(csr, x, out, ws, **kw):
+        _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, **kw)  # plan, copy
+        call = lambda: _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws,
+                                      plan_valid=True, **kw)
+        call()
+        torch.cuda.synchronize()
+        return line(time_events(call, reps), merge_kernel_ms(call))
+
+    x, out = ctx["x"], ctx["out"]
+    if args.variant == "U":
+        _capi.spmm_csr("copy_lhs", "sum", ctx["csr"], x, None, out, None, None, ctx["ws"],
+                       plan_valid=True, split_keep=True)   # makes the copy; kept from here on
+        call = lambda: _capi.spmm_csr("copy_lhs", "sum", ctx["csr"], x, None, out, None, None, ctx["ws"],
+                                      plan_valid=True, split_keep=True, split_valid=True)
+        call()
+        torch.cuda.synchronize()
+        res["U_static_features"] = line(time_events(call, reps), merge_kernel_ms(call))
+        # leave `out` as the per-call path produced it (bit-identical anyway)
+    gl = synth_csr(n, n, e, "L" if args.variant == "U" else "U", seed=20250824, device=dev)
+    csr = _capi.make_csr(gl["indptr"], gl["indices"], None, n)
+    out2 = torch.empty_like(out)
+    ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, x.dtype, x, None, out2),
+                     dtype=torch.uint8, device=dev)
+    other = "L" if args.variant == "U" else "U"
+    res[other + "_int32"] = run(csr, x, out2, ws)
+    call = lambda: _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out2, None, None, ws,
+                                  plan_valid=True, split_keep=True, split_valid=True)
+    _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out2, None, None, ws, plan_valid=True, split_keep=True)
+    call()
+    torch.cuda.synchronize()
+    res[other + "_static_features"] = line(time_events(call, reps), merge_kernel_ms(call))
+    return res
 
 
 def time_spmm(dev, g, x, reps=10):

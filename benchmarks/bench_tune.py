@@ -17,7 +17,14 @@ sys.path.insert(0, ROOT)
 from tests.graphgen import C2_EDGES, C2_NODES, synth_csr  # noqa: E402
 
 
-def run(dev, g, x, flags, reps):
+def probe_counters(ws, num_rows, nnz):
+    """{local, sampled} of the locality probe stored behind the merge plan (spmm_csr.cuh)."""
+    waves = (num_rows + nnz + 511) // 512
+    off = (8 * (waves + 1) + 255) // 256 * 256
+    return [int(v) for v in ws[off:off + 8].view(torch.int32).tolist()]
+
+
+def run(dev, g, x, flags, reps, split_valid=False):
     from dgl_amd import _capi
 
     default = _capi.get_tuning()
@@ -31,6 +38,7 @@ def run(dev, g, x, flags, reps):
     for _ in range(2):
         _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, plan_valid=True)
     torch.cuda.synchronize()
+    run.probe = probe_counters(ws, n, g["nnz"])
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
     kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
            for _ in range(reps)]
@@ -41,7 +49,8 @@ def run(dev, g, x, flags, reps):
     ev[0].record()
     for k in range(reps):
         _capi.set_profile_events(*kev[k])
-        _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, plan_valid=True)
+        _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, plan_valid=True,
+                       split_valid=split_valid)
         ev[k + 1].record()
     torch.cuda.synchronize()
     _capi.set_profile_events(None, None)
@@ -55,7 +64,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=int, default=1)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--flags", default="0,1,2,4,6,8,9,10,14,15")
+    ap.add_argument("--flags", default="0,1,2,4,6,8,9,10,14,15,73,105")
+    ap.add_argument("--split-valid", action="store_true",
+                    help="also time every split-row setting with the copy kept from the previous call")
     ap.add_argument("--variants", default="U,L")
     ap.add_argument("--feats", default="100,96,128,64,104")
     args = ap.parse_args()
@@ -68,13 +79,17 @@ def main():
             torch.manual_seed(12345)
             x = torch.rand(n, f, device=dev) + 1
             base = None
-            for fl in (flags if f == 100 else [0, 15]):
-                step, kern, out = run(dev, g, x, fl, args.reps)
+            runs = [(fl, False) for fl in (flags if f == 100 else [0, 15])]
+            if args.split_valid and f == 100:
+                runs += [(fl, True) for fl in flags if fl & 8]
+            for fl, sv in runs:
+                step, kern, out = run(dev, g, x, fl, args.reps, split_valid=sv)
                 if base is None:
                     base = out.clone()
                 same = bool(torch.equal(out, base))
                 b_alg = e * (f * 4 + 4) + (n + 1) * 4 + n * f * 4
-                print(json.dumps({"variant": variant, "F": f, "flags": fl, "step_ms": round(step, 4),
+                print(json.dumps({"variant": variant, "F": f, "flags": fl, "split_valid": sv,
+                                  "probe_local_sampled": run.probe, "step_ms": round(step, 4),
                                   "merge_kernel_ms": round(kern, 4),
                                   "G_edges_per_s": round(e / step / 1e6, 3),
                                   "alg_GBps_kernel": round(b_alg / kern / 1e6, 1),

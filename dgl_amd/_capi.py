@@ -73,13 +73,17 @@ def spmm_csr_workspace_bytes(op, reduce, csr, dtype, ufeat, efeat, out):
 
 
 def spmm_csr(op, reduce, csr, ufeat, efeat, out, arg_u=None, arg_e=None, workspace=None,
-             accumulate=False, plan_valid=False, mean=False):
+             accumulate=False, plan_valid=False, mean=False, split_keep=False, split_valid=False):
     """out = g-SpMM over `csr` (rows = destination nodes).  `workspace` is a uint8 tensor of
-    at least spmm_csr_workspace_bytes(); it also caches the merge plan between calls."""
+    at least spmm_csr_workspace_bytes(); it also caches the merge plan between calls.
+    `split_keep`: `ufeat` is static (the caller will pass the same unchanged tensor again), so
+    the split-row copy is made whatever the locality probe says; `split_valid`: the workspace
+    still holds that copy of this very `ufeat` — only for callers that own the tensor."""
     keep = []
     tu, te, to = _tensor(ufeat, keep), _tensor(efeat, keep), _tensor(out, keep)
     flags = (_lib.DGLA_ACCUMULATE if accumulate else 0) | (_lib.DGLA_PLAN_VALID if plan_valid else 0) | \
-        (_lib.DGLA_MEAN if mean else 0)
+        (_lib.DGLA_MEAN if mean else 0) | (_lib.DGLA_SPLIT_VALID if split_valid else 0) | \
+        (_lib.DGLA_SPLIT_KEEP if split_keep else 0)
     check_call(LIB.dgla_spmm_csr(
         op.encode(), reduce.encode(), ctypes.byref(csr), _DTYPES[out.dtype], ctypes.byref(tu),
         ctypes.byref(te), ctypes.byref(to), _ptr(arg_u), _ptr(arg_e), _ptr(workspace),
@@ -345,3 +349,47 @@ def to_block(seeds, src, node_map):
                                  _ptr(local), src_nodes.data_ptr(), num.data_ptr(), None, 0, _stream(seeds)))
     k = int(num.item())
     return local, src_nodes[:k], k
+
+
+def gather_rows(src, idx, out=None):
+    """out[i] = src[idx[i]] along dim 0 (dgla_gather_rows): the pack kernel of the halo exchange."""
+    _require_gpu(src)
+    _require_gpu(idx)
+    if not src.is_contiguous():
+        raise _lib.DGLAMDError("gather_rows: src must be contiguous")
+    idx = idx.contiguous()
+    if out is None:
+        out = torch.empty((idx.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    elif not out.is_contiguous() or out.shape[0] != idx.shape[0] or out.shape[1:] != src.shape[1:] \
+            or out.dtype != src.dtype:
+        raise _lib.DGLAMDError("gather_rows: out must be contiguous with one row per index")
+    row_bytes = src.element_size()
+    for d in src.shape[1:]:
+        row_bytes *= int(d)
+    check_call(LIB.dgla_gather_rows(_idbits(idx), src.data_ptr(), idx.data_ptr(), idx.shape[0],
+                                    row_bytes, out.data_ptr(), _stream(out)))
+    return out
+
+
+def partition_map(mode, num_parts, part_range, idx, want_part=True, want_local=True):
+    """(part, local) ids of the global ids `idx` under a remainder (mode 0) or range (mode 1)
+    partition (dgla_partition_map)."""
+    _require_gpu(idx)
+    idx = idx.contiguous()
+    part = torch.empty_like(idx) if want_part else None
+    local = torch.empty_like(idx) if want_local else None
+    check_call(LIB.dgla_partition_map(_idbits(idx), int(mode), int(num_parts), _ptr(part_range),
+                                      idx.data_ptr(), idx.shape[0], _ptr(part), _ptr(local),
+                                      _stream(idx)))
+    return part, local
+
+
+def partition_to_global(mode, num_parts, part_range, local_idx, part_id):
+    _require_gpu(local_idx)
+    local_idx = local_idx.contiguous()
+    out = torch.empty_like(local_idx)
+    check_call(LIB.dgla_partition_to_global(_idbits(local_idx), int(mode), int(num_parts),
+                                            _ptr(part_range), local_idx.data_ptr(),
+                                            local_idx.shape[0], int(part_id), out.data_ptr(),
+                                            _stream(out)))
+    return out

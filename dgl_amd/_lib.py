@@ -133,6 +133,14 @@ LIB.dgla_to_block.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_int64, c_voi
 LIB.dgla_partition_kway.restype = c_int
 LIB.dgla_partition_kway.argtypes = [c_int, c_int64, c_void_p, c_void_p, c_int, ctypes.c_double, c_int,
                                     ctypes.c_uint64, c_void_p, c_void_p]
+LIB.dgla_gather_rows.restype = c_int
+LIB.dgla_gather_rows.argtypes = [c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]
+LIB.dgla_partition_map.restype = c_int
+LIB.dgla_partition_map.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                   c_void_p]
+LIB.dgla_partition_to_global.restype = c_int
+LIB.dgla_partition_to_global.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p,
+                                         c_void_p]
 LIB.dgla_set_tuning.restype = c_int
 LIB.dgla_set_tuning.argtypes = [c_uint32]
 LIB.dgla_get_tuning.restype = c_uint32
@@ -144,7 +152,11 @@ LIB.dgla_stream_copy_variant.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_
 DGLA_ACCUMULATE = 1
 DGLA_PLAN_VALID = 2
 DGLA_MEAN = 4
+DGLA_SPLIT_VALID = 8
+DGLA_SPLIT_KEEP = 16
 DGLA_TUNE_XCD, DGLA_TUNE_NT_OUT, DGLA_TUNE_NT_IDX, DGLA_TUNE_SPLIT, DGLA_TUNE_GLDS = 1, 2, 4, 8, 16
+DGLA_TUNE_SPLIT_NT, DGLA_TUNE_SPLIT_FORCE = 32, 64
+DEFAULT_TUNING = DGLA_TUNE_XCD | DGLA_TUNE_SPLIT | DGLA_TUNE_GLDS  # csrc/common.h kDefaultTuning
 
 
 def check_call(ret):

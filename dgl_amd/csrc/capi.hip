@@ -323,10 +323,13 @@ int dgla_spmm_csr(const char* op, const char* reduce, const dgla_csr* csr, dgla_
   if (L.mean && (L.red != kSum || L.accumulate))
     return fail("DGLA_MEAN is defined for reduce == sum without DGLA_ACCUMULATE");
   L.plan_valid = (flags & DGLA_PLAN_VALID) != 0;
+  L.split_valid = (flags & DGLA_SPLIT_VALID) != 0 && L.plan_valid;
+  L.split_keep = L.split_valid || (flags & DGLA_SPLIT_KEEP) != 0;
   L.workspace = workspace;
   L.workspace_bytes = workspace_bytes;
   L.stream = static_cast<hipStream_t>(hip_stream);
   if (csr->num_rows == 0 || L.out_len == 0) return 0;
+  const DeviceGuard dev(L.stream, L.out);
   switch (dtype) {
     case DGLA_F32: return launch_spmm_csr_f32(L);
     case DGLA_F64: return launch_spmm_csr_f64(L);
@@ -393,6 +396,7 @@ int dgla_spmm_csr_stacked(const char* op, const dgla_csr* csr, const void* rel, 
   L.workspace_bytes = workspace_bytes;
   L.stream = static_cast<hipStream_t>(hip_stream);
   if (csr->num_rows == 0 || L.out_len == 0) return 0;
+  const DeviceGuard dev(L.stream, L.out);
   switch (dtype) {
     case DGLA_F32: return launch_spmm_csr_f32(L);
     case DGLA_F64: return launch_spmm_csr_f64(L);
@@ -418,6 +422,7 @@ int dgla_spmm_coo(const char* op_s, const char* red_s, const dgla_coo* coo, dgla
     if (op_uses_rhs(op) && !arg_e) return fail("arg_e is required for max/min");
   }
   if (coo->num_cols == 0 || bc.out_len == 0) return 0;
+  const DeviceGuard dev(static_cast<hipStream_t>(hip_stream), out->data);
   return launch_spmm_coo(v, op, red, dtype, op_uses_lhs(op) ? ufeat->data : nullptr,
                          op_uses_rhs(op) ? efeat->data : nullptr, out->data, arg_u, arg_e,
                          bc.out_len, bc.lhs_len, bc.rhs_len, bc.use_bcast, bc.dims,
@@ -472,6 +477,7 @@ static int sddmm_common(const char* op_s, bool use_coo, const dgla_csr* csr, con
   L.bdims = bc.dims;
   L.stream = static_cast<hipStream_t>(stream);
   if (bc.out_len == 0) return 0;
+  const DeviceGuard dev(L.stream, L.out);
   switch (dtype) {
     case DGLA_F32: return launch_sddmm_f32(L);
     case DGLA_F64: return launch_sddmm_f64(L);
@@ -509,6 +515,7 @@ int dgla_edge_softmax_forward(const dgla_csr* csr, dgla_dtype dtype, const dgla_
   if (check_tensor(score, "score", csr->nnz) || check_tensor(out, "out", csr->nnz)) return -1;
   if (feat_len(score) != feat_len(out)) return fail("score and out shapes differ");
   if (csr->nnz == 0 || feat_len(score) == 0) return 0;
+  const DeviceGuard dev(static_cast<hipStream_t>(hip_stream), out->data);
   return launch_edge_softmax(v, dtype, score->data, nullptr, out->data, feat_len(score), false,
                              workspace, workspace_bytes, (flags & DGLA_PLAN_VALID) != 0,
                              static_cast<hipStream_t>(hip_stream));
@@ -527,6 +534,7 @@ int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla
   if (feat_len(out) != feat_len(sds) || feat_len(out) != feat_len(back))
     return fail("out, sds and back shapes differ");
   if (csr->nnz == 0 || feat_len(out) == 0) return 0;
+  const DeviceGuard dev(static_cast<hipStream_t>(hip_stream), back->data);
   return launch_edge_softmax(v, dtype, out->data, sds->data, back->data, feat_len(out), true,
                              workspace, workspace_bytes, (flags & DGLA_PLAN_VALID) != 0,
                              static_cast<hipStream_t>(hip_stream));
@@ -546,11 +554,13 @@ int dgla_spmm_set_profile_events(void* before, void* after) {
 }
 
 int dgla_stream_copy(void* dst, const void* src, size_t bytes, void* hip_stream) {
+  const DeviceGuard dev(static_cast<hipStream_t>(hip_stream), dst);
   return launch_stream_copy(dst, src, bytes, 1 << 2, static_cast<hipStream_t>(hip_stream));
 }
 
 int dgla_stream_copy_variant(void* dst, const void* src, size_t bytes, int variant,
                              void* hip_stream) {
+  const DeviceGuard dev(static_cast<hipStream_t>(hip_stream), dst);
   return launch_stream_copy(dst, src, bytes, variant, static_cast<hipStream_t>(hip_stream));
 }
 

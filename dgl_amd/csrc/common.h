@@ -149,6 +149,8 @@ struct SpmmLaunch {
   bool mean;        // reduce == sum: store sum / max(in_degree, 1)  (the `mean` reducer, fused)
   bool accumulate;  // out += result (reference semantics, spmm.cuh:528-534) vs out = result
   bool plan_valid;  // workspace already holds the merge plan of this CSR
+  bool split_valid; // workspace already holds the split-row copy of this ufeat (DGLA_SPLIT_VALID)
+  bool split_keep;  // static ufeat: use the split-row layout whatever the probe says (DGLA_SPLIT_KEEP)
   void* workspace;
   size_t workspace_bytes;
   hipStream_t stream;
@@ -177,12 +179,17 @@ enum Tune : uint32_t {
   kTuneNtIdx = 4u,  // non-temporal loads of the index streams (indices / indptr / eids)
   kTuneSplit = 8u,  // split-row re-layout of ufeat when rows are not a whole number of 128-B lines
   kTuneGlds = 16u,  // segment_mm: LDS-direct (global_load_lds) slab rings instead of register staging
+  kTuneSplitNt = 32u,     // split-row copy: non-temporal stores of the main array
+  kTuneSplitForce = 64u,  // split-row layout whenever the shape allows, whatever the locality probe says
 };
 // Default: XCD-contiguous order (measured on C2: variant L -3 % time, variant U neutral); the
-// non-temporal bits are neutral and split-row trades a 0.49 ms copy for a 0.51 ms faster gather
-// on variant U but loses on variant L (profiles/r1/tune_ab.jsonl) -> opt-in.  The LDS-direct
+// non-temporal bits are neutral.  Split-row (profiles/r2/tune_split_ab.jsonl, C2, F = 100 fp32):
+// the copy costs 0.33 ms (5.9 TB/s) and the gather drops 4.86 -> 4.38 ms on variant U, so the
+// step gains 3 % even when the copy is repeated on every call and 10 % when the features are
+// static (DGLA_SPLIT_KEEP / _VALID); on variant L the locality probe (81 % local edges against
+// 5 % on U) declines it unless the features are static (4.08 -> 3.75 ms) -> on.  The LDS-direct
 // segment_mm loop is 23-34 % faster at every measured shape (profiles/r1/glds_ab.jsonl) -> on.
-constexpr uint32_t kDefaultTuning = 1u | 16u;
+constexpr uint32_t kDefaultTuning = 1u | 8u | 16u;
 uint32_t& tuning_flags();
 
 // Merge-path geometry of the CSR SpMM (see spmm_csr.cuh).
@@ -202,6 +209,41 @@ struct ProfileEvents {
   hipEvent_t after = nullptr;
 };
 ProfileEvents& profile_events();
+
+// Makes the device that owns the launch current for the lifetime of the guard and restores the
+// previous one afterwards (the reference switches device in its DeviceAPI before every launch,
+// src/runtime/cuda/cuda_device_api.cc SetDevice).  The owner is taken from the stream when one
+// is given; the null stream belongs to whatever device is current, so there the owner is read
+// off a device pointer of the call (normally the output).  Failures of the queries (no GPU in
+// the process, host pointer) leave the current device alone: the launch reports the real error.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  DeviceGuard(hipStream_t stream, const void* device_ptr) {
+    int cur = -1, owner = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return;
+    if (stream != nullptr) {
+      hipDevice_t d;
+      if (hipStreamGetDevice(stream, &d) == hipSuccess) owner = static_cast<int>(d);
+    } else if (device_ptr != nullptr) {
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, device_ptr) == hipSuccess &&
+          at.type == hipMemoryTypeDevice)
+        owner = at.device;
+      else
+        (void)hipGetLastError();  // a host / unregistered pointer is not this guard's business
+    }
+    if (owner >= 0 && owner != cur && hipSetDevice(owner) == hipSuccess) {
+      prev = cur;
+      switched = true;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 #define DGLA_CHECK_HIP(expr)                                                       \
   do {                                                                             \
     hipError_t _e = (expr);                                                        \

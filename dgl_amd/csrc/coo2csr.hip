@@ -138,6 +138,7 @@ int dgla_coo_to_csr(int idtype_bits, int64_t num_rows, int64_t nnz, const void* 
   if (idtype_bits == 32 && (nnz > 0x7fffffffLL || num_rows > 0x7fffffffLL))
     return cfail("int32 ids cannot address this many edges / rows");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, indptr);
   const size_t need = dgla_coo_to_csr_workspace_bytes(idtype_bits, num_rows, nnz);
   void* owned = nullptr;
   if (need && (!workspace || workspace_bytes < need)) {

@@ -1,0 +1,205 @@
+// Device side of the multi-GPU exchange step: row pack kernels for the halo
+// all-to-all and the NDArrayPartition index maps.
+//
+// Reference: python/dgl/cuda/nccl.py:7-183 (sparse_all_to_all_push / _pull: `value[perm]`,
+// `value[resp_idx]`, `return_value[perm] = req_value` are torch index kernels there) and
+// src/partition/cuda/partition_op.cu (MapToLocal / MapToGlobal / GeneratePermutation for the
+// remainder and range partitions; src/partition/ndarray_partition.cc:30-230).
+//
+// gather_rows: dst[i, :] = src[idx[i], :] with 16-byte lane accesses and K rows-pieces in
+// flight per lane — the pack step in front of the all-to-all (and, read the other way round,
+// the un-permute after it).  The scatter-add direction (gradient push) is dgla_scatter_add
+// (segment.hip).  Index maps: one thread per index, closed-form for the remainder partition,
+// a binary search over the (<= a few hundred) range boundaries otherwise.
+#include "../../include/dgl_amd.h"
+
+#include "common.h"
+
+namespace dgla {
+namespace {
+
+int xfail(const std::string& m) {
+  last_error() = m;
+  return -1;
+}
+
+template <typename Idx, typename Piece, int K>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const Piece* __restrict__ src,
+                                                          const Idx* __restrict__ idx,
+                                                          Piece* __restrict__ dst, int64_t n,
+                                                          int pieces, unsigned magic) {
+  const int64_t total = n * pieces;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * (256 * K); base < total;
+       base += static_cast<int64_t>(gridDim.x) * (256 * K)) {
+    const int64_t r0 = base / pieces;  // block-uniform
+    const unsigned j0 = static_cast<unsigned>(base - r0 * pieces);
+    Piece v[K];
+    int64_t at[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      int64_t i = base + k * 256 + threadIdx.x;
+      if (i >= total) i = total - 1;
+      // row of piece i: block-local piece number / pieces by multiply-high (exact: the numbers
+      // stay below 2^16, magic = ceil(2^32 / pieces))
+      const unsigned loc = j0 + static_cast<unsigned>(i - base);
+      const unsigned dr = __umulhi(loc, magic);
+      const unsigned j = loc - dr * static_cast<unsigned>(pieces);
+      at[k] = static_cast<int64_t>(idx[r0 + dr]) * pieces + j;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = src[at[k]];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int64_t i = base + k * 256 + threadIdx.x;
+      if (i < total) dst[i] = v[k];
+    }
+  }
+}
+
+template <typename Idx, typename Piece>
+int run_gather(const void* src, const void* idx, void* dst, int64_t n, int64_t row_bytes,
+               hipStream_t s) {
+  constexpr int K = 4;
+  const int64_t pieces = row_bytes / static_cast<int64_t>(sizeof(Piece));
+  if (pieces > 0xffff) return xfail("gather_rows: rows longer than 65535 pieces are not supported");
+  const int64_t total = n * pieces;
+  const unsigned blocks =
+      static_cast<unsigned>(std::min<int64_t>((total + 256 * K - 1) / (256 * K), int64_t(1) << 20));
+  const unsigned magic = 0xFFFFFFFFu / static_cast<unsigned>(pieces) + 1u;
+  hipLaunchKernelGGL((gather_rows_kernel<Idx, Piece, K>), dim3(blocks), dim3(256), 0, s,
+                     static_cast<const Piece*>(src), static_cast<const Idx*>(idx),
+                     static_cast<Piece*>(dst), n, static_cast<int>(pieces), magic);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// mode 0: remainder (part = id % k, local = id / k); mode 1: range (part = the range holding id,
+// local = id - range[part]).  Either output may be NULL.
+template <typename Idx>
+__global__ __launch_bounds__(256) void partition_map_kernel(int mode, int num_parts,
+                                                            const Idx* __restrict__ range,
+                                                            const Idx* __restrict__ idx, int64_t n,
+                                                            Idx* __restrict__ part_out,
+                                                            Idx* __restrict__ local_out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) {
+    const Idx g = idx[i];
+    Idx p, l;
+    if (mode == 0) {
+      p = g % static_cast<Idx>(num_parts);
+      l = g / static_cast<Idx>(num_parts);
+    } else {
+      int lo = 0, hi = num_parts - 1;  // largest p with range[p] <= g
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (range[mid] <= g)
+          lo = mid;
+        else
+          hi = mid - 1;
+      }
+      p = static_cast<Idx>(lo);
+      l = g - range[lo];
+    }
+    if (part_out) part_out[i] = p;
+    if (local_out) local_out[i] = l;
+  }
+}
+
+template <typename Idx>
+__global__ __launch_bounds__(256) void partition_to_global_kernel(int mode, int num_parts,
+                                                                  const Idx* __restrict__ range,
+                                                                  const Idx* __restrict__ local,
+                                                                  int64_t n, int part_id,
+                                                                  Idx* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const Idx base = mode == 0 ? Idx(0) : range[part_id];
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride)
+    out[i] = mode == 0 ? local[i] * static_cast<Idx>(num_parts) + static_cast<Idx>(part_id)
+                       : local[i] + base;
+}
+
+unsigned grid_for(int64_t n) {
+  return static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 256 * 32));
+}
+
+}  // namespace
+}  // namespace dgla
+
+using namespace dgla;
+
+extern "C" {
+
+int dgla_gather_rows(int idtype_bits, const void* src, const void* idx, int64_t n,
+                     int64_t row_bytes, void* dst, void* hip_stream) {
+  if (idtype_bits != 32 && idtype_bits != 64) return xfail("idtype must be int32 or int64");
+  if (n < 0 || row_bytes < 0) return xfail("negative size");
+  if (n == 0 || row_bytes == 0) return 0;
+  if (!src || !idx || !dst) return xfail("gather_rows: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, dst);
+  const uintptr_t both = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst);
+  const bool v16 = row_bytes % 16 == 0 && both % 16 == 0;
+  const bool v4 = row_bytes % 4 == 0 && both % 4 == 0;
+#define DGLA_GR(IDX)                                                              \
+  if (v16) return run_gather<IDX, u32x4>(src, idx, dst, n, row_bytes, s);          \
+  if (v4) return run_gather<IDX, uint32_t>(src, idx, dst, n, row_bytes, s);        \
+  return run_gather<IDX, unsigned char>(src, idx, dst, n, row_bytes, s)
+  if (idtype_bits == 32) {
+    DGLA_GR(int32_t);
+  }
+  DGLA_GR(int64_t);
+#undef DGLA_GR
+}
+
+int dgla_partition_map(int idtype_bits, int mode, int num_parts, const void* range, const void* idx,
+                       int64_t n, void* part_out, void* local_out, void* hip_stream) {
+  if (idtype_bits != 32 && idtype_bits != 64) return xfail("idtype must be int32 or int64");
+  if (mode != 0 && mode != 1) return xfail("partition mode must be 0 (remainder) or 1 (range)");
+  if (num_parts < 1) return xfail("num_parts must be positive");
+  if (mode == 1 && !range) return xfail("range partition needs the range array");
+  if (n == 0) return 0;
+  if (n < 0 || !idx) return xfail("partition_map: bad index array");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, idx);
+  if (idtype_bits == 32)
+    hipLaunchKernelGGL(partition_map_kernel<int32_t>, dim3(grid_for(n)), dim3(256), 0, s, mode,
+                       num_parts, static_cast<const int32_t*>(range),
+                       static_cast<const int32_t*>(idx), n, static_cast<int32_t*>(part_out),
+                       static_cast<int32_t*>(local_out));
+  else
+    hipLaunchKernelGGL(partition_map_kernel<int64_t>, dim3(grid_for(n)), dim3(256), 0, s, mode,
+                       num_parts, static_cast<const int64_t*>(range),
+                       static_cast<const int64_t*>(idx), n, static_cast<int64_t*>(part_out),
+                       static_cast<int64_t*>(local_out));
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const void* range,
+                             const void* local_idx, int64_t n, int part_id, void* out,
+                             void* hip_stream) {
+  if (idtype_bits != 32 && idtype_bits != 64) return xfail("idtype must be int32 or int64");
+  if (mode != 0 && mode != 1) return xfail("partition mode must be 0 (remainder) or 1 (range)");
+  if (num_parts < 1 || part_id < 0 || part_id >= num_parts) return xfail("invalid part id");
+  if (mode == 1 && !range) return xfail("range partition needs the range array");
+  if (n == 0) return 0;
+  if (n < 0 || !local_idx || !out) return xfail("partition_to_global: bad arrays");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, out);
+  if (idtype_bits == 32)
+    hipLaunchKernelGGL(partition_to_global_kernel<int32_t>, dim3(grid_for(n)), dim3(256), 0, s,
+                       mode, num_parts, static_cast<const int32_t*>(range),
+                       static_cast<const int32_t*>(local_idx), n, part_id,
+                       static_cast<int32_t*>(out));
+  else
+    hipLaunchKernelGGL(partition_to_global_kernel<int64_t>, dim3(grid_for(n)), dim3(256), 0, s,
+                       mode, num_parts, static_cast<const int64_t*>(range),
+                       static_cast<const int64_t*>(local_idx), n, part_id,
+                       static_cast<int64_t*>(out));
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

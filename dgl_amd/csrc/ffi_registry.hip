@@ -57,6 +57,7 @@ static int ffi_fail(const std::string& msg) {
 
 // thread-local stream, like the reference's per-thread CUDAThreadEntry / current torch stream
 static thread_local hipStream_t tls_stream = nullptr;
+static thread_local int tls_device = -1;  // device id named by the last DGLSetStream, -1 = never set
 
 // ---- argument unpacking -------------------------------------------------------------
 static bool is_array(int tc) { return tc == kArrayHandle || tc == kNDArrayContainer; }
@@ -167,6 +168,19 @@ struct UnitGraph {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   bool plan_valid = false;
+  // Static source features (dgl_amd._CAPI_UnitGraphStaticOperand): `pending_static` is the
+  // token the Python layer announced for the NEXT SpMM's U operand (one-shot, 0 = not static);
+  // `split_key` describes whose split-row copy the workspace holds right now (token 0 = nobody's).
+  int64_t pending_static = 0;
+  struct SplitKey {
+    int64_t token = 0, out_len = 0, rows = 0;
+    int dtype = -1;
+    bool with_arg = false;
+    bool operator==(const SplitKey& o) const {
+      return token == o.token && out_len == o.out_len && rows == o.rows && dtype == o.dtype &&
+             with_arg == o.with_arg;
+    }
+  } split_key;
   // scratch of the merge-path edge softmax on `csc` (its own plan: units of 256 items)
   void* esm_ws = nullptr;
   size_t esm_ws_bytes = 0;
@@ -233,7 +247,10 @@ static int set_format(const FfiArgs& a, int which) {
     const int64_t rows = which == 1 ? g->num_src : g->num_dst;
     if (x->shape[0] != rows + 1) return ffi_fail("indptr must have num_rows + 1 entries");
     (which == 1 ? g->csr : g->csc) = f;
-    if (which == 2) g->plan_valid = g->esm_plan_valid = false;
+    if (which == 2) {
+      g->plan_valid = g->esm_plan_valid = false;
+      g->split_key = UnitGraph::SplitKey();
+    }
   }
   g->num_edges = f.nnz;
   return 0;
@@ -281,6 +298,7 @@ static Registrar r_ws("dgl_amd._CAPI_UnitGraphSetWorkspace", [](const FfiArgs& a
   g->ws = null_array(w) ? nullptr : data_ptr(w);
   g->ws_bytes = null_array(w) ? 0 : static_cast<size_t>(w->shape[0]) * ((w->dtype.bits + 7) / 8);
   g->plan_valid = false;
+  g->split_key = UnitGraph::SplitKey();
   *rtc = kNull;
   return 0;
 });
@@ -353,6 +371,36 @@ static Registrar r_spmm_ws("sparse._CAPI_DGLKernelSpMMWorkspaceBytes",
   return last_error().empty() ? 0 : -1;
 });
 
+// Static source features: turns the token announced for this call into DGLA_SPLIT_KEEP /
+// DGLA_SPLIT_VALID and returns what the workspace's split copy will describe afterwards.
+static UnitGraph::SplitKey static_split_flags(UnitGraph* g, const SpmmCall& c, uint32_t* flags) {
+  UnitGraph::SplitKey key;
+  key.token = g->pending_static;
+  g->pending_static = 0;
+  if (key.token == 0 || null_array(c.U)) return UnitGraph::SplitKey();
+  key.out_len = 1;
+  for (int i = 1; i < c.v.t.ndim; ++i) key.out_len *= c.v.t.shape[i];
+  key.rows = c.u.t.shape[0];
+  key.dtype = static_cast<int>(c.dtype);
+  key.with_arg = strcmp(c.reduce, "sum") != 0;
+  *flags |= DGLA_SPLIT_KEEP;
+  if (g->plan_valid && g->split_key == key) *flags |= DGLA_SPLIT_VALID;
+  return key;
+}
+
+// (g, token): the NEXT sparse._CAPI_DGLKernelSpMM[Mean] call on this graph reads a U operand its
+// owner declared static (dgl_amd.static_features); `token` identifies that tensor for as long
+// as it lives.  One-shot: the SpMM consumes it.
+static Registrar r_static("dgl_amd._CAPI_UnitGraphStaticOperand",
+                          [](const FfiArgs& a, DGLValue*, int* rtc) {
+  void* h;
+  int64_t tok;
+  if (get_handle(a, 0, &h) || get_int(a, 1, &tok)) return -1;
+  static_cast<UnitGraph*>(h)->pending_static = tok;
+  *rtc = kNull;
+  return 0;
+});
+
 static Registrar r_spmm("sparse._CAPI_DGLKernelSpMM", [](const FfiArgs& a, DGLValue*, int* rtc) {
   *rtc = kNull;
   SpmmCall c;
@@ -362,13 +410,15 @@ static Registrar r_spmm("sparse._CAPI_DGLKernelSpMM", [](const FfiArgs& a, DGLVa
   if (g->csc.present) {
     const dgla_csr csc = csr_of(g, g->csc, true);
     uint32_t flags = g->plan_valid ? DGLA_PLAN_VALID : 0;
+    const UnitGraph::SplitKey key = static_split_flags(g, c, &flags);
     // `V` arrives zero-filled (python/dgl/_sparse_ops.py:227) so writing rows instead of
     // accumulating into them gives the same result for the single-relation call.
     const int rc = dgla_spmm_csr(c.op, c.reduce, &csc, c.dtype, &c.u.t, &c.e.t, &c.v.t,
                                  null_array(c.ArgU) ? nullptr : data_ptr(c.ArgU),
                                  null_array(c.ArgE) ? nullptr : data_ptr(c.ArgE), g->ws,
                                  g->ws_bytes, flags, tls_stream);
-    if (rc == 0) g->plan_valid = true;
+    g->plan_valid = rc == 0;
+    g->split_key = rc == 0 ? key : UnitGraph::SplitKey();
     return rc;
   }
   if (g->coo.present) {
@@ -390,10 +440,12 @@ static Registrar r_spmm_mean("sparse._CAPI_DGLKernelSpMMMean",
   UnitGraph* g = c.g;
   if (!g->csc.present) return ffi_fail("SpMMMean needs the CSC format");
   const dgla_csr csc = csr_of(g, g->csc, true);
-  const uint32_t flags = (g->plan_valid ? DGLA_PLAN_VALID : 0) | DGLA_MEAN;
+  uint32_t flags = (g->plan_valid ? DGLA_PLAN_VALID : 0) | DGLA_MEAN;
+  const UnitGraph::SplitKey key = static_split_flags(g, c, &flags);
   const int rc = dgla_spmm_csr(c.op, c.reduce, &csc, c.dtype, &c.u.t, &c.e.t, &c.v.t, nullptr,
                                nullptr, g->ws, g->ws_bytes, flags, tls_stream);
-  if (rc == 0) g->plan_valid = true;
+  g->plan_valid = rc == 0;
+  g->split_key = rc == 0 ? key : UnitGraph::SplitKey();
   return rc;
 });
 
@@ -410,6 +462,8 @@ static Registrar r_spmm_acc("sparse._CAPI_DGLKernelSpMMAccumulate",
   const uint32_t flags = (g->plan_valid ? DGLA_PLAN_VALID : 0) | DGLA_ACCUMULATE;
   const int rc = dgla_spmm_csr(c.op, c.reduce, &csc, c.dtype, &c.u.t, &c.e.t, &c.v.t, nullptr,
                                nullptr, g->ws, g->ws_bytes, flags, tls_stream);
+  g->pending_static = 0;
+  g->split_key = UnitGraph::SplitKey();  // the call may have re-laid ITS operand into the scratch
   if (rc == 0) g->plan_valid = true;
   return rc;
 });
@@ -459,6 +513,7 @@ static int spmm_stacked_ffi(const FfiArgs& a, DGLValue* ret, int* rtc, bool want
       null_array(Ut) ? nullptr : static_cast<const void* const*>(data_ptr(Ut)),
       null_array(Et) ? nullptr : static_cast<const void* const*>(data_ptr(Et)), &v.t, g->ws,
       g->ws_bytes, g->plan_valid ? DGLA_PLAN_VALID : 0, tls_stream);
+  g->split_key = UnitGraph::SplitKey();
   if (rc == 0) g->plan_valid = true;
   return rc;
 }
@@ -990,10 +1045,12 @@ static int spmm_unit(UnitGraph* g, const char* op, const char* reduce, dgla_dtyp
       flags |= DGLA_PLAN_VALID;
     }
     const int rc = dgla_spmm_csr(op, reduce, &csc, dt, u, e, v, arg_u, arg_e, ws, ws_bytes, flags, tls_stream);
-    if (owned)
+    if (owned) {
       (void)hipFreeAsync(owned, tls_stream);
-    else if (rc == 0)
-      g->plan_valid = true;
+    } else {
+      g->split_key = UnitGraph::SplitKey();
+      if (rc == 0) g->plan_valid = true;
+    }
     return rc;
   }
   if (g->coo.present) {
@@ -1291,6 +1348,19 @@ int DGLFuncCall(DGLFunctionHandle func, DGLValue* args, int* type_codes, int num
   DGLValue dummy;
   int dummy_tc = kNull;
   const FfiArgs a{args, type_codes, num_args};
+  // run with the device of the last DGLSetStream current (kernels, stream-ordered allocations
+  // and rocPRIM calls are issued for the CURRENT device); restored on return
+  int prev_dev = -1;
+  bool switched = false;
+  if (tls_device >= 0 && hipGetDevice(&prev_dev) == hipSuccess && prev_dev != tls_device)
+    switched = hipSetDevice(tls_device) == hipSuccess;
+  struct Restore {
+    int dev;
+    bool on;
+    ~Restore() {
+      if (on) (void)hipSetDevice(dev);
+    }
+  } restore{prev_dev, switched};
   try {
     return (*static_cast<PackedFn*>(func))(a, ret_val ? ret_val : &dummy,
                                            ret_type_code ? ret_type_code : &dummy_tc);
@@ -1302,8 +1372,12 @@ int DGLFuncCall(DGLFunctionHandle func, DGLValue* args, int* type_codes, int num
 
 int DGLFuncFree(DGLFunctionHandle) { return 0; }  // global functions are never freed
 
-int DGLSetStream(int, int, void* stream) {
+// The reference's DGLSetStream(device_type, device_id, stream) selects the stream of ONE device
+// (src/runtime/c_runtime_api.cc DGLSetStream -> DeviceAPI::SetStream); the registry functions
+// then run with that device current (DGLFuncCall below), like DeviceAPI::SetDevice does.
+int DGLSetStream(int, int device_id, void* stream) {
   tls_stream = static_cast<hipStream_t>(stream);
+  tls_device = device_id;
   return 0;
 }
 int DGLGetStream(int, int, void** stream) {

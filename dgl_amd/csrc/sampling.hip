@@ -291,6 +291,7 @@ int dgla_sample_neighbors(const dgla_csr* csc, const void* seeds, int64_t num_se
   if (!out_indptr) return sfail("out_indptr is null");
   if (num_seeds > 0 && !seeds) return sfail("seeds is null");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, out_indptr);
   const size_t need = dgla_sample_neighbors_workspace_bytes(csc->idtype_bits, num_seeds);
   void* owned = nullptr;
   if (!workspace || workspace_bytes < need) {
@@ -319,6 +320,7 @@ int dgla_to_block(int idtype_bits, const void* seeds, int64_t num_seeds, const v
   if ((num_seeds > 0 && !seeds) || (nnz > 0 && (!src || !local_src))) return sfail("input arrays are null");
   if (num_seeds + nnz > 0x7fffffffLL) return sfail("a block with more than 2^31-1 source nodes is not supported");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, node_map);
   const size_t need = dgla_to_block_workspace_bytes(idtype_bits, nnz);
   void* owned = nullptr;
   if (!workspace || workspace_bytes < need) {

@@ -306,6 +306,7 @@ int dgla_segment_reduce(const char* reduce, int idtype_bits, dgla_dtype dtype,
   L.accumulate = false;
   L.plan_valid = (flags & DGLA_PLAN_VALID) != 0;
   L.stream = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(L.stream, L.out);
   // scratch: the caller's, or a stream-ordered allocation released after the launches
   void* owned = nullptr;
   if (!workspace) {
@@ -344,6 +345,7 @@ int dgla_scatter_add(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat,
   if (!feat->data || !out->data || !idx) return sfail("feat / idx / out data is null");
   if (dim > 0x7fffffffLL / 4) return sfail("feature length too large");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, out->data);
   const int64_t out_rows = out->shape[0];
   if (n * dim >= kScatterSortMinElems && out_rows > 0) return scatter_add_sorted(idtype_bits, dtype, feat, idx, out, s);
   DGLA_IDX_DTYPE_SWITCH(idtype_bits, dtype, run_scatter_add, feat->data, idx, out->data, n, dim, s);
@@ -361,6 +363,7 @@ int dgla_backward_segment_cmp(int idtype_bits, dgla_dtype dtype, const dgla_tens
   if (n == 0 || dim == 0) return 0;
   if (!feat->data || !out->data || !arg) return sfail("feat / arg / out data is null");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, out->data);
   DGLA_IDX_DTYPE_SWITCH(idtype_bits, dtype, run_bwd_segment_cmp, feat->data, arg, out->data, n, dim, s);
   return sfail("unsupported feature dtype");
 }

@@ -55,15 +55,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---- plan: tiles per relation ---------------------------------------------------------
 // plan[0 .. R]        exclusive prefix of ceil(len / rows_per_tile)
 // plan[R+1 .. 2R+1]   exclusive prefix of len (row offsets)
+// Lengths are clamped to the rows that exist (a device-side seglen cannot be checked on the host
+// without a synchronisation): segments never reach past row num_rows, whatever seglen holds.
 template <typename Idx>
 __global__ void segment_plan_kernel(const Idx* __restrict__ seglen, int64_t num_rel,
-                                    int rows_per_tile, int64_t* __restrict__ plan) {
+                                    int rows_per_tile, int64_t num_rows,
+                                    int64_t* __restrict__ plan) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   int64_t t = 0, r0 = 0;
   for (int64_t r = 0; r < num_rel; ++r) {
     plan[r] = t;
     plan[num_rel + 1 + r] = r0;
-    const int64_t len = static_cast<int64_t>(seglen[r]);
+    int64_t len = static_cast<int64_t>(seglen[r]);
+    if (len < 0) len = 0;
+    if (len > num_rows - r0) len = num_rows - r0;
     t += (len + rows_per_tile - 1) / rows_per_tile;
     r0 += len;
   }
@@ -848,8 +853,24 @@ MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool ne
   return s;
 }
 
+// Rows [sum(seglen), num_rows) belong to no relation: the reference returns zeros there (its
+// output starts as th.zeros, python/dgl/backend/pytorch/sparse.py:975).  Grid-stride over the
+// tail's 4-byte words (or bytes); exits after one load in the usual case sum(seglen) == num_rows.
+__global__ __launch_bounds__(256) void segment_zero_tail_kernel(
+    const int64_t* __restrict__ plan, int64_t num_rel, const int64_t* __restrict__ row_index,
+    unsigned char* __restrict__ c, int64_t num_rows, int64_t row_bytes) {
+  const int64_t total = plan[2 * num_rel + 1];
+  if (total >= num_rows) return;
+  const int64_t n = (num_rows - total) * row_bytes;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t r = total + i / row_bytes, b = i % row_bytes;
+    c[(row_index ? row_index[r] : r) * row_bytes + b] = 0;
+  }
+}
+
 int stage_plan(int idbits, const void* seglen, int seglen_on_host, int64_t num_rel,
-               int rows_per_tile, char* ws, const MmScratch& sc, hipStream_t s) {
+               int rows_per_tile, int64_t num_rows, char* ws, const MmScratch& sc, hipStream_t s) {
   int64_t* plan = reinterpret_cast<int64_t*>(ws + sc.off_plan);
   const void* dev_seglen = seglen;
   if (seglen_on_host) {
@@ -862,25 +883,30 @@ int stage_plan(int idbits, const void* seglen, int seglen_on_host, int64_t num_r
   }
   if (idbits == 32)
     hipLaunchKernelGGL(segment_plan_kernel<int32_t>, dim3(1), dim3(64), 0, s,
-                       static_cast<const int32_t*>(dev_seglen), num_rel, rows_per_tile, plan);
+                       static_cast<const int32_t*>(dev_seglen), num_rel, rows_per_tile, num_rows, plan);
   else
     hipLaunchKernelGGL(segment_plan_kernel<int64_t>, dim3(1), dim3(64), 0, s,
-                       static_cast<const int64_t*>(dev_seglen), num_rel, rows_per_tile, plan);
+                       static_cast<const int64_t*>(dev_seglen), num_rel, rows_per_tile, num_rows, plan);
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// CU count of the CURRENT device (the entry points' DeviceGuard has made the operands' device
+// current), cached per device id.
 int mm_num_cus() {
-  static int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;  // MI355X
-    return n;
-  }();
-  return cus;
+  constexpr int kMaxDev = 64;
+  static int cus[kMaxDev] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;  // MI355X
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
 }
 
 // LDS-direct forward kernel: 16-bit storage, whole 16-byte pieces, K a multiple of the slab.
@@ -1373,6 +1399,7 @@ int dgla_segment_mm_indexed(int idtype_bits, dgla_dtype dtype, const void* a, co
   if (num_rows == 0 || n == 0 || num_rel == 0) return 0;
   if (!a || !b || !c || !seglen) return mfail("segment_mm: null operand");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, c);
   const size_t elem = dtype == DGLA_F64 ? 8 : (dtype == DGLA_F32 ? 4 : 2);
   const MmScratch sc = mm_scratch(num_rel, k, n, elem, !b_trans, false);
   void* owned = nullptr;
@@ -1381,8 +1408,11 @@ int dgla_segment_mm_indexed(int idtype_bits, dgla_dtype dtype, const void* a, co
     workspace = owned;
   }
   char* ws = static_cast<char*>(workspace);
-  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, BM, ws, sc, s);
+  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, BM, num_rows, ws, sc, s);
   if (rc == 0) {
+    hipLaunchKernelGGL(segment_zero_tail_kernel, dim3(256), dim3(256), 0, s,
+                       reinterpret_cast<const int64_t*>(ws + sc.off_plan), num_rel, row_index,
+                       static_cast<unsigned char*>(c), num_rows, n * static_cast<int64_t>(elem));
     switch (dtype) {
       case DGLA_F32: rc = run_segment_mm<float>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
       case DGLA_F64: rc = run_segment_mm<double>(a, b, c, num_rows, k, n, num_rel, b_trans != 0, row_index, ws, sc, s); break;
@@ -1411,6 +1441,7 @@ int dgla_segment_mm_backward_b_indexed(int idtype_bits, dgla_dtype dtype, const 
   if (num_rel == 0 || d1 == 0 || d2 == 0) return 0;
   if (!db || !seglen || (num_rows > 0 && (!a || !dc))) return mfail("segment_mm backward: null operand");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, db);
   const size_t elem = dtype == DGLA_F64 ? 8 : (dtype == DGLA_F32 ? 4 : 2);
   const MmScratch sc = mm_scratch(num_rel, d1, d2, elem, false, elem == 2);
   void* owned = nullptr;
@@ -1419,7 +1450,7 @@ int dgla_segment_mm_backward_b_indexed(int idtype_bits, dgla_dtype dtype, const 
     workspace = owned;
   }
   char* ws = static_cast<char*>(workspace);
-  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, static_cast<int>(bwd_slab_rows(num_rows, d1, d2)), ws, sc, s);
+  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, static_cast<int>(bwd_slab_rows(num_rows, d1, d2)), num_rows, ws, sc, s);
   if (rc == 0) {
     switch (dtype) {
       case DGLA_F32: rc = run_segment_mm_bwd_b<float>(a, dc, db, num_rows, d1, d2, num_rel, row_index, ws, sc, s); break;
@@ -1448,6 +1479,7 @@ int dgla_gather_mm(int idtype_bits, dgla_dtype dtype, const void* a, const void*
   if (num_rows == 0 || n == 0) return 0;
   if (!a || !b || !c) return mfail("gather_mm: null operand");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, c);
 #define DGLA_GMM(IDX)                                                                             \
   switch (dtype) {                                                                                \
     case DGLA_F32: return run_gather_mm<IDX, float>(a, b, c, idx_a, idx_b, idx_c, num_rows, k, n, s);   \

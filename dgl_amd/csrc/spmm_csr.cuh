@@ -49,9 +49,13 @@ struct SpmmParams {
   int mean;       // reduce == sum only: divide every row by max(its edge count, 1) before storing
   uint32_t tune;  // kTune* bits (common.h)
   // split-row layout of ufeat (kTuneSplit, see spmm_split_rows_kernel): features
-  // [0, split_main) of every row live in `ufeat` with pitch split_main, the rest in `utail`
-  // with pitch split_tail.  split_main == 0: plain layout.
+  // [0, split_main) of every row live in `umain` with pitch split_main, the rest in `utail`
+  // with pitch split_tail; `ufeat` stays the caller's tensor.  split_main == 0: plain layout.
+  // `split_meta` (device, may be NULL = always): the locality probe's counters {local, sampled}
+  // — the split copy is made and used only when fewer than half of the sampled edges are local.
+  const void* umain;
   const void* utail;
+  const unsigned* split_meta;
   int split_main, split_tail;
   // stacked multi-relation form (MULTI kernels only)
   const uint8_t* rel;
@@ -113,24 +117,94 @@ __device__ __forceinline__ void store_nt(DT* dst, const VecT<DT, VEC>& v) {
 // 128-byte L2 line straddles ceil-ish(RB / 128) + 1 lines when gathered (F = 100 fp32: 400 B
 // -> always 4 lines = 512 B of fabric traffic per edge).  Copying X once per call into a
 // line-aligned MAIN array (pitch = RB rounded down to 128 B) and a dense TAIL array (pitch =
-// the remainder, small enough to live in L2 / Infinity Cache) turns the gather into
+// the remainder, small enough to live in the Infinity Cache) turns the gather into
 // RB_main / 128 full lines plus one cached access: 2 N RB bytes of streaming traffic buy
-// 128 B x E of gather traffic.  One thread moves one 16-byte piece.
+// 128 B x E of gather traffic.  One thread moves K 16-byte pieces (K loads in flight); the row
+// of a piece comes from one block-uniform 64-bit division plus a 32-bit multiply-high by
+// ceil(2^32 / pieces) (exact for the < 2^16 block-local piece numbers that occur).
 typedef uint32_t piece16_t __attribute__((ext_vector_type(4)));
-template <int PIECE_BYTES>  // template only so that the header can live in several objects
+
+// Should this launch use the split copy?  (device side; uniform)
+__device__ __forceinline__ bool split_wanted(const unsigned* __restrict__ meta) {
+  if (meta == nullptr) return true;
+  const unsigned local = meta[0], sampled = meta[1];
+  return 2u * local < sampled;
+}
+
+template <int K>
 __global__ __launch_bounds__(256) void spmm_split_rows_kernel(
     const piece16_t* __restrict__ x, piece16_t* __restrict__ main_out,
-    piece16_t* __restrict__ tail_out, int64_t num_rows, int pieces, int main_pieces) {
+    piece16_t* __restrict__ tail_out, int64_t num_rows, int pieces, int main_pieces,
+    unsigned magic, const unsigned* __restrict__ meta, int nt_main) {
+  if (!split_wanted(meta)) return;
   const int64_t total = num_rows * pieces;
-  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const int64_t r = i / pieces;
-    const int j = static_cast<int>(i - r * pieces);
-    const piece16_t v = __builtin_nontemporal_load(x + i);
-    if (j < main_pieces)
-      main_out[r * main_pieces + j] = v;
-    else
-      tail_out[r * (pieces - main_pieces) + (j - main_pieces)] = v;
+  const int tail_pieces = pieces - main_pieces;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * (256 * K); base < total;
+       base += static_cast<int64_t>(gridDim.x) * (256 * K)) {
+    const int64_t r0 = base / pieces;
+    const unsigned j0 = static_cast<unsigned>(base - r0 * pieces);
+    piece16_t v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      int64_t i = base + k * 256 + threadIdx.x;
+      if (i >= total) i = total - 1;
+      v[k] = __builtin_nontemporal_load(x + i);  // read once
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int64_t i = base + k * 256 + threadIdx.x;
+      if (i >= total) continue;
+      const unsigned loc = j0 + static_cast<unsigned>(k * 256) + threadIdx.x;
+      const unsigned dr = __umulhi(loc, magic);
+      const unsigned j = loc - dr * static_cast<unsigned>(pieces);
+      const int64_t r = r0 + dr;
+      if (j < static_cast<unsigned>(main_pieces)) {
+        piece16_t* dst = main_out + r * main_pieces + j;
+        if (nt_main)
+          __builtin_nontemporal_store(v[k], dst);  // far larger than the caches: stream it
+        else
+          *dst = v[k];
+      } else {
+        tail_out[r * tail_pieces + (j - main_pieces)] = v[k];  // small: keep it cached
+      }
+    }
+  }
+}
+
+// Locality probe (once per graph, next to the merge plan): of the edges of every `stride`-th
+// unit, how many have their column within `window` rows of the unit's own position (its
+// middle row, rescaled to column ids when the matrix is not square)?  Graphs in a
+// locality-preserving order (METIS / community order) re-use gathered rows in L2 / Infinity
+// Cache and lose more to the re-layout copy than the split gather saves; uniformly random
+// neighbour sets gain.  meta[0] += local edges, meta[1] += sampled edges.
+template <typename Idx>
+__global__ __launch_bounds__(64) void spmm_locality_probe_kernel(
+    const Idx* __restrict__ indices, const int64_t* __restrict__ plan, int64_t num_rows,
+    int64_t num_cols, int64_t nnz, int64_t num_waves, int64_t stride, int64_t window,
+    unsigned* __restrict__ meta) {
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * stride;
+  if (w >= num_waves) return;
+  const int64_t total = num_rows + nnz;
+  const int64_t d0 = w * kWaveItems;
+  int64_t d1 = d0 + kWaveItems;
+  if (d1 > total) d1 = total;
+  const int64_t i0 = plan[w], i1 = plan[w + 1];
+  const int64_t j0 = d0 - i0;
+  const int nE = static_cast<int>((d1 - i1) - j0);
+  const int64_t mid_row = i0 + (i1 - i0) / 2;
+  const int64_t pivot = num_rows == num_cols
+                            ? mid_row
+                            : static_cast<int64_t>(static_cast<double>(mid_row) * num_cols / (num_rows > 0 ? num_rows : 1));
+  unsigned local = 0;
+  for (int e = threadIdx.x; e < nE; e += 64) {
+    const int64_t c = static_cast<int64_t>(indices[j0 + e]);
+    const int64_t d = c > pivot ? c - pivot : pivot - c;
+    local += d <= window ? 1u : 0u;
+  }
+  for (int m = 32; m >= 1; m >>= 1) local += __shfl_xor(local, m, 64);
+  if (threadIdx.x == 0 && nE > 0) {
+    atomicAdd(meta, local);
+    atomicAdd(meta + 1, static_cast<unsigned>(nE));
   }
 }
 
@@ -294,8 +368,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   const DT* __restrict__ Wt = static_cast<const DT*>(p.efeat) + ro_off;
   int64_t lhs_len = p.lhs_len;
   const int64_t rhs_len = p.rhs_len;
-  if (p.split_main > 0) {  // split-row layout: this lane's piece lives in the main or the tail array
+  if (p.split_main > 0 && split_wanted(p.split_meta)) {
+    // split-row layout: this lane's piece lives in the main or the tail array
     if (lo_off < p.split_main) {
+      X = static_cast<const DT*>(p.umain) + lo_off;
       lhs_len = p.split_main;
     } else {
       X = static_cast<const DT*>(p.utail) + (lo_off - p.split_main);
@@ -548,12 +624,16 @@ struct SpmmGeometry {
   int groups;    // lane groups per wave
   int chunks;    // grid.y: feature chunks of 64 * vec
   int64_t num_waves, num_slots;
-  size_t off_plan, off_carry_row, off_carry_val, off_tail_val, off_carry_argu,
+  size_t off_plan, off_meta, off_carry_row, off_carry_val, off_tail_val, off_carry_argu,
       off_carry_arge, off_tail_argu, off_tail_arge, total;
   // split-row layout (0 = not used): bytes of a row kept in the main / tail array
   int split_main_bytes, split_tail_bytes;
   size_t off_split_main, off_split_tail;
 };
+
+// Half-width, in rows, of the window the locality probe counts as "local": 2 x 64 Ki rows of
+// 400 bytes = 52 MB, a fifth of the 256 MiB Infinity Cache.
+constexpr int64_t kSplitProbeWindowRows = 65536;
 
 // Shape-only eligibility of the split-row layout: 16-byte lane accesses cover the row in one
 // chunk, the row is longer than one 128-byte line and not a whole number of lines.
@@ -587,6 +667,8 @@ inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len
   size_t off = 0;
   g.off_plan = off;
   off = align_up(off + sizeof(int64_t) * (g.num_waves + 1), 256);
+  g.off_meta = off;  // locality probe counters {local, sampled}; lives and dies with the plan
+  off += 256;
   g.off_carry_row = off;
   off = align_up(off + sizeof(int64_t) * g.num_slots, 256);
   g.off_carry_val = off;
@@ -627,6 +709,21 @@ inline int launch_plan(const SpmmLaunch& L, const SpmmGeometry& g) {
                      static_cast<const Idx*>(L.csr.indptr), L.csr.num_rows, L.csr.nnz,
                      g.num_waves, reinterpret_cast<int64_t*>(ws + g.off_plan));
   DGLA_CHECK_HIP(hipGetLastError());
+  {
+    // locality probe over ~4096 evenly spaced units, made with every plan (a later call on the
+    // same workspace may be the first one whose shape is eligible for the split-row layout)
+    unsigned* meta = reinterpret_cast<unsigned*>(ws + g.off_meta);
+    DGLA_CHECK_HIP(hipMemsetAsync(meta, 0, 8, L.stream));
+    const int64_t stride = std::max<int64_t>(1, g.num_waves / 4096);
+    const int64_t probes = (g.num_waves + stride - 1) / stride;
+    const int64_t window = kSplitProbeWindowRows;
+    if (L.csr.indices != nullptr && L.csr.nnz > 0)
+      hipLaunchKernelGGL(spmm_locality_probe_kernel<Idx>, dim3(static_cast<unsigned>(probes)),
+                       dim3(64), 0, L.stream, static_cast<const Idx*>(L.csr.indices),
+                       reinterpret_cast<const int64_t*>(ws + g.off_plan), L.csr.num_rows,
+                       L.csr.num_cols, L.csr.nnz, g.num_waves, stride, window, meta);
+    DGLA_CHECK_HIP(hipGetLastError());
+  }
   return 0;
 }
 
@@ -656,11 +753,14 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.arg_empty = L.arg_empty;
   p.mean = L.mean ? 1 : 0;
   p.tune = L.tune;
-  p.utail = nullptr;
+  p.umain = p.utail = nullptr;
+  p.split_meta = nullptr;
   p.split_main = p.split_tail = 0;
   if (g.split_main_bytes > 0) {
-    p.ufeat = ws + g.off_split_main;
+    p.umain = ws + g.off_split_main;
     p.utail = ws + g.off_split_tail;
+    if (!(L.tune & kTuneSplitForce) && !L.split_keep)
+      p.split_meta = reinterpret_cast<const unsigned*>(ws + g.off_meta);
     p.split_main = g.split_main_bytes / static_cast<int>(sizeof(DT));
     p.split_tail = g.split_tail_bytes / static_cast<int>(sizeof(DT));
   }
@@ -685,16 +785,20 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
   const SpmmParams<Idx> p = make_params<Idx, DT>(L, g);
   const unsigned blocks =
       static_cast<unsigned>((g.num_waves + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (g.split_main_bytes > 0) {
+  if (g.split_main_bytes > 0 && !L.split_valid) {
     char* ws = static_cast<char*>(L.workspace);
     const int pieces = (g.split_main_bytes + g.split_tail_bytes) / 16;
     const int64_t total = L.csr.num_cols * pieces;
-    const unsigned sblocks = static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 256 * 64));
-    hipLaunchKernelGGL(spmm_split_rows_kernel<16>, dim3(sblocks), dim3(256), 0, L.stream,
+    constexpr int K = 4;
+    const unsigned sblocks =
+        static_cast<unsigned>(std::min<int64_t>((total + 256 * K - 1) / (256 * K), int64_t(1) << 20));
+    const unsigned magic = 0xFFFFFFFFu / static_cast<unsigned>(pieces) + 1u;
+    hipLaunchKernelGGL(spmm_split_rows_kernel<K>, dim3(sblocks), dim3(256), 0, L.stream,
                        static_cast<const piece16_t*>(L.ufeat),
                        reinterpret_cast<piece16_t*>(ws + g.off_split_main),
                        reinterpret_cast<piece16_t*>(ws + g.off_split_tail), L.csr.num_cols, pieces,
-                       g.split_main_bytes / 16);
+                       g.split_main_bytes / 16, magic, p.split_meta,
+                       (L.tune & kTuneSplitNt) ? 1 : 0);
     DGLA_CHECK_HIP(hipGetLastError());
   }
   const ProfileEvents pe = profile_events();

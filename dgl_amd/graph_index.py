@@ -177,10 +177,14 @@ class Relation:
 
     def to(self, device):
         mv = lambda t: None if t is None else tuple(None if x is None else x.to(device) for x in t)
-        return Relation(self.num_src, self.num_dst, csr=mv(self._csr), csc=mv(self._csc),
-                        idtype=self.idtype, device=torch.device(device), formats=self.formats,
-                        **({} if self._coo is None else
-                           {"row": self._coo[0].to(device), "col": self._coo[1].to(device)}))
+        r = Relation(self.num_src, self.num_dst, csr=mv(self._csr), csc=mv(self._csc),
+                     idtype=self.idtype, device=torch.device(device), formats=self.formats,
+                     **({} if self._coo is None else
+                        {"row": self._coo[0].to(device), "col": self._coo[1].to(device)}))
+        # a COO derived from a CSR / CSC lists the edges in that format's order and carries the
+        # edge ids as its third member: keep the full triple (as astype does)
+        r._coo = mv(self._coo)
+        return r
 
     def astype(self, idtype):
         cv = lambda t: None if t is None else tuple(None if x is None else x.to(idtype) for x in t)

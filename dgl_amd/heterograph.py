@@ -550,7 +550,10 @@ def graph(data, num_nodes=None, idtype=None, device=None):
 
 def heterograph(data_dict, num_nodes_dict=None, idtype=None, device=None):
     """Graph with several node / edge types from ``{(srctype, etype, dsttype): (src, dst)}``."""
-    cets = sorted(data_dict.keys(), key=lambda c: c[1]) if len(data_dict) > 1 else list(data_dict.keys())
+    # relations are ordered by the FULL canonical tuple (create_metagraph_index,
+    # python/dgl/heterograph_index.py:1238-1240 `sorted(canonical_etypes)`): edge-type ids,
+    # g.canonical_etypes and every per-etype tuple argument follow this order
+    cets = sorted(data_dict.keys())
     ntypes = sorted({c[0] for c in cets} | {c[2] for c in cets})
     first = next(iter(data_dict.values()))[0]
     if idtype is None:

@@ -54,12 +54,12 @@ class SEGMENTMM(torch.autograd.Function):
         C = torch.empty((A.shape[0], B.shape[2]), device=A.device, dtype=A.dtype)
         A, B = A.contiguous(), B.contiguous()
         _segment_mm(A, B, C, seglen_A)
+        # rows beyond sum(seglen) belong to no relation: the library zero-fills them (the
+        # reference's output starts as th.zeros); it also clamps device-side lengths to A's rows
         if not seglen_A.is_cuda:  # host lengths: checking costs nothing (a device tensor is
-            total = int(seglen_A.sum())  # trusted, reading it back would synchronise)
+            total = int(seglen_A.sum())  # not read back, that would synchronise)
             if total > A.shape[0]:
                 raise DGLAMDError("Segment index out of bound of A->shape[0].")  # gather_mm.cu:224
-            if total < A.shape[0]:
-                C[total:] = 0  # rows beyond sum(seglen) belong to no relation
         ctx.backward_cache = A, B, seglen_A
         return C
 
@@ -69,7 +69,7 @@ class SEGMENTMM(torch.autograd.Function):
         dZ = dZ.contiguous()
         A_grad = B_grad = None
         if ctx.needs_input_grad[0]:  # A_grad = Out_grad . B^T
-            A_grad = torch.zeros(A.shape, device=A.device, dtype=A.dtype)
+            A_grad = torch.empty(A.shape, device=A.device, dtype=A.dtype)  # tail zero-filled by the library
             _segment_mm(dZ, B, A_grad, seglen_A, b_trans=True)
         if ctx.needs_input_grad[1]:  # B_grad = A^T . Out_grad
             B_grad = torch.empty(B.shape, device=B.device, dtype=B.dtype)
@@ -79,7 +79,10 @@ class SEGMENTMM(torch.autograd.Function):
 
 def _sort_by_relation(idx_b, num_rel):
     sorted_idx, perm = torch.sort(idx_b, stable=True)
-    seglen = torch.bincount(sorted_idx, minlength=num_rel)
+    # ids >= num_rel would make bincount longer than the weight stack: drop those counts, the
+    # rows sort to the end, belong to no relation and come out as zeros (the kernel never
+    # indexes B past its last matrix)
+    seglen = torch.bincount(sorted_idx, minlength=num_rel)[:num_rel].contiguous()
     return perm, seglen
 
 

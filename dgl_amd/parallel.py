@@ -53,20 +53,67 @@ class HaloExchange:
             assert int(serve.min()) >= 0 and int(serve.max()) < self.n_local
         self.serve_rows = serve          # local rows to send, grouped by destination rank
         self._send_buf = None
+        self._recv_buf = None
+
+    def _pack(self, x_local, rows, buf_name):
+        """``x_local[rows]`` into a reusable send buffer: the library's row-gather kernel on the
+        GPU (csrc/exchange.hip), torch's on CPU tensors (gloo tests; host logic, no kernels)."""
+        buf = getattr(self, buf_name)
+        shape = (rows.numel(),) + tuple(x_local.shape[1:])
+        if buf is None or buf.dtype != x_local.dtype or tuple(buf.shape) != shape or \
+                buf.device != x_local.device:
+            buf = torch.empty(shape, dtype=x_local.dtype, device=x_local.device)
+            setattr(self, buf_name, buf)
+        if x_local.is_cuda:
+            from . import _capi
+            _capi.gather_rows(x_local, rows, out=buf)
+        else:
+            torch.index_select(x_local, 0, rows, out=buf)
+        return buf
+
+    def pull_async(self, x_local, halo_out):
+        """Start filling ``halo_out`` (``n_halo`` rows, grouped by owner) with the peers' current
+        values of the requested rows of their ``x_local``; returns a work handle (or None) whose
+        ``wait()`` orders the caller's stream after the exchange.  With RCCL the collective runs
+        on the process group's own stream, so kernels queued between this call and ``wait()``
+        overlap with the transfer (exchange hidden behind the local-column part)."""
+        assert halo_out.shape[0] == self.n_halo and halo_out.is_contiguous()
+        if self.world == 1:
+            return None
+        send = self._pack(x_local[: self.n_local], self.serve_rows, "_send_buf")
+        return dist.all_to_all_single(halo_out, send, self.recv_splits, self.send_splits,
+                                      group=self.group, async_op=True)
 
     def pull(self, x):
         """Fill ``x[n_local:]`` with the peers' current values of the requested rows."""
         assert x.shape[0] == self.n_local + self.n_halo and x.is_contiguous()
         if self.world == 1:
             return x
-        if self._send_buf is None or self._send_buf.dtype != x.dtype or \
-                self._send_buf.shape[1:] != x.shape[1:]:
-            self._send_buf = torch.empty((self.serve_rows.numel(),) + tuple(x.shape[1:]),
-                                         dtype=x.dtype, device=x.device)
-        torch.index_select(x[: self.n_local], 0, self.serve_rows, out=self._send_buf)
-        _all_to_all(x[self.n_local:], self._send_buf, self.recv_splits, self.send_splits,
-                    self.group)
+        w = self.pull_async(x, x[self.n_local:])
+        if w is not None:
+            w.wait()
         return x
+
+    def push(self, halo_grad, local_grad):
+        """Reverse of :meth:`pull` — ``sparse_all_to_all_push`` (python/dgl/cuda/nccl.py:7-93)
+        with the index lists already exchanged: every halo row's value travels back to its
+        owner and is ADDED into ``local_grad`` at the row it was pulled from (the gradient of
+        the pull).  Rows requested by several peers accumulate; summation order = peer order."""
+        assert halo_grad.shape[0] == self.n_halo and local_grad.shape[0] == self.n_local
+        if self.world == 1:
+            return local_grad
+        shape = (self.serve_rows.numel(),) + tuple(halo_grad.shape[1:])
+        if self._recv_buf is None or self._recv_buf.dtype != halo_grad.dtype or \
+                tuple(self._recv_buf.shape) != shape:
+            self._recv_buf = torch.empty(shape, dtype=halo_grad.dtype, device=halo_grad.device)
+        _all_to_all(self._recv_buf, halo_grad.contiguous(), self.send_splits, self.recv_splits,
+                    self.group)
+        if local_grad.is_cuda:
+            from . import _capi
+            _capi.scatter_add(self._recv_buf, self.serve_rows, local_grad)
+        else:
+            local_grad.index_add_(0, self.serve_rows, self._recv_buf)
+        return local_grad
 
     def bytes_per_step(self, elem_size=4):
         return self.n_halo * self.feat * elem_size
@@ -214,3 +261,289 @@ def halo_fraction(indptr, indices, bounds):
     remote = row_part != col_part
     halo_rows = [int(torch.unique(indices[remote & (row_part == p)]).numel()) for p in range(k)]
     return float(remote.float().mean()) if indices.numel() else 0.0, halo_rows
+
+
+# ---------------------------------------------------------------------------------------
+# NDArrayPartition + the general sparse all-to-all (python/dgl/partition.py:474-640,
+# python/dgl/cuda/nccl.py:7-183)
+# ---------------------------------------------------------------------------------------
+class NDArrayPartition:
+    """Assignment of the rows of an array to ``num_parts`` owners: ``mode='remainder'`` (row
+    ``i`` lives on part ``i % num_parts`` as local row ``i // num_parts``) or ``mode='range'``
+    (``part_ranges`` = ``num_parts + 1`` boundaries, on the GPU like the reference requires).
+    Index tensors must live on the GPU — the maps are HIP kernels (csrc/exchange.hip), and the
+    reference has no CPU implementation either (src/partition/ndarray_partition.cc:44-50)."""
+
+    def __init__(self, array_size, num_parts, mode="remainder", part_ranges=None):
+        assert num_parts > 0, 'Invalid "num_parts", must be > 0.'
+        if mode == "remainder":
+            assert part_ranges is None, ('When using remainder-based partitioning, "part_ranges" '
+                                         "should not be specified.")
+            self._mode, self._range = 0, None
+        elif mode == "range":
+            assert part_ranges is not None, ('When using range-based partitioning, "part_ranges" '
+                                             "must not be None.")
+            pr = torch.as_tensor(part_ranges)
+            assert int(pr[0]) == 0 and int(pr[-1]) == array_size, \
+                'part_ranges[0] must be 0, and part_ranges[-1] must be "array_size".'
+            assert pr.numel() == num_parts + 1
+            self._mode, self._range = 1, pr
+            self._range_host = [int(v) for v in pr.tolist()]
+        else:
+            assert False, 'Unknown partition mode "{}"'.format(mode)
+        self._array_size, self._num_parts = int(array_size), int(num_parts)
+
+    def num_parts(self):
+        return self._num_parts
+
+    def array_size(self):
+        return self._array_size
+
+    def local_size(self, part):
+        assert 0 <= part < self._num_parts, "Invalid part ID"
+        if self._mode == 0:  # ndarray_partition.cc:96-102
+            return self._array_size // self._num_parts + (1 if part < self._array_size % self._num_parts else 0)
+        return self._range_host[part + 1] - self._range_host[part]
+
+    def _range_like(self, idx):
+        if self._range is None:
+            return None
+        if self._range.device != idx.device or self._range.dtype != idx.dtype:
+            self._range = self._range.to(device=idx.device, dtype=idx.dtype).contiguous()
+        return self._range
+
+    def map_to_local(self, idxs):
+        from . import _capi
+        return _capi.partition_map(self._mode, self._num_parts, self._range_like(idxs), idxs,
+                                   want_part=False)[1]
+
+    def map_to_global(self, idxs, part_id):
+        from . import _capi
+        return _capi.partition_to_global(self._mode, self._num_parts, self._range_like(idxs), idxs,
+                                         part_id)
+
+    def get_local_indices(self, part, ctx):
+        return self.map_to_global(torch.arange(self.local_size(part), device=ctx), part)
+
+    def generate_permutation(self, idxs):
+        """``(perm, counts)``: ``idxs[perm]`` is grouped by owner part (stable inside a part),
+        ``counts[p]`` (int64) the number of indices owned by part ``p``."""
+        from . import _capi
+        part, _ = _capi.partition_map(self._mode, self._num_parts, self._range_like(idxs), idxs,
+                                      want_local=False)
+        # stable sort by part id = the COO -> CSR compression of (part, position) pairs
+        indptr, _, perm = _capi.coo_to_csr(part, part, None, self._num_parts)
+        return perm, (indptr[1:] - indptr[:-1]).to(torch.int64)
+
+
+def _splits_to_host(*tensors):
+    out = [t.to("cpu", non_blocking=True) for t in tensors]
+    if tensors[0].is_cuda:
+        torch.cuda.current_stream(tensors[0].device).synchronize()
+    return [[int(v) for v in t.tolist()] for t in out]
+
+
+def _take_rows(value, idx):
+    if value.is_cuda:
+        from . import _capi
+        return _capi.gather_rows(value.contiguous(), idx)
+    return value[idx.long()]
+
+
+def sparse_all_to_all_push(idx, value, partition, group=None):
+    """Every rank sends ``(idx[i], value[i])`` to the owner of ``idx[i]``; returns the pairs
+    this rank received, own ones included (python/dgl/cuda/nccl.py:7-93: the gradient push of
+    node embeddings).  The permutation and the row pack are library kernels; the three
+    all-to-alls are RCCL through torch.distributed."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return idx, value
+    perm, send_splits = partition.generate_permutation(idx)
+    recv_splits = torch.empty_like(send_splits)
+    _all_to_all(recv_splits, send_splits, None, None, group)
+    send_idx = _take_rows(idx, perm)
+    send_value = _take_rows(value, perm)
+    recv_l, send_l = _splits_to_host(recv_splits, send_splits)
+    n_recv = sum(recv_l)
+    recv_idx = torch.empty((n_recv,), dtype=idx.dtype, device=idx.device)
+    _all_to_all(recv_idx, send_idx, recv_l, send_l, group)
+    recv_value = torch.empty((n_recv,) + tuple(value.shape[1:]), dtype=value.dtype, device=value.device)
+    _all_to_all(recv_value, send_value, recv_l, send_l, group)
+    return recv_idx, recv_value
+
+
+def sparse_all_to_all_pull(req_idx, value, partition, group=None):
+    """``value_global[req_idx]`` where every rank holds the rows it owns under ``partition`` in
+    its ``value`` (python/dgl/cuda/nccl.py:98-183: feature / embedding pull)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return _take_rows(value, req_idx)
+    perm, req_splits = partition.generate_permutation(req_idx)
+    resp_splits = torch.empty_like(req_splits)
+    _all_to_all(resp_splits, req_splits, None, None, group)
+    req_sorted = _take_rows(req_idx, perm)
+    resp_l, req_l = _splits_to_host(resp_splits, req_splits)
+    resp_idx = torch.empty((sum(resp_l),), dtype=req_idx.dtype, device=req_idx.device)
+    _all_to_all(resp_idx, req_sorted, resp_l, req_l, group)
+    if resp_idx.numel():
+        resp_idx = partition.map_to_local(resp_idx)
+    req_value = torch.empty((req_idx.shape[0],) + tuple(value.shape[1:]), dtype=value.dtype,
+                            device=value.device)
+    _all_to_all(req_value, _take_rows(value, resp_idx), req_l, resp_l, group)
+    out = torch.empty_like(req_value)
+    out[perm.long()] = req_value  # back into the requested order
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# Destination-row sharding straight from a node -> part assignment, and the overlapped
+# sharded g-SpMM built on it (SURVEY.md §8e; reference flow: metis_partition_assignment ->
+# partition_graph_with_halo(reshuffle=True) python/dgl/partition.py:139-186,278-397, then a
+# feature pull python/dgl/cuda/nccl.py:98-183 in front of every aggregation).
+# ---------------------------------------------------------------------------------------
+def shard_from_partition(indptr, indices, node_part, k, rank):
+    """Rank ``rank``'s shard of a square graph (CSR, rows = destination nodes) under the node
+    assignment ``node_part`` — the result of ``reshuffle`` -> ``relabel_csr`` -> ``shard_csr``
+    restricted to this rank's rows, computed with tensor primitives on the CSR's own device
+    (each rank touches E / k edges, not E).  Preprocessing, not the hot path.
+
+    Returns a dict: ``rows`` (old ids of the owned rows, in new order), ``bounds`` (k + 1 part
+    boundaries in new ids), ``local`` / ``halo`` = ``(indptr, indices)`` of the two column
+    blocks of the shard (own columns renumbered ``[0, n_local)``; remote columns renumbered
+    into the halo buffer, grouped by owner), ``requests`` ({owner: owner-local row ids} in halo
+    order), ``n_local``, ``n_halo``, ``cut_edges``."""
+    dev = indptr.device
+    n = indptr.numel() - 1
+    node_part = node_part.to(dev).long()
+    orig_id = torch.argsort(node_part, stable=True)                 # new -> old
+    new_id = torch.empty_like(orig_id)
+    new_id[orig_id] = torch.arange(n, device=dev)                   # old -> new
+    counts = torch.bincount(node_part, minlength=k)
+    bounds = torch.zeros(k + 1, dtype=torch.int64, device=dev)
+    bounds[1:] = torch.cumsum(counts, 0)
+    bounds_h = [int(v) for v in bounds.tolist()]
+    lo, hi = bounds_h[rank], bounds_h[rank + 1]
+    n_local = hi - lo
+    rows_old = orig_id[lo:hi]
+    ip = indptr.long()
+    deg = (ip[1:] - ip[:-1])[rows_old]
+    loc_ptr = torch.zeros(n_local + 1, dtype=torch.int64, device=dev)
+    loc_ptr[1:] = torch.cumsum(deg, 0)
+    nnz = int(loc_ptr[-1])
+    pos = torch.repeat_interleave(ip[:-1][rows_old] - loc_ptr[:-1], deg) + torch.arange(nnz, device=dev)
+    cols = new_id[indices[pos].long()]
+    row_of = torch.repeat_interleave(torch.arange(n_local, device=dev), deg)
+    cols = cols[torch.argsort(row_of * n + cols, stable=True)]      # columns ascending inside a row
+    is_local = (cols >= lo) & (cols < hi)
+
+    def block(mask, new_cols):
+        cnt = torch.zeros(n_local, dtype=torch.int64, device=dev)
+        cnt.index_add_(0, row_of[mask], torch.ones(int(mask.sum()), dtype=torch.int64, device=dev))
+        ptr = torch.zeros(n_local + 1, dtype=torch.int64, device=dev)
+        ptr[1:] = torch.cumsum(cnt, 0)
+        return ptr.to(indptr.dtype), new_cols.to(indices.dtype)
+
+    local = block(is_local, cols[is_local] - lo)
+    remote = ~is_local
+    uniq, inv = torch.unique(cols[remote], return_inverse=True)    # ascending new ids = grouped by owner
+    halo = block(remote, inv)
+    owner = torch.searchsorted(bounds[1:], uniq, right=True)
+    requests = {}
+    for p in range(k):
+        m = owner == p
+        if p != rank and bool(m.any()):
+            requests[p] = uniq[m] - bounds_h[p]
+    return {"rows": rows_old, "bounds": bounds.cpu(), "local": local, "halo": halo,
+            "requests": requests, "n_local": n_local, "n_halo": int(uniq.numel()),
+            "cut_edges": int(remote.sum()), "nnz": nnz, "orig_id": orig_id}
+
+
+class SimulatedExchange:
+    """In-process stand-in for :class:`HaloExchange` over a list of simulated ranks: the pull
+    copies rows between the ranks' feature tensors directly.  Lets one GPU (or the CPU) run the
+    sharded schedule of all ``k`` ranks one after the other — used by the parity tests and by
+    ``bench.py --simulate-ranks`` to time every rank's compute on the one GPU a box has."""
+
+    def __init__(self, shards):
+        self.shards = shards
+        self.x_local = [None] * len(shards)
+
+    def bind(self, rank, x_local):
+        self.x_local[rank] = x_local
+
+    def pull_into(self, rank, halo_out):
+        off = 0
+        sh = self.shards[rank]
+        for p in sorted(sh["requests"]):
+            rows = sh["requests"][p].to(halo_out.device)
+            halo_out[off: off + rows.numel()] = self.x_local[p][rows.long()]
+            off += rows.numel()
+        assert off == sh["n_halo"]
+
+
+def _gpu_spmm_factory(device):
+    """The product backend of :class:`ShardedSpMM`: dgla_spmm_csr on the shard's two column
+    blocks, each with its own cached workspace (merge plan built once)."""
+    from . import _capi
+    state = {}
+
+    def run(tag, csr_pair, n_cols, x, out, accumulate):
+        indptr, indices = csr_pair
+        if indices.numel() == 0:
+            if not accumulate:
+                out.zero_()
+            return
+        ent = state.get(tag)
+        if ent is None:
+            csr = _capi.make_csr(indptr, indices, None, n_cols)
+            ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, x.dtype, x, None, out),
+                             dtype=torch.uint8, device=x.device)
+            ent = state[tag] = [csr, ws, False]
+        csr, ws, valid = ent
+        _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, accumulate=accumulate,
+                       plan_valid=valid)
+        ent[2] = True
+
+    return run
+
+
+class ShardedSpMM:
+    """One rank's part of ``out = A @ X`` (copy_u / sum) with A split by destination rows over
+    the ranks and X by the same node ranges: ``step(x_local, out_local)`` runs
+
+        1. pack + all-to-all of the halo rows        (RCCL, on the process group's stream)
+        2. out  = A[:, own columns]  @ x_local        (concurrently, on the caller's stream)
+        3. out += A[:, halo columns] @ halo           (after the exchange has landed)
+
+    so the exchange hides behind the local-column part of the aggregation.  ``spmm`` is the
+    kernel backend ``(tag, (indptr, indices), n_cols, x, out, accumulate)``; the default is
+    the library's CSR kernel on the GPU.  Tests inject a CPU oracle; nothing here falls back."""
+
+    def __init__(self, shard, feat_shape, dtype, device, exchange=None, group=None, spmm=None,
+                 rank=None):
+        self.shard = shard
+        self.n_local, self.n_halo = shard["n_local"], shard["n_halo"]
+        self.device = torch.device(device)
+        self.halo = torch.empty((self.n_halo,) + tuple(feat_shape), dtype=dtype, device=self.device)
+        self.rank = rank
+        if exchange is None:
+            exchange = HaloExchange(self.n_local, self.n_halo, int(torch.tensor(feat_shape).prod()),
+                                    self.device, requests=shard["requests"], group=group)
+        self.exchange = exchange
+        if spmm is None:
+            if self.device.type != "cuda":
+                raise RuntimeError("ShardedSpMM: the kernel backend runs on a ROCm GPU (no CPU fallback)")
+            spmm = _gpu_spmm_factory(self.device)
+        self.spmm = spmm
+
+    def step(self, x_local, out_local):
+        assert x_local.shape[0] == self.n_local and out_local.shape[0] == self.n_local
+        work = None
+        if isinstance(self.exchange, SimulatedExchange):
+            self.exchange.pull_into(self.rank, self.halo)
+        elif self.n_halo or self.exchange.world > 1:
+            work = self.exchange.pull_async(x_local, self.halo)
+        self.spmm("local", self.shard["local"], self.n_local, x_local, out_local, False)
+        if work is not None:
+            work.wait()
+        if self.n_halo:
+            self.spmm("halo", self.shard["halo"], self.n_halo, self.halo, out_local, True)
+        return out_local

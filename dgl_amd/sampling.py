@@ -32,10 +32,16 @@ def _node_map(g, device):
     return m
 
 
-def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, seed=0):
+def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, seed=None):
     """Frontier graph on the nodes of `g` holding, for every node in `nodes`, ``fanout`` of its
     inbound edges picked uniformly (all of them when it has fewer, or ``fanout == -1``).
-    ``edata[dgl.EID]`` carries the original edge ids."""
+    ``edata[dgl.EID]`` carries the original edge ids.
+
+    ``seed=None`` (default) draws a fresh stream for every call from torch's global CPU
+    generator, like the reference's advancing global RNG (so ``torch.manual_seed`` makes a run
+    reproducible); an explicit integer pins the picks of this call."""
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     if edge_dir not in ("in", "out"):
         raise ValueError("edge_dir must be 'in' or 'out'")
     if prob is not None:

@@ -5,12 +5,43 @@ hetero variants :268-433,568-638, ``_edge_softmax_forward/backward`` :720-800): 
 argument meaning, dtype rules, 1-D feature handling, return values and error messages —
 the arithmetic happens in libdgl_amd.so behind ``sparse._CAPI_DGLKernel*``.
 """
+import itertools
+import weakref
+
 import torch
 
 from . import _ffi
 from ._lib import DGLAMDError
 
 _TARGET = {"u": 0, "e": 1, "v": 2, 0: 0, 1: 1, 2: 2}
+
+# ---- static source features --------------------------------------------------------------
+# When a feature row is not a whole number of 128-byte cache lines (F = 100 fp32) the CSR SpMM
+# gathers faster from a line-aligned "split-row" copy of the features (csrc/spmm_csr.cuh); by
+# default that copy is re-made on every call, because the library cannot know whether a tensor
+# changed between two calls.  A caller that KNOWS its features are static (input features of
+# full-graph training / inference) says so once, and the copy is made once per graph.
+_static = {}             # id(tensor) -> (weakref to the tensor, token)
+_tokens = itertools.count(1)
+
+
+def static_features(t):
+    """Declare ``t`` (a source-node feature tensor) unchanging for as long as it lives: g-SpMM
+    calls that read it keep its split-row copy between calls instead of re-making it.  Writing
+    into ``t`` afterwards is the caller's bug; ``release_static(t)`` takes the promise back.
+    Returns ``t``."""
+    key = id(t)
+    _static[key] = (weakref.ref(t, lambda _r, k=key: _static.pop(k, None)), next(_tokens))
+    return t
+
+
+def release_static(t):
+    _static.pop(id(t), None)
+
+
+def _static_token(t):
+    ent = _static.get(id(t))
+    return ent[1] if ent is not None and ent[0]() is t else 0
 
 
 def infer_broadcast_shape(op, shp1, shp2):
@@ -118,6 +149,9 @@ def _gspmm(gidx, op, reduce_op, u, e, accumulate_into=None, mean=False):
         if fmt == "csc":
             nbytes = _call("sparse._CAPI_DGLKernelSpMMWorkspaceBytes", rel, fmt, *args)
             rel.ensure_workspace(nbytes)
+            tok = _static_token(uu) if (use_u and _static) else 0
+            if tok:  # one-shot announcement consumed by the SpMM call below
+                _call("dgl_amd._CAPI_UnitGraphStaticOperand", rel, fmt, tok)
         name = "sparse._CAPI_DGLKernelSpMM" if accumulate_into is None else \
             "sparse._CAPI_DGLKernelSpMMAccumulate"
         if mean:

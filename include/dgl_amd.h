@@ -49,6 +49,15 @@ typedef enum { DGLA_F32 = 0, DGLA_F64 = 1, DGLA_F16 = 2, DGLA_BF16 = 3 } dgla_dt
                               dgl.ops.gspmm (python/dgl/ops/spmm.py:109-114: sum, then
                               / clamp(in_degrees, 1)) without the second pass over `out`;
                               same two roundings as the reference's sum-then-divide. */
+#define DGLA_SPLIT_KEEP 16u /* the caller promises to hand the SAME, unchanged ufeat to later calls
+                              on this csr + workspace (static input features, e.g. layer 0 of
+                              full-graph training or inference): the split-row copy
+                              (DGLA_TUNE_SPLIT) is made whatever the locality probe says — its
+                              cost is paid once — and later calls pass DGLA_SPLIT_VALID. */
+#define DGLA_SPLIT_VALID 8u /* `workspace` still holds the split-row copy an earlier call (with
+                              DGLA_SPLIT_KEEP) made of THIS ufeat, whose contents have not
+                              changed since: the re-layout copy is skipped.  Needs
+                              DGLA_PLAN_VALID.  Never set it for a tensor you do not own. */
 
 /* CSRMatrix (include/dgl/aten/csr.h:40-49).  For SpMM the rows are DESTINATION nodes
  * (the in-edge CSR / "CSC", src/array/kernel.cc:20-44); for SDDMM rows are SOURCE nodes. */
@@ -292,6 +301,31 @@ int dgla_partition_kway(int idtype_bits, int64_t num_nodes, const void* indptr,
                         const void* indices, int num_parts, double imbalance, int balance_edges,
                         uint64_t seed, int64_t* out_part, int64_t* stats);
 
+/* ---- multi-GPU exchange step -----------------------------------------
+ * Device side of the halo all-to-all: the collective itself is RCCL (torch.distributed), these
+ * are the pack / unpack kernels around it and the NDArrayPartition index maps.
+ *
+ * dgla_gather_rows: dst[i, :] = src[idx[i], :], rows of `row_bytes` bytes — `value[perm]`,
+ *   `value[resp_idx]` in python/dgl/cuda/nccl.py:69-70,176 (torch index kernels there); the
+ *   scatter-add direction of the gradient push is dgla_scatter_add above.
+ * dgla_partition_map / dgla_partition_to_global: MapToLocalFromRemainder / ...FromRange and
+ *   MapToGlobal... of src/partition/cuda/partition_op.cu (declared src/partition/partition_op.h:
+ *   36-130; objects src/partition/ndarray_partition.cc:30-230).
+ *   mode 0 = remainder: part = id % num_parts, local = id / num_parts
+ *   mode 1 = range:     part = the p with range[p] <= id < range[p + 1], local = id - range[p];
+ *                       `range` = DEVICE array of num_parts + 1 ids (idtype_bits), as the
+ *                       reference requires (ndarray_partition.cc:104-112)
+ *   part_out / local_out may be NULL.  GeneratePermutation = dgla_partition_map (parts) +
+ *   dgla_coo_to_csr over the part ids (a stable sort: eids_out is the permutation, indptr the
+ *   prefix of the per-part counts). */
+int dgla_gather_rows(int idtype_bits, const void* src, const void* idx, int64_t n,
+                     int64_t row_bytes, void* dst, void* hip_stream);
+int dgla_partition_map(int idtype_bits, int mode, int num_parts, const void* range, const void* idx,
+                       int64_t n, void* part_out, void* local_out, void* hip_stream);
+int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const void* range,
+                             const void* local_idx, int64_t n, int part_id, void* out,
+                             void* hip_stream);
+
 /* Process-wide tuning bits of the CSR SpMM.  None of them changes a result bit; they select
  * memory-system behaviour and exist so that a benchmark can A/B them on the GPU:
  *   DGLA_TUNE_XCD     units visit the merge path in XCD-contiguous order (block b runs on XCD
@@ -301,7 +335,12 @@ int dgla_partition_kway(int idtype_bits, int64_t num_nodes, const void* indptr,
  *   DGLA_TUNE_SPLIT   when a ufeat row is not a whole number of 128-byte lines (F = 100 fp32:
  *                     400 B = 4 lines touched per gather) the call first copies ufeat into a
  *                     line-aligned main array + a dense tail array inside the workspace and
- *                     gathers from those (3 lines + one cached access per edge)
+ *                     gathers from those (3 lines + one cached access per edge) — unless the
+ *                     locality probe made with the merge plan found that at least half of the
+ *                     sampled edges point within 64 Ki rows of their own row (ordered graphs
+ *                     re-use gathered rows in the caches and lose more to the copy than they gain)
+ *   DGLA_TUNE_SPLIT_NT     the copy stores the main array non-temporally
+ *   DGLA_TUNE_SPLIT_FORCE  ignore the locality probe
  *   DGLA_TUNE_GLDS    dgla_segment_mm / dgla_gather_mm, 16-bit and fp32 storage, operands in
  *                     whole aligned 16-byte pieces: operands go global -> LDS directly (global_load_lds,
  *                     slab rings) instead of through registers; 16-bit results bit-identical,
@@ -313,6 +352,8 @@ int dgla_partition_kway(int idtype_bits, int64_t num_nodes, const void* indptr,
 #define DGLA_TUNE_NT_IDX 4u
 #define DGLA_TUNE_SPLIT 8u
 #define DGLA_TUNE_GLDS 16u
+#define DGLA_TUNE_SPLIT_NT 32u
+#define DGLA_TUNE_SPLIT_FORCE 64u
 int dgla_set_tuning(uint32_t flags);
 uint32_t dgla_get_tuning(void);
 

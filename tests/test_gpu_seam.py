@@ -99,7 +99,8 @@ def check_spmm(res, reduce, dtype):
     if reduce == "sum":
         if exact is not None:
             np.testing.assert_allclose(out, exact, rtol=1e-5, atol=1e-6)
-            np.testing.assert_allclose(out, ref, rtol=1e-5 + 2 * maxdeg * 2.0 ** -24, atol=1e-6)
+            # north_star: within 1e-5 relative of the reference's own fp32 result, flat
+            np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-6)
         else:
             np.testing.assert_allclose(out, ref, **_tol(dtype))
     else:

@@ -1,0 +1,176 @@
+"""GPU tests of the multi-GPU side on ONE device: the exchange kernels (row pack, NDArrayPartition
+maps), the sharded g-SpMM schedule with simulated ranks (every rank's two launches on this GPU,
+halo rows copied in-process) against the unpartitioned kernel and the CPU oracle, and the
+static-feature / locality-probe behaviour of the split-row layout."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests.graphgen import synth_csr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
+@pytest.mark.parametrize("shape,dtype", [((100,), torch.float32), ((8, 4), torch.bfloat16),
+                                         ((3,), torch.float16), ((7,), torch.uint8),
+                                         ((256,), torch.float64), ((), torch.int64)])
+def test_gather_rows_matches_index_select(dev, idt, shape, dtype):
+    from dgl_amd import _capi
+
+    n_src, n = 5000, 12345
+    if dtype in (torch.uint8, torch.int64):
+        src = torch.randint(0, 200, (n_src,) + shape, device=dev).to(dtype)
+    else:
+        src = torch.rand((n_src,) + shape, device=dev).to(dtype)
+    idx = torch.randint(0, n_src, (n,), device=dev).to(idt)
+    got = _capi.gather_rows(src, idx)
+    assert torch.equal(got, src[idx.long()])
+    assert _capi.gather_rows(src, idx[:0]).shape[0] == 0
+
+
+@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
+def test_ndarray_partition_maps(dev, idt):
+    from dgl_amd.parallel import NDArrayPartition
+
+    # python/dgl/partition.py:614-626 docstring example
+    part = NDArrayPartition(10, 2, mode="remainder")
+    idx = torch.tensor([0, 2, 4, 5, 8, 8, 9], device=dev, dtype=idt)
+    perm, counts = part.generate_permutation(idx)
+    assert perm.tolist() == [0, 1, 2, 4, 5, 3, 6] and counts.tolist() == [5, 2]
+    assert counts.dtype == torch.int64 and perm.dtype == idt
+    assert [part.local_size(p) for p in range(2)] == [5, 5]
+
+    n, k = 100_003, 7
+    g = torch.Generator(device=dev).manual_seed(1)
+    idx = torch.randint(0, n, (250_000,), device=dev, generator=g).to(idt)
+    host = idx.cpu().numpy().astype(np.int64)
+    rem = NDArrayPartition(n, k, mode="remainder")
+    assert np.array_equal(rem.map_to_local(idx).cpu().numpy(), host // k)
+    perm, counts = rem.generate_permutation(idx)
+    assert np.array_equal(perm.cpu().numpy(), np.argsort(host % k, kind="stable"))
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(host % k, minlength=k))
+    assert sum(rem.local_size(p) for p in range(k)) == n
+    for p in (0, 3, k - 1):
+        loc = torch.arange(rem.local_size(p), device=dev, dtype=idt)
+        glob = rem.map_to_global(loc, p)
+        assert np.array_equal(glob.cpu().numpy(), np.arange(rem.local_size(p)) * k + p)
+        assert torch.equal(rem.get_local_indices(p, dev).to(idt), glob)
+
+    bounds = np.array([0, 10, 10, 5000, 61234, 90000, 99999, n])  # an empty part included
+    rng = NDArrayPartition(n, k, mode="range", part_ranges=torch.tensor(bounds, device=dev, dtype=idt))
+    owner = np.searchsorted(bounds[1:], host, side="right")
+    assert np.array_equal(rng.map_to_local(idx).cpu().numpy(), host - bounds[owner])
+    perm, counts = rng.generate_permutation(idx)
+    assert np.array_equal(perm.cpu().numpy(), np.argsort(owner, kind="stable"))
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(owner, minlength=k))
+    assert [rng.local_size(p) for p in range(k)] == list(np.diff(bounds))
+    loc = torch.arange(rng.local_size(3), device=dev, dtype=idt)
+    assert np.array_equal(rng.map_to_global(loc, 3).cpu().numpy(), np.arange(rng.local_size(3)) + bounds[3])
+
+
+@pytest.mark.parametrize("variant,k", [("L", 2), ("L", 4), ("U", 4), ("U", 8)])
+def test_sharded_schedule_with_simulated_ranks(dev, variant, k):
+    """partition -> per-rank shards -> (local | halo) launches of every rank == the one-launch
+    result on the whole graph (different summation order: 1e-5) == the CPU oracle."""
+    from dgl_amd import _capi
+    from dgl_amd.parallel import (ShardedSpMM, SimulatedExchange, partition_assignment,
+                                  shard_from_partition)
+
+    n, e, f = 40_000, 900_000, 100
+    g = synth_csr(n, n, e, variant, seed=5, device=dev)
+    torch.manual_seed(8)
+    x = torch.rand(n, f, device=dev) + 1
+    out_full = torch.empty(n, f, device=dev)
+    csr = _capi.make_csr(g["indptr"], g["indices"], None, n)
+    ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, x.dtype, x, None, out_full),
+                     dtype=torch.uint8, device=dev)
+    _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out_full, None, None, ws)
+
+    part, stats = partition_assignment(g["indptr"], g["indices"], k, seed=3)
+    shards = [shard_from_partition(g["indptr"], g["indices"], part, k, r) for r in range(k)]
+    assert sum(s["nnz"] for s in shards) == e
+    assert sum(s["cut_edges"] for s in shards) == stats["cut_edges"]
+    ex = SimulatedExchange(shards)
+    xs = [x[s["rows"]].contiguous() for s in shards]
+    for r in range(k):
+        ex.bind(r, xs[r])
+    got = torch.empty_like(out_full)
+    for r, s in enumerate(shards):
+        op = ShardedSpMM(s, (f,), x.dtype, dev, exchange=ex, rank=r)
+        o = torch.full((s["n_local"], f), float("nan"), device=dev)
+        op.step(xs[r], o)
+        op.step(xs[r], o)  # cached plans, accumulate path again from a fresh local part
+        got[s["rows"]] = o
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.cpu().numpy(), out_full.cpu().numpy(), rtol=1e-5)
+    ref, _, _ = oracle.spmm_csr("copy_lhs", "sum", g["indptr"].cpu().numpy(), g["indices"].cpu().numpy(),
+                                None, x.cpu().numpy(), None)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5)
+
+
+def _probe(ws, n_rows, nnz):
+    waves = (n_rows + nnz + 511) // 512
+    off = (8 * (waves + 1) + 255) // 256 * 256
+    return [int(v) for v in ws[off:off + 8].view(torch.int32).tolist()]
+
+
+def test_locality_probe_and_static_features(dev):
+    """Variant U -> the probe lets the split-row copy run; variant L -> it declines; a static
+    tensor keeps the copy between calls (and forces it on L); all results bit-identical."""
+    from dgl_amd import _capi, _lib
+
+    n, e, f = 306_000, 7_700_000, 100        # X = 122 MB: split-eligible (>= 64 MiB, E >= 4 N)
+    torch.manual_seed(2)
+    x = torch.rand(n, f, device=dev) + 1
+    default = _capi.get_tuning()
+    assert default & _lib.DGLA_TUNE_SPLIT
+    for variant, lo, hi in (("U", 0.0, 0.5), ("L", 0.5, 1.01)):
+        g = synth_csr(n, n, e, variant, seed=6, device=dev)
+        csr = _capi.make_csr(g["indptr"], g["indices"], None, n)
+        outs = []
+        try:
+            for flags, keep in ((default & ~_lib.DGLA_TUNE_SPLIT, False), (default, False),
+                                (default, True), (default | _lib.DGLA_TUNE_SPLIT_FORCE, False)):
+                _capi.set_tuning(flags)
+                out = torch.empty(n, f, device=dev)
+                ws = torch.zeros(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, x.dtype, x, None, out),
+                                 dtype=torch.uint8, device=dev)
+                _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, split_keep=keep)
+                first = out.clone()
+                _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, plan_valid=True,
+                               split_keep=keep, split_valid=keep)
+                assert torch.equal(out, first)
+                local, sampled = _probe(ws, n, e)
+                assert sampled > 0 and lo <= local / sampled < hi, (variant, local, sampled)
+                outs.append(out)
+        finally:
+            _capi.set_tuning(default)
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+
+
+def test_static_features_through_the_operator_api(dev):
+    import dgl_amd as dgl
+    from dgl_amd import ops
+
+    n, e, f = 200_000, 1_600_000, 100      # 80 MB of features: split-eligible
+    gg = synth_csr(n, n, e, "U", seed=9, device=dev, idtype=torch.int64)
+    dst = torch.repeat_interleave(torch.arange(n, device=dev), (gg["indptr"][1:] - gg["indptr"][:-1]))
+    g = dgl.graph((gg["indices"], dst), num_nodes=n)
+    torch.manual_seed(4)
+    x = torch.rand(n, f, device=dev) + 1
+    base = ops.copy_u_sum(g, x)
+    dgl.static_features(x)
+    a = ops.copy_u_sum(g, x)
+    b = ops.copy_u_sum(g, x)          # second call: copy kept
+    assert torch.equal(a, base) and torch.equal(b, base)
+    y = torch.rand(n, f, device=dev) + 1   # another tensor in between invalidates the kept copy
+    c = ops.copy_u_sum(g, y)
+    d = ops.copy_u_sum(g, x)
+    assert torch.equal(d, base) and not torch.equal(c, base)
+    dgl.release_static(x)
+    x.mul_(2)                               # no longer static: the change must be seen
+    e2 = ops.copy_u_sum(g, x)
+    torch.testing.assert_close(e2, 2 * base, rtol=1e-6, atol=0)
