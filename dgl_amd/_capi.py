@@ -393,3 +393,17 @@ def partition_to_global(mode, num_parts, part_range, local_idx, part_id):
                                             local_idx.shape[0], int(part_id), out.data_ptr(),
                                             _stream(out)))
     return out
+
+
+def scatter_rows(src, idx, out):
+    """out[idx[i]] = src[i] along dim 0 (dgla_scatter_rows)."""
+    _require_gpu(src)
+    _require_gpu(idx)
+    if not (src.is_contiguous() and out.is_contiguous() and idx.is_contiguous()):
+        raise _lib.DGLAMDError("scatter_rows: tensors must be contiguous")
+    row_bytes = src.element_size()
+    for d in src.shape[1:]:
+        row_bytes *= int(d)
+    check_call(LIB.dgla_scatter_rows(_idbits(idx), src.data_ptr(), idx.data_ptr(), idx.shape[0],
+                                     row_bytes, out.data_ptr(), _stream(out)))
+    return out

@@ -94,6 +94,8 @@ LIB.dgla_segment_reduce.argtypes = [c_char_p, c_int, c_int, P(Tensor), c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_uint32, c_void_p]
 LIB.dgla_scatter_add.restype = c_int
 LIB.dgla_scatter_add.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
+LIB.dgla_update_grad_minmax.restype = c_int
+LIB.dgla_update_grad_minmax.argtypes = [c_int, c_int, P(Tensor), c_void_p, c_void_p, c_int64, P(Tensor), c_void_p]
 LIB.dgla_backward_segment_cmp.restype = c_int
 LIB.dgla_backward_segment_cmp.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
 LIB.dgla_segment_mm_workspace_bytes.restype = c_size_t
@@ -135,6 +137,8 @@ LIB.dgla_partition_kway.argtypes = [c_int, c_int64, c_void_p, c_void_p, c_int, c
                                     ctypes.c_uint64, c_void_p, c_void_p]
 LIB.dgla_gather_rows.restype = c_int
 LIB.dgla_gather_rows.argtypes = [c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]
+LIB.dgla_scatter_rows.restype = c_int
+LIB.dgla_scatter_rows.argtypes = [c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]
 LIB.dgla_partition_map.restype = c_int
 LIB.dgla_partition_map.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                    c_void_p]

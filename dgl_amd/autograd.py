@@ -9,8 +9,9 @@ runs max-SpMM, sub-SDDMM, exp, sum-SpMM, div-SDDMM there, sparse.py:709-713).
 """
 import torch
 
+from ._lib import DGLAMDError
 from .sparse_kernels import (_edge_softmax_backward, _edge_softmax_forward, _gsddmm,
-                             _gsddmm_hetero, _gspmm, _gspmm_hetero)
+                             _gsddmm_hetero, _gspmm, _gspmm_hetero, _update_grad_minmax_hetero)
 
 
 def _reduce_grad(grad, shape):
@@ -239,46 +240,246 @@ def edge_softmax(gidx, logits, eids=None, norm_by="dst"):
         return EdgeSoftmax.apply(gidx, logits, eids, norm_by)
 
 
-# ---- heterogeneous wrappers (forward only for max/min; sum is differentiable through the
-# per-relation Functions above) --------------------------------------------------------
+# ---- heterogeneous graphs (python/dgl/backend/pytorch/sparse.py:251-440,506-600,750-850) ------
+def _zeros_like_out(gidx, nt, ref):
+    return torch.zeros((gidx.num_nodes(nt),) + tuple(ref.shape[1:]), dtype=ref.dtype, device=ref.device)
+
+
+class GSpMM_hetero(torch.autograd.Function):
+    """g-SpMM over every relation of a heterograph, differentiable (sparse.py:251-440).  The
+    forward is ``_gspmm_hetero`` — ONE stacked launch per destination type for sum reductions —
+    whether or not gradients are needed; the backward runs the same machinery on the reversed
+    graph (sum) or scatters through the recorded winners (max / min)."""
+
+    @staticmethod
+    def forward(ctx, gidx, op, reduce_op, X_len, *feats):
+        out, (argX, argY, argX_nt, argY_et) = _gspmm_hetero(gidx, op, reduce_op, X_len, feats)
+        X, Y = feats[:X_len], feats[X_len:]
+        need = lambda ts: any(t is not None and t.requires_grad for t in ts)
+        ctx.meta = (gidx, op, reduce_op, X_len, len(Y),
+                    tuple(None if t is None else t.shape for t in X),
+                    tuple(None if t is None else t.shape for t in Y))
+        # first relation that has both operands decides whether the last axis is contracted
+        reduce_last = False
+        for et in range(gidx.number_of_etypes()):
+            s, _ = gidx.metagraph.find_edge(et)
+            if X_len and len(Y) and X[s] is not None and Y[et] is not None:
+                reduce_last = _last_dim_is_reduced(X[s], Y[et])
+                break
+        ctx.reduce_last = reduce_last
+        kx, ky, ka = _keep_for_spmm_backward(op, reduce_op, need(X), need(Y))
+        n_nt = gidx.number_of_ntypes()
+        pad = lambda ts: tuple(ts) if ts is not None else (None,) * n_nt
+        ctx.n_saved = (len(X), len(Y), n_nt)
+        ctx.save_for_backward(*(X if kx else (None,) * len(X)), *(Y if ky else (None,) * len(Y)),
+                              *(pad(argX) if ka else (None,) * n_nt), *(pad(argX_nt) if ka else (None,) * n_nt),
+                              *(pad(argY) if ka else (None,) * n_nt), *(pad(argY_et) if ka else (None,) * n_nt))
+        ctx.mark_non_differentiable(*[o for o in out if o is not None and not o.is_floating_point()])
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *dZ):
+        gidx, op, reduce_op, X_len, Y_len, X_shape, Y_shape = ctx.meta
+        nx, ny, n_nt = ctx.n_saved
+        sv = ctx.saved_tensors
+        X, Y = sv[:nx], sv[nx:nx + ny]
+        argX, argX_nt, argY, argY_et = (sv[nx + ny + k * n_nt: nx + ny + (k + 1) * n_nt] for k in range(4))
+        dZ = tuple(None if z is None else z.contiguous() for z in dZ)
+        need_x = any(ctx.needs_input_grad[4:4 + X_len])
+        need_y = any(ctx.needs_input_grad[4 + X_len:])
+        dX, dY = (None,) * X_len, (None,) * Y_len
+        if op != "copy_rhs" and need_x:
+            g_rev = gidx.reverse()
+            if reduce_op == "sum":
+                # on the reversed graph the "source" features are the incoming gradients, indexed
+                # by (forward) destination type
+                if op == "mul":
+                    dX = gspmm_hetero(g_rev, "mul", "sum", len(dZ), *(dZ + tuple(Y)))
+                else:  # add, copy_lhs: coefficient 1
+                    dX = gspmm_hetero(g_rev, "copy_lhs", "sum", len(dZ), *dZ)
+            elif op in ("add", "copy_lhs"):
+                shapes = [None if shp is None else torch.empty(shp[0], 0) for shp in X_shape]
+                dX = _update_grad_minmax_hetero(g_rev, "copy_lhs", dZ, argX, argX_nt, shapes)
+            else:
+                raise NotImplementedError("gradient of u_mul_e with a max / min reducer on a graph with "
+                                          "several relations (the reference has none either)")
+            dX = tuple(None if (d is None or X_shape[i] is None) else _reduce_grad(d, X_shape[i])
+                       for i, d in enumerate(dX))
+        if op != "copy_lhs" and need_y:
+            if reduce_op == "sum":
+                if op == "mul":
+                    dY = gsddmm_hetero(gidx, "dot" if ctx.reduce_last else "mul", X_len, "u", "v",
+                                       *(tuple(X) + dZ))
+                else:  # add, copy_rhs
+                    dY = gsddmm_hetero(gidx, "copy_rhs", gidx.number_of_ntypes(), "u", "v",
+                                       *((None,) * gidx.number_of_ntypes() + dZ))
+            elif op in ("add", "copy_rhs"):
+                shapes = [None if shp is None else torch.empty(shp[0], 0) for shp in Y_shape]
+                dY = _update_grad_minmax_hetero(gidx.reverse(), "copy_rhs", dZ, argY, argY_et, shapes)
+            else:
+                raise NotImplementedError("gradient of u_mul_e with a max / min reducer on a graph with "
+                                          "several relations (the reference has none either)")
+            dY = tuple(None if (d is None or Y_shape[i] is None) else _reduce_grad(d, Y_shape[i])
+                       for i, d in enumerate(dY))
+        fix = lambda gs, n: tuple(gs[i] if i < len(gs) else None for i in range(n))
+        return (None, None, None, None) + fix(dX, X_len) + fix(dY, Y_len)
+
+
+class GSDDMM_hetero(torch.autograd.Function):
+    """g-SDDMM over every relation, differentiable (sparse.py:506-600): one FFI call forward,
+    per-target g-SpMM / g-SDDMM calls over all relations backward."""
+
+    @staticmethod
+    def forward(ctx, gidx, op, X_len, lhs_target, rhs_target, *feats):
+        out = _gsddmm_hetero(gidx, op, X_len, lhs_target, rhs_target, feats)
+        X, Y = feats[:X_len], feats[X_len:]
+        ctx.meta = (gidx, op, X_len, len(Y), lhs_target, rhs_target,
+                    tuple(None if t is None else t.shape for t in X),
+                    tuple(None if t is None else t.shape for t in Y))
+        need = lambda ts: any(t is not None and t.requires_grad for t in ts)
+        prod = op in ("mul", "dot")
+        ctx.save_for_backward(*(X if prod and need(Y) else (None,) * len(X)),
+                              *(Y if prod and need(X) else (None,) * len(Y)))
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *dZ):
+        gidx, op, X_len, Y_len, lt, rt, X_shape, Y_shape = ctx.meta
+        sv = ctx.saved_tensors
+        X, Y = sv[:X_len], sv[X_len:]
+        dZ = tuple(None if z is None else z.contiguous() for z in dZ)
+        n_nt = gidx.number_of_ntypes()
+        none_nt = (None,) * n_nt
+
+        def operand_grad(own_tgt, other_tgt, other, copy_op):
+            # d out / d own, summed over the edges (sparse.py:545-600 in hetero form)
+            if own_tgt in ("u", "v"):
+                g = gidx if own_tgt == "v" else gidx.reverse()
+                if op in ("add", copy_op):
+                    return gspmm_hetero(g, "copy_rhs", "sum", n_nt, *(none_nt + dZ))
+                if other_tgt == "e":
+                    prod = tuple(None if (z is None or o is None) else z * o for z, o in zip(dZ, other))
+                    return gspmm_hetero(g, "copy_rhs", "sum", n_nt, *(none_nt + prod))
+                if other_tgt == own_tgt:
+                    summed = gspmm_hetero(g, "copy_rhs", "sum", n_nt, *(none_nt + dZ))
+                    return tuple(None if (s_ is None or o is None) else s_ * o for s_, o in zip(summed, other))
+                # the other operand sits on the opposite end of the edge: u_mul_e on `g`
+                return gspmm_hetero(g, "mul", "sum", len(other), *(tuple(other) + dZ))
+            if op in ("add", copy_op):
+                return dZ
+            return gsddmm_hetero(gidx, "mul", len(dZ), "e", other_tgt, *(dZ + tuple(other)))
+
+        dX, dY = (None,) * X_len, (None,) * Y_len
+        if op != "copy_rhs" and any(ctx.needs_input_grad[5:5 + X_len]):
+            dX = operand_grad(lt, rt, Y, "copy_lhs")
+            dX = tuple(None if (d is None or X_shape[i] is None) else _reduce_grad(d, X_shape[i])
+                       for i, d in enumerate(dX[:X_len]))
+        if op != "copy_lhs" and any(ctx.needs_input_grad[5 + X_len:]):
+            dY = operand_grad(rt, lt, X, "copy_rhs")
+            dY = tuple(None if (d is None or Y_shape[i] is None) else _reduce_grad(d, Y_shape[i])
+                       for i, d in enumerate(dY[:Y_len]))
+        fix = lambda gs, n: tuple(gs[i] if i < len(gs) else None for i in range(n))
+        return (None, None, None, None, None) + fix(dX, X_len) + fix(dY, Y_len)
+
+
+def _merged_softmax_graph(gidx, ets, norm_by):
+    """One bipartite relation holding the edges of relations `ets` (which share the node type the
+    softmax normalises over) one after the other, cached on the graph index: the fused
+    single-relation softmax kernels then normalise over ALL of a node's edges whatever their
+    type, which is what EdgeSoftmax_hetero computes with five hetero launches (sparse.py:750-800)."""
+    from .graph_index import GraphIndex, Relation
+
+    cache = gidx.__dict__.setdefault("_softmax_merged", {})
+    key = (tuple(ets), norm_by)
+    if key not in cache:
+        rows, cols, offs = [], [], [0]
+        for et in ets:
+            r, c, old = gidx.relations[et].coo()
+            if old is not None:
+                raise DGLAMDError("edge_softmax needs COO in edge-id order")
+            rows.append(r if norm_by == "dst" else c)
+            cols.append(c if norm_by == "dst" else r)
+            offs.append(offs[-1] + r.shape[0])
+        s, d = gidx.metagraph.find_edge(ets[0])
+        nt = d if norm_by == "dst" else s
+        # source ids of different relations may collide; they are irrelevant for the softmax
+        rel = Relation(int(max(int(x.max()) + 1 if x.numel() else 1 for x in rows)), gidx.num_nodes(nt),
+                       torch.cat(rows), torch.cat(cols), idtype=gidx.dtype, device=gidx.ctx)
+        cache[key] = (GraphIndex([rel.num_src, rel.num_dst], [(0, 1)], [rel]), offs)
+    return cache[key]
+
+
+class EdgeSoftmax_hetero(torch.autograd.Function):
+    """Edge softmax over all relations (sparse.py:750-850): the normaliser of a node runs over
+    its incoming (``norm_by='dst'``) or outgoing edges of EVERY type.  Forward and backward are
+    the fused kernels on the merged relation of each node type."""
+
+    @staticmethod
+    def forward(ctx, gidx, eids, norm_by, *score):
+        if eids is not None:
+            raise DGLAMDError("eids is not supported on graphs with several relations")
+        groups = {}
+        for et in range(gidx.number_of_etypes()):
+            s, d = gidx.metagraph.find_edge(et)
+            if et < len(score) and score[et] is not None:
+                groups.setdefault(d if norm_by == "dst" else s, []).append(et)
+        outs = [None] * len(score)
+        ctx.parts = []
+        keep = []
+        for nt, ets in groups.items():
+            sub, offs = _merged_softmax_graph(gidx, ets, norm_by)
+            res = _edge_softmax_forward(sub, torch.cat([score[et] for et in ets]), "copy_rhs")
+            ctx.parts.append((sub, ets, offs))
+            keep.append(res)
+            for i, et in enumerate(ets):
+                outs[et] = res[offs[i]:offs[i + 1]]
+        ctx.save_for_backward(*keep)
+        ctx.n_score = len(score)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grad_out):
+        grads = [None] * ctx.n_score
+        for (sub, ets, offs), out in zip(ctx.parts, ctx.saved_tensors):
+            g = torch.cat([grad_out[et] if grad_out[et] is not None else
+                           torch.zeros_like(out[offs[i]:offs[i + 1]]) for i, et in enumerate(ets)])
+            back = _edge_softmax_backward(sub, out, out * g)
+            for i, et in enumerate(ets):
+                grads[et] = back[offs[i]:offs[i + 1]]
+        return (None, None, None) + tuple(grads)
+
+
+def _neg(ts):
+    return [None if t is None else -t for t in ts]
+
+
+def _inv(ts):
+    return [None if t is None else 1.0 / t for t in ts]
+
+
 def gspmm_hetero(gidx, op, reduce_op, lhs_len, *lhs_and_rhs):
     lhs, rhs = list(lhs_and_rhs[:lhs_len]), list(lhs_and_rhs[lhs_len:])
     if op == "sub":
-        op, rhs = "add", [None if t is None else -t for t in rhs]
+        op, rhs = "add", _neg(rhs)
     elif op == "div":
-        op, rhs = "mul", [None if t is None else 1.0 / t for t in rhs]
-    if reduce_op == "sum" and any(t is not None and t.requires_grad for t in lhs + rhs):
-        # differentiable path: per-relation autograd Functions, summed per destination type
-        outs = [None] * gidx.number_of_ntypes()
-        for et in range(gidx.number_of_etypes()):
-            s, d = gidx.metagraph.find_edge(et)
-            u = lhs[s] if op != "copy_rhs" else None
-            e = rhs[et] if op != "copy_lhs" else None
-            if (op != "copy_rhs" and u is None) or (op != "copy_lhs" and e is None):
-                continue
-            o = gspmm(gidx.get_relation_graph(et), op, "sum", u, e)
-            outs[d] = o if outs[d] is None else outs[d] + o
-        return tuple(outs)
-    out, _ = _gspmm_hetero(gidx, op, reduce_op, lhs_len, tuple(lhs) + tuple(rhs))
-    return out
+        op, rhs = "mul", _inv(rhs)
+    feats = _autocast(*(lhs + rhs))
+    with torch.autocast("cuda", enabled=False):
+        return GSpMM_hetero.apply(gidx, op, reduce_op, lhs_len, *feats)
 
 
 def gsddmm_hetero(gidx, op, lhs_len, lhs_target, rhs_target, *lhs_and_rhs):
     lhs, rhs = list(lhs_and_rhs[:lhs_len]), list(lhs_and_rhs[lhs_len:])
     if op == "sub":
-        op, rhs = "add", [None if t is None else -t for t in rhs]
+        op, rhs = "add", _neg(rhs)
     elif op == "div":
-        op, rhs = "mul", [None if t is None else 1.0 / t for t in rhs]
-    if any(t is not None and t.requires_grad for t in lhs + rhs):
-        outs = []
-        for et in range(gidx.number_of_etypes()):
-            s, d = gidx.metagraph.find_edge(et)
-            pick = lambda tup, tgt: tup[{"u": s, "v": d, "e": et}[tgt]]
-            l = pick(lhs, lhs_target) if op != "copy_rhs" else None
-            r = pick(rhs, rhs_target) if op != "copy_lhs" else None
-            if (op != "copy_rhs" and l is None) or (op != "copy_lhs" and r is None):
-                outs.append(None)
-            else:
-                outs.append(gsddmm(gidx.get_relation_graph(et), op, l, r, lhs_target, rhs_target))
-        return tuple(outs)
-    return _gsddmm_hetero(gidx, op, lhs_len, lhs_target, rhs_target, tuple(lhs) + tuple(rhs))
+        op, rhs = "mul", _inv(rhs)
+    feats = _autocast(*(lhs + rhs))
+    with torch.autocast("cuda", enabled=False):
+        return GSDDMM_hetero.apply(gidx, op, lhs_len, lhs_target, rhs_target, *feats)
+
+
+def edge_softmax_hetero(gidx, eids=None, norm_by="dst", *score):
+    score = _autocast(*score)
+    with torch.autocast("cuda", enabled=False):
+        return EdgeSoftmax_hetero.apply(gidx, eids, norm_by, *score)

@@ -26,7 +26,15 @@ template <typename A>
 __device__ __forceinline__ A esm_exp(A x);
 template <>
 __device__ __forceinline__ float esm_exp<float>(float x) {
-  return expf(x);
+  // exp(x) = 2^(x log2 e) on the hardware's v_exp_f32 (1 ulp).  The product x * log2(e) is kept
+  // as hi + lo (one fma recovers its rounding error, a second constant carries the low bits of
+  // log2 e), so the error of the argument does not grow with |x|: 2^hi * (1 + lo ln 2).
+  // ~7 instructions instead of the ~25 of the library expf; |relative error| < 3e-7 measured
+  // against exp() in fp64 over [-88, 0] (tests/test_gpu_softmax_kernels.py).
+  const float hi = x * 1.44269504088896341f;
+  const float lo = __builtin_fmaf(x, 1.44269504088896341f, -hi) + x * 1.92596299112661746e-8f;
+  const float r = __builtin_amdgcn_exp2f(hi) * __builtin_fmaf(lo, 0.693147180559945309f, 1.0f);
+  return hi < -150.f ? 0.f : r;  // also keeps exp(-inf) = 0 (lo would be NaN there)
 }
 template <>
 __device__ __forceinline__ double esm_exp<double>(double x) {
@@ -184,6 +192,7 @@ struct EsmParams {
   int dim, log2_hp;
   int wave_lds_bytes;
   int vec4;  // fp32, dim % 4 == 0 == padded width, 16-byte aligned operands: rows move as 16-byte pieces
+  int xcd;   // units in XCD-contiguous order (kTuneXcd): neighbouring units share an L2
   int64_t* carry_row;  // [num_units] row continued in the next unit, or -1
   void* carry_stat;    // [num_units, 2 * dim] accumulators: (m | s) forward, (sum | -) backward
   void* tail_stat;     // [num_units, 2 * dim]
@@ -237,13 +246,41 @@ __device__ __forceinline__ A esm_expx(A x) {
     return esm_exp<A>(x);
 }
 
+// Segments (rows or row parts) whose statistics one round of the balanced reduce keeps in LDS.
+constexpr int kEsmSegCap = 64;
+
+// Orders one wave's LDS traffic between the passes of the reduce.  Each wave works on its own
+// LDS slice and the number of rounds differs from wave to wave, so a block barrier is neither
+// needed nor allowed here; LDS operations of ONE wave execute in issue order.
+__device__ __forceinline__ void esm_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// LDS atomics (ds_max_f32 / ds_add_f32 and the f64 forms).  Lanes of one wave reach them in
+// program order, so the order of the additions is fixed: results are run-to-run identical.
+template <typename A>
+__device__ __forceinline__ void esm_lds_max(A* addr, A v) {
+  (void)__hip_atomic_fetch_max(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <typename A>
+__device__ __forceinline__ void esm_lds_add(A* addr, A v) {
+  (void)__hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <typename Idx, typename DT, bool BWD, bool PRECISE>
 __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams<Idx> p) {
   using A = typename Acc<DT>::type;
   extern __shared__ __align__(16) unsigned char esm_smem[];
   const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
-  const int64_t w = static_cast<int64_t>(blockIdx.x) * wpb + wib;
+  unsigned blk = blockIdx.x;
+  if (p.xcd) {  // block b runs on XCD b % 8: give every XCD one contiguous eighth of the units
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u;
+    const unsigned x = blk & 7u, i = blk >> 3;
+    blk = x * q + (x < r ? x : r) + i;
+  }
+  const int64_t w = static_cast<int64_t>(blk) * wpb + wib;
   const int hp = 1 << p.log2_hp, dim = p.dim;
   unsigned char* base = esm_smem + static_cast<size_t>(wib) * p.wave_lds_bytes;
   A* val = reinterpret_cast<A*>(base);                               // [kEsmItems * hp]
@@ -367,130 +404,149 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
     if (cb < u.nE) carry_begin = cb;
     const bool has_carry = carry_begin < u.nE;
     if (lane == 0) p.carry_row[w] = has_carry ? u.i0 + u.R : int64_t(-1);
-    // ---- reduce ---------------------------------------------------------------------------
-    // Segments of up to kBig edges: one lane per (segment, feature), serial over LDS.
-    // Longer ones (at most kEsmItems / kBig per unit) are found with a ballot and reduced by
-    // the whole wave: the es lane groups stride over the segment, xor-shuffles combine them.
-    constexpr int kBig = 24;
+    // ---- reduce: degree-balanced -----------------------------------------------------------
+    // The 64 lanes are es = 64 / hp lane groups x hp features.  The unit's edges are dealt to the
+    // groups in equal contiguous shares; every group WALKS its share once per pass with a moving
+    // segment pointer (a segment = a row, or the part of a row inside this unit), keeping the
+    // running max / sum of the segment it is in in a register and handing it to a per-segment
+    // table in LDS when it leaves the segment.  A 200-edge row and forty 5-edge rows cost the
+    // same: nE / es steps per pass, all lanes busy.  Tables hold kEsmSegCap segments; a unit with
+    // more row ends than that (runs of tiny rows) is processed in several rounds.
+    //   forward : pass 1 max -> tm;  pass 2 ex = exp(x - M) stored back, sum -> ts;
+    //             pass 3 scale by 1 / S (segments cut by the unit boundary stay un-normalised
+    //             and publish (M, S) for the fix-up kernel)
+    //   backward: pass 1 sum(sds) -> ts;  pass 2 val = sds - sum * out
     const int nseg = u.R + (has_carry ? 1 : 0);
     const int h = lane & (hp - 1);
     const int g = lane >> p.log2_hp;
     const int es = 64 >> p.log2_hp;
-    auto seg_bounds = [&](int sg, int* t0, int* t1, bool* partial, A** stat) {
-      const bool is_carry = sg == u.R;
-      const bool is_tail = sg == 0 && first < 0 && !is_carry;
-      int a0 = rend[sg] < 0 ? 0 : rend[sg];
-      if (is_carry) a0 = carry_begin;
-      *t0 = a0;
-      *t1 = is_carry ? u.nE : rend[sg + 1];
-      *partial = is_carry || is_tail;
-      *stat = static_cast<A*>(is_carry ? p.carry_stat : p.tail_stat) + w * 2 * dim;
-    };
-    // (a) short segments
-    for (int sg = g; sg < nseg; sg += es) {
-      int t0, t1;
-      bool partial;
-      A* stat;
-      seg_bounds(sg, &t0, &t1, &partial, &stat);
-      if (t1 - t0 > kBig || h >= dim) continue;
+    const bool hok = h < dim;
+    A* tm = reinterpret_cast<A*>(rend + kEsmItems + 2);  // [kEsmSegCap * hp]
+    A* ts = tm + (BWD ? 0 : kEsmSegCap * hp);            // [kEsmSegCap * hp]
+    auto seg_end = [&](int sg) { return sg < u.R ? rend[sg + 1] : u.nE; };  // carry segment: sg == R
+    const A neg_inf = -static_cast<A>(__builtin_huge_valf());
+    for (int c0 = 0; c0 < nseg; c0 += kEsmSegCap) {
+      const int c1 = c0 + kEsmSegCap < nseg ? c0 + kEsmSegCap : nseg;
+      const int ea = c0 == 0 ? 0 : seg_end(c0 - 1), eb = seg_end(c1 - 1);
+      const int share = (eb - ea + es - 1) / es;
+      int e_s = ea + g * share, e_e = e_s + share;
+      if (e_s > eb) e_s = eb;
+      if (e_e > eb) e_e = eb;
+      // first segment of this group's share: smallest sg in [c0, c1) with seg_end(sg) > e_s
+      int t_first = c0;
+      {
+        int lo = c0, hi = c1 - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (seg_end(mid) > e_s)
+            hi = mid;
+          else
+            lo = mid + 1;
+        }
+        t_first = lo;
+      }
+      for (int i = lane; i < (c1 - c0) * hp; i += 64) {
+        if constexpr (!BWD) tm[i] = neg_inf;
+        ts[i] = A(0);
+      }
+      esm_wave_sync();
       if constexpr (BWD) {
-        A sum = A(0);
-        for (int t = t0; t < t1; ++t) sum += val[(t << p.log2_hp) + h];
-        if (partial) {
-          stat[h] = sum;
-        } else {
-          for (int t = t0; t < t1; ++t) {
-            const int i = (t << p.log2_hp) + h;
-            val[i] = val[i] - sum * val2[i];
+        if (hok && e_s < e_e) {
+          int t = t_first, nxt = seg_end(t);
+          A sum = A(0);
+          for (int e = e_s; e < e_e; ++e) {
+            while (e >= nxt) {
+              esm_lds_add(&ts[((t - c0) << p.log2_hp) + h], sum);
+              sum = A(0);
+              nxt = seg_end(++t);
+            }
+            sum += val[(e << p.log2_hp) + h];
+          }
+          esm_lds_add(&ts[((t - c0) << p.log2_hp) + h], sum);
+        }
+        esm_wave_sync();
+        if (hok && e_s < e_e) {
+          int t = t_first, nxt = seg_end(t);
+          for (int e = e_s; e < e_e; ++e) {
+            while (e >= nxt) nxt = seg_end(++t);
+            const int i = (e << p.log2_hp) + h;
+            val[i] = val[i] - ts[((t - c0) << p.log2_hp) + h] * val2[i];  // partial segments: rewritten by the fix-up
           }
         }
       } else {
-        A mx = -static_cast<A>(__builtin_huge_valf());
-        for (int t = t0; t < t1; ++t) {
-          const A x = val[(t << p.log2_hp) + h];
-          mx = mx > x ? mx : x;
+        if (hok && e_s < e_e) {
+          int t = t_first, nxt = seg_end(t);
+          A mx = neg_inf;
+          for (int e = e_s; e < e_e; ++e) {
+            while (e >= nxt) {
+              esm_lds_max(&tm[((t - c0) << p.log2_hp) + h], mx);
+              mx = neg_inf;
+              nxt = seg_end(++t);
+            }
+            const A x = val[(e << p.log2_hp) + h];
+            mx = mx > x ? mx : x;
+          }
+          esm_lds_max(&tm[((t - c0) << p.log2_hp) + h], mx);
         }
-        A sum = A(0);
-        for (int t = t0; t < t1; ++t) {
-          const int i = (t << p.log2_hp) + h;
-          const A ex = esm_expx<A, PRECISE>(val[i] - mx);
-          val[i] = ex;
-          sum += ex;
+        esm_wave_sync();
+        if (hok && e_s < e_e) {
+          int t = t_first, nxt = seg_end(t);
+          A M = tm[((t - c0) << p.log2_hp) + h], sum = A(0);
+          for (int e = e_s; e < e_e; ++e) {
+            while (e >= nxt) {
+              esm_lds_add(&ts[((t - c0) << p.log2_hp) + h], sum);
+              sum = A(0);
+              nxt = seg_end(++t);
+              M = tm[((t - c0) << p.log2_hp) + h];
+            }
+            const int i = (e << p.log2_hp) + h;
+            const A ex = esm_expx<A, PRECISE>(val[i] - M);
+            val[i] = ex;
+            sum += ex;
+          }
+          esm_lds_add(&ts[((t - c0) << p.log2_hp) + h], sum);
         }
-        if (partial) {
-          stat[h] = mx;
-          stat[dim + h] = sum;
-        } else {
-          for (int t = t0; t < t1; ++t) {
-            const int i = (t << p.log2_hp) + h;
-            val[i] = val[i] / sum;
+        esm_wave_sync();
+        if (hok && e_s < e_e) {
+          int t = t_first, nxt = seg_end(t);
+          auto inv_of = [&](int sg) {
+            const bool partial = (sg == 0 && first < 0) || sg == u.R;
+            return partial ? A(1) : A(1) / ts[((sg - c0) << p.log2_hp) + h];
+          };
+          A inv = inv_of(t);
+          for (int e = e_s; e < e_e; ++e) {
+            while (e >= nxt) {
+              nxt = seg_end(++t);
+              inv = inv_of(t);
+            }
+            const int i = (e << p.log2_hp) + h;
+            val[i] = val[i] * inv;
           }
         }
       }
-    }
-    // (b) long segments, whole wave each (wave-uniform control flow)
-    for (int sbase = 0; sbase < nseg; sbase += 64) {
-      const int sg_l = sbase + lane;
-      bool big = false;
-      if (sg_l < nseg) {
-        int t0, t1;
-        bool partial;
-        A* stat;
-        seg_bounds(sg_l, &t0, &t1, &partial, &stat);
-        big = t1 - t0 > kBig;
-      }
-      unsigned long long mask = __ballot(big);
-      while (mask) {
-        const int bit = __ffsll(static_cast<long long>(mask)) - 1;
-        mask &= mask - 1;
-        int t0, t1;
-        bool partial;
-        A* stat;
-        seg_bounds(sbase + bit, &t0, &t1, &partial, &stat);
-        const bool hok = h < dim;
-        if constexpr (BWD) {
-          A sum = A(0);
-          if (hok)
-            for (int t = t0 + g; t < t1; t += es) sum += val[(t << p.log2_hp) + h];
-          sum = group_reduce_sum<A>(sum, hp, 64);
-          if (partial) {
-            if (hok && g == 0) stat[h] = sum;
-          } else if (hok) {
-            for (int t = t0 + g; t < t1; t += es) {
-              const int i = (t << p.log2_hp) + h;
-              val[i] = val[i] - sum * val2[i];
-            }
+      // segments cut by the unit boundary publish their statistics for the fix-up kernel
+      if (hok && g == 0) {
+        if (c0 == 0 && first < 0 && u.R > 0) {  // tail of a row begun in an earlier unit
+          A* stat = static_cast<A*>(p.tail_stat) + w * 2 * dim;
+          if constexpr (BWD) {
+            stat[h] = ts[h];
+          } else {
+            stat[h] = tm[h];
+            stat[dim + h] = ts[h];
           }
-        } else {
-          A mx = -static_cast<A>(__builtin_huge_valf());
-          if (hok)
-            for (int t = t0 + g; t < t1; t += es) {
-              const A x = val[(t << p.log2_hp) + h];
-              mx = mx > x ? mx : x;
-            }
-          mx = group_reduce_max<A>(mx, hp, 64);
-          A sum = A(0);
-          if (hok)
-            for (int t = t0 + g; t < t1; t += es) {
-              const int i = (t << p.log2_hp) + h;
-              const A ex = esm_expx<A, PRECISE>(val[i] - mx);
-              val[i] = ex;
-              sum += ex;
-            }
-          sum = group_reduce_sum<A>(sum, hp, 64);
-          if (partial) {
-            if (hok && g == 0) {
-              stat[h] = mx;
-              stat[dim + h] = sum;
-            }
-          } else if (hok) {
-            for (int t = t0 + g; t < t1; t += es) {
-              const int i = (t << p.log2_hp) + h;
-              val[i] = val[i] / sum;
-            }
+        }
+        if (has_carry && u.R >= c0 && u.R < c1) {
+          A* stat = static_cast<A*>(p.carry_stat) + w * 2 * dim;
+          const int o = ((u.R - c0) << p.log2_hp) + h;
+          if constexpr (BWD) {
+            stat[h] = ts[o];
+          } else {
+            stat[h] = tm[o];
+            stat[dim + h] = ts[o];
           }
         }
       }
+      esm_wave_sync();
     }
   }
   __syncthreads();
@@ -648,16 +704,28 @@ static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void*
     p.vec4 = (std::is_same<DT, float>::value && dim % 4 == 0 && (1 << g.log2_hp) == dim && al(a) && al(c) &&
               (!backward || al(b))) ? 1 : 0;
   }
+  p.xcd = (tuning_flags() & kTuneXcd) ? 1 : 0;
   p.carry_row = reinterpret_cast<int64_t*>(wsp + g.off_carry_row);
   p.carry_stat = wsp + g.off_carry_stat;
   p.tail_stat = wsp + g.off_tail_stat;
   const int hp = 1 << g.log2_hp;
+  // values (+ out values backward), edge ids, row ends, then the segment tables of the reduce
+  // ((max | sum) forward, sum backward)
   const size_t per_wave = sizeof(A) * kEsmItems * hp * (backward ? 2 : 1) +
-                          sizeof(int64_t) * kEsmItems + sizeof(int) * (kEsmItems + 2) + 8;
+                          sizeof(int64_t) * kEsmItems + sizeof(int) * (kEsmItems + 2) + 8 +
+                          sizeof(A) * kEsmSegCap * hp * (backward ? 1 : 2);
   p.wave_lds_bytes = static_cast<int>((per_wave + 15) / 16 * 16);
-  int wpb = static_cast<int>((64 * 1024) / p.wave_lds_bytes);
-  if (wpb > 4) wpb = 4;
-  if (wpb < 1) wpb = 1;
+  // waves per block: whatever packs most waves into a CU's 160 KB of LDS (a block gets <= 64 KB)
+  int wpb = 1, best_waves = 0;
+  for (int cand : {4, 2, 1}) {
+    const size_t blk = static_cast<size_t>(p.wave_lds_bytes) * cand;
+    if (blk > 64 * 1024) continue;
+    const int waves = static_cast<int>((160 * 1024) / blk) * cand;
+    if (waves > best_waves) {
+      best_waves = waves;
+      wpb = cand;
+    }
+  }
   if (!plan_valid) {
     const int64_t n = g.num_units + 1;
     hipLaunchKernelGGL((esm_plan_kernel<Idx>), dim3(static_cast<unsigned>((n + 255) / 256)),

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const Piece* __restric
       // row of piece i: block-local piece number / pieces by multiply-high (exact: the numbers
       // stay below 2^16, magic = ceil(2^32 / pieces))
       const unsigned loc = j0 + static_cast<unsigned>(i - base);
-      const unsigned dr = __umulhi(loc, magic);
+      const unsigned dr = pieces == 1 ? loc : __umulhi(loc, magic);  // magic wraps to 0 for pieces == 1
       const unsigned j = loc - dr * static_cast<unsigned>(pieces);
       at[k] = static_cast<int64_t>(idx[r0 + dr]) * pieces + j;
     }
@@ -74,6 +74,60 @@ int run_gather(const void* src, const void* idx, void* dst, int64_t n, int64_t r
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// dst[idx[i], :] = src[i, :] — the un-permute after the all-to-all of a pull
+// (`return_value[perm] = req_value`, python/dgl/cuda/nccl.py:180-181).  The source rows and the
+// index stream are read once (non-temporal); blocks are renumbered so that each XCD walks ONE
+// contiguous eighth of the source (block b runs on XCD b % 8), which keeps the partially written
+// destination lines of neighbouring source rows in one L2.
+template <typename Idx, typename Piece, int K>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const Piece* __restrict__ src,
+                                                           const Idx* __restrict__ idx,
+                                                           Piece* __restrict__ dst, int64_t n,
+                                                           int pieces, unsigned magic) {
+  const int64_t total = n * pieces;
+  const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u;
+  const unsigned x = blockIdx.x & 7u, i8 = blockIdx.x >> 3;
+  const unsigned blk = x * q + (x < r ? x : r) + i8;
+  const int64_t base = static_cast<int64_t>(blk) * (256 * K);
+  if (base >= total) return;
+  const int64_t r0 = base / pieces;  // block-uniform
+  const unsigned j0 = static_cast<unsigned>(base - r0 * pieces);
+  Piece v[K];
+  int64_t at[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    int64_t i = base + k * 256 + threadIdx.x;
+    if (i >= total) i = total - 1;
+    v[k] = __builtin_nontemporal_load(src + i);
+    const unsigned loc = j0 + static_cast<unsigned>(i - base);
+    const unsigned dr = pieces == 1 ? loc : __umulhi(loc, magic);  // magic wraps to 0 for pieces == 1
+    const unsigned j = loc - dr * static_cast<unsigned>(pieces);
+    at[k] = static_cast<int64_t>(__builtin_nontemporal_load(idx + (r0 + dr))) * pieces + j;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int64_t i = base + k * 256 + threadIdx.x;
+    if (i < total) dst[at[k]] = v[k];
+  }
+}
+
+template <typename Idx, typename Piece>
+int run_scatter(const void* src, const void* idx, void* dst, int64_t n, int64_t row_bytes,
+                hipStream_t s) {
+  constexpr int K = 4;
+  const int64_t pieces = row_bytes / static_cast<int64_t>(sizeof(Piece));
+  if (pieces > 0xffff) return xfail("scatter_rows: rows longer than 65535 pieces are not supported");
+  const int64_t total = n * pieces;
+  const int64_t blocks = (total + 256 * K - 1) / (256 * K);
+  if (blocks > 0x7fffffffLL) return xfail("scatter_rows: too many pieces for one launch");
+  const unsigned magic = 0xFFFFFFFFu / static_cast<unsigned>(pieces) + 1u;
+  hipLaunchKernelGGL((scatter_rows_kernel<Idx, Piece, K>), dim3(static_cast<unsigned>(blocks)), dim3(256),
+                     0, s, static_cast<const Piece*>(src), static_cast<const Idx*>(idx),
+                     static_cast<Piece*>(dst), n, static_cast<int>(pieces), magic);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 // mode 0: remainder (part = id % k, local = id / k); mode 1: range (part = the range holding id,
 // local = id - range[part]).  Either output may be NULL.
@@ -151,6 +205,28 @@ int dgla_gather_rows(int idtype_bits, const void* src, const void* idx, int64_t 
   }
   DGLA_GR(int64_t);
 #undef DGLA_GR
+}
+
+int dgla_scatter_rows(int idtype_bits, const void* src, const void* idx, int64_t n,
+                      int64_t row_bytes, void* dst, void* hip_stream) {
+  if (idtype_bits != 32 && idtype_bits != 64) return xfail("idtype must be int32 or int64");
+  if (n < 0 || row_bytes < 0) return xfail("negative size");
+  if (n == 0 || row_bytes == 0) return 0;
+  if (!src || !idx || !dst) return xfail("scatter_rows: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, dst);
+  const uintptr_t both = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst);
+  const bool v16 = row_bytes % 16 == 0 && both % 16 == 0;
+  const bool v4 = row_bytes % 4 == 0 && both % 4 == 0;
+#define DGLA_SR(IDX)                                                               \
+  if (v16) return run_scatter<IDX, u32x4>(src, idx, dst, n, row_bytes, s);          \
+  if (v4) return run_scatter<IDX, uint32_t>(src, idx, dst, n, row_bytes, s);        \
+  return run_scatter<IDX, unsigned char>(src, idx, dst, n, row_bytes, s)
+  if (idtype_bits == 32) {
+    DGLA_SR(int32_t);
+  }
+  DGLA_SR(int64_t);
+#undef DGLA_SR
 }
 
 int dgla_partition_map(int idtype_bits, int mode, int num_parts, const void* range, const void* idx,

@@ -838,6 +838,8 @@ struct ObjList {
   uint32_t magic = kMagicList;
   std::vector<ObjValue> items;
 };
+static size_t dtype_bytes(dgla_dtype d) { return d == DGLA_F64 ? 8 : (d == DGLA_F32 ? 4 : 2); }
+
 struct HeteroGraphObj {
   uint32_t magic = kMagicHetero;
   int num_ntypes = 0;
@@ -982,7 +984,6 @@ static int hetero_combine(bool is_max, void* out, const void* cand, void* au, co
   return 0;
 }
 
-static size_t dtype_bytes(dgla_dtype d) { return d == DGLA_F64 ? 8 : (d == DGLA_F32 ? 4 : 2); }
 
 static int fill_identity(dgla_dtype dt, void* p, int64_t n, bool is_max) {
   switch (dt) {
@@ -1204,6 +1205,57 @@ static Registrar r_sddmm_hetero("sparse._CAPI_DGLKernelSDDMMHetero",
     } else {
       return ffi_fail("SDDMM only supports CSR and COO formats");
     }
+    if (rc) return rc;
+  }
+  return 0;
+});
+
+// (hg REVERSED, op, List feat [dZ by dst ntype of the forward graph], List idx, List idx_type,
+//  List out [by src ntype for copy_lhs, by etype for copy_rhs])  —  src/array/kernel.cc:680-697 ->
+// UpdateGradMinMax_hetero (src/array/cuda/segment_reduce.cuh:184-225): for every relation of the
+// reversed graph, the gradient rows of its (forward) destination type flow to the winners of the
+// type this relation contributes; with copy_lhs a (destination type, source type) pair is
+// visited once however many relations connect it (the winners' node type is what is compared).
+static Registrar r_ugmm("sparse._CAPI_DGLKernelUpdateGradMinMaxHetero",
+                        [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  void* h;
+  const char* op;
+  const ObjList *LF, *LI, *LT, *LO;
+  if (get_handle(a, 0, &h) || get_str(a, 1, &op) || get_list(a, 2, &LF) || get_list(a, 3, &LI) ||
+      get_list(a, 4, &LT) || get_list(a, 5, &LO))
+    return -1;
+  if (magic_of(h) != kMagicHetero) return ffi_fail("argument 0: expected a heterograph handle");
+  const bool lhs = strcmp(op, "copy_lhs") == 0;
+  if (!lhs && strcmp(op, "copy_rhs") != 0) return 0;  // segment_reduce.cuh:190: other operators: no-op
+  HeteroGraphObj* hg = static_cast<HeteroGraphObj*>(h);
+  std::vector<std::vector<int>> seen(hg->num_ntypes);
+  for (size_t et = 0; et < hg->rel.size(); ++et) {
+    const int dst_nt = hg->src[et], src_nt = hg->dst[et];  // the graph is reversed
+    if (lhs) {
+      bool dup = false;
+      for (int s : seen[dst_nt]) dup = dup || s == src_nt;
+      if (dup) continue;
+    }
+    seen[dst_nt].push_back(src_nt);
+    const int type = lhs ? src_nt : static_cast<int>(et);
+    DGLArray *feat, *idx, *idt, *out;
+    if (list_array(LF, dst_nt, &feat) || list_array(LI, dst_nt, &idx) || list_array(LT, dst_nt, &idt) ||
+        list_array(LO, type, &out))
+      return -1;
+    if (null_array(feat) || null_array(idx) || null_array(idt) || null_array(out)) continue;
+    dgla_dtype dt;
+    int bi, bt;
+    if (float_dtype(feat, &dt) || idbits_of(idx, &bi) || idbits_of(idt, &bt)) return -1;
+    if (bi != bt) return ffi_fail("idx and idx_type must have the same integer type");
+    for (const DGLArray* t : {feat, idx, idt, out}) {
+      if (!on_gpu(t)) return ffi_fail("array is not on the GPU device of the graph");
+      if (check_contiguous(t, "array")) return -1;
+    }
+    TensorArg f, o;
+    to_tensor(feat, &f);
+    to_tensor(out, &o);
+    const int rc = dgla_update_grad_minmax(bi, dt, &f.t, data_ptr(idx), data_ptr(idt), type, &o.t, tls_stream);
     if (rc) return rc;
   }
   return 0;

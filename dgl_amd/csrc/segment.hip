@@ -149,6 +149,37 @@ int run_bwd_segment_cmp(const void* feat, const void* arg, void* out, int64_t n,
   return 0;
 }
 
+// UpdateGradMinMaxHeteroKernel (src/array/cuda/segment_reduce.cuh:73-92): element (row, col) of
+// the incoming gradient goes to the node / edge that won the forward max / min, but only through
+// the relation type that winner belongs to: out[idx[row, col], col] += feat[row, col] where
+// idx_type[row, col] == type.  Several destinations can share a winner -> atomics, as there.
+template <typename Idx, typename DT>
+__global__ __launch_bounds__(256) void update_grad_minmax_kernel(
+    const DT* __restrict__ feat, const Idx* __restrict__ idx, const Idx* __restrict__ idx_type,
+    DT* __restrict__ out, int64_t n, int64_t dim, Idx type, int64_t out_rows) {
+  const int64_t total = n * dim;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total; i += stride) {
+    if (idx_type[i] != type) continue;
+    const int64_t r = static_cast<int64_t>(idx[i]);
+    if (r < 0 || r >= out_rows) continue;
+    atomic_add_elem<DT>(out + r * dim + (i % dim), feat[i]);
+  }
+}
+
+template <typename Idx, typename DT>
+int run_update_grad_minmax(const void* feat, const void* idx, const void* idx_type, void* out,
+                           int64_t n, int64_t dim, int64_t type, int64_t out_rows, hipStream_t s) {
+  const int64_t total = n * dim;
+  const unsigned blocks = static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 256 * 64));
+  hipLaunchKernelGGL((update_grad_minmax_kernel<Idx, DT>), dim3(blocks), dim3(256), 0, s,
+                     static_cast<const DT*>(feat), static_cast<const Idx*>(idx),
+                     static_cast<const Idx*>(idx_type), static_cast<DT*>(out), n, dim,
+                     static_cast<Idx>(type), out_rows);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 #define DGLA_IDX_DTYPE_SWITCH(idbits, dtype, FN, ...)                                   \
   do {                                                                                  \
     if ((idbits) == 32) {                                                               \
@@ -349,6 +380,24 @@ int dgla_scatter_add(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat,
   const int64_t out_rows = out->shape[0];
   if (n * dim >= kScatterSortMinElems && out_rows > 0) return scatter_add_sorted(idtype_bits, dtype, feat, idx, out, s);
   DGLA_IDX_DTYPE_SWITCH(idtype_bits, dtype, run_scatter_add, feat->data, idx, out->data, n, dim, s);
+  return sfail("unsupported feature dtype");
+}
+
+int dgla_update_grad_minmax(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat,
+                            const void* idx, const void* idx_type, int64_t type,
+                            const dgla_tensor* out, void* hip_stream) {
+  if (idtype_bits != 32 && idtype_bits != 64) return sfail("idtype must be int32 or int64");
+  if (dtype < DGLA_F32 || dtype > DGLA_BF16) return sfail("unsupported feature dtype");
+  if (!feat || !out || feat->ndim < 1 || out->ndim < 1 || !feat->shape || !out->shape)
+    return sfail("feat / out is null");
+  if (row_len(feat) != row_len(out)) return sfail("feat and out have different feature shapes");
+  const int64_t n = feat->shape[0], dim = row_len(out);
+  if (n == 0 || dim == 0 || out->shape[0] == 0) return 0;
+  if (!feat->data || !out->data || !idx || !idx_type) return sfail("feat / idx / idx_type / out data is null");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, out->data);
+  DGLA_IDX_DTYPE_SWITCH(idtype_bits, dtype, run_update_grad_minmax, feat->data, idx, idx_type, out->data,
+                        n, dim, type, out->shape[0], s);
   return sfail("unsupported feature dtype");
 }
 

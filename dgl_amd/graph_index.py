@@ -81,16 +81,29 @@ class Relation:
         new_eids = order.to(self.idtype) if eids is None else eids[order]
         return indptr, minor[order].contiguous(), new_eids.contiguous()
 
+    @staticmethod
+    def _drop_identity_map(fmt):
+        """An edge-id map that says "edge id == position" (a COO that was already sorted by this
+        format's major index, e.g. after dgl.reorder_graph(edge_permute_algo='dst')) is dropped:
+        the kernels then skip the map altogether.  One pass + one synchronisation, at format
+        build time (where the reference synchronises too)."""
+        indptr, indices, eids = fmt
+        if eids is not None and eids.numel() and eids.is_cuda:
+            ident = torch.arange(eids.numel(), device=eids.device, dtype=eids.dtype)
+            if bool(torch.equal(eids, ident)):
+                return indptr, indices, None
+        return fmt
+
     def csr(self):
         if self._csr is None:
             row, col, eids = self.coo()
-            self._csr = self._compress(row, col, eids, self.num_src)
+            self._csr = self._drop_identity_map(self._compress(row, col, eids, self.num_src))
         return self._csr
 
     def csc(self):
         if self._csc is None:
             row, col, eids = self.coo()
-            self._csc = self._compress(col, row, eids, self.num_dst)
+            self._csc = self._drop_identity_map(self._compress(col, row, eids, self.num_dst))
         return self._csc
 
     def has(self, fmt):

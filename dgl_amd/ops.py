@@ -118,31 +118,7 @@ def edge_softmax(graph, logits, eids=None, norm_by="dst"):
     if eids is not None:
         raise DGLAMDError("eids is not supported on graphs with several relations")
     scores = _to_type_tuple(graph, logits, "etype")
-    outs = [None] * gidx.number_of_etypes()
-    by_nt = {}
-    for et in range(gidx.number_of_etypes()):
-        s, d = gidx.metagraph.find_edge(et)
-        if scores[et] is not None:
-            by_nt.setdefault(d if norm_by == "dst" else s, []).append(et)
-    from .graph_index import GraphIndex, Relation
-
-    for nt, ets in by_nt.items():
-        rows, cols, offs = [], [], [0]
-        for et in ets:
-            r, c, old = gidx.relations[et].coo()
-            if old is not None:
-                raise DGLAMDError("edge_softmax needs COO in edge-id order")
-            rows.append(r if norm_by == "dst" else c)
-            cols.append(c if norm_by == "dst" else r)
-            offs.append(offs[-1] + r.shape[0])
-        # source ids of different relations may collide; they are irrelevant for the softmax
-        rel = Relation(int(max(int(x.max()) + 1 if x.numel() else 1 for x in rows)),
-                       gidx.num_nodes(nt), torch.cat(rows), torch.cat(cols),
-                       idtype=gidx.dtype, device=gidx.ctx)
-        sub = GraphIndex([rel.num_src, rel.num_dst], [(0, 1)], [rel])
-        res = _F.edge_softmax(sub, torch.cat([scores[et] for et in ets]), None, "dst")
-        for i, et in enumerate(ets):
-            outs[et] = res[offs[i]:offs[i + 1]]
+    outs = _F.edge_softmax_hetero(gidx, None, norm_by, *scores)
     if isinstance(logits, dict):
         return {graph.canonical_etypes[et]: o for et, o in enumerate(outs) if o is not None}
     return tuple(outs)

@@ -389,7 +389,11 @@ def sparse_all_to_all_pull(req_idx, value, partition, group=None):
                             device=value.device)
     _all_to_all(req_value, _take_rows(value, resp_idx), req_l, resp_l, group)
     out = torch.empty_like(req_value)
-    out[perm.long()] = req_value  # back into the requested order
+    if req_value.is_cuda:  # back into the requested order: out[perm[i]] = req_value[i]
+        from . import _capi
+        _capi.scatter_rows(req_value, perm.contiguous(), out)
+    else:
+        out[perm.long()] = req_value
     return out
 
 

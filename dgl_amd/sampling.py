@@ -96,7 +96,7 @@ def to_block(g, dst_nodes):
     blk = _make_block(blk_ptr, local, num_src, dst_nodes.shape[0], idt, dev)
     blk.srcdata[NID] = src_nodes
     blk.dstdata[NID] = dst_nodes
-    orig = eids[pos]
+    orig = pos.to(idt) if eids is None else eids[pos]  # no map: edge id == CSC position
     blk.edata[EID] = g.edata[EID][orig.long()] if EID in g.edata else orig
     return blk
 

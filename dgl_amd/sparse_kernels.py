@@ -432,3 +432,30 @@ def _gsddmm_hetero(gidx, op, lhs_len, lhs_target, rhs_target, lhs_and_rhs_tuple)
         _call_hetero("sparse._CAPI_DGLKernelSDDMMHetero", gidx, fmts, op, lst("l", n_l), lst("r", n_r),
                      [_nd(o) for o in outs], _TARGET[lhs_target], _TARGET[rhs_target])
     return tuple(None if o is None else (o.squeeze(-1) if sq else o) for o, sq in zip(outs, squeeze))
+
+
+def _update_grad_minmax_hetero(gidx, op, list_x, list_idx, list_idx_etype, list_dX):
+    """Gradient of a max / min reduction over several relations w.r.t. the copied operand
+    (python/dgl/_sparse_ops.py:723-770).  ``gidx`` is the REVERSED graph; ``list_x`` the incoming
+    gradients per (forward) destination node type, ``list_idx`` / ``list_idx_etype`` the winning
+    node (copy_lhs) or edge (copy_rhs) ids and their node / edge types recorded by the forward
+    pass; ``list_dX`` fixes the output row counts (per source node type for copy_lhs, per edge
+    type for copy_rhs).  Returns the gradients in that indexing."""
+    use_u, use_e = op != "copy_rhs", op != "copy_lhs"
+    list_out = [None] * len(list_dX)
+    for etid in range(gidx.number_of_etypes()):
+        src_id, dst_id = gidx.metagraph.find_edge(etid)  # reversed: src_id = forward destination type
+        x = list_x[src_id]
+        if x is None:
+            continue
+        if use_u and list_dX[dst_id] is not None and list_out[dst_id] is None:
+            list_out[dst_id] = torch.zeros((len(list_dX[dst_id]),) + tuple(x.shape[1:]), dtype=x.dtype,
+                                           device=x.device)
+        if use_e and list_dX[etid] is not None and list_out[etid] is None:
+            list_out[etid] = torch.zeros((len(list_dX[etid]),) + tuple(x.shape[1:]), dtype=x.dtype,
+                                         device=x.device)
+    nd = lambda ts: [None if t is None else _nd(t.contiguous()) for t in ts]
+    _call_hetero("sparse._CAPI_DGLKernelUpdateGradMinMaxHetero", gidx,
+                 ["coo" if r.allowed("coo") else r.formats[0] for r in gidx.relations], op, nd(list_x),
+                 nd(list_idx), nd(list_idx_etype), nd(list_out))
+    return tuple(list_out)

@@ -192,7 +192,12 @@ int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla
  *   reference.  `workspace` may be NULL: scratch is then taken from the stream-ordered HIP
  *   allocator for the duration of the call.
  * dgla_scatter_add: out[idx[i], :] += feat[i, :]   (atomic; out is NOT zeroed)
- * dgla_backward_segment_cmp: out[arg[i, k], k] = feat[i, k] wherever arg[i, k] >= 0 */
+ * dgla_backward_segment_cmp: out[arg[i, k], k] = feat[i, k] wherever arg[i, k] >= 0
+ * dgla_update_grad_minmax: out[idx[i, k], k] += feat[i, k] wherever idx_type[i, k] == type —
+ *   one relation's share of the max / min gradient on a heterograph
+ *   (UpdateGradMinMax_hetero<kDGLCUDA,…>, src/array/cuda/segment_reduce.cuh:73-92,184-225):
+ *   idx = the winning node / edge ids the forward pass recorded, idx_type = the node / edge type
+ *   of every winner (-1: nothing won), both [n, dim] of idtype; out is NOT zeroed (atomic). */
 size_t dgla_segment_reduce_workspace_bytes(const char* reduce, int idtype_bits, dgla_dtype dtype,
                                            const dgla_tensor* feat, int64_t num_segments,
                                            const dgla_tensor* out);
@@ -202,6 +207,9 @@ int dgla_segment_reduce(const char* reduce, int idtype_bits, dgla_dtype dtype,
                         size_t workspace_bytes, uint32_t flags, void* hip_stream);
 int dgla_scatter_add(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat, const void* idx,
                      const dgla_tensor* out, void* hip_stream);
+int dgla_update_grad_minmax(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat,
+                            const void* idx, const void* idx_type, int64_t type,
+                            const dgla_tensor* out, void* hip_stream);
 int dgla_backward_segment_cmp(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat,
                               const void* arg, const dgla_tensor* out, void* hip_stream);
 
@@ -320,6 +328,10 @@ int dgla_partition_kway(int idtype_bits, int64_t num_nodes, const void* indptr,
  *   prefix of the per-part counts). */
 int dgla_gather_rows(int idtype_bits, const void* src, const void* idx, int64_t n,
                      int64_t row_bytes, void* dst, void* hip_stream);
+/* dst[idx[i], :] = src[i, :] (idx a permutation, or at least injective). */
+int dgla_scatter_rows(int idtype_bits, const void* src, const void* idx, int64_t n,
+                      int64_t row_bytes, void* dst, void* hip_stream);
+
 int dgla_partition_map(int idtype_bits, int mode, int num_parts, const void* range, const void* idx,
                        int64_t n, void* part_out, void* local_out, void* hip_stream);
 int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const void* range,

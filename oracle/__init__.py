@@ -39,10 +39,16 @@ def build(force=False):
 
 
 def lib():
+    """The oracle library; DGLA_ORACLE_LIB names another build of the same sources (the
+    AddressSanitizer / UBSan build of tests/test_oracle_sanitized.py)."""
     global _lib
     if _lib is None:
-        build()
-        _lib = ctypes.CDLL(_LIB_PATH)
+        alt = os.environ.get("DGLA_ORACLE_LIB")
+        if alt:
+            _lib = ctypes.CDLL(alt)
+        else:
+            build()
+            _lib = ctypes.CDLL(_LIB_PATH)
     return _lib
 
 
@@ -262,6 +268,41 @@ def copy_u_sum_csr(indptr, indices, x, nthreads=None, out=None):
         _i64(n_rows), _ptr(indptr), _ptr(indices), _ptr(x), _ptr(out), _i64(dim),
         _nthreads(nthreads))
     return out
+
+
+def llc_bytes():
+    """Last-level cache size the reference's tiling uses: sysconf(_SC_LEVEL3_CACHE_SIZE), else
+    its compile-time default of 32 MiB... (spmm_blocking_libxsmm.h:44-52)."""
+    try:
+        v = os.sysconf("SC_LEVEL3_CACHE_SIZE")
+        if v and v > 0:
+            return int(v)
+    except (ValueError, OSError):
+        pass
+    return 32 << 20
+
+
+def copy_u_sum_csr_blocked(indptr, indices, x, nthreads=None, out=None, llc=None, num_cols=None):
+    """copy_u+sum organised like the reference's libxsmm path (K-blocked, dynamic M blocks,
+    per-call re-tiling; src/array/cpu/spmm_blocking_libxsmm.h:432-557) with a plain vectorised
+    row add in place of the JIT kernel.  Column ids must ascend inside a row (the reference
+    relies on it too).  Returns ``(out, info)``, info = M/K block sizes and counts."""
+    idt = indptr.dtype
+    n_rows = indptr.shape[0] - 1
+    dim = int(np.prod(x.shape[1:]))
+    if out is None:
+        out = np.zeros((n_rows,) + x.shape[1:], dtype=x.dtype)
+    else:
+        out[...] = 0
+    info = (ctypes.c_int64 * 4)()
+    fn = getattr(lib(), "oracle_spmm_copy_u_sum_csr_blocked_" + _sfx(x.dtype, idt))
+    fn.restype = ctypes.c_int
+    rc = fn(_i64(n_rows), _i64(x.shape[0] if num_cols is None else num_cols), _ptr(indptr), _ptr(indices),
+            _ptr(x), _ptr(out), _i64(dim), _nthreads(nthreads), _i64(llc or llc_bytes()), info)
+    if rc != 0:
+        raise MemoryError("oracle_spmm_copy_u_sum_csr_blocked: scratch allocation failed")
+    return out, {"M_block": int(info[0]), "K_block": int(info[1]), "num_M_blocks": int(info[2]),
+                 "num_K_blocks": int(info[3])}
 
 
 # --------------------------------------------------------------------------- #
