@@ -29,8 +29,12 @@ def timeit(fn, reps=10, warm=3):
 
 
 h, s, i = 8, 4, 4
-for n, e in ((169_343, 2_501_829), (600_000, 15_000_000), (2_449_029, 61_859_140)):
-    for with_eids in (True, False):
+SIZES = ((169_343, 2_501_829), (600_000, 15_000_000), (2_449_029, 61_859_140))
+if len(sys.argv) > 1:  # e.g. "2" = only the largest; "2 nomap" = only without an edge-id map
+    SIZES = (SIZES[int(sys.argv[1])],)
+MAPS = (False,) if "nomap" in sys.argv else ((True,) if "map" in sys.argv else (True, False))
+for n, e in SIZES:
+    for with_eids in MAPS:
         g = synth_csr(n, n, e, "U", device=dev, with_eids=with_eids)
         csr = _capi.make_csr(g["indptr"], g["indices"], g["eids"] if with_eids else None, n)
         x = torch.rand(e, h, 1, device=dev)

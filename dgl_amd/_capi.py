@@ -335,6 +335,26 @@ def sample_neighbors(csr, seeds, fanout, replace=False, rng_seed=0):
     return indptr, src, eids
 
 
+def sample_neighbors_weighted(csr, prob, seeds, fanout, replace=False, rng_seed=0):
+    """Weighted in-neighbour sampling (dgla_sample_neighbors_weighted): `prob` is a float32 /
+    float64 tensor with one non-negative weight per EDGE ID.  Returns ``(indptr, src, eids)``;
+    edges of weight 0 never appear, so rows may hold fewer than `fanout` entries."""
+    _require_gpu(seeds)
+    _require_gpu(prob)
+    if prob.dtype not in (torch.float32, torch.float64) or prob.dim() != 1 or not prob.is_contiguous():
+        raise _lib.DGLAMDError("prob must be a contiguous 1-D float32 / float64 tensor")
+    rng_seed = int(rng_seed) & 0xFFFFFFFFFFFFFFFF
+    n = seeds.shape[0]
+    dev, dt = seeds.device, seeds.dtype
+    indptr = torch.empty(n + 1, dtype=dt, device=dev)
+    src = torch.empty(n * fanout, dtype=dt, device=dev)
+    eids = torch.empty(n * fanout, dtype=dt, device=dev)
+    check_call(LIB.dgla_sample_neighbors_weighted(
+        ctypes.byref(csr), prob.data_ptr(), _DTYPES[prob.dtype], seeds.data_ptr(), n, int(fanout),
+        1 if replace else 0, rng_seed, indptr.data_ptr(), _ptr(src), _ptr(eids), None, 0, _stream(seeds)))
+    return indptr, src, eids
+
+
 def to_block(seeds, src, node_map):
     """Block-local renumbering of `src` (dgla_to_block).  Returns ``(local_src, src_nodes,
     num_src)``; reading ``num_src`` back is the one host synchronisation of block building

@@ -127,6 +127,10 @@ LIB.dgla_sample_neighbors_workspace_bytes.argtypes = [c_int, c_int64]
 LIB.dgla_sample_neighbors.restype = c_int
 LIB.dgla_sample_neighbors.argtypes = [P(CSR), c_void_p, c_int64, c_int, c_int, ctypes.c_uint64, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+LIB.dgla_sample_neighbors_weighted.restype = c_int
+LIB.dgla_sample_neighbors_weighted.argtypes = [P(CSR), c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
+                                               ctypes.c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_size_t, c_void_p]
 LIB.dgla_to_block_workspace_bytes.restype = c_size_t
 LIB.dgla_to_block_workspace_bytes.argtypes = [c_int, c_int64]
 LIB.dgla_to_block.restype = c_int

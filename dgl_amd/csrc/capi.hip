@@ -4,6 +4,7 @@
 // dtype / idtype dispatch (reference: src/array/kernel.cc:20-44,224-248).
 #include "../../include/dgl_amd.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -423,6 +424,34 @@ int dgla_spmm_coo(const char* op_s, const char* red_s, const dgla_coo* coo, dgla
   }
   if (coo->num_cols == 0 || bc.out_len == 0) return 0;
   const DeviceGuard dev(static_cast<hipStream_t>(hip_stream), out->data);
+  if (red == kSum && std::getenv("USE_DETERMINISTIC_ALG") != nullptr && coo->nnz > 0) {
+    // The reference's USE_DETERMINISTIC_ALG (src/array/cuda/spmm.cu:33-35) asks for run-to-run
+    // identical sums.  The CSR kernels always are; the COO kernel adds with float atomics, whose
+    // order is not fixed.  Under the flag a COO sum therefore goes through the deterministic
+    // route: compress the COO by destination (stable sort, csrc/coo2csr.hip) in stream-ordered
+    // scratch and run the merge-path CSR kernel over it — edges of a row are added in COO order.
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const size_t ib = coo->idtype_bits / 8;
+    const size_t a_ptr = (ib * (coo->num_cols + 1) + 255) / 256 * 256, a_e = (ib * coo->nnz + 255) / 256 * 256;
+    char* scratch = nullptr;
+    DGLA_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&scratch), a_ptr + 2 * a_e, s));
+    int rc = dgla_coo_to_csr(coo->idtype_bits, coo->num_cols, coo->nnz, coo->col, coo->row, coo->data,
+                             scratch, scratch + a_ptr, scratch + a_ptr + a_e, nullptr, 0, hip_stream);
+    void* ws = nullptr;
+    if (rc == 0) {
+      dgla_csr csc{coo->num_cols, coo->num_rows, coo->nnz, coo->idtype_bits, scratch, scratch + a_ptr,
+                   scratch + a_ptr + a_e};
+      const size_t need = dgla_spmm_csr_workspace_bytes(op_s, red_s, &csc, dtype, ufeat, efeat, out);
+      if (need) {
+        const hipError_t e = hipMallocAsync(&ws, need, s);
+        if (e != hipSuccess) rc = fail(std::string("hipMallocAsync: ") + hipGetErrorString(e));
+      }
+      if (rc == 0) rc = dgla_spmm_csr(op_s, red_s, &csc, dtype, ufeat, efeat, out, nullptr, nullptr, ws, need, 0, hip_stream);
+    }
+    if (ws) (void)hipFreeAsync(ws, s);
+    (void)hipFreeAsync(scratch, s);
+    return rc;
+  }
   return launch_spmm_coo(v, op, red, dtype, op_uses_lhs(op) ? ufeat->data : nullptr,
                          op_uses_rhs(op) ? efeat->data : nullptr, out->data, arg_u, arg_e,
                          bc.out_len, bc.lhs_len, bc.rhs_len, bc.use_bcast, bc.dims,

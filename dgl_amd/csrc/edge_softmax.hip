@@ -167,10 +167,10 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
 // ogbn-arxiv-shaped graph: 0.53 ms for 80 MB of scores).  Here the CSR is cut by merge path
 // into units of kEsmItems items (edges + row ends) exactly like the SpMM; one wavefront per
 // unit:
-//   1. stage the unit's row ends and edge ids in LDS, then gather all its scores into LDS
-//      with independent loads (one HBM round trip for the whole unit);
-//   2. one lane per (segment, feature) reduces its segment out of LDS; a segment is a row,
-//      or the part of a row inside this unit;
+//   1. stage the unit's row ends and edge ids in LDS; every lane loads four consecutive edges of
+//      the unit with all their features into registers (one HBM round trip for the whole unit);
+//   2. per-segment max / sum through small LDS tables (a segment is a row, or the part of a row
+//      inside this unit); the values never leave the registers;
 //   3. rows that lie entirely inside the unit are finished and written (read once, written
 //      once); a row that straddles units leaves (max, sum) per part in the workspace and its
 //      edges un-normalised;
@@ -268,7 +268,23 @@ __device__ __forceinline__ void esm_lds_add(A* addr, A v) {
   (void)__hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <typename Idx, typename DT, bool BWD, bool PRECISE>
+// One wavefront per unit.  Every lane owns kEsmEpl = 4 CONSECUTIVE edges of the unit and keeps
+// all HP features of them in registers: the scores travel HBM -> registers -> HBM (for edge ids =
+// positions a lane's four rows are 4 * dim * s contiguous bytes: fully coalesced 16-byte loads
+// and stores); LDS holds only the unit's row ends, its edge ids and two small per-segment tables.
+// A segment is a row, or the part of a row inside this unit.  Lanes that share a segment meet in
+// the tables through LDS atomics (ds_max / ds_add; lanes of one wave reach them in program order,
+// so the floating-point sums are run-to-run identical):
+//   forward : pass 1 max -> tm;  pass 2 ex = exp(x - M) kept in registers, sum -> ts;
+//             pass 3 scale by 1 / S; segments cut by the unit boundary stay un-normalised and
+//             publish (M, S) for the fix-up kernel
+//   backward: pass 1 sum(sds) -> ts;  pass 2 c = sds - sum * out
+// A hub row and forty 5-edge rows cost the same (4 edges per lane either way).  The tables hold
+// kEsmSegCap segments; a unit with more row ends than that (runs of tiny rows) takes several
+// rounds over the same registers.
+constexpr int kEsmEpl = kEsmItems / 64;
+
+template <typename Idx, typename DT, bool BWD, bool PRECISE, int HP>
 __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams<Idx> p) {
   using A = typename Acc<DT>::type;
   extern __shared__ __align__(16) unsigned char esm_smem[];
@@ -281,22 +297,21 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
     blk = x * q + (x < r ? x : r) + i;
   }
   const int64_t w = static_cast<int64_t>(blk) * wpb + wib;
-  const int hp = 1 << p.log2_hp, dim = p.dim;
+  const int dim = p.dim;
   unsigned char* base = esm_smem + static_cast<size_t>(wib) * p.wave_lds_bytes;
-  A* val = reinterpret_cast<A*>(base);                               // [kEsmItems * hp]
-  A* val2 = val + (BWD ? kEsmItems * hp : 0);                        // backward: out values
-  int64_t* eid = reinterpret_cast<int64_t*>(val2 + kEsmItems * hp);  // [kEsmItems]
-  int* rend = reinterpret_cast<int*>(eid + kEsmItems);               // [kEsmItems + 2]
+  A* tm = reinterpret_cast<A*>(base);                       // [kEsmSegCap * HP]  (forward only)
+  A* ts = tm + (BWD ? 0 : kEsmSegCap * HP);                 // [kEsmSegCap * HP]
+  int64_t* eid = reinterpret_cast<int64_t*>(ts + kEsmSegCap * HP);  // [kEsmItems]
+  int* rend = reinterpret_cast<int*>(eid + kEsmItems);      // [kEsmItems + 2]
   const DT* __restrict__ pa = static_cast<const DT*>(p.a);
   const DT* __restrict__ pb = static_cast<const DT*>(p.b);
   DT* __restrict__ pc = static_cast<DT*>(p.c);
+  if (w >= p.num_units) return;  // no block-wide barrier below: a wave only touches its own slice
 
-  EsmUnit u{0, 0, 0, 0};
-  int first = 0;
-  if (w < p.num_units) {
-    u = esm_unit<Idx>(p, w);
-    // ---- stage row ends and edge ids: kEsmItems / 64 = 4 independent loads per lane issued
-    // back to back (addresses clamped, not predicated), one HBM round trip ---------------
+  const EsmUnit u = esm_unit<Idx>(p, w);
+  // ---- stage row ends and edge ids: kEsmItems / 64 = 4 independent loads per lane issued back to
+  // back (addresses clamped, not predicated), one HBM round trip ---------------------------------
+  {
     constexpr int KS = kEsmItems / 64;
     const int items = u.R + u.nE;
     if (items > 0) {
@@ -319,262 +334,233 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
           rend[it - u.nE + 1] = static_cast<int>(itemv[k]);
       }
     }
-    const int64_t f = static_cast<int64_t>(p.indptr[u.i0]) - u.j0;
-    first = f < 0 ? -1 : static_cast<int>(f);
-    if (lane == 0) rend[0] = first;
   }
-  __syncthreads();
-  if (w < p.num_units) {
-    // ---- gather the unit's values into LDS: UG loads in flight per lane ----------------
-    constexpr int UG = BWD ? 8 : 16;
-    const int total = u.nE << p.log2_hp;
-    const int h = lane & (hp - 1);  // 64 is a multiple of hp: the same feature every step
+  const int64_t f0 = static_cast<int64_t>(p.indptr[u.i0]) - u.j0;
+  const int first = f0 < 0 ? -1 : static_cast<int>(f0);
+  if (lane == 0) rend[0] = first;
+  esm_wave_sync();
+
+  // segment bounds
+  const int tail_end = (first < 0 && u.R > 0) ? rend[1] : 0;  // edges [0, tail_end) belong to a row begun earlier
+  int carry_begin = u.nE;                                      // edges [carry_begin, nE) continue in the next unit
+  {
+    const int cb = rend[u.R] < 0 ? 0 : rend[u.R];
+    if (cb < u.nE) carry_begin = cb;
+  }
+  const bool has_carry = carry_begin < u.nE;
+  if (lane == 0) p.carry_row[w] = has_carry ? u.i0 + u.R : int64_t(-1);
+  const int nseg = u.R + (has_carry ? 1 : 0);
+  auto seg_end = [&](int sg) { return sg < u.R ? rend[sg + 1] : u.nE; };  // carry segment: sg == R
+
+  // ---- load: this lane's edges [e0, e0 + 4) with all their features -----------------------------
+  const int e0 = lane * kEsmEpl;
+  A v[kEsmEpl][HP];
+  A v2[BWD ? kEsmEpl : 1][BWD ? HP : 1];  // backward: out values
+  int64_t off[kEsmEpl];
+  int seg[kEsmEpl];
+#pragma unroll
+  for (int j = 0; j < kEsmEpl; ++j) {
+    int e = e0 + j;
+    if (e >= u.nE) e = u.nE > 0 ? u.nE - 1 : 0;  // clamp: a valid row, never stored
+    off[j] = (u.nE > 0 ? eid[e] : 0) * dim;
+  }
+  if (u.nE > 0) {
     bool done = false;
-    if constexpr (std::is_same<DT, float>::value) {
-      if (p.vec4) {
-        // 16-byte pieces: 4x fewer memory instructions and 4x the bytes in flight per lane.
-        // Measured against the 4-byte path (H = 8, profiles/r1/edge_softmax_scale.jsonl): GAT size
-        // (2.5 M edges, edge-id map) forward 0.166 -> 0.152 ms, backward 0.211 -> 0.183 ms; 62 M
-        // edges with ids = positions 2.46 -> 2.10 / 3.70 -> 2.57 ms; with a random id map the
-        // 32-byte rows themselves bound the launch (5.5 ms either way).
+    if constexpr (std::is_same<DT, float>::value && HP >= 4) {
+      if (p.vec4) {  // rows are whole 16-byte pieces
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-        constexpr int UV = BWD ? 4 : 8;
-        const int qshift = p.log2_hp - 2;        // 16-byte pieces per row = hp / 4
-        const int total4 = u.nE << qshift;
-        for (int base = lane; base < total4; base += 64 * UV) {
-          f32x4 tv[UV];
-          f32x4 tv2[BWD ? UV : 1];
 #pragma unroll
-          for (int k = 0; k < UV; ++k) {
-            int idx = base + 64 * k;
-            if (idx >= total4) idx = base;
-            const int64_t off = eid[idx >> qshift] * dim + ((idx & ((1 << qshift) - 1)) << 2);
+        for (int j = 0; j < kEsmEpl; ++j)
+#pragma unroll
+          for (int q = 0; q < HP / 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>((BWD ? pb : pa) + off[j] + 4 * q);
+            v[j][4 * q] = t.x, v[j][4 * q + 1] = t.y, v[j][4 * q + 2] = t.z, v[j][4 * q + 3] = t.w;
             if constexpr (BWD) {
-              tv[k] = *reinterpret_cast<const f32x4*>(pb + off);
-              tv2[k] = *reinterpret_cast<const f32x4*>(pa + off);
-            } else {
-              tv[k] = *reinterpret_cast<const f32x4*>(pa + off);
+              const f32x4 t2 = *reinterpret_cast<const f32x4*>(pa + off[j] + 4 * q);
+              v2[j][4 * q] = t2.x, v2[j][4 * q + 1] = t2.y, v2[j][4 * q + 2] = t2.z, v2[j][4 * q + 3] = t2.w;
             }
+          }
+        done = true;
+      }
+    }
+    if (!done) {
+#pragma unroll
+      for (int j = 0; j < kEsmEpl; ++j)
+#pragma unroll
+        for (int h = 0; h < HP; ++h) {
+          const int hh = h < dim ? h : dim - 1;  // clamp: padded features load a valid element
+          v[j][h] = to_acc<DT>((BWD ? pb : pa)[off[j] + hh]);
+          if constexpr (BWD) v2[j][h] = to_acc<DT>(pa[off[j] + hh]);
+        }
+    }
+  }
+  // segment of every edge: a short search for the first, then a walk
+  {
+    int lo = 0, hi = nseg > 0 ? nseg - 1 : 0;
+    while (lo < hi) {  // smallest sg with seg_end(sg) > e0
+      const int mid = (lo + hi) >> 1;
+      if (seg_end(mid) > e0)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    int t = lo;
+#pragma unroll
+    for (int j = 0; j < kEsmEpl; ++j) {
+      const int e = e0 + j;
+      if (e < u.nE)
+        while (e >= seg_end(t)) ++t;
+      seg[j] = e < u.nE ? t : -1;
+    }
+  }
+
+  const A neg_inf = -static_cast<A>(__builtin_huge_valf());
+  for (int c0 = 0; c0 < nseg; c0 += kEsmSegCap) {
+    const int c1 = c0 + kEsmSegCap < nseg ? c0 + kEsmSegCap : nseg;
+    for (int i = lane; i < (c1 - c0) * HP; i += 64) {
+      if constexpr (!BWD) tm[i] = neg_inf;
+      ts[i] = A(0);
+    }
+    esm_wave_sync();
+    auto in_round = [&](int j) { return seg[j] >= c0 && seg[j] < c1; };
+    if constexpr (BWD) {
+      {  // pass 1: per-segment sum of sds
+        A acc[HP];
+        int cur = -1;
+#pragma unroll
+        for (int j = 0; j < kEsmEpl; ++j) {
+          if (!in_round(j)) continue;
+          if (seg[j] != cur) {
+            if (cur >= 0)
+#pragma unroll
+              for (int h = 0; h < HP; ++h) esm_lds_add(&ts[(cur - c0) * HP + h], acc[h]);
+            cur = seg[j];
+#pragma unroll
+            for (int h = 0; h < HP; ++h) acc[h] = A(0);
           }
 #pragma unroll
-          for (int k = 0; k < UV; ++k) {
-            const int idx = base + 64 * k;
-            if (idx < total4) {
-              *reinterpret_cast<f32x4*>(val + (idx << 2)) = tv[k];
-              if constexpr (BWD) *reinterpret_cast<f32x4*>(val2 + (idx << 2)) = tv2[k];
-            }
+          for (int h = 0; h < HP; ++h) acc[h] += v[j][h];
+        }
+        if (cur >= 0)
+#pragma unroll
+          for (int h = 0; h < HP; ++h) esm_lds_add(&ts[(cur - c0) * HP + h], acc[h]);
+      }
+      esm_wave_sync();
+#pragma unroll
+      for (int j = 0; j < kEsmEpl; ++j) {  // pass 2 (partial segments are rewritten by the fix-up)
+        if (!in_round(j)) continue;
+#pragma unroll
+        for (int h = 0; h < HP; ++h) v[j][h] = v[j][h] - ts[(seg[j] - c0) * HP + h] * v2[j][h];
+      }
+    } else {
+      {  // pass 1: per-segment max
+        A acc[HP];
+        int cur = -1;
+#pragma unroll
+        for (int j = 0; j < kEsmEpl; ++j) {
+          if (!in_round(j)) continue;
+          if (seg[j] != cur) {
+            if (cur >= 0)
+#pragma unroll
+              for (int h = 0; h < HP; ++h) esm_lds_max(&tm[(cur - c0) * HP + h], acc[h]);
+            cur = seg[j];
+#pragma unroll
+            for (int h = 0; h < HP; ++h) acc[h] = neg_inf;
           }
+#pragma unroll
+          for (int h = 0; h < HP; ++h) acc[h] = acc[h] > v[j][h] ? acc[h] : v[j][h];
+        }
+        if (cur >= 0)
+#pragma unroll
+          for (int h = 0; h < HP; ++h) esm_lds_max(&tm[(cur - c0) * HP + h], acc[h]);
+      }
+      esm_wave_sync();
+      {  // pass 2: ex = exp(x - M), per-segment sum
+        A acc[HP];
+        int cur = -1;
+#pragma unroll
+        for (int j = 0; j < kEsmEpl; ++j) {
+          if (!in_round(j)) continue;
+          if (seg[j] != cur) {
+            if (cur >= 0)
+#pragma unroll
+              for (int h = 0; h < HP; ++h) esm_lds_add(&ts[(cur - c0) * HP + h], acc[h]);
+            cur = seg[j];
+#pragma unroll
+            for (int h = 0; h < HP; ++h) acc[h] = A(0);
+          }
+#pragma unroll
+          for (int h = 0; h < HP; ++h) {
+            const A ex = esm_expx<A, PRECISE>(v[j][h] - tm[(cur - c0) * HP + h]);
+            v[j][h] = ex;
+            acc[h] += ex;
+          }
+        }
+        if (cur >= 0)
+#pragma unroll
+          for (int h = 0; h < HP; ++h) esm_lds_add(&ts[(cur - c0) * HP + h], acc[h]);
+      }
+      esm_wave_sync();
+#pragma unroll
+      for (int j = 0; j < kEsmEpl; ++j) {  // pass 3: normalise whole rows
+        if (!in_round(j)) continue;
+        const bool partial = (seg[j] == 0 && first < 0) || seg[j] == u.R;
+        if (partial) continue;
+#pragma unroll
+        for (int h = 0; h < HP; ++h) v[j][h] = v[j][h] * (A(1) / ts[(seg[j] - c0) * HP + h]);
+      }
+    }
+    // segments cut by the unit boundary publish their statistics for the fix-up kernel
+    if (lane < HP && lane < dim) {
+      const int h = lane;
+      if (c0 == 0 && first < 0 && u.R > 0) {  // tail of a row begun in an earlier unit
+        A* stat = static_cast<A*>(p.tail_stat) + w * 2 * dim;
+        if constexpr (BWD) {
+          stat[h] = ts[h];
+        } else {
+          stat[h] = tm[h];
+          stat[dim + h] = ts[h];
+        }
+      }
+      if (has_carry && u.R >= c0 && u.R < c1) {
+        A* stat = static_cast<A*>(p.carry_stat) + w * 2 * dim;
+        const int o = (u.R - c0) * HP + h;
+        if constexpr (BWD) {
+          stat[h] = ts[o];
+        } else {
+          stat[h] = tm[o];
+          stat[dim + h] = ts[o];
+        }
+      }
+    }
+    esm_wave_sync();
+  }
+
+  // ---- store: complete rows are final; parts of straddling rows are written un-normalised
+  // (forward) or left to the fix-up (backward) ---------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < kEsmEpl; ++j) {
+    const int e = e0 + j;
+    if (e >= u.nE) continue;
+    const bool partial = e < tail_end || e >= carry_begin;
+    if (BWD && partial) continue;
+    bool done = false;
+    if constexpr (std::is_same<DT, float>::value && HP >= 4) {
+      if (p.vec4) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int q = 0; q < HP / 4; ++q) {
+          f32x4 t;
+          t.x = v[j][4 * q], t.y = v[j][4 * q + 1], t.z = v[j][4 * q + 2], t.w = v[j][4 * q + 3];
+          *reinterpret_cast<f32x4*>(pc + off[j] + 4 * q) = t;
         }
         done = true;
       }
     }
-    if (h < dim && !done) {
-      for (int base = lane; base < total; base += 64 * UG) {
-        A tv[UG];
-        A tv2[BWD ? UG : 1];
+    if (!done) {
 #pragma unroll
-        for (int k = 0; k < UG; ++k) {
-          int idx = base + 64 * k;
-          if (idx >= total) idx = base;  // clamp: a valid element, not stored
-          const int64_t off = eid[idx >> p.log2_hp] * dim + h;
-          if constexpr (BWD) {
-            tv[k] = to_acc<DT>(pb[off]);   // sds
-            tv2[k] = to_acc<DT>(pa[off]);  // out
-          } else {
-            tv[k] = to_acc<DT>(pa[off]);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < UG; ++k) {
-          const int idx = base + 64 * k;
-          if (idx < total) {
-            val[idx] = tv[k];
-            if constexpr (BWD) val2[idx] = tv2[k];
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // segment bounds shared by the reduce and the write pass
-  const int tail_end = (first < 0 && u.R > 0) ? rend[1] : 0;          // edges [0, tail_end) belong to a row begun earlier
-  int carry_begin = u.nE;                                              // edges [carry_begin, nE) continue in the next unit
-  if (w < p.num_units) {
-    const int cb = rend[u.R] < 0 ? 0 : rend[u.R];
-    if (cb < u.nE) carry_begin = cb;
-    const bool has_carry = carry_begin < u.nE;
-    if (lane == 0) p.carry_row[w] = has_carry ? u.i0 + u.R : int64_t(-1);
-    // ---- reduce: degree-balanced -----------------------------------------------------------
-    // The 64 lanes are es = 64 / hp lane groups x hp features.  The unit's edges are dealt to the
-    // groups in equal contiguous shares; every group WALKS its share once per pass with a moving
-    // segment pointer (a segment = a row, or the part of a row inside this unit), keeping the
-    // running max / sum of the segment it is in in a register and handing it to a per-segment
-    // table in LDS when it leaves the segment.  A 200-edge row and forty 5-edge rows cost the
-    // same: nE / es steps per pass, all lanes busy.  Tables hold kEsmSegCap segments; a unit with
-    // more row ends than that (runs of tiny rows) is processed in several rounds.
-    //   forward : pass 1 max -> tm;  pass 2 ex = exp(x - M) stored back, sum -> ts;
-    //             pass 3 scale by 1 / S (segments cut by the unit boundary stay un-normalised
-    //             and publish (M, S) for the fix-up kernel)
-    //   backward: pass 1 sum(sds) -> ts;  pass 2 val = sds - sum * out
-    const int nseg = u.R + (has_carry ? 1 : 0);
-    const int h = lane & (hp - 1);
-    const int g = lane >> p.log2_hp;
-    const int es = 64 >> p.log2_hp;
-    const bool hok = h < dim;
-    A* tm = reinterpret_cast<A*>(rend + kEsmItems + 2);  // [kEsmSegCap * hp]
-    A* ts = tm + (BWD ? 0 : kEsmSegCap * hp);            // [kEsmSegCap * hp]
-    auto seg_end = [&](int sg) { return sg < u.R ? rend[sg + 1] : u.nE; };  // carry segment: sg == R
-    const A neg_inf = -static_cast<A>(__builtin_huge_valf());
-    for (int c0 = 0; c0 < nseg; c0 += kEsmSegCap) {
-      const int c1 = c0 + kEsmSegCap < nseg ? c0 + kEsmSegCap : nseg;
-      const int ea = c0 == 0 ? 0 : seg_end(c0 - 1), eb = seg_end(c1 - 1);
-      const int share = (eb - ea + es - 1) / es;
-      int e_s = ea + g * share, e_e = e_s + share;
-      if (e_s > eb) e_s = eb;
-      if (e_e > eb) e_e = eb;
-      // first segment of this group's share: smallest sg in [c0, c1) with seg_end(sg) > e_s
-      int t_first = c0;
-      {
-        int lo = c0, hi = c1 - 1;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (seg_end(mid) > e_s)
-            hi = mid;
-          else
-            lo = mid + 1;
-        }
-        t_first = lo;
-      }
-      for (int i = lane; i < (c1 - c0) * hp; i += 64) {
-        if constexpr (!BWD) tm[i] = neg_inf;
-        ts[i] = A(0);
-      }
-      esm_wave_sync();
-      if constexpr (BWD) {
-        if (hok && e_s < e_e) {
-          int t = t_first, nxt = seg_end(t);
-          A sum = A(0);
-          for (int e = e_s; e < e_e; ++e) {
-            while (e >= nxt) {
-              esm_lds_add(&ts[((t - c0) << p.log2_hp) + h], sum);
-              sum = A(0);
-              nxt = seg_end(++t);
-            }
-            sum += val[(e << p.log2_hp) + h];
-          }
-          esm_lds_add(&ts[((t - c0) << p.log2_hp) + h], sum);
-        }
-        esm_wave_sync();
-        if (hok && e_s < e_e) {
-          int t = t_first, nxt = seg_end(t);
-          for (int e = e_s; e < e_e; ++e) {
-            while (e >= nxt) nxt = seg_end(++t);
-            const int i = (e << p.log2_hp) + h;
-            val[i] = val[i] - ts[((t - c0) << p.log2_hp) + h] * val2[i];  // partial segments: rewritten by the fix-up
-          }
-        }
-      } else {
-        if (hok && e_s < e_e) {
-          int t = t_first, nxt = seg_end(t);
-          A mx = neg_inf;
-          for (int e = e_s; e < e_e; ++e) {
-            while (e >= nxt) {
-              esm_lds_max(&tm[((t - c0) << p.log2_hp) + h], mx);
-              mx = neg_inf;
-              nxt = seg_end(++t);
-            }
-            const A x = val[(e << p.log2_hp) + h];
-            mx = mx > x ? mx : x;
-          }
-          esm_lds_max(&tm[((t - c0) << p.log2_hp) + h], mx);
-        }
-        esm_wave_sync();
-        if (hok && e_s < e_e) {
-          int t = t_first, nxt = seg_end(t);
-          A M = tm[((t - c0) << p.log2_hp) + h], sum = A(0);
-          for (int e = e_s; e < e_e; ++e) {
-            while (e >= nxt) {
-              esm_lds_add(&ts[((t - c0) << p.log2_hp) + h], sum);
-              sum = A(0);
-              nxt = seg_end(++t);
-              M = tm[((t - c0) << p.log2_hp) + h];
-            }
-            const int i = (e << p.log2_hp) + h;
-            const A ex = esm_expx<A, PRECISE>(val[i] - M);
-            val[i] = ex;
-            sum += ex;
-          }
-          esm_lds_add(&ts[((t - c0) << p.log2_hp) + h], sum);
-        }
-        esm_wave_sync();
-        if (hok && e_s < e_e) {
-          int t = t_first, nxt = seg_end(t);
-          auto inv_of = [&](int sg) {
-            const bool partial = (sg == 0 && first < 0) || sg == u.R;
-            return partial ? A(1) : A(1) / ts[((sg - c0) << p.log2_hp) + h];
-          };
-          A inv = inv_of(t);
-          for (int e = e_s; e < e_e; ++e) {
-            while (e >= nxt) {
-              nxt = seg_end(++t);
-              inv = inv_of(t);
-            }
-            const int i = (e << p.log2_hp) + h;
-            val[i] = val[i] * inv;
-          }
-        }
-      }
-      // segments cut by the unit boundary publish their statistics for the fix-up kernel
-      if (hok && g == 0) {
-        if (c0 == 0 && first < 0 && u.R > 0) {  // tail of a row begun in an earlier unit
-          A* stat = static_cast<A*>(p.tail_stat) + w * 2 * dim;
-          if constexpr (BWD) {
-            stat[h] = ts[h];
-          } else {
-            stat[h] = tm[h];
-            stat[dim + h] = ts[h];
-          }
-        }
-        if (has_carry && u.R >= c0 && u.R < c1) {
-          A* stat = static_cast<A*>(p.carry_stat) + w * 2 * dim;
-          const int o = ((u.R - c0) << p.log2_hp) + h;
-          if constexpr (BWD) {
-            stat[h] = ts[o];
-          } else {
-            stat[h] = tm[o];
-            stat[dim + h] = ts[o];
-          }
-        }
-      }
-      esm_wave_sync();
-    }
-  }
-  __syncthreads();
-  if (w < p.num_units) {
-    // ---- write: complete rows are final; parts of straddling rows are written
-    // un-normalised (forward) or left to the fix-up (backward) ---------------------------
-    const int total = u.nE << p.log2_hp;
-    if constexpr (std::is_same<DT, float>::value) {
-      if (p.vec4) {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const int qshift = p.log2_hp - 2;
-        const int total4 = u.nE << qshift;
-        for (int idx = lane; idx < total4; idx += 64) {
-          const int t = idx >> qshift;
-          const bool partial = t < tail_end || t >= carry_begin;
-          if (BWD && partial) continue;
-          *reinterpret_cast<f32x4*>(pc + eid[t] * dim + ((idx & ((1 << qshift) - 1)) << 2)) =
-              *reinterpret_cast<const f32x4*>(val + (idx << 2));
-        }
-        return;
-      }
-    }
-    for (int idx = lane; idx < total; idx += 64) {
-      const int t = idx >> p.log2_hp, h = idx & (hp - 1);
-      if (h >= dim) continue;
-      const bool partial = t < tail_end || t >= carry_begin;
-      if (BWD && partial) continue;
-      pc[eid[t] * dim + h] = from_acc<DT>(val[idx]);
+      for (int h = 0; h < HP; ++h)
+        if (h < dim) pc[off[j] + h] = from_acc<DT>(v[j][h]);
     }
   }
 }
@@ -709,23 +695,11 @@ static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void*
   p.carry_stat = wsp + g.off_carry_stat;
   p.tail_stat = wsp + g.off_tail_stat;
   const int hp = 1 << g.log2_hp;
-  // values (+ out values backward), edge ids, row ends, then the segment tables of the reduce
-  // ((max | sum) forward, sum backward)
-  const size_t per_wave = sizeof(A) * kEsmItems * hp * (backward ? 2 : 1) +
-                          sizeof(int64_t) * kEsmItems + sizeof(int) * (kEsmItems + 2) + 8 +
-                          sizeof(A) * kEsmSegCap * hp * (backward ? 1 : 2);
+  // per wave: the segment tables of the reduce ((max | sum) forward, sum backward), edge ids, row ends
+  const size_t per_wave = sizeof(A) * kEsmSegCap * hp * (backward ? 1 : 2) + sizeof(int64_t) * kEsmItems +
+                          sizeof(int) * (kEsmItems + 2) + 8;
   p.wave_lds_bytes = static_cast<int>((per_wave + 15) / 16 * 16);
-  // waves per block: whatever packs most waves into a CU's 160 KB of LDS (a block gets <= 64 KB)
-  int wpb = 1, best_waves = 0;
-  for (int cand : {4, 2, 1}) {
-    const size_t blk = static_cast<size_t>(p.wave_lds_bytes) * cand;
-    if (blk > 64 * 1024) continue;
-    const int waves = static_cast<int>((160 * 1024) / blk) * cand;
-    if (waves > best_waves) {
-      best_waves = waves;
-      wpb = cand;
-    }
-  }
+  const int wpb = 4;
   if (!plan_valid) {
     const int64_t n = g.num_units + 1;
     hipLaunchKernelGGL((esm_plan_kernel<Idx>), dim3(static_cast<unsigned>((n + 255) / 256)),
@@ -735,17 +709,28 @@ static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void*
   const unsigned blocks = static_cast<unsigned>((g.num_units + wpb - 1) / wpb);
   const size_t lds = static_cast<size_t>(p.wave_lds_bytes) * wpb;
   constexpr bool kPrecise = sizeof(DT) == 8;
-  if (backward) {
-    hipLaunchKernelGGL((edge_softmax_merge_kernel<Idx, DT, true, kPrecise>), dim3(blocks),
-                       dim3(64 * wpb), lds, s, p);
-    hipLaunchKernelGGL((edge_softmax_fixup_kernel<Idx, DT, true, kPrecise>),
-                       dim3(static_cast<unsigned>(g.num_units)), dim3(64), 0, s, p);
-  } else {
-    hipLaunchKernelGGL((edge_softmax_merge_kernel<Idx, DT, false, kPrecise>), dim3(blocks),
-                       dim3(64 * wpb), lds, s, p);
-    hipLaunchKernelGGL((edge_softmax_fixup_kernel<Idx, DT, false, kPrecise>),
-                       dim3(static_cast<unsigned>(g.num_units)), dim3(64), 0, s, p);
+#define DGLA_ESM_LAUNCH(HPV)                                                                          \
+  do {                                                                                                \
+    if (backward) {                                                                                   \
+      hipLaunchKernelGGL((edge_softmax_merge_kernel<Idx, DT, true, kPrecise, HPV>), dim3(blocks),      \
+                         dim3(64 * wpb), lds, s, p);                                                  \
+      hipLaunchKernelGGL((edge_softmax_fixup_kernel<Idx, DT, true, kPrecise>),                        \
+                         dim3(static_cast<unsigned>(g.num_units)), dim3(64), 0, s, p);                \
+    } else {                                                                                          \
+      hipLaunchKernelGGL((edge_softmax_merge_kernel<Idx, DT, false, kPrecise, HPV>), dim3(blocks),     \
+                         dim3(64 * wpb), lds, s, p);                                                  \
+      hipLaunchKernelGGL((edge_softmax_fixup_kernel<Idx, DT, false, kPrecise>),                       \
+                         dim3(static_cast<unsigned>(g.num_units)), dim3(64), 0, s, p);                \
+    }                                                                                                 \
+  } while (0)
+  switch (hp) {
+    case 1: DGLA_ESM_LAUNCH(1); break;
+    case 2: DGLA_ESM_LAUNCH(2); break;
+    case 4: DGLA_ESM_LAUNCH(4); break;
+    case 8: DGLA_ESM_LAUNCH(8); break;
+    default: DGLA_ESM_LAUNCH(16); break;
   }
+#undef DGLA_ESM_LAUNCH
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
 }

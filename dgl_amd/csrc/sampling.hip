@@ -114,6 +114,145 @@ __global__ __launch_bounds__(256) void sample_pick_kernel(const Idx* __restrict_
   }
 }
 
+// ---- weighted sampling ------------------------------------------------------------------------
+// Reference: CSRRowWiseSampling<kDGLCUDA> with probabilities (src/array/cuda/rowwise_sampling_prob.cu:
+// without replacement A-Res keys u^(1/p) for every edge of a row, a segmented sort, the top
+// `num_picks` — :150-300; with replacement a per-row CDF + binary search — :305-380; picks whose
+// probability is zero are removed afterwards — :395-460).
+//
+// Here: ONE WAVEFRONT per seed row, no key array, no sort, no CDF array.
+//  * without replacement: the equivalent exponential-clock form of A-Res — key = -ln(u) / p, the
+//    `fanout` SMALLEST keys win (u^(1/p) largest <=> -ln(u)/p smallest).  u comes from the
+//    counter-based generator keyed by (seed, row, position), so a key can be RE-computed instead
+//    of stored: round t makes every lane scan its strided share of the row for the smallest key
+//    above the previous round's (key, position), an xor-shuffle argmin elects the pick.
+//    O(fanout * deg / 64) key evaluations per lane, zero scratch, picks independent of the
+//    launch geometry.  Edges with p <= 0 (or NaN) are never picked: a row yields
+//    min(fanout, #positive edges) picks, the reference's result after its removal pass.
+//  * with replacement: the row's total weight by a wave reduction, then per pick a walk over the
+//    row in chunks of 64 with a wave prefix sum until the chunk holding u * total is found.
+template <typename F>
+__device__ __forceinline__ double clock_key(uint64_t seed, uint64_t row, uint64_t pos, F p) {
+  // u in (0, 1]: 53 random bits, never 0, so that -ln(u) is finite
+  const uint64_t r = mix64(mix64(seed ^ (row * 0xD1B54A32D192ED03ull)) + 0x5851F42D4C957F2Dull * (pos + 1));
+  const double u = (static_cast<double>(r >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+  return -log(u) / static_cast<double>(p);
+}
+
+template <typename Idx, typename F>
+__global__ __launch_bounds__(256) void weighted_count_kernel(const Idx* __restrict__ indptr,
+                                                             const Idx* __restrict__ eids,
+                                                             const F* __restrict__ prob,
+                                                             const Idx* __restrict__ seeds,
+                                                             int64_t num_seeds, int fanout, int replace,
+                                                             Idx* __restrict__ counts) {
+  const int64_t i = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i > num_seeds) return;
+  if (i == num_seeds) {
+    if (lane == 0) counts[i] = 0;
+    return;
+  }
+  const int64_t r = static_cast<int64_t>(seeds[i]);
+  const int64_t start = static_cast<int64_t>(indptr[r]);
+  const int64_t deg = static_cast<int64_t>(indptr[r + 1]) - start;
+  int pos = 0;
+  for (int64_t j = lane; j < deg; j += 64) {
+    const F p = prob[eids ? static_cast<int64_t>(eids[start + j]) : start + j];
+    pos += p > F(0) ? 1 : 0;
+  }
+  for (int m = 32; m >= 1; m >>= 1) pos += __shfl_xor(pos, m, 64);
+  int64_t c = pos < fanout ? pos : fanout;
+  if (replace) c = pos == 0 ? 0 : fanout;
+  if (lane == 0) counts[i] = static_cast<Idx>(c);
+}
+
+template <typename Idx, typename F>
+__global__ __launch_bounds__(256) void weighted_pick_kernel(
+    const Idx* __restrict__ indptr, const Idx* __restrict__ indices, const Idx* __restrict__ eids,
+    const F* __restrict__ prob, const Idx* __restrict__ seeds, int64_t num_seeds, int fanout,
+    int replace, uint64_t rng_seed, const Idx* __restrict__ out_indptr, Idx* __restrict__ out_src,
+    Idx* __restrict__ out_eids) {
+  const int64_t i = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= num_seeds) return;
+  const int64_t r = static_cast<int64_t>(seeds[i]);
+  const int64_t start = static_cast<int64_t>(indptr[r]);
+  const int64_t deg = static_cast<int64_t>(indptr[r + 1]) - start;
+  const int64_t o = static_cast<int64_t>(out_indptr[i]);
+  const int picks = static_cast<int>(static_cast<int64_t>(out_indptr[i + 1]) - o);
+  if (picks == 0) return;
+  auto weight = [&](int64_t j) {
+    return prob[eids ? static_cast<int64_t>(eids[start + j]) : start + j];
+  };
+  auto emit = [&](int slot, int64_t pos) {
+    out_src[o + slot] = indices[start + pos];
+    out_eids[o + slot] = eids ? eids[start + pos] : static_cast<Idx>(start + pos);
+  };
+  const double inf = static_cast<double>(__builtin_huge_valf());
+  if (!replace) {
+    double last_key = -1.0;  // keys are >= 0
+    int64_t last_pos = -1;
+    for (int t = 0; t < picks; ++t) {
+      double best = inf;
+      int64_t best_pos = 0x7fffffffffffffffLL;
+      for (int64_t j = lane; j < deg; j += 64) {
+        const F p = weight(j);
+        if (!(p > F(0))) continue;
+        const double k = clock_key<F>(rng_seed, static_cast<uint64_t>(r), static_cast<uint64_t>(j), p);
+        const bool after = k > last_key || (k == last_key && j > last_pos);  // not picked yet
+        if (after && (k < best || (k == best && j < best_pos))) {
+          best = k;
+          best_pos = j;
+        }
+      }
+      for (int m = 32; m >= 1; m >>= 1) {
+        const double ok = __shfl_xor(best, m, 64);
+        const int64_t op = __shfl_xor(best_pos, m, 64);
+        if (ok < best || (ok == best && op < best_pos)) {
+          best = ok;
+          best_pos = op;
+        }
+      }
+      if (lane == 0) emit(t, best_pos);
+      last_key = best;
+      last_pos = best_pos;
+    }
+    return;
+  }
+  // with replacement
+  double total = 0.0;
+  for (int64_t j = lane; j < deg; j += 64) {
+    const F p = weight(j);
+    total += p > F(0) ? static_cast<double>(p) : 0.0;
+  }
+  for (int m = 32; m >= 1; m >>= 1) total += __shfl_xor(total, m, 64);
+  for (int t = 0; t < picks; ++t) {
+    const uint64_t rr = mix64(mix64(rng_seed ^ (static_cast<uint64_t>(r) * 0xD1B54A32D192ED03ull)) + 0x2545F4914F6CDD1Dull * (t + 1));
+    const double target = (static_cast<double>(rr >> 11) + 0.5) * (1.0 / 9007199254740992.0) * total;
+    double run = 0.0;       // weight of the chunks already passed
+    int64_t chosen = -1, last_positive = -1;
+    for (int64_t base = 0; base < deg && chosen < 0; base += 64) {
+      const int64_t j = base + lane;
+      const F p = j < deg ? weight(j) : F(0);
+      const double w = p > F(0) ? static_cast<double>(p) : 0.0;
+      double pre = w;  // inclusive prefix over the lanes
+      for (int m = 1; m < 64; m <<= 1) {
+        const double up = __shfl_up(pre, m, 64);
+        if (lane >= m) pre += up;
+      }
+      const bool hit = w > 0.0 && run + pre >= target;
+      const unsigned long long mask = __ballot(hit);
+      const unsigned long long posm = __ballot(w > 0.0);
+      if (posm) last_positive = base + 63 - __builtin_clzll(posm);
+      if (mask) chosen = base + (__ffsll(static_cast<long long>(mask)) - 1);
+      run += __shfl(pre, 63, 64);
+    }
+    if (chosen < 0) chosen = last_positive;  // rounding left the target past the last prefix
+    if (lane == 0) emit(t, chosen);
+  }
+}
+
 // ---- to_block -------------------------------------------------------------------------------
 template <typename Idx>
 __global__ __launch_bounds__(256) void scatter_seed_ids_kernel(const Idx* __restrict__ seeds,
@@ -221,6 +360,32 @@ int run_sample(const dgla_csr* csc, const void* seeds, int64_t num_seeds, int fa
   return 0;
 }
 
+template <typename Idx, typename F>
+int run_sample_weighted(const dgla_csr* csc, const void* prob, const void* seeds, int64_t num_seeds,
+                        int fanout, int replace, uint64_t rng_seed, void* out_indptr, void* out_src,
+                        void* out_eids, char* ws, hipStream_t s) {
+  Idx* counts = reinterpret_cast<Idx*>(ws);
+  void* temp = ws + align256(sizeof(Idx) * (num_seeds + 1));
+  size_t temp_bytes = scan_temp_bytes<Idx>(num_seeds + 1);
+  const unsigned blocks = static_cast<unsigned>((num_seeds + 1 + 3) / 4);  // 4 waves = 4 rows per block
+  hipLaunchKernelGGL((weighted_count_kernel<Idx, F>), dim3(blocks), dim3(256), 0, s,
+                     static_cast<const Idx*>(csc->indptr), static_cast<const Idx*>(csc->data),
+                     static_cast<const F*>(prob), static_cast<const Idx*>(seeds), num_seeds, fanout, replace,
+                     counts);
+  DGLA_CHECK_HIP(rocprim::exclusive_scan(temp, temp_bytes, static_cast<const Idx*>(counts),
+                                         static_cast<Idx*>(out_indptr), Idx(0),
+                                         static_cast<size_t>(num_seeds + 1), rocprim::plus<Idx>(), s));
+  if (out_src && num_seeds > 0)
+    hipLaunchKernelGGL((weighted_pick_kernel<Idx, F>), dim3(static_cast<unsigned>((num_seeds + 3) / 4)),
+                       dim3(256), 0, s, static_cast<const Idx*>(csc->indptr),
+                       static_cast<const Idx*>(csc->indices), static_cast<const Idx*>(csc->data),
+                       static_cast<const F*>(prob), static_cast<const Idx*>(seeds), num_seeds, fanout, replace,
+                       rng_seed, static_cast<const Idx*>(out_indptr), static_cast<Idx*>(out_src),
+                       static_cast<Idx*>(out_eids));
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename Idx>
 int run_to_block(const void* seeds, int64_t num_seeds, const void* src, int64_t nnz, int32_t* node_map,
                  void* local_src, void* src_nodes, int64_t* num_src_out, char* ws, hipStream_t s) {
@@ -303,6 +468,45 @@ int dgla_sample_neighbors(const dgla_csr* csc, const void* seeds, int64_t num_se
                                            out_src, out_eids, static_cast<char*>(workspace), s)
                      : run_sample<int64_t>(csc, seeds, num_seeds, fanout, replace, rng_seed, out_indptr,
                                            out_src, out_eids, static_cast<char*>(workspace), s);
+  if (owned) (void)hipFreeAsync(owned, s);
+  return rc;
+}
+
+int dgla_sample_neighbors_weighted(const dgla_csr* csc, const void* prob, dgla_dtype prob_dtype,
+                                   const void* seeds, int64_t num_seeds, int fanout, int replace,
+                                   uint64_t rng_seed, void* out_indptr, void* out_src, void* out_eids,
+                                   void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!csc || !csc->indptr) return sfail("csc is null");
+  if (csc->idtype_bits != 32 && csc->idtype_bits != 64) return sfail("idtype must be int32 or int64");
+  if (prob_dtype != DGLA_F32 && prob_dtype != DGLA_F64) return sfail("probabilities must be float32 or float64");
+  if (!prob && csc->nnz > 0) return sfail("prob is null");
+  if (num_seeds < 0) return sfail("negative number of seeds");
+  if (fanout < 1 || fanout > kMaxFanout)
+    return sfail("weighted sampling needs 1 <= fanout <= " + std::to_string(kMaxFanout));
+  if (!out_indptr) return sfail("out_indptr is null");
+  if (num_seeds > 0 && !seeds) return sfail("seeds is null");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, out_indptr);
+  const size_t need = dgla_sample_neighbors_workspace_bytes(csc->idtype_bits, num_seeds);
+  void* owned = nullptr;
+  if (!workspace || workspace_bytes < need) {
+    DGLA_CHECK_HIP(hipMallocAsync(&owned, need, s));
+    workspace = owned;
+  }
+  char* ws = static_cast<char*>(workspace);
+  int rc;
+  if (csc->idtype_bits == 32)
+    rc = prob_dtype == DGLA_F32
+             ? run_sample_weighted<int32_t, float>(csc, prob, seeds, num_seeds, fanout, replace, rng_seed,
+                                                   out_indptr, out_src, out_eids, ws, s)
+             : run_sample_weighted<int32_t, double>(csc, prob, seeds, num_seeds, fanout, replace, rng_seed,
+                                                    out_indptr, out_src, out_eids, ws, s);
+  else
+    rc = prob_dtype == DGLA_F32
+             ? run_sample_weighted<int64_t, float>(csc, prob, seeds, num_seeds, fanout, replace, rng_seed,
+                                                   out_indptr, out_src, out_eids, ws, s)
+             : run_sample_weighted<int64_t, double>(csc, prob, seeds, num_seeds, fanout, replace, rng_seed,
+                                                    out_indptr, out_src, out_eids, ws, s);
   if (owned) (void)hipFreeAsync(owned, s);
   return rc;
 }

@@ -44,8 +44,8 @@ def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, 
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     if edge_dir not in ("in", "out"):
         raise ValueError("edge_dir must be 'in' or 'out'")
-    if prob is not None:
-        raise NotImplementedError("dgl_amd.sampling: uniform sampling only")
+    if isinstance(prob, str):  # name of an edge feature, as in the reference
+        prob = g.edata[prob]
     if len(g.canonical_etypes) != 1:
         raise NotImplementedError("dgl_amd.sampling: single-relation graphs only")
     if edge_dir == "in":
@@ -55,7 +55,16 @@ def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, 
         keep = rel.csr()
         csr = _capi.make_csr(keep[0], keep[1], keep[2], rel.num_dst)
     nodes = nodes.to(device=rel.device, dtype=rel.idtype).contiguous()
-    indptr, nbr, eids = _capi.sample_neighbors(csr, nodes, int(fanout), replace, int(seed))
+    if prob is None:
+        indptr, nbr, eids = _capi.sample_neighbors(csr, nodes, int(fanout), replace, int(seed))
+    else:
+        if fanout < 0:
+            raise ValueError("weighted sampling needs a positive fanout")
+        p = prob.to(rel.device)
+        if p.dtype not in (torch.float32, torch.float64):
+            p = p.float()
+        indptr, nbr, eids = _capi.sample_neighbors_weighted(csr, p.contiguous().reshape(-1), nodes, int(fanout),
+                                                            replace, int(seed))
     n_e = int(indptr[-1])
     own = torch.repeat_interleave(nodes, (indptr[1:] - indptr[:-1]).long())
     src, dst = (nbr[:n_e].contiguous(), own) if edge_dir == "in" else (own, nbr[:n_e].contiguous())
@@ -107,10 +116,11 @@ class NeighborSampler:
     ``(input_nodes, output_nodes, blocks)``; ``blocks[i].srcdata[dgl.NID]`` /
     ``dstdata[dgl.NID]`` / ``edata[dgl.EID]`` hold the original ids."""
 
-    def __init__(self, fanouts, replace=False, seed=0):
+    def __init__(self, fanouts, replace=False, seed=0, prob=None):
         self.fanouts = [int(f) for f in fanouts]
         self.replace = bool(replace)
         self.seed = int(seed)
+        self.prob = prob  # name of an edge feature holding sampling weights (the reference's `prob`)
         self._calls = 0
 
     def sample_blocks(self, g, seed_nodes):
@@ -122,7 +132,12 @@ class NeighborSampler:
         blocks = []
         for layer, fanout in enumerate(reversed(self.fanouts)):
             rng = (self.seed * 1000003 + self._calls) * 64 + layer
-            indptr, src, eids = _capi.sample_neighbors(csr, seeds, fanout, self.replace, rng)
+            if self.prob is None:
+                indptr, src, eids = _capi.sample_neighbors(csr, seeds, fanout, self.replace, rng)
+            else:
+                p = g.edata[self.prob] if isinstance(self.prob, str) else self.prob
+                p = (p if p.dtype in (torch.float32, torch.float64) else p.float()).contiguous().reshape(-1)
+                indptr, src, eids = _capi.sample_neighbors_weighted(csr, p, seeds, fanout, self.replace, rng)
             n_e = int(indptr[-1])   # one read-back per layer (sizes the block)
             local, src_nodes, num_src = _capi.to_block(seeds, src[:n_e], node_map)
             blk = _make_block(indptr, local, num_src, seeds.shape[0], idt, dev)

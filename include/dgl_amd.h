@@ -287,7 +287,19 @@ int dgla_coo_to_csr(int idtype_bits, int64_t num_rows, int64_t nnz, const void* 
  *   int32 scratch with one entry per node of the graph, all -1 on entry and again on exit;
  *   src_nodes [>= num_seeds + nnz] receives the global id of every local source node,
  *   *num_src_out (device memory) their number. */
+ /* dgla_sample_neighbors_weighted: the same with per-edge probabilities `prob` (float32 / float64,
+ *   indexed by EDGE ID like every edge feature) — CSRRowWiseSampling<kDGLCUDA> of
+ *   src/array/cuda/rowwise_sampling_prob.cu: without replacement the A-Res rule (here in its
+ *   exponential-clock form, keys recomputed from a counter-based generator instead of stored and
+ *   sorted), with replacement inverse-CDF picks; edges with prob <= 0 are never returned, so a row
+ *   yields min(fanout, #positive edges) entries (the reference removes them after sampling).
+ *   Call with out_src == NULL first to get out_indptr when the caller does not want to
+ *   over-allocate num_seeds * fanout. */
 size_t dgla_sample_neighbors_workspace_bytes(int idtype_bits, int64_t num_seeds);
+int dgla_sample_neighbors_weighted(const dgla_csr* csc, const void* prob, dgla_dtype prob_dtype,
+                                   const void* seeds, int64_t num_seeds, int fanout, int replace,
+                                   uint64_t rng_seed, void* out_indptr, void* out_src, void* out_eids,
+                                   void* workspace, size_t workspace_bytes, void* hip_stream);
 int dgla_sample_neighbors(const dgla_csr* csc, const void* seeds, int64_t num_seeds, int fanout,
                           int replace, uint64_t rng_seed, void* out_indptr, void* out_src,
                           void* out_eids, void* workspace, size_t workspace_bytes, void* hip_stream);

@@ -355,6 +355,39 @@ def test_spmm_coo(dev, op, reduce):
                 np.testing.assert_array_equal(ae.cpu().numpy(), re_)
 
 
+def test_spmm_coo_deterministic_flag(dev, monkeypatch):
+    """USE_DETERMINISTIC_ALG (src/array/cuda/spmm.cu:33-35): under the flag a COO sum must give
+    the same bits run after run — and, being a position-ordered sum like the CSR kernel's, the
+    bits of the CSC path over the same edges."""
+    from dgl_amd import _capi
+
+    rng = np.random.default_rng(8)
+    n_src, n_dst, e, f = 500, 40, 60_000, 33          # ~1500 edges per destination: heavy atomic contention
+    src = rng.integers(0, n_src, e).astype(np.int32)
+    dst = rng.integers(0, n_dst, e).astype(np.int32)
+    x = torch.from_numpy((rng.random((n_src, f)) * 100).astype(np.float32)).to(dev)
+    w = torch.from_numpy(rng.random((e, 1)).astype(np.float32)).to(dev)
+    row, col = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
+    coo = _capi.make_coo(row, col, None, n_src, n_dst)
+    monkeypatch.setenv("USE_DETERMINISTIC_ALG", "1")
+    outs = []
+    for _ in range(4):
+        o = torch.empty(n_dst, f, device=dev)
+        _capi.spmm_coo("mul", "sum", coo, x, w, o)
+        outs.append(o)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    indptr, indices, eids = _capi.coo_to_csr(col, row, None, n_dst)
+    csr = _capi.make_csr(indptr, indices, eids, n_src)
+    ref = torch.empty(n_dst, f, device=dev)
+    ws = torch.empty(_capi.spmm_csr_workspace_bytes("mul", "sum", csr, x.dtype, x, w, ref), dtype=torch.uint8, device=dev)
+    _capi.spmm_csr("mul", "sum", csr, x, w, ref, None, None, ws)
+    assert torch.equal(outs[0], ref)
+    monkeypatch.delenv("USE_DETERMINISTIC_ALG")
+    o = torch.empty(n_dst, f, device=dev)
+    _capi.spmm_coo("mul", "sum", coo, x, w, o)              # the atomic route: same value to 1e-5
+    torch.testing.assert_close(o, ref, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("heads", [1, 4, 8])
 @pytest.mark.parametrize("merge", [False, True])
 def test_edge_softmax_fused(dev, heads, merge):

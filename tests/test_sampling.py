@@ -178,3 +178,80 @@ def test_sample_neighbors_out_direction_and_to_block(dev):
     assert torch.equal(key(got), key(want))
     with pytest.raises(ValueError, match="do not end in dst_nodes"):
         dgl.to_block(fi, seeds[:10])
+
+
+# ---- weighted sampling (dgla_sample_neighbors_weighted ≙ src/array/cuda/rowwise_sampling_prob.cu) ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
+@pytest.mark.parametrize("pdt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("replace", [False, True])
+def test_weighted_sampling_structure(dev, idt, pdt, replace):
+    from dgl_amd import _capi
+
+    rng = np.random.default_rng(4)
+    n, e, fanout = 300, 9000, 7
+    src = torch.from_numpy(rng.integers(0, n, e)).to(dev)
+    dst = torch.from_numpy(np.concatenate([rng.integers(0, n - 3, e - 700), np.full(700, n - 1)])).to(dev)
+    indptr, indices, eids = _capi.coo_to_csr(dst.to(idt), src.to(idt), None, n)
+    csr = _capi.make_csr(indptr, indices, eids, n)
+    prob = torch.from_numpy(rng.random(e)).to(dev).to(pdt)
+    prob[torch.from_numpy(rng.random(e) < 0.3).to(dev)] = 0            # 30 % of the edges can never be picked
+    prob[(dst == 5)] = 0                                             # a row without any positive edge
+    seeds = torch.arange(n, device=dev, dtype=idt)
+    ip, s_out, e_out = _capi.sample_neighbors_weighted(csr, prob, seeds, fanout, replace, rng_seed=11)
+    ip2, s2, e2 = _capi.sample_neighbors_weighted(csr, prob, seeds, fanout, replace, rng_seed=11)
+    cnt = int(ip[-1])
+    assert torch.equal(ip, ip2) and torch.equal(e_out[:cnt], e2[:cnt])   # reproducible from the seed
+    ip3, _, e3 = _capi.sample_neighbors_weighted(csr, prob, seeds, fanout, replace, rng_seed=12)
+    assert not torch.equal(e_out[:cnt], e3[:int(ip3[-1])]) or cnt == 0
+    ip_h, e_h, s_h = ip.cpu().numpy(), e_out.cpu().numpy(), s_out.cpu().numpy()
+    p_h, src_h, dst_h = prob.cpu().numpy(), src.cpu().numpy(), dst.cpu().numpy()
+    for r in range(n):
+        picked = e_h[ip_h[r]: ip_h[r + 1]]
+        pos = int(((dst_h == r) & (p_h > 0)).sum())
+        assert len(picked) == ((fanout if pos else 0) if replace else min(fanout, pos)), r
+        assert np.all(dst_h[picked] == r) and np.all(p_h[picked] > 0)
+        assert np.array_equal(src_h[picked], s_h[ip_h[r]: ip_h[r + 1]])
+        if not replace:
+            assert len(set(picked.tolist())) == len(picked)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("replace", [False, True])
+def test_weighted_sampling_follows_the_weights(dev, replace):
+    """fanout = 1: P(edge) = w / sum(w), with or without replacement.  4000 independent rows with
+    the same five weights; the empirical frequencies must match to ~3 sigma."""
+    from dgl_amd import _capi
+
+    w = np.array([0.5, 0.0, 2.0, 1.0, 4.5])
+    rows = 4000
+    indptr = torch.arange(0, 5 * rows + 1, 5, dtype=torch.int64, device=dev)
+    indices = torch.arange(5, device=dev).repeat(rows)
+    csr = _capi.make_csr(indptr, indices, None, 5)
+    prob = torch.from_numpy(np.tile(w, rows)).to(dev)
+    seeds = torch.arange(rows, device=dev)
+    ip, s_out, _ = _capi.sample_neighbors_weighted(csr, prob, seeds, 1, replace, rng_seed=99)
+    assert int(ip[-1]) == rows
+    freq = np.bincount(s_out[:rows].cpu().numpy(), minlength=5) / rows
+    want = w / w.sum()
+    sigma = np.sqrt(want * (1 - want) / rows)
+    assert np.all(np.abs(freq - want) <= 4 * sigma + 1e-12), (freq, want)
+    # without replacement, fanout 2: the pair {4, 2} is the most likely, and weight-0 never shows
+    ip, s_out, _ = _capi.sample_neighbors_weighted(csr, prob, seeds, 2, False, rng_seed=5)
+    pairs = s_out[: 2 * rows].cpu().numpy().reshape(rows, 2)
+    assert not np.any(pairs == 1)
+    first = np.bincount(pairs[:, 0], minlength=5) / rows     # the first pick is the smallest key: ~ w / sum(w)
+    assert np.all(np.abs(first - want) <= 4 * sigma + 1e-12)
+
+
+@pytest.mark.gpu
+def test_sample_neighbors_api_with_prob(dev):
+    import dgl_amd as dgl
+
+    g = dgl.graph((torch.tensor([0, 1, 2, 3, 4, 5]), torch.tensor([6, 6, 6, 6, 6, 6])), num_nodes=7, device=dev)
+    g.edata["w"] = torch.tensor([0., 0., 1., 0., 2., 0.], device=dev)
+    sub = dgl.sampling.sample_neighbors(g, torch.tensor([6], device=dev), 4, prob="w", seed=3)
+    assert sorted(sub.edata[dgl.EID].tolist()) == [2, 4]       # only the positive-weight edges exist
+    sampler = dgl.NeighborSampler([3], prob="w")
+    _, _, blocks = sampler.sample_blocks(g, torch.tensor([6], device=dev))
+    assert sorted(blocks[0].edata[dgl.EID].tolist()) == [2, 4]
