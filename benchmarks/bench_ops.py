@@ -40,10 +40,28 @@ def timeit(fn, reps=10, warm=3):
     return float(np.median(ts)), float(np.min(ts))
 
 
-def emit(cfg, op, e, ms, ms_min, nbytes, **kw):
+CACHE_BYTES = 256 << 20  # Infinity Cache: gathered operands smaller than this are served on-die
+
+
+def emit(cfg, op, e, ms, ms_min, nbytes, gathered_bytes=None, compulsory_bytes=None, **kw):
+    """`nbytes` = the no-reuse gather model of SURVEY.md §8d.  That model is roofline evidence only
+    when the gathered operand cannot live in the caches: pass `gathered_bytes` (size of the tensor
+    rows are gathered from) and `compulsory_bytes` (every byte once) and the line says which
+    figure to read — for a cache-resident operand the gather-model fraction exceeds 1 and means
+    nothing about HBM (Weak #8)."""
     r = {"config": cfg, "op": op, "edges": e, "ms_median": round(ms, 4), "ms_min": round(ms_min, 4),
          "edges_per_s": e / (ms * 1e-3), "alg_bytes": nbytes,
          "achieved_GBps": nbytes / (ms * 1e-3) / 1e9, "frac_of_8TBps": nbytes / (ms * 1e-3) / 1e9 / PEAK}
+    if gathered_bytes is not None:
+        resident = gathered_bytes <= CACHE_BYTES
+        r["gathered_operand_MB"] = round(gathered_bytes / 1e6, 1)
+        r["hbm_roofline_evidence"] = not resident
+        if compulsory_bytes is not None:
+            r["compulsory_bytes"] = compulsory_bytes
+            r["compulsory_frac_of_8TBps"] = compulsory_bytes / (ms * 1e-3) / 1e9 / PEAK
+        if resident:
+            r["note"] = ("gathered operand fits the 256 MiB Infinity Cache: frac_of_8TBps is the no-reuse "
+                         "model and NOT an HBM figure; compulsory_frac_of_8TBps is the HBM-side bound")
     r.update(kw)
     print(json.dumps(r), flush=True)
 
@@ -88,7 +106,14 @@ def run_spmm(cfg, name, g, op, red, u, w, fo, dev, eid=False):
                 extra["parity_arg_u_bit_exact"] = bool(np.array_equal(au.cpu().numpy().reshape(ru.shape), ru))
             if re_ is not None:
                 extra["parity_arg_e_bit_exact"] = bool(np.array_equal(ae.cpu().numpy().reshape(re_.shape), re_))
-    emit(cfg, name, g["nnz"], ms, mn, nb, dtype=str(out.dtype), idtype=str(idt), **extra)
+    # the operand rows are gathered from, and every byte of the problem touched once
+    gathered = None if u is None else u.numel() * u.element_size()
+    es = out.element_size()
+    ib = 4 if idt == torch.int32 else 8
+    compulsory = out.numel() * es + (0 if u is None else u.numel() * es) + (0 if w is None else w.numel() * es) + \
+        g["nnz"] * ib * (2 if eid else 1) + (n + 1) * ib
+    emit(cfg, name, g["nnz"], ms, mn, nb, gathered_bytes=gathered, compulsory_bytes=compulsory,
+         dtype=str(out.dtype), idtype=str(idt), **extra)
     return out
 
 
@@ -146,7 +171,8 @@ def c2(dev, args):
     coo = _capi.make_coo(row, col, None, n, n)
     oe = torch.empty(e, 1, device=dev)
     ms, mn = timeit(lambda: _capi.sddmm_coo("dot", coo, x, x, oe, 0, 2), reps=5)
-    emit("C2", "sddmm u_dot_v (D=100)", e, ms, mn, e * (2 * f * 4 + 4 + 8))
+    emit("C2", "sddmm u_dot_v (D=100)", e, ms, mn, e * (2 * f * 4 + 4 + 8), gathered_bytes=n * f * 4,
+         compulsory_bytes=2 * n * f * 4 + e * (4 + 8))
     del oe
     if args.big:
         of = torch.empty(e, f, device=dev)
@@ -181,7 +207,8 @@ def c3(dev, args):
             ms, mn = timeit(lambda: _capi.sddmm_coo("add", coo, el, er, out, 0, 2))
             emit("C3", "sddmm u_add_v (H=8)", e, ms, mn, e * (3 * h * s + 3 * i))
         ms, mn = timeit(lambda: _capi.sddmm_coo("dot", coo, ft, ft, out, 0, 2))
-        emit("C3", "sddmm u_dot_v (H=8,D=%d)" % d, e, ms, mn, e * (2 * h * d * s + h * s + 3 * i))
+        emit("C3", "sddmm u_dot_v (H=8,D=%d)" % d, e, ms, mn, e * (2 * h * d * s + h * s + 3 * i),
+             gathered_bytes=n * h * d * s, compulsory_bytes=2 * n * h * d * s + e * (h * s + 3 * i))
         if d == 8:
             csr = _capi.make_csr(g["indptr"], g["indices"], g["eids"], n)
             a = torch.empty_like(out)

@@ -238,6 +238,18 @@ __device__ __forceinline__ EsmUnit esm_unit(const EsmParams<Idx>& p, int64_t w) 
   return u;
 }
 
+// 1 / x: hardware reciprocal + one Newton step for fp32 (< 1 ulp off the division), a division
+// for fp64
+template <typename A>
+__device__ __forceinline__ A esm_recip(A x) {
+  if constexpr (sizeof(A) == 4) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+  } else {
+    return A(1) / x;
+  }
+}
+
 template <typename A, bool PRECISE>
 __device__ __forceinline__ A esm_expx(A x) {
   if constexpr (PRECISE)
@@ -246,7 +258,7 @@ __device__ __forceinline__ A esm_expx(A x) {
     return esm_exp<A>(x);
 }
 
-// Segments (rows or row parts) whose statistics one round of the balanced reduce keeps in LDS.
+// Rows of the LDS tables holding the totals of lane-crossing segments: one per lane of the wave.
 constexpr int kEsmSegCap = 64;
 
 // Orders one wave's LDS traffic between the passes of the reduce.  Each wave works on its own
@@ -257,32 +269,28 @@ __device__ __forceinline__ void esm_wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// LDS atomics (ds_max_f32 / ds_add_f32 and the f64 forms).  Lanes of one wave reach them in
-// program order, so the order of the additions is fixed: results are run-to-run identical.
-template <typename A>
-__device__ __forceinline__ void esm_lds_max(A* addr, A v) {
-  (void)__hip_atomic_fetch_max(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-template <typename A>
-__device__ __forceinline__ void esm_lds_add(A* addr, A v) {
-  (void)__hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // One wavefront per unit.  Every lane owns kEsmEpl = 4 CONSECUTIVE edges of the unit and keeps
 // all HP features of them in registers: the scores travel HBM -> registers -> HBM (for edge ids =
-// positions a lane's four rows are 4 * dim * s contiguous bytes: fully coalesced 16-byte loads
-// and stores); LDS holds only the unit's row ends, its edge ids and two small per-segment tables.
-// A segment is a row, or the part of a row inside this unit.  Lanes that share a segment meet in
-// the tables through LDS atomics (ds_max / ds_add; lanes of one wave reach them in program order,
-// so the floating-point sums are run-to-run identical):
-//   forward : pass 1 max -> tm;  pass 2 ex = exp(x - M) kept in registers, sum -> ts;
-//             pass 3 scale by 1 / S; segments cut by the unit boundary stay un-normalised and
-//             publish (M, S) for the fix-up kernel
-//   backward: pass 1 sum(sds) -> ts;  pass 2 c = sds - sum * out
-// A hub row and forty 5-edge rows cost the same (4 edges per lane either way).  The tables hold
-// kEsmSegCap segments; a unit with more row ends than that (runs of tiny rows) takes several
-// rounds over the same registers.
+// positions a lane's four rows are 4 * dim * s contiguous bytes: 16-byte loads and stores); LDS
+// holds only the unit's row ends, its edge ids and two 64-row tables.
+//
+// A segment is a row, or the part of a row inside this unit.  A lane's edges are consecutive, so
+// its segments are: possibly one that began in an earlier lane (its "head"), segments lying wholly
+// inside the lane ("local"), possibly one that goes on into later lanes (its "tail"; head == tail
+// when the whole lane sits inside one long row).  Local segments are reduced in registers with one
+// forward and one backward sweep over the four edges.  Crossing segments are reduced ACROSS lanes
+// with a segmented inclusive shuffle scan over (tail-starts-here flag, tail partial) — 6 steps for
+// any mix of row lengths — after which the lane where a crossing segment ENDS holds its total and
+// leaves it in the table row of the lane the segment STARTED in (unique: at most one segment
+// crosses out of a lane).  Everybody then reads the totals it needs.
+//   forward : max -> exp(x - M) -> sum -> scale by 1 / S; segments cut by the unit boundary only
+//             publish (M, S): the fix-up kernel, which sees all parts of the row, writes their edges
+//   backward: sum(sds) -> c = sds - sum * out
+// A hub row and forty 5-edge rows cost the same.  (The first version of this kernel combined
+// lanes through ds_max / ds_add atomics on the tables and spent half of its cycles in LDS issue
+// stalls — 64 lanes on a handful of addresses serialise: profiles/r2/softmax_pmc_atomics.txt.)
 constexpr int kEsmEpl = kEsmItems / 64;
+static_assert(kEsmEpl == 4, "the sweeps below are written out for four edges per lane");
 
 template <typename Idx, typename DT, bool BWD, bool PRECISE, int HP>
 __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams<Idx> p) {
@@ -299,8 +307,8 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
   const int64_t w = static_cast<int64_t>(blk) * wpb + wib;
   const int dim = p.dim;
   unsigned char* base = esm_smem + static_cast<size_t>(wib) * p.wave_lds_bytes;
-  A* tm = reinterpret_cast<A*>(base);                       // [kEsmSegCap * HP]  (forward only)
-  A* ts = tm + (BWD ? 0 : kEsmSegCap * HP);                 // [kEsmSegCap * HP]
+  A* tm = reinterpret_cast<A*>(base);                       // [64 * HP]  (forward only)
+  A* ts = tm + (BWD ? 0 : kEsmSegCap * HP);                 // [64 * HP]
   int64_t* eid = reinterpret_cast<int64_t*>(ts + kEsmSegCap * HP);  // [kEsmItems]
   int* rend = reinterpret_cast<int*>(eid + kEsmItems);      // [kEsmItems + 2]
   const DT* __restrict__ pa = static_cast<const DT*>(p.a);
@@ -309,8 +317,54 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
   if (w >= p.num_units) return;  // no block-wide barrier below: a wave only touches its own slice
 
   const EsmUnit u = esm_unit<Idx>(p, w);
-  // ---- stage row ends and edge ids: kEsmItems / 64 = 4 independent loads per lane issued back to
-  // back (addresses clamped, not predicated), one HBM round trip ---------------------------------
+  const int e0 = lane * kEsmEpl;
+  const int n_valid = u.nE - e0 < kEsmEpl ? (u.nE - e0 > 0 ? u.nE - e0 : 0) : kEsmEpl;
+  A v[kEsmEpl][HP];
+  A v2[BWD ? kEsmEpl : 1][BWD ? HP : 1];  // backward: out values
+  int64_t off[kEsmEpl];
+
+  // this lane's edges with all their features (edges past the unit's end re-load the last one)
+#define DGLA_ESM_LOAD()                                                                              \
+  if (u.nE > 0) {                                                                                     \
+    bool done = false;                                                                                \
+    if constexpr (std::is_same<DT, float>::value && HP >= 4) {                                        \
+      if (p.vec4) { /* rows are whole 16-byte pieces */                                               \
+        typedef float f32x4 __attribute__((ext_vector_type(4)));                                      \
+        _Pragma("unroll") for (int j = 0; j < kEsmEpl; ++j)                                           \
+          _Pragma("unroll") for (int q = 0; q < HP / 4; ++q) {                                        \
+            const f32x4 t = *reinterpret_cast<const f32x4*>((BWD ? pb : pa) + off[j] + 4 * q);        \
+            v[j][4 * q] = t.x, v[j][4 * q + 1] = t.y, v[j][4 * q + 2] = t.z, v[j][4 * q + 3] = t.w;   \
+            if constexpr (BWD) {                                                                      \
+              const f32x4 t2 = *reinterpret_cast<const f32x4*>(pa + off[j] + 4 * q);                  \
+              v2[j][4 * q] = t2.x, v2[j][4 * q + 1] = t2.y, v2[j][4 * q + 2] = t2.z,                  \
+              v2[j][4 * q + 3] = t2.w;                                                                \
+            }                                                                                         \
+          }                                                                                           \
+        done = true;                                                                                  \
+      }                                                                                               \
+    }                                                                                                 \
+    if (!done) {                                                                                      \
+      _Pragma("unroll") for (int j = 0; j < kEsmEpl; ++j)                                             \
+        _Pragma("unroll") for (int h = 0; h < HP; ++h) {                                              \
+          const int hh = h < dim ? h : dim - 1; /* padded features load a valid element */           \
+          v[j][h] = to_acc<DT>((BWD ? pb : pa)[off[j] + hh]);                                         \
+          if constexpr (BWD) v2[j][h] = to_acc<DT>(pa[off[j] + hh]);                                  \
+        }                                                                                             \
+    }                                                                                                 \
+  }
+
+  const bool direct = p.eids == nullptr;  // edge id == position: addresses need no staging
+  if (direct) {
+#pragma unroll
+    for (int j = 0; j < kEsmEpl; ++j) {
+      int e = e0 + j;
+      if (e >= u.nE) e = u.nE > 0 ? u.nE - 1 : 0;
+      off[j] = (u.j0 + e) * dim;
+    }
+    DGLA_ESM_LOAD()  // in flight together with the index loads below: one HBM round trip per unit
+  }
+  // ---- stage row ends (and edge ids): 4 independent loads per lane issued back to back
+  // (addresses clamped, not predicated) ----------------------------------------------------------
   {
     constexpr int KS = kEsmItems / 64;
     const int items = u.R + u.nE;
@@ -339,6 +393,16 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
   const int first = f0 < 0 ? -1 : static_cast<int>(f0);
   if (lane == 0) rend[0] = first;
   esm_wave_sync();
+  if (!direct) {
+#pragma unroll
+    for (int j = 0; j < kEsmEpl; ++j) {
+      int e = e0 + j;
+      if (e >= u.nE) e = u.nE > 0 ? u.nE - 1 : 0;
+      off[j] = (u.nE > 0 ? eid[e] : 0) * dim;
+    }
+    DGLA_ESM_LOAD()
+  }
+#undef DGLA_ESM_LOAD
 
   // segment bounds
   const int tail_end = (first < 0 && u.R > 0) ? rend[1] : 0;  // edges [0, tail_end) belong to a row begun earlier
@@ -351,50 +415,10 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
   if (lane == 0) p.carry_row[w] = has_carry ? u.i0 + u.R : int64_t(-1);
   const int nseg = u.R + (has_carry ? 1 : 0);
   auto seg_end = [&](int sg) { return sg < u.R ? rend[sg + 1] : u.nE; };  // carry segment: sg == R
+  auto seg_start = [&](int sg) { return sg == 0 ? 0 : rend[sg]; };        // = seg_end(sg - 1)
 
-  // ---- load: this lane's edges [e0, e0 + 4) with all their features -----------------------------
-  const int e0 = lane * kEsmEpl;
-  A v[kEsmEpl][HP];
-  A v2[BWD ? kEsmEpl : 1][BWD ? HP : 1];  // backward: out values
-  int64_t off[kEsmEpl];
-  int seg[kEsmEpl];
-#pragma unroll
-  for (int j = 0; j < kEsmEpl; ++j) {
-    int e = e0 + j;
-    if (e >= u.nE) e = u.nE > 0 ? u.nE - 1 : 0;  // clamp: a valid row, never stored
-    off[j] = (u.nE > 0 ? eid[e] : 0) * dim;
-  }
-  if (u.nE > 0) {
-    bool done = false;
-    if constexpr (std::is_same<DT, float>::value && HP >= 4) {
-      if (p.vec4) {  // rows are whole 16-byte pieces
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int j = 0; j < kEsmEpl; ++j)
-#pragma unroll
-          for (int q = 0; q < HP / 4; ++q) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>((BWD ? pb : pa) + off[j] + 4 * q);
-            v[j][4 * q] = t.x, v[j][4 * q + 1] = t.y, v[j][4 * q + 2] = t.z, v[j][4 * q + 3] = t.w;
-            if constexpr (BWD) {
-              const f32x4 t2 = *reinterpret_cast<const f32x4*>(pa + off[j] + 4 * q);
-              v2[j][4 * q] = t2.x, v2[j][4 * q + 1] = t2.y, v2[j][4 * q + 2] = t2.z, v2[j][4 * q + 3] = t2.w;
-            }
-          }
-        done = true;
-      }
-    }
-    if (!done) {
-#pragma unroll
-      for (int j = 0; j < kEsmEpl; ++j)
-#pragma unroll
-        for (int h = 0; h < HP; ++h) {
-          const int hh = h < dim ? h : dim - 1;  // clamp: padded features load a valid element
-          v[j][h] = to_acc<DT>((BWD ? pb : pa)[off[j] + hh]);
-          if constexpr (BWD) v2[j][h] = to_acc<DT>(pa[off[j] + hh]);
-        }
-    }
-  }
   // segment of every edge: a short search for the first, then a walk
+  int seg[kEsmEpl];
   {
     int lo = 0, hi = nseg > 0 ? nseg - 1 : 0;
     while (lo < hi) {  // smallest sg with seg_end(sg) > e0
@@ -413,137 +437,155 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
       seg[j] = e < u.nE ? t : -1;
     }
   }
+  const int sA = n_valid ? seg[0] : -1;
+  const bool a_starts_here = n_valid && seg_start(sA) >= e0;
+  const bool a_ends_here = n_valid && seg_end(sA) <= e0 + n_valid;
+  const bool a_local = a_starts_here && a_ends_here;
+  const int slot_a = n_valid ? seg_start(sA) / kEsmEpl : 0;  // table row of the head segment
+  // per edge: continues the previous edge's segment / is in the head segment / is in a segment
+  // that crosses out of the lane (then it is the lane's tail segment, whose table row is this lane)
+  bool same[kEsmEpl], in_head[kEsmEpl], local[kEsmEpl];
+  int sZ = -1;
+  bool z_starts_here = false, z_local = false;
+  same[0] = false;
+#pragma unroll
+  for (int j = 0; j < kEsmEpl; ++j) {
+    const bool ok = j < n_valid;
+    if (j > 0) same[j] = seg[j] == seg[j - 1];
+    in_head[j] = ok && seg[j] == sA;
+    const bool lc = ok && seg_start(seg[j]) >= e0 && seg_end(seg[j]) <= e0 + n_valid;
+    local[j] = lc;
+    if (j + 1 == n_valid) {
+      sZ = seg[j];
+      z_starts_here = seg_start(seg[j]) >= e0;
+      z_local = lc;
+    }
+  }
+  const int slot_z = z_starts_here ? lane : slot_a;  // a tail that came in from earlier lanes IS the head
+  (void)sZ;
 
+  // value of the lane's LAST valid edge (n_valid is 4 except in the unit's last lane) — a select
+  // chain over scalars: selecting between ARRAY elements would push the array into scratch memory
+  auto last_of = [&](A a0, A a1, A a2, A a3) {
+    return n_valid >= 4 ? a3 : (n_valid == 3 ? a2 : (n_valid == 2 ? a1 : a0));
+  };
+  // ghead[h] / glast[h] = OP over the edges of the lane's head / tail segment; APPLY(j, h, b) runs
+  // for every edge with b = OP over the lane's edges in the same segment
+#define DGLA_ESM_GROUPS(OP, APPLY)                                                  \
+  _Pragma("unroll") for (int h = 0; h < HP; ++h) {                                  \
+    const A f0 = v[0][h];                                                           \
+    const A f1 = same[1] ? OP(f0, v[1][h]) : v[1][h];                                \
+    const A f2 = same[2] ? OP(f1, v[2][h]) : v[2][h];                                \
+    const A f3 = same[3] ? OP(f2, v[3][h]) : v[3][h];                                \
+    const A b3 = f3;                                                                \
+    const A b2 = same[3] ? b3 : f2;                                                 \
+    const A b1 = same[2] ? b2 : f1;                                                 \
+    const A b0 = same[1] ? b1 : f0;                                                 \
+    ghead[h] = b0;                                                                  \
+    glast[h] = last_of(b0, b1, b2, b3);                                              \
+    APPLY(0, h, b0) APPLY(1, h, b1) APPLY(2, h, b2) APPLY(3, h, b3)                  \
+  }
+  // Segmented inclusive scan over the lanes of x = the lane's tail partial, f = "the tail segment
+  // starts in this lane"; afterwards the previous lane's scanned value = everything of this
+  // lane's head segment that lies in earlier lanes, and the lane where a crossing segment ends
+  // writes its total to TABLE[start lane].
+#define DGLA_ESM_PUBLISH(TABLE, IDENT, OP)                                                        \
+  {                                                                                                \
+    A x[HP];                                                                                       \
+    _Pragma("unroll") for (int h = 0; h < HP; ++h) x[h] = n_valid ? glast[h] : (IDENT);             \
+    int f = (!n_valid || z_starts_here) ? 1 : 0;                                                    \
+    _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) {                                            \
+      const int fp = __shfl_up(f, d, 64);                                                           \
+      _Pragma("unroll") for (int h = 0; h < HP; ++h) {                                              \
+        const A xp = __shfl_up(x[h], d, 64);                                                        \
+        if (lane >= d && !f) x[h] = OP(x[h], xp);                                                   \
+      }                                                                                             \
+      if (lane >= d) f |= fp;                                                                       \
+    }                                                                                               \
+    const bool writes = n_valid && !a_starts_here && a_ends_here;                                   \
+    _Pragma("unroll") for (int h = 0; h < HP; ++h) {                                                \
+      const A t = __shfl_up(x[h], 1, 64);                                                           \
+      if (writes) (TABLE)[slot_a * HP + h] = OP(lane > 0 ? t : (IDENT), ghead[h]);                  \
+    }                                                                                               \
+  }
   const A neg_inf = -static_cast<A>(__builtin_huge_valf());
-  for (int c0 = 0; c0 < nseg; c0 += kEsmSegCap) {
-    const int c1 = c0 + kEsmSegCap < nseg ? c0 + kEsmSegCap : nseg;
-    for (int i = lane; i < (c1 - c0) * HP; i += 64) {
-      if constexpr (!BWD) tm[i] = neg_inf;
-      ts[i] = A(0);
-    }
-    esm_wave_sync();
-    auto in_round = [&](int j) { return seg[j] >= c0 && seg[j] < c1; };
-    if constexpr (BWD) {
-      {  // pass 1: per-segment sum of sds
-        A acc[HP];
-        int cur = -1;
-#pragma unroll
-        for (int j = 0; j < kEsmEpl; ++j) {
-          if (!in_round(j)) continue;
-          if (seg[j] != cur) {
-            if (cur >= 0)
-#pragma unroll
-              for (int h = 0; h < HP; ++h) esm_lds_add(&ts[(cur - c0) * HP + h], acc[h]);
-            cur = seg[j];
-#pragma unroll
-            for (int h = 0; h < HP; ++h) acc[h] = A(0);
-          }
-#pragma unroll
-          for (int h = 0; h < HP; ++h) acc[h] += v[j][h];
-        }
-        if (cur >= 0)
-#pragma unroll
-          for (int h = 0; h < HP; ++h) esm_lds_add(&ts[(cur - c0) * HP + h], acc[h]);
-      }
-      esm_wave_sync();
-#pragma unroll
-      for (int j = 0; j < kEsmEpl; ++j) {  // pass 2 (partial segments are rewritten by the fix-up)
-        if (!in_round(j)) continue;
-#pragma unroll
-        for (int h = 0; h < HP; ++h) v[j][h] = v[j][h] - ts[(seg[j] - c0) * HP + h] * v2[j][h];
-      }
-    } else {
-      {  // pass 1: per-segment max
-        A acc[HP];
-        int cur = -1;
-#pragma unroll
-        for (int j = 0; j < kEsmEpl; ++j) {
-          if (!in_round(j)) continue;
-          if (seg[j] != cur) {
-            if (cur >= 0)
-#pragma unroll
-              for (int h = 0; h < HP; ++h) esm_lds_max(&tm[(cur - c0) * HP + h], acc[h]);
-            cur = seg[j];
-#pragma unroll
-            for (int h = 0; h < HP; ++h) acc[h] = neg_inf;
-          }
-#pragma unroll
-          for (int h = 0; h < HP; ++h) acc[h] = acc[h] > v[j][h] ? acc[h] : v[j][h];
-        }
-        if (cur >= 0)
-#pragma unroll
-          for (int h = 0; h < HP; ++h) esm_lds_max(&tm[(cur - c0) * HP + h], acc[h]);
-      }
-      esm_wave_sync();
-      {  // pass 2: ex = exp(x - M), per-segment sum
-        A acc[HP];
-        int cur = -1;
-#pragma unroll
-        for (int j = 0; j < kEsmEpl; ++j) {
-          if (!in_round(j)) continue;
-          if (seg[j] != cur) {
-            if (cur >= 0)
-#pragma unroll
-              for (int h = 0; h < HP; ++h) esm_lds_add(&ts[(cur - c0) * HP + h], acc[h]);
-            cur = seg[j];
-#pragma unroll
-            for (int h = 0; h < HP; ++h) acc[h] = A(0);
-          }
-#pragma unroll
-          for (int h = 0; h < HP; ++h) {
-            const A ex = esm_expx<A, PRECISE>(v[j][h] - tm[(cur - c0) * HP + h]);
-            v[j][h] = ex;
-            acc[h] += ex;
-          }
-        }
-        if (cur >= 0)
-#pragma unroll
-          for (int h = 0; h < HP; ++h) esm_lds_add(&ts[(cur - c0) * HP + h], acc[h]);
-      }
-      esm_wave_sync();
-#pragma unroll
-      for (int j = 0; j < kEsmEpl; ++j) {  // pass 3: normalise whole rows
-        if (!in_round(j)) continue;
-        const bool partial = (seg[j] == 0 && first < 0) || seg[j] == u.R;
-        if (partial) continue;
-#pragma unroll
-        for (int h = 0; h < HP; ++h) v[j][h] = v[j][h] * (A(1) / ts[(seg[j] - c0) * HP + h]);
-      }
-    }
-    // segments cut by the unit boundary publish their statistics for the fix-up kernel
-    if (lane < HP && lane < dim) {
-      const int h = lane;
-      if (c0 == 0 && first < 0 && u.R > 0) {  // tail of a row begun in an earlier unit
-        A* stat = static_cast<A*>(p.tail_stat) + w * 2 * dim;
-        if constexpr (BWD) {
-          stat[h] = ts[h];
-        } else {
-          stat[h] = tm[h];
-          stat[dim + h] = ts[h];
-        }
-      }
-      if (has_carry && u.R >= c0 && u.R < c1) {
-        A* stat = static_cast<A*>(p.carry_stat) + w * 2 * dim;
-        const int o = (u.R - c0) * HP + h;
-        if constexpr (BWD) {
-          stat[h] = ts[o];
-        } else {
-          stat[h] = tm[o];
-          stat[dim + h] = ts[o];
-        }
-      }
-    }
-    esm_wave_sync();
+  auto f_max = [](A a, A b) { return a > b ? a : b; };
+  auto f_add = [](A a, A b) { return a + b; };
+  A ghead[HP], glast[HP];
+  const bool pub_tail = first < 0 && u.R > 0 && lane == 0;  // row begun in an earlier unit
+  const bool tail_empty = tail_end == 0;                    // ... of which only the END falls here
+  const bool pub_carry = has_carry && n_valid && e0 + n_valid == u.nE;  // row going on in the next unit
+  A* tail_stat = static_cast<A*>(p.tail_stat) + w * 2 * dim;
+  A* carry_stat = static_cast<A*>(p.carry_stat) + w * 2 * dim;
+  // statistics of the segments cut by the unit boundary, for the fix-up kernel (OFF = 0: max or the
+  // backward sum, OFF = dim: the forward sum)
+#define DGLA_ESM_STATS(TABLE, IDENT, OFF)                                                              \
+  {                                                                                                     \
+    if (pub_tail)                                                                                       \
+      _Pragma("unroll") for (int h = 0; h < HP; ++h) if (h < dim)                                       \
+        tail_stat[(OFF) + h] = tail_empty ? (IDENT) : (a_local ? ghead[h] : (TABLE)[slot_a * HP + h]);  \
+    if (pub_carry)                                                                                      \
+      _Pragma("unroll") for (int h = 0; h < HP; ++h) if (h < dim)                                       \
+        carry_stat[(OFF) + h] = z_local ? glast[h] : (TABLE)[slot_z * HP + h];                          \
   }
 
-  // ---- store: complete rows are final; parts of straddling rows are written un-normalised
-  // (forward) or left to the fix-up (backward) ---------------------------------------------------
+  if constexpr (BWD) {
+    // sum of sds; local segments finish on the spot, the others wait for the table
+#define DGLA_ESM_SUB_LOCAL(j, h, b) \
+  if (local[j]) v[j][h] = v[j][h] - (b) * v2[j][h];
+    DGLA_ESM_GROUPS(f_add, DGLA_ESM_SUB_LOCAL)
+#undef DGLA_ESM_SUB_LOCAL
+    DGLA_ESM_PUBLISH(ts, A(0), f_add)
+    esm_wave_sync();
+    DGLA_ESM_STATS(ts, A(0), 0)
+#pragma unroll
+    for (int j = 0; j < kEsmEpl; ++j)
+#pragma unroll
+      for (int h = 0; h < HP; ++h)  // (parts of rows cut by the unit boundary are rewritten by the fix-up)
+        if (j < n_valid && !local[j])
+          v[j][h] = v[j][h] - ts[(in_head[j] ? slot_a : slot_z) * HP + h] * v2[j][h];
+  } else {
+    // max; local segments go straight on to exp(x - M), the others wait for the table
+#define DGLA_ESM_EXP_LOCAL(j, h, b) \
+  if (local[j]) v[j][h] = esm_expx<A, PRECISE>(v[j][h] - (b));
+    DGLA_ESM_GROUPS(f_max, DGLA_ESM_EXP_LOCAL)
+#undef DGLA_ESM_EXP_LOCAL
+    DGLA_ESM_PUBLISH(tm, neg_inf, f_max)
+    esm_wave_sync();
+    DGLA_ESM_STATS(tm, neg_inf, 0)
+#pragma unroll
+    for (int j = 0; j < kEsmEpl; ++j)
+#pragma unroll
+      for (int h = 0; h < HP; ++h)
+        if (j < n_valid && !local[j])
+          v[j][h] = esm_expx<A, PRECISE>(v[j][h] - tm[(in_head[j] ? slot_a : slot_z) * HP + h]);
+    // sum; local segments are normalised on the spot
+    const bool part_a = (sA == 0 && first < 0) || sA == u.R;  // the head segment is cut by the unit boundary
+#define DGLA_ESM_NORM_LOCAL(j, h, b) \
+  if (local[j] && !(in_head[j] && part_a) && !(seg[j] == u.R)) v[j][h] = v[j][h] * esm_recip<A>(b);
+    DGLA_ESM_GROUPS(f_add, DGLA_ESM_NORM_LOCAL)
+#undef DGLA_ESM_NORM_LOCAL
+    DGLA_ESM_PUBLISH(ts, A(0), f_add)
+    esm_wave_sync();
+    DGLA_ESM_STATS(ts, A(0), dim)
+#pragma unroll
+    for (int j = 0; j < kEsmEpl; ++j) {
+      const bool partial = (seg[j] == 0 && first < 0) || seg[j] == u.R;  // stays un-normalised: fix-up
+      if (j >= n_valid || local[j] || partial) continue;
+#pragma unroll
+      for (int h = 0; h < HP; ++h)
+        v[j][h] = v[j][h] * esm_recip<A>(ts[(in_head[j] ? slot_a : slot_z) * HP + h]);
+    }
+  }
+
+  // ---- store: complete rows are final; parts of rows cut by the unit boundary are left to the
+  // fix-up kernel --------------------------------------------------------------------------------
 #pragma unroll
   for (int j = 0; j < kEsmEpl; ++j) {
     const int e = e0 + j;
     if (e >= u.nE) continue;
     const bool partial = e < tail_end || e >= carry_begin;
-    if (BWD && partial) continue;
+    if (partial) continue;  // written by the fix-up kernel, which knows the whole row's statistics
     bool done = false;
     if constexpr (std::is_same<DT, float>::value && HP >= 4) {
       if (p.vec4) {
@@ -565,10 +607,19 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
   }
 }
 
+#undef DGLA_ESM_STATS
+#undef DGLA_ESM_GROUPS
+#undef DGLA_ESM_PUBLISH
+
+constexpr int kFixU = 8;  // edges in flight per lane of the fix-up kernel
+
 template <typename Idx, typename DT, bool BWD, bool PRECISE>
-__global__ __launch_bounds__(64) void edge_softmax_fixup_kernel(const EsmParams<Idx> p) {
+__global__ __launch_bounds__(256) void edge_softmax_fixup_kernel(const EsmParams<Idx> p) {
   using A = typename Acc<DT>::type;
-  const int64_t w = blockIdx.x;
+  // one wavefront per unit, four units per workgroup (a 64-thread workgroup per unit made the
+  // launch dispatch-bound: 251 k workgroups for the 62 M-edge graph)
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (w >= p.num_units) return;
   const int dim = p.dim, hp = 1 << p.log2_hp;
   const EsmUnit u = esm_unit<Idx>(p, w);
   const int64_t f = static_cast<int64_t>(p.indptr[u.i0]) - u.j0;
@@ -577,7 +628,7 @@ __global__ __launch_bounds__(64) void edge_softmax_fixup_kernel(const EsmParams<
   const DT* __restrict__ pa = static_cast<const DT*>(p.a);
   const DT* __restrict__ pb = static_cast<const DT*>(p.b);
   DT* __restrict__ pc = static_cast<DT*>(p.c);
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int h = lane & (hp - 1);
   const int es = 64 >> p.log2_hp;
 
@@ -609,10 +660,24 @@ __global__ __launch_bounds__(64) void edge_softmax_fixup_kernel(const EsmParams<
       A sum = A(0);
       for (int64_t q = sa; q < s2; ++q) sum += cs[q * 2 * dim + h];
       sum += ts[s2 * 2 * dim + h];
-      for (int t = t0 + (lane >> p.log2_hp); t < t1; t += es) {
-        const int64_t j = u.j0 + t;
-        const int64_t off = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + h;
-        pc[off] = from_acc<DT>(to_acc<DT>(pb[off]) - sum * to_acc<DT>(pa[off]));
+      // kFixU edges in flight per lane: the loop is a chain of HBM round trips otherwise
+      for (int tb = t0 + (lane >> p.log2_hp); tb < t1; tb += es * kFixU) {
+        int64_t off[kFixU];
+        A xb[kFixU], xa[kFixU];
+#pragma unroll
+        for (int k = 0; k < kFixU; ++k) {
+          const int t = tb + k * es < t1 ? tb + k * es : tb;
+          const int64_t j = u.j0 + t;
+          off[k] = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + h;
+        }
+#pragma unroll
+        for (int k = 0; k < kFixU; ++k) {
+          xb[k] = to_acc<DT>(pb[off[k]]);
+          xa[k] = to_acc<DT>(pa[off[k]]);
+        }
+#pragma unroll
+        for (int k = 0; k < kFixU; ++k)
+          if (tb + k * es < t1) pc[off[k]] = from_acc<DT>(xb[k] - sum * xa[k]);
       }
     } else {
       A M = ts[s2 * 2 * dim + h];
@@ -627,12 +692,23 @@ __global__ __launch_bounds__(64) void edge_softmax_fixup_kernel(const EsmParams<
         const A s_t = ts[s2 * 2 * dim + dim + h];
         if (s_t > A(0)) S += s_t * esm_expx<A, PRECISE>(ts[s2 * 2 * dim + h] - M);
       }
-      const A mine = part == 0 ? cs[w * 2 * dim + h] : ts[w * 2 * dim + h];
-      const A scale = esm_expx<A, PRECISE>(mine - M) / S;
-      for (int t = t0 + (lane >> p.log2_hp); t < t1; t += es) {
-        const int64_t j = u.j0 + t;
-        const int64_t off = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + h;
-        pc[off] = from_acc<DT>(to_acc<DT>(pc[off]) * scale);
+      // straight from the scores (the main kernel wrote nothing for these edges: re-reading x
+      // costs what re-reading an un-normalised output would, and the main kernel saves the write)
+      const A inv = esm_recip<A>(S);
+      for (int tb = t0 + (lane >> p.log2_hp); tb < t1; tb += es * kFixU) {
+        int64_t off[kFixU];
+        A xc[kFixU];
+#pragma unroll
+        for (int k = 0; k < kFixU; ++k) {
+          const int t = tb + k * es < t1 ? tb + k * es : tb;
+          const int64_t j = u.j0 + t;
+          off[k] = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + h;
+        }
+#pragma unroll
+        for (int k = 0; k < kFixU; ++k) xc[k] = to_acc<DT>(pa[off[k]]);
+#pragma unroll
+        for (int k = 0; k < kFixU; ++k)
+          if (tb + k * es < t1) pc[off[k]] = from_acc<DT>(esm_expx<A, PRECISE>(xc[k] - M) * inv);
       }
     }
   }
@@ -715,12 +791,12 @@ static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void*
       hipLaunchKernelGGL((edge_softmax_merge_kernel<Idx, DT, true, kPrecise, HPV>), dim3(blocks),      \
                          dim3(64 * wpb), lds, s, p);                                                  \
       hipLaunchKernelGGL((edge_softmax_fixup_kernel<Idx, DT, true, kPrecise>),                        \
-                         dim3(static_cast<unsigned>(g.num_units)), dim3(64), 0, s, p);                \
+                         dim3(static_cast<unsigned>((g.num_units + 3) / 4)), dim3(256), 0, s, p);     \
     } else {                                                                                          \
       hipLaunchKernelGGL((edge_softmax_merge_kernel<Idx, DT, false, kPrecise, HPV>), dim3(blocks),     \
                          dim3(64 * wpb), lds, s, p);                                                  \
       hipLaunchKernelGGL((edge_softmax_fixup_kernel<Idx, DT, false, kPrecise>),                       \
-                         dim3(static_cast<unsigned>(g.num_units)), dim3(64), 0, s, p);                \
+                         dim3(static_cast<unsigned>((g.num_units + 3) / 4)), dim3(256), 0, s, p);     \
     }                                                                                                 \
   } while (0)
   switch (hp) {

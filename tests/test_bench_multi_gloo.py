@@ -34,6 +34,8 @@ def _worker(rank, world, port, partitioner, ret):
         # differ by up to ~2e-5; the GPU kernels (blocked partial sums) are held to 1e-5 in
         # test_gpu_sharded.py
         np.testing.assert_allclose(ctx["out"].numpy(), full[ctx["shard"]["rows"].numpy()], rtol=1e-4)
+        ctx["step_replicated"]()      # rows sharded, features replicated: no exchange, same rows
+        np.testing.assert_allclose(ctx["out_replicated"].numpy(), full[ctx["shard"]["rows"].numpy()], rtol=1e-4)
         infos = ctx["infos"]
         assert [i["rank"] for i in infos] == list(range(world))
         assert sum(i["edges"] for i in infos) == e and sum(i["rows"] for i in infos) == n

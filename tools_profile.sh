@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-B="python $ROOT/bench.py --no-cpu"
+B="python $ROOT/bench.py --no-cpu --no-variants --no-peak"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $B --steps 10 --warmup 3 > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   N=$(echo $C | tr ' ' '_')
