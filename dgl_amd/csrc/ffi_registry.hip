@@ -172,6 +172,16 @@ struct UnitGraph {
   // token the Python layer announced for the NEXT SpMM's U operand (one-shot, 0 = not static);
   // `split_key` describes whose split-row copy the workspace holds right now (token 0 = nobody's).
   int64_t pending_static = 0;
+  // Static EDGE features (second argument of _CAPI_UnitGraphStaticOperand): a sum-reducing SpMM
+  // over a CSC with an edge-id map keeps a copy of the edge operand in CSC POSITION order
+  // (one dgla_gather_rows through the map, 1.5 ms for 62 M scalar weights) and runs map-free on
+  // it from then on — GCN-style normalisation weights are the same tensor in every layer and
+  // epoch.  `eord` is owned by the graph (hipMalloc; freed with it); `eord_token` / `_row_bytes`
+  // say whose copy it holds.
+  int64_t pending_static_e = 0;
+  void* eord = nullptr;
+  size_t eord_cap = 0;
+  int64_t eord_token = 0, eord_row_bytes = 0;
   struct SplitKey {
     int64_t token = 0, out_len = 0, rows = 0;
     int dtype = -1;
@@ -250,6 +260,7 @@ static int set_format(const FfiArgs& a, int which) {
     if (which == 2) {
       g->plan_valid = g->esm_plan_valid = false;
       g->split_key = UnitGraph::SplitKey();
+      g->eord_token = 0;
     }
   }
   g->num_edges = f.nnz;
@@ -271,7 +282,9 @@ static Registrar r_create("dgl_amd._CAPI_UnitGraphCreate", [](const FfiArgs& a, 
 static Registrar r_free("dgl_amd._CAPI_UnitGraphFree", [](const FfiArgs& a, DGLValue*, int* rtc) {
   void* h;
   if (get_handle(a, 0, &h)) return -1;
-  delete static_cast<UnitGraph*>(h);
+  UnitGraph* g = static_cast<UnitGraph*>(h);
+  if (g->eord) (void)hipFree(g->eord);
+  delete g;
   *rtc = kNull;
   return 0;
 });
@@ -394,12 +407,43 @@ static UnitGraph::SplitKey static_split_flags(UnitGraph* g, const SpmmCall& c, u
 static Registrar r_static("dgl_amd._CAPI_UnitGraphStaticOperand",
                           [](const FfiArgs& a, DGLValue*, int* rtc) {
   void* h;
-  int64_t tok;
+  int64_t tok, tok_e = 0;
   if (get_handle(a, 0, &h) || get_int(a, 1, &tok)) return -1;
+  if (a.n > 2 && get_int(a, 2, &tok_e)) return -1;
   static_cast<UnitGraph*>(h)->pending_static = tok;
+  static_cast<UnitGraph*>(h)->pending_static_e = tok_e;
   *rtc = kNull;
   return 0;
 });
+
+// Static edge operand of a sum-reducing SpMM on a CSC with an edge-id map: point `csc` / `e` at the
+// position-ordered copy kept in the graph (making it first if it is not this tensor's).
+static int static_edge_operand(UnitGraph* g, const SpmmCall& c, dgla_csr* csc, dgla_tensor* e) {
+  const int64_t tok = g->pending_static_e;
+  g->pending_static_e = 0;
+  if (tok == 0 || !csc->data || null_array(c.E) || strcmp(c.reduce, "sum") != 0) return 0;
+  if (c.e.t.shape[0] != csc->nnz || csc->nnz == 0) return 0;
+  int64_t len = 1;
+  for (int i = 1; i < c.e.t.ndim; ++i) len *= c.e.t.shape[i];
+  const int64_t rb = len * static_cast<int64_t>(c.dtype == DGLA_F64 ? 8 : (c.dtype == DGLA_F32 ? 4 : 2));
+  const size_t bytes = static_cast<size_t>(csc->nnz) * rb;
+  if (g->eord_token != tok || g->eord_row_bytes != rb) {
+    if (g->eord_cap < bytes) {
+      if (g->eord) DGLA_CHECK_HIP(hipFree(g->eord));
+      g->eord = nullptr;
+      g->eord_cap = 0;
+      DGLA_CHECK_HIP(hipMalloc(&g->eord, bytes));
+      g->eord_cap = bytes;
+    }
+    g->eord_token = 0;
+    if (dgla_gather_rows(g->idbits, c.e.t.data, csc->data, csc->nnz, rb, g->eord, tls_stream)) return -1;
+    g->eord_token = tok;
+    g->eord_row_bytes = rb;
+  }
+  e->data = g->eord;
+  csc->data = nullptr;
+  return 0;
+}
 
 static Registrar r_spmm("sparse._CAPI_DGLKernelSpMM", [](const FfiArgs& a, DGLValue*, int* rtc) {
   *rtc = kNull;
@@ -408,12 +452,14 @@ static Registrar r_spmm("sparse._CAPI_DGLKernelSpMM", [](const FfiArgs& a, DGLVa
   UnitGraph* g = c.g;
   // aten::SpMM: CSC (in-edge CSR) preferred, else COO (src/array/kernel.cc:26-43)
   if (g->csc.present) {
-    const dgla_csr csc = csr_of(g, g->csc, true);
+    dgla_csr csc = csr_of(g, g->csc, true);
     uint32_t flags = g->plan_valid ? DGLA_PLAN_VALID : 0;
     const UnitGraph::SplitKey key = static_split_flags(g, c, &flags);
+    dgla_tensor e_op = c.e.t;
+    if (static_edge_operand(g, c, &csc, &e_op)) return -1;
     // `V` arrives zero-filled (python/dgl/_sparse_ops.py:227) so writing rows instead of
     // accumulating into them gives the same result for the single-relation call.
-    const int rc = dgla_spmm_csr(c.op, c.reduce, &csc, c.dtype, &c.u.t, &c.e.t, &c.v.t,
+    const int rc = dgla_spmm_csr(c.op, c.reduce, &csc, c.dtype, &c.u.t, &e_op, &c.v.t,
                                  null_array(c.ArgU) ? nullptr : data_ptr(c.ArgU),
                                  null_array(c.ArgE) ? nullptr : data_ptr(c.ArgE), g->ws,
                                  g->ws_bytes, flags, tls_stream);
@@ -439,10 +485,12 @@ static Registrar r_spmm_mean("sparse._CAPI_DGLKernelSpMMMean",
   if (unpack_spmm(a, &c)) return -1;
   UnitGraph* g = c.g;
   if (!g->csc.present) return ffi_fail("SpMMMean needs the CSC format");
-  const dgla_csr csc = csr_of(g, g->csc, true);
+  dgla_csr csc = csr_of(g, g->csc, true);
   uint32_t flags = (g->plan_valid ? DGLA_PLAN_VALID : 0) | DGLA_MEAN;
   const UnitGraph::SplitKey key = static_split_flags(g, c, &flags);
-  const int rc = dgla_spmm_csr(c.op, c.reduce, &csc, c.dtype, &c.u.t, &c.e.t, &c.v.t, nullptr,
+  dgla_tensor e_op = c.e.t;
+  if (static_edge_operand(g, c, &csc, &e_op)) return -1;
+  const int rc = dgla_spmm_csr(c.op, c.reduce, &csc, c.dtype, &c.u.t, &e_op, &c.v.t, nullptr,
                                nullptr, g->ws, g->ws_bytes, flags, tls_stream);
   g->plan_valid = rc == 0;
   g->split_key = rc == 0 ? key : UnitGraph::SplitKey();
@@ -462,7 +510,7 @@ static Registrar r_spmm_acc("sparse._CAPI_DGLKernelSpMMAccumulate",
   const uint32_t flags = (g->plan_valid ? DGLA_PLAN_VALID : 0) | DGLA_ACCUMULATE;
   const int rc = dgla_spmm_csr(c.op, c.reduce, &csc, c.dtype, &c.u.t, &c.e.t, &c.v.t, nullptr,
                                nullptr, g->ws, g->ws_bytes, flags, tls_stream);
-  g->pending_static = 0;
+  g->pending_static = g->pending_static_e = 0;
   g->split_key = UnitGraph::SplitKey();  // the call may have re-laid ITS operand into the scratch
   if (rc == 0) g->plan_valid = true;
   return rc;

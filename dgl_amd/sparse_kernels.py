@@ -26,10 +26,12 @@ _tokens = itertools.count(1)
 
 
 def static_features(t):
-    """Declare ``t`` (a source-node feature tensor) unchanging for as long as it lives: g-SpMM
-    calls that read it keep its split-row copy between calls instead of re-making it.  Writing
-    into ``t`` afterwards is the caller's bug; ``release_static(t)`` takes the promise back.
-    Returns ``t``."""
+    """Declare ``t`` (a source-node OR edge feature tensor) unchanging for as long as it lives.
+    g-SpMM calls that read it as the node operand keep its split-row copy between calls instead
+    of re-making it; sum-reducing calls that read it as the EDGE operand on a graph whose CSC has
+    an edge-id map keep a copy in CSC position order and run map-free (GCN-style normalisation
+    weights: one random 128-byte line per 4-byte weight otherwise).  Writing into ``t``
+    afterwards is the caller's bug; ``release_static(t)`` takes the promise back.  Returns ``t``."""
     key = id(t)
     _static[key] = (weakref.ref(t, lambda _r, k=key: _static.pop(k, None)), next(_tokens))
     return t
@@ -150,8 +152,9 @@ def _gspmm(gidx, op, reduce_op, u, e, accumulate_into=None, mean=False):
             nbytes = _call("sparse._CAPI_DGLKernelSpMMWorkspaceBytes", rel, fmt, *args)
             rel.ensure_workspace(nbytes)
             tok = _static_token(uu) if (use_u and _static) else 0
-            if tok:  # one-shot announcement consumed by the SpMM call below
-                _call("dgl_amd._CAPI_UnitGraphStaticOperand", rel, fmt, tok)
+            tok_e = _static_token(ee) if (use_e and _static and reduce_op == "sum") else 0
+            if tok or tok_e:  # one-shot announcement consumed by the SpMM call below
+                _call("dgl_amd._CAPI_UnitGraphStaticOperand", rel, fmt, tok, tok_e)
         name = "sparse._CAPI_DGLKernelSpMM" if accumulate_into is None else \
             "sparse._CAPI_DGLKernelSpMMAccumulate"
         if mean:

@@ -194,3 +194,43 @@ def test_static_features_through_the_operator_api(dev):
     x.mul_(2)                               # no longer static: the change must be seen
     e2 = ops.copy_u_sum(g, x)
     torch.testing.assert_close(e2, 2 * base, rtol=1e-6, atol=0)
+
+
+def test_static_edge_weights_run_map_free_with_the_same_bits(dev):
+    """A static EDGE operand (dgl_amd.static_features(w)) of a sum-reducing g-SpMM on a graph whose
+    CSC carries an edge-id map is kept in CSC position order after the first call: same bits as
+    the plain path, a different tensor in between or a released tensor invalidates the copy."""
+    import dgl_amd as dgl
+    from dgl_amd import ops
+
+    n, e = 50_000, 700_000
+    gg = synth_csr(n, n, e, "U", seed=31, device=dev, idtype=torch.int32)
+    dst = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int32),
+                                  (gg["indptr"][1:] - gg["indptr"][:-1]).long())
+    perm = torch.randperm(e, device=dev)
+    g = dgl.graph((gg["indices"][perm].contiguous(), dst[perm].contiguous()), num_nodes=n)
+    assert g._graph.relations[0].csc()[2] is not None          # random edge order: there is a map
+    torch.manual_seed(3)
+    x = torch.rand(n, 64, device=dev) + 1
+    w = torch.rand(e, 1, device=dev) + 0.5
+    base = ops.u_mul_e_sum(g, x, w)
+    dgl.static_features(w)
+    a, b = ops.u_mul_e_sum(g, x, w), ops.u_mul_e_sum(g, x, w)
+    assert torch.equal(a, base) and torch.equal(b, base)
+    w2 = torch.rand(e, 1, device=dev) + 0.5
+    c = ops.u_mul_e_sum(g, x, w2)                                # not static: plain path
+    d = ops.u_mul_e_sum(g, x, w)                                 # static copy still w's
+    assert torch.equal(d, base) and not torch.equal(c, base)
+    dgl.static_features(w2)
+    assert torch.equal(ops.u_mul_e_sum(g, x, w2), c)             # copy replaced by w2's
+    assert torch.equal(ops.u_mul_e_sum(g, x, w), base)           # and back
+    mx = ops.u_mul_e_max(g, x, w)                                # max needs real edge ids: plain path
+    dgl.release_static(w)
+    assert torch.equal(ops.u_mul_e_max(g, x, w), mx)
+    w.mul_(3)
+    torch.testing.assert_close(ops.u_mul_e_sum(g, x, w), 3 * base, rtol=1e-5, atol=0)
+    # gradient w.r.t. the node operand flows through the static path unchanged
+    xg = x.clone().requires_grad_(True)
+    dgl.static_features(w)
+    ops.u_mul_e_sum(g, xg, w).sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
