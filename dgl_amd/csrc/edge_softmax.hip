@@ -178,7 +178,13 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
 //      ((m, s) pairs combine as S = sum_i s_i * exp(m_i - M)) and rescales its own unit's
 //      edges, so even a hub row is handled by as many blocks as it has units.
 // =========================================================================================
-constexpr int kEsmItems = 256;
+// One workgroup per unit.  Measured at 62 M edges, H = 8 fp32, forward / backward: 64 threads x
+// 256 items 1.67 / 1.72 ms (48 % of the edges in rows cut by a unit boundary -> fix-up traffic),
+// 256 x 1024 **1.34 / 1.49 ms**, 512 x 2048 1.53 / 2.28 ms (one workgroup per CU: the barriers of
+// the cross-wave scan are no longer hidden).
+constexpr int kEsmThreads = 256;
+constexpr int kEsmWaves = kEsmThreads / 64;
+constexpr int kEsmItems = 4 * kEsmThreads;        // items (edges + row ends) per unit
 
 template <typename Idx>
 struct EsmParams {
@@ -193,6 +199,7 @@ struct EsmParams {
   int wave_lds_bytes;
   int vec4;  // fp32, dim % 4 == 0 == padded width, 16-byte aligned operands: rows move as 16-byte pieces
   int xcd;   // units in XCD-contiguous order (kTuneXcd): neighbouring units share an L2
+  int region_bytes;  // LDS bytes of the tables / row-transposition slices in front of the rest
   int64_t* carry_row;  // [num_units] row continued in the next unit, or -1
   void* carry_stat;    // [num_units, 2 * dim] accumulators: (m | s) forward, (sum | -) backward
   void* tail_stat;     // [num_units, 2 * dim]
@@ -258,18 +265,48 @@ __device__ __forceinline__ A esm_expx(A x) {
     return esm_exp<A>(x);
 }
 
-// Rows of the LDS tables holding the totals of lane-crossing segments: one per lane of the wave.
-constexpr int kEsmSegCap = 64;
+// Rows of the LDS tables holding the totals of lane-crossing segments: one per lane of the workgroup.
+constexpr int kEsmSegCap = kEsmThreads;
 
-// Orders one wave's LDS traffic between the passes of the reduce.  Each wave works on its own
-// LDS slice and the number of rounds differs from wave to wave, so a block barrier is neither
-// needed nor allowed here; LDS operations of ONE wave execute in issue order.
+// Orders ONE wave's LDS traffic (its own staging slice): LDS operations of a wave execute in
+// issue order, so a compiler fence + wave barrier is all it takes.
 __device__ __forceinline__ void esm_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// One wavefront per unit.  Every lane owns kEsmEpl = 4 CONSECUTIVE edges of the unit and keeps
+// Cross-lane moves of the segmented scan as DPP modifiers of a VALU move (row_shr:n inside a row
+// of 16 lanes, row_bcast:15 / :31 between rows, wave_shr:1 for "the previous lane") instead of
+// ds_bpermute: a scan step costs an ALU instruction, not an LDS round trip (the forward pass makes
+// two 6-step scans over HP values per unit; with ds_bpermute they were its critical path).
+// Lanes without a source keep `old`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int esm_dpp(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float esm_dpp(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                               __builtin_bit_cast(int, src), CTRL, ROW_MASK,
+                                                               0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double esm_dpp(double old, double src) {
+  const uint64_t o = __builtin_bit_cast(uint64_t, old), v = __builtin_bit_cast(uint64_t, src);
+  const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(
+      static_cast<int>(o), static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
+  const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(
+      static_cast<int>(o >> 32), static_cast<int>(v >> 32), CTRL, ROW_MASK, 0xf, false));
+  return __builtin_bit_cast(double, (static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// 16-byte piece i of a wave's staging slice lives at piece esm_swz(i): the global side moves
+// pieces lane-linearly (piece 64 k + lane), the register side wants 4 or 8 CONSECUTIVE pieces per
+// lane; XOR-ing the low four bits with bits 4..7 keeps both directions free of bank conflicts
+// (every 16-byte bank group is hit by exactly 4 of the 64 lanes, the minimum for ds_*_b128).
+__device__ __forceinline__ int esm_swz(int i) { return i ^ ((i >> 4) & 15); }
+
+// One workgroup (kEsmThreads = 256 lanes) per unit of kEsmItems = 1024 items.  Every lane owns kEsmEpl = 4 CONSECUTIVE edges of the unit and keeps
 // all HP features of them in registers: the scores travel HBM -> registers -> HBM (for edge ids =
 // positions a lane's four rows are 4 * dim * s contiguous bytes: 16-byte loads and stores); LDS
 // holds only the unit's row ends, its edge ids and two 64-row tables.
@@ -279,8 +316,9 @@ __device__ __forceinline__ void esm_wave_sync() {
 // inside the lane ("local"), possibly one that goes on into later lanes (its "tail"; head == tail
 // when the whole lane sits inside one long row).  Local segments are reduced in registers with one
 // forward and one backward sweep over the four edges.  Crossing segments are reduced ACROSS lanes
-// with a segmented inclusive shuffle scan over (tail-starts-here flag, tail partial) — 6 steps for
-// any mix of row lengths — after which the lane where a crossing segment ENDS holds its total and
+// with a segmented inclusive scan over (tail-starts-here flag, tail partial) — 6 shuffle steps
+// inside each wave, then one hand-over of the four waves' last values through LDS, for any mix of
+// row lengths — after which the lane where a crossing segment ENDS holds its total and
 // leaves it in the table row of the lane the segment STARTED in (unique: at most one segment
 // crosses out of a lane).  Everybody then reads the totals it needs.
 //   forward : max -> exp(x - M) -> sum -> scale by 1 / S; segments cut by the unit boundary only
@@ -289,32 +327,42 @@ __device__ __forceinline__ void esm_wave_sync() {
 // A hub row and forty 5-edge rows cost the same.  (The first version of this kernel combined
 // lanes through ds_max / ds_add atomics on the tables and spent half of its cycles in LDS issue
 // stalls — 64 lanes on a handful of addresses serialise: profiles/r2/softmax_pmc_atomics.txt.)
-constexpr int kEsmEpl = kEsmItems / 64;
+constexpr int kEsmEpl = kEsmItems / kEsmThreads;
 static_assert(kEsmEpl == 4, "the sweeps below are written out for four edges per lane");
 
 template <typename Idx, typename DT, bool BWD, bool PRECISE, int HP>
-__global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams<Idx> p) {
+__global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1 : 4) void edge_softmax_merge_kernel(const EsmParams<Idx> p) {
   using A = typename Acc<DT>::type;
   extern __shared__ __align__(16) unsigned char esm_smem[];
-  const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
+  const int wib = threadIdx.x >> 6, wl = threadIdx.x & 63;
+  const int lane = threadIdx.x;  // lane of the WORKGROUP: the unit's edges [4 lane, 4 lane + 4)
   unsigned blk = blockIdx.x;
   if (p.xcd) {  // block b runs on XCD b % 8: give every XCD one contiguous eighth of the units
     const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u;
     const unsigned x = blk & 7u, i = blk >> 3;
     blk = x * q + (x < r ? x : r) + i;
   }
-  const int64_t w = static_cast<int64_t>(blk) * wpb + wib;
+  const int64_t w = blk;  // one unit per workgroup
   const int dim = p.dim;
-  unsigned char* base = esm_smem + static_cast<size_t>(wib) * p.wave_lds_bytes;
-  A* tm = reinterpret_cast<A*>(base);                       // [64 * HP]  (forward only)
-  A* ts = tm + (BWD ? 0 : kEsmSegCap * HP);                 // [64 * HP]
-  int64_t* eid = reinterpret_cast<int64_t*>(ts + kEsmSegCap * HP);  // [kEsmItems]
+  // fp32, whole rows of 4 or 8 features, edge ids = positions: rows move between HBM and the
+  // registers THROUGH a per-wave LDS slice so that every global instruction is 1 KB contiguous
+  // (lane-linear pieces) although a lane owns four consecutive rows.  The slice (256 rows) shares
+  // its memory with the segment tables, which are only alive between the two transpositions.
+  constexpr int Q = HP / 4;  // 16-byte pieces per row
+  const bool tr = std::is_same<DT, float>::value && (HP == 4 || HP == 8) && p.vec4 && p.eids == nullptr;
+  // (the slice holds HALF of the wave's rows: lanes 0-31 take theirs in round 0, lanes 32-63 in
+  // round 1, so that the slices are no larger than the forward tables they share memory with)
+  unsigned char* stage = esm_smem + static_cast<size_t>(wib) * (32 * kEsmEpl * HP * sizeof(float));
+  A* tm = reinterpret_cast<A*>(esm_smem);                   // [kEsmThreads * HP]  (forward only)
+  A* ts = tm + (BWD ? 0 : kEsmSegCap * HP);                 // [kEsmThreads * HP]
+  A* wv = reinterpret_cast<A*>(esm_smem + p.region_bytes);  // [waves * HP] last scanned value of every wave
+  int64_t* eid = reinterpret_cast<int64_t*>(wv + kEsmWaves * HP);   // [kEsmItems]
   int* rend = reinterpret_cast<int*>(eid + kEsmItems);      // [kEsmItems + 2]
+  int* wf = rend + kEsmItems + 2;                           // [waves] "a segment starts in this wave"
   const DT* __restrict__ pa = static_cast<const DT*>(p.a);
   const DT* __restrict__ pb = static_cast<const DT*>(p.b);
   DT* __restrict__ pc = static_cast<DT*>(p.c);
-  if (w >= p.num_units) return;  // no block-wide barrier below: a wave only touches its own slice
+  if (w >= p.num_units) return;  // block-uniform
 
   const EsmUnit u = esm_unit<Idx>(p, w);
   const int e0 = lane * kEsmEpl;
@@ -354,6 +402,9 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
   }
 
   const bool direct = p.eids == nullptr;  // edge id == position: addresses need no staging
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  [[maybe_unused]] f32x4 tmp[4 * (Q > 0 ? Q : 1)], tmp2[BWD ? 4 * (Q > 0 ? Q : 1) : 1];
+  const int wave_edges = u.nE - wib * (64 * kEsmEpl);  // edges of this wave's slice (may be <= 0)
   if (direct) {
 #pragma unroll
     for (int j = 0; j < kEsmEpl; ++j) {
@@ -361,18 +412,35 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
       if (e >= u.nE) e = u.nE > 0 ? u.nE - 1 : 0;
       off[j] = (u.j0 + e) * dim;
     }
-    DGLA_ESM_LOAD()  // in flight together with the index loads below: one HBM round trip per unit
+    if constexpr (std::is_same<DT, float>::value && (HP == 4 || HP == 8)) {
+      if (tr) {  // lane-linear pieces of the wave's slice; in flight together with the index loads below
+        const int64_t base = (u.j0 + wib * (64 * kEsmEpl)) * dim;
+#pragma unroll
+        for (int k = 0; k < 4 * Q; ++k) {
+          const int i = 64 * k + wl;
+          const bool ok = i / Q < wave_edges;
+          tmp[k] = ok ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(BWD ? pb : pa) + base + 4 * i)
+                      : f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (BWD)
+            tmp2[k] = ok ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(pa) + base + 4 * i)
+                         : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    if (!tr) {
+      DGLA_ESM_LOAD()  // in flight together with the index loads below: one HBM round trip per unit
+    }
   }
   // ---- stage row ends (and edge ids): 4 independent loads per lane issued back to back
   // (addresses clamped, not predicated) ----------------------------------------------------------
   {
-    constexpr int KS = kEsmItems / 64;
+    constexpr int KS = kEsmItems / kEsmThreads;
     const int items = u.R + u.nE;
     if (items > 0) {
       int64_t itemv[KS];
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
-        int it = lane + 64 * k;
+        int it = lane + kEsmThreads * k;
         if (it >= items) it = items - 1;
         if (it < u.nE)
           itemv[k] = p.eids ? static_cast<int64_t>(p.eids[u.j0 + it]) : u.j0 + it;
@@ -381,7 +449,7 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
       }
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
-        const int it = lane + 64 * k;
+        const int it = lane + kEsmThreads * k;
         if (it < u.nE)
           eid[it] = itemv[k];
         else if (it < items)
@@ -392,7 +460,44 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
   const int64_t f0 = static_cast<int64_t>(p.indptr[u.i0]) - u.j0;
   const int first = f0 < 0 ? -1 : static_cast<int>(f0);
   if (lane == 0) rend[0] = first;
-  esm_wave_sync();
+  if constexpr (std::is_same<DT, float>::value && (HP == 4 || HP == 8)) {
+    if (tr) {  // lane-linear pieces -> this lane's four rows, half of the wave per round
+      f32x4* st = reinterpret_cast<f32x4*>(stage);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        if (r) esm_wave_sync();
+#pragma unroll
+        for (int k = 0; k < 2 * Q; ++k) st[esm_swz(64 * k + wl)] = tmp[2 * Q * r + k];
+        esm_wave_sync();
+        if ((wl >> 5) == r) {
+#pragma unroll
+          for (int m = 0; m < 4 * Q; ++m) {
+            const f32x4 t = st[esm_swz(4 * Q * (wl & 31) + m)];
+            v[m / Q][4 * (m % Q)] = t.x, v[m / Q][4 * (m % Q) + 1] = t.y, v[m / Q][4 * (m % Q) + 2] = t.z,
+            v[m / Q][4 * (m % Q) + 3] = t.w;
+          }
+        }
+      }
+      if constexpr (BWD) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          esm_wave_sync();
+#pragma unroll
+          for (int k = 0; k < 2 * Q; ++k) st[esm_swz(64 * k + wl)] = tmp2[2 * Q * r + k];
+          esm_wave_sync();
+          if ((wl >> 5) == r) {
+#pragma unroll
+            for (int m = 0; m < 4 * Q; ++m) {
+              const f32x4 t = st[esm_swz(4 * Q * (wl & 31) + m)];
+              v2[m / Q][4 * (m % Q)] = t.x, v2[m / Q][4 * (m % Q) + 1] = t.y, v2[m / Q][4 * (m % Q) + 2] = t.z,
+              v2[m / Q][4 * (m % Q) + 3] = t.w;
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();  // row ends staged; every wave is done with its staging slice (the tables alias it)
   if (!direct) {
 #pragma unroll
     for (int j = 0; j < kEsmEpl; ++j) {
@@ -489,23 +594,47 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
   // starts in this lane"; afterwards the previous lane's scanned value = everything of this
   // lane's head segment that lies in earlier lanes, and the lane where a crossing segment ends
   // writes its total to TABLE[start lane].
+#define DGLA_ESM_SCAN_STEP(CTRL, ROWS, IDENT, OP)                                                  \
+    {                                                                                              \
+      const int fp = esm_dpp<CTRL, ROWS>(0, f);                                                     \
+      _Pragma("unroll") for (int h = 0; h < HP; ++h) {                                              \
+        const A xp = esm_dpp<CTRL, ROWS>(static_cast<A>(IDENT), x[h]);                              \
+        if (!f) x[h] = OP(x[h], xp);                                                                \
+      }                                                                                             \
+      f |= fp;                                                                                      \
+    }
 #define DGLA_ESM_PUBLISH(TABLE, IDENT, OP)                                                        \
   {                                                                                                \
     A x[HP];                                                                                       \
     _Pragma("unroll") for (int h = 0; h < HP; ++h) x[h] = n_valid ? glast[h] : (IDENT);             \
     int f = (!n_valid || z_starts_here) ? 1 : 0;                                                    \
-    _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) {                                            \
-      const int fp = __shfl_up(f, d, 64);                                                           \
-      _Pragma("unroll") for (int h = 0; h < HP; ++h) {                                              \
-        const A xp = __shfl_up(x[h], d, 64);                                                        \
-        if (lane >= d && !f) x[h] = OP(x[h], xp);                                                   \
-      }                                                                                             \
-      if (lane >= d) f |= fp;                                                                       \
+    /* inside the wave: rows of 16 lanes (row_shr 1, 2, 4, 8), then row 0 -> 1 and 2 -> 3         \
+       (row_bcast:15), then rows 0-1 -> 2-3 (row_bcast:31); a lane without a source sees            \
+       (IDENT, no start) and stays as it is */                                                      \
+    DGLA_ESM_SCAN_STEP(0x111, 0xf, IDENT, OP)                                                       \
+    DGLA_ESM_SCAN_STEP(0x112, 0xf, IDENT, OP)                                                       \
+    DGLA_ESM_SCAN_STEP(0x114, 0xf, IDENT, OP)                                                       \
+    DGLA_ESM_SCAN_STEP(0x118, 0xf, IDENT, OP)                                                       \
+    DGLA_ESM_SCAN_STEP(0x142, 0xa, IDENT, OP)                                                       \
+    DGLA_ESM_SCAN_STEP(0x143, 0xc, IDENT, OP)                                                       \
+    /* across the four waves: what the earlier waves hold of the segment running into this one */   \
+    if (wl == 63) {                                                                                 \
+      wf[wib] = f;                                                                                  \
+      _Pragma("unroll") for (int h = 0; h < HP; ++h) wv[wib * HP + h] = x[h];                       \
     }                                                                                               \
+    __syncthreads();                                                                                \
+    A cin[HP];                                                                                      \
+    _Pragma("unroll") for (int h = 0; h < HP; ++h) cin[h] = (IDENT);                                \
+    for (int q = 0; q < wib; ++q) {                                                                 \
+      const bool st = wf[q] != 0;                                                                   \
+      _Pragma("unroll") for (int h = 0; h < HP; ++h)                                                \
+        cin[h] = st ? wv[q * HP + h] : OP(cin[h], wv[q * HP + h]);                                  \
+    }                                                                                               \
+    _Pragma("unroll") for (int h = 0; h < HP; ++h) if (!f) x[h] = OP(cin[h], x[h]);                 \
     const bool writes = n_valid && !a_starts_here && a_ends_here;                                   \
     _Pragma("unroll") for (int h = 0; h < HP; ++h) {                                                \
-      const A t = __shfl_up(x[h], 1, 64);                                                           \
-      if (writes) (TABLE)[slot_a * HP + h] = OP(lane > 0 ? t : (IDENT), ghead[h]);                  \
+      const A t = esm_dpp<0x138, 0xf>(static_cast<A>(IDENT), x[h]); /* wave_shr:1 */                \
+      if (writes) (TABLE)[slot_a * HP + h] = OP(wl > 0 ? t : cin[h], ghead[h]);                     \
     }                                                                                               \
   }
   const A neg_inf = -static_cast<A>(__builtin_huge_valf());
@@ -536,7 +665,7 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
     DGLA_ESM_GROUPS(f_add, DGLA_ESM_SUB_LOCAL)
 #undef DGLA_ESM_SUB_LOCAL
     DGLA_ESM_PUBLISH(ts, A(0), f_add)
-    esm_wave_sync();
+    __syncthreads();
     DGLA_ESM_STATS(ts, A(0), 0)
 #pragma unroll
     for (int j = 0; j < kEsmEpl; ++j)
@@ -551,7 +680,7 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
     DGLA_ESM_GROUPS(f_max, DGLA_ESM_EXP_LOCAL)
 #undef DGLA_ESM_EXP_LOCAL
     DGLA_ESM_PUBLISH(tm, neg_inf, f_max)
-    esm_wave_sync();
+    __syncthreads();
     DGLA_ESM_STATS(tm, neg_inf, 0)
 #pragma unroll
     for (int j = 0; j < kEsmEpl; ++j)
@@ -566,7 +695,7 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
     DGLA_ESM_GROUPS(f_add, DGLA_ESM_NORM_LOCAL)
 #undef DGLA_ESM_NORM_LOCAL
     DGLA_ESM_PUBLISH(ts, A(0), f_add)
-    esm_wave_sync();
+    __syncthreads();
     DGLA_ESM_STATS(ts, A(0), dim)
 #pragma unroll
     for (int j = 0; j < kEsmEpl; ++j) {
@@ -580,6 +709,35 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
 
   // ---- store: complete rows are final; parts of rows cut by the unit boundary are left to the
   // fix-up kernel --------------------------------------------------------------------------------
+  if constexpr (std::is_same<DT, float>::value && (HP == 4 || HP == 8)) {
+    if (tr) {
+      __syncthreads();  // nobody reads the tables any more: the staging slices may overwrite them
+      f32x4* st = reinterpret_cast<f32x4*>(stage);
+      const int64_t base = (u.j0 + wib * (64 * kEsmEpl)) * dim;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        if (r) esm_wave_sync();
+        if ((wl >> 5) == r) {
+#pragma unroll
+          for (int m = 0; m < 4 * Q; ++m) {
+            f32x4 t;
+            t.x = v[m / Q][4 * (m % Q)], t.y = v[m / Q][4 * (m % Q) + 1], t.z = v[m / Q][4 * (m % Q) + 2],
+            t.w = v[m / Q][4 * (m % Q) + 3];
+            st[esm_swz(4 * Q * (wl & 31) + m)] = t;
+          }
+        }
+        esm_wave_sync();
+#pragma unroll
+        for (int k = 0; k < 2 * Q; ++k) {
+          const int i = 128 * Q * r + 64 * k + wl;  // piece of the wave's slice
+          const int e = wib * (64 * kEsmEpl) + i / Q;
+          if (e < u.nE && !(e < tail_end || e >= carry_begin))
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(pc) + base + 4 * i) = st[esm_swz(64 * k + wl)];
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < kEsmEpl; ++j) {
     const int e = e0 + j;
@@ -610,6 +768,7 @@ __global__ __launch_bounds__(256) void edge_softmax_merge_kernel(const EsmParams
 #undef DGLA_ESM_STATS
 #undef DGLA_ESM_GROUPS
 #undef DGLA_ESM_PUBLISH
+#undef DGLA_ESM_SCAN_STEP
 
 constexpr int kFixU = 8;  // edges in flight per lane of the fix-up kernel
 
@@ -771,30 +930,34 @@ static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void*
   p.carry_stat = wsp + g.off_carry_stat;
   p.tail_stat = wsp + g.off_tail_stat;
   const int hp = 1 << g.log2_hp;
-  // per wave: the segment tables of the reduce ((max | sum) forward, sum backward), edge ids, row ends
-  const size_t per_wave = sizeof(A) * kEsmSegCap * hp * (backward ? 1 : 2) + sizeof(int64_t) * kEsmItems +
-                          sizeof(int) * (kEsmItems + 2) + 8;
-  p.wave_lds_bytes = static_cast<int>((per_wave + 15) / 16 * 16);
-  const int wpb = 4;
+  // per workgroup: the segment tables ((max | sum) forward, sum backward), the waves' scan
+  // hand-over, edge ids, row ends
+  // (the fp32 row-transposition slices, 4 waves x 128 rows x hp x 4 B, share the tables' memory)
+  const size_t tables = sizeof(A) * kEsmSegCap * hp * (backward ? 1 : 2);
+  const size_t slices = (sizeof(DT) == 4 && (hp == 4 || hp == 8)) ? size_t(kEsmItems / 2) * hp * 4 : 0;
+  p.region_bytes = static_cast<int>(((tables > slices ? tables : slices) + 15) / 16 * 16);
+  const size_t per_block = p.region_bytes + sizeof(A) * kEsmWaves * hp +
+                           sizeof(int64_t) * kEsmItems + sizeof(int) * (kEsmItems + 2 + kEsmWaves) + 8;
+  p.wave_lds_bytes = static_cast<int>((per_block + 15) / 16 * 16);
   if (!plan_valid) {
     const int64_t n = g.num_units + 1;
     hipLaunchKernelGGL((esm_plan_kernel<Idx>), dim3(static_cast<unsigned>((n + 255) / 256)),
                        dim3(256), 0, s, p.indptr, csr.num_rows, csr.nnz, g.num_units,
                        reinterpret_cast<int64_t*>(wsp + g.off_plan));
   }
-  const unsigned blocks = static_cast<unsigned>((g.num_units + wpb - 1) / wpb);
-  const size_t lds = static_cast<size_t>(p.wave_lds_bytes) * wpb;
+  const unsigned blocks = static_cast<unsigned>(g.num_units);
+  const size_t lds = static_cast<size_t>(p.wave_lds_bytes);
   constexpr bool kPrecise = sizeof(DT) == 8;
 #define DGLA_ESM_LAUNCH(HPV)                                                                          \
   do {                                                                                                \
     if (backward) {                                                                                   \
       hipLaunchKernelGGL((edge_softmax_merge_kernel<Idx, DT, true, kPrecise, HPV>), dim3(blocks),      \
-                         dim3(64 * wpb), lds, s, p);                                                  \
+                         dim3(kEsmThreads), lds, s, p);                                                  \
       hipLaunchKernelGGL((edge_softmax_fixup_kernel<Idx, DT, true, kPrecise>),                        \
                          dim3(static_cast<unsigned>((g.num_units + 3) / 4)), dim3(256), 0, s, p);     \
     } else {                                                                                          \
       hipLaunchKernelGGL((edge_softmax_merge_kernel<Idx, DT, false, kPrecise, HPV>), dim3(blocks),     \
-                         dim3(64 * wpb), lds, s, p);                                                  \
+                         dim3(kEsmThreads), lds, s, p);                                                  \
       hipLaunchKernelGGL((edge_softmax_fixup_kernel<Idx, DT, false, kPrecise>),                       \
                          dim3(static_cast<unsigned>((g.num_units + 3) / 4)), dim3(256), 0, s, p);     \
     }                                                                                                 \
