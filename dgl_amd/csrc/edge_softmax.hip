@@ -31,10 +31,12 @@ __device__ __forceinline__ float esm_exp<float>(float x) {
   // log2 e), so the error of the argument does not grow with |x|: 2^hi * (1 + lo ln 2).
   // ~7 instructions instead of the ~25 of the library expf; |relative error| < 3e-7 measured
   // against exp() in fp64 over [-88, 0] (tests/test_gpu_softmax_kernels.py).
+  // (arguments are <= 0 here; clamped at -200, where 2^hi is 0 already, so that exp(-inf) = 0
+  // instead of the NaN that lo would become)
+  asm("v_max_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(-200.f));
   const float hi = x * 1.44269504088896341f;
   const float lo = __builtin_fmaf(x, 1.44269504088896341f, -hi) + x * 1.92596299112661746e-8f;
-  const float r = __builtin_amdgcn_exp2f(hi) * __builtin_fmaf(lo, 0.693147180559945309f, 1.0f);
-  return hi < -150.f ? 0.f : r;  // also keeps exp(-inf) = 0 (lo would be NaN there)
+  return __builtin_amdgcn_exp2f(hi) * __builtin_fmaf(lo, 0.693147180559945309f, 1.0f);
 }
 template <>
 __device__ __forceinline__ double esm_exp<double>(double x) {
@@ -184,14 +186,20 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
 // the cross-wave scan are no longer hidden).
 constexpr int kEsmThreads = 256;
 constexpr int kEsmWaves = kEsmThreads / 64;
-constexpr int kEsmItems = 4 * kEsmThreads;        // items (edges + row ends) per unit
+constexpr int kEsmItems = 4 * kEsmThreads;        // items (edges + row ends) a unit holds at most
+// Unit boundaries sit kEsmStride items apart on the merge path and are then moved FORWARD to the end
+// of the row they cut when that takes at most kEsmSlack edges (+ the row-end item): rows of ordinary
+// length are never cut, so the carry / tail / fix-up machinery only runs for rows longer than that.
+constexpr int kEsmSlack = 63;
+constexpr int kEsmStride = kEsmItems - kEsmSlack - 1;
 
 template <typename Idx>
 struct EsmParams {
   const Idx* indptr;
   const Idx* eids;
   int64_t num_rows, nnz, num_units;
-  const int64_t* plan;  // [num_units + 1]
+  const int64_t* plan;   // [num_units + 1] first row of every unit
+  const int64_t* planj;  // [num_units + 1] first edge of every unit
   const void* a;
   const void* b;
   void* c;
@@ -207,11 +215,13 @@ struct EsmParams {
 
 template <typename Idx>
 __global__ void esm_plan_kernel(const Idx* __restrict__ indptr, int64_t num_rows, int64_t nnz,
-                                int64_t num_units, int64_t* __restrict__ plan) {
-  // plan[w] = largest i in [0, N] with indptr[i] + i <= w * kEsmItems (see spmm_csr.cuh)
+                                int64_t num_units, int64_t* __restrict__ plan, int64_t* __restrict__ planj) {
+  // boundary w: the merge-path point (i, j) on the diagonal w * kEsmStride — i = largest row with
+  // indptr[i] + i <= d (see spmm_csr.cuh) — moved to the end of row i when the row is cut there
+  // and has at most kEsmSlack edges left
   const int64_t w = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (w > num_units) return;
-  int64_t d = w * kEsmItems;
+  int64_t d = w * kEsmStride;
   const int64_t total = num_rows + nnz;
   if (d > total) d = total;
   int64_t lo = 0, hi = num_rows;
@@ -222,7 +232,16 @@ __global__ void esm_plan_kernel(const Idx* __restrict__ indptr, int64_t num_rows
     else
       hi = mid - 1;
   }
-  plan[w] = lo;
+  int64_t i = lo, j = d - lo;
+  if (i < num_rows) {
+    const int64_t begin = static_cast<int64_t>(indptr[i]), end = static_cast<int64_t>(indptr[i + 1]);
+    if (j > begin && end - j <= kEsmSlack) {
+      j = end;
+      i = i + 1;
+    }
+  }
+  plan[w] = i;
+  planj[w] = j;
 }
 
 struct EsmUnit {
@@ -233,28 +252,20 @@ struct EsmUnit {
 template <typename Idx>
 __device__ __forceinline__ EsmUnit esm_unit(const EsmParams<Idx>& p, int64_t w) {
   EsmUnit u;
-  const int64_t total = p.num_rows + p.nnz;
-  const int64_t d0 = w * kEsmItems;
-  int64_t d1 = d0 + kEsmItems;
-  if (d1 > total) d1 = total;
   u.i0 = p.plan[w];
-  const int64_t i1 = p.plan[w + 1];
-  u.j0 = d0 - u.i0;
-  u.R = static_cast<int>(i1 - u.i0);
-  u.nE = static_cast<int>((d1 - i1) - u.j0);
+  u.j0 = p.planj[w];
+  u.R = static_cast<int>(p.plan[w + 1] - u.i0);
+  u.nE = static_cast<int>(p.planj[w + 1] - u.j0);
   return u;
 }
 
-// 1 / x: hardware reciprocal + one Newton step for fp32 (< 1 ulp off the division), a division
-// for fp64
+// 1 / x: the hardware reciprocal for fp32 (1 ulp), a division for fp64
 template <typename A>
 __device__ __forceinline__ A esm_recip(A x) {
-  if constexpr (sizeof(A) == 4) {
-    const float r = __builtin_amdgcn_rcpf(x);
-    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
-  } else {
+  if constexpr (sizeof(A) == 4)
+    return __builtin_amdgcn_rcpf(x);
+  else
     return A(1) / x;
-  }
 }
 
 template <typename A, bool PRECISE>
@@ -298,6 +309,88 @@ __device__ __forceinline__ double esm_dpp(double old, double src) {
   const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(
       static_cast<int>(o >> 32), static_cast<int>(v >> 32), CTRL, ROW_MASK, 0xf, false));
   return __builtin_bit_cast(double, (static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// ---- fp32 segmented scans over the lanes of a wave, written in assembly ---------------------------
+// Step "lane l takes from lane l - d unless a segment starts in (l - d, l]" as ONE instruction per
+// value: the receiving lane's flag is kept as a factor nf (1: no start yet, 0: start seen) and the
+// shifted operand comes in through the DPP modifier,
+//     sum:  x += x[l - d] * nf           v_fmac_f32_dpp
+//     max:  t  = x[l - d] + pen          v_add_f32_dpp      (pen = 0 / -inf)
+//           x  = max(x, t)               v_max_f32
+// (the compiler's version is a DPP move, the operation and a select per value).  Lanes without a
+// source lane are not written (bound_ctrl:0): x stays, and a stale t is a value x has already
+// absorbed.  The s_nop at the head of every block covers the "VALU write -> DPP read" and
+// "EXEC write -> DPP" wait states for whatever the compiler placed in front of it; inside a
+// block the producers are the previous step's instructions, HP or more issue slots away.
+#define DGLA_ESM_SUM_OP(i, C) "v_fmac_f32_dpp %" #i ", %" #i ", %[nf] " C "\n\t"
+#define DGLA_ESM_MAX_OP(i, C) \
+  "v_add_f32_dpp %[t" #i "], %" #i ", %[nf] " C "\n\tv_max_f32 %" #i ", %" #i ", %[t" #i "]\n\t"
+#define DGLA_ESM_R1(OP, C) OP(0, C)
+#define DGLA_ESM_R2(OP, C) DGLA_ESM_R1(OP, C) OP(1, C)
+#define DGLA_ESM_R4(OP, C) DGLA_ESM_R2(OP, C) OP(2, C) OP(3, C)
+#define DGLA_ESM_R8(OP, C) DGLA_ESM_R4(OP, C) OP(4, C) OP(5, C) OP(6, C) OP(7, C)
+#define DGLA_ESM_R16(OP, C) \
+  DGLA_ESM_R8(OP, C) OP(8, C) OP(9, C) OP(10, C) OP(11, C) OP(12, C) OP(13, C) OP(14, C) OP(15, C)
+#define DGLA_ESM_X1 "+v"(x[0])
+#define DGLA_ESM_X2 DGLA_ESM_X1, "+v"(x[1])
+#define DGLA_ESM_X4 DGLA_ESM_X2, "+v"(x[2]), "+v"(x[3])
+#define DGLA_ESM_X8 DGLA_ESM_X4, "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+#define DGLA_ESM_X16 \
+  DGLA_ESM_X8, "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])
+#define DGLA_ESM_T1 [t0] "+v"(t[0])
+#define DGLA_ESM_T2 DGLA_ESM_T1, [t1] "+v"(t[1])
+#define DGLA_ESM_T4 DGLA_ESM_T2, [t2] "+v"(t[2]), [t3] "+v"(t[3])
+#define DGLA_ESM_T8 DGLA_ESM_T4, [t4] "+v"(t[4]), [t5] "+v"(t[5]), [t6] "+v"(t[6]), [t7] "+v"(t[7])
+#define DGLA_ESM_T16                                                                                  \
+  DGLA_ESM_T8, [t8] "+v"(t[8]), [t9] "+v"(t[9]), [t10] "+v"(t[10]), [t11] "+v"(t[11]), [t12] "+v"(t[12]), \
+      [t13] "+v"(t[13]), [t14] "+v"(t[14]), [t15] "+v"(t[15])
+#define DGLA_ESM_SUM_STEP(N, C)                                                             \
+  asm volatile("s_nop 4\n\t" DGLA_ESM_R##N(DGLA_ESM_SUM_OP, C) "v_mul_f32_dpp %[nf], %[nf], %[nf] " C \
+               : DGLA_ESM_X##N, [nf] "+v"(nf));
+#define DGLA_ESM_MAX_STEP(N, C)                                                             \
+  asm volatile("s_nop 4\n\t" DGLA_ESM_R##N(DGLA_ESM_MAX_OP, C) "v_add_f32_dpp %[nf], %[nf], %[nf] " C \
+               : DGLA_ESM_X##N, DGLA_ESM_T##N, [nf] "+v"(nf));
+#define DGLA_ESM_ALL_STEPS(STEP, N)                        \
+  STEP(N, "row_shr:1 row_mask:0xf bank_mask:0xf")          \
+  STEP(N, "row_shr:2 row_mask:0xf bank_mask:0xf")          \
+  STEP(N, "row_shr:4 row_mask:0xf bank_mask:0xf")          \
+  STEP(N, "row_shr:8 row_mask:0xf bank_mask:0xf")          \
+  STEP(N, "row_bcast:15 row_mask:0xa bank_mask:0xf")       \
+  STEP(N, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+
+// x: the lanes' values, f: "a segment starts in this lane"; on return x = segmented inclusive sum
+// over the lanes of the wave and f = "a segment starts in this lane or an earlier one"
+template <int HP>
+__device__ __forceinline__ void esm_scan_sum_f32(float (&x)[HP], int& f) {
+  float nf = f ? 0.f : 1.f;
+  if constexpr (HP == 1) { DGLA_ESM_ALL_STEPS(DGLA_ESM_SUM_STEP, 1) }
+  else if constexpr (HP == 2) { DGLA_ESM_ALL_STEPS(DGLA_ESM_SUM_STEP, 2) }
+  else if constexpr (HP == 4) { DGLA_ESM_ALL_STEPS(DGLA_ESM_SUM_STEP, 4) }
+  else if constexpr (HP == 8) { DGLA_ESM_ALL_STEPS(DGLA_ESM_SUM_STEP, 8) }
+  else { static_assert(HP == 16, "feature widths are padded to 1, 2, 4, 8 or 16"); DGLA_ESM_ALL_STEPS(DGLA_ESM_SUM_STEP, 16) }
+  f = nf != 1.f;
+}
+template <int HP>
+__device__ __forceinline__ void esm_scan_max_f32(float (&x)[HP], int& f) {
+  const float ninf = -__builtin_huge_valf();
+  float nf = f ? ninf : 0.f;  // the penalty added to what comes in from earlier lanes
+  float t[HP];
+#pragma unroll
+  for (int h = 0; h < HP; ++h) t[h] = ninf;
+  if constexpr (HP == 1) { DGLA_ESM_ALL_STEPS(DGLA_ESM_MAX_STEP, 1) }
+  else if constexpr (HP == 2) { DGLA_ESM_ALL_STEPS(DGLA_ESM_MAX_STEP, 2) }
+  else if constexpr (HP == 4) { DGLA_ESM_ALL_STEPS(DGLA_ESM_MAX_STEP, 4) }
+  else if constexpr (HP == 8) { DGLA_ESM_ALL_STEPS(DGLA_ESM_MAX_STEP, 8) }
+  else { static_assert(HP == 16, "feature widths are padded to 1, 2, 4, 8 or 16"); DGLA_ESM_ALL_STEPS(DGLA_ESM_MAX_STEP, 16) }
+  f = nf < 0.f;
+}
+
+// x = max(x, x of the DPP source lane); lanes without a source keep x
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int esm_max_dpp(int x) {
+  const int o = __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xf, false);
+  return o > x ? o : x;
 }
 
 // 16-byte piece i of a wave's staging slice lives at piece esm_swz(i): the global side moves
@@ -359,10 +452,13 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
   int64_t* eid = reinterpret_cast<int64_t*>(wv + kEsmWaves * HP);   // [kEsmItems]
   int* rend = reinterpret_cast<int*>(eid + kEsmItems);      // [kEsmItems + 2]
   int* wf = rend + kEsmItems + 2;                           // [waves] "a segment starts in this wave"
+  unsigned* sb = reinterpret_cast<unsigned*>(wf + kEsmWaves);  // [kEsmItems / 32 + 2] start bits of the edges
   const DT* __restrict__ pa = static_cast<const DT*>(p.a);
   const DT* __restrict__ pb = static_cast<const DT*>(p.b);
   DT* __restrict__ pc = static_cast<DT*>(p.c);
   if (w >= p.num_units) return;  // block-uniform
+  if (lane < kEsmItems / 32 + 2) sb[lane] = 0u;
+  __syncthreads();  // (early: nothing is waiting on memory yet)
 
   const EsmUnit u = esm_unit<Idx>(p, w);
   const int e0 = lane * kEsmEpl;
@@ -405,6 +501,10 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   [[maybe_unused]] f32x4 tmp[4 * (Q > 0 ? Q : 1)], tmp2[BWD ? 4 * (Q > 0 ? Q : 1) : 1];
   const int wave_edges = u.nE - wib * (64 * kEsmEpl);  // edges of this wave's slice (may be <= 0)
+  // slots past the unit's last edge hold the identity of the first reduction (-inf forward, whose
+  // exp is the 0 of the second one; 0 backward) and count as continuing the last edge's segment:
+  // the lane's last group is then always the one of slot 3
+  [[maybe_unused]] const float pad = BWD ? 0.f : -__builtin_huge_valf();
   if (direct) {
 #pragma unroll
     for (int j = 0; j < kEsmEpl; ++j) {
@@ -420,7 +520,7 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
           const int i = 64 * k + wl;
           const bool ok = i / Q < wave_edges;
           tmp[k] = ok ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(BWD ? pb : pa) + base + 4 * i)
-                      : f32x4{0.f, 0.f, 0.f, 0.f};
+                      : f32x4{pad, pad, pad, pad};
           if constexpr (BWD)
             tmp2[k] = ok ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(pa) + base + 4 * i)
                          : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -450,16 +550,25 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
         const int it = lane + kEsmThreads * k;
-        if (it < u.nE)
-          eid[it] = itemv[k];
-        else if (it < items)
-          rend[it - u.nE + 1] = static_cast<int>(itemv[k]);
+        if (it < u.nE) {
+          if (!direct) eid[it] = itemv[k];
+        } else if (it < items) {
+          const int r = static_cast<int>(itemv[k]);  // in [0, nE]
+          rend[it - u.nE + 1] = r;
+          atomicOr(&sb[r >> 5], 1u << (r & 31));
+        }
       }
     }
   }
   const int64_t f0 = static_cast<int64_t>(p.indptr[u.i0]) - u.j0;
   const int first = f0 < 0 ? -1 : static_cast<int>(f0);
-  if (lane == 0) rend[0] = first;
+  if (lane == 0) {
+    rend[0] = first;
+    // the unit's first edge begins a segment and its end closes one (the pieces of rows cut by
+    // the unit boundary are segments of their own; the fix-up kernel joins them)
+    atomicOr(&sb[0], 1u);
+    atomicOr(&sb[u.nE >> 5], 1u << (u.nE & 31));
+  }
   if constexpr (std::is_same<DT, float>::value && (HP == 4 || HP == 8)) {
     if (tr) {  // lane-linear pieces -> this lane's four rows, half of the wave per round
       f32x4* st = reinterpret_cast<f32x4*>(stage);
@@ -508,6 +617,16 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
     DGLA_ESM_LOAD()
   }
 #undef DGLA_ESM_LOAD
+  if (!tr && n_valid < kEsmEpl) {  // (only the unit's last lanes)
+#pragma unroll
+    for (int j = 0; j < kEsmEpl; ++j)
+#pragma unroll
+      for (int h = 0; h < HP; ++h)
+        if (j >= n_valid) {
+          v[j][h] = BWD ? A(0) : -static_cast<A>(__builtin_huge_valf());
+          if constexpr (BWD) v2[j][h] = A(0);
+        }
+  }
 
   // segment bounds
   const int tail_end = (first < 0 && u.R > 0) ? rend[1] : 0;  // edges [0, tail_end) belong to a row begun earlier
@@ -518,65 +637,65 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
   }
   const bool has_carry = carry_begin < u.nE;
   if (lane == 0) p.carry_row[w] = has_carry ? u.i0 + u.R : int64_t(-1);
-  const int nseg = u.R + (has_carry ? 1 : 0);
-  auto seg_end = [&](int sg) { return sg < u.R ? rend[sg + 1] : u.nE; };  // carry segment: sg == R
-  auto seg_start = [&](int sg) { return sg == 0 ? 0 : rend[sg]; };        // = seg_end(sg - 1)
 
-  // segment of every edge: a short search for the first, then a walk
-  int seg[kEsmEpl];
+  // ---- segments from the START BITS of the unit's edges (bit e: a row ends right before edge e,
+  // set by the row-end items while they were staged): the lane reads the bits of its four edges
+  // and of the edge after them; no search through the row ends ------------------------------------
+  unsigned bits;  // bit j: edge e0 + j begins a segment (j = 0 .. 4)
   {
-    int lo = 0, hi = nseg > 0 ? nseg - 1 : 0;
-    while (lo < hi) {  // smallest sg with seg_end(sg) > e0
-      const int mid = (lo + hi) >> 1;
-      if (seg_end(mid) > e0)
-        hi = mid;
-      else
-        lo = mid + 1;
-    }
-    int t = lo;
-#pragma unroll
-    for (int j = 0; j < kEsmEpl; ++j) {
-      const int e = e0 + j;
-      if (e < u.nE)
-        while (e >= seg_end(t)) ++t;
-      seg[j] = e < u.nE ? t : -1;
-    }
+    const unsigned wlo = sb[e0 >> 5], whi = sb[(e0 >> 5) + 1];
+    bits = __builtin_amdgcn_alignbit(whi, wlo, e0 & 31) & 31u;
   }
-  const int sA = n_valid ? seg[0] : -1;
-  const bool a_starts_here = n_valid && seg_start(sA) >= e0;
-  const bool a_ends_here = n_valid && seg_end(sA) <= e0 + n_valid;
+  const unsigned upto_valid = (2u << n_valid) - 1u;  // positions 0 .. n_valid
+  const bool a_starts_here = n_valid && (bits & 1u);
+  const bool a_ends_here = n_valid && (bits & upto_valid & ~1u);
   const bool a_local = a_starts_here && a_ends_here;
-  const int slot_a = n_valid ? seg_start(sA) / kEsmEpl : 0;  // table row of the head segment
   // per edge: continues the previous edge's segment / is in the head segment / is in a segment
-  // that crosses out of the lane (then it is the lane's tail segment, whose table row is this lane)
+  // that begins and ends inside the lane
   bool same[kEsmEpl], in_head[kEsmEpl], local[kEsmEpl];
-  int sZ = -1;
-  bool z_starts_here = false, z_local = false;
-  same[0] = false;
 #pragma unroll
   for (int j = 0; j < kEsmEpl; ++j) {
     const bool ok = j < n_valid;
-    if (j > 0) same[j] = seg[j] == seg[j - 1];
-    in_head[j] = ok && seg[j] == sA;
-    const bool lc = ok && seg_start(seg[j]) >= e0 && seg_end(seg[j]) <= e0 + n_valid;
-    local[j] = lc;
-    if (j + 1 == n_valid) {
-      sZ = seg[j];
-      z_starts_here = seg_start(seg[j]) >= e0;
-      z_local = lc;
+    const unsigned through_j = (2u << j) - 1u;  // positions 0 .. j
+    same[j] = j > 0 && (!ok || !((bits >> j) & 1u));
+    in_head[j] = ok && !(bits & through_j & ~1u);
+    local[j] = ok && (bits & through_j) && (bits & upto_valid & ~through_j);
+  }
+  // the lane's tail segment (the one of its last valid edge) begins in this lane / also ends in it
+  const bool z_starts_here = n_valid && (bits & (upto_valid >> 1));
+  const bool z_local = z_starts_here && ((bits >> n_valid) & 1u);
+  // table row of the head segment = the lane it begins in: the nearest earlier lane of this wave
+  // whose tail segment begins there (a max-scan of lane numbers), else the last start bit in front
+  // of the wave's edges (every wave looks through the bit words of the waves before it)
+  int slot_a;
+  {
+    int y = z_starts_here ? lane : -1;
+    y = esm_max_dpp<0x111, 0xf>(y);
+    y = esm_max_dpp<0x112, 0xf>(y);
+    y = esm_max_dpp<0x114, 0xf>(y);
+    y = esm_max_dpp<0x118, 0xf>(y);
+    y = esm_max_dpp<0x142, 0xa>(y);
+    y = esm_max_dpp<0x143, 0xc>(y);
+    const int prev = esm_dpp<0x138, 0xf>(-1, y);  // wave_shr:1; lane 0 keeps -1
+    int before = -1;  // last start position in front of this wave's first edge
+    if (wib > 0) {
+      const unsigned word = wl < 8 * wib ? sb[wl] : 0u;
+      int t = word ? 32 * wl + 31 - __builtin_clz(word) : -1;
+      t = esm_max_dpp<0x111, 0xf>(t);
+      t = esm_max_dpp<0x112, 0xf>(t);
+      t = esm_max_dpp<0x114, 0xf>(t);
+      t = esm_max_dpp<0x118, 0xf>(t);
+      t = esm_max_dpp<0x142, 0xa>(t);
+      before = __builtin_amdgcn_readlane(t, 31);  // 8 * wib <= 24 words: rows 0 and 1
     }
+    const int from_before = before < 0 ? 0 : before >> 2;
+    slot_a = a_starts_here ? lane : (prev > from_before ? prev : from_before);
   }
   const int slot_z = z_starts_here ? lane : slot_a;  // a tail that came in from earlier lanes IS the head
-  (void)sZ;
 
-  // value of the lane's LAST valid edge (n_valid is 4 except in the unit's last lane) — a select
-  // chain over scalars: selecting between ARRAY elements would push the array into scratch memory
-  auto last_of = [&](A a0, A a1, A a2, A a3) {
-    return n_valid >= 4 ? a3 : (n_valid == 3 ? a2 : (n_valid == 2 ? a1 : a0));
-  };
-  // ghead[h] / glast[h] = OP over the edges of the lane's head / tail segment; APPLY(j, h, b) runs
-  // for every edge with b = OP over the lane's edges in the same segment
-#define DGLA_ESM_GROUPS(OP, APPLY)                                                  \
+  // grp[j][h] = OP over the lane's edges in edge j's segment; ghead[h] / glast[h] = that of the
+  // lane's head / tail segment
+#define DGLA_ESM_GROUPS(OP)                                                         \
   _Pragma("unroll") for (int h = 0; h < HP; ++h) {                                  \
     const A f0 = v[0][h];                                                           \
     const A f1 = same[1] ? OP(f0, v[1][h]) : v[1][h];                                \
@@ -587,8 +706,16 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
     const A b1 = same[2] ? b2 : f1;                                                 \
     const A b0 = same[1] ? b1 : f0;                                                 \
     ghead[h] = b0;                                                                  \
-    glast[h] = last_of(b0, b1, b2, b3);                                              \
-    APPLY(0, h, b0) APPLY(1, h, b1) APPLY(2, h, b2) APPLY(3, h, b3)                  \
+    glast[h] = b3;                                                                  \
+    grp[0][h] = b0, grp[1][h] = b1, grp[2][h] = b2, grp[3][h] = b3;                  \
+  }
+  // stat[j][h] = OP over the WHOLE segment of edge j: the lane's own value for a segment inside the
+  // lane, else the table row of the head / tail segment (two rows per lane)
+#define DGLA_ESM_WHOLE(TABLE)                                                        \
+  _Pragma("unroll") for (int h = 0; h < HP; ++h) {                                  \
+    const A ta = (TABLE)[slot_a * HP + h], tz = (TABLE)[slot_z * HP + h];            \
+    _Pragma("unroll") for (int j = 0; j < kEsmEpl; ++j)                              \
+      grp[j][h] = local[j] ? grp[j][h] : (in_head[j] ? ta : tz);                     \
   }
   // Segmented inclusive scan over the lanes of x = the lane's tail partial, f = "the tail segment
   // starts in this lane"; afterwards the previous lane's scanned value = everything of this
@@ -603,7 +730,7 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
       }                                                                                             \
       f |= fp;                                                                                      \
     }
-#define DGLA_ESM_PUBLISH(TABLE, IDENT, OP)                                                        \
+#define DGLA_ESM_PUBLISH(TABLE, IDENT, OP, IS_MAX)                                                \
   {                                                                                                \
     A x[HP];                                                                                       \
     _Pragma("unroll") for (int h = 0; h < HP; ++h) x[h] = n_valid ? glast[h] : (IDENT);             \
@@ -611,12 +738,16 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
     /* inside the wave: rows of 16 lanes (row_shr 1, 2, 4, 8), then row 0 -> 1 and 2 -> 3         \
        (row_bcast:15), then rows 0-1 -> 2-3 (row_bcast:31); a lane without a source sees            \
        (IDENT, no start) and stays as it is */                                                      \
-    DGLA_ESM_SCAN_STEP(0x111, 0xf, IDENT, OP)                                                       \
-    DGLA_ESM_SCAN_STEP(0x112, 0xf, IDENT, OP)                                                       \
-    DGLA_ESM_SCAN_STEP(0x114, 0xf, IDENT, OP)                                                       \
-    DGLA_ESM_SCAN_STEP(0x118, 0xf, IDENT, OP)                                                       \
-    DGLA_ESM_SCAN_STEP(0x142, 0xa, IDENT, OP)                                                       \
-    DGLA_ESM_SCAN_STEP(0x143, 0xc, IDENT, OP)                                                       \
+    if constexpr (std::is_same<A, float>::value) {                                                  \
+      if constexpr (IS_MAX) esm_scan_max_f32<HP>(x, f); else esm_scan_sum_f32<HP>(x, f);            \
+    } else {                                                                                        \
+      DGLA_ESM_SCAN_STEP(0x111, 0xf, IDENT, OP)                                                     \
+      DGLA_ESM_SCAN_STEP(0x112, 0xf, IDENT, OP)                                                     \
+      DGLA_ESM_SCAN_STEP(0x114, 0xf, IDENT, OP)                                                     \
+      DGLA_ESM_SCAN_STEP(0x118, 0xf, IDENT, OP)                                                     \
+      DGLA_ESM_SCAN_STEP(0x142, 0xa, IDENT, OP)                                                     \
+      DGLA_ESM_SCAN_STEP(0x143, 0xc, IDENT, OP)                                                     \
+    }                                                                                               \
     /* across the four waves: what the earlier waves hold of the segment running into this one */   \
     if (wl == 63) {                                                                                 \
       wf[wib] = f;                                                                                  \
@@ -638,7 +769,15 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
     }                                                                                               \
   }
   const A neg_inf = -static_cast<A>(__builtin_huge_valf());
-  auto f_max = [](A a, A b) { return a > b ? a : b; };
+  auto f_max = [](A a, A b) {
+    if constexpr (sizeof(A) == 4) {  // one v_max_f32 (fmaxf() adds two canonicalising ones, a > b ? a : b a select)
+      float r;
+      asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+      return r;
+    } else {
+      return a > b ? a : b;
+    }
+  };
   auto f_add = [](A a, A b) { return a + b; };
   A ghead[HP], glast[HP];
   const bool pub_tail = first < 0 && u.R > 0 && lane == 0;  // row begun in an earlier unit
@@ -658,53 +797,41 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
         carry_stat[(OFF) + h] = z_local ? glast[h] : (TABLE)[slot_z * HP + h];                          \
   }
 
+  A grp[kEsmEpl][HP];
   if constexpr (BWD) {
-    // sum of sds; local segments finish on the spot, the others wait for the table
-#define DGLA_ESM_SUB_LOCAL(j, h, b) \
-  if (local[j]) v[j][h] = v[j][h] - (b) * v2[j][h];
-    DGLA_ESM_GROUPS(f_add, DGLA_ESM_SUB_LOCAL)
-#undef DGLA_ESM_SUB_LOCAL
-    DGLA_ESM_PUBLISH(ts, A(0), f_add)
+    // sum of sds over the row, then sds - out * sum (parts of rows cut by the unit boundary are
+    // rewritten by the fix-up)
+    DGLA_ESM_GROUPS(f_add)
+    DGLA_ESM_PUBLISH(ts, A(0), f_add, false)
     __syncthreads();
     DGLA_ESM_STATS(ts, A(0), 0)
+    DGLA_ESM_WHOLE(ts)
 #pragma unroll
     for (int j = 0; j < kEsmEpl; ++j)
 #pragma unroll
-      for (int h = 0; h < HP; ++h)  // (parts of rows cut by the unit boundary are rewritten by the fix-up)
-        if (j < n_valid && !local[j])
-          v[j][h] = v[j][h] - ts[(in_head[j] ? slot_a : slot_z) * HP + h] * v2[j][h];
+      for (int h = 0; h < HP; ++h) v[j][h] = v[j][h] - grp[j][h] * v2[j][h];
   } else {
-    // max; local segments go straight on to exp(x - M), the others wait for the table
-#define DGLA_ESM_EXP_LOCAL(j, h, b) \
-  if (local[j]) v[j][h] = esm_expx<A, PRECISE>(v[j][h] - (b));
-    DGLA_ESM_GROUPS(f_max, DGLA_ESM_EXP_LOCAL)
-#undef DGLA_ESM_EXP_LOCAL
-    DGLA_ESM_PUBLISH(tm, neg_inf, f_max)
+    // max, exp(x - M)
+    DGLA_ESM_GROUPS(f_max)
+    DGLA_ESM_PUBLISH(tm, neg_inf, f_max, true)
     __syncthreads();
     DGLA_ESM_STATS(tm, neg_inf, 0)
+    DGLA_ESM_WHOLE(tm)
 #pragma unroll
     for (int j = 0; j < kEsmEpl; ++j)
 #pragma unroll
-      for (int h = 0; h < HP; ++h)
-        if (j < n_valid && !local[j])
-          v[j][h] = esm_expx<A, PRECISE>(v[j][h] - tm[(in_head[j] ? slot_a : slot_z) * HP + h]);
-    // sum; local segments are normalised on the spot
-    const bool part_a = (sA == 0 && first < 0) || sA == u.R;  // the head segment is cut by the unit boundary
-#define DGLA_ESM_NORM_LOCAL(j, h, b) \
-  if (local[j] && !(in_head[j] && part_a) && !(seg[j] == u.R)) v[j][h] = v[j][h] * esm_recip<A>(b);
-    DGLA_ESM_GROUPS(f_add, DGLA_ESM_NORM_LOCAL)
-#undef DGLA_ESM_NORM_LOCAL
-    DGLA_ESM_PUBLISH(ts, A(0), f_add)
+      for (int h = 0; h < HP; ++h) v[j][h] = esm_expx<A, PRECISE>(v[j][h] - grp[j][h]);
+    // sum, e / S (pieces of rows cut by the unit boundary are normalised by their partial sum here:
+    // they are not stored, the fix-up kernel writes those edges)
+    DGLA_ESM_GROUPS(f_add)
+    DGLA_ESM_PUBLISH(ts, A(0), f_add, false)
     __syncthreads();
     DGLA_ESM_STATS(ts, A(0), dim)
+    DGLA_ESM_WHOLE(ts)
 #pragma unroll
-    for (int j = 0; j < kEsmEpl; ++j) {
-      const bool partial = (seg[j] == 0 && first < 0) || seg[j] == u.R;  // stays un-normalised: fix-up
-      if (j >= n_valid || local[j] || partial) continue;
+    for (int j = 0; j < kEsmEpl; ++j)
 #pragma unroll
-      for (int h = 0; h < HP; ++h)
-        v[j][h] = v[j][h] * esm_recip<A>(ts[(in_head[j] ? slot_a : slot_z) * HP + h]);
-    }
+      for (int h = 0; h < HP; ++h) v[j][h] = v[j][h] * esm_recip<A>(grp[j][h]);
   }
 
   // ---- store: complete rows are final; parts of rows cut by the unit boundary are left to the
@@ -767,21 +894,25 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
 
 #undef DGLA_ESM_STATS
 #undef DGLA_ESM_GROUPS
+#undef DGLA_ESM_WHOLE
 #undef DGLA_ESM_PUBLISH
 #undef DGLA_ESM_SCAN_STEP
 
 constexpr int kFixU = 8;  // edges in flight per lane of the fix-up kernel
+constexpr int kFixB = 8;  // unit boundaries looked at by one wavefront of the fix-up kernel
 
+// The row that unit w carries into unit w + 1 (row >= 0), done by one wavefront: the part of it
+// inside unit w plus, when the row ends in unit w + 1, that unit's tail — one contiguous range of
+// the row's edges, found from three neighbouring carry_row entries, two plan entries and two row
+// pointers (three dependent memory round trips before the edges; walking unit by unit through
+// esm_unit() made it ~16 and the kernel latency-bound).
 template <typename Idx, typename DT, bool BWD, bool PRECISE>
-__global__ __launch_bounds__(256) void edge_softmax_fixup_kernel(const EsmParams<Idx> p) {
+__device__ __forceinline__ void edge_softmax_fixup_boundary(const EsmParams<Idx>& p, int64_t w, int64_t row) {
   using A = typename Acc<DT>::type;
-  // one wavefront per unit, four units per workgroup (a 64-thread workgroup per unit made the
-  // launch dispatch-bound: 251 k workgroups for the 62 M-edge graph)
-  const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (w >= p.num_units) return;
   const int dim = p.dim, hp = 1 << p.log2_hp;
-  const EsmUnit u = esm_unit<Idx>(p, w);
-  const int64_t f = static_cast<int64_t>(p.indptr[u.i0]) - u.j0;
+  const int64_t crm = w > 0 ? p.carry_row[w - 1] : int64_t(-1);
+  const int64_t crp = w + 1 < p.num_units ? p.carry_row[w + 1] : int64_t(-1);
+  const int64_t j0 = p.planj[w], j1 = p.planj[w + 1];  // first edge of unit w / of unit w + 1
   const A* cs = static_cast<const A*>(p.carry_stat);
   const A* ts = static_cast<const A*>(p.tail_stat);
   const DT* __restrict__ pa = static_cast<const DT*>(p.a);
@@ -790,43 +921,32 @@ __global__ __launch_bounds__(256) void edge_softmax_fixup_kernel(const EsmParams
   const int lane = threadIdx.x & 63;
   const int h = lane & (hp - 1);
   const int es = 64 >> p.log2_hp;
-
-  // part: 0 = this unit's carry segment, 1 = this unit's tail segment
-  for (int part = 0; part < 2; ++part) {
-    int64_t row, sa, s2;  // run of carries [sa, s2) plus the tail held by unit s2
-    int t0, t1;
-    if (part == 0) {
-      row = p.carry_row[w];
-      if (row < 0) continue;
-      sa = w;
-      while (sa > 0 && p.carry_row[sa - 1] == row) --sa;
-      s2 = w + 1;
-      while (s2 < p.num_units && p.carry_row[s2] == row) ++s2;
-      const int64_t cb = static_cast<int64_t>(p.indptr[u.i0 + u.R]) - u.j0;
-      t0 = cb < 0 ? 0 : static_cast<int>(cb);
-      t1 = u.nE;
-    } else {
-      if (!(f < 0 && u.R > 0)) continue;
-      row = u.i0;
-      s2 = w;
-      sa = w;
-      while (sa > 0 && p.carry_row[sa - 1] == row) --sa;
-      t0 = 0;
-      t1 = static_cast<int>(static_cast<int64_t>(p.indptr[u.i0 + 1]) - u.j0);
-    }
-    if (h >= dim) continue;
+  const int64_t row_begin = static_cast<int64_t>(p.indptr[row]), row_end = static_cast<int64_t>(p.indptr[row + 1]);
+  // units [sa, s2) carry the row, unit s2 holds its tail
+  int64_t sa = w, s2 = w + 1;
+  if (crm == row) {
+    sa = w - 1;
+    while (sa > 0 && p.carry_row[sa - 1] == row) --sa;
+  }
+  if (crp == row) {
+    s2 = w + 2;
+    while (s2 < p.num_units && p.carry_row[s2] == row) ++s2;
+  }
+  const int64_t t0 = crm == row ? j0 : row_begin;  // this wave's edges of the row: [t0, t1)
+  const int64_t t1 = crp == row ? j1 : row_end;
+  {
+    if (h >= dim) return;
     if constexpr (BWD) {
       A sum = A(0);
       for (int64_t q = sa; q < s2; ++q) sum += cs[q * 2 * dim + h];
       sum += ts[s2 * 2 * dim + h];
       // kFixU edges in flight per lane: the loop is a chain of HBM round trips otherwise
-      for (int tb = t0 + (lane >> p.log2_hp); tb < t1; tb += es * kFixU) {
+      for (int64_t tb = t0 + (lane >> p.log2_hp); tb < t1; tb += es * kFixU) {
         int64_t off[kFixU];
         A xb[kFixU], xa[kFixU];
 #pragma unroll
         for (int k = 0; k < kFixU; ++k) {
-          const int t = tb + k * es < t1 ? tb + k * es : tb;
-          const int64_t j = u.j0 + t;
+          const int64_t j = tb + k * es < t1 ? tb + k * es : tb;
           off[k] = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + h;
         }
 #pragma unroll
@@ -854,13 +974,12 @@ __global__ __launch_bounds__(256) void edge_softmax_fixup_kernel(const EsmParams
       // straight from the scores (the main kernel wrote nothing for these edges: re-reading x
       // costs what re-reading an un-normalised output would, and the main kernel saves the write)
       const A inv = esm_recip<A>(S);
-      for (int tb = t0 + (lane >> p.log2_hp); tb < t1; tb += es * kFixU) {
+      for (int64_t tb = t0 + (lane >> p.log2_hp); tb < t1; tb += es * kFixU) {
         int64_t off[kFixU];
         A xc[kFixU];
 #pragma unroll
         for (int k = 0; k < kFixU; ++k) {
-          const int t = tb + k * es < t1 ? tb + k * es : tb;
-          const int64_t j = u.j0 + t;
+          const int64_t j = tb + k * es < t1 ? tb + k * es : tb;
           off[k] = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + h;
         }
 #pragma unroll
@@ -873,10 +992,28 @@ __global__ __launch_bounds__(256) void edge_softmax_fixup_kernel(const EsmParams
   }
 }
 
+// kFixB consecutive unit boundaries per wavefront, four wavefronts per workgroup: boundaries that
+// cut no row (all of them, on a graph without rows longer than kEsmSlack) cost one load for the
+// kFixB of them; the others are done one after the other by the whole wavefront.
+template <typename Idx, typename DT, bool BWD, bool PRECISE>
+__global__ __launch_bounds__(256) void edge_softmax_fixup_kernel(const EsmParams<Idx> p) {
+  const int64_t w0 = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * kFixB;
+  if (w0 >= p.num_units) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t mine = (lane < kFixB && w0 + lane < p.num_units) ? p.carry_row[w0 + lane] : int64_t(-1);
+  uint64_t cut = __ballot(mine >= 0);
+  while (cut) {
+    const int k = __builtin_ctzll(cut);
+    cut &= cut - 1;
+    const int64_t row = __shfl(mine, k, 64);
+    edge_softmax_fixup_boundary<Idx, DT, BWD, PRECISE>(p, w0 + k, row);
+  }
+}
+
 struct EsmGeometry {
   int log2_hp;
   int64_t num_units;
-  size_t off_plan, off_carry_row, off_carry_stat, off_tail_stat, total;
+  size_t off_plan, off_planj, off_carry_row, off_carry_stat, off_tail_stat, total;
 };
 
 static size_t esm_align(size_t x) { return (x + 255) / 256 * 256; }
@@ -885,9 +1022,11 @@ static EsmGeometry esm_geometry(int64_t num_rows, int64_t nnz, int dim, size_t a
   EsmGeometry g;
   g.log2_hp = 0;
   while ((1 << g.log2_hp) < dim) ++g.log2_hp;
-  g.num_units = (num_rows + nnz + kEsmItems - 1) / kEsmItems;
+  g.num_units = (num_rows + nnz + kEsmStride - 1) / kEsmStride;
   size_t off = 0;
   g.off_plan = off;
+  off = esm_align(off + sizeof(int64_t) * (g.num_units + 1));
+  g.off_planj = off;
   off = esm_align(off + sizeof(int64_t) * (g.num_units + 1));
   g.off_carry_row = off;
   off = esm_align(off + sizeof(int64_t) * g.num_units);
@@ -915,6 +1054,7 @@ static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void*
   p.nnz = csr.nnz;
   p.num_units = g.num_units;
   p.plan = reinterpret_cast<const int64_t*>(wsp + g.off_plan);
+  p.planj = reinterpret_cast<const int64_t*>(wsp + g.off_planj);
   p.a = a;
   p.b = b;
   p.c = c;
@@ -937,13 +1077,15 @@ static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void*
   const size_t slices = (sizeof(DT) == 4 && (hp == 4 || hp == 8)) ? size_t(kEsmItems / 2) * hp * 4 : 0;
   p.region_bytes = static_cast<int>(((tables > slices ? tables : slices) + 15) / 16 * 16);
   const size_t per_block = p.region_bytes + sizeof(A) * kEsmWaves * hp +
-                           sizeof(int64_t) * kEsmItems + sizeof(int) * (kEsmItems + 2 + kEsmWaves) + 8;
+                           sizeof(int64_t) * kEsmItems + sizeof(int) * (kEsmItems + 2 + kEsmWaves) +
+                           sizeof(unsigned) * (kEsmItems / 32 + 2) + 8;
   p.wave_lds_bytes = static_cast<int>((per_block + 15) / 16 * 16);
   if (!plan_valid) {
     const int64_t n = g.num_units + 1;
     hipLaunchKernelGGL((esm_plan_kernel<Idx>), dim3(static_cast<unsigned>((n + 255) / 256)),
                        dim3(256), 0, s, p.indptr, csr.num_rows, csr.nnz, g.num_units,
-                       reinterpret_cast<int64_t*>(wsp + g.off_plan));
+                       reinterpret_cast<int64_t*>(wsp + g.off_plan),
+                       reinterpret_cast<int64_t*>(wsp + g.off_planj));
   }
   const unsigned blocks = static_cast<unsigned>(g.num_units);
   const size_t lds = static_cast<size_t>(p.wave_lds_bytes);
@@ -954,12 +1096,12 @@ static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void*
       hipLaunchKernelGGL((edge_softmax_merge_kernel<Idx, DT, true, kPrecise, HPV>), dim3(blocks),      \
                          dim3(kEsmThreads), lds, s, p);                                                  \
       hipLaunchKernelGGL((edge_softmax_fixup_kernel<Idx, DT, true, kPrecise>),                        \
-                         dim3(static_cast<unsigned>((g.num_units + 3) / 4)), dim3(256), 0, s, p);     \
+                         dim3(static_cast<unsigned>((g.num_units + 4 * kFixB - 1) / (4 * kFixB))), dim3(256), 0, s, p);     \
     } else {                                                                                          \
       hipLaunchKernelGGL((edge_softmax_merge_kernel<Idx, DT, false, kPrecise, HPV>), dim3(blocks),     \
                          dim3(kEsmThreads), lds, s, p);                                                  \
       hipLaunchKernelGGL((edge_softmax_fixup_kernel<Idx, DT, false, kPrecise>),                       \
-                         dim3(static_cast<unsigned>((g.num_units + 3) / 4)), dim3(256), 0, s, p);     \
+                         dim3(static_cast<unsigned>((g.num_units + 4 * kFixB - 1) / (4 * kFixB))), dim3(256), 0, s, p);     \
     }                                                                                                 \
   } while (0)
   switch (hp) {
