@@ -167,23 +167,24 @@ __global__ __launch_bounds__(256) void edge_softmax_kernel(
 // The lane-group kernel above gives one row to one lane group, so a 10k-edge hub row is
 // walked serially by 4-64 lanes while the rest of the chip idles (measured on the
 // ogbn-arxiv-shaped graph: 0.53 ms for 80 MB of scores).  Here the CSR is cut by merge path
-// into units of kEsmItems items (edges + row ends) exactly like the SpMM; one wavefront per
-// unit:
-//   1. stage the unit's row ends and edge ids in LDS; every lane loads four consecutive edges of
-//      the unit with all their features into registers (one HBM round trip for the whole unit);
-//   2. per-segment max / sum through small LDS tables (a segment is a row, or the part of a row
-//      inside this unit); the values never leave the registers;
+// into units of at most kEsmItems items (edges + row ends) like the SpMM; one workgroup per unit:
+//   1. stage the unit's row ends (and edge ids) in LDS, the row ends also as START BITS of the
+//      edges; every lane loads four consecutive edges of the unit with all their features into
+//      registers (one HBM round trip for the whole unit);
+//   2. per-segment max / sum — a segment is a row, or the piece of a row inside this unit: inside
+//      a lane in registers, across lanes by a segmented DPP scan, across waves through LDS; the
+//      values never leave the registers;
 //   3. rows that lie entirely inside the unit are finished and written (read once, written
-//      once); a row that straddles units leaves (max, sum) per part in the workspace and its
-//      edges un-normalised;
-//   4. a fix-up kernel, one 64-lane block per unit, merges the parts of each straddling row
-//      ((m, s) pairs combine as S = sum_i s_i * exp(m_i - M)) and rescales its own unit's
-//      edges, so even a hub row is handled by as many blocks as it has units.
+//      once); a row cut by a unit boundary leaves (max, sum) per piece in the workspace and its
+//      edges unwritten;
+//   4. a fix-up kernel merges the pieces of each cut row ((m, s) pairs combine as
+//      S = sum_i s_i * exp(m_i - M)) and writes its edges from the scores, one wavefront per
+//      boundary, so even a hub row is handled by as many wavefronts as it has units.
 // =========================================================================================
-// One workgroup per unit.  Measured at 62 M edges, H = 8 fp32, forward / backward: 64 threads x
-// 256 items 1.67 / 1.72 ms (48 % of the edges in rows cut by a unit boundary -> fix-up traffic),
-// 256 x 1024 **1.34 / 1.49 ms**, 512 x 2048 1.53 / 2.28 ms (one workgroup per CU: the barriers of
-// the cross-wave scan are no longer hidden).
+// Measured at 62 M edges, H = 8 fp32, forward / backward: 64 threads x 256 items 1.67 / 1.72 ms
+// (48 % of the edges in rows cut by a unit boundary -> fix-up traffic), 256 x 1024 1.34 / 1.49 ms,
+// 512 x 2048 1.53 / 2.28 ms (one workgroup per CU: the barriers of the cross-wave scan are no longer
+// hidden); 256 x 1024 with start bits, row-aligned boundaries and assembly scans **1.00 / 1.09 ms**.
 constexpr int kEsmThreads = 256;
 constexpr int kEsmWaves = kEsmThreads / 64;
 constexpr int kEsmItems = 4 * kEsmThreads;        // items (edges + row ends) a unit holds at most
@@ -399,27 +400,32 @@ __device__ __forceinline__ int esm_max_dpp(int x) {
 // (every 16-byte bank group is hit by exactly 4 of the 64 lanes, the minimum for ds_*_b128).
 __device__ __forceinline__ int esm_swz(int i) { return i ^ ((i >> 4) & 15); }
 
-// One workgroup (kEsmThreads = 256 lanes) per unit of kEsmItems = 1024 items.  Every lane owns kEsmEpl = 4 CONSECUTIVE edges of the unit and keeps
-// all HP features of them in registers: the scores travel HBM -> registers -> HBM (for edge ids =
-// positions a lane's four rows are 4 * dim * s contiguous bytes: 16-byte loads and stores); LDS
-// holds only the unit's row ends, its edge ids and two 64-row tables.
+// One workgroup (kEsmThreads = 256 lanes) per unit of at most kEsmItems = 1024 items.  Every lane
+// owns kEsmEpl = 4 CONSECUTIVE edges of the unit and keeps all HP features of them in registers:
+// the scores travel HBM -> registers -> HBM (for edge ids = positions a lane's four rows are
+// 4 * dim * s contiguous bytes); LDS holds the unit's row ends, the start bits of its edges, its
+// edge ids and two 256-row tables.
 //
-// A segment is a row, or the part of a row inside this unit.  A lane's edges are consecutive, so
-// its segments are: possibly one that began in an earlier lane (its "head"), segments lying wholly
-// inside the lane ("local"), possibly one that goes on into later lanes (its "tail"; head == tail
-// when the whole lane sits inside one long row).  Local segments are reduced in registers with one
-// forward and one backward sweep over the four edges.  Crossing segments are reduced ACROSS lanes
-// with a segmented inclusive scan over (tail-starts-here flag, tail partial) — 6 shuffle steps
-// inside each wave, then one hand-over of the four waves' last values through LDS, for any mix of
-// row lengths — after which the lane where a crossing segment ENDS holds its total and
-// leaves it in the table row of the lane the segment STARTED in (unique: at most one segment
-// crosses out of a lane).  Everybody then reads the totals it needs.
+// A segment is a row, or the piece of a row inside this unit; edge e begins one when a row ends
+// right before it (bit e of the start-bit mask, set while the row ends are staged; the unit's
+// first edge and its end count as bounds too).  A lane's edges are consecutive, so its segments
+// are: possibly one that began in an earlier lane (its "head"), segments lying wholly inside the
+// lane ("local"), possibly one that goes on into later lanes (its "tail"; head == tail when the
+// whole lane sits inside one long row) — all read off the five start bits of the lane's edges
+// and the edge after them.  Local segments are reduced in registers with one forward and one
+// backward sweep over the four edges.  Crossing segments are reduced ACROSS lanes with a
+// segmented inclusive scan over (tail-starts-here flag, tail partial) — 6 DPP steps inside each
+// wave, then one hand-over of the four waves' last values through LDS, for any mix of row lengths
+// — after which the lane where a crossing segment ENDS holds its total and leaves it in the
+// table row of the lane the segment STARTED in (unique: at most one segment crosses out of a
+// lane).  Everybody then reads the two table rows it may need (head, tail).
 //   forward : max -> exp(x - M) -> sum -> scale by 1 / S; segments cut by the unit boundary only
-//             publish (M, S): the fix-up kernel, which sees all parts of the row, writes their edges
+//             publish (M, S): the fix-up kernel, which sees all pieces of the row, writes their edges
 //   backward: sum(sds) -> c = sds - sum * out
-// A hub row and forty 5-edge rows cost the same.  (The first version of this kernel combined
-// lanes through ds_max / ds_add atomics on the tables and spent half of its cycles in LDS issue
-// stalls — 64 lanes on a handful of addresses serialise: profiles/r2/softmax_pmc_atomics.txt.)
+// A hub row and forty 5-edge rows cost the same.  (Earlier versions: ds_max / ds_add atomics on
+// the tables spent half of their cycles in LDS issue stalls, profiles/r2/softmax_pmc_atomics.txt;
+// a binary search through the row ends for every lane's first edge, ds_bpermute shuffles and
+// compiler-generated selects made the forward pass VALU-bound, profiles/r2/softmax_pmc_valu.txt.)
 constexpr int kEsmEpl = kEsmItems / kEsmThreads;
 static_assert(kEsmEpl == 4, "the sweeps below are written out for four edges per lane");
 
