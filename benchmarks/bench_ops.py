@@ -277,6 +277,33 @@ def c5(dev, args):
     emit("C5", "one relation copy_u_sum bf16 F=256 (write)", e, ms, mn, e * (f * s + i) + (n + 1) * i + n * f * s)
 
 
+def c5max(dev, args):
+    """Hetero max with type trackers: 8 relations x 2.5 M edges into one node type of 2 M nodes,
+    F = 64 fp32, through the operator layer (`_gspmm_hetero`): the reference's running compare
+    relation by relation (2 launches + scratch per relation) against ONE stacked launch."""
+    from dgl_amd import sparse_kernels
+    from dgl_amd.graph_index import GraphIndex, Relation
+
+    n, e, f, r = 2_000_000 // args.scale, 2_500_000 // args.scale, 64, 8
+    torch.manual_seed(4)
+    x = torch.rand(n, f, device=dev) + 1
+    rels = []
+    for k in range(r):
+        g = synth_csr(n, n, e, "U", seed=200 + k, device=dev)
+        rels.append(Relation(n, n, csc=(g["indptr"], g["indices"], None), idtype=torch.int32, device=dev))
+    gidx = GraphIndex([n], [(0, 0)] * r, rels)
+    u = (x,)
+    e_t = tuple([None] * r)
+    s, i = 4, 4
+    for fused, tag in ((False, "running compare relation by relation"), (True, "ONE stacked launch + arg pass")):
+        sparse_kernels.FUSE_HETERO = fused
+        ms, mn = timeit(lambda: sparse_kernels._gspmm_hetero(gidx, "copy_lhs", "max", 1, u + e_t), reps=5, warm=2)
+        # compulsory: every edge's source row + index (+ relation byte when stacked), out + 2 id arrays written
+        nb = r * e * (f * s + i + (1 if fused else 0)) + (n + 1) * i + n * f * (s + 2 * i)
+        emit("C5", "hetero copy_u_max + trackers, 8 relations, fp32 F=64: %s" % tag, r * e, ms, mn, nb)
+    sparse_kernels.FUSE_HETERO = True
+
+
 def seg(dev, args):
     """Segment reduce / scatter add at readout-like shapes: F = 100 fp32.
     (a) 62 M rows in 2.4 M segments of C2's degree sequence (= copy_e SpMM of C2),
@@ -522,7 +549,7 @@ def main():
     global VERIFY
     VERIFY = args.verify
     dev = torch.device("cuda:0")
-    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("SEG", seg), ("MM", mm), ("SAMPLE", sample), ("GAT", gat_graph), ("FMT", fmt)):
+    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("C5MAX", c5max), ("SEG", seg), ("MM", mm), ("SAMPLE", sample), ("GAT", gat_graph), ("FMT", fmt)):
         if args.only and name not in args.only.split(","):
             continue
         fn(dev, args)

@@ -67,6 +67,14 @@ LIB.dgla_spmm_csr_stacked.argtypes = [c_char_p, P(CSR), c_void_p, c_int, c_int, 
 LIB.dgla_spmm_csr_stacked_workspace_bytes.restype = c_size_t
 LIB.dgla_spmm_csr_stacked_workspace_bytes.argtypes = [c_char_p, P(CSR), c_int, P(Tensor), P(Tensor),
                                                       P(Tensor)]
+LIB.dgla_spmm_csr_stacked_cmp.restype = c_int
+LIB.dgla_spmm_csr_stacked_cmp.argtypes = [c_char_p, c_char_p, P(CSR), c_void_p, c_int, c_void_p, c_void_p,
+                                          c_int, P(Tensor), P(Tensor), c_void_p, c_void_p, P(Tensor),
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                          c_uint32, c_void_p]
+LIB.dgla_spmm_csr_stacked_cmp_workspace_bytes.restype = c_size_t
+LIB.dgla_spmm_csr_stacked_cmp_workspace_bytes.argtypes = [c_char_p, c_char_p, P(CSR), c_int, P(Tensor),
+                                                          P(Tensor), P(Tensor)]
 LIB.dgla_spmm_coo.restype = c_int
 LIB.dgla_spmm_coo.argtypes = [c_char_p, c_char_p, P(COO), c_int, P(Tensor), P(Tensor), P(Tensor),
                               c_void_p, c_void_p, c_void_p]

@@ -287,6 +287,36 @@ static int build_spmm_launch(const char* op_s, const char* red_s, const dgla_csr
 
 using namespace dgla;
 
+// ---- stacked max / min: winning stacked position -> (column, edge id, node type, edge type) ----
+struct StackedTypes {
+  int32_t src_ntype[256];
+  int32_t etype[256];
+};
+
+template <typename Idx>
+__global__ void stacked_args_kernel(Idx* __restrict__ pos_buf, const Idx* __restrict__ indices,
+                                    const Idx* __restrict__ eids, const uint8_t* __restrict__ rel,
+                                    Idx* __restrict__ arg_u, Idx* __restrict__ arg_e,
+                                    Idx* __restrict__ arg_u_ntype, Idx* __restrict__ arg_e_etype,
+                                    const StackedTypes types, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) {
+    const int64_t pos = static_cast<int64_t>(pos_buf[i]);  // read before any tracker aliasing it is written
+    Idx u = 0, e = 0, nt = -1, et = -1;  // no edge: args stay 0, trackers -1 (spmm_hetero.cu:100-117)
+    if (pos >= 0) {
+      const int r = rel[pos];
+      if (arg_u) u = indices[pos];
+      if (arg_e) e = eids ? eids[pos] : static_cast<Idx>(pos);
+      nt = static_cast<Idx>(types.src_ntype[r]);
+      et = static_cast<Idx>(types.etype[r]);
+    }
+    if (arg_u) arg_u[i] = u;
+    if (arg_e) arg_e[i] = e;
+    if (arg_u_ntype) arg_u_ntype[i] = nt;
+    if (arg_e_etype) arg_e_etype[i] = et;
+  }
+}
+
 extern "C" {
 
 const char* dgla_last_error(void) { return last_error().c_str(); }
@@ -346,7 +376,7 @@ int dgla_spmm_csr(const char* op, const char* reduce, const dgla_csr* csr, dgla_
 // they are aligned with it before the common checks.
 static int build_stacked_launch(const char* op, const dgla_csr* csr, dgla_dtype dtype,
                                 const dgla_tensor* ufeat0, const dgla_tensor* efeat0,
-                                const dgla_tensor* out, SpmmLaunch* L) {
+                                const dgla_tensor* out, SpmmLaunch* L, const char* reduce = "sum") {
   if (!csr) return fail("csr is null");
   dgla_csr c = *csr;
   const int opc = parse_op(op, false);
@@ -360,7 +390,7 @@ static int build_stacked_launch(const char* op, const dgla_csr* csr, dgla_dtype 
     eshape[0] = c.nnz;
     e0 = dgla_tensor{efeat0->data, efeat0->ndim, eshape.data()};
   }
-  return build_spmm_launch(op, "sum", &c, dtype, ufeat0, &e0, out, L);
+  return build_spmm_launch(op, reduce, &c, dtype, ufeat0, &e0, out, L);
 }
 
 size_t dgla_spmm_csr_stacked_workspace_bytes(const char* op, const dgla_csr* csr,
@@ -405,6 +435,88 @@ int dgla_spmm_csr_stacked(const char* op, const dgla_csr* csr, const void* rel, 
     case DGLA_BF16: return launch_spmm_csr_bf16(L);
   }
   return fail("unsupported feature dtype");
+}
+
+size_t dgla_spmm_csr_stacked_cmp_workspace_bytes(const char* op, const char* reduce, const dgla_csr* csr,
+                                                 dgla_dtype dtype, const dgla_tensor* ufeat0,
+                                                 const dgla_tensor* efeat0, const dgla_tensor* out) {
+  SpmmLaunch L{};
+  if (build_stacked_launch(op, csr, dtype, ufeat0, efeat0, out, &L, reduce)) return 0;
+  switch (dtype) {
+    case DGLA_F32: return spmm_csr_workspace_f32(L);
+    case DGLA_F64: return spmm_csr_workspace_f64(L);
+    case DGLA_F16: return spmm_csr_workspace_f16(L);
+    case DGLA_BF16: return spmm_csr_workspace_bf16(L);
+  }
+  return 0;
+}
+
+int dgla_spmm_csr_stacked_cmp(const char* op, const char* reduce, const dgla_csr* csr, const void* rel,
+                              int num_rel, const int32_t* src_ntype, const int32_t* etype,
+                              dgla_dtype dtype, const dgla_tensor* ufeat0, const dgla_tensor* efeat0,
+                              const void* const* ufeat_ptrs, const void* const* efeat_ptrs,
+                              const dgla_tensor* out, void* arg_u, void* arg_e, void* arg_u_ntype,
+                              void* arg_e_etype, void* workspace, size_t workspace_bytes,
+                              uint32_t flags, void* hip_stream) {
+  if (!rel) return fail("rel is null");
+  if (num_rel < 1 || num_rel > 256) return fail("num_rel must be in [1, 256]");
+  if (!src_ntype || !etype) return fail("src_ntype / etype tables are null");
+  SpmmLaunch L{};
+  if (build_stacked_launch(op, csr, dtype, ufeat0, efeat0, out, &L, reduce)) return -1;
+  if (L.red == kSum) return fail("dgla_spmm_csr_stacked_cmp is for max / min (sum: dgla_spmm_csr_stacked)");
+  const bool use_u = op_uses_lhs(L.op), use_e = op_uses_rhs(L.op);
+  if (use_u && !ufeat_ptrs) return fail("ufeat_ptrs is null");
+  if (use_e && !efeat_ptrs) return fail("efeat_ptrs is null");
+  if (use_u && (!arg_u || !arg_u_ntype)) return fail("arg_u and arg_u_ntype are required for max/min");
+  if (use_e && (!arg_e || !arg_e_etype)) return fail("arg_e and arg_e_etype are required for max/min");
+  if (flags & DGLA_ACCUMULATE) return fail("max / min do not accumulate");
+  // the kernels leave the winner's stacked position in one of the tracker arrays; the pass below
+  // turns it into the four outputs (that array last)
+  void* pos_buf = use_u ? arg_u_ntype : arg_e_etype;
+  L.rel = rel;
+  L.ufeat_tab = ufeat_ptrs;
+  L.efeat_tab = efeat_ptrs;
+  L.arg_u = nullptr;
+  L.arg_e = pos_buf;
+  L.arg_empty = -1;
+  L.plan_valid = (flags & DGLA_PLAN_VALID) != 0;
+  L.workspace = workspace;
+  L.workspace_bytes = workspace_bytes;
+  L.stream = static_cast<hipStream_t>(hip_stream);
+  if (csr->num_rows == 0 || L.out_len == 0) return 0;
+  const DeviceGuard dev(L.stream, L.out);
+  int rc = -1;
+  switch (dtype) {
+    case DGLA_F32: rc = launch_spmm_csr_f32(L); break;
+    case DGLA_F64: rc = launch_spmm_csr_f64(L); break;
+    case DGLA_F16: rc = launch_spmm_csr_f16(L); break;
+    case DGLA_BF16: rc = launch_spmm_csr_bf16(L); break;
+  }
+  if (rc) return rc;
+  StackedTypes types;
+  for (int k = 0; k < 256; ++k) {
+    types.src_ntype[k] = k < num_rel ? src_ntype[k] : -1;
+    types.etype[k] = k < num_rel ? etype[k] : -1;
+  }
+  const int64_t n = csr->num_rows * static_cast<int64_t>(L.out_len);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if (csr->idtype_bits == 32)
+    hipLaunchKernelGGL(stacked_args_kernel<int32_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, L.stream,
+                       static_cast<int32_t*>(pos_buf), static_cast<const int32_t*>(csr->indices),
+                       static_cast<const int32_t*>(csr->data), static_cast<const uint8_t*>(rel),
+                       static_cast<int32_t*>(use_u ? arg_u : nullptr), static_cast<int32_t*>(use_e ? arg_e : nullptr),
+                       static_cast<int32_t*>(use_u ? arg_u_ntype : nullptr),
+                       static_cast<int32_t*>(use_e ? arg_e_etype : nullptr), types, n);
+  else
+    hipLaunchKernelGGL(stacked_args_kernel<int64_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, L.stream,
+                       static_cast<int64_t*>(pos_buf), static_cast<const int64_t*>(csr->indices),
+                       static_cast<const int64_t*>(csr->data), static_cast<const uint8_t*>(rel),
+                       static_cast<int64_t*>(use_u ? arg_u : nullptr), static_cast<int64_t*>(use_e ? arg_e : nullptr),
+                       static_cast<int64_t*>(use_u ? arg_u_ntype : nullptr),
+                       static_cast<int64_t*>(use_e ? arg_e_etype : nullptr), types, n);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 int dgla_spmm_coo(const char* op_s, const char* red_s, const dgla_coo* coo, dgla_dtype dtype,

@@ -574,6 +574,76 @@ static Registrar r_stkw("sparse._CAPI_DGLKernelSpMMStackedWorkspaceBytes",
   return spmm_stacked_ffi(a, ret, rtc, true);
 });
 
+// Fused max / min over the relations sharing one destination node type, with the node / edge type
+// trackers of SpMMCsrHetero's compare path (spmm_hetero.cu:87-117,160-188) — ONE launch + one
+// elementwise pass instead of two launches and a scratch buffer per relation.
+//   (g_stacked, op, reduce, U0, E0, Utab, Etab, V, rel, types, ArgU, ArgE, ArgU_ntype, ArgE_etype)
+// types: HOST int32 array [2, num_rel] = source node type, edge type of every stacked relation.
+static int spmm_stacked_cmp_ffi(const FfiArgs& a, DGLValue* ret, int* rtc, bool want_bytes) {
+  void* h;
+  const char *op, *reduce;
+  DGLArray *U0, *E0, *Ut, *Et, *V, *rel, *types, *AU, *AE, *UT, *ET;
+  if (get_handle(a, 0, &h) || get_str(a, 1, &op) || get_str(a, 2, &reduce) || get_array(a, 3, &U0) ||
+      get_array(a, 4, &E0) || get_array(a, 5, &Ut) || get_array(a, 6, &Et) || get_array(a, 7, &V) ||
+      get_array(a, 8, &rel) || get_array(a, 9, &types) || get_array(a, 10, &AU) || get_array(a, 11, &AE) ||
+      get_array(a, 12, &UT) || get_array(a, 13, &ET))
+    return -1;
+  UnitGraph* g = static_cast<UnitGraph*>(h);
+  if (!g->csc.present) return ffi_fail("stacked SpMM needs the CSC format");
+  if (null_array(V)) return ffi_fail("out array is empty");
+  dgla_dtype dt;
+  if (float_dtype(V, &dt)) return -1;
+  for (const DGLArray* t : {U0, E0}) {
+    dgla_dtype d;
+    if (null_array(t)) continue;
+    if (!on_gpu(t)) return ffi_fail("operand is not on the GPU device of the graph");
+    if (check_contiguous(t, "operand") || float_dtype(t, &d)) return -1;
+    if (d != dt) return ffi_fail("operand and output dtypes differ");
+  }
+  TensorArg u, e, v;
+  to_tensor(U0, &u);
+  to_tensor(E0, &e);
+  to_tensor(V, &v);
+  const dgla_csr csc = csr_of(g, g->csc, true);
+  if (want_bytes) {
+    *rtc = kObjectInt;
+    last_error().clear();
+    ret->v_int64 = static_cast<int64_t>(
+        dgla_spmm_csr_stacked_cmp_workspace_bytes(op, reduce, &csc, dt, &u.t, &e.t, &v.t));
+    return last_error().empty() ? 0 : -1;
+  }
+  *rtc = kNull;
+  if (null_array(rel) || rel->dtype.bits != 8) return ffi_fail("rel must be a uint8 array");
+  if (null_array(types) || on_gpu(types) || types->dtype.bits != 32 || types->ndim != 2 || types->shape[0] != 2)
+    return ffi_fail("types must be a host int32 array of shape [2, num_rel]");
+  const int64_t n_rel = types->shape[1];
+  for (const DGLArray* t : {AU, AE, UT, ET}) {
+    if (null_array(t)) continue;
+    if (!on_gpu(t)) return ffi_fail("arg array is not on the GPU device of the graph");
+    if (check_contiguous(t, "arg array")) return -1;
+    if (t->dtype.bits != g->idbits) return ffi_fail("arg arrays must have the graph's id type");
+  }
+  const int32_t* tp = static_cast<const int32_t*>(data_ptr(types));
+  const int rc = dgla_spmm_csr_stacked_cmp(
+      op, reduce, &csc, data_ptr(rel), static_cast<int>(n_rel), tp, tp + n_rel, dt, &u.t, &e.t,
+      null_array(Ut) ? nullptr : static_cast<const void* const*>(data_ptr(Ut)),
+      null_array(Et) ? nullptr : static_cast<const void* const*>(data_ptr(Et)), &v.t,
+      null_array(AU) ? nullptr : data_ptr(AU), null_array(AE) ? nullptr : data_ptr(AE),
+      null_array(UT) ? nullptr : data_ptr(UT), null_array(ET) ? nullptr : data_ptr(ET), g->ws, g->ws_bytes,
+      g->plan_valid ? DGLA_PLAN_VALID : 0, tls_stream);
+  g->split_key = UnitGraph::SplitKey();
+  if (rc == 0) g->plan_valid = true;
+  return rc;
+}
+static Registrar r_stkc("sparse._CAPI_DGLKernelSpMMStackedCmp",
+                        [](const FfiArgs& a, DGLValue* ret, int* rtc) {
+  return spmm_stacked_cmp_ffi(a, ret, rtc, false);
+});
+static Registrar r_stkcw("sparse._CAPI_DGLKernelSpMMStackedCmpWorkspaceBytes",
+                         [](const FfiArgs& a, DGLValue* ret, int* rtc) {
+  return spmm_stacked_cmp_ffi(a, ret, rtc, true);
+});
+
 static Registrar r_sddmm("sparse._CAPI_DGLKernelSDDMM", [](const FfiArgs& a, DGLValue*, int* rtc) {
   *rtc = kNull;
   void* h;

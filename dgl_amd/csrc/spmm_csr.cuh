@@ -240,6 +240,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   using A = typename Acc<DT>::type;
   constexpr bool UL = op_uses_lhs(OP), UR = op_uses_rhs(OP);
   constexpr bool ARG = RED != kSum;
+  // what max / min record about the winning edge: its column (arg_u) and its edge id (arg_e) —
+  // in the stacked form its POSITION in the stacked CSR (in the arg_e channel), from which the
+  // caller derives column, relation-local edge id and the relation (= node / edge type trackers)
+  constexpr bool TU = UL && !MULTI, TE = UR || MULTI;
   // rhs element(s) per lane and edge: a full vector only when rhs is laid out like out
   constexpr int RV = (BC == kBcNone) ? VEC : 1;
 
@@ -419,6 +423,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   };
   reset();
 
+  // the arg_e value of the unit's edge bi (bi < 0: no edge won)
+  auto edge_name = [&](int bi) -> Idx {
+    if (bi < 0) return static_cast<Idx>(p.arg_empty);
+    if constexpr (MULTI)
+      return static_cast<Idx>(j0 + bi);
+    else if constexpr (UR)
+      return eidl[bi];
+    else
+      return Idx(0);
+  };
   DT* __restrict__ out = static_cast<DT*>(p.out);
   // Does local row t_s have edges before this group's range?  Then earlier groups hold
   // carries for it and its total is assembled by the fix-up kernel from `tail_val`.
@@ -434,8 +448,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           const int bi = best[v];
-          if constexpr (UL) p.tail_argu[slot * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : static_cast<Idx>(p.arg_empty);
-          if constexpr (UR) p.tail_arge[slot * F + k0 + v] = bi >= 0 ? eidl[bi] : static_cast<Idx>(p.arg_empty);
+          if constexpr (TU) p.tail_argu[slot * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : static_cast<Idx>(p.arg_empty);
+          if constexpr (TE) p.tail_arge[slot * F + k0 + v] = edge_name(bi);
         }
       }
       first_is_tail = false;
@@ -467,8 +481,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           const int bi = best[v];
-          if constexpr (UL) p.arg_u[row * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : static_cast<Idx>(p.arg_empty);
-          if constexpr (UR) p.arg_e[row * F + k0 + v] = bi >= 0 ? eidl[bi] : static_cast<Idx>(p.arg_empty);
+          if constexpr (TU) p.arg_u[row * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : static_cast<Idx>(p.arg_empty);
+          if constexpr (TE) p.arg_e[row * F + k0 + v] = edge_name(bi);
         }
       }
     }
@@ -544,8 +558,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         const int bi = best[v];
-        if constexpr (UL) p.carry_argu[slot * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : static_cast<Idx>(p.arg_empty);
-        if constexpr (UR) p.carry_arge[slot * F + k0 + v] = bi >= 0 ? eidl[bi] : static_cast<Idx>(p.arg_empty);
+        if constexpr (TU) p.carry_argu[slot * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : static_cast<Idx>(p.arg_empty);
+        if constexpr (TE) p.carry_arge[slot * F + k0 + v] = edge_name(bi);
       }
     }
   }
@@ -556,11 +570,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
 // carries in slot (= CSR position) order, then the tail held by slot s2, and write the row.
 // One 64-lane block per slot; non-leaders exit at once.
 // ---------------------------------------------------------------------------------------
-template <typename Idx, typename DT, int OP, int RED>
+template <typename Idx, typename DT, int OP, int RED, bool MULTI = false>
 __global__ __launch_bounds__(64) void spmm_csr_fixup_kernel(const SpmmParams<Idx> p,
                                                             int64_t num_slots) {
   using A = typename Acc<DT>::type;
-  constexpr bool UL = op_uses_lhs(OP), UR = op_uses_rhs(OP);
+  constexpr bool UL = op_uses_lhs(OP) && !MULTI, UR = op_uses_rhs(OP) || MULTI;  // tracked channels
   constexpr bool ARG = RED != kSum;
   // grid-stride over the slots: one block per slot would need num_slots * 64 threads, which
   // passes HIP's 2^32 threads-per-launch limit for narrow features on billion-edge graphs
@@ -813,8 +827,20 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
       else
         hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false, true>),
                            dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
+    } else if constexpr ((OP == kCopyLhs || OP == kCopyRhs || OP == kMul) && BC != kBcGeneral) {
+      // max / min over the stacked edges: earlier relations win ties, like the reference's
+      // running compare relation by relation (spmm.cuh:552-606); arg_e receives stacked positions
+      hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false, true>),
+                         dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
+      DGLA_CHECK_HIP(hipGetLastError());
+      if (pe.after) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
+      hipLaunchKernelGGL((spmm_csr_fixup_kernel<Idx, DT, OP, RED, true>),
+                         dim3(static_cast<unsigned>(std::min<int64_t>(g.num_slots, int64_t(1) << 24))),
+                         dim3(64), 0, L.stream, p, g.num_slots);
+      DGLA_CHECK_HIP(hipGetLastError());
+      return 0;
     } else {
-      last_error() = "stacked SpMM supports copy_lhs / copy_rhs / mul with reduce sum only";
+      last_error() = "stacked SpMM supports copy_lhs / copy_rhs / mul only";
       return -1;
     }
   } else if constexpr (RED == kSum) {

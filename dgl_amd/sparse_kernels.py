@@ -251,7 +251,7 @@ def _gspmm_hetero(gidx, op, reduce_op, u_len, u_and_e_tuple):
     type, outputs by destination node type.
 
     Destination types whose relations can be summed by one stacked launch take that route
-    (``_fused_hetero_sum``); everything else goes through ``sparse._CAPI_DGLKernelSpMMHetero``
+    (``_fused_hetero``: sum, and max / min with their type trackers); everything else goes through ``sparse._CAPI_DGLKernelSpMMHetero``
     with the reference's argument lists: the per-relation loop, the accumulate-into-``V``
     contract for sum and the strict running compare with node / edge type tracking for
     max / min all live on the C++ side (csrc/ffi_registry.hip ≙ spmm_hetero.cu:26-200)."""
@@ -260,11 +260,12 @@ def _gspmm_hetero(gidx, op, reduce_op, u_len, u_and_e_tuple):
     n_nt, n_et = gidx.number_of_ntypes(), gidx.number_of_etypes()
     outs = [None] * n_nt
     use_cmp = reduce_op in ("max", "min")
-    fused = _fused_hetero_sum(gidx, op, reduce_op, u_tuple, e_tuple, outs)
-
     list_u, list_e, list_v = [None] * n_nt, [None] * n_et, [None] * n_nt
     arg_u, arg_e = [None] * n_nt, [None] * n_nt
     arg_u_nt, arg_e_et = [None] * n_nt, [None] * n_nt
+    fused = _fused_hetero(gidx, op, reduce_op, u_tuple, e_tuple, outs,
+                          (arg_u, arg_e, arg_u_nt, arg_e_et))
+
     squeeze = [False] * n_nt
     feat_shape = {}
     fmts = ["coo"] * n_et
@@ -333,15 +334,20 @@ def _gspmm_hetero(gidx, op, reduce_op, u_len, u_and_e_tuple):
 _FUSED_OPS = ("copy_lhs", "copy_rhs", "mul")
 
 
-def _fused_hetero_sum(gidx, op, reduce_op, u_tuple, e_tuple, outs):
+FUSE_HETERO = True  # tests switch the stacked launches off to compare them with the sequential path
+
+
+def _fused_hetero(gidx, op, reduce_op, u_tuple, e_tuple, outs, arg_lists):
     """Destination node types whose relations are reduced by ONE stacked launch
-    (sparse._CAPI_DGLKernelSpMMStacked) instead of the reference's per-relation accumulate
-    loop.  Fills ``outs[d]`` for those types and returns their set; everything it does not
-    take (max/min, other operators, mixed shapes, COO-only graphs, a single relation) is left
-    to the sequential path."""
+    (sparse._CAPI_DGLKernelSpMMStacked for sum, ...StackedCmp for max / min with the node / edge
+    type trackers) instead of the reference's per-relation loop.  Fills ``outs[d]`` (and, for
+    max / min, the four ``arg_lists``) for those types and returns their set; everything it does
+    not take (other operators, mixed shapes, COO-only graphs, a single relation) is left to the
+    sequential path."""
     done = set()
-    if reduce_op != "sum" or op not in _FUSED_OPS:
+    if not FUSE_HETERO or reduce_op not in ("sum", "max", "min") or op not in _FUSED_OPS:
         return done
+    use_cmp = reduce_op != "sum"
     use_u, use_e = op != "copy_rhs", op != "copy_lhs"
     by_dst = {}
     for et in range(gidx.number_of_etypes()):
@@ -378,11 +384,25 @@ def _fused_hetero_sum(gidx, op, reduce_op, u_tuple, e_tuple, outs):
         es_c = [e.contiguous() for e in es] if use_e else None
         table = lambda ts: None if ts is None else _nd(torch.tensor(
             [t.data_ptr() for t in ts], dtype=torch.int64, device=ref.device))
-        args = (op, _nd(us_c[0]) if use_u else None, _nd(es_c[0]) if use_e else None,
-                table(us_c), table(es_c), _nd(v), _ffi.NDArray(rel))
-        nbytes = _call("sparse._CAPI_DGLKernelSpMMStackedWorkspaceBytes", stk, "csc", *args)
-        stk.ensure_workspace(nbytes)
-        _call("sparse._CAPI_DGLKernelSpMMStacked", stk, "csc", *args)
+        if use_cmp:
+            ids = lambda: torch.empty(v.shape, dtype=stk.idtype, device=ref.device)
+            au, ant = (ids(), ids()) if use_u else (None, None)
+            ae, aet = (ids(), ids()) if use_e else (None, None)
+            types = torch.tensor([[gidx.metagraph.find_edge(et)[0] for et, _, _ in items],
+                                  [et for et, _, _ in items]], dtype=torch.int32)
+            args = (op, reduce_op, _nd(us_c[0]) if use_u else None, _nd(es_c[0]) if use_e else None,
+                    table(us_c), table(es_c), _nd(v), _ffi.NDArray(rel), _ffi.NDArray(types, host_ok=True),
+                    _nd(au), _nd(ae), _nd(ant), _nd(aet))
+            nbytes = _call("sparse._CAPI_DGLKernelSpMMStackedCmpWorkspaceBytes", stk, "csc", *args)
+            stk.ensure_workspace(nbytes)
+            _call("sparse._CAPI_DGLKernelSpMMStackedCmp", stk, "csc", *args)
+            arg_lists[0][d], arg_lists[1][d], arg_lists[2][d], arg_lists[3][d] = au, ae, ant, aet
+        else:
+            args = (op, _nd(us_c[0]) if use_u else None, _nd(es_c[0]) if use_e else None,
+                    table(us_c), table(es_c), _nd(v), _ffi.NDArray(rel))
+            nbytes = _call("sparse._CAPI_DGLKernelSpMMStackedWorkspaceBytes", stk, "csc", *args)
+            stk.ensure_workspace(nbytes)
+            _call("sparse._CAPI_DGLKernelSpMMStacked", stk, "csc", *args)
         outs[d] = v
         done.add(d)
     return done

@@ -136,6 +136,29 @@ int dgla_spmm_csr_stacked(const char* op, const dgla_csr* csr, const void* rel, 
                           uint32_t flags, void* hip_stream);
 
 /*
+ * Multi-relation g-SpMM with reduce = max / min in ONE launch, with the node / edge type trackers
+ * of SpMMCsrHetero's compare path (src/array/cuda/spmm_hetero.cu:87-117,160-188 ->
+ * SpMMCmpCsrHeteroKernel, spmm.cuh:552-606: a running compare relation by relation, an earlier
+ * relation keeps a tie).  `csr`, `rel`, the operand tables and `op` as for dgla_spmm_csr_stacked.
+ *   src_ntype / etype   HOST arrays [num_rel]: source node type / edge type of every stacked relation
+ *   arg_u, arg_u_ntype  [num_rows, out_len] ids: winning source node and its node type
+ *                       (required when the operator reads ufeat, else NULL)
+ *   arg_e, arg_e_etype  [num_rows, out_len] ids: winning relation-local edge id and its edge type
+ *                       (required when the operator reads efeat, else NULL)
+ * An output element no edge reaches holds the reducer's identity, args 0 and trackers -1.
+ */
+size_t dgla_spmm_csr_stacked_cmp_workspace_bytes(const char* op, const char* reduce, const dgla_csr* csr,
+                                                 dgla_dtype dtype, const dgla_tensor* ufeat0,
+                                                 const dgla_tensor* efeat0, const dgla_tensor* out);
+int dgla_spmm_csr_stacked_cmp(const char* op, const char* reduce, const dgla_csr* csr, const void* rel,
+                              int num_rel, const int32_t* src_ntype, const int32_t* etype,
+                              dgla_dtype dtype, const dgla_tensor* ufeat0, const dgla_tensor* efeat0,
+                              const void* const* ufeat_ptrs, const void* const* efeat_ptrs,
+                              const dgla_tensor* out, void* arg_u, void* arg_e, void* arg_u_ntype,
+                              void* arg_e_etype, void* workspace, size_t workspace_bytes,
+                              uint32_t flags, void* hip_stream);
+
+/*
  * g-SpMM on COO (edge-parallel with device atomics).  Replaces aten::COOSpMM
  * (array.cc:1170-1190) -> SpMMCoo<kDGLCUDA,...> (spmm.cu:80-106, spmm.cuh:624-682).
  * `out` (and arg_*) are fully written by the call.  fp16 / bf16 are refused like the

@@ -1,0 +1,74 @@
+"""Stacked max / min over several relations (sparse._CAPI_DGLKernelSpMMStackedCmp: one launch + one
+elementwise pass) against the sequential path (sparse._CAPI_DGLKernelSpMMHetero: the reference's
+running compare relation by relation, src/array/cuda/spmm_hetero.cu:87-188) — outputs, winning
+source node / edge id and the node / edge type trackers bit for bit, on graphs large enough for
+rows that straddle merge-path units (hub rows), with ties and rows nobody reaches."""
+import numpy as np
+import pytest
+import torch
+
+from tests.graphgen import coo_to_csc
+
+pytestmark = pytest.mark.gpu
+
+NUM_NODES = [3000, 1700, 900]
+META = [(0, 0), (1, 0), (2, 0), (1, 2)]  # three relations reduce into type 0, one into type 2
+
+
+def _graph(dev, idtype, seed):
+    from dgl_amd.graph_index import GraphIndex, Relation
+
+    rng = np.random.default_rng(seed)
+    rels, n_edges = [], []
+    for k, (s, d) in enumerate(META):
+        ne = 40_000 + 7_000 * k
+        src = rng.integers(0, NUM_NODES[s], ne)
+        dst = rng.integers(0, NUM_NODES[d] - 50, ne)  # the last 50 nodes get nothing
+        dst[: 6_000 + 1_000 * k] = 17 + k            # hub rows, longer than a merge-path unit
+        indptr, indices, eids = coo_to_csc(src, dst, NUM_NODES[d], idtype)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        idt = torch.int32 if idtype == np.int32 else torch.int64
+        rels.append(Relation(NUM_NODES[s], NUM_NODES[d], csc=(t(indptr), t(indices), t(eids)), idtype=idt, device=dev))
+        n_edges.append(ne)
+    return GraphIndex(NUM_NODES, META, rels), n_edges
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("idtype", [np.int32, np.int64])
+@pytest.mark.parametrize("reduce", ["max", "min"])
+@pytest.mark.parametrize("op,fshape,eshape", [("copy_lhs", (8,), None), ("copy_rhs", None, (5,)),
+                                              ("mul", (4, 8), (4, 1)), ("mul", (16,), (16,))])
+def test_stacked_cmp_equals_sequential(dev, monkeypatch, op, fshape, eshape, reduce, idtype, dtype):
+    from dgl_amd import _ffi, sparse_kernels
+
+    gidx, n_edges = _graph(dev, idtype, seed=11)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    q = lambda shape: (torch.round(torch.rand(shape, generator=g) * 6) / 2 + 1).to(dtype).to(dev)  # many ties
+    use_u, use_e = op != "copy_rhs", op != "copy_lhs"
+    u = tuple(q((n,) + fshape) for n in NUM_NODES) if use_u else tuple([None] * len(NUM_NODES))
+    e = tuple(q((n,) + eshape) for n in n_edges) if use_e else tuple([None] * len(META))
+
+    called = []
+    real = _ffi.get_global_func
+    monkeypatch.setattr(_ffi, "get_global_func", lambda name: (called.append(name), real(name))[1])
+    fused = sparse_kernels._gspmm_hetero(gidx, op, reduce, len(u), u + e)
+    assert "sparse._CAPI_DGLKernelSpMMStackedCmp" in called
+    called.clear()
+    monkeypatch.setattr(sparse_kernels, "FUSE_HETERO", False)
+    seq = sparse_kernels._gspmm_hetero(gidx, op, reduce, len(u), u + e)
+    assert "sparse._CAPI_DGLKernelSpMMStackedCmp" not in called and "sparse._CAPI_DGLKernelSpMMHetero" in called
+
+    for nt in range(len(NUM_NODES)):
+        a, b = fused[0][nt], seq[0][nt]
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b), "out of node type %d" % nt
+    for k, name in enumerate(("arg_u", "arg_e", "arg_u_ntype", "arg_e_etype")):
+        for nt in range(len(NUM_NODES)):
+            a, b = fused[1][k][nt], seq[1][k][nt]
+            assert (a is None) == (b is None), (name, nt)
+            if a is not None:
+                assert a.dtype == b.dtype and torch.equal(a, b), "%s of node type %d" % (name, nt)
+    # node type 0 is the stacked one: trackers name all three relations, -1 where nobody arrives
+    tr = fused[1][2][0] if use_u else fused[1][3][0]  # source node types 0, 1, 2 = edge types 0, 1, 2 here
+    assert set(tr.unique().tolist()) == {-1, 0, 1, 2}
