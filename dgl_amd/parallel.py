@@ -14,7 +14,19 @@ import torch
 import torch.distributed as dist
 
 
+def _host_staged(t, group):
+    """Device tensors under the gloo backend (flow tests of the multi-process code on one GPU):
+    gloo's all-to-all only takes host tensors, so the exchange is staged through host memory.
+    RCCL ("nccl") never takes this route."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def _all_to_all(out, inp, out_splits, in_splits, group=None):
+    if _host_staged(out, group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+        return
     dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
 
 
@@ -81,6 +93,9 @@ class HaloExchange:
         if self.world == 1:
             return None
         send = self._pack(x_local[: self.n_local], self.serve_rows, "_send_buf")
+        if _host_staged(halo_out, self.group):
+            _all_to_all(halo_out, send, self.recv_splits, self.send_splits, self.group)
+            return None
         return dist.all_to_all_single(halo_out, send, self.recv_splits, self.send_splits,
                                       group=self.group, async_op=True)
 
