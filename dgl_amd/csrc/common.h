@@ -181,6 +181,7 @@ enum Tune : uint32_t {
   kTuneGlds = 16u,  // segment_mm: LDS-direct (global_load_lds) slab rings instead of register staging
   kTuneSplitNt = 32u,     // split-row copy: non-temporal stores of the main array
   kTuneSplitForce = 64u,  // split-row layout whenever the shape allows, whatever the locality probe says
+  kTuneMmF32 = 128u,      // segment_mm fp32: v_mfma_f32_32x32x2_f32 instead of the 3 x bf16 split
 };
 // Default: XCD-contiguous order (measured on C2: variant L -3 % time, variant U neutral); the
 // non-temporal bits are neutral.  Split-row (profiles/r2/tune_split_ab.jsonl, C2, F = 100 fp32):

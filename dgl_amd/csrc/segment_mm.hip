@@ -398,7 +398,42 @@ __device__ __attribute__((aligned(256))) char g_mm_zero_page[256];
 
 constexpr int kGldsSlabBytes = 64;  // bytes of K per tile row and slab (32 16-bit / 16 fp32 elements)
 
-template <typename DT, int TBN, int BMT, int NA, int NB>  // BMT x TBN output tile, 2 * BMT threads
+// fp32 operands as three bf16 terms (X3).  x = h + m + l with h = the top 8 significant bits of x,
+// m = the top 8 of x - h, l = the rest: an EXACT split of the 24-bit significand (truncations, so
+// every difference is exact), and a * b = (ah + am + al)(bh + bm + bl) is evaluated as the six
+// products of order <= 2 (hh, hm, mh, mm, hl, lh) on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation; the dropped ml, lm, ll terms are < 2^-23 |a b|.  Six 32-cycle MFMAs replace eight
+// 64-cycle v_mfma_f32_32x32x2_f32 per 16 k (gfx950 has no xf32 MFMA): 2.7x less matrix-pipe time
+// for fp32-level accuracy (tests/test_mm.py's bound: 4 sqrt(k) 2^-24 sum |a||b| against the exact
+// fp64 product).  An infinite input gives NaN (inf - inf in the split) where a true fp32 product
+// may give inf.  kTuneMmF32 selects the plain fp32 MFMA path instead.
+__device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, b16x8& h, b16x8& m, b16x8& l) {
+  uint32_t hp[4], mp[4], lp[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // elements 2q, 2q + 1 of the 8
+    uint32_t hb[2], mb[2], lb[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = 2 * q + e;
+      const float x = k < 4 ? lo4[k] : hi4[k - 4];
+      const uint32_t xb = __builtin_bit_cast(uint32_t, x);
+      hb[e] = xb & 0xffff0000u;
+      const float r = x - __builtin_bit_cast(float, hb[e]);
+      mb[e] = __builtin_bit_cast(uint32_t, r) & 0xffff0000u;
+      lb[e] = __builtin_bit_cast(uint32_t, r - __builtin_bit_cast(float, mb[e]));
+    }
+    // the upper halves of two dwords -> one dword (low half = first element)
+    hp[q] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
+    mp[q] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
+    lp[q] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
+  }
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  h = __builtin_bit_cast(b16x8, (u32x4_t{hp[0], hp[1], hp[2], hp[3]}));
+  m = __builtin_bit_cast(b16x8, (u32x4_t{mp[0], mp[1], mp[2], mp[3]}));
+  l = __builtin_bit_cast(b16x8, (u32x4_t{lp[0], lp[1], lp[2], lp[3]}));
+}
+
+template <typename DT, int TBN, int BMT, int NA, int NB, bool X3 = false>  // BMT x TBN output tile, 2 * BMT threads
 __global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(const MmParams p) {
   using M = Mma<DT>;
   constexpr int ES = sizeof(DT);  // 2: 32x32x16 MFMAs, LDS-staged epilogue; 4: 32x32x2 MFMAs, direct stores
@@ -547,6 +582,34 @@ __global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(con
           }
         }
       }
+    } else if constexpr (X3) {
+      // fp32 as 3 x bf16: the lane's 8 k of the slab (chunks khalf and 2 + khalf — the same
+      // permutation of the contraction index for both operands) split into (h, m, l)
+      const int c0 = ((0 * 2 + khalf) ^ swz) * 16, c1 = ((1 * 2 + khalf) ^ swz) * 16;
+      b16x8 ah[2], am[2], al[2], bh[NJ], bm[NJ], bl[NJ];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const char* sa = bufa + a_off + i * 32 * 64;
+        split3(*reinterpret_cast<const f32x4*>(sa + c0), *reinterpret_cast<const f32x4*>(sa + c1), ah[i], am[i], al[i]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const char* sb = bufb + b_off + jj * 32 * 64;
+        split3(*reinterpret_cast<const f32x4*>(sb + c0), *reinterpret_cast<const f32x4*>(sb + c1), bh[jj], bm[jj], bl[jj]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {  // small terms first
+          f32x16 c = acc[i][jj];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[jj], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[jj], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[jj], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[jj], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[jj], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jj], c, 0, 0, 0);
+          acc[i][jj] = c;
+        }
     } else {
       // fp32: a lane reads 4 consecutive k of its row in one ds_read_b128 (chunk 2u + khalf) and
       // feeds them to 4 MFMAs; the MFMA's k = 0 / 1 halves are then k = 8u + j and 8u + 4 + j —
@@ -958,6 +1021,16 @@ int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, 
     const bool vec = p.vec_a && p.vec_b && p.vec_c;
     {
       if (glds_eligible(sizeof(DT), K, N, p.vec_a && p.vec_b, p.vec_c != 0)) {
+        if constexpr (sizeof(DT) == 4) {
+          if (!(p.tune & kTuneMmF32)) {  // fp32 operands as three bf16 terms (default)
+            if (wide)
+              hipLaunchKernelGGL((segment_mm_glds_kernel<DT, 256, 128, 6, 2, true>), grid, block, 0, s, p);
+            else
+              hipLaunchKernelGGL((segment_mm_glds_kernel<DT, 128, 128, 6, 2, true>), grid, block, 0, s, p);
+            DGLA_CHECK_HIP(hipGetLastError());
+            return 0;
+          }
+        }
         if (wide)
           hipLaunchKernelGGL((segment_mm_glds_kernel<DT, 256, 128, 6, 2>), grid, block, 0, s, p);
         else
