@@ -22,6 +22,12 @@ def _graph(kind, rng):
         deg = rng.integers(0, 12, size=3000)
         deg[17] = 9000
         deg[2500] = 3001
+    elif kind.startswith("const"):  # every row the same length L: unit boundaries (960 items apart,
+        L = int(kind[5:])           # moved forward by <= 63 edges to a row end) meet rows at every phase
+        deg = np.full(max(20_000 // (L + 1), 40), L, dtype=np.int64)
+    elif kind == "slack":       # row lengths 56..72 around the 63-edge slack, then rows around a unit's capacity
+        deg = np.concatenate([rng.integers(56, 73, size=600), rng.integers(940, 1040, size=40),
+                              rng.integers(0, 3, size=500), rng.integers(56, 73, size=300)])
     else:                       # lognormal-ish mix
         deg = np.minimum(rng.lognormal(2.0, 1.3, size=4000), 3000).astype(np.int64)
     indptr = np.zeros(deg.size + 1, dtype=np.int64)
@@ -29,13 +35,15 @@ def _graph(kind, rng):
     return indptr
 
 
-@pytest.mark.parametrize("kind", ["ones", "tiny", "hub", "mix"])
+@pytest.mark.parametrize("kind", ["ones", "tiny", "hub", "mix", "slack", "const62", "const63", "const64", "const65",
+                                  "const958", "const959", "const960", "const1023", "const1024", "const1025",
+                                  "const2500"])
 @pytest.mark.parametrize("dim", [1, 3, 4, 8, 16])
 @pytest.mark.parametrize("with_eids", [False, True])
 def test_merge_softmax_against_oracle(dev, kind, dim, with_eids):
     from dgl_amd import _capi
 
-    rng = np.random.default_rng(hash((kind, dim)) % 2 ** 31)
+    rng = np.random.default_rng(sum(map(ord, kind)) * 131 + dim)
     indptr = _graph(kind, rng)
     e, n = int(indptr[-1]), indptr.size - 1
     eids = rng.permutation(e).astype(np.int32) if with_eids else None
