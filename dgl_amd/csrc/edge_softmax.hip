@@ -940,6 +940,81 @@ __device__ __forceinline__ void edge_softmax_fixup_boundary(const EsmParams<Idx>
   }
   const int64_t t0 = crm == row ? j0 : row_begin;  // this wave's edges of the row: [t0, t1)
   const int64_t t1 = crp == row ? j1 : row_end;
+  if constexpr (std::is_same<DT, float>::value) {
+    if (p.vec4) {
+      // fp32 rows of whole 16-byte pieces: a lane owns FOUR features of an edge (one 16-byte load
+      // and store, one address computation), dim / 4 lanes per edge — the scalar loop below spends
+      // ~25 instructions per feature, which for the 7 % of C2's edges in cut rows was most of
+      // this kernel's 0.14 ms
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const int Q = dim >> 2, q = lane % Q, slot = lane / Q, per = 64 / Q;  // Q in {1, 2, 4}
+      if (slot >= per) return;  // (Q == 3 cannot occur: vec4 needs dim == its power-of-two padding)
+      const float* cs4 = static_cast<const float*>(p.carry_stat) + 4 * q;
+      const float* ts4 = static_cast<const float*>(p.tail_stat) + 4 * q;
+      const float* fa = reinterpret_cast<const float*>(pa);
+      const float* fb = reinterpret_cast<const float*>(pb);
+      float* fc = reinterpret_cast<float*>(pc);
+      auto ld4 = [](const float* ptr) { return *reinterpret_cast<const f32x4*>(ptr); };
+      if constexpr (BWD) {
+        f32x4 sum = ld4(ts4 + s2 * 2 * dim);
+        for (int64_t u = sa; u < s2; ++u) sum += ld4(cs4 + u * 2 * dim);
+        for (int64_t tb = t0 + slot; tb < t1; tb += per * kFixU) {
+          f32x4 xb[kFixU], xa[kFixU];
+          int64_t off[kFixU];
+#pragma unroll
+          for (int k = 0; k < kFixU; ++k) {
+            const int64_t j = tb + k * per < t1 ? tb + k * per : tb;
+            off[k] = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + 4 * q;
+          }
+#pragma unroll
+          for (int k = 0; k < kFixU; ++k) xb[k] = ld4(fb + off[k]), xa[k] = ld4(fa + off[k]);
+#pragma unroll
+          for (int k = 0; k < kFixU; ++k)
+            if (tb + k * per < t1) *reinterpret_cast<f32x4*>(fc + off[k]) = xb[k] - sum * xa[k];
+        }
+      } else {
+        const f32x4 mt = ld4(ts4 + s2 * 2 * dim), st = ld4(ts4 + s2 * 2 * dim + dim);
+        f32x4 M = mt;
+        for (int64_t u = sa; u < s2; ++u) {
+          const f32x4 m = ld4(cs4 + u * 2 * dim);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) M[c] = M[c] > m[c] ? M[c] : m[c];
+        }
+        f32x4 S = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t u = sa; u < s2; ++u) {
+          const f32x4 m = ld4(cs4 + u * 2 * dim), sp = ld4(cs4 + u * 2 * dim + dim);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) S[c] += sp[c] * esm_expx<float, PRECISE>(m[c] - M[c]);
+        }
+        f32x4 inv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (st[c] > 0.f) S[c] += st[c] * esm_expx<float, PRECISE>(mt[c] - M[c]);
+          inv[c] = esm_recip<float>(S[c]);
+        }
+        for (int64_t tb = t0 + slot; tb < t1; tb += per * kFixU) {
+          f32x4 xc[kFixU];
+          int64_t off[kFixU];
+#pragma unroll
+          for (int k = 0; k < kFixU; ++k) {
+            const int64_t j = tb + k * per < t1 ? tb + k * per : tb;
+            off[k] = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + 4 * q;
+          }
+#pragma unroll
+          for (int k = 0; k < kFixU; ++k) xc[k] = ld4(fa + off[k]);
+#pragma unroll
+          for (int k = 0; k < kFixU; ++k)
+            if (tb + k * per < t1) {
+              f32x4 o;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) o[c] = esm_expx<float, PRECISE>(xc[k][c] - M[c]) * inv[c];
+              *reinterpret_cast<f32x4*>(fc + off[k]) = o;
+            }
+        }
+      }
+      return;
+    }
+  }
   {
     if (h >= dim) return;
     if constexpr (BWD) {
@@ -998,21 +1073,25 @@ __device__ __forceinline__ void edge_softmax_fixup_boundary(const EsmParams<Idx>
   }
 }
 
-// kFixB consecutive unit boundaries per wavefront, four wavefronts per workgroup: boundaries that
-// cut no row (all of them, on a graph without rows longer than kEsmSlack) cost one load for the
-// kFixB of them; the others are done one after the other by the whole wavefront.
+// kFixB unit boundaries per wavefront, four wavefronts per workgroup: boundaries that cut no row
+// (all of them, on a graph without rows longer than kEsmSlack) cost one load for the kFixB of
+// them; the others are done one after the other by the whole wavefront.  A wavefront's boundaries
+// lie num_waves apart, not next to each other: the 17 consecutive boundaries a 17 k-edge hub row
+// cuts then go to 17 wavefronts instead of 3 (the kernel's duration was the longest such chain).
 template <typename Idx, typename DT, bool BWD, bool PRECISE>
 __global__ __launch_bounds__(256) void edge_softmax_fixup_kernel(const EsmParams<Idx> p) {
-  const int64_t w0 = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * kFixB;
-  if (w0 >= p.num_units) return;
+  const int64_t num_waves = (p.num_units + kFixB - 1) / kFixB;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (wave >= num_waves) return;
   const int lane = threadIdx.x & 63;
-  const int64_t mine = (lane < kFixB && w0 + lane < p.num_units) ? p.carry_row[w0 + lane] : int64_t(-1);
+  const int64_t my_w = wave + lane * num_waves;
+  const int64_t mine = (lane < kFixB && my_w < p.num_units) ? p.carry_row[my_w] : int64_t(-1);
   uint64_t cut = __ballot(mine >= 0);
   while (cut) {
     const int k = __builtin_ctzll(cut);
     cut &= cut - 1;
     const int64_t row = __shfl(mine, k, 64);
-    edge_softmax_fixup_boundary<Idx, DT, BWD, PRECISE>(p, w0 + k, row);
+    edge_softmax_fixup_boundary<Idx, DT, BWD, PRECISE>(p, wave + k * num_waves, row);
   }
 }
 
