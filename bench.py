@@ -458,6 +458,49 @@ def main():
                 "parity_max_rel_err_vs_single_gpu_launch": float(err_rep),
                 "note": "same %d-way row shards, source features resident on every GPU (static input "
                         "features), no collective in the step" % world}}
+        # variant: the FEATURE axis sharded instead of the rows — every rank holds the whole graph
+        # and a slice of the feature columns (widths multiples of 4), no exchange at all; the
+        # output comes out column-sharded.  Not the north_star's node-cut: what the same kernels
+        # do when the communication is moved out of the SpMM (narrow rows gather less efficiently).
+        if not args.no_variants:
+            per = -(-f // world // 4) * 4 if f % 4 == 0 else -(-f // world)  # 16 of 100 columns at 8 ranks: 64-byte rows
+            w4 = [max(0, min(per, f - r * per)) for r in range(world)]
+            c0 = sum(w4[:rank])
+            xc = xf[:, c0:c0 + w4[rank]].contiguous()
+            oc = torch.empty(n, w4[rank], device=dev)
+            if w4[rank] > 0:
+                wsc = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, xc.dtype, xc, None, oc),
+                                  dtype=torch.uint8, device=dev)
+                pv = [False]
+
+                def step_cols():
+                    _capi.spmm_csr("copy_lhs", "sum", csr, xc, None, oc, None, None, wsc, plan_valid=pv[0])
+                    pv[0] = True
+            else:
+                def step_cols():
+                    pass
+            for _ in range(max(args.warmup, 1)):
+                step_cols()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step_cols()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_c = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_c, op=dist.ReduceOp.MAX)
+            rc = full[:, c0:c0 + w4[rank]]
+            err_c = ((oc - rc).abs() / rc.abs().clamp_min(1e-30)).max() if w4[rank] else torch.zeros((), device=dev)
+            dist.all_reduce(err_c, op=dist.ReduceOp.MAX)
+            if rank == 0:
+                ms_c = float(t_c.item()) / args.steps * 1e3
+                result["variants"]["feature_columns_sharded_no_exchange"] = {
+                    "ms_per_step": ms_c, "edges_per_s": e / (ms_c * 1e-3), "column_widths": w4,
+                    "parity_max_rel_err_vs_single_gpu_launch": float(err_c),
+                    "note": "whole graph on every GPU, feature columns sharded (output column-sharded), "
+                            "no collective in the step"}
+            del xc, oc
         del full, ws
         # variant L (80 % of a row's neighbours within +-32 k rows) with contiguous row ranges — the
         # partition a locality-ordered graph gets for free: same schedule, smaller halo

@@ -39,4 +39,6 @@ def test_bench_two_ranks_on_one_gpu():
     v = line["variants"]
     assert v["features_replicated_no_exchange"]["parity_max_rel_err_vs_single_gpu_launch"] < 1e-5
     assert v["L_range_partition_sharded_features"]["cut_fraction"] < cfg["cut_fraction"]
+    assert v["feature_columns_sharded_no_exchange"]["parity_max_rel_err_vs_single_gpu_launch"] < 1e-5
+    assert sum(v["feature_columns_sharded_no_exchange"]["column_widths"]) == 100
     assert 0 < line["roofline"]["frac"] < 1.5
