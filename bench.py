@@ -241,10 +241,35 @@ def multi_gpu(args, dev, n, e, f, rank, world, dist, spmm=None):
     part = torch.empty(n, dtype=torch.int64, device=dev)
     stats = {}
     if rank == 0:
+        done = None
         if args.partitioner == "kway":
-            p, stats = partition_assignment(g["indptr"], g["indices"], world, seed=1)
-            part.copy_(p)
-        else:
+            # the partitioner is host code (minutes on a graph of this size): run it in a daemon
+            # thread with a time budget so that a slow host cannot stall the other ranks past the
+            # collective time-out; past the budget the run falls back to contiguous ranges and says so
+            import threading
+
+            box = {}
+
+            budget = getattr(args, "partition_budget", 240.0)
+
+            def work():
+                try:
+                    box["r"] = partition_assignment(g["indptr"], g["indices"], world, seed=1)
+                except BaseException as ex:  # re-raised on the main thread
+                    box["e"] = ex
+
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            th.join(timeout=budget)
+            if "e" in box:
+                raise box["e"]
+            done = box.get("r")
+            if done is not None:
+                part.copy_(done[0])
+                stats = done[1]
+            else:
+                stats = {"fallback": "k-way partitioner exceeded %.0f s: contiguous ranges used" % budget}
+        if done is None:
             bounds = partition_rows(g["indptr"].cpu(), world)
             part.copy_(torch.searchsorted(bounds[1:].contiguous(), torch.arange(n), right=True))
     dist.broadcast(part, src=0)
@@ -285,6 +310,8 @@ def main():
     ap.add_argument("--scale", type=int, default=1, help="divide N and E (debug only)")
     ap.add_argument("--partitioner", default="kway", choices=["kway", "range"],
                     help="N>1: node partitioner (kway = native multilevel, range = contiguous rows)")
+    ap.add_argument("--partition-budget", type=float, default=240.0,
+                    help="N>1: seconds the k-way partitioner may take before contiguous ranges are used")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-peak", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
