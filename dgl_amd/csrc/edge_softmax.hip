@@ -701,12 +701,12 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
 
   // grp[j][h] = OP over the lane's edges in edge j's segment; ghead[h] / glast[h] = that of the
   // lane's head / tail segment
-#define DGLA_ESM_GROUPS(OP)                                                         \
+#define DGLA_ESM_GROUPS(OP, IDENT)                                                  \
   _Pragma("unroll") for (int h = 0; h < HP; ++h) {                                  \
     const A f0 = v[0][h];                                                           \
-    const A f1 = same[1] ? OP(f0, v[1][h]) : v[1][h];                                \
-    const A f2 = same[2] ? OP(f1, v[2][h]) : v[2][h];                                \
-    const A f3 = same[3] ? OP(f2, v[3][h]) : v[3][h];                                \
+    const A f1 = OP(v[1][h], same[1] ? f0 : (IDENT));                                \
+    const A f2 = OP(v[2][h], same[2] ? f1 : (IDENT));                                \
+    const A f3 = OP(v[3][h], same[3] ? f2 : (IDENT));                                \
     const A b3 = f3;                                                                \
     const A b2 = same[3] ? b3 : f2;                                                 \
     const A b1 = same[2] ? b2 : f1;                                                 \
@@ -765,18 +765,22 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
     for (int q = 0; q < wib; ++q) {                                                                 \
       const bool st = wf[q] != 0;                                                                   \
       _Pragma("unroll") for (int h = 0; h < HP; ++h)                                                \
-        cin[h] = st ? wv[q * HP + h] : OP(cin[h], wv[q * HP + h]);                                  \
+        cin[h] = OP(st ? (IDENT) : cin[h], wv[q * HP + h]);                                         \
     }                                                                                               \
-    _Pragma("unroll") for (int h = 0; h < HP; ++h) if (!f) x[h] = OP(cin[h], x[h]);                 \
+    _Pragma("unroll") for (int h = 0; h < HP; ++h) x[h] = OP(f ? (IDENT) : cin[h], x[h]);           \
     const bool writes = n_valid && !a_starts_here && a_ends_here;                                   \
     _Pragma("unroll") for (int h = 0; h < HP; ++h) {                                                \
       const A t = esm_dpp<0x138, 0xf>(static_cast<A>(IDENT), x[h]); /* wave_shr:1 */                \
-      if (writes) (TABLE)[slot_a * HP + h] = OP(wl > 0 ? t : cin[h], ghead[h]);                     \
+      const A total = OP(wl > 0 ? t : cin[h], ghead[h]);                                            \
+      if (writes) (TABLE)[slot_a * HP + h] = total;                                                 \
     }                                                                                               \
   }
   const A neg_inf = -static_cast<A>(__builtin_huge_valf());
   auto f_max = [](A a, A b) {
-    if constexpr (sizeof(A) == 4) {  // one v_max_f32 (fmaxf() adds two canonicalising ones, a > b ? a : b a select)
+    if constexpr (sizeof(A) == 4) {
+      // one v_max_f32: fmaxf() adds canonicalising v_max of its inputs, a > b ? a : b is a compare
+      // + select.  (An asm statement is never if-converted: every use below is unconditional —
+      // the in-lane sweeps mask the OPERAND with the identity instead of selecting the result.)
       float r;
       asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
       return r;
@@ -807,7 +811,7 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
   if constexpr (BWD) {
     // sum of sds over the row, then sds - out * sum (parts of rows cut by the unit boundary are
     // rewritten by the fix-up)
-    DGLA_ESM_GROUPS(f_add)
+    DGLA_ESM_GROUPS(f_add, A(0))
     DGLA_ESM_PUBLISH(ts, A(0), f_add, false)
     __syncthreads();
     DGLA_ESM_STATS(ts, A(0), 0)
@@ -818,7 +822,7 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
       for (int h = 0; h < HP; ++h) v[j][h] = v[j][h] - grp[j][h] * v2[j][h];
   } else {
     // max, exp(x - M)
-    DGLA_ESM_GROUPS(f_max)
+    DGLA_ESM_GROUPS(f_max, neg_inf)
     DGLA_ESM_PUBLISH(tm, neg_inf, f_max, true)
     __syncthreads();
     DGLA_ESM_STATS(tm, neg_inf, 0)
@@ -829,7 +833,7 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
       for (int h = 0; h < HP; ++h) v[j][h] = esm_expx<A, PRECISE>(v[j][h] - grp[j][h]);
     // sum, e / S (pieces of rows cut by the unit boundary are normalised by their partial sum here:
     // they are not stored, the fix-up kernel writes those edges)
-    DGLA_ESM_GROUPS(f_add)
+    DGLA_ESM_GROUPS(f_add, A(0))
     DGLA_ESM_PUBLISH(ts, A(0), f_add, false)
     __syncthreads();
     DGLA_ESM_STATS(ts, A(0), dim)
