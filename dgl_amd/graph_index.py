@@ -81,14 +81,18 @@ class Relation:
         new_eids = order.to(self.idtype) if eids is None else eids[order]
         return indptr, minor[order].contiguous(), new_eids.contiguous()
 
+    _IDENTITY_CHECK_MIN_EDGES = 1 << 20
+
     @staticmethod
     def _drop_identity_map(fmt):
         """An edge-id map that says "edge id == position" (a COO that was already sorted by this
         format's major index, e.g. after dgl.reorder_graph(edge_permute_algo='dst')) is dropped:
         the kernels then skip the map altogether.  One pass + one synchronisation, at format
-        build time (where the reference synchronises too)."""
+        build time (where the reference synchronises too) — only for graphs large enough for the
+        map to cost anything: on sampled mini-batch blocks (built every step) the check's
+        synchronisation would cost more than the map ever does."""
         indptr, indices, eids = fmt
-        if eids is not None and eids.numel() and eids.is_cuda:
+        if eids is not None and eids.numel() >= Relation._IDENTITY_CHECK_MIN_EDGES and eids.is_cuda:
             ident = torch.arange(eids.numel(), device=eids.device, dtype=eids.dtype)
             if bool(torch.equal(eids, ident)):
                 return indptr, indices, None

@@ -460,3 +460,24 @@ def test_fused_mean_equals_sum_then_divide(dev, tdtype, op):
         g2 = torch.autograd.grad((want * wgt).sum(), ins2)
         for a, b in zip(g1, g2):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_identity_edge_id_map_is_dropped_for_large_sorted_coo(dev, monkeypatch):
+    """A COO already sorted by destination gives a CSC whose edge-id map is the identity: large
+    graphs drop it at format build time (the kernels then run map-free); mini-batch-sized graphs
+    skip the check (its synchronisation would cost more than the map)."""
+    from dgl_amd.graph_index import Relation
+
+    n, e = 500, 6000
+    g = torch.Generator().manual_seed(3)
+    dst = torch.sort(torch.randint(0, n, (e,), generator=g)).values.to(dev)
+    src = torch.randint(0, n, (e,), generator=g).to(dev)
+    small = Relation(n, n, row=src, col=dst, idtype=torch.int64, device=dev)
+    assert small.csc()[2] is not None                      # below the threshold: map kept
+    monkeypatch.setattr(Relation, "_IDENTITY_CHECK_MIN_EDGES", 1000)
+    big = Relation(n, n, row=src, col=dst, idtype=torch.int64, device=dev)
+    assert big.csc()[2] is None                            # identity recognised and dropped
+    assert torch.equal(big.csc()[0], small.csc()[0]) and torch.equal(big.csc()[1], small.csc()[1])
+    assert torch.equal(small.csc()[2], torch.arange(e, device=dev))
+    shuffled = Relation(n, n, row=src.flip(0).contiguous(), col=dst.flip(0).contiguous(), idtype=torch.int64, device=dev)
+    assert shuffled.csc()[2] is not None                   # not the identity: kept
