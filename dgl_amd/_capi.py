@@ -207,6 +207,8 @@ def set_tuning(flags):
     """Process-wide tuning bits of the CSR SpMM (include/dgl_amd.h: DGLA_TUNE_*); results are
     bit-identical under every setting."""
     check_call(LIB.dgla_set_tuning(int(flags)))
+    from . import sparse_kernels
+    sparse_kernels._tuning_epoch[0] = int(flags)  # scratch sizes remembered per relation depend on the bits
 
 
 def get_tuning():

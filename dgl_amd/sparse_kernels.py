@@ -75,6 +75,13 @@ def _check_pair(u, e, use_u, use_e, what):
             "please convert them to the same type.".format(u.dtype, e.dtype))
 
 
+def _capi_tuning():
+    return _tuning_epoch[0]
+
+
+_tuning_epoch = [0]  # bumped by dgl_amd._capi.set_tuning
+
+
 def _call(name, rel, fmt, *args):
     dev = rel.device
     _ffi.use_current_stream(dev)
@@ -149,7 +156,15 @@ def _gspmm(gidx, op, reduce_op, u, e, accumulate_into=None, mean=False):
         ee = e.contiguous() if use_e else None
         args = (op, reduce_op, _nd(uu), _nd(ee), _nd(v), _nd(arg_u), _nd(arg_e))
         if fmt == "csc":
-            nbytes = _call("sparse._CAPI_DGLKernelSpMMWorkspaceBytes", rel, fmt, *args)
+            # scratch size of this (operator, shapes) on this relation: asked once, remembered on
+            # the relation (a second FFI round trip per call was a quarter of the host time of a
+            # small-graph operator); the tuning bits are part of the key because the split-row
+            # layout lives in the same scratch
+            key = (op, reduce_op, dtype, u_shp[1:], e_shp[1:], _capi_tuning())
+            need = rel.__dict__.setdefault("_ws_need", {})
+            nbytes = need.get(key)
+            if nbytes is None:
+                nbytes = need[key] = _call("sparse._CAPI_DGLKernelSpMMWorkspaceBytes", rel, fmt, *args)
             rel.ensure_workspace(nbytes)
             tok = _static_token(uu) if (use_u and _static) else 0
             tok_e = _static_token(ee) if (use_e and _static and reduce_op == "sum") else 0
@@ -203,8 +218,11 @@ def _softmax_scratch(rel, t):
     dim = 1
     for d in t.shape[1:]:
         dim *= int(d)
-    nbytes = _call("sparse._CAPI_DGLKernelEdge_softmaxWorkspaceBytes", rel, "csc", dim,
-                   64 if t.dtype == torch.float64 else 32)
+    bits = 64 if t.dtype == torch.float64 else 32
+    need = rel.__dict__.setdefault("_esm_need", {})
+    nbytes = need.get((dim, bits))
+    if nbytes is None:  # asked once per (width, accumulator) and relation
+        nbytes = need[(dim, bits)] = _call("sparse._CAPI_DGLKernelEdge_softmaxWorkspaceBytes", rel, "csc", dim, bits)
     rel.ensure_softmax_workspace(nbytes)
 
 
