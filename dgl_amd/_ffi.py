@@ -99,6 +99,9 @@ class _Boxed:
         self.parts, self.handle = [], None
 
 
+_encoded = {}
+
+
 def _pack(args):
     n = len(args)
     values = (DGLValue * max(n, 1))()
@@ -115,7 +118,7 @@ def _pack(args):
             values[i].v_handle = None
             codes[i] = kNull
         elif isinstance(a, NDArray):
-            values[i].v_handle = ctypes.cast(ctypes.pointer(a.arr), ctypes.c_void_p)
+            values[i].v_handle = ctypes.addressof(a.arr)  # (kept alive through `keep`)
             codes[i] = kArrayHandle
             keep.append(a)
         elif isinstance(a, bool) or isinstance(a, int):
@@ -125,7 +128,11 @@ def _pack(args):
             values[i].v_float64 = a
             codes[i] = kObjectFloat
         elif isinstance(a, str):
-            b = a.encode("utf-8")
+            b = _encoded.get(a)
+            if b is None:  # operator / reducer names: a handful of distinct strings
+                b = a.encode("utf-8")
+                if len(_encoded) < 1024:
+                    _encoded[a] = b
             keep.append(b)
             values[i].v_str = b
             codes[i] = kStr
