@@ -42,6 +42,7 @@ class Relation:
         self._set = set()
         self._rev = None
         self._degs = {}
+        self.transient = False  # a sampled block, rebuilt every step (sparse_kernels._spmm_format)
 
     # ---- sizes ---------------------------------------------------------------------
     @property
@@ -57,8 +58,9 @@ class Relation:
             src_fmt = self._csr if self._csr is not None else self._csc
             indptr, indices, eids = src_fmt
             counts = (indptr[1:] - indptr[:-1]).long()
-            major = torch.repeat_interleave(
-                torch.arange(counts.numel(), device=self.device, dtype=self.idtype), counts)
+            major = torch.repeat_interleave(  # (output_size: no read-back of the total)
+                torch.arange(counts.numel(), device=self.device, dtype=self.idtype), counts,
+                output_size=int(indices.shape[0]))
             if self._csr is not None:
                 self._coo = (major, indices, eids)
             else:
@@ -180,6 +182,7 @@ class Relation:
             r._csr, r._csc = self._csc, self._csr
             r.formats = tuple({"csr": "csc", "csc": "csr", "coo": "coo"}[f] for f in self.formats)
             r._handle, r._ws, r._esm_ws, r._set, r._degs = None, None, None, set(), {}
+            r.transient = self.transient
             r._rev = self
             self._rev = r
         return self._rev

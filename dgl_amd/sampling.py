@@ -66,7 +66,7 @@ def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, 
         indptr, nbr, eids = _capi.sample_neighbors_weighted(csr, p.contiguous().reshape(-1), nodes, int(fanout),
                                                             replace, int(seed))
     n_e = int(indptr[-1])
-    own = torch.repeat_interleave(nodes, (indptr[1:] - indptr[:-1]).long())
+    own = torch.repeat_interleave(nodes, (indptr[1:] - indptr[:-1]).long(), output_size=n_e)
     src, dst = (nbr[:n_e].contiguous(), own) if edge_dir == "in" else (own, nbr[:n_e].contiguous())
     r = Relation(rel.num_src, rel.num_dst, src, dst, idtype=rel.idtype, device=rel.device)
     out = DGLGraph(GraphIndex([g.num_nodes()], [(0, 0)], [r]), ["_N"], [("_N", "_E", "_N")])
@@ -76,6 +76,7 @@ def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, 
 
 def _make_block(indptr, local_src, num_src, num_dst, idtype, device):
     rel = Relation(num_src, num_dst, csc=(indptr, local_src, None), idtype=idtype, device=device)
+    rel.transient = True
     blk = DGLGraph(GraphIndex([num_src, num_dst], [(0, 1)], [rel]), ["_N", "_N"], [("_N", "_E", "_N")],
                    src_ntypes=[0], dst_ntypes=[1])
     blk.is_block = True
@@ -92,14 +93,15 @@ def to_block(g, dst_nodes):
     dst_nodes = dst_nodes.to(device=dev, dtype=idt).contiguous()
     indptr, indices, eids = rel.csc()                       # rows = every node of g
     deg = (indptr[1:] - indptr[:-1])[dst_nodes.long()]
-    if int(deg.sum()) != rel.num_edges:
+    total = int(deg.sum())  # the one read-back of this function
+    if total != rel.num_edges:
         raise ValueError("to_block: some edges of the frontier do not end in dst_nodes")
     blk_ptr = torch.zeros(dst_nodes.shape[0] + 1, dtype=idt, device=dev)
     blk_ptr[1:] = torch.cumsum(deg, 0)
     # positions of the kept CSC entries, row by row in dst_nodes order
     starts = indptr[:-1][dst_nodes.long()].long()
-    pos = torch.repeat_interleave(starts - blk_ptr[:-1].long(), deg.long()) + \
-        torch.arange(int(blk_ptr[-1]), device=dev)
+    pos = torch.repeat_interleave(starts - blk_ptr[:-1].long(), deg.long(), output_size=total) + \
+        torch.arange(total, device=dev)
     src = indices[pos].contiguous()
     local, src_nodes, num_src = _capi.to_block(dst_nodes, src, _node_map(g, dev))
     blk = _make_block(blk_ptr, local, num_src, dst_nodes.shape[0], idt, dev)

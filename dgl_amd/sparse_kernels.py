@@ -6,6 +6,7 @@ argument meaning, dtype rules, 1-D feature handling, return values and error mes
 the arithmetic happens in libdgl_amd.so behind ``sparse._CAPI_DGLKernel*``.
 """
 import itertools
+import os
 import weakref
 
 import torch
@@ -94,10 +95,17 @@ def _call_hetero(name, gidx, fmts, *args):
     return _ffi.get_global_func(name)(gidx.hetero_handle(fmts), *args)
 
 
-def _spmm_format(rel):
+def _spmm_format(rel, reduce_op="max", dtype=None):
     # aten::SpMM: SelectFormat(0, CSC_CODE) — CSC (built on demand) unless the graph is
-    # restricted to COO (src/array/kernel.cc:26-43)
+    # restricted to COO (src/array/kernel.cc:26-43).  One departure: a TRANSIENT relation (a
+    # sampled mini-batch block or its reverse, rebuilt every step) that has no CSC yet takes a
+    # fp32 / fp64 SUM through the COO kernel (edge-parallel hardware atomics, like the reference's
+    # own COO path) instead of sorting its edges into a CSC that is used once: the conversion
+    # was half of a mini-batch GraphSAGE backward pass.  USE_DETERMINISTIC_ALG keeps the CSC route.
     if rel.allowed("csc"):
+        if (rel.transient and reduce_op == "sum" and not rel.has("csc") and rel.allowed("coo") and
+                dtype in (torch.float32, torch.float64) and "USE_DETERMINISTIC_ALG" not in os.environ):
+            return "coo"
         return "csc"
     if rel.allowed("coo"):
         return "coo"
@@ -151,7 +159,7 @@ def _gspmm(gidx, op, reduce_op, u, e, accumulate_into=None, mean=False):
         if use_e:
             arg_e = mk(v_shp, dtype=rel.idtype, device=dev)
     if n_edges > 0 and v.numel() > 0:
-        fmt = _spmm_format(rel)
+        fmt = _spmm_format(rel, reduce_op if accumulate_into is None and not mean else "max", dtype)
         uu = u.contiguous() if use_u else None
         ee = e.contiguous() if use_e else None
         args = (op, reduce_op, _nd(uu), _nd(ee), _nd(v), _nd(arg_u), _nd(arg_e))

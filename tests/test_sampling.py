@@ -255,3 +255,46 @@ def test_sample_neighbors_api_with_prob(dev):
     sampler = dgl.NeighborSampler([3], prob="w")
     _, _, blocks = sampler.sample_blocks(g, torch.tensor([6], device=dev))
     assert sorted(blocks[0].edata[dgl.EID].tolist()) == [2, 4]
+
+
+@pytest.mark.gpu
+def test_block_backward_takes_the_coo_sum_and_agrees_with_the_csc_route(dev, monkeypatch):
+    """Sampled blocks are transient: the backward pass of copy_u + mean on a block runs the sum
+    over the reversed block through the COO kernel (no CSC is sorted for one use); under
+    USE_DETERMINISTIC_ALG it builds the CSC like the reference.  Both gradients agree, and both
+    equal the gradient of a dense evaluation."""
+    import dgl_amd as dgl
+    import dgl_amd.function as fn
+
+    g, src, dst = _graph(dev, torch.int64, n=3000, e=60000, seed=9)
+    sampler = dgl.NeighborSampler([10], seed=4)
+    seeds = torch.arange(0, 3000, 5, device=dev)
+    inp, _, (blk,) = sampler.sample_blocks(g, seeds)
+    torch.manual_seed(1)
+    h0 = torch.randn(inp.shape[0], 24, device=dev)
+    up = torch.randn(seeds.shape[0], 24, device=dev)
+
+    def grad_of(block):
+        h = h0.clone().requires_grad_(True)
+        with block.local_scope():
+            block.srcdata["h"] = h
+            block.update_all(fn.copy_u("h", "m"), fn.mean("m", "n"))
+            (block.dstdata["n"] * up).sum().backward()
+        return h.grad
+
+    rel = blk._graph.relations[0]
+    assert rel.transient and rel.reverse().transient
+    g_coo = grad_of(blk)
+    assert "coo" in rel.reverse()._set and "csc" not in rel.reverse()._set     # no CSC was built
+    # the reference's route: a fresh block (same sample), CSC of the reversed block
+    monkeypatch.setenv("USE_DETERMINISTIC_ALG", "1")
+    _, _, (blk2,) = dgl.NeighborSampler([10], seed=4).sample_blocks(g, seeds)
+    g_csc = grad_of(blk2)
+    assert "csc" in blk2._graph.relations[0].reverse()._set
+    assert torch.allclose(g_coo, g_csc, rtol=1e-5, atol=1e-6)
+    # dense check: d/dh of sum_v up[v] . mean_{u -> v} h[u]
+    ip, ix, _ = rel.csc()
+    deg = (ip[1:] - ip[:-1]).clamp(min=1).to(h0.dtype)
+    rows = torch.repeat_interleave(torch.arange(seeds.shape[0], device=dev), (ip[1:] - ip[:-1]).long())
+    want = torch.zeros_like(h0).index_add_(0, ix.long(), (up / deg.unsqueeze(-1))[rows])
+    assert torch.allclose(g_coo, want, rtol=1e-5, atol=1e-6)
