@@ -398,36 +398,33 @@ __device__ __attribute__((aligned(256))) char g_mm_zero_page[256];
 
 constexpr int kGldsSlabBytes = 64;  // bytes of K per tile row and slab (32 16-bit / 16 fp32 elements)
 
-// fp32 operands as three bf16 terms (X3).  x = h + m + l with h = the top 8 significant bits of x,
-// m = the top 8 of x - h, l = the rest: an EXACT split of the 24-bit significand (truncations, so
-// every difference is exact), and a * b = (ah + am + al)(bh + bm + bl) is evaluated as the six
-// products of order <= 2 (hh, hm, mh, mm, hl, lh) on v_mfma_f32_32x32x16_bf16 with fp32
-// accumulation; the dropped ml, lm, ll terms are < 2^-23 |a b|.  Six 32-cycle MFMAs replace eight
-// 64-cycle v_mfma_f32_32x32x2_f32 per 16 k (gfx950 has no xf32 MFMA): 2.7x less matrix-pipe time
-// for fp32-level accuracy (tests/test_mm.py's bound: 4 sqrt(k) 2^-24 sum |a||b| against the exact
-// fp64 product).  An infinite input gives NaN (inf - inf in the split) where a true fp32 product
-// may give inf.  kTuneMmF32 selects the plain fp32 MFMA path instead.
+// fp32 operands as three bf16 terms (X3).  x = h + m + l with h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m), all round-to-nearest on gfx950's v_cvt_pk_bf16_f32: the differences are exact
+// in fp32 (bf16 has fp32's exponent range), |m| <= 2^-9 |x|, |l| <= 2^-18 |x|, and what is left of
+// x after the three terms is below 2^-27 |x|.  a * b = (ah + am + al)(bh + bm + bl) is evaluated as
+// the six products of order <= 2 (hh, hm, mh, mm, hl, lh) on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation, small terms first; the dropped ml, lm, ll terms are < 2^-26 |a b| and of either
+// sign.  Six 32-cycle MFMAs replace eight 64-cycle v_mfma_f32_32x32x2_f32 per 16 k (gfx950 has no
+// xf32 MFMA): 2.7x less matrix-pipe time for fp32-level accuracy (tests/test_mm.py's bound:
+// 4 sqrt(k) 2^-24 sum |a||b| against the exact fp64 product, down to k = 1).  An infinite input
+// gives NaN (inf - inf in the split) where a true fp32 product may give inf.  kTuneMmF32 selects
+// the plain fp32 MFMA path instead.
 __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, b16x8& h, b16x8& m, b16x8& l) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
   uint32_t hp[4], mp[4], lp[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {  // elements 2q, 2q + 1 of the 8
-    uint32_t hb[2], mb[2], lb[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int k = 2 * q + e;
-      const float x = k < 4 ? lo4[k] : hi4[k - 4];
-      const uint32_t xb = __builtin_bit_cast(uint32_t, x);
-      hb[e] = xb & 0xffff0000u;
-      const float r = x - __builtin_bit_cast(float, hb[e]);
-      mb[e] = __builtin_bit_cast(uint32_t, r) & 0xffff0000u;
-      lb[e] = __builtin_bit_cast(uint32_t, r - __builtin_bit_cast(float, mb[e]));
-    }
-    // the upper halves of two dwords -> one dword (low half = first element)
-    hp[q] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
-    mp[q] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
-    lp[q] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
+    const f32x2 x = q < 2 ? f32x2{lo4[2 * q], lo4[2 * q + 1]} : f32x2{hi4[2 * q - 4], hi4[2 * q - 3]};
+    const b16x2 hb = __builtin_convertvector(x, b16x2);
+    const f32x2 r = x - __builtin_convertvector(hb, f32x2);
+    const b16x2 mb = __builtin_convertvector(r, b16x2);
+    const b16x2 lb = __builtin_convertvector(r - __builtin_convertvector(mb, f32x2), b16x2);
+    hp[q] = __builtin_bit_cast(uint32_t, hb);
+    mp[q] = __builtin_bit_cast(uint32_t, mb);
+    lp[q] = __builtin_bit_cast(uint32_t, lb);
   }
-  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
   h = __builtin_bit_cast(b16x8, (u32x4_t{hp[0], hp[1], hp[2], hp[3]}));
   m = __builtin_bit_cast(b16x8, (u32x4_t{mp[0], mp[1], mp[2], mp[3]}));
   l = __builtin_bit_cast(b16x8, (u32x4_t{lp[0], lp[1], lp[2], lp[3]}));
@@ -1235,7 +1232,7 @@ __global__ __launch_bounds__(256, NS >= 4 ? 2 : (NS == 3 ? 3 : 4)) void segment_
 // 16 rows x 128 features of A and of dC per slot, NS slots, counted vmcnt as above.
 constexpr int kBwdGldsRowsF32 = 16;
 
-template <int NS>
+template <int NS, bool X3 = false>  // X3: operands as three bf16 terms (see split3)
 __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_glds_f32_kernel(const MmBwdParams p) {
   constexpr int kPart = kBwdGldsRowsF32 * 512;  // one operand of a slot: 16 rows x 128 features x 4 B
   constexpr int kSlot = 2 * kPart;
@@ -1322,6 +1319,39 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_glds_f32_kernel(const
     __builtin_amdgcn_s_barrier();
     issue(t + NS - 1);
     const char* slot = smem + (t % NS) * kSlot;
+    if constexpr (X3) {
+      // the slot's 16 contraction rows in ONE 32x32x16 step: lane (feature f, k-half kh) reads its
+      // feature at rows 8 kh .. 8 kh + 7 (ds_read_b32, 32 consecutive banks per row as before),
+      // splits the eight values into (h, m, l) and runs the six bf16 products per tile
+      b16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const char* pa8 = slot + (wm * 64 + i * 32 + f) * 4 + kh * 8 * 512;
+        const char* pb8 = slot + kPart + (wn * 64 + i * 32 + f) * 4 + kh * 8 * 512;
+        f32x4 a0, a1, b0, b1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a0[r] = *reinterpret_cast<const float*>(pa8 + r * 512);
+          a1[r] = *reinterpret_cast<const float*>(pa8 + (4 + r) * 512);
+          b0[r] = *reinterpret_cast<const float*>(pb8 + r * 512);
+          b1[r] = *reinterpret_cast<const float*>(pb8 + (4 + r) * 512);
+        }
+        split3(a0, a1, ah[i], am[i], al[i]);
+        split3(b0, b1, bh[i], bm[i], bl[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {  // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+      continue;
+    }
 #pragma unroll
     for (int s2 = 0; s2 < kBwdGldsRowsF32 / 2; ++s2) {
       float a[2], b[2];
@@ -1416,10 +1446,18 @@ int run_segment_mm_bwd_b(const void* a, const void* dc, void* db, int64_t M, int
     }
     if constexpr (sizeof(DT) == 4) {
       direct = p.vec_a && p.vec_dc && !row_index && D1 >= 4 && D2 >= 4 && (tuning_flags() & kTuneGlds);
-      if (direct && p.tiles_i * p.tiles_j >= 8)
-        hipLaunchKernelGGL((segment_mm_bwd_b_glds_f32_kernel<2>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
-      else if (direct)
-        hipLaunchKernelGGL((segment_mm_bwd_b_glds_f32_kernel<5>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+      const bool x3 = !(tuning_flags() & kTuneMmF32);  // fp32 as an exact 3 x bf16 split (default)
+      if (direct && p.tiles_i * p.tiles_j >= 8) {
+        if (x3)
+          hipLaunchKernelGGL((segment_mm_bwd_b_glds_f32_kernel<2, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+        else
+          hipLaunchKernelGGL((segment_mm_bwd_b_glds_f32_kernel<2>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+      } else if (direct) {
+        if (x3)
+          hipLaunchKernelGGL((segment_mm_bwd_b_glds_f32_kernel<5, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+        else
+          hipLaunchKernelGGL((segment_mm_bwd_b_glds_f32_kernel<5>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+      }
     }
     if (!direct)
       hipLaunchKernelGGL((segment_mm_bwd_b_kernel<DT>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);

@@ -393,11 +393,11 @@ int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const voi
  *                     slab rings) instead of through registers; 16-bit results bit-identical,
  *                     fp32 contracts k in a permuted order; the 16-bit weight gradient reads
  *                     its fragments with transposing LDS loads (default on)
- *   DGLA_TUNE_MM_F32  dgla_segment_mm / dgla_gather_mm forward and operand gradient, fp32: multiply
- *                     on v_mfma_f32_32x32x2_f32.  Default (bit off): every fp32 operand is split
- *                     exactly into three bf16 terms and the six products of order <= 2 run on
+ *   DGLA_TUNE_MM_F32  dgla_segment_mm / dgla_gather_mm and their gradients, fp32: multiply on
+ *                     v_mfma_f32_32x32x2_f32.  Default (bit off): every fp32 operand is split into
+ *                     three round-to-nearest bf16 terms and the six products of order <= 2 run on
  *                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation — fp32-level accuracy (dropped
- *                     terms < 2^-23 |a b|) at 2.7x less matrix-pipe time; gfx950 has no xf32 MFMA
+ *                     terms < 2^-26 |a b|) at 2.7x less matrix-pipe time; gfx950 has no xf32 MFMA
  * The reference has no counterpart (its kernels take no hints). */
 #define DGLA_TUNE_XCD 1u
 #define DGLA_TUNE_NT_OUT 2u
