@@ -54,14 +54,17 @@ def _stream(t):
 
 def make_csr(indptr, indices, eids, num_cols):
     _require_gpu(indptr)
-    return CSR(indptr.shape[0] - 1, int(num_cols), indices.shape[0], _idbits(indptr),
-               indptr.data_ptr(), _ptr(indices), _ptr(eids))
+    c = CSR(indptr.shape[0] - 1, int(num_cols), indices.shape[0], _idbits(indptr),
+            indptr.data_ptr(), _ptr(indices), _ptr(eids))
+    c._keep = (indptr, indices, eids)  # the struct borrows the pointers: keep the tensors alive with it
+    return c
 
 
 def make_coo(row, col, eids, num_src, num_dst):
     _require_gpu(row)
-    return COO(int(num_src), int(num_dst), row.shape[0], _idbits(row), _ptr(row), _ptr(col),
-               _ptr(eids))
+    c = COO(int(num_src), int(num_dst), row.shape[0], _idbits(row), _ptr(row), _ptr(col), _ptr(eids))
+    c._keep = (row, col, eids)
+    return c
 
 
 def spmm_csr_workspace_bytes(op, reduce, csr, dtype, ufeat, efeat, out):
