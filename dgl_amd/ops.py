@@ -193,3 +193,11 @@ def copy_v(g, x):
 def copy_e(g, x):
     """Identity on edge features (ops/sddmm.py:190-207)."""
     return x
+
+
+# python/dgl/ops/__init__.py also re-exports the segment and gather / segment matmul operators
+# (ops/segment.py:6, ops/gather_mm.py:6): dgl.ops.segment_reduce, segment_softmax, segment_mm, gather_mm
+from .mm import gather_mm, segment_mm  # noqa: E402,F401
+from .segment import segment_reduce, segment_softmax  # noqa: E402,F401
+
+__all__ += ["segment_reduce", "segment_softmax", "segment_mm", "gather_mm"]
