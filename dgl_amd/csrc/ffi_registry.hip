@@ -182,6 +182,12 @@ struct UnitGraph {
   void* eord = nullptr;
   size_t eord_cap = 0;
   int64_t eord_token = 0, eord_row_bytes = 0;
+  // Without an announcement the same copy is kept by CONTENT for narrow edge operands (scalar
+  // weights up to 16 bytes per edge): a 128-bit hash of the operand (one streaming pass, 0.05 ms
+  // for 62 M fp32 weights) is compared ON THE DEVICE with the hash the copy was made from; the
+  // gather pass exits at once when they agree.  `eord_hash` = {hash of this call's operand [2],
+  // hash of the copy's source [2]} in device memory.
+  uint64_t* eord_hash = nullptr;
   struct SplitKey {
     int64_t token = 0, out_len = 0, rows = 0;
     int dtype = -1;
@@ -261,6 +267,7 @@ static int set_format(const FfiArgs& a, int which) {
       g->plan_valid = g->esm_plan_valid = false;
       g->split_key = UnitGraph::SplitKey();
       g->eord_token = 0;
+      if (g->eord_hash) (void)hipMemsetAsync(g->eord_hash + 2, 0xff, 16, tls_stream);  // copy belongs to nobody
     }
   }
   g->num_edges = f.nnz;
@@ -284,6 +291,7 @@ static Registrar r_free("dgl_amd._CAPI_UnitGraphFree", [](const FfiArgs& a, DGLV
   if (get_handle(a, 0, &h)) return -1;
   UnitGraph* g = static_cast<UnitGraph*>(h);
   if (g->eord) (void)hipFree(g->eord);
+  if (g->eord_hash) (void)hipFree(g->eord_hash);
   delete g;
   *rtc = kNull;
   return 0;
@@ -416,16 +424,175 @@ static Registrar r_static("dgl_amd._CAPI_UnitGraphStaticOperand",
   return 0;
 });
 
+// ---- content-keyed position-ordered copy of a narrow edge operand -------------------------
+__device__ __forceinline__ uint32_t eord_mix(uint32_t x, uint32_t c1, uint32_t c2) {  // murmur3-style finaliser
+  x ^= x >> 16;
+  x *= c1;
+  x ^= x >> 13;
+  x *= c2;
+  return x ^ (x >> 16);
+}
+
+// partial[2 b], partial[2 b + 1] = block b's share of two independent position-dependent sums over
+// the operand's 4-byte words (sums: independent of which thread adds what, so the total is a
+// function of the contents).  No atomics: 16 k same-address atomics were 0.4 ms, the pass's bytes
+// take 0.05 ms; eord_hash_finish_kernel adds the partials up.
+constexpr int kEordHashBlocks = 2048;
+__global__ __launch_bounds__(256) void eord_hash_kernel(const uint32_t* __restrict__ words, int64_t n_words,
+                                                        const unsigned char* __restrict__ tail, int n_tail,
+                                                        uint64_t* __restrict__ partial) {
+  uint64_t h0 = 0, h1 = 0;
+  auto add = [&](uint32_t w, int64_t i) {
+    const uint32_t lo = static_cast<uint32_t>(i), hi = static_cast<uint32_t>(i >> 32);
+    const uint32_t a = eord_mix(w ^ (lo * 0x9e3779b1u) ^ (hi * 0x7feb352du), 0x85ebca6bu, 0xc2b2ae35u);
+    const uint32_t b = eord_mix((w + 0x632be5abu) ^ (lo * 0x846ca68bu) ^ hi, 0x7feb352du, 0x846ca68bu);
+    h0 += (static_cast<uint64_t>(a) << 13) ^ b;
+    h1 += (static_cast<uint64_t>(b) << 17) + a;
+  };
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x, n_vec = n_words >> 2;
+  const int64_t t0 = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  for (int64_t i = t0; i < n_vec; i += stride) {  // the operand is 16-byte aligned (checked by the caller)
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(words) + i);
+    add(v.x, 4 * i), add(v.y, 4 * i + 1), add(v.z, 4 * i + 2), add(v.w, 4 * i + 3);
+  }
+  if (t0 < (n_words & 3)) add(words[4 * n_vec + t0], 4 * n_vec + t0);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int t = 0; t < n_tail; ++t) h0 += eord_mix(0x1234567u * (t + 1) + tail[t], 0x85ebca6bu, 0xc2b2ae35u);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    h0 += __shfl_xor(h0, d, 64);
+    h1 += __shfl_xor(h1, d, 64);
+  }
+  __shared__ uint64_t part[4][2];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][0] = h0, part[threadIdx.x >> 6][1] = h1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+    partial[2 * blockIdx.x + 1] = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+  }
+}
+
+__global__ __launch_bounds__(256) void eord_hash_finish_kernel(const uint64_t* __restrict__ partial, int blocks,
+                                                               uint64_t* __restrict__ hash) {
+  uint64_t h0 = 0, h1 = 0;
+  for (int b = threadIdx.x; b < blocks; b += 256) h0 += partial[2 * b], h1 += partial[2 * b + 1];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    h0 += __shfl_xor(h0, d, 64);
+    h1 += __shfl_xor(h1, d, 64);
+  }
+  __shared__ uint64_t part[4][2];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][0] = h0, part[threadIdx.x >> 6][1] = h1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    hash[0] = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+    hash[1] = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+  }
+}
+
+// dst[pos] = src[map[pos]] (rows of RB bytes) unless the copy already holds this content
+template <typename Idx, typename Row>
+__global__ __launch_bounds__(256) void eord_gather_if_kernel(const Row* __restrict__ src, const Idx* __restrict__ map,
+                                                             Row* __restrict__ dst, int64_t n,
+                                                             const uint64_t* __restrict__ hash) {
+  if (hash[0] == hash[2] && hash[1] == hash[3]) return;  // uniform: `hash[2..3]` change only in the commit below
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride)
+    dst[i] = src[static_cast<int64_t>(map[i])];
+}
+
+__global__ void eord_commit_kernel(uint64_t* hash) {
+  hash[2] = hash[0];
+  hash[3] = hash[1];
+}
+
+static int64_t g_eord_auto_min_edges = int64_t(1) << 20;  // below: the map costs too little to bother
+// (n): graphs with at least n edges keep narrow edge operands by content; n < 0 switches it off
+static Registrar r_eord_min("dgl_amd._CAPI_SetAutoEdgeOperandMinEdges",
+                            [](const FfiArgs& a, DGLValue*, int* rtc) {
+  int64_t n;
+  if (get_int(a, 0, &n)) return -1;
+  g_eord_auto_min_edges = n < 0 ? INT64_MAX : n;
+  *rtc = kNull;
+  return 0;
+});
+constexpr int64_t kEordAutoMaxRowBytes = 16;             // scalar weights .. 4 floats per edge
+
+// No announcement, narrow operand, large graph: keep the position-ordered copy by content.
+static int auto_edge_operand(UnitGraph* g, const SpmmCall& c, dgla_csr* csc, dgla_tensor* e, int64_t rb) {
+  const size_t bytes = static_cast<size_t>(csc->nnz) * rb;
+  if (!g->eord_hash) {
+    DGLA_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g->eord_hash), 32 + 16 * kEordHashBlocks));
+    DGLA_CHECK_HIP(hipMemsetAsync(g->eord_hash, 0xff, 32, tls_stream));
+  }
+  if (g->eord_cap < bytes) {
+    if (g->eord) DGLA_CHECK_HIP(hipFree(g->eord));
+    g->eord = nullptr;
+    g->eord_cap = 0;
+    DGLA_CHECK_HIP(hipMalloc(&g->eord, bytes));
+    g->eord_cap = bytes;
+    DGLA_CHECK_HIP(hipMemsetAsync(g->eord_hash + 2, 0xff, 16, tls_stream));
+  }
+  if (g->eord_token != 0 || g->eord_row_bytes != rb) {  // the copy is an announced tensor's / another width's
+    DGLA_CHECK_HIP(hipMemsetAsync(g->eord_hash + 2, 0xff, 16, tls_stream));
+    g->eord_token = 0;
+    g->eord_row_bytes = rb;
+  }
+  const int64_t n_words = static_cast<int64_t>(bytes / 4);
+  const int n_tail = static_cast<int>(bytes % 4);
+  const int blocks = static_cast<int>(std::min<int64_t>((n_words + 1023) / 1024 + 1, kEordHashBlocks));
+  uint64_t* partial = g->eord_hash + 4;
+  hipLaunchKernelGGL(eord_hash_kernel, dim3(blocks), dim3(256), 0, tls_stream,
+                     static_cast<const uint32_t*>(c.e.t.data), n_words,
+                     static_cast<const unsigned char*>(c.e.t.data) + n_words * 4, n_tail, partial);
+  hipLaunchKernelGGL(eord_hash_finish_kernel, dim3(1), dim3(256), 0, tls_stream, partial, blocks, g->eord_hash);
+  const unsigned gb = static_cast<unsigned>(std::min<int64_t>((csc->nnz + 255) / 256, 65536));
+#define DGLA_EORD_GATHER(IDX, ROW)                                                                      \
+  hipLaunchKernelGGL((eord_gather_if_kernel<IDX, ROW>), dim3(gb), dim3(256), 0, tls_stream,              \
+                     static_cast<const ROW*>(c.e.t.data), static_cast<const IDX*>(csc->data),           \
+                     static_cast<ROW*>(g->eord), csc->nnz, g->eord_hash)
+  typedef uint32_t row16_t __attribute__((ext_vector_type(4)));
+  typedef uint32_t row8_t __attribute__((ext_vector_type(2)));
+  if (g->idbits == 32) {
+    switch (rb) {
+      case 2: DGLA_EORD_GATHER(int32_t, uint16_t); break;
+      case 4: DGLA_EORD_GATHER(int32_t, uint32_t); break;
+      case 8: DGLA_EORD_GATHER(int32_t, row8_t); break;
+      default: DGLA_EORD_GATHER(int32_t, row16_t); break;
+    }
+  } else {
+    switch (rb) {
+      case 2: DGLA_EORD_GATHER(int64_t, uint16_t); break;
+      case 4: DGLA_EORD_GATHER(int64_t, uint32_t); break;
+      case 8: DGLA_EORD_GATHER(int64_t, row8_t); break;
+      default: DGLA_EORD_GATHER(int64_t, row16_t); break;
+    }
+  }
+#undef DGLA_EORD_GATHER
+  hipLaunchKernelGGL(eord_commit_kernel, dim3(1), dim3(1), 0, tls_stream, g->eord_hash);
+  DGLA_CHECK_HIP(hipGetLastError());
+  e->data = g->eord;
+  csc->data = nullptr;
+  return 0;
+}
+
 // Static edge operand of a sum-reducing SpMM on a CSC with an edge-id map: point `csc` / `e` at the
 // position-ordered copy kept in the graph (making it first if it is not this tensor's).
 static int static_edge_operand(UnitGraph* g, const SpmmCall& c, dgla_csr* csc, dgla_tensor* e) {
   const int64_t tok = g->pending_static_e;
   g->pending_static_e = 0;
-  if (tok == 0 || !csc->data || null_array(c.E) || strcmp(c.reduce, "sum") != 0) return 0;
+  if (!csc->data || null_array(c.E) || strcmp(c.reduce, "sum") != 0) return 0;
   if (c.e.t.shape[0] != csc->nnz || csc->nnz == 0) return 0;
   int64_t len = 1;
   for (int i = 1; i < c.e.t.ndim; ++i) len *= c.e.t.shape[i];
   const int64_t rb = len * static_cast<int64_t>(c.dtype == DGLA_F64 ? 8 : (c.dtype == DGLA_F32 ? 4 : 2));
+  if (tok == 0) {
+    if (csc->nnz < g_eord_auto_min_edges || rb > kEordAutoMaxRowBytes || (rb != 2 && rb != 4 && rb != 8 && rb != 16) ||
+        (reinterpret_cast<uintptr_t>(c.e.t.data) & 15))
+      return 0;
+    return auto_edge_operand(g, c, csc, e, rb);
+  }
   const size_t bytes = static_cast<size_t>(csc->nnz) * rb;
   if (g->eord_token != tok || g->eord_row_bytes != rb) {
     if (g->eord_cap < bytes) {
@@ -436,6 +603,7 @@ static int static_edge_operand(UnitGraph* g, const SpmmCall& c, dgla_csr* csc, d
       g->eord_cap = bytes;
     }
     g->eord_token = 0;
+    if (g->eord_hash) DGLA_CHECK_HIP(hipMemsetAsync(g->eord_hash + 2, 0xff, 16, tls_stream));
     if (dgla_gather_rows(g->idbits, c.e.t.data, csc->data, csc->nnz, rb, g->eord, tls_stream)) return -1;
     g->eord_token = tok;
     g->eord_row_bytes = rb;

@@ -234,3 +234,52 @@ def test_static_edge_weights_run_map_free_with_the_same_bits(dev):
     dgl.static_features(w)
     ops.u_mul_e_sum(g, xg, w).sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+@pytest.mark.parametrize("dtype,width", [(torch.float32, 1), (torch.float16, 1), (torch.float64, 1), (torch.float32, 4)])
+@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
+def test_narrow_edge_operands_are_kept_by_content(dev, dtype, width, idt):
+    """Without any announcement a narrow edge operand (<= 16 bytes per edge) of a sum over a CSC with
+    an edge-id map is copied into position order once and re-used while its CONTENT hash agrees
+    (compared on the device): same bits as the map path, in-place changes and other tensors are
+    picked up, an equal tensor at another address re-uses the copy."""
+    import dgl_amd as dgl
+    from dgl_amd import _ffi, ops
+
+    setter = _ffi.get_global_func("dgl_amd._CAPI_SetAutoEdgeOperandMinEdges")
+    n, e = 20_000, 300_000
+    gg = synth_csr(n, n, e, "U", seed=17, device=dev, idtype=idt)
+    dst = torch.repeat_interleave(torch.arange(n, device=dev, dtype=idt), (gg["indptr"][1:] - gg["indptr"][:-1]).long())
+    perm = torch.randperm(e, device=dev)
+    src_p, dst_p = gg["indices"][perm].contiguous(), dst[perm].contiguous()
+    torch.manual_seed(5)
+    x = (torch.rand(n, 4 * width if width > 1 else 24, device=dev) + 1).to(dtype)
+    if width > 1:
+        x = x.reshape(n, width, 4)
+        w = (torch.rand(e, width, 1, device=dev) + 0.5).to(dtype)
+    else:
+        w = (torch.rand(e, 1, device=dev) + 0.5).to(dtype)
+    try:
+        setter(-1)                                               # off: the plain map path
+        g0 = dgl.graph((src_p, dst_p), num_nodes=n, idtype=idt)
+        want = ops.u_mul_e_sum(g0, x, w)
+        want2 = ops.u_mul_e_sum(g0, x, w * 2)
+        setter(0)                                                # on for every size
+        g = dgl.graph((src_p, dst_p), num_nodes=n, idtype=idt)
+        assert g._graph.relations[0].csc()[2] is not None
+        a = ops.u_mul_e_sum(g, x, w)
+        b = ops.u_mul_e_sum(g, x, w)                             # copy re-used
+        c = ops.u_mul_e_sum(g, x, w.clone())                     # equal content elsewhere: re-used too
+        assert torch.equal(a, want) and torch.equal(b, want) and torch.equal(c, want)
+        d = ops.u_mul_e_sum(g, x, w * 2)                         # other content: gathered again
+        assert torch.equal(d, want2)
+        w.mul_(2)                                                # changed in place
+        assert torch.equal(ops.u_mul_e_sum(g, x, w), want2)
+        # a permutation of the same multiset of values is different content
+        wp = w[torch.randperm(e, device=dev)].contiguous()
+        setter(-1)
+        ref_p = ops.u_mul_e_sum(g0, x, wp)
+        setter(0)
+        assert torch.equal(ops.u_mul_e_sum(g, x, wp), ref_p)
+    finally:
+        setter(1 << 20)
