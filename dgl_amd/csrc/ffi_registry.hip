@@ -522,6 +522,15 @@ constexpr int64_t kEordAutoMaxRowBytes = 16;             // scalar weights .. 4 
 // No announcement, narrow operand, large graph: keep the position-ordered copy by content.
 static int auto_edge_operand(UnitGraph* g, const SpmmCall& c, dgla_csr* csc, dgla_tensor* e, int64_t rb) {
   const size_t bytes = static_cast<size_t>(csc->nnz) * rb;
+  if (!g->eord_hash || g->eord_cap < bytes) {
+    // the copy has to be allocated (hipMalloc): not while the stream is being captured into a
+    // hipGraph — the call then takes the plain map path, and so does every replay of that graph
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(tls_stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return 0;
+    }
+  }
   if (!g->eord_hash) {
     DGLA_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g->eord_hash), 32 + 16 * kEordHashBlocks));
     DGLA_CHECK_HIP(hipMemsetAsync(g->eord_hash, 0xff, 32, tls_stream));
