@@ -440,6 +440,8 @@ def main():
             cut = sum(i["cut_edges"] for i in infos)
             result["config"].update({
                 "cut_fraction": cut / e, "partition_seconds": ctx["partition_s"],
+                "partition_stats": {k: (int(v) if hasattr(v, "__int__") and not isinstance(v, (str, float)) else v)
+                                    for k, v in (ctx["partition_stats"] or {}).items()},
                 "per_rank": infos,
                 "halo_rows_max": max(i["halo_rows"] for i in infos),
                 "exchange_bytes_per_step_max_rank": max(i["halo_bytes"] for i in infos),
