@@ -22,6 +22,9 @@
 // orders and a seeded xorshift, single-threaded host code (this is offline preprocessing,
 // exactly as METIS is in the reference).
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <numeric>
@@ -110,7 +113,7 @@ Graph symmetrise(int64_t n, const Idx* indptr, const Idx* indices, bool balance_
 // with the largest edge weight among those with room (ties: keep the current one, else the
 // lighter label).  Returns the number of moves of the last sweep.
 int64_t label_propagation(const Graph& g, std::vector<vid>& label, std::vector<wgt>& load,
-                          wgt max_load, int sweeps, Rng& rng, bool random_order) {
+                          wgt max_load, int sweeps, Rng& rng, bool random_order, int64_t min_moves = 0) {
   const vid n = g.n;
   std::vector<vid> order(n);
   std::iota(order.begin(), order.end(), 0);
@@ -148,7 +151,10 @@ int64_t label_propagation(const Graph& g, std::vector<vid>& label, std::vector<w
         ++moved;
       }
     }
-    if (moved == 0) break;
+    // converged, or (min_moves > 0) moving so little that another sweep over the whole graph is not
+    // worth its time: a sweep that still moves most vertices on a structure-less graph does not
+    // converge either, which the sweep count bounds
+    if (moved == 0 || moved < min_moves) break;
   }
   return moved;
 }
@@ -328,7 +334,14 @@ constexpr int kClusterFactor = 18;  // coarse vertices per part at most this hea
 template <typename Idx>
 int partition_impl(int64_t n, const Idx* indptr, const Idx* indices, int k, double imbalance,
                    bool balance_edges, uint64_t seed, int64_t* out_part, int64_t* stats) {
+  const bool trace = std::getenv("DGLA_PARTITION_TRACE") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_last = now();
+  auto lap = [&](const char* what) {
+    if (trace) { const double t = now(); std::fprintf(stderr, "[partition] %-28s %.2f s\n", what, t - t_last); t_last = t; }
+  };
   Graph g0 = symmetrise(n, indptr, indices, balance_edges);
+  lap("symmetrise");
   const wgt avg = (g0.total_vwgt + k - 1) / k;
   wgt max_vw = 0;
   for (wgt w : g0.vwgt) max_vw = std::max(max_vw, w);
@@ -348,8 +361,10 @@ int partition_impl(int64_t n, const Idx* indptr, const Idx* indices, int k, doub
     std::vector<wgt> load(g.vwgt);
     const wgt cluster_cap = std::max<wgt>(max_load / kClusterFactor, 1);
     label_propagation(g, label, load, cluster_cap, 3, rng, true);
+    lap("coarsen: label propagation");
     vid nc = 0;
     Graph c = contract(g, label, &nc);
+    lap("coarsen: contract");
     if (nc > g.n * 0.95) break;  // no longer shrinking (e.g. isolated vertices only)
     maps.push_back(std::move(label));
     levels.push_back(std::move(c));
@@ -368,8 +383,9 @@ int partition_impl(int64_t n, const Idx* indptr, const Idx* indices, int k, doub
     std::vector<vid> fine(g.n);
     for (vid v = 0; v < g.n; ++v) fine[v] = part[maps[l][v]];
     part.swap(fine);
-    label_propagation(g, part, load, max_load, l == 0 ? 6 : 8, rng, true);
+    label_propagation(g, part, load, max_load, l == 0 ? 6 : 8, rng, true, g.n / 200);
     rebalance(g, k, max_load, part, load);
+    lap("refine level");
   }
   for (int64_t v = 0; v < n; ++v) out_part[v] = part[v];
   if (stats) {
