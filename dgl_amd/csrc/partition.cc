@@ -151,10 +151,8 @@ int64_t label_propagation(const Graph& g, std::vector<vid>& label, std::vector<w
         ++moved;
       }
     }
-    // converged, or (min_moves > 0) moving so little that another sweep over the whole graph is not
-    // worth its time: a sweep that still moves most vertices on a structure-less graph does not
-    // converge either, which the sweep count bounds
-    if (moved == 0 || moved < min_moves) break;
+    if (moved == 0 || moved < min_moves) break;  // converged (min_moves > 0: or nearly; unused — stopping
+                                                 // refinement at 0.5 % moves tripled the cut on planted communities)
   }
   return moved;
 }
@@ -383,7 +381,7 @@ int partition_impl(int64_t n, const Idx* indptr, const Idx* indices, int k, doub
     std::vector<vid> fine(g.n);
     for (vid v = 0; v < g.n; ++v) fine[v] = part[maps[l][v]];
     part.swap(fine);
-    label_propagation(g, part, load, max_load, l == 0 ? 6 : 8, rng, true, g.n / 200);
+    label_propagation(g, part, load, max_load, l == 0 ? 6 : 8, rng, true);
     rebalance(g, k, max_load, part, load);
     lap("refine level");
   }
