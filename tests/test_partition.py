@@ -101,3 +101,31 @@ def test_partitioned_spmm_equals_unpartitioned():
     naive_frac, naive_rows = halo_fraction(indptr, indices, naive)
     assert frac < 0.5 * naive_frac and sum(halo_rows) < sum(naive_rows)
     assert abs(frac - st["cut_fraction"]) < 0.05
+
+
+def test_vertex_order_candidate_wins_on_a_banded_graph_and_only_there():
+    """partition_assignment also evaluates contiguous edge-balanced ranges in the given vertex
+    order and keeps the better cut: a banded graph (neighbours within a window of the row id —
+    ids assigned by locality) is cut best by ranges, which the label-propagation multilevel scheme
+    does not find; with shuffled ids the multilevel answer stays."""
+    rng = np.random.default_rng(5)
+    n, deg, k = 40_000, 12, 8
+    dst = np.repeat(np.arange(n), deg)
+    src = np.clip(dst + rng.integers(-300, 301, n * deg), 0, n - 1)
+    indptr, indices, _ = coo_to_csc(src, dst, n, np.int64)
+    part, st = partition_assignment(torch.from_numpy(indptr), torch.from_numpy(indices), k, seed=1)
+    assert st["method"] == "ranges (vertex order)" and st["cut_fraction"] < 0.04, st
+    assert st["multilevel_cut_fraction"] > st["cut_fraction"]
+    assert torch.equal(part, torch.sort(part).values)            # contiguous ranges in id order
+    counts = torch.bincount(part, minlength=k)
+    assert int(counts.max()) <= 1.05 * n / k
+    # recount of the cut
+    rows = np.repeat(np.arange(n), np.diff(indptr))
+    p = part.numpy()
+    assert int((p[rows] != p[indices]).sum()) == st["cut_edges"]
+    _, st_ml = partition_assignment(torch.from_numpy(indptr), torch.from_numpy(indices), k, seed=1, order_aware=False)
+    assert st_ml["method"] == "multilevel"
+    # shuffled ids (test_recovers_planted_communities' graph): ranges would cut 87.5 %, the multilevel answer is kept
+    ip, ix, _ = planted(8, 1500, 12, 0.9, seed=1)
+    _, st2 = partition_assignment(ip, ix, 8, imbalance=0.05, seed=3)
+    assert st2["method"] == "multilevel"
