@@ -173,6 +173,26 @@ def cpu_baseline(g, x, budget_s=20.0):
     }, out
 
 
+def spawn_ranks(n, share_gpu=False):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks under
+    torch.distributed.run on this node (one rank per GPU, rendezvous on 127.0.0.1) and return its
+    exit code.  Refuses when fewer than N GPUs are visible (unless the gloo flow-test backend is
+    selected, where the ranks share what is there)."""
+    import socket
+    import subprocess
+
+    ndev = torch.cuda.device_count()
+    if ndev < n and not share_gpu:
+        print("bench.py: --gpus %d but only %d GPU(s) visible" % (n, ndev), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, cwd=ROOT)
+
+
 def time_events(fn, reps):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
     ev[0].record()
@@ -321,11 +341,26 @@ def main():
     ap.add_argument("--extra", action="store_true", help="also time int64 ids")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback)")
+    share_gpu = os.environ.get("DGLA_BENCH_BACKEND", "nccl") == "gloo"  # flow tests: ranks share a GPU
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, one per GPU, like the
+        # reference's multi-GPU bench spawns its own workers
+        # (benchmarks/benchmarks/multigpu/bench_multigpu_sage.py:176-186)
+        raise SystemExit(spawn_ranks(args.gpus, share_gpu))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks"
+                         % (args.gpus, world))
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        if not share_gpu:
+            raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible); one rank per GPU"
+                             % (local_rank, ndev))
+        local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -406,7 +441,7 @@ def main():
             "metric": "edges/sec for g-SpMM copy_u+sum (feat=100); % HBM roofline",
             "value": e / (ms_per_step * 1e-3),
             "unit": "edges/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": dist.get_world_size() if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "strong",

@@ -158,7 +158,16 @@ def c2(dev, args):
     rel_m = Relation(n, n, csc=(g["indptr"], g["indices"], g["eids"]), idtype=g["indptr"].dtype, device=dev)
     dgm = DGLGraph(GraphIndex([n], [(0, 0)], [rel_m]), ["_N"], [("_N", "_E", "_N")])
     ms, mn = timeit(lambda: dgl.ops.u_mul_e_sum(dgm, x, w1))
-    emit("C2", "u_mul_e_sum(scalar e, eid map) through dgl.ops, same weights every call (content-keyed copy)",
+    emit("C2", "u_mul_e_sum(scalar e, eid map) through dgl.ops, default (plain map path)",
+         e, ms, mn, spmm_bytes(n, e, f, f, 4, 4) + e * 4)
+    dgl.static_features(w1)
+    ms, mn = timeit(lambda: dgl.ops.u_mul_e_sum(dgm, x, w1))
+    dgl.release_static(w1)
+    emit("C2", "u_mul_e_sum(scalar e, eid map) through dgl.ops, weights announced static_features",
+         e, ms, mn, spmm_bytes(n, e, f, f, 4, 4) + e * 4)
+    dgl.set_auto_edge_operand(0)  # opt-in from here to the end of this block
+    ms, mn = timeit(lambda: dgl.ops.u_mul_e_sum(dgm, x, w1))
+    emit("C2", "u_mul_e_sum(scalar e, eid map) through dgl.ops, same weights every call (opt-in content-keyed copy)",
          e, ms, mn, spmm_bytes(n, e, f, f, 4, 4) + e * 4)
     ws_ = [w1 + k for k in range(4)]
     k_ = [0]
@@ -170,6 +179,7 @@ def c2(dev, args):
     ms, mn = timeit(changing)
     emit("C2", "u_mul_e_sum(scalar e, eid map) through dgl.ops, different weights every call (hash + re-gather)",
          e, ms, mn, spmm_bytes(n, e, f, f, 4, 4) + e * 12)
+    dgl.set_auto_edge_operand(None)
     del dgm, rel_m, ws_
     xg = x.clone().requires_grad_(True)
 

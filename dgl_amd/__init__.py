@@ -19,6 +19,6 @@ from .ops import edge_softmax  # noqa: E402,F401
 from .sampling import EID, NID, NeighborSampler, to_block  # noqa: E402,F401
 from .mm import gather_mm, segment_mm  # noqa: E402,F401
 from .segment import scatter_add, segment_reduce, segment_softmax  # noqa: E402,F401
-from .sparse_kernels import release_static, static_features  # noqa: E402,F401
+from .sparse_kernels import release_static, set_auto_edge_operand, static_features  # noqa: E402,F401
 
 DGLError = DGLAMDError

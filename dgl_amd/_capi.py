@@ -207,8 +207,10 @@ def set_profile_events(before, after):
 
 
 def set_tuning(flags):
-    """Process-wide tuning bits of the CSR SpMM (include/dgl_amd.h: DGLA_TUNE_*); results are
-    bit-identical under every setting."""
+    """Process-wide tuning bits (include/dgl_amd.h: DGLA_TUNE_*).  The SpMM bits (XCD, NT_*, SPLIT*)
+    never change result bits.  The matrix-multiply bits do: DGLA_TUNE_GLDS contracts fp32 k in a
+    permuted order and DGLA_TUNE_MM_F32 selects the exact fp32 MFMA instead of the default
+    three-term bf16 split (same fp32-level error bound, different low-order bits)."""
     check_call(LIB.dgla_set_tuning(int(flags)))
     from . import sparse_kernels
     sparse_kernels._tuning_epoch[0] = int(flags)  # scratch sizes remembered per relation depend on the bits

@@ -206,7 +206,10 @@ def list_global_func_names():
 def use_current_stream(device):
     """Queue the following kernel calls of this thread on PyTorch's current stream of
     `device` (reference: tensoradapter CUDACurrentStream, src/runtime/cuda/cuda_device_api.cc:362-367)."""
-    LIB.DGLSetStream(kDGLROCM, device.index or 0, torch.cuda.current_stream(device).cuda_stream)
+    # an index-less torch.device("cuda") means the CURRENT device (rank r under
+    # torch.cuda.set_device(r)), not device 0: DGLFuncCall makes this id current around the call
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    LIB.DGLSetStream(kDGLROCM, idx, torch.cuda.current_stream(idx).cuda_stream)
 
 
 # ---- DLPack hand-over (python/dgl/_ffi/_ctypes/ndarray.py:28-45) ---------------------------------

@@ -406,17 +406,56 @@ constexpr int kGldsSlabBytes = 64;  // bytes of K per tile row and slab (32 16-b
 // accumulation, small terms first; the dropped ml, lm, ll terms are < 2^-26 |a b| and of either
 // sign.  Six 32-cycle MFMAs replace eight 64-cycle v_mfma_f32_32x32x2_f32 per 16 k (gfx950 has no
 // xf32 MFMA): 2.7x less matrix-pipe time for fp32-level accuracy (tests/test_mm.py's bound:
-// 4 sqrt(k) 2^-24 sum |a||b| against the exact fp64 product, down to k = 1).  An infinite input
-// gives NaN (inf - inf in the split) where a true fp32 product may give inf.  kTuneMmF32 selects
-// the plain fp32 MFMA path instead.
+// 4 sqrt(k) 2^-24 sum |a||b| against the exact fp64 product, down to k = 1).
+// Non-finite operands (round 3): x = +-inf would give r = inf - inf = NaN and a NaN product where an
+// fp32 GEMM gives +-inf, and |x| >= 0x7f7f8000 rounds to a bf16 infinity.  The common path pays one
+// v_max3_f32 per two elements to learn whether the wave holds such a value at all; if it does (wave-
+// uniform branch, practically never taken) the terms are rebuilt element by element: h truncated
+// instead of rounded where rounding would overflow, m = l = 0 for +-inf, so that inf * b = inf,
+// inf * 0 = NaN, inf - inf = NaN, NaN * b = NaN come out exactly as IEEE fp32 arithmetic gives them
+// (tests/test_mm.py::test_segment_mm_nonfinite).  kTuneMmF32 selects the plain fp32 MFMA path.
+__device__ __attribute__((noinline)) void split3_careful(const float* x8, uint32_t* hp, uint32_t* mp, uint32_t* lp) {
+  uint16_t hb[8], mb[8], lb[8];
+  for (int t = 0; t < 8; ++t) {
+    const float x = x8[t];
+    const uint32_t xb = __builtin_bit_cast(uint32_t, x);
+    const uint32_t ax = xb & 0x7fffffffu;
+    if (ax >= 0x7f800000u) {  // inf or NaN: carried by the leading term alone
+      hb[t] = static_cast<uint16_t>((xb >> 16) | (ax > 0x7f800000u ? 0x40u : 0u));  // keep NaNs NaN after truncation
+      mb[t] = 0, lb[t] = 0;
+      continue;
+    }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+    uint32_t h16;
+    if (ax >= 0x7f7f8000u) {
+      h16 = xb >> 16;  // rounding to nearest would give a bf16 infinity: truncate (|r| < 2^-8 |x|, exact)
+    } else {
+      h16 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{x, 0.f}), b16x2)) & 0xffffu;
+    }
+    const float r = x - __builtin_bit_cast(float, h16 << 16);
+    const uint32_t m16 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{r, 0.f}), b16x2)) & 0xffffu;
+    const float r2 = r - __builtin_bit_cast(float, m16 << 16);
+    const uint32_t l16 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{r2, 0.f}), b16x2)) & 0xffffu;
+    hb[t] = static_cast<uint16_t>(h16), mb[t] = static_cast<uint16_t>(m16), lb[t] = static_cast<uint16_t>(l16);
+  }
+  for (int q = 0; q < 4; ++q) {
+    hp[q] = hb[2 * q] | (static_cast<uint32_t>(hb[2 * q + 1]) << 16);
+    mp[q] = mb[2 * q] | (static_cast<uint32_t>(mb[2 * q + 1]) << 16);
+    lp[q] = lb[2 * q] | (static_cast<uint32_t>(lb[2 * q + 1]) << 16);
+  }
+}
+
 __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, b16x8& h, b16x8& m, b16x8& l) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
   uint32_t hp[4], mp[4], lp[4];
+  float amax = 0.f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {  // elements 2q, 2q + 1 of the 8
     const f32x2 x = q < 2 ? f32x2{lo4[2 * q], lo4[2 * q + 1]} : f32x2{hi4[2 * q - 4], hi4[2 * q - 3]};
+    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));  // v_max3_f32 |x|
     const b16x2 hb = __builtin_convertvector(x, b16x2);
     const f32x2 r = x - __builtin_convertvector(hb, f32x2);
     const b16x2 mb = __builtin_convertvector(r, b16x2);
@@ -424,6 +463,12 @@ __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, b16x8& 
     hp[q] = __builtin_bit_cast(uint32_t, hb);
     mp[q] = __builtin_bit_cast(uint32_t, mb);
     lp[q] = __builtin_bit_cast(uint32_t, lb);
+  }
+  // a NaN operand is dropped by fmax but needs no care (every term is NaN and so is the product);
+  // +-inf and values that round to a bf16 infinity do
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax < __builtin_bit_cast(float, 0x7f7f8000u))) != 0, 0)) {
+    const float x8[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    split3_careful(x8, hp, mp, lp);
   }
   h = __builtin_bit_cast(b16x8, (u32x4_t{hp[0], hp[1], hp[2], hp[3]}));
   m = __builtin_bit_cast(b16x8, (u32x4_t{mp[0], mp[1], mp[2], mp[3]}));

@@ -10,6 +10,7 @@ built (rows = seeds), i.e. in the format the SpMM consumes — no COO round trip
 import torch
 
 from . import _capi
+from ._lib import DGLAMDError as _DGLError
 from .graph_index import GraphIndex, Relation
 from .heterograph import DGLGraph
 
@@ -60,6 +61,11 @@ def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, 
     else:
         if fanout < 0:
             raise ValueError("weighted sampling needs a positive fanout")
+        # the kernels index `prob` by EDGE ID of g: anything else is an out-of-bounds device read
+        # (reference: CHECK on the probability array's length, src/array/array.cc RowWiseSampling)
+        if prob.dim() == 0 or prob.shape[0] != rel.num_edges or prob.numel() != rel.num_edges:
+            raise _DGLError("sample_neighbors: prob must hold one value per edge of the graph "
+                            "(%d), got shape %s" % (rel.num_edges, tuple(prob.shape)))
         p = prob.to(rel.device)
         if p.dtype not in (torch.float32, torch.float64):
             p = p.float()
@@ -138,6 +144,10 @@ class NeighborSampler:
                 indptr, src, eids = _capi.sample_neighbors(csr, seeds, fanout, self.replace, rng)
             else:
                 p = g.edata[self.prob] if isinstance(self.prob, str) else self.prob
+                if p.dim() == 0 or p.shape[0] != rel.num_edges or p.numel() != rel.num_edges:
+                    raise _DGLError("NeighborSampler: prob must hold one value per edge of the graph "
+                                    "(%d), got shape %s" % (rel.num_edges, tuple(p.shape)))
+                p = p.to(dev)
                 p = (p if p.dtype in (torch.float32, torch.float64) else p.float()).contiguous().reshape(-1)
                 indptr, src, eids = _capi.sample_neighbors_weighted(csr, p, seeds, fanout, self.replace, rng)
             n_e = int(indptr[-1])   # one read-back per layer (sizes the block)

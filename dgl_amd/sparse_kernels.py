@@ -12,7 +12,7 @@ import weakref
 import torch
 
 from . import _ffi
-from ._lib import DGLAMDError
+from ._lib import LIB as _LIB, DGLAMDError
 
 _TARGET = {"u": 0, "e": 1, "v": 2, 0: 0, 1: 1, 2: 2}
 
@@ -40,6 +40,18 @@ def static_features(t):
 
 def release_static(t):
     _static.pop(id(t), None)
+
+
+def set_auto_edge_operand(min_edges):
+    """OPT-IN: on graphs with at least ``min_edges`` edges keep a CSC-position-ordered copy of narrow
+    (<= 16 bytes per edge) edge operands of sum-reducing g-SpMM **by content hash** (no announcement
+    needed; csrc/ffi_registry.hip ``auto_edge_operand``).  ``None`` / a negative value switches it
+    off, which is the default: the stale-copy test is a 128-bit non-cryptographic hash compared on
+    the device — a probabilistic shortcut — and the copy keeps 16 bytes per edge of device memory
+    for the life of the graph.  ``static_features(w)`` gives the same speed without a hash."""
+    from . import _ffi
+
+    _ffi.get_global_func("dgl_amd._CAPI_SetAutoEdgeOperandMinEdges")(-1 if min_edges is None else int(min_edges))
 
 
 def _static_token(t):
@@ -77,10 +89,13 @@ def _check_pair(u, e, use_u, use_e, what):
 
 
 def _capi_tuning():
-    return _tuning_epoch[0]
+    # the library's tuning bits read at call time (a host read of one word): raw
+    # LIB.dgla_set_tuning calls change the split-row bit without going through
+    # dgl_amd._capi.set_tuning, and a scratch size cached under the old bits could be too small
+    return _LIB.dgla_get_tuning()
 
 
-_tuning_epoch = [0]  # bumped by dgl_amd._capi.set_tuning
+_tuning_epoch = [0]  # kept for callers of dgl_amd._capi.set_tuning; no longer the cache key
 
 
 def _call(name, rel, fmt, *args):

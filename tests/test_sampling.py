@@ -255,6 +255,10 @@ def test_sample_neighbors_api_with_prob(dev):
     sampler = dgl.NeighborSampler([3], prob="w")
     _, _, blocks = sampler.sample_blocks(g, torch.tensor([6], device=dev))
     assert sorted(blocks[0].edata[dgl.EID].tolist()) == [2, 4]
+    # a probability tensor that is not one value per edge of g is rejected before any kernel reads it
+    for bad in (torch.ones(3, device=dev), torch.ones(6, 2, device=dev), torch.ones(7, device=dev)):
+        with pytest.raises(dgl.DGLError, match="one value per edge"):
+            dgl.sampling.sample_neighbors(g, torch.tensor([6], device=dev), 2, prob=bad, seed=3)
 
 
 @pytest.mark.gpu
