@@ -51,7 +51,9 @@ def pmc_traffic(kernel_substr="spmm_csr_merge_kernel"):
     import csv
     import glob
 
-    dirs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*")))
+    # the most recent round whose PMC passes are committed
+    dirs = [d for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*")))
+            if all(os.path.exists(os.path.join(d, "pmc_%s.csv" % c)) for c in ("FETCH_SIZE", "WRITE_SIZE"))]
     if not dirs:
         return None, None
     vals = {}

@@ -206,6 +206,10 @@ def set_profile_events(before, after):
         LIB.dgla_spmm_set_profile_events(before.cuda_event, after.cuda_event)
 
 
+TUNE_XCD, TUNE_NT_OUT, TUNE_NT_IDX, TUNE_SPLIT, TUNE_GLDS, TUNE_SPLIT_NT, TUNE_SPLIT_FORCE, TUNE_MM_F32 = (
+    1, 2, 4, 8, 16, 32, 64, 128)  # include/dgl_amd.h DGLA_TUNE_*
+
+
 def set_tuning(flags):
     """Process-wide tuning bits (include/dgl_amd.h: DGLA_TUNE_*).  The SpMM bits (XCD, NT_*, SPLIT*)
     never change result bits.  The matrix-multiply bits do: DGLA_TUNE_GLDS contracts fp32 k in a

@@ -74,6 +74,7 @@ __global__ void segment_plan_kernel(const Idx* __restrict__ seglen, int64_t num_
   }
   plan[num_rel] = t;
   plan[2 * num_rel + 1] = r0;
+  plan[3 * num_rel + 2] = 0;  // NaN flag of the X3 (fp32 as 3 x bf16) kernels, behind the staged seglen
 }
 
 // Values that are the same in every lane (derived from blockIdx and the plan): tell the compiler,
@@ -210,6 +211,7 @@ struct MmParams {
   const int64_t* row_index;  // optional: logical row r of A and C lives at physical row row_index[r]
   int64_t n_tiles;   // ceil(N / BN)
   uint32_t tune;     // kTune* bits
+  uint32_t* nan_flag;  // X3 kernels: raised when an accumulator came out NaN (zeroed by the plan kernel)
 };
 
 // ---- forward: C_r = A_r . Bt_r^T ----------------------------------------------------------
@@ -407,55 +409,24 @@ constexpr int kGldsSlabBytes = 64;  // bytes of K per tile row and slab (32 16-b
 // sign.  Six 32-cycle MFMAs replace eight 64-cycle v_mfma_f32_32x32x2_f32 per 16 k (gfx950 has no
 // xf32 MFMA): 2.7x less matrix-pipe time for fp32-level accuracy (tests/test_mm.py's bound:
 // 4 sqrt(k) 2^-24 sum |a||b| against the exact fp64 product, down to k = 1).
-// Non-finite operands (round 3): x = +-inf would give r = inf - inf = NaN and a NaN product where an
-// fp32 GEMM gives +-inf, and |x| >= 0x7f7f8000 rounds to a bf16 infinity.  The common path pays one
-// v_max3_f32 per two elements to learn whether the wave holds such a value at all; if it does (wave-
-// uniform branch, practically never taken) the terms are rebuilt element by element: h truncated
-// instead of rounded where rounding would overflow, m = l = 0 for +-inf, so that inf * b = inf,
-// inf * 0 = NaN, inf - inf = NaN, NaN * b = NaN come out exactly as IEEE fp32 arithmetic gives them
+// Non-finite operands (round 3): x = +-inf gives r = inf - inf = NaN, and |x| >= 0x7f7f8000 rounds to
+// a bf16 infinity with r = -inf; either way the m term is NaN and EVERY output the value enters comes
+// out NaN, where IEEE fp32 arithmetic may give +-inf or a finite number.  The K loop is left alone
+// (a check inside it cost 2.7x: 8.3 -> 23.5 ms; an in-epilogue repair cost registers: 228 -> 256 VGPRs
+// + scratch); instead the epilogue looks at its accumulators — a NaN there is the only symptom — and
+// raises a flag in the plan scratch; x3_repair_{fwd,bwd}_kernel, launched behind every X3 kernel, exit
+// on their first load unless it is set and otherwise recompute every NaN element of the result as a
+// plain fp32 dot product from global memory.  inf * b = inf, inf * 0 = NaN, inf - inf = NaN, NaN * b =
+// NaN then come out as an fp32 GEMM gives them
 // (tests/test_mm.py::test_segment_mm_nonfinite).  kTuneMmF32 selects the plain fp32 MFMA path.
-__device__ __attribute__((noinline)) void split3_careful(const float* x8, uint32_t* hp, uint32_t* mp, uint32_t* lp) {
-  uint16_t hb[8], mb[8], lb[8];
-  for (int t = 0; t < 8; ++t) {
-    const float x = x8[t];
-    const uint32_t xb = __builtin_bit_cast(uint32_t, x);
-    const uint32_t ax = xb & 0x7fffffffu;
-    if (ax >= 0x7f800000u) {  // inf or NaN: carried by the leading term alone
-      hb[t] = static_cast<uint16_t>((xb >> 16) | (ax > 0x7f800000u ? 0x40u : 0u));  // keep NaNs NaN after truncation
-      mb[t] = 0, lb[t] = 0;
-      continue;
-    }
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
-    uint32_t h16;
-    if (ax >= 0x7f7f8000u) {
-      h16 = xb >> 16;  // rounding to nearest would give a bf16 infinity: truncate (|r| < 2^-8 |x|, exact)
-    } else {
-      h16 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{x, 0.f}), b16x2)) & 0xffffu;
-    }
-    const float r = x - __builtin_bit_cast(float, h16 << 16);
-    const uint32_t m16 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{r, 0.f}), b16x2)) & 0xffffu;
-    const float r2 = r - __builtin_bit_cast(float, m16 << 16);
-    const uint32_t l16 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2{r2, 0.f}), b16x2)) & 0xffffu;
-    hb[t] = static_cast<uint16_t>(h16), mb[t] = static_cast<uint16_t>(m16), lb[t] = static_cast<uint16_t>(l16);
-  }
-  for (int q = 0; q < 4; ++q) {
-    hp[q] = hb[2 * q] | (static_cast<uint32_t>(hb[2 * q + 1]) << 16);
-    mp[q] = mb[2 * q] | (static_cast<uint32_t>(mb[2 * q + 1]) << 16);
-    lp[q] = lb[2 * q] | (static_cast<uint32_t>(lb[2 * q + 1]) << 16);
-  }
-}
-
 __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, b16x8& h, b16x8& m, b16x8& l) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
   uint32_t hp[4], mp[4], lp[4];
-  float amax = 0.f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {  // elements 2q, 2q + 1 of the 8
     const f32x2 x = q < 2 ? f32x2{lo4[2 * q], lo4[2 * q + 1]} : f32x2{hi4[2 * q - 4], hi4[2 * q - 3]};
-    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));  // v_max3_f32 |x|
     const b16x2 hb = __builtin_convertvector(x, b16x2);
     const f32x2 r = x - __builtin_convertvector(hb, f32x2);
     const b16x2 mb = __builtin_convertvector(r, b16x2);
@@ -464,15 +435,21 @@ __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, b16x8& 
     mp[q] = __builtin_bit_cast(uint32_t, mb);
     lp[q] = __builtin_bit_cast(uint32_t, lb);
   }
-  // a NaN operand is dropped by fmax but needs no care (every term is NaN and so is the product);
-  // +-inf and values that round to a bf16 infinity do
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(amax < __builtin_bit_cast(float, 0x7f7f8000u))) != 0, 0)) {
-    const float x8[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-    split3_careful(x8, hp, mp, lp);
-  }
   h = __builtin_bit_cast(b16x8, (u32x4_t{hp[0], hp[1], hp[2], hp[3]}));
   m = __builtin_bit_cast(b16x8, (u32x4_t{mp[0], mp[1], mp[2], mp[3]}));
   l = __builtin_bit_cast(b16x8, (u32x4_t{lp[0], lp[1], lp[2], lp[3]}));
+}
+
+template <int NI, int NJ>
+__device__ __forceinline__ bool any_nan(const f32x16 (&acc)[NI][NJ]) {
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bad |= acc[i][j][r] != acc[i][j][r];
+  return __builtin_amdgcn_ballot_w64(bad) != 0;
 }
 
 template <typename DT, int TBN, int BMT, int NA, int NB, bool X3 = false>  // BMT x TBN output tile, 2 * BMT threads
@@ -676,6 +653,9 @@ __global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(con
   }
 
   if constexpr (ES == 4) {
+    if constexpr (X3) {  // non-finite operands (see split3): tell x3_repair_fwd_kernel to look
+      if (__builtin_expect(any_nan(acc), 0) && lane == 0) atomicOr(p.nan_flag, 1u);
+    }
     // fp32: a half-wave owns 32 consecutive columns of one row = one 128-byte line per store
     if (p.row_index)
       store_acc_direct<DT, NJ, true>(C, acc, p.row_index, row0 + wm * 64, row_end, n0 + wn * (TBN / 2) + lrow, N, 4 * khalf);
@@ -766,7 +746,60 @@ struct MmBwdParams {
   int tiles_i, tiles_j;  // ceil(D1 / 128), ceil(D2 / 128)
   int64_t slab_rows;     // rows per split-K slab
   const int64_t* row_index;  // optional: logical row r of A and dC lives at physical row row_index[r]
+  uint32_t* nan_flag;  // X3 kernel: raised when an accumulator came out NaN (zeroed by the plan kernel)
 };
+
+// ---- repair passes of the X3 kernels (see split3) ------------------------------------------------
+// Launched behind every X3 kernel; every thread returns after one load unless the flag is up.
+// Forward: every NaN element of C is recomputed as the fp32 dot product IEEE arithmetic defines.
+__global__ __launch_bounds__(256) void x3_repair_fwd_kernel(const MmParams p) {
+  if (*p.nan_flag == 0) return;
+  const int64_t* row_off = p.plan + p.num_rel + 1;
+  const int64_t total = row_off[p.num_rel];
+  const float* A = static_cast<const float*>(p.a);
+  const float* Bt = static_cast<const float*>(p.bt);
+  float* C = static_cast<float*>(p.c);
+  const int64_t n_el = total * p.N, stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < n_el; e += stride) {
+    const int64_t r = e / p.N;
+    const int col = static_cast<int>(e % p.N);
+    const int64_t pr = p.row_index ? p.row_index[r] : r;
+    const float v = C[pr * p.N + col];
+    if (v == v) continue;
+    const int64_t rel = find_segment(row_off, p.num_rel, r);
+    const float* a = A + pr * p.K;
+    const float* b = Bt + (rel * p.N + col) * static_cast<int64_t>(p.K);
+    float acc = 0.f;
+    for (int k = 0; k < p.K; ++k) acc = __builtin_fmaf(a[k], b[k], acc);
+    C[pr * p.N + col] = acc;
+  }
+}
+
+// Weight gradient: one wave per element of acc[R, D1, D2]; a NaN element is recomputed over the
+// whole segment (lanes stride the rows, partial sums combined by shuffles).
+__global__ __launch_bounds__(256) void x3_repair_bwd_kernel(const MmBwdParams p) {
+  if (*p.nan_flag == 0) return;
+  const int64_t* row_off = p.plan + p.num_rel + 1;
+  const float* A = static_cast<const float*>(p.a);
+  const float* dC = static_cast<const float*>(p.dc);
+  const int lane = threadIdx.x & 63;
+  const int64_t n_el = p.num_rel * static_cast<int64_t>(p.D1) * p.D2;
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * (blockDim.x >> 6);
+  for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x >> 6) + (threadIdx.x >> 6); e < n_el; e += n_waves) {
+    const float v = p.acc[e];
+    if (v == v) continue;
+    const int64_t rel = e / (static_cast<int64_t>(p.D1) * p.D2);
+    const int row = static_cast<int>((e / p.D2) % p.D1), col = static_cast<int>(e % p.D2);
+    float acc = 0.f;
+    for (int64_t m = row_off[rel] + lane; m < row_off[rel + 1]; m += 64) {
+      const int64_t pm = p.row_index ? p.row_index[m] : m;
+      acc = __builtin_fmaf(A[pm * p.D1 + row], dC[pm * p.D2 + col], acc);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane == 0) p.acc[e] = acc;
+  }
+}
 
 template <typename DT>
 __global__ __launch_bounds__(256) void segment_mm_bwd_b_kernel(const MmBwdParams p) {
@@ -949,7 +982,7 @@ MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool ne
   MmScratch s;
   size_t off = 0;
   s.off_plan = off;
-  off = align256(off + sizeof(int64_t) * (2 * num_rel + 2) + /* staged seglen */ 8 * num_rel);
+  off = align256(off + sizeof(int64_t) * (2 * num_rel + 2) + /* staged seglen */ 8 * num_rel + /* NaN flag */ 8);
   s.off_bt = off;
   if (need_bt) off = align256(off + static_cast<size_t>(num_rel) * K * N * elem);
   s.off_acc = off;
@@ -1049,6 +1082,7 @@ int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, 
   p.row_index = row_index;
   p.n_tiles = 1;
   p.tune = tuning_flags();
+  p.nan_flag = reinterpret_cast<uint32_t*>(const_cast<int64_t*>(p.plan) + 3 * num_rel + 2);
   if constexpr (sizeof(DT) == 8) {
     const int64_t total = M * N;
     hipLaunchKernelGGL((segment_mm_plain_kernel<DT>), dim3(static_cast<unsigned>((total + 255) / 256)),
@@ -1069,6 +1103,7 @@ int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, 
               hipLaunchKernelGGL((segment_mm_glds_kernel<DT, 256, 128, 6, 2, true>), grid, block, 0, s, p);
             else
               hipLaunchKernelGGL((segment_mm_glds_kernel<DT, 128, 128, 6, 2, true>), grid, block, 0, s, p);
+            hipLaunchKernelGGL(x3_repair_fwd_kernel, dim3(1024), dim3(256), 0, s, p);  // no-op unless a NaN came out
             DGLA_CHECK_HIP(hipGetLastError());
             return 0;
           }
@@ -1413,6 +1448,9 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_glds_f32_kernel(const
     }
   }
 
+  if constexpr (X3) {  // non-finite operands (see split3): tell x3_repair_bwd_kernel to look
+    if (__builtin_expect(any_nan(acc), 0) && lane == 0) atomicOr(p.nan_flag, 1u);
+  }
   float* out = p.acc + rel * static_cast<int64_t>(D1) * D2;
   const int col_l = lane & 31, rbase = 4 * (lane >> 5);
 #pragma unroll
@@ -1471,6 +1509,7 @@ int run_segment_mm_bwd_b(const void* a, const void* dc, void* db, int64_t M, int
     p.tiles_j = static_cast<int>((D2 + BN - 1) / BN);
     p.slab_rows = bwd_slab_rows(M, D1, D2);
     p.row_index = row_index;
+    p.nan_flag = reinterpret_cast<uint32_t*>(const_cast<int64_t*>(plan) + 3 * num_rel + 2);
     const int64_t max_slabs = ((M + p.slab_rows - 1) / p.slab_rows + num_rel + 7) / 8 * 8;
     const int64_t blocks = max_slabs * p.tiles_i * p.tiles_j;
     if (blocks >= (int64_t(1) << 24)) return mfail("segment_mm backward: too many tiles (" +
@@ -1503,6 +1542,10 @@ int run_segment_mm_bwd_b(const void* a, const void* dc, void* db, int64_t M, int
         else
           hipLaunchKernelGGL((segment_mm_bwd_b_glds_f32_kernel<5>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
       }
+    }
+    if constexpr (sizeof(DT) == 4) {
+      if (direct && !(tuning_flags() & kTuneMmF32))  // no-op unless an X3 accumulator came out NaN
+        hipLaunchKernelGGL(x3_repair_bwd_kernel, dim3(512), dim3(256), 0, s, p);
     }
     if (!direct)
       hipLaunchKernelGGL((segment_mm_bwd_b_kernel<DT>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);

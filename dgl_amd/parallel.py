@@ -30,6 +30,56 @@ def _all_to_all(out, inp, out_splits, in_splits, group=None):
     dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
 
 
+def chunk_layout(counts, n_chunks):
+    """Chunk-major layout of a halo block whose rows are wanted ``counts[p]`` from peer ``p``.
+
+    Peer ``p``'s request list is cut into ``n_chunks`` contiguous pieces (piece ``c`` = entries
+    ``[cnt*c // C, cnt*(c+1) // C)`` — a function of the count alone, so the owner derives the same
+    cut from the split it was told) and the halo block is stored chunk by chunk, peers ascending
+    inside a chunk: chunk ``c`` of EVERY peer is one all-to-all, all xGMI links busy, and the
+    columns of chunk ``c`` are one contiguous range of the halo buffer.
+
+    Returns ``(pieces, bounds, old2new)``: ``pieces[c][p]`` rows, ``bounds`` = ``C + 1`` chunk
+    offsets, ``old2new`` (int64) = position in the chunk-major block of the row at position ``i``
+    of the peer-major block (requests concatenated by ascending owner)."""
+    C = max(1, int(n_chunks))
+    counts = [int(v) for v in counts]
+    pieces = [[cnt * (c + 1) // C - cnt * c // C for cnt in counts] for c in range(C)]
+    bounds = [0]
+    for c in range(C):
+        bounds.append(bounds[-1] + sum(pieces[c]))
+    old2new = torch.empty(sum(counts), dtype=torch.int64)
+    old_off = 0
+    within = [0] * C  # running offset inside each chunk
+    for p, cnt in enumerate(counts):
+        for c in range(C):
+            lo, n = cnt * c // C, pieces[c][p]
+            if n:
+                old2new[old_off + lo: old_off + lo + n] = torch.arange(bounds[c] + within[c],
+                                                                       bounds[c] + within[c] + n)
+            within[c] += n
+        old_off += cnt
+    return pieces, bounds, old2new
+
+
+class _Works:
+    """The C asynchronous all-to-alls of one pull: ``wait_chunk(c)`` orders the caller's stream
+    after chunk ``c`` only, ``wait()`` after all of them."""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait_chunk(self, c):
+        w = self.works[c]
+        if w is not None:
+            w.wait()
+            self.works[c] = None
+
+    def wait(self):
+        for c in range(len(self.works)):
+            self.wait_chunk(c)
+
+
 class HaloExchange:
     """Pulls remote feature rows into the tail of a local feature buffer.
 
@@ -39,8 +89,9 @@ class HaloExchange:
     rank ``p`` in the order they appear in the halo block.
     """
 
-    def __init__(self, n_local, n_halo, feat, device, seed=0, requests=None, group=None):
+    def __init__(self, n_local, n_halo, feat, device, seed=0, requests=None, group=None, chunks=1):
         self.group = group
+        self.chunks = max(1, int(chunks))
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.n_local, self.n_halo, self.feat = int(n_local), int(n_halo), int(feat)
@@ -63,41 +114,52 @@ class HaloExchange:
         _all_to_all(serve, want, self.send_splits, self.recv_splits, group)
         if serve.numel():
             assert int(serve.min()) >= 0 and int(serve.max()) < self.n_local
-        self.serve_rows = serve          # local rows to send, grouped by destination rank
+        # ---- chunked pipeline (chunks > 1): the halo block is stored CHUNK-MAJOR (chunk_layout); one
+        # all-to-all per chunk, so the consumer can start on chunk c while chunk c + 1 is in flight.
+        # With chunks == 1 everything below degenerates to the peer-major layout documented above.
+        self.recv_pieces, self.chunk_bounds, self.halo_old2new = chunk_layout(self.recv_splits, self.chunks)
+        self.send_pieces, self.serve_bounds, serve_o2n = chunk_layout(self.send_splits, self.chunks)
+        if self.chunks > 1 and serve.numel():
+            cm = torch.empty_like(serve)
+            cm[serve_o2n.to(serve.device)] = serve
+            serve = cm
+        self.serve_rows = serve          # local rows to send: chunk by chunk, destination ranks ascending inside
         self._send_buf = None
         self._recv_buf = None
 
-    def _pack(self, x_local, rows, buf_name):
-        """``x_local[rows]`` into a reusable send buffer: the library's row-gather kernel on the
-        GPU (csrc/exchange.hip), torch's on CPU tensors (gloo tests; host logic, no kernels)."""
-        buf = getattr(self, buf_name)
-        shape = (rows.numel(),) + tuple(x_local.shape[1:])
-        if buf is None or buf.dtype != x_local.dtype or tuple(buf.shape) != shape or \
-                buf.device != x_local.device:
-            buf = torch.empty(shape, dtype=x_local.dtype, device=x_local.device)
-            setattr(self, buf_name, buf)
-        if x_local.is_cuda:
-            from . import _capi
-            _capi.gather_rows(x_local, rows, out=buf)
-        else:
-            torch.index_select(x_local, 0, rows, out=buf)
-        return buf
-
     def pull_async(self, x_local, halo_out):
-        """Start filling ``halo_out`` (``n_halo`` rows, grouped by owner) with the peers' current
-        values of the requested rows of their ``x_local``; returns a work handle (or None) whose
-        ``wait()`` orders the caller's stream after the exchange.  With RCCL the collective runs
-        on the process group's own stream, so kernels queued between this call and ``wait()``
-        overlap with the transfer (exchange hidden behind the local-column part)."""
+        """Start filling ``halo_out`` (``n_halo`` rows; peer-major, or chunk-major when ``chunks > 1``)
+        with the peers' current values of the requested rows of their ``x_local``; returns a handle
+        (or None) whose ``wait()`` / ``wait_chunk(c)`` orders the caller's stream after the whole
+        exchange / after chunk ``c``.  With RCCL the collectives run on the process group's own
+        stream, each ordered after the pack kernel of ITS chunk only, so kernels queued between
+        this call and the waits overlap with the transfers."""
         assert halo_out.shape[0] == self.n_halo and halo_out.is_contiguous()
         if self.world == 1:
             return None
-        send = self._pack(x_local[: self.n_local], self.serve_rows, "_send_buf")
-        if _host_staged(halo_out, self.group):
-            _all_to_all(halo_out, send, self.recv_splits, self.send_splits, self.group)
-            return None
-        return dist.all_to_all_single(halo_out, send, self.recv_splits, self.send_splits,
-                                      group=self.group, async_op=True)
+        shape = (self.serve_rows.numel(),) + tuple(x_local.shape[1:])
+        buf = self._send_buf
+        if buf is None or buf.dtype != x_local.dtype or tuple(buf.shape) != shape or buf.device != x_local.device:
+            buf = self._send_buf = torch.empty(shape, dtype=x_local.dtype, device=x_local.device)
+        xl = x_local[: self.n_local]
+        works = []
+        for c in range(self.chunks):
+            s0, s1 = self.serve_bounds[c], self.serve_bounds[c + 1]
+            h0, h1 = self.chunk_bounds[c], self.chunk_bounds[c + 1]
+            rows, send = self.serve_rows[s0:s1], buf[s0:s1]
+            if s1 > s0:  # pack this chunk (csrc/exchange.hip on the GPU; torch on CPU tensors under gloo)
+                if xl.is_cuda:
+                    from . import _capi
+                    _capi.gather_rows(xl, rows, out=send)
+                else:
+                    torch.index_select(xl, 0, rows, out=send)
+            if _host_staged(halo_out, self.group):
+                _all_to_all(halo_out[h0:h1], send, self.recv_pieces[c], self.send_pieces[c], self.group)
+                works.append(None)
+            else:
+                works.append(dist.all_to_all_single(halo_out[h0:h1], send, self.recv_pieces[c],
+                                                    self.send_pieces[c], group=self.group, async_op=True))
+        return _Works(works)
 
     def pull(self, x):
         """Fill ``x[n_local:]`` with the peers' current values of the requested rows."""
@@ -121,8 +183,11 @@ class HaloExchange:
         if self._recv_buf is None or self._recv_buf.dtype != halo_grad.dtype or \
                 tuple(self._recv_buf.shape) != shape:
             self._recv_buf = torch.empty(shape, dtype=halo_grad.dtype, device=halo_grad.device)
-        _all_to_all(self._recv_buf, halo_grad.contiguous(), self.send_splits, self.recv_splits,
-                    self.group)
+        hg = halo_grad.contiguous()
+        for c in range(self.chunks):  # the halo block is chunk-major: one all-to-all per chunk, as in the pull
+            s0, s1 = self.serve_bounds[c], self.serve_bounds[c + 1]
+            h0, h1 = self.chunk_bounds[c], self.chunk_bounds[c + 1]
+            _all_to_all(self._recv_buf[s0:s1], hg[h0:h1], self.send_pieces[c], self.recv_pieces[c], self.group)
         if local_grad.is_cuda:
             from . import _capi
             _capi.scatter_add(self._recv_buf, self.serve_rows, local_grad)
@@ -511,27 +576,66 @@ def row_slice_csr(indptr, indices, rows):
     return ptr.to(indptr.dtype), indices[pos].contiguous()
 
 
+def split_halo_block(halo_pair, n_local, old2new, bounds):
+    """The halo-column block ``(indptr, indices)`` of a shard, column ids renumbered from the
+    peer-major to the chunk-major halo layout (``old2new``), cut into one CSR per chunk (all
+    ``n_local`` rows each; column ids stay absolute positions in the halo buffer).  Inside a row
+    the edges keep their order, which is ascending in the new numbering too."""
+    indptr, indices = halo_pair
+    dev = indptr.device
+    ip = indptr.long()
+    deg = ip[1:] - ip[:-1]
+    row_of = torch.repeat_interleave(torch.arange(n_local, device=dev), deg)
+    new_cols = old2new.to(dev)[indices.long()]
+    b = torch.tensor(bounds, dtype=torch.int64, device=dev)
+    chunk_of = torch.bucketize(new_cols, b[1:], right=True)
+    blocks = []
+    for c in range(len(bounds) - 1):
+        m = chunk_of == c
+        cnt = torch.zeros(n_local, dtype=torch.int64, device=dev)
+        cnt.index_add_(0, row_of[m], torch.ones(int(m.sum()), dtype=torch.int64, device=dev))
+        ptr = torch.zeros(n_local + 1, dtype=torch.int64, device=dev)
+        ptr[1:] = torch.cumsum(cnt, 0)
+        blocks.append((ptr.to(indptr.dtype), new_cols[m].to(indices.dtype).contiguous()))
+    return blocks
+
+
 class SimulatedExchange:
     """In-process stand-in for :class:`HaloExchange` over a list of simulated ranks: the pull
     copies rows between the ranks' feature tensors directly.  Lets one GPU (or the CPU) run the
     sharded schedule of all ``k`` ranks one after the other — used by the parity tests and by
     ``bench.py --simulate-ranks`` to time every rank's compute on the one GPU a box has."""
 
-    def __init__(self, shards):
+    def __init__(self, shards, chunks=1):
         self.shards = shards
         self.x_local = [None] * len(shards)
+        self.chunks = max(1, int(chunks))
+        self._layout = {}
 
     def bind(self, rank, x_local):
         self.x_local[rank] = x_local
 
+    def layout(self, rank):
+        """(chunk_bounds, old2new) of rank's halo block, as HaloExchange(chunks=...) lays it out."""
+        if rank not in self._layout:
+            sh = self.shards[rank]
+            counts = [int(sh["requests"][p].numel()) if p in sh["requests"] else 0
+                      for p in range(len(self.shards))]
+            _, bounds, o2n = chunk_layout(counts, self.chunks)
+            self._layout[rank] = (bounds, o2n)
+        return self._layout[rank]
+
     def pull_into(self, rank, halo_out):
-        off = 0
         sh = self.shards[rank]
-        for p in sorted(sh["requests"]):
-            rows = sh["requests"][p].to(halo_out.device)
-            halo_out[off: off + rows.numel()] = self.x_local[p][rows.long()]
-            off += rows.numel()
-        assert off == sh["n_halo"]
+        parts = [self.x_local[p][sh["requests"][p].to(halo_out.device).long()] for p in sorted(sh["requests"])]
+        assert sum(t.shape[0] for t in parts) == sh["n_halo"]
+        if not parts:
+            return
+        peer_major = torch.cat(parts)
+        if self.chunks == 1:
+            halo_out.copy_(peer_major)
+        else:
+            halo_out[self.layout(rank)[1].to(halo_out.device)] = peer_major
 
 
 def _gpu_spmm_factory(device):
@@ -573,7 +677,7 @@ class ShardedSpMM:
     the library's CSR kernel on the GPU.  Tests inject a CPU oracle; nothing here falls back."""
 
     def __init__(self, shard, feat_shape, dtype, device, exchange=None, group=None, spmm=None,
-                 rank=None):
+                 rank=None, chunks=1):
         self.shard = shard
         self.n_local, self.n_halo = shard["n_local"], shard["n_halo"]
         self.device = torch.device(device)
@@ -581,8 +685,19 @@ class ShardedSpMM:
         self.rank = rank
         if exchange is None:
             exchange = HaloExchange(self.n_local, self.n_halo, int(torch.tensor(feat_shape).prod()),
-                                    self.device, requests=shard["requests"], group=group)
+                                    self.device, requests=shard["requests"], group=group, chunks=chunks)
         self.exchange = exchange
+        # chunked pipeline: the halo-column block is split by chunk of the (chunk-major) halo buffer;
+        # chunk c's launch is queued as soon as chunk c's all-to-all has landed, while c + 1 travels
+        self.chunks = int(getattr(exchange, "chunks", 1))
+        if self.chunks > 1 and self.n_halo:
+            if isinstance(exchange, SimulatedExchange):
+                bounds, o2n = exchange.layout(rank)
+            else:
+                bounds, o2n = exchange.chunk_bounds, exchange.halo_old2new
+            self.halo_blocks = split_halo_block(shard["halo"], self.n_local, o2n, bounds)
+        else:
+            self.halo_blocks = [shard["halo"]]
         if spmm is None:
             if self.device.type != "cuda":
                 raise RuntimeError("ShardedSpMM: the kernel backend runs on a ROCm GPU (no CPU fallback)")
@@ -597,8 +712,15 @@ class ShardedSpMM:
         elif self.n_halo or self.exchange.world > 1:
             work = self.exchange.pull_async(x_local, self.halo)
         self.spmm("local", self.shard["local"], self.n_local, x_local, out_local, False)
-        if work is not None:
-            work.wait()
-        if self.n_halo:
-            self.spmm("halo", self.shard["halo"], self.n_halo, self.halo, out_local, True)
+        if not self.n_halo:
+            if work is not None:
+                work.wait()
+            return out_local
+        for c, blk in enumerate(self.halo_blocks):
+            if work is not None:
+                if len(self.halo_blocks) > 1:
+                    work.wait_chunk(c)
+                else:
+                    work.wait()
+            self.spmm("halo" if c == 0 else "halo%d" % c, blk, self.n_halo, self.halo, out_local, True)
         return out_local

@@ -44,7 +44,7 @@ class RemainderDouble:
         return idx // self.k
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, chunks=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -67,7 +67,14 @@ def _worker(rank, world, port, ret):
         sh = shard_from_partition(g["indptr"], g["indices"], part, world, rank)
         assert sh["nnz"] == int(sh["local"][0][-1]) + int(sh["halo"][0][-1])
         rows = sh["rows"]
-        op = ShardedSpMM(sh, (f,), torch.float64, "cpu", spmm=oracle_backend())
+        op = ShardedSpMM(sh, (f,), torch.float64, "cpu", spmm=oracle_backend(), chunks=chunks)
+        assert op.chunks == chunks and len(op.halo_blocks) == (chunks if sh["n_halo"] else 1)
+        if chunks > 1 and sh["n_halo"]:
+            # the chunk blocks partition the halo-column block: same edges, columns inside their chunk
+            assert sum(int(b[0][-1]) for b in op.halo_blocks) == int(sh["halo"][0][-1])
+            for c, (bp, bi) in enumerate(op.halo_blocks):
+                if bi.numel():
+                    assert int(bi.min()) >= op.exchange.chunk_bounds[c] and int(bi.max()) < op.exchange.chunk_bounds[c + 1]
         x_loc = x_full[rows].contiguous()
         out = torch.empty(sh["n_local"], f, dtype=torch.float64)
         op.step(x_loc, out)
@@ -123,13 +130,34 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_spmm_and_exchange(world):
-    port = 23000 + (os.getpid() % 2000) + world
+@pytest.mark.parametrize("world,chunks", [(2, 1), (4, 1), (4, 3), (2, 4)])
+def test_sharded_spmm_and_exchange(world, chunks):
+    """chunks > 1: the pipelined schedule (chunk-major halo block, one all-to-all per chunk, the
+    halo-column block cut per chunk) must give what the unpartitioned graph gives, pull and push
+    stay transposes of each other (VERDICT r2 Next #3)."""
+    port = 23000 + (os.getpid() % 2000) + world * 8 + chunks
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, chunks), nprocs=world, join=True)
     assert dict(ret) == {r: "ok" for r in range(world)}
+
+
+def test_chunk_layout_is_a_permutation_and_owner_derivable():
+    from dgl_amd.parallel import chunk_layout
+
+    counts = [0, 7, 3, 0, 10, 1]
+    for C in (1, 2, 3, 5, 16):
+        pieces, bounds, o2n = chunk_layout(counts, C)
+        assert sorted(o2n.tolist()) == list(range(sum(counts)))
+        assert bounds[0] == 0 and bounds[-1] == sum(counts) and len(pieces) == C
+        assert [sum(pieces[c][p] for c in range(C)) for p in range(len(counts))] == counts
+        # inside a chunk: peers ascending, each peer's piece contiguous and in request order
+        off = 0
+        for p, cnt in enumerate(counts):
+            pos = o2n[off: off + cnt]
+            assert bool((pos[1:] > pos[:-1]).all()) if cnt > 1 else True
+            off += cnt
+    assert torch.equal(chunk_layout(counts, 1)[2], torch.arange(sum(counts)))
 
 
 def test_shard_from_partition_matches_relabel_then_shard():
