@@ -175,7 +175,7 @@ def cpu_baseline(g, x, budget_s=20.0):
     }, out
 
 
-def spawn_ranks(n, share_gpu=False):
+def spawn_ranks(n, share_gpu=False, script=None):
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks under
     torch.distributed.run on this node (one rank per GPU, rendezvous on 127.0.0.1) and return its
     exit code.  Refuses when fewer than N GPUs are visible (unless the gloo flow-test backend is
@@ -191,7 +191,8 @@ def spawn_ranks(n, share_gpu=False):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(script or __file__)] + sys.argv[1:]
     return subprocess.call(cmd, cwd=ROOT)
 
 

@@ -29,6 +29,60 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 from tests.graphgen import C2_EDGES, C2_NODES, synth_csr  # noqa: E402
 
 
+def sync_grads(grads, dist, world):
+    """Gradient all-reduce (mean) of one step: ONE flat buffer, one collective — what DDP's bucket
+    does for a model this small (reference: DistributedDataParallel in
+    benchmarks/benchmarks/multigpu/bench_multigpu_sage.py:86-90).  Under the gloo flow-test backend
+    device tensors are staged through host memory."""
+    if dist is None or world == 1:
+        return list(grads)
+    flat = torch.cat([gr.reshape(-1) for gr in grads])
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        h = flat.cpu()
+        dist.all_reduce(h)
+        flat = h.to(flat.device)
+    else:
+        dist.all_reduce(flat)
+    flat /= world
+    off, synced = 0, []
+    for gr in grads:
+        synced.append(flat[off:off + gr.numel()].view_as(gr))
+        off += gr.numel()
+    return synced
+
+
+def reduce_host(values, op, dist, dev):
+    """all-reduce a short list of Python floats with whatever the backend takes (RCCL: device
+    tensors; gloo: host tensors)."""
+    t = torch.tensor(values, dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+    dist.all_reduce(t, op=op)
+    return [float(v) for v in t.tolist()]
+
+
+class FeatureStore:
+    """Input features of the mini-batch: ``replicated`` (every GPU holds all N rows — what 288 GB of
+    HBM make natural) or ``sharded`` (row i lives on rank i % world, local row i // world — the
+    reference's NDArrayPartition 'remainder' mode, python/dgl/partition.py:474-640 — and every
+    batch pulls its input rows with sparse_all_to_all_pull, python/dgl/cuda/nccl.py:98-183)."""
+
+    def __init__(self, feat_full, mode, rank, world):
+        from dgl_amd.parallel import NDArrayPartition
+
+        self.mode, self.world = mode, world
+        if mode == "sharded" and world > 1:
+            self.part = NDArrayPartition(feat_full.shape[0], world, mode="remainder")
+            self.local = feat_full[rank::world].contiguous()
+        else:
+            self.part, self.local = None, feat_full
+
+    def fetch(self, ids):
+        if self.part is None:
+            return self.local[ids]
+        from dgl_amd.parallel import sparse_all_to_all_pull
+
+        return sparse_all_to_all_pull(ids, self.local, self.part)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
@@ -36,10 +90,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scale", type=int, default=1)
     ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--features", default="replicated", choices=["replicated", "sharded"],
+                    help="sharded: features partitioned over the ranks, pulled per batch (the reference's layout)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    gloo = os.environ.get("DGLA_BENCH_BACKEND", "nccl") == "gloo"   # flow test: ranks may share a GPU
+    if local_rank >= torch.cuda.device_count():
+        if not gloo:
+            raise SystemExit("bench_sage.py: rank %d has no GPU of its own" % local_rank)
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -47,7 +108,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import dgl_amd as dgl
     import dgl_amd.function as fn
@@ -59,7 +123,7 @@ def main():
     rel = Relation(n, n, csc=(gs["indptr"], gs["indices"], None), idtype=torch.int64, device=dev)
     g = DGLGraph(GraphIndex([n], [(0, 0)], [rel]), ["_N"], [("_N", "_E", "_N")])
     torch.manual_seed(0)
-    feat = torch.rand(n, f, device=dev)
+    store = FeatureStore(torch.rand(n, f, device=dev), args.features, rank, world)
     labels = torch.randint(0, classes, (n,), device=dev)
     params = [torch.randn(f, args.hidden, device=dev) * 0.05, torch.randn(f, args.hidden, device=dev) * 0.05,
               torch.randn(args.hidden, classes, device=dev) * 0.05, torch.randn(args.hidden, classes, device=dev) * 0.05]
@@ -80,20 +144,12 @@ def main():
         seeds = torch.randint(0, n, (args.batch,), device=dev, generator=gen).unique()
         inp, out, blocks = sampler.sample_blocks(g, seeds)
         edges[0] += sum(b.num_edges() for b in blocks)
-        h = feat[inp]
+        h = store.fetch(inp)
         h = torch.relu(sage(blocks[0], h, params[0], params[1]))
         logits = sage(blocks[1], h, params[2], params[3])
         loss = torch.nn.functional.cross_entropy(logits, labels[out.long()])
         grads = torch.autograd.grad(loss, params)
-        if dist is not None:
-            flat = torch.cat([gr.reshape(-1) for gr in grads])
-            dist.all_reduce(flat)
-            flat /= world
-            off, synced = 0, []
-            for gr in grads:
-                synced.append(flat[off:off + gr.numel()].view_as(gr))
-                off += gr.numel()
-            grads = synced
+        grads = sync_grads(grads, dist, world)
         with torch.no_grad():
             for p, gr in zip(params, grads):
                 p -= 0.1 * gr
@@ -112,19 +168,23 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    tot_edges = float(edges[0])
+    # replicas must hold the same parameters after the same synchronised steps
+    chk = [float(p.detach().double().sum()) for p in params]
+    spread = 0.0
     if dist is not None:
-        t = torch.tensor([dt, float(edges[0])], device=dev, dtype=torch.float64)
-        tm = t.clone()
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, tot_edges = float(tm[0]), float(t[1])
-    else:
-        tot_edges = float(edges[0])
+        dt = reduce_host([dt], dist.ReduceOp.MAX, dist, dev)[0]
+        tot_edges = reduce_host([tot_edges], dist.ReduceOp.SUM, dist, dev)[0]
+        hi = reduce_host(chk, dist.ReduceOp.MAX, dist, dev)
+        lo = reduce_host(chk, dist.ReduceOp.MIN, dist, dev)
+        spread = max(abs(a - b) / max(abs(a), 1e-30) for a, b in zip(hi, lo))
     if rank == 0:
         print(json.dumps({
             "workload": "2-layer GraphSAGE-mean mini-batch training step, fanouts (15, 10), batch %d per GPU, "
-                        "graph N=%d E=%d (variant L), F=%d -> %d -> %d, fp32; graph + features replicated per GPU"
+                        "graph N=%d E=%d (variant L), F=%d -> %d -> %d, fp32; graph replicated per GPU"
                         % (args.batch, n, e, f, args.hidden, classes),
+            "features": args.features if world > 1 else "local",
+            "param_checksum_rel_spread_across_ranks": spread,
             "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
             "seeds_per_s": args.batch * world * args.steps / dt,
             "sampled_edges_per_s": tot_edges / dt, "final_loss": float(loss.detach())}))

@@ -64,3 +64,23 @@ def test_bench_rejects_world_size_mismatch():
                         "--warmup", "1", "--scale", "64"], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, cwd=ROOT, timeout=250)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+@pytest.mark.timeout(900)
+def test_bench_rgcn_two_ranks_on_one_gpu():
+    """configs[4] with N > 1 (row e3): benchmarks/bench_rgcn.py starts its own two ranks (gloo flow
+    backend, the ranks share the one GPU), every rank's rows ≡ the single-GPU stacked launch."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["DGLA_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "bench_rgcn.py"), "--gpus", "2",
+                        "--steps", "3", "--warmup", "1", "--scale", "50", "--chunks", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["dtype"] == "bf16" and r["edges_per_s"] > 0
+    assert r["parity_max_rel_err_vs_single_gpu_stacked_launch"] <= 2.0 ** -7
+    assert sum(i["edges"] for i in r["per_rank"]) == 8 * (12_500_000 // 50)
+    assert 0.3 < r["cut_fraction"] < 0.7      # uniform graph, two ranges: about one half
