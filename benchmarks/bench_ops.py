@@ -534,6 +534,87 @@ def gat_graph(dev, args):
         emit("GAT", "GATConv forward H=8 D=%d, one hipGraph replay" % d, e, ms, mn, nb)
 
 
+def edge_order(dev, args):
+    """Position-ordered hand-off of edge tensors (dgl_amd.edge_order; VERDICT r2 Next #4) through the
+    operator API on graphs that carry DGL's usual random edge-id map: edge softmax alone (plain
+    edge-id-ordered scores in; forward, and forward + backward), and the GATConv forward layer, with
+    the hand-off off / on; the map-free kernel time is the yardstick."""
+    import dgl_amd as dgl
+    import dgl_amd.function as fn
+    from dgl_amd.graph_index import GraphIndex, Relation
+    from dgl_amd.heterograph import DGLGraph
+
+    h, s, i = 8, 4, 4
+    sizes = [(169_343, 2_501_829, "C3")]
+    if args.scale == 1:
+        sizes.append((C2_NODES, C2_EDGES, "C2-size"))
+    for n, e, tag in sizes:
+        g = synth_csr(n, n, e, "U", device=dev, with_eids=True)
+        rel = Relation(n, n, csc=(g["indptr"], g["indices"], g["eids"]), idtype=g["indptr"].dtype, device=dev)
+        dg = DGLGraph(GraphIndex([n], [(0, 0)], [rel]), ["_N"], [("_N", "_E", "_N")])
+        rel0 = Relation(n, n, csc=(g["indptr"], g["indices"], None), idtype=g["indptr"].dtype, device=dev)
+        dg0 = DGLGraph(GraphIndex([n], [(0, 0)], [rel0]), ["_N"], [("_N", "_E", "_N")])
+        x = torch.rand(e, h, 1, device=dev)
+        nb_f = e * (2 * h * s + i) + (n + 1) * i
+        nb_fb = e * (5 * h * s + 2 * i) + 2 * (n + 1) * i      # fwd: read + write; bwd: out, grad in, grad out
+        ms0, mn0 = timeit(lambda: dgl.edge_softmax(dg0, x))
+        emit(tag, "edge_softmax fwd via API, map-free graph (yardstick)", e, ms0, mn0, nb_f - e * i)
+        for on in (False, True):
+            dgl.set_edge_order_handoff(on)
+            ms, mn = timeit(lambda: dgl.edge_softmax(dg, x))
+            emit(tag, "edge_softmax fwd via API, random edge-id map, hand-off %s" % ("ON (gather in, position-ordered out)" if on else "off"),
+                 e, ms, mn, nb_f, ratio_to_map_free=ms / ms0)
+            xg = x.clone().requires_grad_(True)
+            up = torch.rand(e, h, 1, device=dev)
+
+            def fb():
+                xg.grad = None
+                (dgl.edge_softmax(dg, xg) * 2.0).backward(up)   # (* 2.0 keeps the layout: `up` plays a position-ordered gradient)
+
+            ms, mn = timeit(fb)
+            emit(tag, "edge_softmax fwd + bwd via API, random edge-id map, hand-off %s" % ("ON" if on else "off"),
+                 e, ms, mn, nb_fb)
+            del xg, up
+        dgl.set_edge_order_handoff(True)
+        # the GAT forward layer (H = 8) and one training step of it
+        for d in (8, 32):
+            ft = torch.randn(n, h, d, device=dev)
+            el = torch.randn(n, h, 1, device=dev)
+            er = torch.randn(n, h, 1, device=dev)
+
+            def layer(graph, ft=ft, el=el, er=er):
+                with graph.local_scope():
+                    graph.srcdata.update({"ft": ft, "el": el})
+                    graph.dstdata.update({"er": er})
+                    graph.apply_edges(fn.u_add_v("el", "er", "e"))
+                    sc = torch.nn.functional.leaky_relu(graph.edata.pop("e"), 0.2)
+                    graph.edata["a"] = dgl.edge_softmax(graph, sc)
+                    graph.update_all(fn.u_mul_e("ft", "a", "m"), fn.sum("m", "o"))
+                    return graph.dstdata["o"]
+
+            nb = e * (h * 4 * 6 + h * d * 4 + 3 * 4) + n * h * d * 4
+            ms0, mn0 = timeit(lambda: layer(dg0), reps=10, warm=3)
+            emit(tag, "GATConv forward H=8 D=%d via API, map-free graph (yardstick)" % d, e, ms0, mn0, nb)
+            for on in (False, True):
+                dgl.set_edge_order_handoff(on)
+                ms, mn = timeit(lambda: layer(dg), reps=10, warm=3)
+                emit(tag, "GATConv forward H=8 D=%d via API, random edge-id map, hand-off %s" % (d, "ON" if on else "off"),
+                     e, ms, mn, nb, ratio_to_map_free=ms / ms0)
+                ps = [t.clone().requires_grad_(True) for t in (ft, el, er)]
+
+                def train():
+                    for p in ps:
+                        p.grad = None
+                    layer(dg, *ps).square().sum().backward()
+
+                ms, mn = timeit(train, reps=10, warm=3)
+                emit(tag, "GATConv forward + backward H=8 D=%d via API, random edge-id map, hand-off %s" % (d, "ON" if on else "off"),
+                     e, ms, mn, 3 * nb)
+            dgl.set_edge_order_handoff(True)
+            del ft, el, er
+        del g, dg, dg0, rel, rel0, x
+
+
 def fmt(dev, args):
     """COO -> CSC of the C2 graph: dgla_coo_to_csr (radix sort of (dst, position)
     + one fused gather / indptr kernel) vs the same result from torch primitives (stable argsort,
@@ -578,7 +659,7 @@ def main():
     global VERIFY
     VERIFY = args.verify
     dev = torch.device("cuda:0")
-    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("C5MAX", c5max), ("SEG", seg), ("MM", mm), ("SAMPLE", sample), ("GAT", gat_graph), ("FMT", fmt)):
+    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("C5MAX", c5max), ("SEG", seg), ("MM", mm), ("SAMPLE", sample), ("GAT", gat_graph), ("EO", edge_order), ("FMT", fmt)):
         if args.only and name not in args.only.split(","):
             continue
         fn(dev, args)

@@ -27,6 +27,9 @@ def _tensor(t, keep):
     unsqueeze in python/dgl/_sparse_ops.py:208-217)."""
     if t is None:
         return Tensor(None, 0, None)
+    if type(t) is not torch.Tensor:
+        from .edge_order import reject_tagged
+        reject_tagged(t)
     _require_gpu(t)
     if not t.is_contiguous():
         raise _lib.DGLAMDError("feature tensors must be contiguous")

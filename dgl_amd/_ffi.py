@@ -60,6 +60,9 @@ class NDArray:
     def __init__(self, t, unsqueeze=False, host_ok=False):
         # host_ok: small integer side inputs the reference itself keeps in host memory
         # (segment_mm's seglen, python/dgl/ops/gather_mm.py:57) travel as kDGLCPU arrays
+        if type(t) is not torch.Tensor:
+            from .edge_order import reject_tagged
+            reject_tagged(t)
         if not t.is_cuda and not (host_ok and not t.dtype.is_floating_point):
             raise _lib.DGLAMDError("dgl_amd: tensors must live on a ROCm GPU (no CPU fallback)")
         if not t.is_contiguous():

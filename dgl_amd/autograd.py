@@ -9,6 +9,7 @@ runs max-SpMM, sub-SDDMM, exp, sum-SpMM, div-SDDMM there, sparse.py:709-713).
 """
 import torch
 
+from . import edge_order as _eo
 from ._lib import DGLAMDError
 from .sparse_kernels import (_edge_softmax_backward, _edge_softmax_forward, _gsddmm,
                              _gsddmm_hetero, _gspmm, _gspmm_hetero, _update_grad_minmax_hetero)
@@ -82,9 +83,9 @@ class GSpMM(torch.autograd.Function):
         if op != "copy_lhs" and ctx.needs_input_grad[4]:
             if reduce_op == "sum":
                 if op == "mul":
-                    dY = gsddmm(gidx, "dot" if reduce_last else "mul", X, dZ)
+                    dY = gsddmm(gidx, "dot" if reduce_last else "mul", X, dZ, _handoff=False)
                 else:  # add, copy_rhs
-                    dY = gsddmm(gidx, "copy_rhs", X, dZ)
+                    dY = gsddmm(gidx, "copy_rhs", X, dZ, _handoff=False)
             else:
                 dY = torch.zeros((y_shape[0],) + tuple(dZ.shape[1:]), dtype=dtype, device=device)
                 if op == "mul":
@@ -127,9 +128,9 @@ class GSpMMMean(torch.autograd.Function):
             dX = _reduce_grad(dX, x_shape)
         if op != "copy_lhs" and ctx.needs_input_grad[3]:
             if op == "mul":
-                dY = gsddmm(gidx, "dot" if reduce_last else "mul", X, dZ)
+                dY = gsddmm(gidx, "dot" if reduce_last else "mul", X, dZ, _handoff=False)
             else:
-                dY = gsddmm(gidx, "copy_rhs", X, dZ)
+                dY = gsddmm(gidx, "copy_rhs", X, dZ, _handoff=False)
             dY = _reduce_grad(dY, y_shape)
         return None, None, dX, dY, None
 
@@ -140,6 +141,8 @@ def gspmm_mean(gidx, op, lhs_data, rhs_data, in_deg):
         op, rhs_data = "add", -rhs_data
     if op == "div":
         op, rhs_data = "mul", 1.0 / rhs_data
+    lhs_data = None if lhs_data is None else _eo.plain(lhs_data)
+    rhs_data = None if rhs_data is None else _eo.plain(rhs_data)
     lhs_data, rhs_data = _autocast(lhs_data, rhs_data)
     with torch.autocast("cuda", enabled=False):
         return GSpMMMean.apply(gidx, op, lhs_data, rhs_data, in_deg)
@@ -176,7 +179,7 @@ class GSDDMM(torch.autograd.Function):
                 return gspmm(g, "mul", "sum", other, dZ)
             if op in ("add", copy_op):
                 return dZ
-            return gsddmm(gidx, "mul", dZ, other, "e", other_tgt)
+            return gsddmm(gidx, "mul", dZ, other, "e", other_tgt, _handoff=False)
 
         dX = dY = None
         if op != "copy_rhs" and ctx.needs_input_grad[2]:
@@ -214,27 +217,71 @@ def _autocast(*tensors):
     return tuple(t.to(dt) if (t is not None and t.is_floating_point()) else t for t in tensors)
 
 
+def _edge_operand_route(gidx, op, reduce_op, rhs_data):
+    """Can a position-ordered edge operand be used as it is?  Returns the relation it is ordered by
+    (then dgl_amd.edge_order.PosGSpMM runs), else None (then the tensor is converted to edge-id order)."""
+    rel = _eo.tag_of(rhs_data)
+    if rel is None or reduce_op != "sum" or op == "copy_lhs" or gidx.number_of_etypes() != 1:
+        return None
+    q = gidx.relations[0]
+    if rel is q:
+        return rel if q.allowed("csc") else None
+    if rel.reverse() is q:
+        return rel if rel.allowed("csr") else None
+    return None
+
+
 def gspmm(gidx, op, reduce_op, lhs_data, rhs_data):
     if op == "sub":
         op, rhs_data = "add", -rhs_data
     elif op == "div":
         op, rhs_data = "mul", 1.0 / rhs_data
+    lhs_data = _eo.plain(lhs_data) if lhs_data is not None else None
+    rel = _edge_operand_route(gidx, op, reduce_op, rhs_data) if not torch.is_autocast_enabled() else None
+    if rel is not None:
+        return _eo.PosGSpMM.apply(gidx, op, lhs_data, rhs_data, rel)
+    rhs_data = _eo.plain(rhs_data) if rhs_data is not None else None
     lhs_data, rhs_data = _autocast(lhs_data, rhs_data)
     with torch.autocast("cuda", enabled=False):
         return GSpMM.apply(gidx, op, reduce_op, lhs_data, rhs_data)
 
 
-def gsddmm(gidx, op, lhs_data, rhs_data, lhs_target="u", rhs_target="v"):
+def gsddmm(gidx, op, lhs_data, rhs_data, lhs_target="u", rhs_target="v", _handoff=True):
+    """``_handoff=False``: the result is the gradient of an EDGE-ID-ORDERED tensor (the backward passes
+    of the plain Functions above): it must come out edge-id ordered and untagged."""
     if op == "sub":
         op, rhs_data = "add", -rhs_data
     elif op == "div":
         op, rhs_data = "mul", 1.0 / rhs_data
+    # position-ordered hand-off (dgl_amd.edge_order): the result is produced in the CSC position order
+    # of the relation when the graph's edge ids are not its CSC order anyway and no operand is an
+    # edge-id-ordered edge tensor; 'e' operands tagged with this relation are read as they are
+    if _handoff and gidx.number_of_etypes() == 1 and not torch.is_autocast_enabled():
+        rel = gidx.relations[0]
+        use = {"l": op != "copy_rhs", "r": op != "copy_lhs"}
+        nat_l = use["l"] and lhs_target == "e" and _eo.tag_of(lhs_data) is rel
+        nat_r = use["r"] and rhs_target == "e" and _eo.tag_of(rhs_data) is rel
+        plain_e = (use["l"] and lhs_target == "e" and not nat_l) or (use["r"] and rhs_target == "e" and not nat_r)
+        if not plain_e and (nat_l or nat_r or _eo.wants_handoff(rel)) and rel.allowed("csc") and \
+                (lhs_data if use["l"] else rhs_data).is_cuda:
+            lhs_data = lhs_data if (nat_l or lhs_data is None) else _eo.plain(lhs_data)
+            rhs_data = rhs_data if (nat_r or rhs_data is None) else _eo.plain(rhs_data)
+            return _eo.PosGSDDMM.apply(gidx, op, lhs_data, rhs_data, lhs_target, rhs_target)
+    lhs_data = _eo.plain(lhs_data) if lhs_data is not None else None
+    rhs_data = _eo.plain(rhs_data) if rhs_data is not None else None
     lhs_data, rhs_data = _autocast(lhs_data, rhs_data)
     with torch.autocast("cuda", enabled=False):
         return GSDDMM.apply(gidx, op, lhs_data, rhs_data, lhs_target, rhs_target)
 
 
 def edge_softmax(gidx, logits, eids=None, norm_by="dst"):
+    if eids is None and norm_by == "dst" and gidx.number_of_etypes() == 1 and logits.is_cuda and \
+            not torch.is_autocast_enabled():
+        rel = gidx.relations[0]
+        tag = _eo.tag_of(logits)
+        if rel.allowed("csc") and (tag is rel or (tag is None and _eo.wants_handoff(rel))):
+            return _eo.PosEdgeSoftmax.apply(gidx, logits)
+    logits = _eo.plain(logits)
     (logits,) = _autocast(logits)
     with torch.autocast("cuda", enabled=False):
         return EdgeSoftmax.apply(gidx, logits, eids, norm_by)
@@ -463,7 +510,7 @@ def gspmm_hetero(gidx, op, reduce_op, lhs_len, *lhs_and_rhs):
         op, rhs = "add", _neg(rhs)
     elif op == "div":
         op, rhs = "mul", _inv(rhs)
-    feats = _autocast(*(lhs + rhs))
+    feats = _autocast(*[None if t is None else _eo.plain(t) for t in (lhs + rhs)])
     with torch.autocast("cuda", enabled=False):
         return GSpMM_hetero.apply(gidx, op, reduce_op, lhs_len, *feats)
 
@@ -474,12 +521,12 @@ def gsddmm_hetero(gidx, op, lhs_len, lhs_target, rhs_target, *lhs_and_rhs):
         op, rhs = "add", _neg(rhs)
     elif op == "div":
         op, rhs = "mul", _inv(rhs)
-    feats = _autocast(*(lhs + rhs))
+    feats = _autocast(*[None if t is None else _eo.plain(t) for t in (lhs + rhs)])
     with torch.autocast("cuda", enabled=False):
         return GSDDMM_hetero.apply(gidx, op, lhs_len, lhs_target, rhs_target, *feats)
 
 
 def edge_softmax_hetero(gidx, eids=None, norm_by="dst", *score):
-    score = _autocast(*score)
+    score = _autocast(*[None if t is None else _eo.plain(t) for t in score])
     with torch.autocast("cuda", enabled=False):
         return EdgeSoftmax_hetero.apply(gidx, eids, norm_by, *score)
