@@ -209,8 +209,8 @@ def set_profile_events(before, after):
         LIB.dgla_spmm_set_profile_events(before.cuda_event, after.cuda_event)
 
 
-TUNE_XCD, TUNE_NT_OUT, TUNE_NT_IDX, TUNE_SPLIT, TUNE_GLDS, TUNE_SPLIT_NT, TUNE_SPLIT_FORCE, TUNE_MM_F32 = (
-    1, 2, 4, 8, 16, 32, 64, 128)  # include/dgl_amd.h DGLA_TUNE_*
+TUNE_XCD, TUNE_NT_OUT, TUNE_NT_IDX, TUNE_SPLIT, TUNE_GLDS, TUNE_SPLIT_NT, TUNE_SPLIT_FORCE, TUNE_MM_F32, TUNE_SPLIT_CLASSIC = (
+    1, 2, 4, 8, 16, 32, 64, 128, 256)  # include/dgl_amd.h DGLA_TUNE_*
 
 
 def set_tuning(flags):

@@ -182,6 +182,8 @@ enum Tune : uint32_t {
   kTuneSplitNt = 32u,     // split-row copy: non-temporal stores of the main array
   kTuneSplitForce = 64u,  // split-row layout whenever the shape allows, whatever the locality probe says
   kTuneMmF32 = 128u,      // segment_mm fp32: v_mfma_f32_32x32x2_f32 instead of the 3 x bf16 split
+  kTuneSplitClassic = 256u,  // split-row layout: copy WHOLE rows (main + tail arrays, round 2) instead of
+                             // the edge layout that leaves the line-aligned interior of every row in place
 };
 // Default: XCD-contiguous order (measured on C2: variant L -3 % time, variant U neutral); the
 // non-temporal bits are neutral.  Split-row (profiles/r2/tune_split_ab.jsonl, C2, F = 100 fp32):

@@ -57,6 +57,12 @@ struct SpmmParams {
   const void* utail;
   const unsigned* split_meta;
   int split_main, split_tail;
+  // edge layout (split_edge_lines > 0; see spmm_split_edges_kernel): a row of 128 k + t bytes keeps
+  // its k - 1 line-aligned interior lines in `ufeat`; `umain` holds ONE 128-byte line per row (the
+  // ragged head + the part of the ragged tail that completes the line), `utail` the last t bytes.
+  int split_edge_lines;  // k - 1 (0: classic layout / none)
+  int split_t16;         // t / 16
+  int split_base16;      // (address of ufeat mod 128) / 16: where row 0 starts inside its line
   // stacked multi-relation form (MULTI kernels only)
   const uint8_t* rel;
   const void* const* xtab;
@@ -167,6 +173,58 @@ __global__ __launch_bounds__(256) void spmm_split_rows_kernel(
       } else {
         tail_out[r * tail_pieces + (j - main_pieces)] = v[k];  // small: keep it cached
       }
+    }
+  }
+}
+
+// Edge layout (round 3; default for rows of 128 k + t bytes with k >= 2).  Row r of X starts at byte
+// RB r, i.e. o = (t r) mod 128 bytes into a 128-byte line: [RB r, RB r + 128 - o) is a ragged HEAD,
+// then k - 1 WHOLE aligned lines, then a ragged tail of o + t bytes.  Only the ragged ends are
+// copied: S1[r] (one aligned 128-byte line per row) = head ++ first o bytes of the tail, S2[r] = the
+// last t bytes (dense; small enough for the Infinity Cache).  A gather then touches k - 1 lines of X
+// in place + 1 line of S1 + a cached piece, like the classic layout, but the copy moves
+// (128 + t) / RB of X instead of all of it (F = 100 fp32: 0.67 GB instead of 1.96 GB per call,
+// 0.33 -> 0.12 ms): the boundary line between two rows is read once and feeds both rows' S1 lines.
+// (o also counts the offset of X itself inside its line, `base16`, so that the in-place pieces are
+// whole lines for any 16-byte-aligned X.)  Piece p of the (8 + t16) side pieces of row r:  p < 8: S1 piece p  <-  row piece (p < 8 - o16 ? p :
+// p + 8 (k - 1));  p >= 8: S2 piece p - 8  <-  row piece RB/16 - t16 + (p - 8).
+template <int K>
+__global__ __launch_bounds__(256) void spmm_split_edges_kernel(
+    const piece16_t* __restrict__ x, piece16_t* __restrict__ s1, piece16_t* __restrict__ s2,
+    int64_t num_rows, int row_pieces, int t16, int interior_pieces, unsigned magic,
+    const unsigned* __restrict__ meta, unsigned base16) {
+  if (!split_wanted(meta)) return;
+  const int side = 8 + t16;
+  const int64_t total = num_rows * side;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * (256 * K); base < total;
+       base += static_cast<int64_t>(gridDim.x) * (256 * K)) {
+    const int64_t r0 = base / side;
+    const unsigned p0 = static_cast<unsigned>(base - r0 * side);
+    piece16_t v[K];
+    int64_t row[K];
+    unsigned pp[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      int64_t i = base + k * 256 + threadIdx.x;
+      if (i >= total) i = total - 1;
+      const unsigned loc = p0 + static_cast<unsigned>(i - base);
+      const unsigned dr = __umulhi(loc, magic);
+      const unsigned p = loc - dr * static_cast<unsigned>(side);
+      const int64_t r = r0 + dr;
+      const unsigned o16 = (static_cast<unsigned>(t16) * static_cast<unsigned>(r & 7) + base16) & 7u;
+      const unsigned j = p < 8u ? (p < 8u - o16 ? p : p + static_cast<unsigned>(interior_pieces))
+                                : static_cast<unsigned>(row_pieces - t16) + (p - 8u);
+      row[k] = r;
+      pp[k] = p;
+      v[k] = __builtin_nontemporal_load(x + r * row_pieces + j);  // read once
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (base + k * 256 + threadIdx.x >= total) continue;
+      if (pp[k] < 8u)
+        s1[row[k] * 8 + pp[k]] = v[k];
+      else
+        s2[row[k] * t16 + (pp[k] - 8u)] = v[k];
     }
   }
 }
@@ -372,9 +430,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   const DT* __restrict__ Wt = static_cast<const DT*>(p.efeat) + ro_off;
   int64_t lhs_len = p.lhs_len;
   const int64_t rhs_len = p.rhs_len;
+  // edge layout (wave-uniform switch): per-lane constants of the address select in load_batch
+  constexpr int E16 = 16 / static_cast<int>(sizeof(DT));  // elements per 16-byte piece
+  bool edge_layout = false;
+  [[maybe_unused]] unsigned ej = 0u;       // this lane's piece index in the row (huge: never in place)
+  [[maybe_unused]] int e_piece_lo = 0, e_piece_hi = 0;  // side-array element offset when the piece is in the head / tail
+  [[maybe_unused]] int e_pitch = 0;        // side-array pitch of this lane in elements
+  [[maybe_unused]] const DT* e_side = nullptr;
   if (p.split_main > 0 && split_wanted(p.split_meta)) {
-    // split-row layout: this lane's piece lives in the main or the tail array
-    if (lo_off < p.split_main) {
+    if (p.split_edge_lines > 0) {
+      if constexpr (UL && !MULTI && VEC * sizeof(DT) == 16) {
+        edge_layout = true;
+        const int j = lo_off / E16, rp = p.lhs_len / E16;
+        if (j >= rp - p.split_t16) {  // the dense tail array: a fixed place for this lane
+          ej = 0x40000000u;
+          e_side = static_cast<const DT*>(p.utail);
+          e_pitch = p.split_t16 * E16;
+          e_piece_lo = e_piece_hi = (j - (rp - p.split_t16)) * E16;
+        } else {
+          ej = static_cast<unsigned>(j);
+          e_side = static_cast<const DT*>(p.umain);
+          e_pitch = 8 * E16;
+          e_piece_lo = j * E16;
+          e_piece_hi = (j - 8 * p.split_edge_lines) * E16;
+        }
+      }
+    } else if (lo_off < p.split_main) {
+      // classic split-row layout: this lane's piece lives in the main or the tail array
       X = static_cast<const DT*>(p.umain) + lo_off;
       lhs_len = p.split_main;
     } else {
@@ -382,6 +464,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
       lhs_len = p.split_tail;
     }
   }
+  [[maybe_unused]] const unsigned e_in_place = 8u * static_cast<unsigned>(p.split_edge_lines);
+  [[maybe_unused]] const unsigned e_t16 = static_cast<unsigned>(p.split_t16);
+  [[maybe_unused]] const unsigned e_base16 = static_cast<unsigned>(p.split_base16);
 
   using XV = VecT<DT, VEC>;
   using WV = VecT<DT, RV>;
@@ -398,7 +483,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
         const int64_t c = cols[ee];
         const DT* xb = X;
         if constexpr (MULTI) xb = s_xb[wib][ee] + lo_off;
-        b.x[u] = *reinterpret_cast<const XV*>(xb + c * lhs_len);
+        bool done = false;
+        if constexpr (!MULTI && VEC * sizeof(DT) == 16) {
+          if (edge_layout) {  // (wave-uniform)
+            // row c starts o16 pieces into a line: pieces [8 - o16, 8 - o16 + 8 (k - 1)) are whole
+            // aligned lines of X itself, the ragged ends live in the side line of the row
+            const unsigned o16 = (e_t16 * static_cast<unsigned>(c) + e_base16) & 7u;
+            const unsigned head = 8u - o16;
+            const bool in_place = (ej - head) < e_in_place;
+            const int side_off = ej < head ? e_piece_lo : e_piece_hi;
+            const DT* base = in_place ? X : e_side;
+            const int64_t pitch = in_place ? lhs_len : static_cast<int64_t>(e_pitch);
+            const int add = in_place ? 0 : side_off;
+            b.x[u] = *reinterpret_cast<const XV*>(base + (c * pitch + add));
+            done = true;
+          }
+        }
+        if (!done) b.x[u] = *reinterpret_cast<const XV*>(xb + c * lhs_len);
       }
       if constexpr (UR) {
         const int64_t eid = static_cast<int64_t>(eidl[ee]);
@@ -643,6 +744,7 @@ struct SpmmGeometry {
   // split-row layout (0 = not used): bytes of a row kept in the main / tail array
   int split_main_bytes, split_tail_bytes;
   size_t off_split_main, off_split_tail;
+  int split_edge_lines;  // > 0: edge layout (main = one 128-byte side line per row, k - 1 lines stay in place)
 };
 
 // Half-width, in rows, of the window the locality probe counts as "local": 2 x 64 Ki rows of
@@ -666,7 +768,8 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len, int vec,
                                   size_t acc_bytes, int idbytes, bool with_arg,
-                                  int64_t split_rows = 0, int64_t split_row_bytes = 0) {
+                                  int64_t split_rows = 0, int64_t split_row_bytes = 0,
+                                  bool edge_layout = false) {
   SpmmGeometry g;
   g.vec = vec;
   int64_t lanes = (out_len + vec - 1) / vec;
@@ -700,9 +803,14 @@ inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len
   }
   g.split_main_bytes = g.split_tail_bytes = 0;
   g.off_split_main = g.off_split_tail = off;
+  g.split_edge_lines = 0;
   if (split_rows > 0) {
     g.split_main_bytes = static_cast<int>(split_row_bytes / 128 * 128);
     g.split_tail_bytes = static_cast<int>(split_row_bytes - g.split_main_bytes);
+    if (edge_layout && split_row_bytes >= 256) {  // rows of two or more whole lines: copy the ragged ends only
+      g.split_edge_lines = g.split_main_bytes / 128 - 1;
+      g.split_main_bytes = 128;                   // the side line of a row
+    }
     g.off_split_main = off;
     off = align_up(off + static_cast<size_t>(split_rows) * g.split_main_bytes, 256);
     g.off_split_tail = off;
@@ -770,6 +878,7 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.umain = p.utail = nullptr;
   p.split_meta = nullptr;
   p.split_main = p.split_tail = 0;
+  p.split_edge_lines = p.split_t16 = p.split_base16 = 0;
   if (g.split_main_bytes > 0) {
     p.umain = ws + g.off_split_main;
     p.utail = ws + g.off_split_tail;
@@ -777,6 +886,9 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
       p.split_meta = reinterpret_cast<const unsigned*>(ws + g.off_meta);
     p.split_main = g.split_main_bytes / static_cast<int>(sizeof(DT));
     p.split_tail = g.split_tail_bytes / static_cast<int>(sizeof(DT));
+    p.split_edge_lines = g.split_edge_lines;
+    p.split_t16 = g.split_tail_bytes / 16;
+    p.split_base16 = static_cast<int>((reinterpret_cast<uintptr_t>(L.ufeat) & 127u) >> 4);
   }
   p.rel = static_cast<const uint8_t*>(L.rel);
   p.xtab = L.ufeat_tab;
@@ -799,7 +911,23 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
   const SpmmParams<Idx> p = make_params<Idx, DT>(L, g);
   const unsigned blocks =
       static_cast<unsigned>((g.num_waves + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (g.split_main_bytes > 0 && !L.split_valid) {
+  if (g.split_edge_lines > 0 && !L.split_valid) {
+    char* ws = static_cast<char*>(L.workspace);
+    const int t16 = g.split_tail_bytes / 16, side = 8 + t16;
+    const int row_pieces = static_cast<int>(L.lhs_len * static_cast<int64_t>(sizeof(DT)) / 16);
+    const int64_t total = L.csr.num_cols * side;
+    constexpr int K = 4;
+    const unsigned sblocks =
+        static_cast<unsigned>(std::min<int64_t>((total + 256 * K - 1) / (256 * K), int64_t(1) << 20));
+    const unsigned magic = 0xFFFFFFFFu / static_cast<unsigned>(side) + 1u;
+    hipLaunchKernelGGL(spmm_split_edges_kernel<K>, dim3(sblocks), dim3(256), 0, L.stream,
+                       static_cast<const piece16_t*>(L.ufeat),
+                       reinterpret_cast<piece16_t*>(ws + g.off_split_main),
+                       reinterpret_cast<piece16_t*>(ws + g.off_split_tail), L.csr.num_cols, row_pieces,
+                       t16, 8 * g.split_edge_lines, magic, p.split_meta,
+                       static_cast<unsigned>(p.split_base16));
+    DGLA_CHECK_HIP(hipGetLastError());
+  } else if (g.split_main_bytes > 0 && !L.split_valid) {
     char* ws = static_cast<char*>(L.workspace);
     const int pieces = (g.split_main_bytes + g.split_tail_bytes) / 16;
     const int64_t total = L.csr.num_cols * pieces;
@@ -951,7 +1079,8 @@ inline int launch_spmm_csr_typed(const SpmmLaunch& L) {
     // has room (dgla_spmm_csr_workspace_bytes accounts for it), else the plain layout runs
     const SpmmGeometry gs = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
                                           L.csr.idbits / 8, L.red != kSum, L.csr.num_cols,
-                                          L.lhs_len * static_cast<int64_t>(sizeof(DT)));
+                                          L.lhs_len * static_cast<int64_t>(sizeof(DT)),
+                                          !(L.tune & kTuneSplitClassic));
     if (L.workspace && L.workspace_bytes >= gs.total) g = gs;
   }
   if (L.workspace_bytes < g.total || (g.total && !L.workspace)) {
@@ -978,7 +1107,8 @@ inline size_t spmm_csr_workspace_typed(const SpmmLaunch& L) {
   for (int vec : {1, full / 2 > 1 ? full / 2 : 1, full}) {
     const size_t t = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
                                    L.csr.idbits / 8, L.red != kSum, split ? L.csr.num_cols : 0,
-                                   L.lhs_len * static_cast<int64_t>(sizeof(DT)))
+                                   L.lhs_len * static_cast<int64_t>(sizeof(DT)),
+                                   !(L.tune & kTuneSplitClassic))
                          .total;
     if (t > best) best = t;
   }

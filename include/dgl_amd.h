@@ -398,6 +398,10 @@ int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const voi
  *                     three round-to-nearest bf16 terms and the six products of order <= 2 run on
  *                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation — fp32-level accuracy (dropped
  *                     terms < 2^-26 |a b|) at 2.7x less matrix-pipe time; gfx950 has no xf32 MFMA
+ *   DGLA_TUNE_SPLIT_CLASSIC  split-row layout as in round 2: every row is copied (line-aligned main
+ *                     array + dense tail array).  Default (bit off) for rows of two or more whole
+ *                     lines: only the two ragged ENDS of every row are copied (one 128-byte line
+ *                     per row + the dense tail); the line-aligned interior is gathered in place
  * The reference has no counterpart (its kernels take no hints). */
 #define DGLA_TUNE_XCD 1u
 #define DGLA_TUNE_NT_OUT 2u
@@ -407,6 +411,7 @@ int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const voi
 #define DGLA_TUNE_SPLIT_NT 32u
 #define DGLA_TUNE_SPLIT_FORCE 64u
 #define DGLA_TUNE_MM_F32 128u
+#define DGLA_TUNE_SPLIT_CLASSIC 256u
 int dgla_set_tuning(uint32_t flags);
 uint32_t dgla_get_tuning(void);
 

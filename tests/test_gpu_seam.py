@@ -597,7 +597,10 @@ def test_edge_softmax_geometries(dev, n_dst, n_edges, dim, idtype, dtype, merge)
 # --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("feat,tdtype", [(100, torch.float32), (36, torch.float32),
                                          (100, torch.bfloat16), (200, torch.float16),
-                                         (50, torch.float64)])
+                                         (50, torch.float64),
+                                         # edge layout of the split rows: 128 k + t bytes, k >= 2
+                                         (68, torch.float32), (76, torch.float32), (132, torch.float32),
+                                         (252, torch.float32), (136, torch.bfloat16), (38, torch.float64)])
 @pytest.mark.parametrize("op,reduce", [("copy_lhs", "sum"), ("mul", "sum"), ("copy_lhs", "max")])
 def test_spmm_tuning_bits_do_not_change_results(dev, feat, tdtype, op, reduce):
     from dgl_amd import _capi
@@ -613,7 +616,7 @@ def test_spmm_tuning_bits_do_not_change_results(dev, feat, tdtype, op, reduce):
     results = {}
     default = _capi.get_tuning()
     try:
-        for flags in (0, 1, 2, 4, 8, 15, 31):
+        for flags in (0, 1, 2, 4, 8, 15, 31, 8 | 64, 8 | 256, 8 | 64 | 256):
             _capi.set_tuning(flags)
             assert _capi.get_tuning() == flags
             out = torch.full((n_dst, feat), -3.0, dtype=tdtype, device=dev)
@@ -634,8 +637,13 @@ def test_spmm_tuning_bits_do_not_change_results(dev, feat, tdtype, op, reduce):
         if a is not None:
             assert torch.equal(a, base[1]), "flags=%d" % flags
     row_bytes = feat * x.element_size()
-    if row_bytes % 128 and row_bytes >= 128 and row_bytes % 16 == 0 and row_bytes * n_src >= 64 << 20:
-        assert results[8][2] >= results[0][2] + n_src * row_bytes  # the re-laid-out copy of X
+    if row_bytes % 128 and row_bytes >= 128 and row_bytes % 16 == 0 and row_bytes * n_src >= 64 << 20 \
+            and row_bytes <= 1024:
+        # classic layout: the re-laid-out copy of all of X; edge layout (rows of two or more whole lines):
+        # one side line + the dense tail per row
+        assert results[8 | 256][2] >= results[0][2] + n_src * row_bytes
+        side = 128 + row_bytes % 128 if row_bytes >= 256 else row_bytes
+        assert results[0][2] + n_src * side <= results[8][2] < results[0][2] + n_src * side + (1 << 20)
     # and the shared result is the right one
     host = [t.cpu().numpy() for t in (g["indptr"], g["indices"], g["eids"])]
     if tdtype in (torch.float32, torch.float64):
