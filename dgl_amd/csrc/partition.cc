@@ -3,32 +3,42 @@
 // Takes the place of METIS in the reference's `metis_partition_assignment`
 // (python/dgl/partition.py:278-397 -> _CAPI_DGLMetisPartition_Hetero; METIS itself is an
 // un-vendored submodule, third_party/METIS is empty in the checkout).  Written from the
-// published multilevel scheme, in the label-propagation flavour that suits power-law graphs
-// (Meyerhenke, Sanders, Schulz: "Partitioning complex networks via size-constrained
-// clustering", SEA 2014), not from METIS code:
+// published multilevel scheme, not from METIS code:
 //
 //   1. symmetrise the input (the reference does the same, partition.py:319-327);
-//   2. COARSEN: size-constrained label propagation clusters the graph (a cluster may not
-//      outgrow max_part_weight / kClusterFactor), clusters are contracted into weighted
-//      vertices / edges; repeat until the graph is small or stops shrinking;
-//   3. INITIAL PARTITION of the coarsest graph: greedy graph growing from k seeds picked far
-//      apart, vertices handed to the lightest part they touch;
+//   2. COARSEN with size-constrained label propagation — the clustering that suits power-law
+//      graphs, where matchings stall on hubs (Meyerhenke, Sanders, Schulz: "Partitioning complex
+//      networks via size-constrained clustering", SEA 2014): a cluster may not outgrow
+//      max_part_weight / kClusterFactor; clusters are contracted into weighted vertices / edges;
+//      repeat until the graph is small or stops shrinking;
+//   3. INITIAL PARTITION of the coarsest graph by RECURSIVE BISECTION (round 3): every bisection
+//      grows one side from a pseudo-peripheral vertex (double BFS sweep), always taking the frontier
+//      vertex most strongly connected to the grown side (greedy graph growing, Karypis & Kumar,
+//      SIAM J. Sci. Comput. 20(1), 1998), refines the cut with Fiduccia-Mattheyses passes (best
+//      prefix of a sequence of single moves, negative gains allowed) and keeps the best of several
+//      starts.  Round 2 grew k regions at once from the k heaviest vertices, which interleaved the
+//      parts of graphs with one-dimensional structure (band graphs, variant L);
 //   4. UNCOARSEN: project, then refine each level with size-constrained label propagation
 //      (a vertex moves to the neighbouring part it is connected to most strongly if that
 //      part has room), plus a rebalancing pass when a part is over the limit.
 //
 // Vertex weight = 1 (+ in-degree when balance_edges, the reference's flag of the same name):
-// the SpMM work of a row partition is its in-edge count.  Deterministic: fixed visiting
-// orders and a seeded xorshift, single-threaded host code (this is offline preprocessing,
-// exactly as METIS is in the reference).
+// the SpMM work of a row partition is its in-edge count.
+// Threads (round 3): the neighbourhood scans of label propagation, the contraction and the
+// symmetrisation run on std::thread workers over fixed vertex chunks; label propagation is
+// chunk-synchronous — proposals of a chunk are computed in parallel from the state at the chunk's
+// start and applied in order — so the answer does not depend on the number of threads.
+// Deterministic: fixed visiting orders and a seeded xorshift.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dgl_amd.h"
@@ -63,6 +73,38 @@ struct Rng {
   uint64_t below(uint64_t n) { return next() % n; }
 };
 
+int num_threads() {
+  static int n = [] {
+    int t = 0;
+    if (const char* v = std::getenv("DGLA_PARTITION_THREADS")) t = std::atoi(v);
+    if (t <= 0) t = static_cast<int>(std::thread::hardware_concurrency());
+    if (t <= 0) t = 1;
+    return std::min(t, 64);
+  }();
+  return n;
+}
+
+// fn(begin, end, thread) over a static split of [0, n) into contiguous ranges
+template <typename F>
+void parallel_for(int64_t n, int64_t min_per_thread, F fn) {
+  int t = num_threads();
+  if (n < 2 * min_per_thread) t = 1;
+  t = static_cast<int>(std::min<int64_t>(t, std::max<int64_t>(1, n / std::max<int64_t>(min_per_thread, 1))));
+  if (t <= 1) {
+    fn(int64_t(0), n, 0);
+    return;
+  }
+  std::vector<std::thread> th;
+  th.reserve(t - 1);
+  const int64_t per = (n + t - 1) / t;
+  for (int i = 1; i < t; ++i) {
+    const int64_t b = std::min<int64_t>(n, i * per), e = std::min<int64_t>(n, b + per);
+    th.emplace_back([=, &fn] { fn(b, e, i); });
+  }
+  fn(int64_t(0), std::min<int64_t>(n, per), 0);
+  for (auto& x : th) x.join();
+}
+
 template <typename Idx>
 Graph symmetrise(int64_t n, const Idx* indptr, const Idx* indices, bool balance_edges) {
   // undirected multigraph of the CSR (rows = destinations): u -- v for every stored edge,
@@ -87,20 +129,32 @@ Graph symmetrise(int64_t n, const Idx* indptr, const Idx* indices, bool balance_
       tmp[fill[r]++] = static_cast<vid>(c);
       tmp[fill[c]++] = static_cast<vid>(r);
     }
+  // per vertex: sort the neighbour list, merge parallel edges into weights (two passes, threads)
   g.xadj.assign(n + 1, 0);
-  g.adj.reserve(tmp.size());
-  g.ewgt.reserve(tmp.size());
-  for (int64_t v = 0; v < n; ++v) {
-    std::sort(tmp.begin() + deg[v], tmp.begin() + deg[v + 1]);
-    for (int64_t j = deg[v]; j < deg[v + 1];) {
-      int64_t e = j;
-      while (e < deg[v + 1] && tmp[e] == tmp[j]) ++e;
-      g.adj.push_back(tmp[j]);
-      g.ewgt.push_back(e - j);
-      j = e;
+  parallel_for(n, 4096, [&](int64_t b, int64_t e, int) {
+    for (int64_t v = b; v < e; ++v) {
+      std::sort(tmp.begin() + deg[v], tmp.begin() + deg[v + 1]);
+      int64_t u = 0;
+      for (int64_t j = deg[v]; j < deg[v + 1]; ++j) u += (j == deg[v] || tmp[j] != tmp[j - 1]);
+      g.xadj[v + 1] = u;
     }
-    g.xadj[v + 1] = static_cast<int64_t>(g.adj.size());
-  }
+  });
+  std::partial_sum(g.xadj.begin(), g.xadj.end(), g.xadj.begin());
+  g.adj.resize(g.xadj[n]);
+  g.ewgt.resize(g.xadj[n]);
+  parallel_for(n, 4096, [&](int64_t b, int64_t e, int) {
+    for (int64_t v = b; v < e; ++v) {
+      int64_t o = g.xadj[v];
+      for (int64_t j = deg[v]; j < deg[v + 1];) {
+        int64_t k2 = j;
+        while (k2 < deg[v + 1] && tmp[k2] == tmp[j]) ++k2;
+        g.adj[o] = tmp[j];
+        g.ewgt[o] = k2 - j;
+        ++o;
+        j = k2;
+      }
+    }
+  });
   g.vwgt.assign(n, 1);
   if (balance_edges)
     for (int64_t r = 0; r < n; ++r) g.vwgt[r] += static_cast<wgt>(indptr[r + 1] - indptr[r]);
@@ -117,42 +171,58 @@ int64_t label_propagation(const Graph& g, std::vector<vid>& label, std::vector<w
   const vid n = g.n;
   std::vector<vid> order(n);
   std::iota(order.begin(), order.end(), 0);
-  std::vector<wgt> conn(load.size(), 0);
-  std::vector<vid> touched;
+  const int T = num_threads();
+  std::vector<std::vector<wgt>> conn_t(T);
+  std::vector<std::vector<vid>> touched_t(T);
+  std::vector<vid> prop(n);
+  // chunk-synchronous: proposals of one chunk come from the labels / loads at the chunk's start
+  // (threads), then are applied in visiting order with the load limit checked against the
+  // CURRENT loads (sequential).  Small chunks keep it close to the sequential algorithm.
+  const int64_t chunk = std::max<int64_t>(1024, std::min<int64_t>(65536, n / 64 + 1));
   int64_t moved = 0;
   for (int it = 0; it < sweeps; ++it) {
     if (random_order)
       for (vid i = n - 1; i > 0; --i) std::swap(order[i], order[rng.below(i + 1)]);
     moved = 0;
-    for (vid oi = 0; oi < n; ++oi) {
-      const vid v = order[oi];
-      const vid cur = label[v];
-      touched.clear();
-      for (int64_t j = g.xadj[v]; j < g.xadj[v + 1]; ++j) {
-        const vid l = label[g.adj[j]];
-        if (conn[l] == 0) touched.push_back(l);
-        conn[l] += g.ewgt[j];
-      }
-      vid best = cur;
-      wgt best_conn = conn[cur];
-      for (vid l : touched) {
-        if (l == cur) continue;
-        if (load[l] + g.vwgt[v] > max_load) continue;
-        if (conn[l] > best_conn || (conn[l] == best_conn && best != cur && load[l] < load[best])) {
-          best = l;
-          best_conn = conn[l];
+    for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+      const int64_t c1 = std::min<int64_t>(n, c0 + chunk);
+      parallel_for(c1 - c0, 512, [&](int64_t b, int64_t e, int tid) {
+        std::vector<wgt>& conn = conn_t[tid];
+        std::vector<vid>& touched = touched_t[tid];
+        if (conn.size() != load.size()) conn.assign(load.size(), 0);
+        for (int64_t oi = c0 + b; oi < c0 + e; ++oi) {
+          const vid v = order[oi];
+          const vid cur = label[v];
+          touched.clear();
+          for (int64_t j = g.xadj[v]; j < g.xadj[v + 1]; ++j) {
+            const vid l = label[g.adj[j]];
+            if (conn[l] == 0) touched.push_back(l);
+            conn[l] += g.ewgt[j];
+          }
+          vid best = cur;
+          wgt best_conn = conn[cur];
+          for (vid l : touched) {
+            if (l == cur) continue;
+            if (load[l] + g.vwgt[v] > max_load) continue;
+            if (conn[l] > best_conn || (conn[l] == best_conn && best != cur && (load[l] < load[best] || (load[l] == load[best] && l < best)))) {
+              best = l;
+              best_conn = conn[l];
+            }
+          }
+          for (vid l : touched) conn[l] = 0;
+          prop[oi] = best;
         }
-      }
-      for (vid l : touched) conn[l] = 0;
-      if (best != cur) {
+      });
+      for (int64_t oi = c0; oi < c1; ++oi) {
+        const vid v = order[oi], best = prop[oi], cur = label[v];
+        if (best == cur || load[best] + g.vwgt[v] > max_load) continue;
         load[cur] -= g.vwgt[v];
         load[best] += g.vwgt[v];
         label[v] = best;
         ++moved;
       }
     }
-    if (moved == 0 || moved < min_moves) break;  // converged (min_moves > 0: or nearly; unused — stopping
-                                                 // refinement at 0.5 % moves tripled the cut on planted communities)
+    if (moved == 0 || moved < min_moves) break;
   }
   return moved;
 }
@@ -182,115 +252,238 @@ Graph contract(const Graph& g, std::vector<vid>& label, vid* num_coarse) {
     for (vid v = 0; v < n; ++v) members[pos[label[v]]++] = v;
   }
   c.xadj.assign(nc + 1, 0);
-  std::vector<wgt> acc(nc, 0);
-  std::vector<vid> touched;
-  for (vid cv = 0; cv < nc; ++cv) {
-    touched.clear();
-    for (int64_t m = start[cv]; m < start[cv + 1]; ++m) {
-      const vid v = members[m];
-      for (int64_t j = g.xadj[v]; j < g.xadj[v + 1]; ++j) {
-        const vid cu = label[g.adj[j]];
-        if (cu == cv) continue;
-        if (acc[cu] == 0) touched.push_back(cu);
-        acc[cu] += g.ewgt[j];
+  const int T = num_threads();
+  std::vector<std::vector<vid>> adj_t(T);
+  std::vector<std::vector<wgt>> w_t(T);
+  std::vector<int64_t> first_cv(T + 1, nc);
+  parallel_for(nc, 256, [&](int64_t b, int64_t e, int tid) {
+    first_cv[tid] = b;
+    std::vector<wgt> acc(nc, 0);
+    std::vector<vid> touched;
+    std::vector<vid>& la = adj_t[tid];
+    std::vector<wgt>& lw = w_t[tid];
+    for (int64_t cv = b; cv < e; ++cv) {
+      touched.clear();
+      for (int64_t m = start[cv]; m < start[cv + 1]; ++m) {
+        const vid v = members[m];
+        for (int64_t j = g.xadj[v]; j < g.xadj[v + 1]; ++j) {
+          const vid cu = label[g.adj[j]];
+          if (cu == cv) continue;
+          if (acc[cu] == 0) touched.push_back(cu);
+          acc[cu] += g.ewgt[j];
+        }
       }
+      std::sort(touched.begin(), touched.end());
+      for (vid cu : touched) {
+        la.push_back(cu);
+        lw.push_back(acc[cu]);
+        acc[cu] = 0;
+      }
+      c.xadj[cv + 1] = static_cast<int64_t>(touched.size());
     }
-    std::sort(touched.begin(), touched.end());
-    for (vid cu : touched) {
-      c.adj.push_back(cu);
-      c.ewgt.push_back(acc[cu]);
-      acc[cu] = 0;
-    }
-    c.xadj[cv + 1] = static_cast<int64_t>(c.adj.size());
+  });
+  std::partial_sum(c.xadj.begin(), c.xadj.end(), c.xadj.begin());
+  c.adj.resize(c.xadj[nc]);
+  c.ewgt.resize(c.xadj[nc]);
+  for (int t = 0; t < T; ++t) {  // thread t produced the lists of coarse vertices [first_cv[t], ...) in order
+    if (adj_t[t].empty()) continue;
+    std::copy(adj_t[t].begin(), adj_t[t].end(), c.adj.begin() + c.xadj[first_cv[t]]);
+    std::copy(w_t[t].begin(), w_t[t].end(), c.ewgt.begin() + c.xadj[first_cv[t]]);
   }
   return c;
 }
 
-// Greedy graph growing on the (small) coarsest graph.
-void initial_partition(const Graph& g, int k, wgt max_load, std::vector<vid>& part,
-                       std::vector<wgt>& load, Rng& rng) {
-  const vid n = g.n;
-  part.assign(n, -1);
-  load.assign(k, 0);
-  // seeds: the heaviest unassigned vertex that is not adjacent to an earlier seed
-  std::vector<vid> by_weight(n);
-  std::iota(by_weight.begin(), by_weight.end(), 0);
-  std::stable_sort(by_weight.begin(), by_weight.end(),
-                   [&](vid a, vid b) { return g.vwgt[a] > g.vwgt[b]; });
-  std::vector<char> near_seed(n, 0);
-  std::vector<std::vector<vid>> frontier(k);
-  int p = 0;
-  for (vid v : by_weight) {
-    if (p == k) break;
-    if (near_seed[v]) continue;
-    part[v] = p;
-    load[p] += g.vwgt[v];
-    frontier[p].push_back(v);
-    near_seed[v] = 1;
-    for (int64_t j = g.xadj[v]; j < g.xadj[v + 1]; ++j) near_seed[g.adj[j]] = 1;
-    ++p;
-  }
-  for (vid v : by_weight) {  // fewer than k independent seeds: take anything unassigned
-    if (p == k) break;
-    if (part[v] >= 0) continue;
-    part[v] = p;
-    load[p] += g.vwgt[v];
-    frontier[p].push_back(v);
-    ++p;
-  }
-  // grow: always extend the lightest part that still has a frontier
-  std::vector<size_t> head(k, 0);
-  vid assigned = 0;
-  for (vid v = 0; v < n; ++v) assigned += part[v] >= 0;
-  while (assigned < n) {
-    int best = -1;
-    for (int q = 0; q < k; ++q)
-      if (head[q] < frontier[q].size() && (best < 0 || load[q] < load[best])) best = q;
-    if (best < 0) {  // disconnected remainder: give the next free vertex to the lightest part
-      int light = 0;
-      for (int q = 1; q < k; ++q)
-        if (load[q] < load[light]) light = q;
-      for (vid v : by_weight)
-        if (part[v] < 0) {
-          part[v] = light;
-          load[light] += g.vwgt[v];
-          frontier[light].push_back(v);
-          ++assigned;
-          break;
-        }
-      continue;
-    }
-    const vid v = frontier[best][head[best]++];
-    for (int64_t j = g.xadj[v]; j < g.xadj[v + 1]; ++j) {
-      const vid u = g.adj[j];
-      if (part[u] >= 0) continue;
-      if (load[best] + g.vwgt[u] > max_load) continue;
-      part[u] = best;
-      load[best] += g.vwgt[u];
-      frontier[best].push_back(u);
-      ++assigned;
-    }
-    if (head[best] == frontier[best].size()) {
-      // exhausted without room for its neighbours: they will be picked up by other parts or
-      // by the disconnected-remainder rule above
-      bool any = false;
-      for (int q = 0; q < k; ++q) any = any || head[q] < frontier[q].size();
-      if (!any) {
-        int light = 0;
-        for (int q = 1; q < k; ++q)
-          if (load[q] < load[light]) light = q;
-        for (vid u : by_weight)
-          if (part[u] < 0) {
-            part[u] = light;
-            load[light] += g.vwgt[u];
-            frontier[light].push_back(u);
-            ++assigned;
-            break;
-          }
+// ---- initial partition of the (small) coarsest graph: recursive bisection -------------------------
+// One bisection of the block `blk` (vertices with part[v] == cur) into cur / other: grow `other`
+// from a pseudo-peripheral vertex until it holds `target` weight, refine with FM, best of `tries`.
+struct Bisector {
+  const Graph& g;
+  std::vector<vid>& part;
+  Rng& rng;
+  std::vector<int> dist;       // BFS scratch
+  std::vector<char> side;      // 1 = other side (current try)
+  std::vector<char> best_side;
+  std::vector<wgt> gain;       // FM: gain of moving v to the opposite side
+  std::vector<char> locked;
+
+  Bisector(const Graph& g_, std::vector<vid>& part_, Rng& rng_)
+      : g(g_), part(part_), rng(rng_), dist(g_.n), side(g_.n), best_side(g_.n), gain(g_.n), locked(g_.n) {}
+
+  vid farthest_from(vid s, vid cur, const std::vector<vid>& blk) {
+    for (vid v : blk) dist[v] = -1;
+    std::vector<vid> q{s};
+    dist[s] = 0;
+    vid last = s;
+    for (size_t h = 0; h < q.size(); ++h) {
+      const vid v = q[h];
+      last = v;
+      for (int64_t j = g.xadj[v]; j < g.xadj[v + 1]; ++j) {
+        const vid u = g.adj[j];
+        if (part[u] != cur || dist[u] >= 0) continue;
+        dist[u] = dist[v] + 1;
+        q.push_back(u);
       }
     }
+    return last;
   }
-  (void)rng;
+
+  wgt cut_of(vid cur, const std::vector<vid>& blk) const {
+    wgt c = 0;
+    for (vid v : blk)
+      if (side[v])
+        for (int64_t j = g.xadj[v]; j < g.xadj[v + 1]; ++j)
+          if (part[g.adj[j]] == cur && !side[g.adj[j]]) c += g.ewgt[j];
+    return c;
+  }
+
+  // greedy graph growing: the frontier vertex with the largest (connection to the grown side -
+  // connection to the rest) joins next; disconnected remainders restart from any unvisited vertex
+  void grow(vid seed, vid cur, const std::vector<vid>& blk, wgt target) {
+    for (vid v : blk) side[v] = 0, gain[v] = 0, locked[v] = 0;
+    wgt w = 0;
+    std::vector<vid> frontier;
+    auto add = [&](vid v) {
+      side[v] = 1;
+      w += g.vwgt[v];
+      for (int64_t j = g.xadj[v]; j < g.xadj[v + 1]; ++j) {
+        const vid u = g.adj[j];
+        if (part[u] != cur || side[u]) continue;
+        if (!locked[u]) {
+          locked[u] = 1;  // "is in the frontier list"
+          frontier.push_back(u);
+        }
+        gain[u] += 2 * g.ewgt[j];
+      }
+    };
+    for (vid v : blk)  // gain[u] starts as -(all connections inside the block)
+      for (int64_t j = g.xadj[v]; j < g.xadj[v + 1]; ++j)
+        if (part[g.adj[j]] == cur) gain[v] -= g.ewgt[j];
+    add(seed);
+    size_t scan = 0;
+    while (w < target) {
+      vid pick = -1;
+      size_t at = 0;
+      for (size_t i = 0; i < frontier.size(); ++i) {
+        const vid u = frontier[i];
+        if (side[u]) continue;
+        if (pick < 0 || gain[u] > gain[pick] || (gain[u] == gain[pick] && u < pick)) pick = u, at = i;
+      }
+      if (pick < 0) {  // disconnected remainder
+        while (scan < blk.size() && side[blk[scan]]) ++scan;
+        if (scan == blk.size()) break;
+        pick = blk[scan];
+      } else {
+        frontier[at] = frontier.back();
+        frontier.pop_back();
+      }
+      if (w + g.vwgt[pick] > target && w + g.vwgt[pick] - target > target - w && w > 0) break;  // closer without it
+      add(pick);
+    }
+  }
+
+  // Fiduccia-Mattheyses: passes of single moves (highest gain first, balance kept within `tol` of
+  // `target`), every vertex moved at most once per pass, the best prefix of the pass is kept
+  void fm(vid cur, const std::vector<vid>& blk, wgt target, wgt tol) {
+    wgt w = 0;
+    for (vid v : blk) w += side[v] ? g.vwgt[v] : 0;
+    for (int pass = 0; pass < 8; ++pass) {
+      for (vid v : blk) {
+        locked[v] = 0;
+        wgt in = 0, out = 0;
+        for (int64_t j = g.xadj[v]; j < g.xadj[v + 1]; ++j) {
+          const vid u = g.adj[j];
+          if (part[u] != cur) continue;
+          (side[u] == side[v] ? in : out) += g.ewgt[j];
+        }
+        gain[v] = out - in;
+      }
+      std::vector<vid> moves;
+      wgt run = 0, best_run = 0;
+      size_t best_len = 0;
+      wgt ww = w;
+      const size_t limit = std::min<size_t>(blk.size(), 4096);
+      for (size_t step = 0; step < limit; ++step) {
+        vid pick = -1;
+        for (vid v : blk) {
+          if (locked[v]) continue;
+          const wgt nw = side[v] ? ww - g.vwgt[v] : ww + g.vwgt[v];
+          const wgt dev_now = ww > target ? ww - target : target - ww;
+          const wgt dev_new = nw > target ? nw - target : target - nw;
+          if (dev_new > tol && dev_new >= dev_now) continue;  // may not leave (or worsen) the balance window
+          if (pick < 0 || gain[v] > gain[pick] || (gain[v] == gain[pick] && v < pick)) pick = v;
+        }
+        if (pick < 0) break;
+        locked[pick] = 1;
+        run += gain[pick];
+        ww += side[pick] ? -g.vwgt[pick] : g.vwgt[pick];
+        side[pick] ^= 1;
+        for (int64_t j = g.xadj[pick]; j < g.xadj[pick + 1]; ++j) {
+          const vid u = g.adj[j];
+          if (part[u] != cur) continue;
+          gain[u] += (side[u] == side[pick]) ? -2 * g.ewgt[j] : 2 * g.ewgt[j];
+        }
+        moves.push_back(pick);
+        if (run > best_run) best_run = run, best_len = moves.size();
+        if (moves.size() > best_len + 64) break;  // no improvement for a while
+      }
+      for (size_t i = moves.size(); i > best_len; --i) side[moves[i - 1]] ^= 1;  // roll back past the best prefix
+      w = 0;
+      for (vid v : blk) w += side[v] ? g.vwgt[v] : 0;
+      if (best_run <= 0) break;
+    }
+  }
+
+  void bisect(vid cur, vid other, const std::vector<vid>& blk, wgt target, wgt tol, int tries) {
+    if (blk.size() < 2) return;
+    wgt best_cut = -1;
+    for (int t = 0; t < tries; ++t) {
+      vid s = blk[rng.below(blk.size())];
+      s = farthest_from(s, cur, blk);
+      if (t & 1) s = farthest_from(s, cur, blk);  // the other end of the pseudo-diameter
+      grow(s, cur, blk, target);
+      fm(cur, blk, target, tol);
+      const wgt c = cut_of(cur, blk);
+      wgt w = 0;
+      for (vid v : blk) w += side[v] ? g.vwgt[v] : 0;
+      const wgt dev = w > target ? w - target : target - w;
+      // feasible tries beat infeasible ones; among equals the smaller cut wins
+      const wgt score = c + (dev > tol ? (dev - tol) * 1024 : 0);
+      if (best_cut < 0 || score < best_cut) {
+        best_cut = score;
+        for (vid v : blk) best_side[v] = side[v];
+      }
+    }
+    for (vid v : blk)
+      if (best_side[v]) part[v] = other;
+  }
+};
+
+void recursive_bisection(const Graph& g, int k, wgt max_load, double imbalance, std::vector<vid>& part,
+                         std::vector<wgt>& load, Rng& rng) {
+  part.assign(g.n, 0);
+  load.assign(k, 0);
+  Bisector bs(g, part, rng);
+  int depth = 0;
+  while ((1 << depth) < k) ++depth;
+  // block `id` owns part ids [id, id + parts)
+  std::function<void(vid, int)> split = [&](vid id, int parts) {
+    if (parts <= 1) return;
+    std::vector<vid> blk;
+    wgt total = 0;
+    for (vid v = 0; v < g.n; ++v)
+      if (part[v] == id) blk.push_back(v), total += g.vwgt[v];
+    const int right = parts / 2, left = parts - right;
+    const wgt target = static_cast<wgt>(static_cast<double>(total) * right / parts);
+    wgt heaviest = 0;
+    for (vid v : blk) heaviest = std::max(heaviest, g.vwgt[v]);
+    const wgt tol = std::max<wgt>(heaviest / 2 + 1, static_cast<wgt>(imbalance * target / std::max(depth, 1)));
+    bs.bisect(id, id + left, blk, target, tol, 6);
+    split(id, left);
+    split(id + left, right);
+  };
+  split(0, k);
+  for (vid v = 0; v < g.n; ++v) load[part[v]] += g.vwgt[v];
+  (void)max_load;
 }
 
 // Move boundary vertices out of overloaded parts into the neighbouring (else lightest) part
@@ -371,7 +564,8 @@ int partition_impl(int64_t n, const Idx* indptr, const Idx* indices, int k, doub
   // ---- initial partition -------------------------------------------------------------
   std::vector<vid> part;
   std::vector<wgt> load;
-  initial_partition(levels.back(), k, max_load, part, load, rng);
+  recursive_bisection(levels.back(), k, max_load, imbalance, part, load, rng);
+  lap("initial partition (recursive bisection)");
   label_propagation(levels.back(), part, load, max_load, 12, rng, true);
   rebalance(levels.back(), k, max_load, part, load);
 

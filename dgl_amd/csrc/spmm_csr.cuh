@@ -67,7 +67,10 @@ struct SpmmParams {
   const uint8_t* rel;
   const void* const* xtab;
   const void* const* wtab;
-  // fix-up workspace, one slot per lane group: slot = wave * G + group
+  // fix-up workspace, one slot per lane group: slot = wave * G + group — or, with `wave_slots`
+  // (sum reducer, two lane groups per wave), ONE slot per wave: the two groups settle the row that
+  // crosses between them in registers (see the end of spmm_csr_merge_kernel)
+  int wave_slots;
   int64_t* carry_row;  // row id of the slot's carry-out, or -1
   void* carry_val;     // [slots, out_len] accumulator type: head part of a straddling row
   void* tail_val;      // [slots, out_len] accumulator type: tail part of a straddling row
@@ -420,7 +423,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   };
   const int t_s = rows_before(dlo), t_e = rows_before(dhi);
   const int e_s = dlo - t_s, e_e = dhi - t_e;
-  const int64_t slot = w * G + g;
+  // wave-level slots (sum, G == 2): group 1 keeps the tail of the row that crosses in from group 0
+  // in registers; the two parts meet at the end of the kernel
+  const bool wslots = (RED == kSum) && p.wave_slots != 0;
+  const int64_t slot = wslots ? w : w * G + g;
 
   // ---- per-lane operand offsets -------------------------------------------------------
   int lo_off = k0, ro_off = k0;
@@ -538,10 +544,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   // Does local row t_s have edges before this group's range?  Then earlier groups hold
   // carries for it and its total is assembled by the fix-up kernel from `tail_val`.
   bool first_is_tail = rend[t_s] < e_s;
+  [[maybe_unused]] A treg[VEC];       // wslots, group 1: the crossing row's part inside this group
+  [[maybe_unused]] bool have_tail = false;
+  [[maybe_unused]] int tail_t = 0;    // its local row
 
   auto flush = [&](int t) {
     const int64_t row = i0 + t;
-    if (first_is_tail) {
+    if (first_is_tail && RED == kSum && wslots && g == 1) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) treg[v] = acc[v];
+      have_tail = true;
+      tail_t = t;
+      first_is_tail = false;
+    } else if (first_is_tail) {
       A* tv = static_cast<A*>(p.tail_val) + slot * F + k0;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) tv[v] = acc[v];
@@ -648,6 +663,69 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
     ++t;
   }
 
+  if constexpr (RED == kSum) {
+    if (wslots) {
+      // ---- the two groups of the wave meet (lane lg of group 1 <-> lane lg of group 0) -----------
+      // c0 = group 0's carry-out.  Group 1 either closed that row (have_tail: total = c0 + treg, in
+      // position order) or lies wholly inside it (no row end: the wave's carry-out is c0 + its own
+      // part).  A total whose row began in THIS unit is final and is written here; one that began
+      // in an earlier unit is the wave's tail for the fix-up kernel.
+      A c0[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) c0[v] = __shfl_xor(acc[v], 32, 64);
+      const int cnt0 = __shfl_xor(cnt, 32, 64);
+      if (g == 1) {
+        const bool g0_carry = cnt0 > 0;
+        int64_t crow = -1;
+        if (have_tail) {  // (implies g0_carry)
+          A tot[VEC];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) tot[v] = c0[v] + treg[v];
+          const bool began_here = tail_t > 0 || rend[0] >= 0;
+          if (began_here) {
+            DT* o = out + (i0 + tail_t) * F + k0;
+            VecT<DT, VEC> ov;
+            if constexpr (ACCUM) {
+              ov = *reinterpret_cast<VecT<DT, VEC>*>(o);
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(to_acc<DT>(ov.v[v]) + tot[v]);
+            } else if (p.mean) {
+              const int deg = rend[tail_t + 1] - rend[tail_t];
+              const A den = round_to_storage<DT>(static_cast<A>(deg > 1 ? deg : 1));
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(round_to_storage<DT>(tot[v]) / den);
+            } else {
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(tot[v]);
+            }
+            if (p.tune & kTuneNtOut)
+              store_nt(o, ov);
+            else
+              *reinterpret_cast<VecT<DT, VEC>*>(o) = ov;
+          } else {
+            A* tv = static_cast<A*>(p.tail_val) + slot * F + k0;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) tv[v] = tot[v];
+          }
+          if (cnt > 0) {  // group 1's own unfinished last row
+            crow = i0 + t;
+            A* cv = static_cast<A*>(p.carry_val) + slot * F + k0;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) cv[v] = acc[v];
+          }
+        } else if (g0_carry || cnt > 0) {
+          // no crossing row closed in group 1: either group 0 ended on a row end (then this is group
+          // 1's own carry) or the row runs through all of group 1 (then its parts add up, in order)
+          crow = i0 + t;
+          A* cv = static_cast<A*>(p.carry_val) + slot * F + k0;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) cv[v] = g0_carry ? (cnt > 0 ? c0[v] + acc[v] : c0[v]) : acc[v];
+        }
+        if (lg == 0) p.carry_row[slot] = crow;
+      }
+      return;
+    }
+  }
   // ---- carry-out: head part of the row that continues in the next group ---------------
   const bool has_carry = cnt > 0;
   if (lg == 0 && blockIdx.y == 0) p.carry_row[slot] = has_carry ? i0 + t : int64_t(-1);
@@ -738,6 +816,7 @@ struct SpmmGeometry {
   int log2_lpe;  // lanes per feature row
   int groups;    // lane groups per wave
   int chunks;    // grid.y: feature chunks of 64 * vec
+  int wave_slots;  // one fix-up slot per wave (see SpmmParams::wave_slots)
   int64_t num_waves, num_slots;
   size_t off_plan, off_meta, off_carry_row, off_carry_val, off_tail_val, off_carry_argu,
       off_carry_arge, off_tail_argu, off_tail_arge, total;
@@ -780,7 +859,10 @@ inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len
   g.groups = 64 >> l2;
   g.chunks = static_cast<int>((out_len + 64 * vec - 1) / (64 * vec));
   g.num_waves = spmm_num_waves(num_rows, nnz);
-  g.num_slots = g.num_waves * g.groups;
+  // sum reducer with two lane groups per wave (17 .. 32 lanes per feature row, e.g. F = 100 fp32):
+  // one fix-up slot per wave instead of one per group
+  g.wave_slots = (!with_arg && g.groups == 2 && g.chunks == 1) ? 1 : 0;
+  g.num_slots = g.num_waves * (g.wave_slots ? 1 : g.groups);
   size_t off = 0;
   g.off_plan = off;
   off = align_up(off + sizeof(int64_t) * (g.num_waves + 1), 256);
@@ -893,6 +975,7 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.rel = static_cast<const uint8_t*>(L.rel);
   p.xtab = L.ufeat_tab;
   p.wtab = L.efeat_tab;
+  p.wave_slots = g.wave_slots;
   p.carry_row = reinterpret_cast<int64_t*>(ws + g.off_carry_row);
   p.carry_val = ws + g.off_carry_val;
   p.tail_val = ws + g.off_tail_val;

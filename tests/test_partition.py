@@ -103,29 +103,54 @@ def test_partitioned_spmm_equals_unpartitioned():
     assert abs(frac - st["cut_fraction"]) < 0.05
 
 
-def test_vertex_order_candidate_wins_on_a_banded_graph_and_only_there():
-    """partition_assignment also evaluates contiguous edge-balanced ranges in the given vertex
-    order and keeps the better cut: a banded graph (neighbours within a window of the row id —
-    ids assigned by locality) is cut best by ranges, which the label-propagation multilevel scheme
-    does not find; with shuffled ids the multilevel answer stays."""
+def test_banded_graph_multilevel_is_no_worse_than_vertex_order_ranges():
+    """A banded graph (neighbours within a window of the row id — ids assigned by locality) is cut
+    best by contiguous ranges in id order.  Round 2's multilevel answer lost to them (0.56 vs 0.47 of
+    the edges at C2 scale) and a fallback picked the ranges; with the recursive-bisection initial
+    partition the multilevel answer itself must be at least as good (VERDICT r2 Next #7), and the
+    order-aware entry point still returns the better of the two."""
     rng = np.random.default_rng(5)
     n, deg, k = 40_000, 12, 8
     dst = np.repeat(np.arange(n), deg)
     src = np.clip(dst + rng.integers(-300, 301, n * deg), 0, n - 1)
     indptr, indices, _ = coo_to_csc(src, dst, n, np.int64)
-    part, st = partition_assignment(torch.from_numpy(indptr), torch.from_numpy(indices), k, seed=1)
-    assert st["method"] == "ranges (vertex order)" and st["cut_fraction"] < 0.04, st
-    assert st["multilevel_cut_fraction"] > st["cut_fraction"]
-    assert torch.equal(part, torch.sort(part).values)            # contiguous ranges in id order
-    counts = torch.bincount(part, minlength=k)
-    assert int(counts.max()) <= 1.05 * n / k
-    # recount of the cut
+    ip, ix = torch.from_numpy(indptr), torch.from_numpy(indices)
     rows = np.repeat(np.arange(n), np.diff(indptr))
-    p = part.numpy()
-    assert int((p[rows] != p[indices]).sum()) == st["cut_edges"]
-    _, st_ml = partition_assignment(torch.from_numpy(indptr), torch.from_numpy(indices), k, seed=1, order_aware=False)
+    bounds = partition_rows(ip, k)
+    rng_part = torch.searchsorted(bounds[1:].contiguous(), torch.arange(n), right=True).numpy()
+    range_cut = float((rng_part[rows] != rng_part[indices]).mean())
+    part_ml, st_ml = partition_assignment(ip, ix, k, seed=1, order_aware=False)
     assert st_ml["method"] == "multilevel"
+    p = part_ml.numpy()
+    ml_cut = float((p[rows] != p[indices]).mean())
+    assert ml_cut <= 1.05 * range_cut, (ml_cut, range_cut)
+    counts = torch.bincount(part_ml, weights=torch.from_numpy(np.diff(indptr) + 1).double(), minlength=k)
+    assert float(counts.max()) <= 1.04 * float(counts.sum()) / k + 50
+    part, st = partition_assignment(ip, ix, k, seed=1)           # order-aware: the better of the two
+    assert st["cut_fraction"] <= min(ml_cut, range_cut) + 1e-9 and st["cut_fraction"] < 0.04, st
+    q = part.numpy()
+    assert int((q[rows] != q[indices]).sum()) == st["cut_edges"]
     # shuffled ids (test_recovers_planted_communities' graph): ranges would cut 87.5 %, the multilevel answer is kept
-    ip, ix, _ = planted(8, 1500, 12, 0.9, seed=1)
-    _, st2 = partition_assignment(ip, ix, 8, imbalance=0.05, seed=3)
+    ip2, ix2, _ = planted(8, 1500, 12, 0.9, seed=1)
+    _, st2 = partition_assignment(ip2, ix2, 8, imbalance=0.05, seed=3)
     assert st2["method"] == "multilevel"
+
+
+def test_thread_count_does_not_change_the_answer():
+    import subprocess
+    import sys
+
+    code = ("import sys, torch; sys.path.insert(0, %r);"
+            "from tests.test_partition import planted; from dgl_amd.parallel import partition_assignment;"
+            "ip, ix, _ = planted(4, 4000, 10, 0.8, seed=2);"
+            "p, st = partition_assignment(ip, ix, 4, seed=5, order_aware=False);"
+            "print(int((p * torch.arange(1, p.numel() + 1)).sum()), st['cut_edges'])")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for t in ("1", "3", "8"):
+        r = subprocess.run([sys.executable, "-c", code % root], env=dict(os.environ, DGLA_PARTITION_THREADS=t),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip())
+    assert outs[0] == outs[1] == outs[2], outs
