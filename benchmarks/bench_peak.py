@@ -39,6 +39,11 @@ def main():
                 ms = t_ms(lambda: _capi.stream_copy_variant(dst, src, v))
                 moved = nbytes if mode == 2 else 2 * nbytes
                 res["%s_bpc%d_u%d" % (mname, 4 << bsel, 8 if usel else 4)] = round(moved / ms / 1e6, 1)
+        for usel in range(2):  # one tile per workgroup (no grid-stride loop)
+            v = mode | (usel << 4) | 32
+            ms = t_ms(lambda: _capi.stream_copy_variant(dst, src, v))
+            moved = nbytes if mode == 2 else 2 * nbytes
+            res["%s_onetile_u%d" % (mname, 8 if usel else 4)] = round(moved / ms / 1e6, 1)
     ms = t_ms(lambda: dst.copy_(src))
     res["torch_copy_"] = round(2 * nbytes / ms / 1e6, 1)
     print(json.dumps({"unit": "GB/s", "bytes": nbytes, "results": res,

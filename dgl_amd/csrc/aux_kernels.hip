@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const u32x4* __restric
   if constexpr (MODE == 2) dst[blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x] = acc;
 }
 
-// variant = MODE + 4 * (blocks-per-CU selector) + 16 * (unroll selector); 0 is the default
+// variant = MODE + 4 * (blocks-per-CU selector) + 16 * (unroll selector) + 32 * (one tile per
+// workgroup); 0 is the default
 // used for the roofline denominator, the others exist for benchmarks/bench_peak.py.
 int launch_stream_copy(void* dst, const void* src, size_t bytes, int variant, hipStream_t stream) {
   const size_t n = bytes / 16;
@@ -60,7 +61,10 @@ int launch_stream_copy(void* dst, const void* src, size_t bytes, int variant, hi
   const int usel = (variant >> 4) & 1;               // 0: U = 4, 1: U = 8
   const size_t tile = 256 * static_cast<size_t>(usel ? 8 : 4);
   size_t blocks = (n + tile - 1) / tile;
-  if (blocks > static_cast<size_t>(256 * bpc)) blocks = 256 * bpc;
+  // bit 5: ONE tile per workgroup, no grid-stride loop (a grid of millions of short workgroups —
+  // the shape of the split-row copy, which moves 5.9 TB/s where the persistent grid moves 5.0-5.2)
+  if (!(variant & 32) && blocks > static_cast<size_t>(256 * bpc)) blocks = 256 * bpc;
+  if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
   const dim3 g(static_cast<unsigned>(blocks)), b(256);
   const u32x4* s = static_cast<const u32x4*>(src);
   u32x4* d = static_cast<u32x4*>(dst);
