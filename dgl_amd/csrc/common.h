@@ -184,6 +184,9 @@ enum Tune : uint32_t {
   kTuneMmF32 = 128u,      // segment_mm fp32: v_mfma_f32_32x32x2_f32 instead of the 3 x bf16 split
   kTuneSplitClassic = 256u,  // split-row layout: copy WHOLE rows (main + tail arrays, round 2) instead of
                              // the edge layout that leaves the line-aligned interior of every row in place
+  kTuneTailPass = 512u,      // copy_u + sum, fp32 rows of 128 k + 16 bytes: the 16-byte row tails are summed
+                             // by a column-sliced pass of their own (spmm_tail.hip); changes the summation
+                             // ORDER of the last four output columns (the only SpMM bit that touches a result bit)
 };
 // Default: XCD-contiguous order (measured on C2: variant L -3 % time, variant U neutral); the
 // non-temporal bits are neutral.  Split-row (profiles/r2/tune_split_ab.jsonl, C2, F = 100 fp32):
@@ -192,7 +195,7 @@ enum Tune : uint32_t {
 // static (DGLA_SPLIT_KEEP / _VALID); on variant L the locality probe (81 % local edges against
 // 5 % on U) declines it unless the features are static (4.08 -> 3.75 ms) -> on.  The LDS-direct
 // segment_mm loop is 23-34 % faster at every measured shape (profiles/r1/glds_ab.jsonl) -> on.
-constexpr uint32_t kDefaultTuning = 1u | 8u | 16u;
+constexpr uint32_t kDefaultTuning = 1u | 8u | 16u | 512u;
 uint32_t& tuning_flags();
 
 // Merge-path geometry of the CSR SpMM (see spmm_csr.cuh).
@@ -204,6 +207,30 @@ inline int64_t spmm_num_waves(int64_t num_rows, int64_t nnz) {
 }
 
 std::string& last_error();
+
+// Column-sliced tail pass (spmm_tail.hip; geometry and call sites in spmm_csr.cuh).
+constexpr int kTailWaveItems = 256;  // merge items per wavefront of the tail kernel (it has its own plan)
+struct SpmmTailLaunch {
+  const int32_t* vptr;   // [slices * num_rows + 1] row pointers of the slice-major virtual CSR
+  const int32_t* tcol;   // [nnz] column ids in virtual-CSR order
+  const int64_t* plan;   // [num_waves + 1] merge plan of the virtual CSR
+  int64_t num_rows, nnz, num_waves;
+  int slices;
+  const void* s2;        // [num_cols] 16-byte row tails of ufeat
+  void* part;            // [slices * num_rows] 16-byte partial sums
+  int64_t* carry_row;    // [num_waves]
+  void* carry_val;       // [num_waves] 16 bytes
+  void* tail_val;        // [num_waves] 16 bytes
+  const unsigned* meta;  // the locality probe's counters (NULL: always run)
+  uint32_t tune;
+  hipStream_t stream;
+};
+size_t spmm_tail_build_scratch_bytes(int64_t nnz, int slices);
+int spmm_tail_build(const CsrView& csr, int slices, int32_t* vptr, int32_t* tcol, int64_t* plan,
+                    int64_t num_waves, char* scratch, hipStream_t s);
+int spmm_tail_launch(const SpmmTailLaunch& t);
+int spmm_tail_combine(const SpmmTailLaunch& t, void* out, int64_t out_len, const void* indptr, bool mean,
+                      bool accumulate);
 
 // Optional HIP events recorded around the dominant (merge) kernel of dgla_spmm_csr, so a
 // benchmark can time that kernel alone on the launch stream (dgla_spmm_set_profile_events).

@@ -168,6 +168,7 @@ struct UnitGraph {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   bool plan_valid = false;
+  uint32_t plan_tune = 0;  // layout-relevant tuning bits the plan in `ws` was built under (plan_ok())
   // Static source features (dgl_amd._CAPI_UnitGraphStaticOperand): `pending_static` is the
   // token the Python layer announced for the NEXT SpMM's U operand (one-shot, 0 = not static);
   // `split_key` describes whose split-row copy the workspace holds right now (token 0 = nobody's).
@@ -202,6 +203,18 @@ struct UnitGraph {
   size_t esm_ws_bytes = 0;
   bool esm_plan_valid = false;
 };
+
+// Is the merge plan in g->ws still the one the NEXT call expects?  The tuning bits that decide
+// the workspace layout (split-row layouts, the tail pass's slice structure next to the plan) are
+// part of what a plan is: a change of any of them since the plan was built invalidates it.
+static bool plan_ok(UnitGraph* g) {
+  const uint32_t layout = tuning_flags() & (kTuneSplit | kTuneSplitClassic | kTuneTailPass);
+  if (g->plan_tune != layout) {
+    g->plan_valid = false;
+    g->plan_tune = layout;
+  }
+  return g->plan_valid;
+}
 
 static int idbits_of(const DGLArray* t, int* bits) {
   if (t->dtype.code != 0 || (t->dtype.bits != 32 && t->dtype.bits != 64))
@@ -405,7 +418,7 @@ static UnitGraph::SplitKey static_split_flags(UnitGraph* g, const SpmmCall& c, u
   key.dtype = static_cast<int>(c.dtype);
   key.with_arg = strcmp(c.reduce, "sum") != 0;
   *flags |= DGLA_SPLIT_KEEP;
-  if (g->plan_valid && g->split_key == key) *flags |= DGLA_SPLIT_VALID;
+  if (plan_ok(g) && g->split_key == key) *flags |= DGLA_SPLIT_VALID;
   return key;
 }
 
@@ -650,7 +663,7 @@ static Registrar r_spmm("sparse._CAPI_DGLKernelSpMM", [](const FfiArgs& a, DGLVa
   // aten::SpMM: CSC (in-edge CSR) preferred, else COO (src/array/kernel.cc:26-43)
   if (g->csc.present) {
     dgla_csr csc = csr_of(g, g->csc, true);
-    uint32_t flags = g->plan_valid ? DGLA_PLAN_VALID : 0;
+    uint32_t flags = plan_ok(g) ? DGLA_PLAN_VALID : 0;
     const UnitGraph::SplitKey key = static_split_flags(g, c, &flags);
     dgla_tensor e_op = c.e.t;
     if (static_edge_operand(g, c, &csc, &e_op)) return -1;
@@ -683,7 +696,7 @@ static Registrar r_spmm_mean("sparse._CAPI_DGLKernelSpMMMean",
   UnitGraph* g = c.g;
   if (!g->csc.present) return ffi_fail("SpMMMean needs the CSC format");
   dgla_csr csc = csr_of(g, g->csc, true);
-  uint32_t flags = (g->plan_valid ? DGLA_PLAN_VALID : 0) | DGLA_MEAN;
+  uint32_t flags = (plan_ok(g) ? DGLA_PLAN_VALID : 0) | DGLA_MEAN;
   const UnitGraph::SplitKey key = static_split_flags(g, c, &flags);
   dgla_tensor e_op = c.e.t;
   if (static_edge_operand(g, c, &csc, &e_op)) return -1;
@@ -704,7 +717,7 @@ static Registrar r_spmm_acc("sparse._CAPI_DGLKernelSpMMAccumulate",
   UnitGraph* g = c.g;
   if (!g->csc.present) return ffi_fail("SpMMAccumulate needs the CSC format");  // kernel.cc:212-217
   const dgla_csr csc = csr_of(g, g->csc, true);
-  const uint32_t flags = (g->plan_valid ? DGLA_PLAN_VALID : 0) | DGLA_ACCUMULATE;
+  const uint32_t flags = (plan_ok(g) ? DGLA_PLAN_VALID : 0) | DGLA_ACCUMULATE;
   const int rc = dgla_spmm_csr(c.op, c.reduce, &csc, c.dtype, &c.u.t, &c.e.t, &c.v.t, nullptr,
                                nullptr, g->ws, g->ws_bytes, flags, tls_stream);
   g->pending_static = g->pending_static_e = 0;
@@ -757,7 +770,7 @@ static int spmm_stacked_ffi(const FfiArgs& a, DGLValue* ret, int* rtc, bool want
       op, &csc, data_ptr(rel), static_cast<int>(n_rel), dt, &u.t, &e.t,
       null_array(Ut) ? nullptr : static_cast<const void* const*>(data_ptr(Ut)),
       null_array(Et) ? nullptr : static_cast<const void* const*>(data_ptr(Et)), &v.t, g->ws,
-      g->ws_bytes, g->plan_valid ? DGLA_PLAN_VALID : 0, tls_stream);
+      g->ws_bytes, plan_ok(g) ? DGLA_PLAN_VALID : 0, tls_stream);
   g->split_key = UnitGraph::SplitKey();
   if (rc == 0) g->plan_valid = true;
   return rc;
@@ -827,7 +840,7 @@ static int spmm_stacked_cmp_ffi(const FfiArgs& a, DGLValue* ret, int* rtc, bool 
       null_array(Et) ? nullptr : static_cast<const void* const*>(data_ptr(Et)), &v.t,
       null_array(AU) ? nullptr : data_ptr(AU), null_array(AE) ? nullptr : data_ptr(AE),
       null_array(UT) ? nullptr : data_ptr(UT), null_array(ET) ? nullptr : data_ptr(ET), g->ws, g->ws_bytes,
-      g->plan_valid ? DGLA_PLAN_VALID : 0, tls_stream);
+      plan_ok(g) ? DGLA_PLAN_VALID : 0, tls_stream);
   g->split_key = UnitGraph::SplitKey();
   if (rc == 0) g->plan_valid = true;
   return rc;
@@ -1357,7 +1370,7 @@ static int spmm_unit(UnitGraph* g, const char* op, const char* reduce, dgla_dtyp
       DGLA_CHECK_HIP(hipMallocAsync(&owned, need, tls_stream));
       ws = owned;
       ws_bytes = need;
-    } else if (g->plan_valid) {
+    } else if (plan_ok(g)) {
       flags |= DGLA_PLAN_VALID;
     }
     const int rc = dgla_spmm_csr(op, reduce, &csc, dt, u, e, v, arg_u, arg_e, ws, ws_bytes, flags, tls_stream);

@@ -23,6 +23,8 @@
 //    CSR position exactly like the reference's sequential loop (functor.cuh:246-254).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -63,6 +65,9 @@ struct SpmmParams {
   int split_edge_lines;  // k - 1 (0: classic layout / none)
   int split_t16;         // t / 16
   int split_base16;      // (address of ufeat mod 128) / 16: where row 0 starts inside its line
+  // column-sliced tail pass (spmm_tail.hip): the lanes that would gather the 16-byte row tails sit
+  // this launch out — the last four output columns are produced by that pass
+  int tail_pass;
   // stacked multi-relation form (MULTI kernels only)
   const uint8_t* rel;
   const void* const* xtab;
@@ -470,6 +475,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
       lhs_len = p.split_tail;
     }
   }
+  if (edge_layout && p.tail_pass && ej == 0x40000000u) return;  // the tail pass owns these columns
   [[maybe_unused]] const unsigned e_in_place = 8u * static_cast<unsigned>(p.split_edge_lines);
   [[maybe_unused]] const unsigned e_t16 = static_cast<unsigned>(p.split_t16);
   [[maybe_unused]] const unsigned e_base16 = static_cast<unsigned>(p.split_base16);
@@ -767,10 +773,12 @@ __global__ __launch_bounds__(64) void spmm_csr_fixup_kernel(const SpmmParams<Idx
     // slot s2 holds the tail (the group in which the row ends); it always exists because a
     // row with a carry has its row-end item in a later slot.
     const int F = p.out_len;
+    // columns owned by the tail pass (same device-side decision as the merge kernel)
+    const int Fk = (p.tail_pass && p.split_main > 0 && split_wanted(p.split_meta)) ? F - p.split_tail : F;
     const A* cv = static_cast<const A*>(p.carry_val);
     const A* tv = static_cast<const A*>(p.tail_val);
     DT* out = static_cast<DT*>(p.out);
-    for (int k = threadIdx.x; k < F; k += 64) {
+    for (int k = threadIdx.x; k < Fk; k += 64) {
       A acc = cv[s * F + k];
       Idx au = 0, ae = 0;
       if constexpr (ARG) {
@@ -824,7 +832,34 @@ struct SpmmGeometry {
   int split_main_bytes, split_tail_bytes;
   size_t off_split_main, off_split_tail;
   int split_edge_lines;  // > 0: edge layout (main = one 128-byte side line per row, k - 1 lines stay in place)
+  // column-sliced tail pass (spmm_tail.hip).  tail_slices > 0: the workspace of this graph holds,
+  // next to the merge plan and as long-lived as it, the slice-major virtual CSR (vptr / col) and
+  // its merge plan; tail_pass: THIS call's shape uses it (partial sums + fix-up slots in the scratch)
+  int tail_slices;
+  bool tail_pass;
+  int64_t tail_waves;
+  size_t off_tail_vptr, off_tail_col, off_tail_plan, off_tail_part, off_tail_crow, off_tail_cval,
+      off_tail_tval, off_tail_scratch;
 };
+
+// Graph-level eligibility of the tail pass and its slice count (0 = none).  Depends on the CSR and
+// the tuning bits only — never on the operator or the feature shape — because the structure is
+// built with the merge plan and must sit at the same place for every later call on the workspace.
+// Slices of ~2.5 MB of 16-byte tails (a 4 MiB L2 minus the streams that pass through it).
+inline int spmm_tail_slices(const SpmmLaunch& L) {
+  if (!(L.tune & kTuneTailPass) || !(L.tune & kTuneSplit) || (L.tune & kTuneSplitClassic)) return 0;
+  if (L.rel != nullptr || L.csr.idbits != 32 || L.csr.indices == nullptr) return 0;
+  if (L.csr.nnz >= (int64_t(1) << 31) || L.csr.nnz < 4 * L.csr.num_cols) return 0;
+  // (both knobs are read per call so that tests can exercise small graphs and many slice counts)
+  const char* emin = getenv("DGLA_TAIL_MIN_COLS");
+  const int64_t min_cols = emin && atoll(emin) > 0 ? atoll(emin) : (int64_t(1) << 20);
+  if (L.csr.num_cols < min_cols) return 0;  // tails of under 16 MB: half of them hit in L2 anyway
+  const char* ekb = getenv("DGLA_TAIL_SLICE_KB");
+  const int64_t slice_bytes = (ekb && atoll(ekb) > 0 ? atoll(ekb) : 2560) << 10;
+  const int64_t s = (L.csr.num_cols * 16 + slice_bytes - 1) / slice_bytes;
+  if (s > 32) return 0;  // partial sums of S x rows x 16 bytes: past this the pass costs what it saves
+  return static_cast<int>(s < 2 ? 2 : s);
+}
 
 // Half-width, in rows, of the window the locality probe counts as "local": 2 x 64 Ki rows of
 // 400 bytes = 52 MB, a fifth of the 256 MiB Infinity Cache.
@@ -848,7 +883,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len, int vec,
                                   size_t acc_bytes, int idbytes, bool with_arg,
                                   int64_t split_rows = 0, int64_t split_row_bytes = 0,
-                                  bool edge_layout = false) {
+                                  bool edge_layout = false, int tail_slices = 0, bool tail_pass = false) {
   SpmmGeometry g;
   g.vec = vec;
   int64_t lanes = (out_len + vec - 1) / vec;
@@ -868,6 +903,21 @@ inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len
   off = align_up(off + sizeof(int64_t) * (g.num_waves + 1), 256);
   g.off_meta = off;  // locality probe counters {local, sampled}; lives and dies with the plan
   off += 256;
+  g.tail_slices = tail_slices;
+  g.tail_pass = false;
+  g.tail_waves = 0;
+  g.off_tail_vptr = g.off_tail_col = g.off_tail_plan = off;
+  if (tail_slices > 0) {  // long-lived like the plan: before anything whose size depends on the call
+    const int64_t vrows = num_rows * tail_slices;
+    g.tail_waves = (vrows + nnz + kTailWaveItems - 1) / kTailWaveItems;
+    g.off_tail_vptr = off;
+    off = align_up(off + sizeof(int32_t) * (vrows + 1), 256);
+    g.off_tail_col = off;
+    off = align_up(off + sizeof(int32_t) * nnz, 256);
+    g.off_tail_plan = off;
+    off = align_up(off + sizeof(int64_t) * (g.tail_waves + 1), 256);
+  }
+  g.off_tail_scratch = off;  // everything from here on is per-call scratch
   g.off_carry_row = off;
   off = align_up(off + sizeof(int64_t) * g.num_slots, 256);
   g.off_carry_val = off;
@@ -897,6 +947,22 @@ inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len
     off = align_up(off + static_cast<size_t>(split_rows) * g.split_main_bytes, 256);
     g.off_split_tail = off;
     off = align_up(off + static_cast<size_t>(split_rows) * g.split_tail_bytes, 256);
+  }
+  g.off_tail_part = g.off_tail_crow = g.off_tail_cval = g.off_tail_tval = off;
+  if (tail_slices > 0 && tail_pass && g.split_edge_lines > 0 && g.split_tail_bytes == 16) {
+    g.tail_pass = true;
+    g.off_tail_part = off;
+    off = align_up(off + size_t(16) * num_rows * tail_slices, 256);
+    g.off_tail_crow = off;
+    off = align_up(off + sizeof(int64_t) * g.tail_waves, 256);
+    g.off_tail_cval = off;
+    off = align_up(off + size_t(16) * g.tail_waves, 256);
+    g.off_tail_tval = off;
+    off = align_up(off + size_t(16) * g.tail_waves, 256);
+  }
+  if (tail_slices > 0) {  // the one-time build borrows the per-call scratch
+    const size_t need = g.off_tail_scratch + spmm_tail_build_scratch_bytes(nnz, tail_slices);
+    if (off < need) off = need;
   }
   g.total = off;
   return g;
@@ -928,7 +994,33 @@ inline int launch_plan(const SpmmLaunch& L, const SpmmGeometry& g) {
                        L.csr.num_cols, L.csr.nnz, g.num_waves, stride, window, meta);
     DGLA_CHECK_HIP(hipGetLastError());
   }
+  if (g.tail_slices > 0)
+    return spmm_tail_build(L.csr, g.tail_slices, reinterpret_cast<int32_t*>(ws + g.off_tail_vptr),
+                           reinterpret_cast<int32_t*>(ws + g.off_tail_col),
+                           reinterpret_cast<int64_t*>(ws + g.off_tail_plan), g.tail_waves,
+                           ws + g.off_tail_scratch, L.stream);
   return 0;
+}
+
+inline SpmmTailLaunch make_tail_launch(const SpmmLaunch& L, const SpmmGeometry& g, const unsigned* meta) {
+  char* ws = static_cast<char*>(L.workspace);
+  SpmmTailLaunch t;
+  t.vptr = reinterpret_cast<const int32_t*>(ws + g.off_tail_vptr);
+  t.tcol = reinterpret_cast<const int32_t*>(ws + g.off_tail_col);
+  t.plan = reinterpret_cast<const int64_t*>(ws + g.off_tail_plan);
+  t.num_rows = L.csr.num_rows;
+  t.nnz = L.csr.nnz;
+  t.num_waves = g.tail_waves;
+  t.slices = g.tail_slices;
+  t.s2 = ws + g.off_split_tail;
+  t.part = ws + g.off_tail_part;
+  t.carry_row = reinterpret_cast<int64_t*>(ws + g.off_tail_crow);
+  t.carry_val = ws + g.off_tail_cval;
+  t.tail_val = ws + g.off_tail_tval;
+  t.meta = meta;
+  t.tune = L.tune;
+  t.stream = L.stream;
+  return t;
 }
 
 template <typename Idx, typename DT>
@@ -972,6 +1064,7 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
     p.split_t16 = g.split_tail_bytes / 16;
     p.split_base16 = static_cast<int>((reinterpret_cast<uintptr_t>(L.ufeat) & 127u) >> 4);
   }
+  p.tail_pass = g.tail_pass ? 1 : 0;
   p.rel = static_cast<const uint8_t*>(L.rel);
   p.xtab = L.ufeat_tab;
   p.wtab = L.efeat_tab;
@@ -1028,6 +1121,12 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
   }
   const ProfileEvents pe = profile_events();
   if (pe.before) DGLA_CHECK_HIP(hipEventRecord(pe.before, L.stream));
+  if (g.tail_pass) {
+    // the row tails first (their side array was written a moment ago): tail kernel + its fix-up;
+    // the combine pass follows the main kernel.  With profile events set, the bracket covers
+    // all of it — the pair is one operator.
+    if (spmm_tail_launch(make_tail_launch(L, g, p.split_meta))) return -1;
+  }
   if (L.rel != nullptr) {
     // stacked multi-relation launch: the operator subset the fused hetero path uses
     if constexpr (RED == kSum && (OP == kCopyLhs || OP == kCopyRhs || OP == kMul) &&
@@ -1066,11 +1165,17 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
                        dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
   }
   DGLA_CHECK_HIP(hipGetLastError());
-  if (pe.after) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
+  if (pe.after && !g.tail_pass) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
   hipLaunchKernelGGL((spmm_csr_fixup_kernel<Idx, DT, OP, RED>),
                      dim3(static_cast<unsigned>(std::min<int64_t>(g.num_slots, int64_t(1) << 24))),
                      dim3(64), 0, L.stream, p, g.num_slots);
   DGLA_CHECK_HIP(hipGetLastError());
+  if (g.tail_pass) {
+    if (spmm_tail_combine(make_tail_launch(L, g, p.split_meta), L.out, L.out_len, L.csr.indptr, L.mean,
+                          L.accumulate))
+      return -1;
+    if (pe.after) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
+  }
   return 0;
 }
 
@@ -1155,15 +1260,17 @@ template <typename DT>
 inline int launch_spmm_csr_typed(const SpmmLaunch& L) {
   using A = typename Acc<DT>::type;
   const int vec = spmm_pick_vec<DT>(L);
+  const int tail_slices = spmm_tail_slices(L);
+  const bool tail_shape = std::is_same<DT, float>::value && L.op == kCopyLhs && L.red == kSum;
   SpmmGeometry g = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
-                                 L.csr.idbits / 8, L.red != kSum);
+                                 L.csr.idbits / 8, L.red != kSum, 0, 0, false, tail_slices);
   if (vec * sizeof(DT) == 16 && g.chunks == 1 && spmm_split_shape_ok(L, sizeof(DT))) {
     // same carve-up plus the two re-laid-out copies of X; used only if the caller's workspace
     // has room (dgla_spmm_csr_workspace_bytes accounts for it), else the plain layout runs
     const SpmmGeometry gs = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
                                           L.csr.idbits / 8, L.red != kSum, L.csr.num_cols,
                                           L.lhs_len * static_cast<int64_t>(sizeof(DT)),
-                                          !(L.tune & kTuneSplitClassic));
+                                          !(L.tune & kTuneSplitClassic), tail_slices, tail_shape);
     if (L.workspace && L.workspace_bytes >= gs.total) g = gs;
   }
   if (L.workspace_bytes < g.total || (g.total && !L.workspace)) {
@@ -1187,11 +1294,13 @@ inline size_t spmm_csr_workspace_typed(const SpmmLaunch& L) {
   constexpr int full = 16 / sizeof(DT);
   size_t best = 0;
   const bool split = spmm_split_shape_ok(L, sizeof(DT));
+  const int tail_slices = spmm_tail_slices(L);
+  const bool tail_shape = std::is_same<DT, float>::value && L.op == kCopyLhs && L.red == kSum;
   for (int vec : {1, full / 2 > 1 ? full / 2 : 1, full}) {
     const size_t t = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
                                    L.csr.idbits / 8, L.red != kSum, split ? L.csr.num_cols : 0,
                                    L.lhs_len * static_cast<int64_t>(sizeof(DT)),
-                                   !(L.tune & kTuneSplitClassic))
+                                   !(L.tune & kTuneSplitClassic), tail_slices, tail_shape)
                          .total;
     if (t > best) best = t;
   }

@@ -373,8 +373,8 @@ int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const voi
                              const void* local_idx, int64_t n, int part_id, void* out,
                              void* hip_stream);
 
-/* Process-wide tuning bits of the CSR SpMM.  None of them changes a result bit; they select
- * memory-system behaviour and exist so that a benchmark can A/B them on the GPU:
+/* Process-wide tuning bits of the CSR SpMM.  Except DGLA_TUNE_TAIL_PASS none of them changes a
+ * result bit; they select memory-system behaviour and exist so that a benchmark can A/B them:
  *   DGLA_TUNE_XCD     units visit the merge path in XCD-contiguous order (block b runs on XCD
  *                     b % 8, so each XCD's L2 sees one contiguous eighth of the rows)
  *   DGLA_TUNE_NT_OUT  finished output rows are stored non-temporally
@@ -402,6 +402,16 @@ int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const voi
  *                     array + dense tail array).  Default (bit off) for rows of two or more whole
  *                     lines: only the two ragged ENDS of every row are copied (one 128-byte line
  *                     per row + the dense tail); the line-aligned interior is gathered in place
+ *   DGLA_TUNE_TAIL_PASS  copy_lhs + sum (also mean / accumulate) on fp32 rows of 128 k + 16 bytes
+ *                     (F = 100), int32 ids, graphs of >= 2^20 columns with the split layout in use: the
+ *                     16-byte row tails are summed by a pass of their own over a column-sliced copy of
+ *                     the graph structure, in which they hit in the XCD's L2, and the main kernel
+ *                     gathers three whole lines per edge instead of four requests.  The structure
+ *                     (4 x (S x rows + nnz) bytes, S = slices of ~2.5 MB of tails) is built WITH THE
+ *                     MERGE PLAN of every such graph and lives next to it in the workspace.  The last
+ *                     four output columns are then summed in (slice, CSR position) order instead of
+ *                     CSR position: deterministic, different low-order bits (default on).  Changing
+ *                     this bit changes the workspace layout: do not pass DGLA_PLAN_VALID across it.
  * The reference has no counterpart (its kernels take no hints). */
 #define DGLA_TUNE_XCD 1u
 #define DGLA_TUNE_NT_OUT 2u
@@ -412,6 +422,7 @@ int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const voi
 #define DGLA_TUNE_SPLIT_FORCE 64u
 #define DGLA_TUNE_MM_F32 128u
 #define DGLA_TUNE_SPLIT_CLASSIC 256u
+#define DGLA_TUNE_TAIL_PASS 512u
 int dgla_set_tuning(uint32_t flags);
 uint32_t dgla_get_tuning(void);
 
