@@ -76,8 +76,7 @@ def test_tail_pass_matches_oracle_and_leaves_other_columns_alone(dev, small_grap
     torch.manual_seed(feat)
     x = torch.rand(n_src, feat, device=dev) + 0.5
     csr = _capi.make_csr(g["indptr"], g["indices"], None, n_src)
-    default = _capi.get_tuning()
-    assert default & _lib.DGLA_TUNE_TAIL_PASS
+    default = _capi.get_tuning() | _lib.DGLA_TUNE_TAIL_PASS  # the pass is opt-in
     outs = {}
     try:
         for flags in (default & ~_lib.DGLA_TUNE_TAIL_PASS, default):
@@ -95,7 +94,7 @@ def test_tail_pass_matches_oracle_and_leaves_other_columns_alone(dev, small_grap
             assert torch.equal(first, out), "run-to-run bits (cached plan) differ, flags=%d" % flags
             outs[flags] = (out.clone(), ws.numel())
     finally:
-        _capi.set_tuning(default)
+        _capi.set_tuning(default & ~_lib.DGLA_TUNE_TAIL_PASS)
     plain, tail = outs[default & ~_lib.DGLA_TUNE_TAIL_PASS], outs[default]
     # the pass really ran: its structure + partial sums are in the workspace
     slices = -(-n_src * 16 // (slice_kb << 10))
@@ -128,7 +127,7 @@ def test_tail_pass_is_skipped_for_other_operators_and_widths(dev, small_graph_kn
     n_dst, n_src, e = 40_000, 200_000, 900_000
     g = synth_csr(n_dst, n_src, e, "U", seed=5, device=dev, with_eids=True)
     csr = _capi.make_csr(g["indptr"], g["indices"], g["eids"], n_src)
-    default = _capi.get_tuning()
+    default = _capi.get_tuning() | _lib.DGLA_TUNE_TAIL_PASS  # the pass is opt-in
     torch.manual_seed(1)
     res = {}
     try:
@@ -153,7 +152,7 @@ def test_tail_pass_is_skipped_for_other_operators_and_widths(dev, small_graph_kn
                 got.append((feat, op, red, out.clone()))
             res[flags] = got
     finally:
-        _capi.set_tuning(default)
+        _capi.set_tuning(default & ~_lib.DGLA_TUNE_TAIL_PASS)
     for (f, op, red, a), (_, _, _, b) in zip(res[default & ~_lib.DGLA_TUNE_TAIL_PASS], res[default]):
         if (f, op, red) == (100, "copy_lhs", "sum"):
             assert torch.equal(a[:, :96], b[:, :96])
