@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--features", default="replicated", choices=["replicated", "sharded"],
                     help="sharded: features partitioned over the ranks, pulled per batch (the reference's layout)")
+    ap.add_argument("--mode", default="both", choices=["eager", "graph", "both"],
+                    help="graph: the whole step (sampling included) captured once in a hipGraph over padded, "
+                         "static-shape blocks (NeighborSampler.sample_blocks_padded) and replayed")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -115,6 +118,7 @@ def main():
 
     import dgl_amd as dgl
     import dgl_amd.function as fn
+    from dgl_amd._capi import SINK_ROWS
     from dgl_amd.graph_index import GraphIndex, Relation
     from dgl_amd.heterograph import DGLGraph
 
@@ -155,20 +159,85 @@ def main():
                 p -= 0.1 * gr
         return loss
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    edges[0] = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    tot_edges = float(edges[0])
+    # ---- the same step on padded, static-shape blocks: nothing is read back, so everything from the
+    # neighbour draws to the SGD update is ONE captured hipGraph; per step the host copies a fresh
+    # seed batch into the static buffer, replays, and (N > 1) all-reduces the gradients.
+    static_seeds = torch.zeros(args.batch, dtype=torch.int64, device=dev)
+    edge_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+    static_grads = [torch.zeros_like(p) for p in params]
+    static_loss = torch.zeros((), device=dev)
+
+    def padded_body():
+        inp, n_inp, out, blocks = sampler.sample_blocks_padded(g, static_seeds)
+        for b in blocks:
+            ip = b._graph.relations[0].csc()[0]
+            d = b.num_dst_nodes() - SINK_ROWS
+            edge_ctr.add_(ip[d:d + 1].long())         # real picks of the layer (where the sink rows start)
+        h = store.fetch(inp)
+        h = torch.relu(sage(blocks[0], h, params[0], params[1]))
+        h = h[: blocks[1].num_src_nodes()]            # drop the outer block's sink row
+        logits = sage(blocks[1], h, params[2], params[3])[: args.batch]
+        loss = torch.nn.functional.cross_entropy(logits, labels[out.long()])
+        grads = torch.autograd.grad(loss, params)
+        if world == 1:
+            with torch.no_grad():
+                for p, gr in zip(params, grads):
+                    p -= 0.1 * gr
+        else:
+            for sg, gr in zip(static_grads, grads):
+                sg.copy_(gr)
+        static_loss.copy_(loss.detach())
+
+    graph = None
+
+    def step_graph():
+        static_seeds.copy_(torch.randint(0, n, (args.batch,), device=dev, generator=gen))
+        graph.replay()
+        if world > 1:
+            grads = sync_grads(static_grads, dist, world)
+            with torch.no_grad():
+                for p, gr in zip(params, grads):
+                    p -= 0.1 * gr
+        return static_loss
+
+    def timed(fn):
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        edges[0] = 0
+        edge_ctr.zero_()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        return time.perf_counter() - t0, loss
+
+    results = {}
+    if args.mode in ("graph", "both"):  # (captured before any eager step has put autograd nodes on other streams)
+        if args.features == "sharded" and world > 1:
+            raise SystemExit("--mode graph keeps the feature pull outside the captured region: use --features replicated")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):                          # warm every lazily built plan / scratch first
+                static_seeds.copy_(torch.randint(0, n, (args.batch,), device=dev, generator=gen))
+                padded_body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            padded_body()
+        dt, loss = timed(step_graph)
+        results["graph"] = (dt, float(edge_ctr.item()), loss)
+    if args.mode in ("eager", "both"):
+        dt, loss = timed(step)
+        results["eager"] = (dt, float(edges[0]), loss)
+    best = "graph" if "graph" in results else "eager"
+    dt, tot_edges, loss = results[best]
     # replicas must hold the same parameters after the same synchronised steps
     chk = [float(p.detach().double().sum()) for p in params]
     spread = 0.0
@@ -185,6 +254,9 @@ def main():
                         % (args.batch, n, e, f, args.hidden, classes),
             "features": args.features if world > 1 else "local",
             "param_checksum_rel_spread_across_ranks": spread,
+            "step": "one hipGraph replay over padded static-shape blocks (sampling, block building, gather, "
+                    "forward, backward, SGD inside the graph)" if best == "graph" else "eager (sizes read back per layer)",
+            "ms_per_step_by_mode": {k: v[0] / args.steps * 1e3 for k, v in results.items()},
             "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
             "seeds_per_s": args.batch * world * args.steps / dt,
             "sampled_edges_per_s": tot_edges / dt, "final_loss": float(loss.detach())}))

@@ -387,6 +387,51 @@ def to_block(seeds, src, node_map):
     return local, src_nodes[:k], k
 
 
+SINK_ROWS = 64  # sink rows of a padded block (dgla_sample_neighbors_padded)
+
+
+def sample_neighbors_padded(csr, seeds, num_valid, fanout, replace=False, rng_seed=0, rng_counter=None,
+                            sink_rows=SINK_ROWS):
+    """Static-shape form of :func:`sample_neighbors` (dgla_sample_neighbors_padded): nothing is read
+    back.  ``seeds`` has ``n`` slots of which the first ``num_valid`` (int64 device tensor of one
+    element, or None = all) are real.  Returns ``(indptr[n + 1 + sink_rows], src[n * fanout],
+    eids[n * fanout])``: the real rows' picks first, then the edges of ``sink_rows`` extra SINK rows
+    (rows ``n ..``) pointing at the real seeds in turn.  ``rng_counter`` (int64 device tensor) is added to the draw counter on the device,
+    so a captured call samples afresh on every replay once the caller bumps it."""
+    _require_gpu(seeds)
+    n = seeds.shape[0]
+    dev, dt = seeds.device, seeds.dtype
+    cap = n * int(fanout)
+    indptr = torch.empty(n + 1 + int(sink_rows), dtype=dt, device=dev)
+    src = torch.empty(cap, dtype=dt, device=dev)
+    eids = torch.empty(cap, dtype=dt, device=dev)
+    ws = torch.empty(max(1, LIB.dgla_sample_neighbors_workspace_bytes(_idbits(seeds), n)), dtype=torch.uint8,
+                     device=dev)
+    check_call(LIB.dgla_sample_neighbors_padded(
+        ctypes.byref(csr), seeds.data_ptr(), n, _ptr(num_valid), int(fanout), 1 if replace else 0,
+        int(rng_seed) & 0xFFFFFFFFFFFFFFFF, _ptr(rng_counter), int(sink_rows), indptr.data_ptr(), src.data_ptr(),
+        eids.data_ptr(),
+        ws.data_ptr(), ws.numel(), _stream(seeds)))
+    return indptr, src, eids
+
+
+def to_block_padded(seeds, num_valid, src, node_map, fill=0, num_nodes=0):
+    """Static-shape form of :func:`to_block` (dgla_to_block_padded).  Returns ``(local_src,
+    src_nodes[n + nnz], num_src)`` with ``num_src`` an int64 DEVICE tensor; entries of ``src_nodes``
+    past it hold ``fill`` (a valid node id).  Only the first ``num_valid`` seeds claim a local id."""
+    _require_gpu(src)
+    n, nnz = seeds.shape[0], src.shape[0]
+    dev, dt = seeds.device, seeds.dtype
+    local = torch.empty(nnz, dtype=dt, device=dev)
+    src_nodes = torch.full((n + nnz,), int(fill), dtype=dt, device=dev)
+    num = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(1, LIB.dgla_to_block_workspace_bytes(_idbits(seeds), nnz)), dtype=torch.uint8, device=dev)
+    check_call(LIB.dgla_to_block_padded(_idbits(seeds), seeds.data_ptr(), n, _ptr(num_valid), _ptr(src), nnz,
+                                        int(num_nodes), node_map.data_ptr(), _ptr(local), src_nodes.data_ptr(), num.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), _stream(seeds)))
+    return local, src_nodes, num
+
+
 def gather_rows(src, idx, out=None):
     """out[i] = src[idx[i]] along dim 0 (dgla_gather_rows): the pack kernel of the halo exchange."""
     _require_gpu(src)

@@ -144,6 +144,13 @@ LIB.dgla_to_block_workspace_bytes.argtypes = [c_int, c_int64]
 LIB.dgla_to_block.restype = c_int
 LIB.dgla_to_block.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_size_t, c_void_p]
+LIB.dgla_sample_neighbors_padded.restype = c_int
+LIB.dgla_sample_neighbors_padded.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, ctypes.c_uint64,
+                                             c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                             c_void_p]
+LIB.dgla_to_block_padded.restype = c_int
+LIB.dgla_to_block_padded.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
 LIB.dgla_partition_kway.restype = c_int
 LIB.dgla_partition_kway.argtypes = [c_int, c_int64, c_void_p, c_void_p, c_int, ctypes.c_double, c_int,
                                     ctypes.c_uint64, c_void_p, c_void_p]

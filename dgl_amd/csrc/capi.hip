@@ -421,6 +421,7 @@ int dgla_spmm_csr_stacked(const char* op, const dgla_csr* csr, const void* rel, 
   L.rel = rel;
   L.ufeat_tab = ufeat_ptrs;
   L.efeat_tab = efeat_ptrs;
+  L.num_rel = num_rel;
   L.accumulate = (flags & DGLA_ACCUMULATE) != 0;
   L.plan_valid = (flags & DGLA_PLAN_VALID) != 0;
   L.workspace = workspace;
@@ -476,6 +477,7 @@ int dgla_spmm_csr_stacked_cmp(const char* op, const char* reduce, const dgla_csr
   L.rel = rel;
   L.ufeat_tab = ufeat_ptrs;
   L.efeat_tab = efeat_ptrs;
+  L.num_rel = num_rel;
   L.arg_u = nullptr;
   L.arg_e = pos_buf;
   L.arg_empty = -1;

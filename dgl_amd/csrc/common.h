@@ -144,6 +144,7 @@ struct SpmmLaunch {
   const void* rel;               // uint8 [nnz] or nullptr (single relation)
   const void* const* ufeat_tab;  // [num_rel]
   const void* const* efeat_tab;  // [num_rel]
+  int num_rel = 0;               // <= 256
   int arg_empty;    // arg value of an output element no edge won: 0 (g-SpMM), -1 (segment reduce)
   uint32_t tune;    // kTune* bits, from dgla_set_tuning()
   bool mean;        // reduce == sum: store sum / max(in_degree, 1)  (the `mean` reducer, fused)

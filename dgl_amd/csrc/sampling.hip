@@ -56,12 +56,13 @@ template <typename Idx>
 __global__ __launch_bounds__(256) void sample_count_kernel(const Idx* __restrict__ indptr,
                                                            const Idx* __restrict__ seeds,
                                                            int64_t num_seeds, int fanout, int replace,
-                                                           Idx* __restrict__ counts) {
+                                                           Idx* __restrict__ counts,
+                                                           const int64_t* __restrict__ num_valid = nullptr) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i > num_seeds) return;
-  if (i == num_seeds) {
-    counts[i] = 0;  // so that an exclusive scan over num_seeds + 1 entries ends with the total
-    return;
+  if (i == num_seeds || (num_valid != nullptr && i >= *num_valid)) {
+    counts[i] = 0;  // so that an exclusive scan over num_seeds + 1 entries ends with the total;
+    return;         // padded form: seeds past the device-side count are padding and pick nothing
   }
   const int64_t r = static_cast<int64_t>(seeds[i]);
   const int64_t deg = static_cast<int64_t>(indptr[r + 1]) - static_cast<int64_t>(indptr[r]);
@@ -80,9 +81,15 @@ __global__ __launch_bounds__(256) void sample_pick_kernel(const Idx* __restrict_
                                                           uint64_t rng_seed,
                                                           const Idx* __restrict__ out_indptr,
                                                           Idx* __restrict__ out_src,
-                                                          Idx* __restrict__ out_eids) {
+                                                          Idx* __restrict__ out_eids,
+                                                          const int64_t* __restrict__ num_valid = nullptr,
+                                                          const int64_t* __restrict__ rng_counter = nullptr) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i >= num_seeds) return;
+  if (num_valid != nullptr && i >= *num_valid) return;
+  // padded form: the call's stream position comes from device memory, so that a captured launch
+  // draws fresh neighbours on every replay
+  if (rng_counter != nullptr) rng_seed += static_cast<uint64_t>(*rng_counter) * 0x9E3779B97F4A7C15ull;
   const int64_t r = static_cast<int64_t>(seeds[i]);
   const int64_t start = static_cast<int64_t>(indptr[r]);
   const int64_t deg = static_cast<int64_t>(indptr[r + 1]) - start;
@@ -253,15 +260,43 @@ __global__ __launch_bounds__(256) void weighted_pick_kernel(
   }
 }
 
+// Padded form of the sampler's output (static shapes, no read-back; dgla_sample_neighbors_padded):
+// the picks fill [0, total) of a buffer of `cap` = num_seeds * fanout entries; the rest becomes the
+// edges of `sinks` extra SINK rows (rows num_seeds .. num_seeds + sinks - 1, equal shares; the last
+// out_indptr entry = cap) pointing at the real seeds in turn — nodes the block holds anyway — so that
+// every consumer sees a well-formed CSR of fixed size whose real rows are untouched.  Several sink
+// rows and spread-out targets instead of one row aimed at one node: a single 80 k-edge row made the
+// SpMM's fix-up walk 160 carry slots serially (38 us) and the backward COO kernel's atomics pile up
+// on one feature row (66 us).
+template <typename Idx>
+__global__ __launch_bounds__(256) void pad_tail_kernel(Idx* __restrict__ out_indptr, int64_t num_seeds,
+                                                       int64_t cap, int sinks, const Idx* __restrict__ seeds,
+                                                       const int64_t* __restrict__ num_valid,
+                                                       Idx* __restrict__ out_src, Idx* __restrict__ out_eids) {
+  const int64_t j = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int64_t total = static_cast<int64_t>(out_indptr[num_seeds]);
+  const int64_t pad = cap - total;
+  if (j >= 1 && j <= sinks) out_indptr[num_seeds + j] = static_cast<Idx>(total + pad * j / sinks);
+  if (j >= total && j < cap) {
+    int64_t nv = num_valid != nullptr ? *num_valid : num_seeds;
+    if (nv < 1) nv = 1;
+    out_src[j] = seeds[(j - total) % nv];
+    out_eids[j] = Idx(0);
+  }
+}
+
 // ---- to_block -------------------------------------------------------------------------------
 template <typename Idx>
 __global__ __launch_bounds__(256) void scatter_seed_ids_kernel(const Idx* __restrict__ seeds,
                                                                int64_t num_seeds,
                                                                int32_t* __restrict__ node_map,
-                                                               Idx* __restrict__ src_nodes) {
+                                                               Idx* __restrict__ src_nodes,
+                                                               const int64_t* __restrict__ num_valid = nullptr) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i >= num_seeds) return;
-  node_map[seeds[i]] = static_cast<int32_t>(i);
+  // padded form: seeds past the device-side count are padding (copies of some node id): they keep
+  // their row in the block but must not claim the node's local id
+  if (num_valid == nullptr || i < *num_valid) node_map[seeds[i]] = static_cast<int32_t>(i);
   src_nodes[i] = seeds[i];
 }
 
@@ -339,14 +374,15 @@ size_t sort_keys_temp_bytes(int64_t n) {
 
 template <typename Idx>
 int run_sample(const dgla_csr* csc, const void* seeds, int64_t num_seeds, int fanout, int replace,
-               uint64_t rng_seed, void* out_indptr, void* out_src, void* out_eids, char* ws, hipStream_t s) {
+               uint64_t rng_seed, void* out_indptr, void* out_src, void* out_eids, char* ws, hipStream_t s,
+               const int64_t* num_valid = nullptr, const int64_t* rng_counter = nullptr, int sinks = 0) {
   // counts -> exclusive scan in place of out_indptr (num_seeds + 1 entries)
   Idx* counts = reinterpret_cast<Idx*>(ws);
   void* temp = ws + align256(sizeof(Idx) * (num_seeds + 1));
   size_t temp_bytes = scan_temp_bytes<Idx>(num_seeds + 1);
   hipLaunchKernelGGL(sample_count_kernel<Idx>, dim3(grid1(num_seeds + 1)), dim3(256), 0, s,
                      static_cast<const Idx*>(csc->indptr), static_cast<const Idx*>(seeds), num_seeds,
-                     fanout, replace, counts);
+                     fanout, replace, counts, num_valid);
   DGLA_CHECK_HIP(rocprim::exclusive_scan(temp, temp_bytes, static_cast<const Idx*>(counts),
                                          static_cast<Idx*>(out_indptr), Idx(0),
                                          static_cast<size_t>(num_seeds + 1), rocprim::plus<Idx>(), s));
@@ -355,7 +391,13 @@ int run_sample(const dgla_csr* csc, const void* seeds, int64_t num_seeds, int fa
                        static_cast<const Idx*>(csc->indptr), static_cast<const Idx*>(csc->indices),
                        static_cast<const Idx*>(csc->data), static_cast<const Idx*>(seeds), num_seeds, fanout,
                        replace, rng_seed, static_cast<const Idx*>(out_indptr), static_cast<Idx*>(out_src),
-                       static_cast<Idx*>(out_eids));
+                       static_cast<Idx*>(out_eids), num_valid, rng_counter);
+  if (sinks > 0) {
+    const int64_t cap = num_seeds * fanout;
+    hipLaunchKernelGGL(pad_tail_kernel<Idx>, dim3(grid1(cap > sinks ? cap : sinks + 1)), dim3(256), 0, s,
+                       static_cast<Idx*>(out_indptr), num_seeds, cap, sinks, static_cast<const Idx*>(seeds),
+                       num_valid, static_cast<Idx*>(out_src), static_cast<Idx*>(out_eids));
+  }
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -388,7 +430,8 @@ int run_sample_weighted(const dgla_csr* csc, const void* prob, const void* seeds
 
 template <typename Idx>
 int run_to_block(const void* seeds, int64_t num_seeds, const void* src, int64_t nnz, int32_t* node_map,
-                 void* local_src, void* src_nodes, int64_t* num_src_out, char* ws, hipStream_t s) {
+                 void* local_src, void* src_nodes, int64_t* num_src_out, char* ws, hipStream_t s,
+                 const int64_t* num_valid = nullptr, int key_bits = 0) {
   const size_t a_sorted = align256(sizeof(Idx) * (nnz + 1));
   const size_t a_flag = align256(sizeof(int32_t) * (nnz + 1));
   Idx* sorted = reinterpret_cast<Idx*>(ws);
@@ -396,11 +439,13 @@ int run_to_block(const void* seeds, int64_t num_seeds, const void* src, int64_t 
   int32_t* rank = reinterpret_cast<int32_t*>(ws + a_sorted + a_flag);
   void* temp = ws + a_sorted + 2 * a_flag;
   hipLaunchKernelGGL(scatter_seed_ids_kernel<Idx>, dim3(grid1(num_seeds)), dim3(256), 0, s,
-                     static_cast<const Idx*>(seeds), num_seeds, node_map, static_cast<Idx*>(src_nodes));
+                     static_cast<const Idx*>(seeds), num_seeds, node_map, static_cast<Idx*>(src_nodes), num_valid);
   if (nnz > 0) {
     size_t tb = sort_keys_temp_bytes<Idx>(nnz);
+    // (ids are below the node count: sort only the bits they use — 3 passes instead of 8 for int64)
     DGLA_CHECK_HIP(rocprim::radix_sort_keys(temp, tb, static_cast<const Idx*>(src), sorted,
-                                            static_cast<size_t>(nnz), 0, sizeof(Idx) * 8, s));
+                                            static_cast<size_t>(nnz), 0,
+                                            key_bits > 0 ? key_bits : static_cast<int>(sizeof(Idx) * 8), s));
   }
   hipLaunchKernelGGL(flag_new_nodes_kernel<Idx>, dim3(grid1(nnz + 1)), dim3(256), 0, s, sorted, nnz, node_map,
                      flag);
@@ -509,6 +554,55 @@ int dgla_sample_neighbors_weighted(const dgla_csr* csc, const void* prob, dgla_d
                                                     out_indptr, out_src, out_eids, ws, s);
   if (owned) (void)hipFreeAsync(owned, s);
   return rc;
+}
+
+int dgla_sample_neighbors_padded(const dgla_csr* csc, const void* seeds, int64_t num_seeds,
+                                 const int64_t* num_valid, int fanout, int replace, uint64_t rng_seed,
+                                 const int64_t* rng_counter, int sink_rows, void* out_indptr, void* out_src,
+                                 void* out_eids, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (sink_rows < 1 || sink_rows > 4096) return sfail("sink_rows must be in [1, 4096]");
+  if (!csc || !csc->indptr) return sfail("csc is null");
+  if (csc->idtype_bits != 32 && csc->idtype_bits != 64) return sfail("idtype must be int32 or int64");
+  if (num_seeds < 1) return sfail("the padded form needs at least one seed slot");
+  if (fanout < 1 || fanout > kMaxFanout)
+    return sfail("the padded form needs 1 <= fanout <= " + std::to_string(kMaxFanout));
+  if (!out_indptr || !out_src || !out_eids || !seeds) return sfail("seeds / output arrays are null");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, out_indptr);
+  const size_t need = dgla_sample_neighbors_workspace_bytes(csc->idtype_bits, num_seeds);
+  if (!workspace || workspace_bytes < need)  // no allocation here: the call must be capturable
+    return sfail("sample_neighbors_padded: workspace of " + std::to_string(need) + " bytes required");
+  return csc->idtype_bits == 32
+             ? run_sample<int32_t>(csc, seeds, num_seeds, fanout, replace, rng_seed, out_indptr, out_src,
+                                   out_eids, static_cast<char*>(workspace), s, num_valid, rng_counter, sink_rows)
+             : run_sample<int64_t>(csc, seeds, num_seeds, fanout, replace, rng_seed, out_indptr, out_src,
+                                   out_eids, static_cast<char*>(workspace), s, num_valid, rng_counter, sink_rows);
+}
+
+int dgla_to_block_padded(int idtype_bits, const void* seeds, int64_t num_seeds, const int64_t* num_valid,
+                         const void* src, int64_t nnz, int64_t num_nodes, void* node_map, void* local_src,
+                         void* src_nodes, int64_t* num_src_out, void* workspace, size_t workspace_bytes,
+                         void* hip_stream) {
+  int key_bits = 0;
+  if (num_nodes > 0) {
+    key_bits = 1;
+    while ((int64_t(1) << key_bits) < num_nodes) ++key_bits;
+  }
+  if (idtype_bits != 32 && idtype_bits != 64) return sfail("idtype must be int32 or int64");
+  if (num_seeds < 1 || nnz < 0) return sfail("bad size");
+  if (!node_map || !src_nodes || !num_src_out || !seeds) return sfail("node_map / src_nodes / num_src_out / seeds is null");
+  if (nnz > 0 && (!src || !local_src)) return sfail("input arrays are null");
+  if (num_seeds + nnz > 0x7fffffffLL) return sfail("a block with more than 2^31-1 source nodes is not supported");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, node_map);
+  const size_t need = dgla_to_block_workspace_bytes(idtype_bits, nnz);
+  if (!workspace || workspace_bytes < need)
+    return sfail("to_block_padded: workspace of " + std::to_string(need) + " bytes required");
+  return idtype_bits == 32
+             ? run_to_block<int32_t>(seeds, num_seeds, src, nnz, static_cast<int32_t*>(node_map), local_src,
+                                     src_nodes, num_src_out, static_cast<char*>(workspace), s, num_valid, key_bits)
+             : run_to_block<int64_t>(seeds, num_seeds, src, nnz, static_cast<int32_t*>(node_map), local_src,
+                                     src_nodes, num_src_out, static_cast<char*>(workspace), s, num_valid, key_bits);
 }
 
 size_t dgla_to_block_workspace_bytes(int idtype_bits, int64_t nnz) {

@@ -72,6 +72,7 @@ struct SpmmParams {
   const uint8_t* rel;
   const void* const* xtab;
   const void* const* wtab;
+  int num_rel;
   // fix-up workspace, one slot per lane group: slot = wave * G + group — or, with `wave_slots`
   // (sum reducer, two lane groups per wave), ONE slot per wave: the two groups settle the row that
   // crosses between them in registers (see the end of spmm_csr_merge_kernel)
@@ -316,8 +317,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   __shared__ int s_cols[kWavesPerBlock][kWaveItems];
   __shared__ int s_rend[kWavesPerBlock][kWaveItems + 2];
   __shared__ Idx s_eid[UR ? kWavesPerBlock : 1][UR ? kWaveItems : 1];
-  __shared__ const DT* s_xb[(MULTI && UL) ? kWavesPerBlock : 1][(MULTI && UL) ? kWaveItems : 1];
-  __shared__ const DT* s_wb[(MULTI && UR) ? kWavesPerBlock : 1][(MULTI && UR) ? kWaveItems : 1];
+  // stacked form: one relation BYTE per staged edge + the relations' operand base pointers once per
+  // workgroup (an 8-byte pointer per edge had doubled the LDS footprint: 20 instead of 28 waves per CU)
+  __shared__ uint8_t s_rel[MULTI ? kWavesPerBlock : 1][MULTI ? kWaveItems : 1];
+  __shared__ const DT* s_tx[(MULTI && UL) ? 256 : 1];
+  __shared__ const DT* s_tw[(MULTI && UR) ? 256 : 1];
+  if constexpr (MULTI) {
+    for (int i = threadIdx.x; i < p.num_rel; i += 64 * kWavesPerBlock) {
+      if constexpr (UL) s_tx[i] = static_cast<const DT*>(p.xtab[i]);
+      if constexpr (UR) s_tw[i] = static_cast<const DT*>(p.wtab[i]);
+    }
+  }
 
   const int wib = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
@@ -382,8 +392,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
         if (it < nE) {
           s_cols[wib][it] = static_cast<int>(itemv[k]);
           if constexpr (UR) s_eid[wib][it] = has_eid ? eidv[k] : static_cast<Idx>(j0 + it);
-          if constexpr (MULTI && UL) s_xb[wib][it] = static_cast<const DT*>(p.xtab[relv[k]]);
-          if constexpr (MULTI && UR) s_wb[wib][it] = static_cast<const DT*>(p.wtab[relv[k]]);
+          if constexpr (MULTI) s_rel[wib][it] = relv[k];
         } else if (it < items) {
           s_rend[wib][it - nE + 1] = static_cast<int>(static_cast<int64_t>(itemv[k]) - j0);
         }
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
       if constexpr (UL) {
         const int64_t c = cols[ee];
         const DT* xb = X;
-        if constexpr (MULTI) xb = s_xb[wib][ee] + lo_off;
+        if constexpr (MULTI) xb = s_tx[s_rel[wib][ee]] + lo_off;
         bool done = false;
         if constexpr (!MULTI && VEC * sizeof(DT) == 16) {
           if (edge_layout) {  // (wave-uniform)
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
       if constexpr (UR) {
         const int64_t eid = static_cast<int64_t>(eidl[ee]);
         const DT* wb = Wt;
-        if constexpr (MULTI) wb = s_wb[wib][ee] + ro_off;
+        if constexpr (MULTI) wb = s_tw[s_rel[wib][ee]] + ro_off;
         b.w[u] = *reinterpret_cast<const WV*>(wb + eid * rhs_len);
       }
     }
@@ -1068,6 +1077,7 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.rel = static_cast<const uint8_t*>(L.rel);
   p.xtab = L.ufeat_tab;
   p.wtab = L.efeat_tab;
+  p.num_rel = L.num_rel;
   p.wave_slots = g.wave_slots;
   p.carry_row = reinterpret_cast<int64_t*>(ws + g.off_carry_row);
   p.carry_val = ws + g.off_carry_val;

@@ -160,3 +160,45 @@ class NeighborSampler:
             seeds = src_nodes
         self._calls += 1
         return seeds, output_nodes, blocks
+
+    def sample_blocks_padded(self, g, seed_nodes, num_valid=None):
+        """Static-shape ``sample_blocks``: no size is read back, every tensor has a shape that depends
+        only on ``len(seed_nodes)`` and the fanouts, so the call — and the training step around it —
+        can be captured in one hipGraph (``torch.cuda.graph``) and replayed.
+
+        ``seed_nodes`` has B slots of which the first ``num_valid`` (int64 device tensor, None = all)
+        are real.  Layer by layer (output side first) a block has D destination SLOTS + 64 SINK rows
+        and D + D * fanout source slots: real picks first, then the sink rows' edges (pointing at the
+        real destination nodes in turn); source slots past the block's ``num_src`` (device tensor) are
+        padding holding node 0.  Real rows are exactly what :meth:`sample_blocks` builds for the same
+        draw counter; padded / sink rows produce values nobody reads.  Returns ``(input_nodes,
+        num_input, output_nodes, blocks)``; ``blocks[i].num_src_valid`` / ``.num_dst_valid`` are the
+        device-side counts.  Each call advances a DEVICE-side draw counter (``self.counter``), so a
+        replayed graph samples fresh neighbours."""
+        if self.prob is not None:
+            raise _DGLError("sample_blocks_padded: weighted sampling has no padded form yet")
+        if min(self.fanouts) < 1:
+            raise _DGLError("sample_blocks_padded needs positive fanouts")
+        rel, csr, keep = _csc_of(g)
+        dev, idt = rel.device, rel.idtype
+        node_map = _node_map(g, dev)
+        if getattr(self, "counter", None) is None or self.counter.device != dev:
+            self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        seeds = seed_nodes.to(device=dev, dtype=idt).contiguous()
+        output_nodes, nv = seeds, num_valid
+        blocks = []
+        for layer, fanout in enumerate(reversed(self.fanouts)):
+            rng = (self.seed * 1000003) * 64 + layer
+            indptr, src, eids = _capi.sample_neighbors_padded(csr, seeds, nv, fanout, self.replace, rng,
+                                                              self.counter)
+            local, src_nodes, num_src = _capi.to_block_padded(seeds, nv, src, node_map, num_nodes=rel.num_src)
+            d = seeds.shape[0] + _capi.SINK_ROWS
+            blk = _make_block(indptr, local, src_nodes.shape[0], d, idt, dev)
+            blk.srcdata[NID] = src_nodes
+            blk.dstdata[NID] = src_nodes[:d]
+            blk.edata[EID] = eids
+            blk.num_dst_valid, blk.num_src_valid = nv, num_src
+            blocks.insert(0, blk)
+            seeds, nv = src_nodes, num_src
+        self.counter += 1
+        return seeds, nv, output_nodes, blocks

@@ -331,6 +331,37 @@ int dgla_to_block(int idtype_bits, const void* seeds, int64_t num_seeds, const v
                   void* node_map, void* local_src, void* src_nodes, int64_t* num_src_out,
                   void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* Padded (static-shape) forms of the two calls above: no size ever travels to the host, so a whole
+ * mini-batch step — sample, build blocks, gather, g-SpMM, backward, update — can be captured in ONE
+ * hipGraph and replayed (the reference synchronises after every sampling layer to size the next
+ * allocation: python/dgl/dataloading/neighbor_sampler.py sample_blocks -> cuda_to_block.cu).
+ * dgla_sample_neighbors_padded: `seeds` has num_seeds SLOTS of which the first *num_valid (device
+ *   memory; NULL = all) are real — the rest are padding (any valid node id) and pick nothing.
+ *   fanout > 0.  out_src / out_eids hold cap = num_seeds * fanout entries: the picks in
+ *   [0, out_indptr[num_seeds]), then the edges of `sink_rows` extra SINK rows (rows num_seeds ..
+ *   num_seeds + sink_rows - 1 in equal shares; out_indptr has num_seeds + 1 + sink_rows entries,
+ *   the last = cap) that point at the real seeds in turn.  A consumer sees a well-formed CSR with
+ *   num_seeds + sink_rows rows and cap edges whose real rows are exactly the unpadded call's; the
+ *   sink rows' results are garbage to be ignored.  The draw counter is
+ *   rng_seed + *rng_counter * 0x9E3779B97F4A7C15 (rng_counter: device int64 or NULL), so a
+ *   captured launch samples afresh whenever the caller bumps the counter on the device.
+ *   `workspace` (dgla_sample_neighbors_workspace_bytes) is REQUIRED: the call allocates nothing.
+ * dgla_to_block_padded: like dgla_to_block over all cap entries of the padded `src`; only the first
+ *   *num_valid seeds claim a local id (padding slots keep their row — the destination nodes of the
+ *   block are still its first num_seeds source nodes — but edges never resolve to them); new nodes
+ *   get ids from num_seeds upwards; entries of src_nodes past *num_src_out are left untouched
+ *   (pre-fill the buffer with a valid node id).  num_nodes > 0 (the graph's node count) lets the
+ *   sort look at the used key bits only.  `workspace` (dgla_to_block_workspace_bytes(nnz))
+ *   is required. */
+int dgla_sample_neighbors_padded(const dgla_csr* csc, const void* seeds, int64_t num_seeds,
+                                 const int64_t* num_valid, int fanout, int replace, uint64_t rng_seed,
+                                 const int64_t* rng_counter, int sink_rows, void* out_indptr, void* out_src,
+                                 void* out_eids, void* workspace, size_t workspace_bytes, void* hip_stream);
+int dgla_to_block_padded(int idtype_bits, const void* seeds, int64_t num_seeds, const int64_t* num_valid,
+                         const void* src, int64_t nnz, int64_t num_nodes, void* node_map, void* local_src,
+                         void* src_nodes, int64_t* num_src_out, void* workspace, size_t workspace_bytes,
+                         void* hip_stream);
+
 /* ---- k-way node-cut partitioner (host code) ---------------------------------
  * Stands where METIS stands in the reference: metis_partition_assignment
  * (python/dgl/partition.py:278-397 -> _CAPI_DGLMetisPartition_Hetero).  Multilevel
