@@ -217,9 +217,12 @@ def main():
         return time.perf_counter() - t0, loss
 
     results = {}
+    if args.features == "sharded" and world > 1:
+        # the per-batch feature pull is a collective with data-dependent split sizes: not capturable
+        if args.mode == "graph":
+            raise SystemExit("--mode graph needs --features replicated (the sharded pull is not capturable)")
+        args.mode = "eager"
     if args.mode in ("graph", "both"):  # (captured before any eager step has put autograd nodes on other streams)
-        if args.features == "sharded" and world > 1:
-            raise SystemExit("--mode graph keeps the feature pull outside the captured region: use --features replicated")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -36,6 +36,7 @@ struct SpmmParams {
   const Idx* indices;
   const Idx* eids;
   int64_t num_rows, nnz, num_waves;
+  int wave_items;       // merge items per wavefront: kWaveItems, or a smaller power of two on small graphs
   const int64_t* plan;  // [num_waves + 1] row coordinate of each unit boundary
   const void* ufeat;
   const void* efeat;
@@ -94,10 +95,10 @@ struct SpmmParams {
 template <typename Idx>
 __global__ void spmm_merge_plan_kernel(const Idx* __restrict__ indptr, int64_t num_rows,
                                        int64_t nnz, int64_t num_waves,
-                                       int64_t* __restrict__ plan) {
+                                       int64_t* __restrict__ plan, int wave_items) {
   const int64_t w = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (w > num_waves) return;
-  int64_t d = w * kWaveItems;
+  int64_t d = w * wave_items;
   const int64_t total = num_rows + nnz;
   if (d > total) d = total;
   int64_t lo = 0, hi = num_rows;
@@ -248,12 +249,12 @@ template <typename Idx>
 __global__ __launch_bounds__(64) void spmm_locality_probe_kernel(
     const Idx* __restrict__ indices, const int64_t* __restrict__ plan, int64_t num_rows,
     int64_t num_cols, int64_t nnz, int64_t num_waves, int64_t stride, int64_t window,
-    unsigned* __restrict__ meta) {
+    unsigned* __restrict__ meta, int wave_items) {
   const int64_t w = static_cast<int64_t>(blockIdx.x) * stride;
   if (w >= num_waves) return;
   const int64_t total = num_rows + nnz;
-  const int64_t d0 = w * kWaveItems;
-  int64_t d1 = d0 + kWaveItems;
+  const int64_t d0 = w * wave_items;
+  int64_t d1 = d0 + wave_items;
   if (d1 > total) d1 = total;
   const int64_t i0 = plan[w], i1 = plan[w + 1];
   const int64_t j0 = d0 - i0;
@@ -350,8 +351,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   int R = 0, nE = 0;
   if (w < p.num_waves) {
     const int64_t total = p.num_rows + p.nnz;
-    const int64_t d0 = w * kWaveItems;
-    int64_t d1 = d0 + kWaveItems;
+    const int64_t d0 = w * p.wave_items;
+    int64_t d1 = d0 + p.wave_items;
     if (d1 > total) d1 = total;
     i0 = p.plan[w];
     const int64_t i1 = p.plan[w + 1];
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
       uint8_t relv[MULTI ? kWaveItems / 64 : 1];
 #pragma unroll
       for (int k = 0; k < kWaveItems / 64; ++k) {
+        if (64 * k >= p.wave_items) break;  // (uniform) small graphs run shorter units
         int it = lane + 64 * k;
         if (it >= items) it = items - 1;
         // column ids are only needed to gather ufeat rows (and to name arg_u): copy_rhs /
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
       const int64_t first = static_cast<int64_t>(p.indptr[i0]) - j0;
 #pragma unroll
       for (int k = 0; k < kWaveItems / 64; ++k) {
+        if (64 * k >= p.wave_items) break;
         const int it = lane + 64 * k;
         if (it < nE) {
           s_cols[wib][it] = static_cast<int>(itemv[k]);
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   const int g = lane >> p.log2_lpe;
   const int lg = lane & (lpe - 1);
   const int G = 64 >> p.log2_lpe;
-  const int Tg = kWaveItems >> (6 - p.log2_lpe);
+  const int Tg = p.wave_items >> (6 - p.log2_lpe);
   const int F = p.out_len;
   const int k0 = (static_cast<int>(blockIdx.y) * 64 + lg) * VEC;  // first feature of this lane
   if (k0 >= F) return;
@@ -834,6 +837,7 @@ struct SpmmGeometry {
   int groups;    // lane groups per wave
   int chunks;    // grid.y: feature chunks of 64 * vec
   int wave_slots;  // one fix-up slot per wave (see SpmmParams::wave_slots)
+  int wave_items;  // merge items per wavefront (see below)
   int64_t num_waves, num_slots;
   size_t off_plan, off_meta, off_carry_row, off_carry_val, off_tail_val, off_carry_argu,
       off_carry_arge, off_tail_argu, off_tail_arge, total;
@@ -874,6 +878,9 @@ inline int spmm_tail_slices(const SpmmLaunch& L) {
 // 400 bytes = 52 MB, a fifth of the 256 MiB Infinity Cache.
 constexpr int64_t kSplitProbeWindowRows = 65536;
 
+// Below this many 512-item units a graph is "small": its units are shortened (spmm_geometry).
+constexpr int64_t kSmallGraphUnits = 4096;  // 16 per CU
+
 // Shape-only eligibility of the split-row layout: 16-byte lane accesses cover the row in one
 // chunk, the row is longer than one 128-byte line and not a whole number of lines.
 inline bool spmm_split_shape_ok(const SpmmLaunch& L, size_t elem_bytes) {
@@ -902,7 +909,14 @@ inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len
   g.log2_lpe = l2;
   g.groups = 64 >> l2;
   g.chunks = static_cast<int>((out_len + 64 * vec - 1) / (64 * vec));
-  g.num_waves = spmm_num_waves(num_rows, nnz);
+  // Unit size.  512 items keep 8 + 8 gathers in flight per lane over 32 batches — right when every
+  // CU holds many waves.  A graph with fewer than ~16 units per CU (a sampled mini-batch block: 180 k
+  // items = 350 units) leaves most CUs with ONE wave whose 32 dependent batches each wait a full
+  // memory round trip (66 us for a 20 us job): such graphs get shorter units, down to 64 items.
+  g.wave_items = kWaveItems;
+  while (g.wave_items > 64 && (num_rows + nnz + g.wave_items - 1) / g.wave_items < kSmallGraphUnits)
+    g.wave_items >>= 1;
+  g.num_waves = (num_rows + nnz + g.wave_items - 1) / g.wave_items;
   // sum reducer with two lane groups per wave (17 .. 32 lanes per feature row, e.g. F = 100 fp32):
   // one fix-up slot per wave instead of one per group
   g.wave_slots = (!with_arg && g.groups == 2 && g.chunks == 1) ? 1 : 0;
@@ -986,7 +1000,7 @@ inline int launch_plan(const SpmmLaunch& L, const SpmmGeometry& g) {
   const unsigned blocks = static_cast<unsigned>((n + threads - 1) / threads);
   hipLaunchKernelGGL(spmm_merge_plan_kernel<Idx>, dim3(blocks), dim3(threads), 0, L.stream,
                      static_cast<const Idx*>(L.csr.indptr), L.csr.num_rows, L.csr.nnz,
-                     g.num_waves, reinterpret_cast<int64_t*>(ws + g.off_plan));
+                     g.num_waves, reinterpret_cast<int64_t*>(ws + g.off_plan), g.wave_items);
   DGLA_CHECK_HIP(hipGetLastError());
   {
     // locality probe over ~4096 evenly spaced units, made with every plan (a later call on the
@@ -1000,7 +1014,7 @@ inline int launch_plan(const SpmmLaunch& L, const SpmmGeometry& g) {
       hipLaunchKernelGGL(spmm_locality_probe_kernel<Idx>, dim3(static_cast<unsigned>(probes)),
                        dim3(64), 0, L.stream, static_cast<const Idx*>(L.csr.indices),
                        reinterpret_cast<const int64_t*>(ws + g.off_plan), L.csr.num_rows,
-                       L.csr.num_cols, L.csr.nnz, g.num_waves, stride, window, meta);
+                       L.csr.num_cols, L.csr.nnz, g.num_waves, stride, window, meta, g.wave_items);
     DGLA_CHECK_HIP(hipGetLastError());
   }
   if (g.tail_slices > 0)
@@ -1042,6 +1056,7 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.num_rows = L.csr.num_rows;
   p.nnz = L.csr.nnz;
   p.num_waves = g.num_waves;
+  p.wave_items = g.wave_items;
   p.plan = reinterpret_cast<const int64_t*>(ws + g.off_plan);
   p.ufeat = L.ufeat;
   p.efeat = L.efeat;
