@@ -66,6 +66,11 @@ struct SpmmParams {
   int split_edge_lines;  // k - 1 (0: classic layout / none)
   int split_t16;         // t / 16
   int split_base16;      // (address of ufeat mod 128) / 16: where row 0 starts inside its line
+  // straddle layout (split_straddle_slack >= 0; see spmm_straddle_rows_kernel): rows of RB bytes at
+  // 8-byte alignment; a row that starts more than `slack` bytes into its line touches one line more
+  // than ceil(RB / 128) and is gathered from its line-aligned copy in `umain` (pitch split_main)
+  int split_straddle_slack;  // -1: not in use
+  int split_row_bytes, split_base_bytes;
   // column-sliced tail pass (spmm_tail.hip): the lanes that would gather the 16-byte row tails sit
   // this launch out — the last four output columns are produced by that pass
   int tail_pass;
@@ -236,6 +241,29 @@ __global__ __launch_bounds__(256) void spmm_split_edges_kernel(
       else
         s2[row[k] * t16 + (pp[k] - 8u)] = v[k];
     }
+  }
+}
+
+// Straddle layout (round 3; rows of RB bytes, RB a multiple of 8 but not of 16 — bf16 / fp16 F = 100:
+// 200 bytes — gathered with 8-byte lane accesses).  Such a row needs ceil(RB / 128) lines but touches
+// one more whenever it starts more than slack = ceil(RB / 128) * 128 - RB bytes into its line (200
+// bytes: slack 56, every second row, 2.5 requests per edge instead of 2 — and the kernel runs at
+// the request rate).  Only THOSE rows are copied, each to the line-aligned slot of its row index in
+// a side array of pitch ceil(RB / 128) * 128; the others are gathered in place.  One thread per
+// 8-byte piece of a copied row; rows that stay in place cost one index computation.
+typedef uint32_t piece8_t __attribute__((ext_vector_type(2)));
+template <int UNUSED>  // (a template so that the header can be included by several translation units)
+__global__ __launch_bounds__(256) void spmm_straddle_rows_kernel(
+    const piece8_t* __restrict__ x, piece8_t* __restrict__ side, int64_t num_rows, int row_pieces,
+    int pitch_pieces, int slack, unsigned base_bytes, unsigned magic, const unsigned* __restrict__ meta) {
+  if (!split_wanted(meta)) return;
+  const int64_t total = num_rows * row_pieces;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / row_pieces;
+    const int j = static_cast<int>(i - r * row_pieces);
+    const unsigned o = static_cast<unsigned>((static_cast<uint64_t>(r) * (row_pieces * 8) + base_bytes) & 127u);
+    if (o > static_cast<unsigned>(slack)) side[r * pitch_pieces + j] = __builtin_nontemporal_load(x + i);
   }
 }
 
@@ -460,7 +488,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   [[maybe_unused]] int e_piece_lo = 0, e_piece_hi = 0;  // side-array element offset when the piece is in the head / tail
   [[maybe_unused]] int e_pitch = 0;        // side-array pitch of this lane in elements
   [[maybe_unused]] const DT* e_side = nullptr;
-  if (p.split_main > 0 && split_wanted(p.split_meta)) {
+  bool straddle = false;  // (wave-uniform)
+  if (p.split_main > 0 && p.split_straddle_slack >= 0) {
+    if constexpr (UL && !MULTI && VEC * sizeof(DT) == 8) straddle = split_wanted(p.split_meta);
+  } else if (p.split_main > 0 && split_wanted(p.split_meta)) {
     if (p.split_edge_lines > 0) {
       if constexpr (UL && !MULTI && VEC * sizeof(DT) == 16) {
         edge_layout = true;
@@ -520,6 +551,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
             const int64_t pitch = in_place ? lhs_len : static_cast<int64_t>(e_pitch);
             const int add = in_place ? 0 : side_off;
             b.x[u] = *reinterpret_cast<const XV*>(base + (c * pitch + add));
+            done = true;
+          }
+        }
+        if constexpr (!MULTI && VEC * sizeof(DT) == 8) {
+          if (straddle) {
+            // row c starts o bytes into its line; past the slack it would touch one line too many:
+            // take its line-aligned copy
+            const unsigned o = static_cast<unsigned>((static_cast<uint64_t>(c) * static_cast<unsigned>(p.split_row_bytes) +
+                                                      static_cast<unsigned>(p.split_base_bytes)) & 127u);
+            const bool from_side = o > static_cast<unsigned>(p.split_straddle_slack);
+            const DT* base = from_side ? static_cast<const DT*>(p.umain) + lo_off : xb;
+            const int64_t pitch = from_side ? static_cast<int64_t>(p.split_main) : lhs_len;
+            b.x[u] = *reinterpret_cast<const XV*>(base + c * pitch);
             done = true;
           }
         }
@@ -845,6 +889,7 @@ struct SpmmGeometry {
   int split_main_bytes, split_tail_bytes;
   size_t off_split_main, off_split_tail;
   int split_edge_lines;  // > 0: edge layout (main = one 128-byte side line per row, k - 1 lines stay in place)
+  bool split_straddle;   // straddle layout (8-byte lanes): main = line-aligned row slots of pitch split_main_bytes
   // column-sliced tail pass (spmm_tail.hip).  tail_slices > 0: the workspace of this graph holds,
   // next to the merge plan and as long-lived as it, the slice-major virtual CSR (vptr / col) and
   // its merge plan; tail_pass: THIS call's shape uses it (partial sums + fix-up slots in the scratch)
@@ -887,7 +932,13 @@ inline bool spmm_split_shape_ok(const SpmmLaunch& L, size_t elem_bytes) {
   if (!(L.tune & kTuneSplit) || L.rel != nullptr || !op_uses_lhs(L.op)) return false;
   if (L.bcast == kBcGeneral || L.lhs_len != L.out_len) return false;
   const int64_t rb = L.lhs_len * static_cast<int64_t>(elem_bytes);
-  if (rb % 16 || rb > 1024 || rb < 128 || rb % 128 == 0) return false;
+  if (rb % 8 || rb > 1024 || rb < 128 || rb % 128 == 0) return false;
+  if (rb % 16) {
+    // 8-byte-aligned rows (straddle layout): only worth it when rows can straddle an extra line at
+    // all, i.e. the slack is smaller than the largest start offset (120)
+    const int64_t slack = (rb + 127) / 128 * 128 - rb;
+    if (slack >= 120 || (L.tune & kTuneSplitClassic)) return false;
+  }
   // pays off only when rows are re-read (average in-degree) and X does not fit the caches
   if (L.csr.nnz < 4 * L.csr.num_cols) return false;
   if (L.csr.num_cols * rb < (int64_t(64) << 20)) return false;
@@ -959,7 +1010,14 @@ inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len
   g.split_main_bytes = g.split_tail_bytes = 0;
   g.off_split_main = g.off_split_tail = off;
   g.split_edge_lines = 0;
-  if (split_rows > 0) {
+  g.split_straddle = false;
+  if (split_rows > 0 && split_row_bytes % 16 != 0) {  // 8-byte-aligned rows: the straddle layout
+    g.split_straddle = true;
+    g.split_main_bytes = static_cast<int>((split_row_bytes + 127) / 128 * 128);
+    g.off_split_main = g.off_split_tail = off;
+    off = align_up(off + static_cast<size_t>(split_rows) * g.split_main_bytes, 256);
+    g.off_split_tail = off;
+  } else if (split_rows > 0) {
     g.split_main_bytes = static_cast<int>(split_row_bytes / 128 * 128);
     g.split_tail_bytes = static_cast<int>(split_row_bytes - g.split_main_bytes);
     if (edge_layout && split_row_bytes >= 256) {  // rows of two or more whole lines: copy the ragged ends only
@@ -1005,12 +1063,16 @@ inline int launch_plan(const SpmmLaunch& L, const SpmmGeometry& g) {
   {
     // locality probe over ~4096 evenly spaced units, made with every plan (a later call on the
     // same workspace may be the first one whose shape is eligible for the split-row layout)
+    // ... unless NO shape could ever be eligible on this graph (spmm_split_shape_ok's graph-side
+    // conditions with the widest row, 1024 bytes): a sampled mini-batch block pays 35 us for the
+    // probe's few thousand same-address atomics and can never use their answer
+    const bool split_possible = L.csr.nnz >= 4 * L.csr.num_cols && L.csr.num_cols * 1024 >= (int64_t(64) << 20);
     unsigned* meta = reinterpret_cast<unsigned*>(ws + g.off_meta);
-    DGLA_CHECK_HIP(hipMemsetAsync(meta, 0, 8, L.stream));
+    if (split_possible) DGLA_CHECK_HIP(hipMemsetAsync(meta, 0, 8, L.stream));
     const int64_t stride = std::max<int64_t>(1, g.num_waves / 4096);
     const int64_t probes = (g.num_waves + stride - 1) / stride;
     const int64_t window = kSplitProbeWindowRows;
-    if (L.csr.indices != nullptr && L.csr.nnz > 0)
+    if (split_possible && L.csr.indices != nullptr && L.csr.nnz > 0)
       hipLaunchKernelGGL(spmm_locality_probe_kernel<Idx>, dim3(static_cast<unsigned>(probes)),
                        dim3(64), 0, L.stream, static_cast<const Idx*>(L.csr.indices),
                        reinterpret_cast<const int64_t*>(ws + g.off_plan), L.csr.num_rows,
@@ -1077,7 +1139,17 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.split_meta = nullptr;
   p.split_main = p.split_tail = 0;
   p.split_edge_lines = p.split_t16 = p.split_base16 = 0;
-  if (g.split_main_bytes > 0) {
+  p.split_straddle_slack = -1;
+  p.split_row_bytes = p.split_base_bytes = 0;
+  if (g.split_straddle) {
+    p.umain = ws + g.off_split_main;
+    if (!(L.tune & kTuneSplitForce) && !L.split_keep)
+      p.split_meta = reinterpret_cast<const unsigned*>(ws + g.off_meta);
+    p.split_main = g.split_main_bytes / static_cast<int>(sizeof(DT));
+    p.split_row_bytes = static_cast<int>(L.lhs_len * static_cast<int64_t>(sizeof(DT)));
+    p.split_straddle_slack = g.split_main_bytes - p.split_row_bytes;
+    p.split_base_bytes = static_cast<int>(reinterpret_cast<uintptr_t>(L.ufeat) & 127u);
+  } else if (g.split_main_bytes > 0) {
     p.umain = ws + g.off_split_main;
     p.utail = ws + g.off_split_tail;
     if (!(L.tune & kTuneSplitForce) && !L.split_keep)
@@ -1112,7 +1184,17 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
   const SpmmParams<Idx> p = make_params<Idx, DT>(L, g);
   const unsigned blocks =
       static_cast<unsigned>((g.num_waves + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (g.split_edge_lines > 0 && !L.split_valid) {
+  if (g.split_straddle && !L.split_valid) {
+    char* ws = static_cast<char*>(L.workspace);
+    const int row_pieces = p.split_row_bytes / 8;
+    const int64_t total = L.csr.num_cols * row_pieces;
+    const unsigned sblocks = static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, int64_t(1) << 20));
+    hipLaunchKernelGGL(spmm_straddle_rows_kernel<0>, dim3(sblocks), dim3(256), 0, L.stream,
+                       static_cast<const piece8_t*>(L.ufeat), reinterpret_cast<piece8_t*>(ws + g.off_split_main),
+                       L.csr.num_cols, row_pieces, g.split_main_bytes / 8, p.split_straddle_slack,
+                       static_cast<unsigned>(p.split_base_bytes), 0u, p.split_meta);
+    DGLA_CHECK_HIP(hipGetLastError());
+  } else if (g.split_edge_lines > 0 && !L.split_valid) {
     char* ws = static_cast<char*>(L.workspace);
     const int t16 = g.split_tail_bytes / 16, side = 8 + t16;
     const int row_pieces = static_cast<int>(L.lhs_len * static_cast<int64_t>(sizeof(DT)) / 16);
@@ -1289,7 +1371,9 @@ inline int launch_spmm_csr_typed(const SpmmLaunch& L) {
   const bool tail_shape = std::is_same<DT, float>::value && L.op == kCopyLhs && L.red == kSum;
   SpmmGeometry g = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
                                  L.csr.idbits / 8, L.red != kSum, 0, 0, false, tail_slices);
-  if (vec * sizeof(DT) == 16 && g.chunks == 1 && spmm_split_shape_ok(L, sizeof(DT))) {
+  const int64_t rb_l = L.lhs_len * static_cast<int64_t>(sizeof(DT));
+  const bool vec_ok = rb_l % 16 == 0 ? vec * sizeof(DT) == 16 : vec * sizeof(DT) == 8;
+  if (vec_ok && g.chunks == 1 && spmm_split_shape_ok(L, sizeof(DT))) {
     // same carve-up plus the two re-laid-out copies of X; used only if the caller's workspace
     // has room (dgla_spmm_csr_workspace_bytes accounts for it), else the plain layout runs
     const SpmmGeometry gs = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),

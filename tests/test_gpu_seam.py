@@ -600,7 +600,10 @@ def test_edge_softmax_geometries(dev, n_dst, n_edges, dim, idtype, dtype, merge)
                                          (50, torch.float64),
                                          # edge layout of the split rows: 128 k + t bytes, k >= 2
                                          (68, torch.float32), (76, torch.float32), (132, torch.float32),
-                                         (252, torch.float32), (136, torch.bfloat16), (38, torch.float64)])
+                                         (252, torch.float32), (136, torch.bfloat16), (38, torch.float64),
+                                         # straddle layout: 8-byte-aligned rows gathered with 8-byte lanes
+                                         (50, torch.float32), (25, torch.float64), (84, torch.bfloat16),
+                                         (300, torch.float16)])
 @pytest.mark.parametrize("op,reduce", [("copy_lhs", "sum"), ("mul", "sum"), ("copy_lhs", "max")])
 def test_spmm_tuning_bits_do_not_change_results(dev, feat, tdtype, op, reduce):
     from dgl_amd import _capi
