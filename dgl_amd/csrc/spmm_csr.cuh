@@ -824,8 +824,19 @@ __global__ __launch_bounds__(64) void spmm_csr_fixup_kernel(const SpmmParams<Idx
     const int64_t row = p.carry_row[s];
     if (row < 0) continue;
     if (s > 0 && p.carry_row[s - 1] == row) continue;
+    // end of the run: 64 slots per step (a row of a few-segments reduction, or a hub row, spans
+    // hundreds of slots: walking them one dependent load at a time was most of this kernel's time)
     int64_t s2 = s + 1;
-    while (s2 < num_slots && p.carry_row[s2] == row) ++s2;
+    for (;;) {
+      const int64_t q = s2 + threadIdx.x;
+      const bool same = q < num_slots && p.carry_row[q] == row;
+      const uint64_t m = __ballot(same);
+      if (m != ~uint64_t(0)) {
+        s2 += __builtin_ctzll(~m);
+        break;
+      }
+      s2 += 64;
+    }
     // slot s2 holds the tail (the group in which the row ends); it always exists because a
     // row with a carry has its row-end item in a later slot.
     const int F = p.out_len;
@@ -853,7 +864,16 @@ __global__ __launch_bounds__(64) void spmm_csr_fixup_kernel(const SpmmParams<Idx
           }
         }
       };
-      for (int64_t q = s + 1; q < s2; ++q) combine(cv[q * F + k], p.carry_argu, p.carry_arge, q * F + k);
+      // same order as ever, but eight carries are in flight at a time
+      int64_t q = s + 1;
+      for (; q + 8 <= s2; q += 8) {
+        A v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = cv[(q + u) * F + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) combine(v[u], p.carry_argu, p.carry_arge, (q + u) * F + k);
+      }
+      for (; q < s2; ++q) combine(cv[q * F + k], p.carry_argu, p.carry_arge, q * F + k);
       combine(tv[s2 * F + k], p.tail_argu, p.tail_arge, s2 * F + k);
       const int64_t o = row * F + k;
       if (RED == kSum && p.mean) {
