@@ -165,6 +165,35 @@ def cpu_baseline(g, x, budget_s=20.0):
             one_pass(cores)
     except Exception as ex:  # pragma: no cover
         blocked = {"error": repr(ex)}
+    # (iii) independent sanity lines: the same sum through scipy's CSR product (one
+    # thread) and torch.sparse.mm (torch's CPU threads) on a BOUNDED sample — the first eighth of
+    # the rows; both are checked against the reference's rows before their rate is reported
+    sanity = {}
+    try:
+        import scipy.sparse as sp
+
+        rows = (indptr.shape[0] - 1) // 8
+        ip8 = indptr[: rows + 1]
+        nz8 = int(ip8[-1])
+        a = sp.csr_matrix((np.ones(nz8, dtype=xh.dtype), indices[:nz8], ip8), shape=(rows, xh.shape[0]))
+        t0 = time.perf_counter()
+        y = a @ xh
+        dt = time.perf_counter() - t0
+        ok = bool(np.allclose(y, out[:rows], rtol=1e-4, atol=1e-4)) if use_ref else None
+        sanity["scipy_csr_matmul"] = {"value": nz8 / dt, "unit": "edges/s", "cores": 1, "agrees_with_reference": ok,
+                                      "sample": "first %d rows (%d edges)" % (rows, nz8)}
+        ta = torch.sparse_csr_tensor(torch.from_numpy(ip8.astype(np.int64)), torch.from_numpy(indices[:nz8].astype(np.int64)),
+                                     torch.ones(nz8), size=(rows, xh.shape[0]))
+        xt = torch.from_numpy(xh)
+        torch.sparse.mm(ta, xt[:, :4].contiguous())  # warm-up
+        t0 = time.perf_counter()
+        yt = torch.sparse.mm(ta, xt)
+        dt = time.perf_counter() - t0
+        ok = bool(np.allclose(yt.numpy(), out[:rows], rtol=1e-4, atol=1e-4)) if use_ref else None
+        sanity["torch_sparse_mm"] = {"value": nz8 / dt, "unit": "edges/s", "cores": torch.get_num_threads(),
+                                     "agrees_with_reference": ok, "sample": "first %d rows (%d edges)" % (rows, nz8)}
+    except Exception as ex:  # pragma: no cover
+        sanity["error"] = repr(ex)
     cpu_model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -185,6 +214,7 @@ def cpu_baseline(g, x, budget_s=20.0):
         "sample": "full workload (%d edges, F=%d), best of %d passes (thread-count sweep over "
                   "%d hardware threads) after 1 warm-up; %s" % (g["nnz"], x.shape[1], reps, ncpu, what),
         "libxsmm_style_blocked": blocked,
+        "sanity": sanity,
     }, out
 
 
