@@ -22,5 +22,6 @@ from .segment import scatter_add, segment_reduce, segment_softmax  # noqa: E402,
 from .sparse_kernels import release_static, set_auto_edge_operand, static_features  # noqa: E402,F401
 
 from .edge_order import set_edge_order_handoff  # noqa: E402,F401
+from .capture import CapturedStep  # noqa: E402,F401
 
 DGLError = DGLAMDError

@@ -152,15 +152,8 @@ def test_padded_blocks_aggregate_like_a_dense_reference_and_replay_in_a_hipgraph
     eager_first = out_buf.clone()
 
     # capture, then replay at the same counter value: same draws, same numbers
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        body()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        body()
+    step = dgl.CapturedStep(lambda s: body() and None, {"s": seeds}, warmup=1)   # `s` IS the static seed buffer
+    graph = step.graph
     sampler.counter.zero_()
     graph.replay()
     torch.cuda.synchronize()
@@ -170,10 +163,9 @@ def test_padded_blocks_aggregate_like_a_dense_reference_and_replay_in_a_hipgraph
     torch.cuda.synchronize()
     assert int(sampler.counter) == 2
     assert not torch.equal(picks_buf, first_picks)
-    # a new seed batch through the same graph
-    seeds.copy_(torch.randperm(n, device=dev, generator=gen)[:batch])
+    # a new seed batch through the same graph (CapturedStep copies it into the static buffer)
     sampler.counter.fill_(40)
-    graph.replay()
+    step(s=torch.randperm(n, device=dev, generator=gen)[:batch])
     torch.cuda.synchronize()
     replayed = out_buf.clone()
     sampler.counter.fill_(40)
