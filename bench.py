@@ -308,9 +308,25 @@ def multi_gpu(args, dev, n, e, f, rank, world, dist, spmm=None):
     t0 = time.perf_counter()
     part = torch.empty(n, dtype=torch.int64, device=dev)
     stats = {}
+    # the assignment depends only on (graph generator inputs, k): kept on disk between runs of this
+    # box (a SCALE series re-runs the same k only when repeated, but repeated runs are the common case
+    # while tuning); a stale or unreadable file is ignored
+    import tempfile
+
+    cache = os.path.join(tempfile.gettempdir(), "dgl_amd_partition_v3_%s_n%d_e%d_k%d_%s.pt" % (
+        args.variant, n, e, world, args.partitioner))
     if rank == 0:
         done = None
-        if args.partitioner == "kway":
+        if args.partitioner == "kway" and os.path.exists(cache):
+            try:
+                saved = torch.load(cache)
+                if saved["part"].shape[0] == n:
+                    part.copy_(saved["part"])
+                    stats = dict(saved["stats"], cached=True)
+                    done = (None, stats)
+            except Exception:  # noqa: BLE001
+                done = None
+        if args.partitioner == "kway" and done is None:
             # the partitioner is host code (minutes on a graph of this size): run it in a daemon
             # thread with a time budget so that a slow host cannot stall the other ranks past the
             # collective time-out; past the budget the run falls back to contiguous ranges and says so
@@ -335,6 +351,10 @@ def multi_gpu(args, dev, n, e, f, rank, world, dist, spmm=None):
             if done is not None:
                 part.copy_(done[0])
                 stats = done[1]
+                try:
+                    torch.save({"part": done[0].cpu(), "stats": stats}, cache)
+                except Exception:  # noqa: BLE001
+                    pass
             else:
                 stats = {"fallback": "k-way partitioner exceeded %.0f s: contiguous ranges used" % budget}
         if done is None:
