@@ -391,7 +391,7 @@ SINK_ROWS = 64  # sink rows of a padded block (dgla_sample_neighbors_padded)
 
 
 def sample_neighbors_padded(csr, seeds, num_valid, fanout, replace=False, rng_seed=0, rng_counter=None,
-                            sink_rows=SINK_ROWS):
+                            sink_rows=SINK_ROWS, prob=None):
     """Static-shape form of :func:`sample_neighbors` (dgla_sample_neighbors_padded): nothing is read
     back.  ``seeds`` has ``n`` slots of which the first ``num_valid`` (int64 device tensor of one
     element, or None = all) are real.  Returns ``(indptr[n + 1 + sink_rows], src[n * fanout],
@@ -407,8 +407,13 @@ def sample_neighbors_padded(csr, seeds, num_valid, fanout, replace=False, rng_se
     eids = torch.empty(cap, dtype=dt, device=dev)
     ws = torch.empty(max(1, LIB.dgla_sample_neighbors_workspace_bytes(_idbits(seeds), n)), dtype=torch.uint8,
                      device=dev)
+    if prob is not None:
+        _require_gpu(prob)
+        if prob.dtype not in (torch.float32, torch.float64) or prob.dim() != 1 or not prob.is_contiguous():
+            raise _lib.DGLAMDError("prob must be a contiguous 1-D float32 / float64 tensor")
     check_call(LIB.dgla_sample_neighbors_padded(
-        ctypes.byref(csr), seeds.data_ptr(), n, _ptr(num_valid), int(fanout), 1 if replace else 0,
+        ctypes.byref(csr), _ptr(prob), _DTYPES[prob.dtype] if prob is not None else 0, seeds.data_ptr(), n,
+        _ptr(num_valid), int(fanout), 1 if replace else 0,
         int(rng_seed) & 0xFFFFFFFFFFFFFFFF, _ptr(rng_counter), int(sink_rows), indptr.data_ptr(), src.data_ptr(),
         eids.data_ptr(),
         ws.data_ptr(), ws.numel(), _stream(seeds)))

@@ -145,9 +145,9 @@ LIB.dgla_to_block.restype = c_int
 LIB.dgla_to_block.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_size_t, c_void_p]
 LIB.dgla_sample_neighbors_padded.restype = c_int
-LIB.dgla_sample_neighbors_padded.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, ctypes.c_uint64,
-                                             c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                                             c_void_p]
+LIB.dgla_sample_neighbors_padded.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, c_int,
+                                             ctypes.c_uint64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_size_t, c_void_p]
 LIB.dgla_to_block_padded.restype = c_int
 LIB.dgla_to_block_padded.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]

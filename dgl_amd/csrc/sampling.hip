@@ -171,11 +171,12 @@ __global__ __launch_bounds__(256) void weighted_count_kernel(const Idx* __restri
                                                              const F* __restrict__ prob,
                                                              const Idx* __restrict__ seeds,
                                                              int64_t num_seeds, int fanout, int replace,
-                                                             Idx* __restrict__ counts) {
+                                                             Idx* __restrict__ counts,
+                                                             const int64_t* __restrict__ num_valid = nullptr) {
   const int64_t i = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (i > num_seeds) return;
-  if (i == num_seeds) {
+  if (i == num_seeds || (num_valid != nullptr && i >= *num_valid)) {  // (padding slots pick nothing)
     if (lane == 0) counts[i] = 0;
     return;
   }
@@ -198,10 +199,11 @@ __global__ __launch_bounds__(256) void weighted_pick_kernel(
     const Idx* __restrict__ indptr, const Idx* __restrict__ indices, const Idx* __restrict__ eids,
     const F* __restrict__ prob, const Idx* __restrict__ seeds, int64_t num_seeds, int fanout,
     int replace, uint64_t rng_seed, const Idx* __restrict__ out_indptr, Idx* __restrict__ out_src,
-    Idx* __restrict__ out_eids) {
+    Idx* __restrict__ out_eids, const int64_t* __restrict__ rng_counter = nullptr) {
   const int64_t i = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (i >= num_seeds) return;
+  if (rng_counter != nullptr) rng_seed += static_cast<uint64_t>(*rng_counter) * 0x9E3779B97F4A7C15ull;
   const int64_t r = static_cast<int64_t>(seeds[i]);
   const int64_t start = static_cast<int64_t>(indptr[r]);
   const int64_t deg = static_cast<int64_t>(indptr[r + 1]) - start;
@@ -424,7 +426,8 @@ int run_sample(const dgla_csr* csc, const void* seeds, int64_t num_seeds, int fa
 template <typename Idx, typename F>
 int run_sample_weighted(const dgla_csr* csc, const void* prob, const void* seeds, int64_t num_seeds,
                         int fanout, int replace, uint64_t rng_seed, void* out_indptr, void* out_src,
-                        void* out_eids, char* ws, hipStream_t s) {
+                        void* out_eids, char* ws, hipStream_t s, const int64_t* num_valid = nullptr,
+                        const int64_t* rng_counter = nullptr, int sinks = 0) {
   Idx* counts = reinterpret_cast<Idx*>(ws);
   void* temp = ws + align256(sizeof(Idx) * (num_seeds + 1));
   size_t temp_bytes = scan_temp_bytes<Idx>(num_seeds + 1);
@@ -432,7 +435,7 @@ int run_sample_weighted(const dgla_csr* csc, const void* prob, const void* seeds
   hipLaunchKernelGGL((weighted_count_kernel<Idx, F>), dim3(blocks), dim3(256), 0, s,
                      static_cast<const Idx*>(csc->indptr), static_cast<const Idx*>(csc->data),
                      static_cast<const F*>(prob), static_cast<const Idx*>(seeds), num_seeds, fanout, replace,
-                     counts);
+                     counts, num_valid);
   DGLA_CHECK_HIP(rocprim::exclusive_scan(temp, temp_bytes, static_cast<const Idx*>(counts),
                                          static_cast<Idx*>(out_indptr), Idx(0),
                                          static_cast<size_t>(num_seeds + 1), rocprim::plus<Idx>(), s));
@@ -442,7 +445,13 @@ int run_sample_weighted(const dgla_csr* csc, const void* prob, const void* seeds
                        static_cast<const Idx*>(csc->indices), static_cast<const Idx*>(csc->data),
                        static_cast<const F*>(prob), static_cast<const Idx*>(seeds), num_seeds, fanout, replace,
                        rng_seed, static_cast<const Idx*>(out_indptr), static_cast<Idx*>(out_src),
-                       static_cast<Idx*>(out_eids));
+                       static_cast<Idx*>(out_eids), rng_counter);
+  if (sinks > 0) {
+    const int64_t cap = num_seeds * fanout;
+    hipLaunchKernelGGL(pad_tail_kernel<Idx>, dim3(grid1(cap > sinks ? cap : sinks + 1)), dim3(256), 0, s,
+                       static_cast<Idx*>(out_indptr), num_seeds, cap, sinks, static_cast<const Idx*>(seeds),
+                       num_valid, static_cast<Idx*>(out_src), static_cast<Idx*>(out_eids));
+  }
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -575,11 +584,13 @@ int dgla_sample_neighbors_weighted(const dgla_csr* csc, const void* prob, dgla_d
   return rc;
 }
 
-int dgla_sample_neighbors_padded(const dgla_csr* csc, const void* seeds, int64_t num_seeds,
-                                 const int64_t* num_valid, int fanout, int replace, uint64_t rng_seed,
-                                 const int64_t* rng_counter, int sink_rows, void* out_indptr, void* out_src,
-                                 void* out_eids, void* workspace, size_t workspace_bytes, void* hip_stream) {
+int dgla_sample_neighbors_padded(const dgla_csr* csc, const void* prob, dgla_dtype prob_dtype, const void* seeds,
+                                 int64_t num_seeds, const int64_t* num_valid, int fanout, int replace,
+                                 uint64_t rng_seed, const int64_t* rng_counter, int sink_rows, void* out_indptr,
+                                 void* out_src, void* out_eids, void* workspace, size_t workspace_bytes,
+                                 void* hip_stream) {
   if (sink_rows < 1 || sink_rows > 4096) return sfail("sink_rows must be in [1, 4096]");
+  if (prob && prob_dtype != DGLA_F32 && prob_dtype != DGLA_F64) return sfail("probabilities must be float32 or float64");
   if (!csc || !csc->indptr) return sfail("csc is null");
   if (csc->idtype_bits != 32 && csc->idtype_bits != 64) return sfail("idtype must be int32 or int64");
   if (num_seeds < 1) return sfail("the padded form needs at least one seed slot");
@@ -591,11 +602,25 @@ int dgla_sample_neighbors_padded(const dgla_csr* csc, const void* seeds, int64_t
   const size_t need = dgla_sample_neighbors_workspace_bytes(csc->idtype_bits, num_seeds);
   if (!workspace || workspace_bytes < need)  // no allocation here: the call must be capturable
     return sfail("sample_neighbors_padded: workspace of " + std::to_string(need) + " bytes required");
+  char* ws = static_cast<char*>(workspace);
+  if (prob) {
+    if (csc->idtype_bits == 32)
+      return prob_dtype == DGLA_F32
+                 ? run_sample_weighted<int32_t, float>(csc, prob, seeds, num_seeds, fanout, replace, rng_seed, out_indptr,
+                                                       out_src, out_eids, ws, s, num_valid, rng_counter, sink_rows)
+                 : run_sample_weighted<int32_t, double>(csc, prob, seeds, num_seeds, fanout, replace, rng_seed, out_indptr,
+                                                        out_src, out_eids, ws, s, num_valid, rng_counter, sink_rows);
+    return prob_dtype == DGLA_F32
+               ? run_sample_weighted<int64_t, float>(csc, prob, seeds, num_seeds, fanout, replace, rng_seed, out_indptr,
+                                                     out_src, out_eids, ws, s, num_valid, rng_counter, sink_rows)
+               : run_sample_weighted<int64_t, double>(csc, prob, seeds, num_seeds, fanout, replace, rng_seed, out_indptr,
+                                                      out_src, out_eids, ws, s, num_valid, rng_counter, sink_rows);
+  }
   return csc->idtype_bits == 32
              ? run_sample<int32_t>(csc, seeds, num_seeds, fanout, replace, rng_seed, out_indptr, out_src,
-                                   out_eids, static_cast<char*>(workspace), s, num_valid, rng_counter, sink_rows)
+                                   out_eids, ws, s, num_valid, rng_counter, sink_rows)
              : run_sample<int64_t>(csc, seeds, num_seeds, fanout, replace, rng_seed, out_indptr, out_src,
-                                   out_eids, static_cast<char*>(workspace), s, num_valid, rng_counter, sink_rows);
+                                   out_eids, ws, s, num_valid, rng_counter, sink_rows);
 }
 
 int dgla_to_block_padded(int idtype_bits, const void* seeds, int64_t num_seeds, const int64_t* num_valid,

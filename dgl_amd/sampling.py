@@ -175,8 +175,6 @@ class NeighborSampler:
         num_input, output_nodes, blocks)``; ``blocks[i].num_src_valid`` / ``.num_dst_valid`` are the
         device-side counts.  Each call advances a DEVICE-side draw counter (``self.counter``), so a
         replayed graph samples fresh neighbours."""
-        if self.prob is not None:
-            raise _DGLError("sample_blocks_padded: weighted sampling has no padded form yet")
         if min(self.fanouts) < 1:
             raise _DGLError("sample_blocks_padded needs positive fanouts")
         rel, csr, keep = _csc_of(g)
@@ -186,11 +184,19 @@ class NeighborSampler:
             self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         seeds = seed_nodes.to(device=dev, dtype=idt).contiguous()
         output_nodes, nv = seeds, num_valid
+        p = None
+        if self.prob is not None:
+            p = g.edata[self.prob] if isinstance(self.prob, str) else self.prob
+            if p.dim() == 0 or p.shape[0] != rel.num_edges or p.numel() != rel.num_edges:
+                raise _DGLError("NeighborSampler: prob must hold one value per edge of the graph "
+                                "(%d), got shape %s" % (rel.num_edges, tuple(p.shape)))
+            p = p.to(dev)
+            p = (p if p.dtype in (torch.float32, torch.float64) else p.float()).contiguous().reshape(-1)
         blocks = []
         for layer, fanout in enumerate(reversed(self.fanouts)):
             rng = (self.seed * 1000003) * 64 + layer
             indptr, src, eids = _capi.sample_neighbors_padded(csr, seeds, nv, fanout, self.replace, rng,
-                                                              self.counter)
+                                                              self.counter, prob=p)
             local, src_nodes, num_src = _capi.to_block_padded(seeds, nv, src, node_map, num_nodes=rel.num_src)
             d = seeds.shape[0] + _capi.SINK_ROWS
             blk = _make_block(indptr, local, src_nodes.shape[0], d, idt, dev)

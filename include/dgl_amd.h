@@ -345,6 +345,7 @@ int dgla_to_block(int idtype_bits, const void* seeds, int64_t num_seeds, const v
  *   sink rows' results are garbage to be ignored.  The draw counter is
  *   rng_seed + *rng_counter * 0x9E3779B97F4A7C15 (rng_counter: device int64 or NULL), so a
  *   captured launch samples afresh whenever the caller bumps the counter on the device.
+ *   `prob` != NULL: weighted picks as dgla_sample_neighbors_weighted (float32 / float64 per EDGE ID).
  *   `workspace` (dgla_sample_neighbors_workspace_bytes) is REQUIRED: the call allocates nothing.
  * dgla_to_block_padded: like dgla_to_block over all cap entries of the padded `src`; only the first
  *   *num_valid seeds claim a local id (padding slots keep their row — the destination nodes of the
@@ -353,10 +354,11 @@ int dgla_to_block(int idtype_bits, const void* seeds, int64_t num_seeds, const v
  *   (pre-fill the buffer with a valid node id).  num_nodes > 0 (the graph's node count) lets the
  *   sort look at the used key bits only.  `workspace` (dgla_to_block_workspace_bytes(nnz))
  *   is required. */
-int dgla_sample_neighbors_padded(const dgla_csr* csc, const void* seeds, int64_t num_seeds,
-                                 const int64_t* num_valid, int fanout, int replace, uint64_t rng_seed,
-                                 const int64_t* rng_counter, int sink_rows, void* out_indptr, void* out_src,
-                                 void* out_eids, void* workspace, size_t workspace_bytes, void* hip_stream);
+int dgla_sample_neighbors_padded(const dgla_csr* csc, const void* prob, dgla_dtype prob_dtype, const void* seeds,
+                                 int64_t num_seeds, const int64_t* num_valid, int fanout, int replace,
+                                 uint64_t rng_seed, const int64_t* rng_counter, int sink_rows, void* out_indptr,
+                                 void* out_src, void* out_eids, void* workspace, size_t workspace_bytes,
+                                 void* hip_stream);
 int dgla_to_block_padded(int idtype_bits, const void* seeds, int64_t num_seeds, const int64_t* num_valid,
                          const void* src, int64_t nnz, int64_t num_nodes, void* node_map, void* local_src,
                          void* src_nodes, int64_t* num_src_out, void* workspace, size_t workspace_bytes,

@@ -59,6 +59,33 @@ def test_padded_sampler_equals_the_unpadded_one_on_real_rows(dev, idtype, replac
 
 
 @pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("replace", [False, True])
+def test_padded_weighted_sampler_equals_the_unpadded_one_on_real_rows(dev, idtype, replace):
+    from dgl_amd import _capi
+
+    n, n_slots, n_valid, fanout = 5000, 90, 41, 6
+    g, gs = _graph(dev, idtype)
+    csr = _capi.make_csr(gs["indptr"], gs["indices"], None, n)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    prob = torch.rand(gs["indices"].shape[0], device=dev, generator=gen)
+    prob[::7] = 0                                           # edges that may never be picked
+    seeds = torch.randperm(n, device=dev, generator=gen)[:n_slots].to(idtype)
+    seeds[n_valid:] = 0
+    nv = torch.tensor([n_valid], dtype=torch.int64, device=dev)
+    ctr = torch.tensor([3], dtype=torch.int64, device=dev)
+    indptr, src, eids = _capi.sample_neighbors_padded(csr, seeds, nv, fanout, replace, 77, ctr, prob=prob)
+    ref_ptr, ref_src, ref_eids = _capi.sample_neighbors_weighted(csr, prob, seeds[:n_valid].contiguous(), fanout,
+                                                                 replace, (77 + 3 * GOLD) & 0xFFFFFFFFFFFFFFFF)
+    torch.cuda.synchronize()
+    total = int(ref_ptr[-1])
+    assert torch.equal(indptr[: n_valid + 1], ref_ptr)
+    assert bool((indptr[n_valid: n_slots + 1] == total).all()) and int(indptr[-1]) == n_slots * fanout
+    assert torch.equal(src[:total], ref_src[:total]) and torch.equal(eids[:total], ref_eids[:total])
+    assert bool((prob[eids[:total].long()] > 0).all())
+    assert bool(torch.isin(src[total:], seeds[:n_valid]).all())
+
+
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
 def test_padded_to_block_renumbers_like_the_unpadded_one(dev, idtype):
     from dgl_amd import _capi
     from dgl_amd.sampling import _node_map
