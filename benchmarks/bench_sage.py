@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--features", default="replicated", choices=["replicated", "sharded"],
                     help="sharded: features partitioned over the ranks, pulled per batch (the reference's layout)")
+    ap.add_argument("--shape", default="products", choices=["products", "papers100m"],
+                    help="papers100m: BASELINE configs[3]'s own size — 111 M nodes, 1.6 G edges, F = 128, 172 classes "
+                         "(13 GB of int64 CSC + 57 GB of fp32 features resident on the one GPU)")
     ap.add_argument("--mode", default="both", choices=["eager", "graph", "both"],
                     help="graph: the whole step (sampling included) captured once in a hipGraph over padded, "
                          "static-shape blocks (NeighborSampler.sample_blocks_padded) and replayed")
@@ -123,7 +126,11 @@ def main():
     from dgl_amd.heterograph import DGLGraph
 
     n, e, f, classes = C2_NODES // args.scale, C2_EDGES // args.scale, 100, 47
-    gs = synth_csr(n, n, e, "L", seed=20250824, device=dev, idtype=torch.int64)   # same graph on every rank
+    if args.shape == "papers100m":   # ogbn-papers100M: 111 059 956 nodes, 1 615 685 872 edges, 128 features, 172 classes
+        n, e, f, classes = 111_059_956 // args.scale, 1_615_685_872 // args.scale, 128, 172
+    # (columns need not be sorted inside a row for sampling; at 1.6 G edges the sort is the slow part)
+    gs = synth_csr(n, n, e, "L", seed=20250824, device=dev, idtype=torch.int64,
+                   sort_cols=args.shape != "papers100m")   # same graph on every rank
     rel = Relation(n, n, csc=(gs["indptr"], gs["indices"], None), idtype=torch.int64, device=dev)
     g = DGLGraph(GraphIndex([n], [(0, 0)], [rel]), ["_N"], [("_N", "_E", "_N")])
     torch.manual_seed(0)
@@ -247,6 +254,8 @@ def main():
                         "graph N=%d E=%d (variant L), F=%d -> %d -> %d, fp32; graph replicated per GPU"
                         % (args.batch, n, e, f, args.hidden, classes),
             "features": args.features if world > 1 else "local",
+            "resident_GB": {"csc": round((gs["indptr"].numel() + gs["indices"].numel()) * 8 / 1e9, 1),
+                            "features": round(store.local.numel() * store.local.element_size() / 1e9, 1)},
             "param_checksum_rel_spread_across_ranks": spread,
             "step": "one hipGraph replay over padded static-shape blocks (sampling, block building, gather, "
                     "forward, backward, SGD inside the graph)" if best == "graph" else "eager (sizes read back per layer)",
