@@ -374,15 +374,24 @@ def sample_neighbors_weighted(csr, prob, seeds, fanout, replace=False, rng_seed=
 def to_block(seeds, src, node_map):
     """Block-local renumbering of `src` (dgla_to_block).  Returns ``(local_src, src_nodes,
     num_src)``; reading ``num_src`` back is the one host synchronisation of block building
-    (the reference synchronises at the same place, cuda_to_block.cu)."""
+    (the reference synchronises at the same place, cuda_to_block.cu).  The node count is known here
+    (``node_map`` has one entry per node), so the sort inside looks at the used key bits only
+    (dgla_to_block_padded with every seed valid: 3 radix passes instead of 8 for int64 ids)."""
     _require_gpu(src)
     n, nnz = seeds.shape[0], src.shape[0]
     dev, dt = seeds.device, seeds.dtype
     local = torch.empty(nnz, dtype=dt, device=dev)
     src_nodes = torch.empty(n + nnz, dtype=dt, device=dev)
     num = torch.empty(1, dtype=torch.int64, device=dev)
-    check_call(LIB.dgla_to_block(_idbits(seeds), seeds.data_ptr(), n, _ptr(src), nnz, node_map.data_ptr(),
-                                 _ptr(local), src_nodes.data_ptr(), num.data_ptr(), None, 0, _stream(seeds)))
+    if n > 0:
+        ws = torch.empty(max(1, LIB.dgla_to_block_workspace_bytes(_idbits(seeds), nnz)), dtype=torch.uint8, device=dev)
+        check_call(LIB.dgla_to_block_padded(_idbits(seeds), seeds.data_ptr(), n, None, _ptr(src), nnz,
+                                            int(node_map.shape[0]), node_map.data_ptr(), _ptr(local),
+                                            src_nodes.data_ptr(), num.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            _stream(seeds)))
+    else:
+        check_call(LIB.dgla_to_block(_idbits(seeds), seeds.data_ptr(), n, _ptr(src), nnz, node_map.data_ptr(),
+                                     _ptr(local), src_nodes.data_ptr(), num.data_ptr(), None, 0, _stream(seeds)))
     k = int(num.item())
     return local, src_nodes[:k], k
 
