@@ -10,8 +10,17 @@ ring all-gather).
 Reference counterpart: ``sparse_all_to_all_pull`` (python/dgl/cuda/nccl.py:98-183), which
 re-sends split counts and indices on every call.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+# World-size-1 runs skip every collective.  DGLA_FORCE_COLLECTIVES=1 keeps them (a rank exchanging
+# with itself): the only way to put the real RCCL calls, their stream ordering and the chunked waits
+# under test on a pool of single-GPU boxes (tests/test_gpu_rccl_world1.py; the reference's own
+# tests/python/pytorch/cuda/test_nccl.py:14-31 runs its NCCL wrappers with one rank the same way).
+_FORCE_COLLECTIVES = os.environ.get("DGLA_FORCE_COLLECTIVES", "0") == "1"
 
 
 def _host_staged(t, group):
@@ -135,7 +144,7 @@ class HaloExchange:
         stream, each ordered after the pack kernel of ITS chunk only, so kernels queued between
         this call and the waits overlap with the transfers."""
         assert halo_out.shape[0] == self.n_halo and halo_out.is_contiguous()
-        if self.world == 1:
+        if self.world == 1 and not _FORCE_COLLECTIVES:
             return None
         shape = (self.serve_rows.numel(),) + tuple(x_local.shape[1:])
         buf = self._send_buf
@@ -164,7 +173,7 @@ class HaloExchange:
     def pull(self, x):
         """Fill ``x[n_local:]`` with the peers' current values of the requested rows."""
         assert x.shape[0] == self.n_local + self.n_halo and x.is_contiguous()
-        if self.world == 1:
+        if self.world == 1 and not _FORCE_COLLECTIVES:
             return x
         w = self.pull_async(x, x[self.n_local:])
         if w is not None:
@@ -177,7 +186,7 @@ class HaloExchange:
         owner and is ADDED into ``local_grad`` at the row it was pulled from (the gradient of
         the pull).  Rows requested by several peers accumulate; summation order = peer order."""
         assert halo_grad.shape[0] == self.n_halo and local_grad.shape[0] == self.n_local
-        if self.world == 1:
+        if self.world == 1 and not _FORCE_COLLECTIVES:
             return local_grad
         shape = (self.serve_rows.numel(),) + tuple(halo_grad.shape[1:])
         if self._recv_buf is None or self._recv_buf.dtype != halo_grad.dtype or \
@@ -457,7 +466,7 @@ def sparse_all_to_all_push(idx, value, partition, group=None):
     this rank received, own ones included (python/dgl/cuda/nccl.py:7-93: the gradient push of
     node embeddings).  The permutation and the row pack are library kernels; the three
     all-to-alls are RCCL through torch.distributed."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _FORCE_COLLECTIVES):
         return idx, value
     perm, send_splits = partition.generate_permutation(idx)
     recv_splits = torch.empty_like(send_splits)
@@ -476,7 +485,7 @@ def sparse_all_to_all_push(idx, value, partition, group=None):
 def sparse_all_to_all_pull(req_idx, value, partition, group=None):
     """``value_global[req_idx]`` where every rank holds the rows it owns under ``partition`` in
     its ``value`` (python/dgl/cuda/nccl.py:98-183: feature / embedding pull)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _FORCE_COLLECTIVES):
         return _take_rows(value, req_idx)
     perm, req_splits = partition.generate_permutation(req_idx)
     resp_splits = torch.empty_like(req_splits)
