@@ -109,8 +109,11 @@ def test_user_visible_values_are_edge_id_ordered(dev):
     other = dgl.ops.u_add_v(g2, el, er)
     out = dgl.ops.copy_e_sum(g, other)
     s2, d2 = g2.edges()
-    want2 = torch.zeros(n, 4, 1, device=dev).index_add_(0, dst.long(), el[s2.long()] + er[d2.long()])
-    torch.testing.assert_close(out, want2, rtol=1e-5, atol=1e-6)
+    # (fp64 reference: an fp32 index_add_ runs on atomics in a different order every time, and with
+    # randn operands a near-zero sum of a dozen terms carries ~1e-6 of ABSOLUTE error either way)
+    want2 = torch.zeros(n, 4, 1, device=dev, dtype=torch.float64).index_add_(
+        0, dst.long(), (el[s2.long()] + er[d2.long()]).double())
+    torch.testing.assert_close(out.double(), want2, rtol=1e-5, atol=1e-5)
     # max / min reducers need edge ids for arg_e: the tagged operand is converted, results unchanged
     mx = dgl.ops.copy_e_max(g, got)
     ref = torch.full((n, 4, 1), float("-inf"), device=dev).index_reduce_(0, dst.long(), want, "amax", include_self=True)
