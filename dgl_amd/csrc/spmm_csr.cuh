@@ -55,7 +55,8 @@ struct SpmmParams {
   // [0, split_main) of every row live in `umain` with pitch split_main, the rest in `utail`
   // with pitch split_tail; `ufeat` stays the caller's tensor.  split_main == 0: plain layout.
   // `split_meta` (device, may be NULL = always): the locality probe's counters {local, sampled}
-  // — the split copy is made and used only when fewer than half of the sampled edges are local.
+  // — the split copy is made and used only when the graph is not in a locality-preserving order
+  // (split_wanted(): fewer than 15/16 of the sampled edges local for the cheap layouts, 1/2 for the classic one).
   const void* umain;
   const void* utail;
   const unsigned* split_meta;
@@ -145,11 +146,16 @@ __device__ __forceinline__ void store_nt(DT* dst, const VecT<DT, VEC>& v) {
 // ceil(2^32 / pieces) (exact for the < 2^16 block-local piece numbers that occur).
 typedef uint32_t piece16_t __attribute__((ext_vector_type(4)));
 
-// Should this launch use the split copy?  (device side; uniform)
-__device__ __forceinline__ bool split_wanted(const unsigned* __restrict__ meta) {
+// Should this launch use the split copy?  (device side; uniform)  `cheap`: the layouts that copy only
+// the rows' ragged ends (edge layout: 0.10 ms on C2) or only the straddling rows — with them the copy
+// pays for itself even on a graph in community order (variant L, 81 % of the sampled edges local:
+// 3.81 ms with the copy against 4.03 ms without), so it is declined only when practically every
+// gather stays inside the window (>= 15/16 local); the whole-row copy of the classic layout
+// (0.33 ms) keeps round 2's rule of one half.
+__device__ __forceinline__ bool split_wanted(const unsigned* __restrict__ meta, bool cheap = false) {
   if (meta == nullptr) return true;
   const unsigned local = meta[0], sampled = meta[1];
-  return 2u * local < sampled;
+  return cheap ? 16u * local < 15u * sampled : 2u * local < sampled;
 }
 
 template <int K>
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256) void spmm_split_edges_kernel(
     const piece16_t* __restrict__ x, piece16_t* __restrict__ s1, piece16_t* __restrict__ s2,
     int64_t num_rows, int row_pieces, int t16, int interior_pieces, unsigned magic,
     const unsigned* __restrict__ meta, unsigned base16) {
-  if (!split_wanted(meta)) return;
+  if (!split_wanted(meta, true)) return;
   const int side = 8 + t16;
   const int64_t total = num_rows * side;
   for (int64_t base = static_cast<int64_t>(blockIdx.x) * (256 * K); base < total;
@@ -256,7 +262,7 @@ template <int UNUSED>  // (a template so that the header can be included by seve
 __global__ __launch_bounds__(256) void spmm_straddle_rows_kernel(
     const piece8_t* __restrict__ x, piece8_t* __restrict__ side, int64_t num_rows, int row_pieces,
     int pitch_pieces, int slack, unsigned base_bytes, unsigned magic, const unsigned* __restrict__ meta) {
-  if (!split_wanted(meta)) return;
+  if (!split_wanted(meta, true)) return;
   const int64_t total = num_rows * row_pieces;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += stride) {
@@ -490,8 +496,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   [[maybe_unused]] const DT* e_side = nullptr;
   bool straddle = false;  // (wave-uniform)
   if (p.split_main > 0 && p.split_straddle_slack >= 0) {
-    if constexpr (UL && !MULTI && VEC * sizeof(DT) == 8) straddle = split_wanted(p.split_meta);
-  } else if (p.split_main > 0 && split_wanted(p.split_meta)) {
+    if constexpr (UL && !MULTI && VEC * sizeof(DT) == 8) straddle = split_wanted(p.split_meta, true);
+  } else if (p.split_main > 0 && split_wanted(p.split_meta, p.split_edge_lines > 0)) {
     if (p.split_edge_lines > 0) {
       if constexpr (UL && !MULTI && VEC * sizeof(DT) == 16) {
         edge_layout = true;
@@ -841,7 +847,7 @@ __global__ __launch_bounds__(64) void spmm_csr_fixup_kernel(const SpmmParams<Idx
     // row with a carry has its row-end item in a later slot.
     const int F = p.out_len;
     // columns owned by the tail pass (same device-side decision as the merge kernel)
-    const int Fk = (p.tail_pass && p.split_main > 0 && split_wanted(p.split_meta)) ? F - p.split_tail : F;
+    const int Fk = (p.tail_pass && p.split_main > 0 && split_wanted(p.split_meta, true)) ? F - p.split_tail : F;
     const A* cv = static_cast<const A*>(p.carry_val);
     const A* tv = static_cast<const A*>(p.tail_val);
     DT* out = static_cast<DT*>(p.out);

@@ -34,7 +34,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bool tail_wanted(const unsigned* __restrict__ meta) {
   if (meta == nullptr) return true;
-  return 2u * meta[0] < meta[1];  // the locality probe's verdict, as split_wanted() in spmm_csr.cuh
+  return 16u * meta[0] < 15u * meta[1];  // the locality probe's verdict, as split_wanted(meta, true) in spmm_csr.cuh
 }
 
 struct SliceOf {

@@ -416,9 +416,12 @@ int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const voi
  *                     400 B = 4 lines touched per gather) the call first copies ufeat into a
  *                     line-aligned main array + a dense tail array inside the workspace and
  *                     gathers from those (3 lines + one cached access per edge) — unless the
- *                     locality probe made with the merge plan found that at least half of the
- *                     sampled edges point within 64 Ki rows of their own row (ordered graphs
- *                     re-use gathered rows in the caches and lose more to the copy than they gain)
+ *                     locality probe made with the merge plan found the graph in a locality-
+ *                     preserving order: at least 15/16 of the sampled edges within 64 Ki rows of
+ *                     their own row for the layouts that copy only the rows' ragged ends / the
+ *                     straddling rows (the default ones: their copy costs 0.1 ms on the headline
+ *                     graph and pays even at 81 % local edges), at least half for the whole-row
+ *                     copy of DGLA_TUNE_SPLIT_CLASSIC
  *   DGLA_TUNE_SPLIT_NT     the copy stores the main array non-temporally
  *   DGLA_TUNE_SPLIT_FORCE  ignore the locality probe
  *   DGLA_TUNE_GLDS    dgla_segment_mm / dgla_gather_mm, 16-bit and fp32 storage, operands in

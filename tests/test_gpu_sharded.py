@@ -137,8 +137,9 @@ def _probe(ws, n_rows, nnz):
 
 
 def test_locality_probe_and_static_features(dev):
-    """Variant U -> the probe lets the split-row copy run; variant L -> it declines; a static
-    tensor keeps the copy between calls (and forces it on L); all results bit-identical."""
+    """The probe's counters tell variant U (5 % local edges) from variant L (81 %); with the cheap
+    edge layout both take the copy (it is declined from 15/16 local edges on), the classic whole-row
+    copy only U; a static tensor keeps the copy between calls; all results bit-identical."""
     from dgl_amd import _capi, _lib
 
     n, e, f = 306_000, 7_700_000, 100        # X = 122 MB: split-eligible (>= 64 MiB, E >= 4 N)
