@@ -952,6 +952,16 @@ constexpr int64_t kSplitProbeWindowRows = 65536;
 // Below this many 512-item units a graph is "small": its units are shortened (spmm_geometry).
 constexpr int64_t kSmallGraphUnits = 4096;  // 16 per CU
 
+// Smallest gathered operand the split layouts are used for (bytes; DGLA_SPLIT_MIN_MB overrides, for
+// experiments and tests).  Measured on C2's rows with fewer distinct columns
+// (DGLA_SPLIT_MIN_MB = 1 against 64): X = 61 MB 4.23 -> 3.92 ms (its 2.4 MB of tails then live in
+// L2), X = 15 MB and 4 MB unchanged (everything is cache-resident either way) -> 16 MB.
+inline int64_t spmm_split_min_bytes() {
+  const char* e = getenv("DGLA_SPLIT_MIN_MB");
+  const int64_t mb = e && atoll(e) > 0 ? atoll(e) : 16;
+  return mb << 20;
+}
+
 // Shape-only eligibility of the split-row layout: 16-byte lane accesses cover the row in one
 // chunk, the row is longer than one 128-byte line and not a whole number of lines.
 inline bool spmm_split_shape_ok(const SpmmLaunch& L, size_t elem_bytes) {
@@ -967,7 +977,7 @@ inline bool spmm_split_shape_ok(const SpmmLaunch& L, size_t elem_bytes) {
   }
   // pays off only when rows are re-read (average in-degree) and X does not fit the caches
   if (L.csr.nnz < 4 * L.csr.num_cols) return false;
-  if (L.csr.num_cols * rb < (int64_t(64) << 20)) return false;
+  if (L.csr.num_cols * rb < spmm_split_min_bytes()) return false;
   return true;
 }
 
@@ -1092,7 +1102,7 @@ inline int launch_plan(const SpmmLaunch& L, const SpmmGeometry& g) {
     // ... unless NO shape could ever be eligible on this graph (spmm_split_shape_ok's graph-side
     // conditions with the widest row, 1024 bytes): a sampled mini-batch block pays 35 us for the
     // probe's few thousand same-address atomics and can never use their answer
-    const bool split_possible = L.csr.nnz >= 4 * L.csr.num_cols && L.csr.num_cols * 1024 >= (int64_t(64) << 20);
+    const bool split_possible = L.csr.nnz >= 4 * L.csr.num_cols && L.csr.num_cols * 1024 >= spmm_split_min_bytes();
     unsigned* meta = reinterpret_cast<unsigned*>(ws + g.off_meta);
     if (split_possible) DGLA_CHECK_HIP(hipMemsetAsync(meta, 0, 8, L.stream));
     const int64_t stride = std::max<int64_t>(1, g.num_waves / 4096);
