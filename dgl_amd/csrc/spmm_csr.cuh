@@ -950,7 +950,8 @@ inline int spmm_tail_slices(const SpmmLaunch& L) {
 constexpr int64_t kSplitProbeWindowRows = 65536;
 
 // Below this many 512-item units a graph is "small": its units are shortened (spmm_geometry).
-constexpr int64_t kSmallGraphUnits = 4096;  // 16 per CU
+constexpr int64_t kSmallGraphUnits = 4096;  // 16 per CU.  (DGLA_SMALL_GRAPH_UNITS overrides; measured at C3 size,
+                                            // 5.2 k units: 16384 / 65536 make u_mul_e_sum 0.159 -> 0.168 / 0.184 ms)
 
 // Smallest gathered operand the split layouts are used for (bytes; DGLA_SPLIT_MIN_MB overrides, for
 // experiments and tests).  Measured on C2's rows with fewer distinct columns
@@ -1001,7 +1002,11 @@ inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len
   // items = 350 units) leaves most CUs with ONE wave whose 32 dependent batches each wait a full
   // memory round trip (66 us for a 20 us job): such graphs get shorter units, down to 64 items.
   g.wave_items = kWaveItems;
-  while (g.wave_items > 64 && (num_rows + nnz + g.wave_items - 1) / g.wave_items < kSmallGraphUnits)
+  static const int64_t small_units = [] {
+    const char* e = getenv("DGLA_SMALL_GRAPH_UNITS");
+    return e && atoll(e) > 0 ? atoll(e) : kSmallGraphUnits;
+  }();
+  while (g.wave_items > 64 && (num_rows + nnz + g.wave_items - 1) / g.wave_items < small_units)
     g.wave_items >>= 1;
   g.num_waves = (num_rows + nnz + g.wave_items - 1) / g.wave_items;
   // sum reducer with two lane groups per wave (17 .. 32 lanes per feature row, e.g. F = 100 fp32):
