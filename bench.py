@@ -749,6 +749,16 @@ def variants(dev, ctx, n, e, f, args, reps=10):
     call()
     torch.cuda.synchronize()
     res[other + "_static_features"] = line(time_events(call, reps), merge_kernel_ms(call))
+    del gl, csr, ws
+    # DGL's default id type: the same graph with int64 ids (408 algorithmic bytes per edge)
+    g64 = synth_csr(n, n, e, args.variant, seed=20250824, device=dev, idtype=torch.int64)
+    csr64 = _capi.make_csr(g64["indptr"], g64["indices"], None, n)
+    ws64 = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr64, x.dtype, x, None, out2),
+                       dtype=torch.uint8, device=dev)
+    d64 = run(csr64, x, out2, ws64)
+    if "merge_kernel_ms" in d64:
+        d64["roofline_frac"] = algorithmic_bytes(n, e, f, i=8) / (d64["merge_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    res[args.variant + "_int64"] = d64
     return res
 
 

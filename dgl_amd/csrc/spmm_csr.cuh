@@ -261,7 +261,7 @@ typedef uint32_t piece8_t __attribute__((ext_vector_type(2)));
 template <int UNUSED>  // (a template so that the header can be included by several translation units)
 __global__ __launch_bounds__(256) void spmm_straddle_rows_kernel(
     const piece8_t* __restrict__ x, piece8_t* __restrict__ side, int64_t num_rows, int row_pieces,
-    int pitch_pieces, int slack, unsigned base_bytes, unsigned magic, const unsigned* __restrict__ meta) {
+    int pitch_pieces, int slack, unsigned base_bytes, const unsigned* __restrict__ meta) {
   if (!split_wanted(meta, true)) return;
   const int64_t total = num_rows * row_pieces;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
@@ -1233,7 +1233,7 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
     hipLaunchKernelGGL(spmm_straddle_rows_kernel<0>, dim3(sblocks), dim3(256), 0, L.stream,
                        static_cast<const piece8_t*>(L.ufeat), reinterpret_cast<piece8_t*>(ws + g.off_split_main),
                        L.csr.num_cols, row_pieces, g.split_main_bytes / 8, p.split_straddle_slack,
-                       static_cast<unsigned>(p.split_base_bytes), 0u, p.split_meta);
+                       static_cast<unsigned>(p.split_base_bytes), p.split_meta);
     DGLA_CHECK_HIP(hipGetLastError());
   } else if (g.split_edge_lines > 0 && !L.split_valid) {
     char* ws = static_cast<char*>(L.workspace);
