@@ -17,6 +17,8 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "common.h"
 
@@ -65,7 +67,49 @@ __global__ void zero_indptr_kernel(Idx* indptr, int64_t n) {
   if (i < n) indptr[i] = 0;
 }
 
+// int32 ids: the column id travels WITH the sort as the low half of a 64-bit value (position in the
+// high half), so that the compress pass reads everything in order — gathering col[perm[i]] afterwards
+// was one fabric request per edge (62 M of them: 1.1 of the 2.8 ms at C2 size) against 4 more bytes
+// per element and pass in the sort.
+struct PackColPos {
+  const int32_t* col;
+  __host__ __device__ uint64_t operator()(int32_t i) const {
+    return static_cast<uint64_t>(static_cast<uint32_t>(col[i])) | (static_cast<uint64_t>(static_cast<uint32_t>(i)) << 32);
+  }
+};
+
+__global__ __launch_bounds__(256) void compress_packed_kernel(const int32_t* __restrict__ sorted_row,
+                                                              const uint64_t* __restrict__ packed,
+                                                              const int32_t* __restrict__ eids,
+                                                              int32_t* __restrict__ indptr,
+                                                              int32_t* __restrict__ indices,
+                                                              int32_t* __restrict__ eids_out, int64_t nnz,
+                                                              int64_t num_rows) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < nnz; i += stride) {
+    const uint64_t v = __builtin_nontemporal_load(packed + i);
+    const int32_t pos = static_cast<int32_t>(v >> 32);
+    indices[i] = static_cast<int32_t>(v & 0xffffffffu);
+    eids_out[i] = eids ? eids[pos] : pos;
+    const int64_t r = static_cast<int64_t>(sorted_row[i]);
+    const int64_t rp = i > 0 ? static_cast<int64_t>(sorted_row[i - 1]) : -1;
+    for (int64_t q = rp + 1; q <= r; ++q) indptr[q] = static_cast<int32_t>(i);
+    if (i == nnz - 1)
+      for (int64_t q = r + 1; q <= num_rows; ++q) indptr[q] = static_cast<int32_t>(nnz);
+  }
+}
+
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+using PackIt = rocprim::transform_iterator<rocprim::counting_iterator<int32_t>, PackColPos, uint64_t>;
+
+size_t sort_packed_temp_bytes(int64_t nnz, int end_bit) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
+                                  PackIt(rocprim::counting_iterator<int32_t>(0), PackColPos{nullptr}),
+                                  static_cast<uint64_t*>(nullptr), static_cast<size_t>(nnz), 0, end_bit, nullptr);
+  return bytes;
+}
 
 int bits_for(int64_t num_rows) {
   int b = 1;
@@ -83,7 +127,12 @@ size_t sort_temp_bytes(int64_t nnz, int end_bit) {
 
 template <typename Idx>
 size_t workspace_typed(int64_t nnz, int64_t num_rows) {
-  return align256(sizeof(Idx) * nnz) * 3 + align256(sort_temp_bytes<Idx>(nnz, bits_for(num_rows)));
+  const size_t plain = align256(sizeof(Idx) * nnz) * 3 + align256(sort_temp_bytes<Idx>(nnz, bits_for(num_rows)));
+  if (sizeof(Idx) == 4) {  // packed form: sorted rows + 64-bit (column, position) values
+    const size_t packed = align256(4 * nnz) + align256(8 * nnz) + align256(sort_packed_temp_bytes(nnz, bits_for(num_rows)));
+    return plain > packed ? plain : packed;
+  }
+  return plain;
 }
 
 template <typename Idx>
@@ -95,6 +144,24 @@ int run(int64_t num_rows, int64_t nnz, const void* row, const void* col, const v
     DGLA_CHECK_HIP(hipGetLastError());
     return 0;
   }
+  int64_t blocks = (nnz + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if constexpr (sizeof(Idx) == 4) {
+    int32_t* sorted_row = reinterpret_cast<int32_t*>(ws);
+    uint64_t* packed = reinterpret_cast<uint64_t*>(ws + align256(4 * nnz));
+    void* temp = ws + align256(4 * nnz) + align256(8 * nnz);
+    const int end_bit = bits_for(num_rows);
+    size_t temp_bytes = sort_packed_temp_bytes(nnz, end_bit);
+    DGLA_CHECK_HIP(rocprim::radix_sort_pairs(
+        temp, temp_bytes, static_cast<const int32_t*>(row), sorted_row,
+        PackIt(rocprim::counting_iterator<int32_t>(0), PackColPos{static_cast<const int32_t*>(col)}), packed,
+        static_cast<size_t>(nnz), 0, end_bit, s));
+    hipLaunchKernelGGL(compress_packed_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, sorted_row,
+                       packed, static_cast<const int32_t*>(eids), static_cast<int32_t*>(indptr),
+                       static_cast<int32_t*>(indices), static_cast<int32_t*>(eids_out), nnz, num_rows);
+    DGLA_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   const size_t arr = align256(sizeof(Idx) * nnz);
   Idx* pos = reinterpret_cast<Idx*>(ws);
   Idx* sorted_row = reinterpret_cast<Idx*>(ws + arr);
@@ -102,8 +169,6 @@ int run(int64_t num_rows, int64_t nnz, const void* row, const void* col, const v
   void* temp = ws + 3 * arr;
   const int end_bit = bits_for(num_rows);
   size_t temp_bytes = sort_temp_bytes<Idx>(nnz, end_bit);
-  int64_t blocks = (nnz + 255) / 256;
-  if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(iota_kernel<Idx>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, pos, nnz);
   DGLA_CHECK_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, static_cast<const Idx*>(row), sorted_row,
                                            static_cast<const Idx*>(pos), perm, static_cast<size_t>(nnz), 0,
