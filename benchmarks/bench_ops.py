@@ -630,7 +630,7 @@ def fmt(dev, args):
         del g, perm
         i = 4 if idt == torch.int32 else 8
         nb = e * i * 4 + (n + 1) * i
-        ms, mn = timeit(lambda: _capi.coo_to_csr(dst, src, None, n), reps=5, warm=2)
+        ms, mn = timeit(lambda: _capi.coo_to_csr(dst, src, None, n, n), reps=5, warm=2)
         emit("FMT", "COO -> CSC, %d edges, %s ids: dgla_coo_to_csr" % (e, str(idt)), e, ms, mn, nb)
 
         def torch_path():

@@ -314,18 +314,19 @@ def gather_mm(a, b, c, idx_a=None, idx_b=None, idx_c=None):
                                   a.shape[1], b.shape[-1], _stream(a)))
 
 
-def coo_to_csr(row, col, eids, num_rows):
+def coo_to_csr(row, col, eids, num_rows, num_minor=0):
     """(indptr, indices, eids_out) of the CSR that compresses `row` (dgla_coo_to_csr): stable,
-    so COO order is kept inside every row; `eids_out[i]` = edge id of CSR position i."""
+    so COO order is kept inside every row; `eids_out[i]` = edge id of CSR position i.  `num_minor`
+    (every `col` id is below it) lets int64 graphs take the packed 32-bit sort."""
     _require_gpu(row)
     bits = _idbits(row)
     nnz = row.shape[0]
     indptr = torch.empty(num_rows + 1, dtype=row.dtype, device=row.device)
     indices = torch.empty(nnz, dtype=row.dtype, device=row.device)
     eids_out = torch.empty(nnz, dtype=row.dtype, device=row.device)
-    check_call(LIB.dgla_coo_to_csr(bits, int(num_rows), nnz, _ptr(row), _ptr(col), _ptr(eids),
-                                   indptr.data_ptr(), _ptr(indices), _ptr(eids_out), None, 0,
-                                   _stream(row)))
+    check_call(LIB.dgla_coo_to_csr_bounded(bits, int(num_rows), int(num_minor), nnz, _ptr(row), _ptr(col),
+                                           _ptr(eids), indptr.data_ptr(), _ptr(indices), _ptr(eids_out), None, 0,
+                                           _stream(row)))
     return indptr, indices, eids_out
 
 

@@ -130,6 +130,9 @@ LIB.dgla_coo_to_csr_workspace_bytes.argtypes = [c_int, c_int64, c_int64]
 LIB.dgla_coo_to_csr.restype = c_int
 LIB.dgla_coo_to_csr.argtypes = [c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_size_t, c_void_p]
+LIB.dgla_coo_to_csr_bounded.restype = c_int
+LIB.dgla_coo_to_csr_bounded.argtypes = [c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
 LIB.dgla_sample_neighbors_workspace_bytes.restype = c_size_t
 LIB.dgla_sample_neighbors_workspace_bytes.argtypes = [c_int, c_int64]
 LIB.dgla_sample_neighbors.restype = c_int

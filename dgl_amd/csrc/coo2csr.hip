@@ -67,46 +67,59 @@ __global__ void zero_indptr_kernel(Idx* indptr, int64_t n) {
   if (i < n) indptr[i] = 0;
 }
 
-// int32 ids: the column id travels WITH the sort as the low half of a 64-bit value (position in the
-// high half), so that the compress pass reads everything in order — gathering col[perm[i]] afterwards
-// was one fabric request per edge (62 M of them: 1.1 of the 2.8 ms at C2 size) against 4 more bytes
-// per element and pass in the sort.
+// Ids below 2^31 (int32 graphs always; int64 graphs whose node and edge counts fit, i.e. nearly all):
+// the column id travels WITH the sort as the low half of a 64-bit value (position in the high half)
+// and the key is the 32-bit row id, both built by transform iterators, so that the compress pass
+// reads everything in order — gathering col[perm[i]] afterwards was one fabric request per edge
+// (62 M of them: 1.1 of the 2.8 ms at C2 size) against 4 more bytes per element and pass in the sort.
+template <typename Idx>
 struct PackColPos {
-  const int32_t* col;
+  const Idx* col;
   __host__ __device__ uint64_t operator()(int32_t i) const {
     return static_cast<uint64_t>(static_cast<uint32_t>(col[i])) | (static_cast<uint64_t>(static_cast<uint32_t>(i)) << 32);
   }
 };
+template <typename Idx>
+struct Key32 {
+  const Idx* row;
+  __host__ __device__ int32_t operator()(int32_t i) const { return static_cast<int32_t>(row[i]); }
+};
 
+template <typename Idx>
 __global__ __launch_bounds__(256) void compress_packed_kernel(const int32_t* __restrict__ sorted_row,
                                                               const uint64_t* __restrict__ packed,
-                                                              const int32_t* __restrict__ eids,
-                                                              int32_t* __restrict__ indptr,
-                                                              int32_t* __restrict__ indices,
-                                                              int32_t* __restrict__ eids_out, int64_t nnz,
+                                                              const Idx* __restrict__ eids,
+                                                              Idx* __restrict__ indptr,
+                                                              Idx* __restrict__ indices,
+                                                              Idx* __restrict__ eids_out, int64_t nnz,
                                                               int64_t num_rows) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < nnz; i += stride) {
     const uint64_t v = __builtin_nontemporal_load(packed + i);
-    const int32_t pos = static_cast<int32_t>(v >> 32);
-    indices[i] = static_cast<int32_t>(v & 0xffffffffu);
-    eids_out[i] = eids ? eids[pos] : pos;
+    const int64_t pos = static_cast<int64_t>(v >> 32);
+    indices[i] = static_cast<Idx>(v & 0xffffffffu);
+    eids_out[i] = eids ? eids[pos] : static_cast<Idx>(pos);
     const int64_t r = static_cast<int64_t>(sorted_row[i]);
     const int64_t rp = i > 0 ? static_cast<int64_t>(sorted_row[i - 1]) : -1;
-    for (int64_t q = rp + 1; q <= r; ++q) indptr[q] = static_cast<int32_t>(i);
+    for (int64_t q = rp + 1; q <= r; ++q) indptr[q] = static_cast<Idx>(i);
     if (i == nnz - 1)
-      for (int64_t q = r + 1; q <= num_rows; ++q) indptr[q] = static_cast<int32_t>(nnz);
+      for (int64_t q = r + 1; q <= num_rows; ++q) indptr[q] = static_cast<Idx>(nnz);
   }
 }
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-using PackIt = rocprim::transform_iterator<rocprim::counting_iterator<int32_t>, PackColPos, uint64_t>;
+template <typename Idx>
+using PackIt = rocprim::transform_iterator<rocprim::counting_iterator<int32_t>, PackColPos<Idx>, uint64_t>;
+template <typename Idx>
+using KeyIt = rocprim::transform_iterator<rocprim::counting_iterator<int32_t>, Key32<Idx>, int32_t>;
 
+template <typename Idx>
 size_t sort_packed_temp_bytes(int64_t nnz, int end_bit) {
   size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
-                                  PackIt(rocprim::counting_iterator<int32_t>(0), PackColPos{nullptr}),
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, KeyIt<Idx>(rocprim::counting_iterator<int32_t>(0), Key32<Idx>{nullptr}),
+                                  static_cast<int32_t*>(nullptr),
+                                  PackIt<Idx>(rocprim::counting_iterator<int32_t>(0), PackColPos<Idx>{nullptr}),
                                   static_cast<uint64_t*>(nullptr), static_cast<size_t>(nnz), 0, end_bit, nullptr);
   return bytes;
 }
@@ -128,16 +141,15 @@ size_t sort_temp_bytes(int64_t nnz, int end_bit) {
 template <typename Idx>
 size_t workspace_typed(int64_t nnz, int64_t num_rows) {
   const size_t plain = align256(sizeof(Idx) * nnz) * 3 + align256(sort_temp_bytes<Idx>(nnz, bits_for(num_rows)));
-  if (sizeof(Idx) == 4) {  // packed form: sorted rows + 64-bit (column, position) values
-    const size_t packed = align256(4 * nnz) + align256(8 * nnz) + align256(sort_packed_temp_bytes(nnz, bits_for(num_rows)));
-    return plain > packed ? plain : packed;
-  }
-  return plain;
+  // packed form (ids below 2^31): sorted 32-bit rows + 64-bit (column, position) values
+  const size_t packed =
+      align256(4 * nnz) + align256(8 * nnz) + align256(sort_packed_temp_bytes<Idx>(nnz, bits_for(num_rows)));
+  return plain > packed ? plain : packed;
 }
 
 template <typename Idx>
 int run(int64_t num_rows, int64_t nnz, const void* row, const void* col, const void* eids, void* indptr,
-        void* indices, void* eids_out, char* ws, hipStream_t s) {
+        void* indices, void* eids_out, char* ws, hipStream_t s, bool cols_fit32) {
   if (nnz == 0) {
     hipLaunchKernelGGL(zero_indptr_kernel<Idx>, dim3(static_cast<unsigned>((num_rows + 256) / 256)), dim3(256),
                        0, s, static_cast<Idx*>(indptr), num_rows + 1);
@@ -146,19 +158,21 @@ int run(int64_t num_rows, int64_t nnz, const void* row, const void* col, const v
   }
   int64_t blocks = (nnz + 255) / 256;
   if (blocks > 65536) blocks = 65536;
-  if constexpr (sizeof(Idx) == 4) {
+  const bool packable = cols_fit32 && nnz < (int64_t(1) << 31) && num_rows < (int64_t(1) << 31);
+  if (packable) {
     int32_t* sorted_row = reinterpret_cast<int32_t*>(ws);
     uint64_t* packed = reinterpret_cast<uint64_t*>(ws + align256(4 * nnz));
     void* temp = ws + align256(4 * nnz) + align256(8 * nnz);
     const int end_bit = bits_for(num_rows);
-    size_t temp_bytes = sort_packed_temp_bytes(nnz, end_bit);
+    size_t temp_bytes = sort_packed_temp_bytes<Idx>(nnz, end_bit);
+    const rocprim::counting_iterator<int32_t> zero(0);
     DGLA_CHECK_HIP(rocprim::radix_sort_pairs(
-        temp, temp_bytes, static_cast<const int32_t*>(row), sorted_row,
-        PackIt(rocprim::counting_iterator<int32_t>(0), PackColPos{static_cast<const int32_t*>(col)}), packed,
-        static_cast<size_t>(nnz), 0, end_bit, s));
-    hipLaunchKernelGGL(compress_packed_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, sorted_row,
-                       packed, static_cast<const int32_t*>(eids), static_cast<int32_t*>(indptr),
-                       static_cast<int32_t*>(indices), static_cast<int32_t*>(eids_out), nnz, num_rows);
+        temp, temp_bytes, KeyIt<Idx>(zero, Key32<Idx>{static_cast<const Idx*>(row)}), sorted_row,
+        PackIt<Idx>(zero, PackColPos<Idx>{static_cast<const Idx*>(col)}), packed, static_cast<size_t>(nnz), 0,
+        end_bit, s));
+    hipLaunchKernelGGL(compress_packed_kernel<Idx>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, sorted_row,
+                       packed, static_cast<const Idx*>(eids), static_cast<Idx*>(indptr), static_cast<Idx*>(indices),
+                       static_cast<Idx*>(eids_out), nnz, num_rows);
     DGLA_CHECK_HIP(hipGetLastError());
     return 0;
   }
@@ -193,9 +207,9 @@ size_t dgla_coo_to_csr_workspace_bytes(int idtype_bits, int64_t num_rows, int64_
   return idtype_bits == 32 ? workspace_typed<int32_t>(nnz, num_rows) : workspace_typed<int64_t>(nnz, num_rows);
 }
 
-int dgla_coo_to_csr(int idtype_bits, int64_t num_rows, int64_t nnz, const void* row, const void* col,
-                    const void* eids, void* indptr, void* indices, void* eids_out, void* workspace,
-                    size_t workspace_bytes, void* hip_stream) {
+static int coo_to_csr_impl(int idtype_bits, int64_t num_rows, int64_t num_minor, int64_t nnz, const void* row,
+                           const void* col, const void* eids, void* indptr, void* indices, void* eids_out,
+                           void* workspace, size_t workspace_bytes, void* hip_stream) {
   if (idtype_bits != 32 && idtype_bits != 64) return cfail("idtype must be int32 or int64");
   if (num_rows < 0 || nnz < 0) return cfail("negative size");
   if (!indptr) return cfail("indptr is null");
@@ -210,13 +224,29 @@ int dgla_coo_to_csr(int idtype_bits, int64_t num_rows, int64_t nnz, const void* 
     DGLA_CHECK_HIP(hipMallocAsync(&owned, need, s));
     workspace = owned;
   }
+  // int64 ids: the packed form needs the minor ids to fit 32 bits, which only the caller can promise
+  const bool minor_fit32 = num_minor > 0 && num_minor < (int64_t(1) << 31);
   const int rc = idtype_bits == 32
                      ? run<int32_t>(num_rows, nnz, row, col, eids, indptr, indices, eids_out,
-                                    static_cast<char*>(workspace), s)
+                                    static_cast<char*>(workspace), s, true)
                      : run<int64_t>(num_rows, nnz, row, col, eids, indptr, indices, eids_out,
-                                    static_cast<char*>(workspace), s);
+                                    static_cast<char*>(workspace), s, minor_fit32);
   if (owned) (void)hipFreeAsync(owned, s);
   return rc;
+}
+
+int dgla_coo_to_csr(int idtype_bits, int64_t num_rows, int64_t nnz, const void* row, const void* col,
+                    const void* eids, void* indptr, void* indices, void* eids_out, void* workspace,
+                    size_t workspace_bytes, void* hip_stream) {
+  return coo_to_csr_impl(idtype_bits, num_rows, 0, nnz, row, col, eids, indptr, indices, eids_out, workspace,
+                         workspace_bytes, hip_stream);
+}
+
+int dgla_coo_to_csr_bounded(int idtype_bits, int64_t num_rows, int64_t num_minor, int64_t nnz, const void* row,
+                            const void* col, const void* eids, void* indptr, void* indices, void* eids_out,
+                            void* workspace, size_t workspace_bytes, void* hip_stream) {
+  return coo_to_csr_impl(idtype_bits, num_rows, num_minor, nnz, row, col, eids, indptr, indices, eids_out,
+                         workspace, workspace_bytes, hip_stream);
 }
 
 }  // extern "C"

@@ -67,7 +67,7 @@ class Relation:
                 self._coo = (indices, major, eids)
         return self._coo
 
-    def _compress(self, major, minor, eids, n_major):
+    def _compress(self, major, minor, eids, n_major, n_minor=0):
         # stable sort by the major index keeps edge-id order inside each row, which fixes the
         # CSR position order (and therefore arg-max/min tie-breaking) deterministically
         if major.is_cuda:
@@ -75,7 +75,7 @@ class Relation:
             # ≙ aten::COOToCSR<kDGLCUDA>, src/array/cuda/coo2csr.cu:28-110)
             from . import _capi
             return _capi.coo_to_csr(major.contiguous(), minor.contiguous(),
-                                    None if eids is None else eids.contiguous(), n_major)
+                                    None if eids is None else eids.contiguous(), n_major, n_minor)
         order = torch.argsort(major, stable=True)
         counts = torch.bincount(major.long(), minlength=n_major)
         indptr = torch.zeros(n_major + 1, dtype=self.idtype, device=self.device)
@@ -103,13 +103,13 @@ class Relation:
     def csr(self):
         if self._csr is None:
             row, col, eids = self.coo()
-            self._csr = self._drop_identity_map(self._compress(row, col, eids, self.num_src))
+            self._csr = self._drop_identity_map(self._compress(row, col, eids, self.num_src, self.num_dst))
         return self._csr
 
     def csc(self):
         if self._csc is None:
             row, col, eids = self.coo()
-            self._csc = self._drop_identity_map(self._compress(col, row, eids, self.num_dst))
+            self._csc = self._drop_identity_map(self._compress(col, row, eids, self.num_dst, self.num_src))
         return self._csc
 
     def has(self, fmt):

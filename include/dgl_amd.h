@@ -293,6 +293,12 @@ size_t dgla_coo_to_csr_workspace_bytes(int idtype_bits, int64_t num_rows, int64_
 int dgla_coo_to_csr(int idtype_bits, int64_t num_rows, int64_t nnz, const void* row, const void* col,
                     const void* eids, void* indptr, void* indices, void* eids_out, void* workspace,
                     size_t workspace_bytes, void* hip_stream);
+/* The same with the caller's promise that every minor id (`col`) is below num_minor: with int64 ids
+ * and num_rows, num_minor, nnz < 2^31 the sort then runs on 32-bit keys with the minor id packed into
+ * its 64-bit value, like the int32 form (3.35 -> ~2.1 ms at 62 M edges). */
+int dgla_coo_to_csr_bounded(int idtype_bits, int64_t num_rows, int64_t num_minor, int64_t nnz, const void* row,
+                            const void* col, const void* eids, void* indptr, void* indices, void* eids_out,
+                            void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* ---- uniform neighbour sampling and block construction -------------------
  * Replace CSRRowWiseSamplingUniform<kDGLCUDA> (src/array/cuda/rowwise_sampling.cu:43-330, behind

@@ -72,11 +72,13 @@ def test_coo_to_csr_bit_exact(dev, idtype, n, m, e, with_eids):
     col = rng.integers(0, m, e).astype(idtype)
     eids = rng.permutation(e).astype(idtype) if with_eids else None
     t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
-    ip, ix, ei = _capi.coo_to_csr(t(row), t(col), t(eids), n)
     wip, wix, wei = _expect(row, col, eids, n)
-    np.testing.assert_array_equal(ip.cpu().numpy(), wip)
-    np.testing.assert_array_equal(ix.cpu().numpy(), wix)
-    np.testing.assert_array_equal(ei.cpu().numpy(), wei)
+    # without a bound on the minor ids (int64: permutation form) and with it (packed 32-bit sort)
+    for num_minor in (0, m):
+        ip, ix, ei = _capi.coo_to_csr(t(row), t(col), t(eids), n, num_minor)
+        np.testing.assert_array_equal(ip.cpu().numpy(), wip)
+        np.testing.assert_array_equal(ix.cpu().numpy(), wix)
+        np.testing.assert_array_equal(ei.cpu().numpy(), wei)
 
 
 @pytest.mark.gpu
