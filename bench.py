@@ -363,7 +363,8 @@ def multi_gpu(args, dev, n, e, f, rank, world, dist, spmm=None):
     dist.broadcast(part, src=0)
     t_part = time.perf_counter() - t0
     sh = shard_from_partition(g["indptr"], g["indices"], part, world, rank)
-    op = ShardedSpMM(sh, (f,), x_full.dtype, dev, spmm=spmm)  # spmm=None: the library's kernels
+    op = ShardedSpMM(sh, (f,), x_full.dtype, dev, spmm=spmm,  # spmm=None: the library's kernels
+                     chunks=max(1, int(getattr(args, "chunks", 1))))
     x_loc = x_full[sh["rows"]].contiguous()
     out = torch.empty(sh["n_local"], f, device=dev)
 
@@ -400,6 +401,9 @@ def main():
                     help="N>1: node partitioner (kway = native multilevel, range = contiguous rows)")
     ap.add_argument("--partition-budget", type=float, default=240.0,
                     help="N>1: seconds the k-way partitioner may take before contiguous ranges are used")
+    ap.add_argument("--chunks", type=int, default=2,
+                    help="N > 1: pipeline chunks of the halo exchange (chunk c's halo-column launch is queued "
+                         "when chunk c has landed, while chunk c + 1 travels); 1 = one all-to-all per step")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-peak", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
@@ -521,8 +525,9 @@ def main():
                 "step": "one dgla_spmm_csr call over the whole graph, X treated as new on every "
                         "step (split-row copy of X when the locality probe wants it, merge kernel, "
                         "fix-up kernel)" if world == 1 else
-                        "ShardedSpMM.step on every rank: pack + halo all-to-all (RCCL) overlapped "
-                        "with the own-column launch, then the halo-column launch accumulates",
+                        "ShardedSpMM.step on every rank: pack + halo all-to-all (RCCL, %d pipeline chunk(s)) "
+                        "overlapped with the own-column launch, then the halo-column launch(es) accumulate"
+                        % max(1, int(getattr(args, "chunks", 1))),
                 "parallelism": "1 GPU" if world == 1 else
                                "%d-way node partition (%s), destination rows + features sharded, "
                                "halo pull by all_to_all_single over RCCL" % (world, args.partitioner),
