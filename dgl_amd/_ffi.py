@@ -7,6 +7,7 @@ Tensors are NOT copied and no DLPack capsule is needed: a ``DGLArray`` struct is
 straight from the torch tensor (pointer, shape, dtype, device_type = kDGLROCM = 10).
 """
 import ctypes
+import struct
 
 import torch
 
@@ -45,7 +46,8 @@ _DT = {
 
 LIB.DGLGetLastError.restype = ctypes.c_char_p
 LIB.DGLFuncGetGlobal.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
-LIB.DGLFuncCall.argtypes = [ctypes.c_void_p, ctypes.POINTER(DGLValue), ctypes.POINTER(ctypes.c_int),
+# (args / type codes travel as raw arrays: DGLValue is an 8-byte union, written below as int64 words)
+LIB.DGLFuncCall.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                             ctypes.c_int, ctypes.POINTER(DGLValue), ctypes.POINTER(ctypes.c_int)]
 LIB.DGLSetStream.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 LIB.DGLObjectFree.argtypes = [ctypes.c_void_p]
@@ -102,45 +104,65 @@ class _Boxed:
         self.parts, self.handle = [], None
 
 
-_encoded = {}
+_encoded = {}   # str -> (bytes kept alive, address of its buffer)
+_arrays = {}    # arity -> (c_int64 array type, c_int array type)
+_f2i = struct.Struct("d").pack, struct.Struct("q").unpack
 
 
 def _pack(args):
+    """DGLValue[] + type codes of one call.  The union is written as raw 8-byte words (attribute
+    access on a ctypes union array builds a Python object per field: 19 of the 57 us one small
+    operator call cost on the host)."""
     n = len(args)
-    values = (DGLValue * max(n, 1))()
-    codes = (ctypes.c_int * max(n, 1))()
+    types = _arrays.get(n)
+    if types is None:
+        types = _arrays[n] = (ctypes.c_int64 * max(n, 1), ctypes.c_int * max(n, 1))
+    values, codes = types[0](), types[1]()
     keep = []
     for i, a in enumerate(args):
-        if isinstance(a, (list, tuple)):
-            a = _Boxed(a)
-            keep.append(a)
-            values[i].v_handle = a.handle
-            codes[i] = kObjectHandle
-            continue
-        if a is None:
-            values[i].v_handle = None
-            codes[i] = kNull
-        elif isinstance(a, NDArray):
-            values[i].v_handle = ctypes.addressof(a.arr)  # (kept alive through `keep`)
+        t = type(a)
+        if t is NDArray:
+            values[i] = ctypes.addressof(a.arr)  # (kept alive through `keep`)
             codes[i] = kArrayHandle
             keep.append(a)
-        elif isinstance(a, bool) or isinstance(a, int):
-            values[i].v_int64 = int(a)
+        elif a is None:
+            codes[i] = kNull
+        elif t is str:
+            ent = _encoded.get(a)
+            if ent is None:  # operator / reducer names: a handful of distinct strings
+                b = a.encode("utf-8")
+                ent = (b, ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p).value)
+                if len(_encoded) < 1024:
+                    _encoded[a] = ent
+            keep.append(ent[0])
+            values[i] = ent[1]
+            codes[i] = kStr
+        elif t is int or t is bool:
+            values[i] = int(a)
+            codes[i] = kObjectInt
+        elif t is ObjectHandle:
+            values[i] = a.handle or 0
+            codes[i] = kObjectHandle
+        elif t is float:
+            values[i] = _f2i[1](_f2i[0](a))[0]
+            codes[i] = kObjectFloat
+        elif isinstance(a, (list, tuple)):
+            a = _Boxed(a)
+            keep.append(a)
+            values[i] = a.handle or 0
+            codes[i] = kObjectHandle
+        elif isinstance(a, NDArray):
+            values[i] = ctypes.addressof(a.arr)
+            codes[i] = kArrayHandle
+            keep.append(a)
+        elif isinstance(a, (bool, int)):
+            values[i] = int(a)
             codes[i] = kObjectInt
         elif isinstance(a, float):
-            values[i].v_float64 = a
+            values[i] = _f2i[1](_f2i[0](float(a)))[0]
             codes[i] = kObjectFloat
-        elif isinstance(a, str):
-            b = _encoded.get(a)
-            if b is None:  # operator / reducer names: a handful of distinct strings
-                b = a.encode("utf-8")
-                if len(_encoded) < 1024:
-                    _encoded[a] = b
-            keep.append(b)
-            values[i].v_str = b
-            codes[i] = kStr
         elif isinstance(a, ObjectHandle):
-            values[i].v_handle = a.handle
+            values[i] = a.handle or 0
             codes[i] = kObjectHandle
         else:
             raise TypeError("cannot pass %r through the FFI" % type(a))
@@ -169,7 +191,7 @@ class Function:
         ret, ret_code = DGLValue(), ctypes.c_int(kNull)
         rc = LIB.DGLFuncCall(self.handle, values, codes, n, ctypes.byref(ret), ctypes.byref(ret_code))
         for k in keep:
-            if isinstance(k, _Boxed):
+            if type(k) is _Boxed:
                 k.free()
         del keep
         if rc != 0:
