@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256) void sample_count_kernel(const Idx* __restrict
   counts[i] = static_cast<Idx>(c);
 }
 
-template <typename Idx>
+// FM: capacity of the position array.  FM <= 32: the array lives in REGISTERS (every loop over it is
+// unrolled to its static bound and predicated) — with the run-time bound of kMaxFanout it sat in
+// scratch memory, and Floyd's duplicate check (m reads per draw) made the kernel 30-50 us for a
+// few thousand seeds; larger fanouts keep the general form.
+template <typename Idx, int FM>
 __global__ __launch_bounds__(256) void sample_pick_kernel(const Idx* __restrict__ indptr,
                                                           const Idx* __restrict__ indices,
                                                           const Idx* __restrict__ eids,
@@ -97,7 +101,8 @@ __global__ __launch_bounds__(256) void sample_pick_kernel(const Idx* __restrict_
   // Positions first (arithmetic only), then the picked neighbours in batches of 8 independent loads:
   // a load -> store pair per pick made every pick wait a full memory round trip (15 picks: 34 us for
   // a kernel whose traffic is a few hundred kilobytes).
-  int64_t chosen[kMaxFanout];
+  constexpr bool REG = FM <= 32;
+  int64_t chosen[FM];
   int64_t n = 0;
   bool identity = false;  // chosen[k] == k: the whole neighbourhood, in CSR order
   if (fanout < 0 || (!replace && deg <= fanout)) {
@@ -106,35 +111,93 @@ __global__ __launch_bounds__(256) void sample_pick_kernel(const Idx* __restrict_
   } else if (deg == 0) {
     return;
   } else if (replace) {
-    for (int k = 0; k < fanout; ++k) chosen[k] = static_cast<int64_t>(draw(rng_seed, r, k, deg));
+    if constexpr (REG) {
+#pragma unroll
+      for (int k = 0; k < FM; ++k)
+        if (k < fanout) chosen[k] = static_cast<int64_t>(draw(rng_seed, r, k, deg));
+    } else {
+      for (int k = 0; k < fanout; ++k) chosen[k] = static_cast<int64_t>(draw(rng_seed, r, k, deg));
+    }
     n = fanout;
   } else {
     // Floyd: for j = deg - fanout .. deg - 1: t = U[0, j]; take t unless already taken, else j
-    int m = 0;
-    for (int64_t j = deg - fanout; j < deg; ++j) {
-      int64_t t = static_cast<int64_t>(draw(rng_seed, r, static_cast<uint32_t>(m), j + 1));
-      bool dup = false;
-      for (int q = 0; q < m; ++q) dup = dup || chosen[q] == t;
-      if (dup) t = j;
-      chosen[m] = t;
-      ++m;
+    if constexpr (REG) {
+#pragma unroll
+      for (int m = 0; m < FM; ++m) {
+        if (m < fanout) {
+          const int64_t j = deg - fanout + m;
+          int64_t t = static_cast<int64_t>(draw(rng_seed, r, static_cast<uint32_t>(m), j + 1));
+          bool dup = false;
+#pragma unroll
+          for (int q = 0; q < FM; ++q)
+            if (q < m) dup = dup || chosen[q] == t;
+          chosen[m] = dup ? j : t;
+        }
+      }
+    } else {
+      int m = 0;
+      for (int64_t j = deg - fanout; j < deg; ++j) {
+        int64_t t = static_cast<int64_t>(draw(rng_seed, r, static_cast<uint32_t>(m), j + 1));
+        bool dup = false;
+        for (int q = 0; q < m; ++q) dup = dup || chosen[q] == t;
+        if (dup) t = j;
+        chosen[m] = t;
+        ++m;
+      }
     }
-    n = m;
+    n = fanout;
   }
-  for (int64_t k = 0; k < n; k += 8) {
-    Idx sv[8], ev[8];
+  if (identity) {  // (any length: never touches `chosen`)
+    for (int64_t k = 0; k < n; k += 8) {
+      Idx sv[8], ev[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t kk = k + u < n ? k + u : n - 1;
-      const int64_t pos = identity ? kk : chosen[kk];
-      sv[u] = indices[start + pos];
-      ev[u] = eids ? eids[start + pos] : static_cast<Idx>(start + pos);
+      for (int u = 0; u < 8; ++u) {
+        const int64_t pos = k + u < n ? k + u : n - 1;
+        sv[u] = indices[start + pos];
+        ev[u] = eids ? eids[start + pos] : static_cast<Idx>(start + pos);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (k + u < n) {
+          out_src[o + k + u] = sv[u];
+          out_eids[o + k + u] = ev[u];
+        }
+      }
+    }
+    return;
+  }
+  if constexpr (REG) {
+    // all picks' loads are independent: issue them, then store
+    Idx sv[FM], ev[FM];
+#pragma unroll
+    for (int k = 0; k < FM; ++k) {
+      if (k < n) {
+        sv[k] = indices[start + chosen[k]];
+        ev[k] = eids ? eids[start + chosen[k]] : static_cast<Idx>(start + chosen[k]);
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (k + u < n) {
-        out_src[o + k + u] = sv[u];
-        out_eids[o + k + u] = ev[u];
+    for (int k = 0; k < FM; ++k) {
+      if (k < n) {
+        out_src[o + k] = sv[k];
+        out_eids[o + k] = ev[k];
+      }
+    }
+  } else {
+    for (int64_t k = 0; k < n; k += 8) {
+      Idx sv[8], ev[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t kk = k + u < n ? k + u : n - 1;
+        sv[u] = indices[start + chosen[kk]];
+        ev[u] = eids ? eids[start + chosen[kk]] : static_cast<Idx>(start + chosen[kk]);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (k + u < n) {
+          out_src[o + k + u] = sv[u];
+          out_eids[o + k + u] = ev[u];
+        }
       }
     }
   }
@@ -407,12 +470,21 @@ int run_sample(const dgla_csr* csc, const void* seeds, int64_t num_seeds, int fa
   DGLA_CHECK_HIP(rocprim::exclusive_scan(temp, temp_bytes, static_cast<const Idx*>(counts),
                                          static_cast<Idx*>(out_indptr), Idx(0),
                                          static_cast<size_t>(num_seeds + 1), rocprim::plus<Idx>(), s));
-  if (out_src)
-    hipLaunchKernelGGL(sample_pick_kernel<Idx>, dim3(grid1(num_seeds)), dim3(256), 0, s,
-                       static_cast<const Idx*>(csc->indptr), static_cast<const Idx*>(csc->indices),
-                       static_cast<const Idx*>(csc->data), static_cast<const Idx*>(seeds), num_seeds, fanout,
-                       replace, rng_seed, static_cast<const Idx*>(out_indptr), static_cast<Idx*>(out_src),
-                       static_cast<Idx*>(out_eids), num_valid, rng_counter);
+  if (out_src) {
+#define DGLA_PICK(FM)                                                                                      \
+  hipLaunchKernelGGL((sample_pick_kernel<Idx, FM>), dim3(grid1(num_seeds)), dim3(256), 0, s,                \
+                     static_cast<const Idx*>(csc->indptr), static_cast<const Idx*>(csc->indices),          \
+                     static_cast<const Idx*>(csc->data), static_cast<const Idx*>(seeds), num_seeds, fanout, \
+                     replace, rng_seed, static_cast<const Idx*>(out_indptr), static_cast<Idx*>(out_src),    \
+                     static_cast<Idx*>(out_eids), num_valid, rng_counter)
+    if (fanout > 0 && fanout <= 16)
+      DGLA_PICK(16);
+    else if (fanout > 0 && fanout <= 32)
+      DGLA_PICK(32);
+    else
+      DGLA_PICK(kMaxFanout);
+#undef DGLA_PICK
+  }
   if (sinks > 0) {
     const int64_t cap = num_seeds * fanout;
     hipLaunchKernelGGL(pad_tail_kernel<Idx>, dim3(grid1(cap > sinks ? cap : sinks + 1)), dim3(256), 0, s,
