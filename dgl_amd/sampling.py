@@ -141,7 +141,8 @@ class NeighborSampler:
         for layer, fanout in enumerate(reversed(self.fanouts)):
             rng = (self.seed * 1000003 + self._calls) * 64 + layer
             if self.prob is None:
-                indptr, src, eids = _capi.sample_neighbors(csr, seeds, fanout, self.replace, rng)
+                if not (fanout > 0 and seeds.shape[0] > 0):
+                    indptr, src, eids = _capi.sample_neighbors(csr, seeds, fanout, self.replace, rng)
             else:
                 p = g.edata[self.prob] if isinstance(self.prob, str) else self.prob
                 if p.dim() == 0 or p.shape[0] != rel.num_edges or p.numel() != rel.num_edges:
@@ -150,8 +151,19 @@ class NeighborSampler:
                 p = p.to(dev)
                 p = (p if p.dtype in (torch.float32, torch.float64) else p.float()).contiguous().reshape(-1)
                 indptr, src, eids = _capi.sample_neighbors_weighted(csr, p, seeds, fanout, self.replace, rng)
-            n_e = int(indptr[-1])   # one read-back per layer (sizes the block)
-            local, src_nodes, num_src = _capi.to_block(seeds, src[:n_e], node_map)
+            n = seeds.shape[0]
+            if self.prob is None and fanout > 0 and n > 0:
+                # ONE read-back per layer instead of two: renumber the whole fixed-size pick buffer
+                # (its unused tail is filled with the first seed, which adds no node) and fetch the
+                # number of picks and of source nodes together.  Same picks, same local ids.
+                indptr, src, eids = _capi.sample_neighbors_padded(csr, seeds, None, fanout, self.replace, rng, None,
+                                                                  sink_rows=1)
+                local, src_nodes, num = _capi.to_block_padded(seeds, None, src, node_map, num_nodes=rel.num_src)
+                n_e, num_src = (int(v) for v in torch.stack([indptr[n].long(), num[0]]).tolist())
+                indptr, local, src_nodes = indptr[: n + 1], local[:n_e], src_nodes[:num_src]
+            else:
+                n_e = int(indptr[-1])   # one read-back here, one in to_block
+                local, src_nodes, num_src = _capi.to_block(seeds, src[:n_e], node_map)
             blk = _make_block(indptr, local, num_src, seeds.shape[0], idt, dev)
             blk.srcdata[NID] = src_nodes
             blk.dstdata[NID] = seeds
