@@ -349,9 +349,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   // rhs element(s) per lane and edge: a full vector only when rhs is laid out like out
   constexpr int RV = (BC == kBcNone) ? VEC : 1;
 
-  __shared__ int s_cols[kWavesPerBlock][kWaveItems];
+  // column ids only where the operator gathers lhs rows; edge ids only when the CSR carries an
+  // edge-id map (DYNAMIC LDS, sized by the launch: a map-free copy_rhs — segment reduce, copy_e —
+  // staged 16 KB of positions it can compute, and with int64 ids that alone held it to 16 waves per CU)
+  __shared__ int s_cols[UL ? kWavesPerBlock : 1][UL ? kWaveItems : 1];
   __shared__ int s_rend[kWavesPerBlock][kWaveItems + 2];
-  __shared__ Idx s_eid[UR ? kWavesPerBlock : 1][UR ? kWaveItems : 1];
+  extern __shared__ __align__(8) unsigned char s_dyn[];
   // stacked form: one relation BYTE per staged edge + the relations' operand base pointers once per
   // workgroup (an 8-byte pointer per edge had doubled the LDS footprint: 20 instead of 28 waves per CU)
   __shared__ uint8_t s_rel[MULTI ? kWavesPerBlock : 1][MULTI ? kWaveItems : 1];
@@ -427,8 +430,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
         if (64 * k >= p.wave_items) break;
         const int it = lane + 64 * k;
         if (it < nE) {
-          s_cols[wib][it] = static_cast<int>(itemv[k]);
-          if constexpr (UR) s_eid[wib][it] = has_eid ? eidv[k] : static_cast<Idx>(j0 + it);
+          if constexpr (UL) s_cols[wib][it] = static_cast<int>(itemv[k]);
+          if constexpr (UR) {
+            if (has_eid) reinterpret_cast<Idx*>(s_dyn)[wib * kWaveItems + it] = eidv[k];
+          }
           if constexpr (MULTI) s_rel[wib][it] = relv[k];
         } else if (it < items) {
           s_rend[wib][it - nE + 1] = static_cast<int>(static_cast<int64_t>(itemv[k]) - j0);
@@ -451,9 +456,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   const int k0 = (static_cast<int>(blockIdx.y) * 64 + lg) * VEC;  // first feature of this lane
   if (k0 >= F) return;
 
-  const int* cols = s_cols[wib];
+  const int* cols = s_cols[UL ? wib : 0];
   const int* rend = s_rend[wib];
-  const Idx* eidl = s_eid[UR ? wib : 0];
+  const Idx* eidl = reinterpret_cast<const Idx*>(s_dyn) + wib * kWaveItems;  // (valid only with has_eid)
 
   // ---- split the unit between the lane groups (merge search in LDS) -------------------
   const int items = R + nE;
@@ -576,7 +581,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
         if (!done) b.x[u] = *reinterpret_cast<const XV*>(xb + c * lhs_len);
       }
       if constexpr (UR) {
-        const int64_t eid = static_cast<int64_t>(eidl[ee]);
+        const int64_t eid = has_eid ? static_cast<int64_t>(eidl[ee]) : j0 + ee;  // no map: edge id == position
         const DT* wb = Wt;
         if constexpr (MULTI) wb = s_tw[s_rel[wib][ee]] + ro_off;
         b.w[u] = *reinterpret_cast<const WV*>(wb + eid * rhs_len);
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
     if constexpr (MULTI)
       return static_cast<Idx>(j0 + bi);
     else if constexpr (UR)
-      return eidl[bi];
+      return has_eid ? eidl[bi] : static_cast<Idx>(j0 + bi);
     else
       return Idx(0);
   };
@@ -1267,6 +1272,10 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
                        (L.tune & kTuneSplitNt) ? 1 : 0);
     DGLA_CHECK_HIP(hipGetLastError());
   }
+  // dynamic LDS: the unit's edge ids, only when the operator reads edge features through a map
+  const unsigned dyn_lds = (op_uses_rhs(OP) && L.csr.eids != nullptr)
+                               ? static_cast<unsigned>(kWavesPerBlock * kWaveItems * sizeof(Idx))
+                               : 0u;
   const ProfileEvents pe = profile_events();
   if (pe.before) DGLA_CHECK_HIP(hipEventRecord(pe.before, L.stream));
   if (g.tail_pass) {
@@ -1281,15 +1290,15 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
                   BC != kBcGeneral) {
       if (L.accumulate)
         hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, true, true>),
-                           dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
+                           dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
       else
         hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false, true>),
-                           dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
+                           dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
     } else if constexpr ((OP == kCopyLhs || OP == kCopyRhs || OP == kMul) && BC != kBcGeneral) {
       // max / min over the stacked edges: earlier relations win ties, like the reference's
       // running compare relation by relation (spmm.cuh:552-606); arg_e receives stacked positions
       hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false, true>),
-                         dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
+                         dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
       DGLA_CHECK_HIP(hipGetLastError());
       if (pe.after) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
       hipLaunchKernelGGL((spmm_csr_fixup_kernel<Idx, DT, OP, RED, true>),
@@ -1304,13 +1313,13 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
   } else if constexpr (RED == kSum) {
     if (L.accumulate)
       hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, true>),
-                         dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
+                         dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
     else
       hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false>),
-                         dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
+                         dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
   } else {
     hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false>),
-                       dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), 0, L.stream, p);
+                       dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
   }
   DGLA_CHECK_HIP(hipGetLastError());
   if (pe.after && !g.tail_pass) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
