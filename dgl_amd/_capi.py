@@ -210,7 +210,7 @@ def set_profile_events(before, after):
 
 
 (TUNE_XCD, TUNE_NT_OUT, TUNE_NT_IDX, TUNE_SPLIT, TUNE_GLDS, TUNE_SPLIT_NT, TUNE_SPLIT_FORCE, TUNE_MM_F32,
- TUNE_SPLIT_CLASSIC, TUNE_TAIL_PASS) = (1, 2, 4, 8, 16, 32, 64, 128, 256, 512)  # include/dgl_amd.h DGLA_TUNE_*
+ TUNE_SPLIT_CLASSIC, TUNE_TAIL_PASS, TUNE_NT_STREAM) = (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024)  # include/dgl_amd.h DGLA_TUNE_*
 
 
 def set_tuning(flags):

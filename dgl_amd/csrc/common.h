@@ -189,6 +189,8 @@ enum Tune : uint32_t {
                              // by a column-sliced pass of their own (spmm_tail.hip); changes the summation
                              // ORDER of the last four output columns (the only SpMM bit that touches a result
                              // bit).  Opt-in: measured +2 % on the headline graph for +1 GB of workspace
+  kTuneNtStream = 1024u,     // sum reducers: non-temporal loads of an edge operand that has no edge-id map
+                             // (read exactly once, in position order; for a segment reduce: the rows)
 };
 // Default: XCD-contiguous order (measured on C2: variant L -3 % time, variant U neutral); the
 // non-temporal bits are neutral.  Split-row (profiles/r2/tune_split_ab.jsonl, C2, F = 100 fp32):
@@ -197,7 +199,7 @@ enum Tune : uint32_t {
 // static (DGLA_SPLIT_KEEP / _VALID); on variant L the locality probe (81 % local edges against
 // 5 % on U) declines it unless the features are static (4.08 -> 3.75 ms) -> on.  The LDS-direct
 // segment_mm loop is 23-34 % faster at every measured shape (profiles/r1/glds_ab.jsonl) -> on.
-constexpr uint32_t kDefaultTuning = 1u | 8u | 16u;
+constexpr uint32_t kDefaultTuning = 1u | 8u | 16u | 1024u;
 uint32_t& tuning_flags();
 
 // Merge-path geometry of the CSR SpMM (see spmm_csr.cuh).

@@ -135,6 +135,27 @@ __device__ __forceinline__ void store_nt(DT* dst, const VecT<DT, VEC>& v) {
   }
 }
 
+// Non-temporal load of one lane access: for operands read exactly once in position order (the
+// edge operand without an edge-id map, the rows of a segment reduce).  Measured on the load shape
+// of this kernel (benchmarks/micro/seq_rows.hip): 6.3 TB/s with default loads, 6.9-7.1 with these.
+template <typename DT, int VEC>
+__device__ __forceinline__ VecT<DT, VEC> load_nt(const DT* src) {
+  constexpr int B = sizeof(DT) * VEC;
+  VecT<DT, VEC> v;
+  if constexpr (B == 16) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<u4*>(&v) = __builtin_nontemporal_load(reinterpret_cast<const u4*>(src));
+  } else if constexpr (B == 8) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u2*>(&v) = __builtin_nontemporal_load(reinterpret_cast<const u2*>(src));
+  } else if constexpr (B == 4) {
+    *reinterpret_cast<uint32_t*>(&v) = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src));
+  } else {
+    v = *reinterpret_cast<const VecT<DT, VEC>*>(src);
+  }
+  return v;
+}
+
 // Split-row re-layout (kTuneSplit).  A feature row of RB bytes that is not a multiple of the
 // 128-byte L2 line straddles ceil-ish(RB / 128) + 1 lines when gathered (F = 100 fp32: 400 B
 // -> always 4 lines = 512 B of fabric traffic per edge).  Copying X once per call into a
@@ -383,6 +404,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   const int64_t w = static_cast<int64_t>(blk) * kWavesPerBlock + wib;
   const bool has_eid = p.eids != nullptr;
   const bool nt_idx = (p.tune & kTuneNtIdx) != 0;
+  // sums only: measured in one process (profiles/r3/nt_stream_ab.jsonl) sum -7 % (64 long segments) / -1 %
+  // (612 k segments), max with arg -2.5 % / +3.8 %; g-SpMM with a scalar edge operand neutral
+  [[maybe_unused]] const bool nt_rhs = !ARG && (p.tune & kTuneNtStream) != 0 && !has_eid;
 
   int64_t i0 = 0, j0 = 0;
   int R = 0, nE = 0;
@@ -584,7 +608,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
         const int64_t eid = has_eid ? static_cast<int64_t>(eidl[ee]) : j0 + ee;  // no map: edge id == position
         const DT* wb = Wt;
         if constexpr (MULTI) wb = s_tw[s_rel[wib][ee]] + ro_off;
-        b.w[u] = *reinterpret_cast<const WV*>(wb + eid * rhs_len);
+        if (!nt_rhs)
+          b.w[u] = *reinterpret_cast<const WV*>(wb + eid * rhs_len);
+        else
+          b.w[u] = load_nt<DT, RV>(wb + eid * rhs_len);  // position order: every piece read once
       }
     }
   };

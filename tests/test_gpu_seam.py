@@ -657,3 +657,45 @@ def test_spmm_tuning_bits_do_not_change_results(dev, feat, tdtype, op, reduce):
         else:
             np.testing.assert_array_equal(base[0].cpu().numpy(), ref)
             np.testing.assert_array_equal(base[1].cpu().numpy(), ru)
+
+
+@pytest.mark.parametrize("feat,tdtype", [(100, torch.float32), (1, torch.float32), (50, torch.bfloat16),
+                                         (25, torch.float64), (7, torch.float16)])
+def test_position_ordered_operand_nontemporal_loads_same_bits(dev, feat, tdtype):
+    """DGLA_TUNE_NT_STREAM: an edge operand without an edge-id map (and the rows of a segment sum) is
+    loaded non-temporally — a cache-policy hint, so the bits must not move (no reference counterpart)."""
+    from dgl_amd import _capi
+
+    n_dst, n_src, e = 20_000, 30_000, 400_000
+    g = synth_csr(n_dst, n_src, e, "U", seed=78, device=dev, with_eids=False)
+    csr = _capi.make_csr(g["indptr"], g["indices"], None, n_src)
+    torch.manual_seed(6)
+    w = (torch.rand(e, feat, device=dev) + 1).to(tdtype)
+    x = (torch.rand(n_src, feat, device=dev) + 1).to(tdtype)
+    off = g["indptr"].to(torch.int64)
+    default = _capi.get_tuning()
+    got = {}
+    try:
+        for on in (0, 1):
+            _capi.set_tuning((default & ~_capi.TUNE_NT_STREAM) | (_capi.TUNE_NT_STREAM if on else 0))
+            seg = torch.full((n_dst, feat), -3.0, dtype=tdtype, device=dev)
+            _capi.segment_reduce("sum", w, off, seg)
+            mul = torch.full((n_dst, feat), -3.0, dtype=tdtype, device=dev)
+            ws = torch.empty(_capi.spmm_csr_workspace_bytes("mul", "sum", csr, x.dtype, x, w, mul), dtype=torch.uint8,
+                             device=dev)
+            _capi.spmm_csr("mul", "sum", csr, x, w, mul, None, None, ws)
+            cpy = torch.full((n_dst, feat), -3.0, dtype=tdtype, device=dev)
+            ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_rhs", "sum", csr, w.dtype, None, w, cpy),
+                             dtype=torch.uint8, device=dev)
+            _capi.spmm_csr("copy_rhs", "sum", csr, None, w, cpy, None, None, ws)
+            torch.cuda.synchronize()
+            got[on] = (seg, mul, cpy)
+    finally:
+        _capi.set_tuning(default)
+    for a, b in zip(got[0], got[1]):
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+    assert torch.equal(got[1][0].view(torch.uint8), got[1][2].view(torch.uint8))  # segment sum == copy_e sum
+    if tdtype in (torch.float32, torch.float64):
+        host = [t.cpu().numpy() for t in (g["indptr"], g["indices"])]
+        ref, _, _ = oracle.spmm_csr("mul", "sum", host[0], host[1], None, x.cpu().numpy(), w.cpu().numpy())
+        np.testing.assert_allclose(got[1][1].cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
