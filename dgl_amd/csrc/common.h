@@ -189,8 +189,8 @@ enum Tune : uint32_t {
                              // by a column-sliced pass of their own (spmm_tail.hip); changes the summation
                              // ORDER of the last four output columns (the only SpMM bit that touches a result
                              // bit).  Opt-in: measured +2 % on the headline graph for +1 GB of workspace
-  kTuneNtStream = 1024u,     // sum reducers: non-temporal loads of an edge operand that has no edge-id map
-                             // (read exactly once, in position order; for a segment reduce: the rows)
+  kTuneNtStream = 1024u,     // copy_rhs over long rows (>= 64 edges on average) without an edge-id map — a
+                             // readout-like segment reduce: non-temporal loads of the rows
 };
 // Default: XCD-contiguous order (measured on C2: variant L -3 % time, variant U neutral); the
 // non-temporal bits are neutral.  Split-row (profiles/r2/tune_split_ab.jsonl, C2, F = 100 fp32):

@@ -357,7 +357,7 @@ __device__ __forceinline__ typename Acc<DT>::type round_to_storage(typename Acc<
 // one launch): every edge carries its relation id, and the relation's operand base pointers
 // are staged in LDS next to the column ids, so the gather loop reads (column, base) pairs.
 template <typename Idx, typename DT, int VEC, int OP, int RED, int BC, int U, bool ACCUM,
-          bool MULTI = false>
+          bool MULTI = false, bool NTR = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
     const SpmmParams<Idx> p) {
   using A = typename Acc<DT>::type;
@@ -404,9 +404,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   const int64_t w = static_cast<int64_t>(blk) * kWavesPerBlock + wib;
   const bool has_eid = p.eids != nullptr;
   const bool nt_idx = (p.tune & kTuneNtIdx) != 0;
-  // sums only: measured in one process (profiles/r3/nt_stream_ab.jsonl) sum -7 % (64 long segments) / -1 %
-  // (612 k segments), max with arg -2.5 % / +3.8 %; g-SpMM with a scalar edge operand neutral
-  [[maybe_unused]] const bool nt_rhs = !ARG && (p.tune & kTuneNtStream) != 0 && !has_eid;
+  // NTR (kTuneNtStream; copy_rhs over long rows without an edge-id map, i.e. a readout-like segment reduce):
+  // the edge operand is loaded non-temporally.  A compile-time switch: selecting the load flavour per load at run
+  // time put a branch between the prefetch loads and made the compiler drain them (vmcnt(0)) before
+  // every reduction instead of waiting with a count.
 
   int64_t i0 = 0, j0 = 0;
   int R = 0, nE = 0;
@@ -608,10 +609,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
         const int64_t eid = has_eid ? static_cast<int64_t>(eidl[ee]) : j0 + ee;  // no map: edge id == position
         const DT* wb = Wt;
         if constexpr (MULTI) wb = s_tw[s_rel[wib][ee]] + ro_off;
-        if (!nt_rhs)
-          b.w[u] = *reinterpret_cast<const WV*>(wb + eid * rhs_len);
-        else
+        if constexpr (NTR)
           b.w[u] = load_nt<DT, RV>(wb + eid * rhs_len);  // position order: every piece read once
+        else
+          b.w[u] = *reinterpret_cast<const WV*>(wb + eid * rhs_len);
       }
     }
   };
@@ -1252,6 +1253,14 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
 // Gathers in flight per lane (x2 with the prefetched batch).
 constexpr int kSpmmUnroll = 4;
 
+// kTuneNtStream: copy_rhs without an edge-id map and with LONG rows (>= 64 edges on average, e.g. a graph
+// readout).  Interleaved A/B (profiles/r3/nt_stream_ab.jsonl, 15.5 M rows x 400 B): 64 segments sum -8 %,
+// max -5 %; 612 k segments (25 rows each) sum -2 %, max +9 %; 2.4 M segments (6 rows each) +7 % / +10 %:
+// next to many output rows the non-temporal stream loses.
+inline bool spmm_nt_stream(const SpmmLaunch& L) {
+  return (L.tune & kTuneNtStream) && L.csr.eids == nullptr && L.csr.nnz >= 64 * L.csr.num_rows;
+}
+
 template <typename Idx, typename DT, int VEC, int OP, int RED, int BC>
 inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
   const SpmmParams<Idx> p = make_params<Idx, DT>(L, g);
@@ -1341,8 +1350,16 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
     if (L.accumulate)
       hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, true>),
                          dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
-    else
+    else if (OP == kCopyRhs && BC == kBcNone && spmm_nt_stream(L)) {
+      if constexpr (OP == kCopyRhs && BC == kBcNone)
+        hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false, false, true>),
+                           dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
+    } else
       hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false>),
+                         dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
+  } else if (OP == kCopyRhs && BC == kBcNone && spmm_nt_stream(L)) {
+    if constexpr (OP == kCopyRhs && BC == kBcNone)
+      hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false, false, true>),
                          dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
   } else {
     hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false>),

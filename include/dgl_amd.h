@@ -456,14 +456,17 @@ int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const voi
  *                     4.61 -> 4.51 ms on the headline graph (the pass's own L2 gathers and partial sums
  *                     cost most of what the fourth request did) for +1 GB of workspace.  Changing
  *                     this bit changes the workspace layout: do not pass DGLA_PLAN_VALID across it.
- *   DGLA_TUNE_NT_STREAM  sum reducers: an edge operand WITHOUT an edge-id map — read exactly once and in
- *                     position order; for dgla_segment_reduce these are the rows themselves — is loaded
- *                     non-temporally.  On the load shape of the merge kernel a pure in-order stream runs at
- *                     6.3 TB/s with default loads and 6.9-7.1 TB/s with these (benchmarks/micro/seq_rows.hip);
- *                     segment sum over 64 long segments 1.12 -> 1.04 ms, over 612 k short ones -1 %, g-SpMM
- *                     with a scalar edge operand neutral.  Random gathers are indifferent (operands behind
- *                     an edge-id map keep default loads); max / min with arg outputs measured mixed
- *                     (-2.5 % / +3.8 %) and keep default loads as well.  Default on.
+ *   DGLA_TUNE_NT_STREAM  copy_rhs WITHOUT an edge-id map over long rows (nnz >= 64 num_rows: a readout-like
+ *                     dgla_segment_reduce, copy_e on a graph of hubs): the edge operand — read exactly once, in
+ *                     position order — is loaded non-temporally.  On the load shape of the merge kernel a pure
+ *                     in-order stream runs at 6.3 TB/s with default loads and 6.9-7.1 TB/s with these
+ *                     (benchmarks/micro/seq_rows.hip); segment sum of 15.5 M x 400 B rows into 64 segments
+ *                     1.10 -> 1.01 ms, max 1.34 -> 1.26.  Next to many output rows the hint LOSES (612 k
+ *                     segments: sum -2 %, max +9 %; 2.4 M segments: +7 % / +10 %), hence the row-length rule;
+ *                     random gathers are indifferent to it (operands behind an edge-id map keep default loads).
+ *                     The load flavour is a compile-time variant of the kernel: chosen per load at run time it
+ *                     put branches between the prefetch loads and the compiler drained them before every
+ *                     reduction.  Default on.
  * The reference has no counterpart (its kernels take no hints). */
 #define DGLA_TUNE_XCD 1u
 #define DGLA_TUNE_NT_OUT 2u

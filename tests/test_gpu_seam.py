@@ -659,14 +659,16 @@ def test_spmm_tuning_bits_do_not_change_results(dev, feat, tdtype, op, reduce):
             np.testing.assert_array_equal(base[1].cpu().numpy(), ru)
 
 
+@pytest.mark.parametrize("n_dst", [2_000, 20_000])  # rows of 200 edges (the hint applies) / 20 (it does not)
 @pytest.mark.parametrize("feat,tdtype", [(100, torch.float32), (1, torch.float32), (50, torch.bfloat16),
                                          (25, torch.float64), (7, torch.float16)])
-def test_position_ordered_operand_nontemporal_loads_same_bits(dev, feat, tdtype):
-    """DGLA_TUNE_NT_STREAM: an edge operand without an edge-id map (and the rows of a segment sum) is
-    loaded non-temporally — a cache-policy hint, so the bits must not move (no reference counterpart)."""
+def test_position_ordered_operand_nontemporal_loads_same_bits(dev, feat, tdtype, n_dst):
+    """DGLA_TUNE_NT_STREAM: copy_rhs over long rows without an edge-id map (a readout-like segment reduce)
+    loads the rows non-temporally — a cache-policy hint, so the bits must not move (no reference
+    counterpart)."""
     from dgl_amd import _capi
 
-    n_dst, n_src, e = 20_000, 30_000, 400_000
+    n_src, e = 30_000, 400_000
     g = synth_csr(n_dst, n_src, e, "U", seed=78, device=dev, with_eids=False)
     csr = _capi.make_csr(g["indptr"], g["indices"], None, n_src)
     torch.manual_seed(6)
@@ -680,6 +682,9 @@ def test_position_ordered_operand_nontemporal_loads_same_bits(dev, feat, tdtype)
             _capi.set_tuning((default & ~_capi.TUNE_NT_STREAM) | (_capi.TUNE_NT_STREAM if on else 0))
             seg = torch.full((n_dst, feat), -3.0, dtype=tdtype, device=dev)
             _capi.segment_reduce("sum", w, off, seg)
+            smax = torch.full((n_dst, feat), -3.0, dtype=tdtype, device=dev)
+            amax = torch.full((n_dst, feat), -7, dtype=torch.int64, device=dev)
+            _capi.segment_reduce("max", w, off, smax, amax)
             mul = torch.full((n_dst, feat), -3.0, dtype=tdtype, device=dev)
             ws = torch.empty(_capi.spmm_csr_workspace_bytes("mul", "sum", csr, x.dtype, x, w, mul), dtype=torch.uint8,
                              device=dev)
@@ -689,12 +694,18 @@ def test_position_ordered_operand_nontemporal_loads_same_bits(dev, feat, tdtype)
                              dtype=torch.uint8, device=dev)
             _capi.spmm_csr("copy_rhs", "sum", csr, None, w, cpy, None, None, ws)
             torch.cuda.synchronize()
-            got[on] = (seg, mul, cpy)
+            got[on] = (seg, mul, cpy, smax, amax)
     finally:
         _capi.set_tuning(default)
     for a, b in zip(got[0], got[1]):
         assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
     assert torch.equal(got[1][0].view(torch.uint8), got[1][2].view(torch.uint8))  # segment sum == copy_e sum
+    deg = (off[1:] - off[:-1])
+    rows_of = torch.repeat_interleave(torch.arange(n_dst, device=dev), deg)
+    ref_max = torch.full((n_dst, feat), float("-inf"), dtype=torch.float64, device=dev).index_reduce_(
+        0, rows_of, w.double(), "amax", include_self=True)
+    has = (deg > 0)[:, None].expand(-1, feat)
+    assert torch.equal(got[1][3].double()[has], ref_max[has])
     if tdtype in (torch.float32, torch.float64):
         host = [t.cpu().numpy() for t in (g["indptr"], g["indices"])]
         ref, _, _ = oracle.spmm_csr("mul", "sum", host[0], host[1], None, x.cpu().numpy(), w.cpu().numpy())
