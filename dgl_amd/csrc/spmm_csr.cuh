@@ -156,6 +156,31 @@ __device__ __forceinline__ VecT<DT, VEC> load_nt(const DT* src) {
   return v;
 }
 
+// Load of one lane access through a pointer the compiler cannot see the address space of (the operand
+// tables of the stacked kernels live in LDS): an explicit GLOBAL load.  As a generic pointer it became
+// flat_load, whose completion the compiler cannot count — every reduction of the stacked kernels then
+// waited for vmcnt(0), i.e. drained the prefetched batch (seen in the disassembly, round 3).
+template <typename DT, int VEC>
+__device__ __forceinline__ VecT<DT, VEC> load_global(const DT* src) {
+  constexpr int B = sizeof(DT) * VEC;
+  VecT<DT, VEC> v;
+  if constexpr (B % 16 == 0) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u4* gptr;
+#pragma unroll
+    for (int i = 0; i < B / 16; ++i) reinterpret_cast<u4*>(&v)[i] = ((gptr)src)[i];
+  } else if constexpr (B == 8) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u2*>(&v) = *(const __attribute__((address_space(1))) u2*)src;
+  } else if constexpr (B == 4) {
+    *reinterpret_cast<uint32_t*>(&v) = *(const __attribute__((address_space(1))) uint32_t*)src;
+  } else {
+    static_assert(B == 2, "lane access of 2, 4, 8 or a multiple of 16 bytes");
+    *reinterpret_cast<uint16_t*>(&v) = *(const __attribute__((address_space(1))) uint16_t*)src;
+  }
+  return v;
+}
+
 // Split-row re-layout (kTuneSplit).  A feature row of RB bytes that is not a multiple of the
 // 128-byte L2 line straddles ceil-ish(RB / 128) + 1 lines when gathered (F = 100 fp32: 400 B
 // -> always 4 lines = 512 B of fabric traffic per edge).  Copying X once per call into a
@@ -603,7 +628,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
             done = true;
           }
         }
-        if (!done) b.x[u] = *reinterpret_cast<const XV*>(xb + c * lhs_len);
+        if constexpr (MULTI)
+          b.x[u] = load_global<DT, VEC>(xb + c * lhs_len);
+        else if (!done)
+          b.x[u] = *reinterpret_cast<const XV*>(xb + c * lhs_len);
       }
       if constexpr (UR) {
         const int64_t eid = has_eid ? static_cast<int64_t>(eidl[ee]) : j0 + ee;  // no map: edge id == position
@@ -611,6 +639,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
         if constexpr (MULTI) wb = s_tw[s_rel[wib][ee]] + ro_off;
         if constexpr (NTR)
           b.w[u] = load_nt<DT, RV>(wb + eid * rhs_len);  // position order: every piece read once
+        else if constexpr (MULTI)
+          b.w[u] = load_global<DT, RV>(wb + eid * rhs_len);
         else
           b.w[u] = *reinterpret_cast<const WV*>(wb + eid * rhs_len);
       }
