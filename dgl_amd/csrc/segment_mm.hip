@@ -465,7 +465,6 @@ __global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(con
   static_assert(nA * NW * 1024 == kASlab && nB * NW * 1024 == kBSlab, "whole DMA instructions per wave");
   constexpr int kBBase = NA * kASlab;
   constexpr int kCPitch = TBN * 2 + 16;
-  static_assert(64 * kCPitch <= NA * kASlab + NB * kBSlab, "half a C tile must fit");
   __shared__ __attribute__((aligned(1024))) char smem[NA * kASlab + NB * kBSlab];
 
   const int64_t* tile_off = p.plan;
@@ -597,7 +596,10 @@ __global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(con
 #pragma unroll
           for (int jj = 0; jj < NJ; ++jj) {
             const char* sb = bufb + b_off + jj * 32 * 64 + chunk;
-            M::step(sa, sb, 0, 0, acc[i][jj]);
+            // operands swapped: the MFMA produces the TRANSPOSED 32 x 32 block, so a lane ends up with
+            // four CONSECUTIVE COLUMNS of one C row per register quad (row = lane & 31,
+            // col = 8 q + 4 (lane >> 5) + j) and the epilogue stages 8-byte pieces, not 2-byte ones
+            M::step(sb, sa, 0, 0, acc[i][jj]);
           }
         }
       }
@@ -664,44 +666,49 @@ __global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(con
     return;
   }
 
-  // epilogue: as in segment_mm_kernel (LDS-staged 16-byte row pieces)
-  const int rbase = 4 * khalf;
+  // epilogue: the whole C tile is staged in the (now idle) slab rings — every wave writes its 64 x TBN/2
+  // part as 8-byte pieces (see the operand swap above), one barrier, then 16-byte row pieces go out.
+  // (Round 2 staged 64 rows at a time with 2-byte LDS writes: 4 serial phases of 128 ds_write_b16 per
+  // wave with one workgroup per CU — about 40 % of the tile's time.)
+  static_assert(BMT * kCPitch <= NA * kASlab + NB * kBSlab, "the C tile must fit in the rings");
   constexpr int CPR = TBN * 2 / 16;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  __syncthreads();  // everybody is done reading the last slab
 #pragma unroll
-  for (int half = 0; half < BMT / 64; ++half) {
-    __syncthreads();
-    if (wm == half) {
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
+      for (int q = 0; q < 4; ++q) {
+        const int row = wm * 64 + i * 32 + lrow;
+        const int col = wn * (TBN / 2) + jj * 32 + 8 * q + 4 * khalf;
+        DT t4[4];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-            const int col = wn * (TBN / 2) + jj * 32 + lrow;
-            *reinterpret_cast<DT*>(smem + row * kCPitch + col * ES) = from_acc<DT>(acc[i][jj][r]);
-          }
-    }
-    __syncthreads();
-    int64_t prow[64 * CPR / NT];  // physical rows first (one wait), then the stores
-#pragma unroll
-    for (int h = 0; h < 64 * CPR / NT; ++h) {
-      const int64_t grow = row0 + half * 64 + (tid + NT * h) / CPR;
-      prow[h] = grow < row_end ? (p.row_index ? p.row_index[grow] : grow) : -1;
-    }
-#pragma unroll
-    for (int h = 0; h < 64 * CPR / NT; ++h) {
-      const int pidx = tid + NT * h;
-      const int row = pidx / CPR, chunk = pidx % CPR;
-      const int col = n0 + chunk * 8;
-      if (prow[h] >= 0 && col < N) {
-        u32x4* dstp = reinterpret_cast<u32x4*>(C + prow[h] * N + col);
-        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * kCPitch + chunk * 16);
-        if (nt_c)
-          __builtin_nontemporal_store(v, dstp);
-        else
-          *dstp = v;
+        for (int j4 = 0; j4 < 4; ++j4) t4[j4] = from_acc<DT>(acc[i][jj][4 * q + j4]);
+        u32x2 w;
+        __builtin_memcpy(&w, t4, 8);
+        *reinterpret_cast<u32x2*>(smem + row * kCPitch + col * ES) = w;
       }
+  __syncthreads();
+  constexpr int NP = BMT * CPR / NT;  // 16-byte pieces per thread
+  int64_t prow[NP];  // physical rows first (one wait), then the stores
+#pragma unroll
+  for (int h = 0; h < NP; ++h) {
+    const int64_t grow = row0 + (tid + NT * h) / CPR;
+    prow[h] = grow < row_end ? (p.row_index ? p.row_index[grow] : grow) : -1;
+  }
+#pragma unroll
+  for (int h = 0; h < NP; ++h) {
+    const int pidx = tid + NT * h;
+    const int row = pidx / CPR, chunk = pidx % CPR;
+    const int col = n0 + chunk * 8;
+    if (prow[h] >= 0 && col < N) {
+      u32x4* dstp = reinterpret_cast<u32x4*>(C + prow[h] * N + col);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * kCPitch + chunk * 16);
+      if (nt_c)
+        __builtin_nontemporal_store(v, dstp);
+      else
+        *dstp = v;
     }
   }
 }
