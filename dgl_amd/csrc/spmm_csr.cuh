@@ -506,9 +506,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   const int k0 = (static_cast<int>(blockIdx.y) * 64 + lg) * VEC;  // first feature of this lane
   if (k0 >= F) return;
 
-  const int* cols = s_cols[UL ? wib : 0];
-  const int* rend = s_rend[wib];
-  const Idx* eidl = reinterpret_cast<const Idx*>(s_dyn) + wib * kWaveItems;  // (valid only with has_eid)
+  // explicit LDS pointers: as plain pointers some instantiations (general broadcast + arg outputs) lost the
+  // address space and read the winners' column ids with flat_load, which the compiler cannot count
+  typedef const __attribute__((address_space(3))) int* lds_int_ptr;
+  typedef const __attribute__((address_space(3))) Idx* lds_idx_ptr;
+  const lds_int_ptr cols = (lds_int_ptr)s_cols[UL ? wib : 0];
+  const lds_int_ptr rend = (lds_int_ptr)s_rend[wib];
+  const lds_idx_ptr eidl = (lds_idx_ptr)s_dyn + wib * kWaveItems;  // (valid only with has_eid)
 
   // ---- split the unit between the lane groups (merge search in LDS) -------------------
   const int items = R + nE;
