@@ -457,7 +457,10 @@ __global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(con
   using M = Mma<DT>;
   constexpr int ES = sizeof(DT);  // 2: 32x32x16 MFMAs, LDS-staged epilogue; 4: 32x32x2 MFMAs, direct stores
   static_assert(ES == 2 || ES == 4, "16-bit and fp32 storage");
-  static_assert(NA >= NB && NB >= 2, "A ring at least as deep as the weight ring");
+  // NA > NB strictly: iteration i issues [weights slab i + NB - 1, A slab i + NA - 1]; with NA == NB the A load
+  // that follows weights slab t in issue order is A slab t ITSELF, which wait_for_slab would leave in flight
+  // (tried as (3, 3) in round 3: wrong sums)
+  static_assert(NA > NB && NB >= 2, "A ring deeper than the weight ring");
   constexpr int NJ = TBN / 64;
   constexpr int NT = 2 * BMT, NW = NT / 64;   // threads, waves (one wave per 64 x TBN/2 of C)
   constexpr int kASlab = BMT * 64, kBSlab = TBN * 64;  // bytes of one slab of each operand
