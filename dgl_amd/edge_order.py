@@ -61,14 +61,38 @@ def raw(t):
     return t
 
 
+class _Tag:
+    """The layout tag of ONE storage.  Every alias of the storage (views, ``detach()``, ``.data``)
+    holds the same object, so re-laying the storage into edge-id order (``rel = None``) is seen by
+    all of them at once."""
+    __slots__ = ("rel",)
+
+    def __init__(self, rel):
+        self.rel = rel
+
+
 def tag_of(t):
-    return getattr(t, "_dgla_rel", None) if type(t) is PosOrdered else None
+    return t._dgla_rel if type(t) is PosOrdered else None
 
 
-def wrap(t, rel):
+def _same_storage(a, b):
+    try:
+        return a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.numel() > 0
+    except RuntimeError:
+        return False
+
+
+def wrap(t, rel, alias_of=None):
+    """Tag the plain tensor ``t`` as position-ordered on ``rel``.  ``alias_of``: a tagged tensor ``t``
+    was derived from — when both share one storage they share one tag object."""
+    _install_backward_hook()
     with _no_tf():
         r = t.as_subclass(PosOrdered)
-    r._dgla_rel = rel
+        if alias_of is not None and alias_of._dgla_tag is not None and alias_of._dgla_tag.rel is rel \
+                and _same_storage(r, alias_of):
+            r._dgla_tag = alias_of._dgla_tag
+        else:
+            r._dgla_tag = _Tag(rel)
     return r
 
 
@@ -129,7 +153,7 @@ plain = to_eid_order  # what every entry point that does not understand tags app
 _META_METHODS = {
     "size", "dim", "ndimension", "numel", "nelement", "element_size", "data_ptr", "is_contiguous", "stride",
     "storage_offset", "is_floating_point", "is_complex", "is_signed", "get_device", "is_pinned", "is_shared",
-    "untyped_storage", "__len__", "__hash__", "retain_grad", "register_hook", "is_set_to", "type",
+    "untyped_storage", "__len__", "__hash__", "retain_grad", "register_hook", "is_set_to",
     "_is_view", "is_inference", "is_neg", "is_conj", "has_names", "requires_grad_",
 }
 _META_PROPS = {
@@ -198,12 +222,79 @@ def _reduce_keeps_rows(args, kwargs, me):
     return all(isinstance(d, int) and (d % nd) != 0 for d in dims)
 
 
+_INPLACE_DUNDER = {"__iadd__": "add", "__isub__": "sub", "__imul__": "mul", "__itruediv__": "div",
+                   "__ipow__": "pow"}
+_UNARY_KEEP_NAMES = {f.__name__ for f in _UNARY_KEEP} - {"clone", "detach", "contiguous", "float", "double", "half",
+                                                         "bfloat16", "zeros_like", "ones_like", "empty_like",
+                                                         "__neg__", "__abs__", "__pos__", "dropout",
+                                                         "feature_alpha_dropout", "alpha_dropout"}
+_BINARY_KEEP_NAMES = {"mul", "add", "sub", "div", "true_divide", "pow"}
+
+
+def _other_tensors(args, kwargs, me):
+    return [a for a in _flatten((args, kwargs)) if isinstance(a, torch.Tensor) and a is not me]
+
+
+def _grads_to_pos(outputs, grads):
+    """Explicit gradients (``Tensor.backward(gradient)``, ``autograd.backward(grad_tensors=)``,
+    ``autograd.grad(grad_outputs=)``) are written by the caller in EDGE-ID order; the producer of a
+    tagged output reads its gradient in the storage layout.  Convert each gradient that belongs to
+    a tagged output (a gradient already tagged with the same relation is taken as it is)."""
+    if grads is None:
+        return None
+    single = isinstance(grads, torch.Tensor)
+    outs = (outputs,) if isinstance(outputs, torch.Tensor) else tuple(outputs)
+    gl = (grads,) if single else tuple(grads)
+    res = []
+    for o, g in zip(outs, gl):
+        rel = tag_of(o)
+        if g is None or rel is None:
+            res.append(raw(g) if g is not None and tag_of(g) is None else
+                       (to_eid_order(g) if g is not None else None))
+        elif tag_of(g) is rel:
+            res.append(raw(g))
+        else:
+            gp = to_eid_order(g)
+            if gp.dim() == 0 or gp.shape[0] != rel.num_edges:
+                gp = gp.expand(raw(o).shape)
+            res.append(_ToPos.apply(gp, rel))
+    res.extend(raw(g) if isinstance(g, torch.Tensor) else g for g in gl[len(outs):])
+    return res[0] if single else tuple(res)
+
+
+_BACKWARD_HOOKED = [False]
+
+
+def _install_backward_hook():
+    """``torch.autograd.backward`` does not dispatch to ``__torch_function__`` (``autograd.grad`` and
+    ``Tensor.backward`` do), so the conversion of explicit ``grad_tensors`` is put in front of it the first
+    time a tagged tensor exists; programs that never start a hand-off never see it."""
+    if _BACKWARD_HOOKED[0]:
+        return
+    _BACKWARD_HOOKED[0] = True
+    inner = torch.autograd.backward
+
+    def backward(tensors, grad_tensors=None, *args, **kwargs):
+        if grad_tensors is not None and any(tag_of(t) is not None for t in _flatten((tensors,))):
+            grad_tensors = _grads_to_pos(tensors, grad_tensors)
+        return inner(tensors, grad_tensors, *args, **kwargs)
+
+    backward.__doc__ = inner.__doc__
+    backward.__wrapped__ = inner
+    torch.autograd.backward = backward
+
+
 class PosOrdered(torch.Tensor):
     """An ``(E, ...)`` edge tensor whose rows are stored in the position order of the in-edge CSR
     of ``_dgla_rel`` instead of edge-id order.  Behaves like the edge-id-ordered tensor under every
     torch function (see the module docstring)."""
 
-    _dgla_rel = None
+    _dgla_tag = None
+
+    @property
+    def _dgla_rel(self):
+        tag = self._dgla_tag
+        return None if tag is None else tag.rel
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -223,25 +314,43 @@ class PosOrdered(torch.Tensor):
             if pname in ("data", "grad", "_grad"):  # tensors with the storage layout of `me`
                 with _no_tf():
                     r = func(*args, **kwargs)
-                return wrap(r, me._dgla_rel) if isinstance(r, torch.Tensor) else r
+                return wrap(r, me._dgla_rel, alias_of=me) if isinstance(r, torch.Tensor) else r
         elif name in _META_METHODS:
             with _no_tf():
                 return func(*args, **kwargs)
         elif func is torch.autograd.grad:
-            # gradients arrive in the layout of the tensor they belong to: tag those of tagged inputs
+            # gradients arrive in the layout of the tensor they belong to: tag those of tagged inputs;
+            # explicit grad_outputs are the caller's (edge-id order): convert those of tagged outputs
+            args, kwargs = list(args), dict(kwargs)
+            outputs = kwargs["outputs"] if "outputs" in kwargs else args[0]
+            if "grad_outputs" in kwargs:
+                kwargs["grad_outputs"] = _grads_to_pos(outputs, kwargs["grad_outputs"])
+            elif len(args) > 2:
+                args[2] = _grads_to_pos(outputs, args[2])
             with _no_tf():
                 res = func(*args, **kwargs)
             inputs = kwargs.get("inputs", args[1] if len(args) > 1 else None)
             inputs = (inputs,) if isinstance(inputs, torch.Tensor) else tuple(inputs)
             return tuple(wrap(r, i._dgla_rel) if (r is not None and type(i) is PosOrdered and i._dgla_rel is not None)
                          else r for r, i in zip(res, inputs))
-        elif func is torch.autograd.backward or name == "backward":
+        elif name == "backward":
+            # Tensor.backward(self, gradient) ends in torch.autograd.backward, which converts the
+            # explicit gradient (_install_backward_hook)
             with _no_tf():
                 return func(*args, **kwargs)
         # -- order-preserving functions: run on the storage, keep the tag -----------------------
         keep = False
-        if func in _UNARY_KEEP:
-            keep = len(tagged) == 1 and args and args[0] is me and "out" not in kwargs
+        if name == "type" and func is torch.Tensor.type:
+            # t.type() is metadata; t.type(dtype) is a cast like .float(): same rows, keep the tag
+            if len(args) == 1 and not kwargs:
+                with _no_tf():
+                    return func(*args, **kwargs)
+            keep = len(tagged) == 1 and args[0] is me
+        elif func in _UNARY_KEEP:
+            # bounds / fill values given as tensors (torch.clamp(t, min=per_edge)) must not care about
+            # the row order either
+            keep = len(tagged) == 1 and args and args[0] is me and "out" not in kwargs \
+                and all(_row_broadcastable(o, me) for o in _other_tensors(args, kwargs, me))
         elif func in _BINARY_KEEP:
             others = [a for a in args[:2] if a is not me]
             keep = len(args) >= 2 and all(_row_broadcastable(o, me) for o in others) and "out" not in kwargs \
@@ -252,7 +361,7 @@ class PosOrdered(torch.Tensor):
             with _no_tf():
                 res = func(*_untag(args), **_untag(kwargs))
             if isinstance(res, torch.Tensor) and res.dim() >= 1 and res.shape[0] == me.shape[0]:
-                return me if res is raw(me) else wrap(res, me._dgla_rel)
+                return me if res is raw(me) else wrap(res, me._dgla_rel, alias_of=me)
             # (requires_grad_ and friends return their argument)
             return res
         if func in _SHAPE_KEEP and len(tagged) == 1 and args and args[0] is me:
@@ -260,17 +369,43 @@ class PosOrdered(torch.Tensor):
                 res = func(*_untag(args), **_untag(kwargs))
             if isinstance(res, torch.Tensor) and res.dim() >= 1 and res.shape[0] == me.shape[0] \
                     and me.dim() >= 1 and (me.is_contiguous() or res.dim() == me.dim()):
-                return wrap(res, me._dgla_rel)
+                return wrap(res, me._dgla_rel, alias_of=me)
             # axis 0 changed: fall through and redo it on the edge-id-ordered values
-        # -- in-place modification by a function that does not preserve the order ------------------
-        inplace = (name.endswith("_") and not name.endswith("__")) or name in ("__setitem__", "__iadd__", "__isub__",
-                                                                               "__imul__", "__itruediv__") \
-            or any(type(o) is PosOrdered for o in _flatten(kwargs.get("out", ())))
+        # -- in-place functions ------------------------------------------------------------------------
+        out_targets = [o for o in _flatten(kwargs.get("out", ())) if isinstance(o, torch.Tensor)]
+        inplace = (name.endswith("_") and not name.endswith("__")) or name == "__setitem__" \
+            or name in _INPLACE_DUNDER or bool(out_targets)
         if inplace:
-            for t in tagged:
-                _untag_in_place(t)
+            # the tensors WRITTEN: args[0] of an in-place method, or the out= targets; everything else
+            # is only read and goes in as an edge-id-ordered copy (its own storage is left alone)
+            written = out_targets if out_targets else ([args[0]] if args and isinstance(args[0], torch.Tensor) else [])
+            tgt = written[0] if len(written) == 1 and not out_targets and tag_of(written[0]) is not None else None
+            if tgt is not None:
+                base = _INPLACE_DUNDER.get(name, name[:-1] if name.endswith("_") else name)
+                rest = _other_tensors(args[1:], kwargs, tgt)
+                if (base in _UNARY_KEEP_NAMES or base in _BINARY_KEEP_NAMES) \
+                        and all(_row_broadcastable(o, tgt) for o in rest):
+                    # order-preserving: run on the storage as it is, the tag (of every alias) stays
+                    with _no_tf():
+                        func(*_untag(args), **_untag(kwargs))
+                    return tgt
+                if base == "copy" and len(args) >= 2 and isinstance(args[1], torch.Tensor) and not tgt.requires_grad:
+                    # t.copy_(src): src's rows into position order, the tag stays
+                    src, rel = args[1], tag_of(tgt)
+                    if tag_of(src) is rel or _row_broadcastable(src, tgt):
+                        s_pos = raw(src)
+                    else:
+                        s_eid = to_eid_order(src)
+                        s_pos = _ToPos.apply(s_eid.expand(raw(tgt).shape) if s_eid.shape != raw(tgt).shape else s_eid, rel)
+                    with _no_tf():
+                        func(raw(tgt), s_pos, *args[2:], **kwargs)
+                    return tgt
+            for t in written:
+                if tag_of(t) is not None:
+                    _untag_in_place(t)
+            conv = {id(t): to_eid_order(t) for t in tagged if tag_of(t) is not None}
             with _no_tf():
-                return func(*args, **kwargs)
+                return func(*_map(args, conv), **_map(kwargs, conv))
         # -- everything else sees edge-id order -----------------------------------------------------
         conv = {id(t): to_eid_order(t) for t in tagged}
         with _no_tf():
@@ -302,7 +437,7 @@ def _map(x, conv):
         return [_map(y, conv) for y in x]
     if isinstance(x, dict):
         return {k: _map(v, conv) for k, v in x.items()}
-    return conv.get(id(x), x) if type(x) is PosOrdered else x
+    return conv.get(id(x), raw(x)) if type(x) is PosOrdered else x
 
 
 def _untag(x):
@@ -328,7 +463,8 @@ def _untag_in_place(t):
                           "graph; take t.eid_order() first or call dgl_amd.set_edge_order_handoff(False)")
     with torch.no_grad():
         x.copy_(to_eid_order(t).detach())
-    t._dgla_rel = None
+    # one tag object per storage: every alias (views, detach(), .data) is edge-id ordered from here on
+    t._dgla_tag.rel = None
 
 
 def reject_tagged(t):

@@ -91,3 +91,167 @@ def test_pos_ordered_tensor_semantics(monkeypatch):
     import pickle, io
     b = io.BytesIO(); torch.save(t, b); b.seek(0); back = torch.load(b, weights_only=False)
     assert type(back) is torch.Tensor and torch.equal(back, eid_vals)
+
+
+def _patched(monkeypatch):
+    from dgl_amd import _capi
+
+    def gather_rows(src, idx, out=None):
+        r = src[idx.long()]
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
+    def scatter_rows(src, idx, out):
+        out[idx.long()] = src
+        return out
+
+    monkeypatch.setattr(_capi, "gather_rows", gather_rows)
+    monkeypatch.setattr(_capi, "scatter_rows", scatter_rows)
+
+
+class _Rel:
+    def __init__(s, m):
+        s.m = m
+        s.num_edges = m.numel()
+        s.transient = False
+
+    def csc(s):
+        return (None, None, s.m)
+
+
+def test_explicit_gradients_are_taken_in_edge_id_order(monkeypatch):
+    """Tensor.backward(gradient) / autograd.backward(grad_tensors) /
+    autograd.grad(grad_outputs) hand over the CALLER's edge-id-ordered gradient; the producer of a
+    tagged output reads position order.  A non-uniform explicit gradient must give the plain result."""
+    from dgl_amd import edge_order as E
+
+    _patched(monkeypatch)
+    torch.manual_seed(1)
+    Eg = 11
+    m = torch.randperm(Eg)
+    rel = _Rel(m)
+    eid_vals = torch.randn(Eg, 3, dtype=torch.float64)
+    gy = torch.randn(Eg, 3, dtype=torch.float64)             # edge-id ordered, non-uniform
+    xp = eid_vals.clone().requires_grad_(True)
+    F.leaky_relu(xp, 0.2).backward(gy)
+    want = xp.grad                                            # edge-id order
+
+    def fresh():
+        x = eid_vals[m].clone().requires_grad_(True)          # storage in position order
+        return x, E.wrap(x, rel)
+
+    x, t = fresh()
+    F.leaky_relu(t, 0.2).backward(gy)
+    assert torch.allclose(x.grad, want[m])
+    x, t = fresh()
+    F.leaky_relu(t, 0.2).backward(gradient=gy)
+    assert torch.allclose(x.grad, want[m])
+    x, t = fresh()
+    torch.autograd.backward([F.leaky_relu(t, 0.2)], grad_tensors=[gy])
+    assert torch.allclose(x.grad, want[m])
+    x, t = fresh()
+    torch.autograd.backward(F.leaky_relu(t, 0.2), gy)
+    assert torch.allclose(x.grad, want[m])
+    x, t = fresh()
+    y = F.leaky_relu(t, 0.2)
+    (g,) = torch.autograd.grad(y, x, grad_outputs=gy)
+    assert torch.allclose(g, want[m])
+    x, t = fresh()
+    y = F.leaky_relu(t, 0.2)
+    (g,) = torch.autograd.grad([y], [t], [gy])
+    assert type(g) is E.PosOrdered and torch.allclose(g.eid_order(), want)
+    # a gradient already tagged with the same relation is taken as it is
+    x, t = fresh()
+    F.leaky_relu(t, 0.2).backward(E.wrap(gy[m].clone(), rel))
+    assert torch.allclose(x.grad, want[m])
+    # plain outputs next to tagged ones keep their gradients untouched
+    x, t = fresh()
+    z = torch.ones(4, dtype=torch.float64, requires_grad=True)
+    gz = torch.arange(4, dtype=torch.float64)
+    torch.autograd.backward([F.leaky_relu(t, 0.2), z * 2], [gy, gz])
+    assert torch.allclose(x.grad, want[m]) and torch.allclose(z.grad, 2 * gz)
+
+
+def test_in_place_functions_only_relay_what_they_write(monkeypatch):
+    """pure sources of an in-place function keep their storage and tag; aliases of a
+    re-laid storage lose the tag together; a tagged source that requires grad can be copied from."""
+    from dgl_amd import edge_order as E
+
+    _patched(monkeypatch)
+    torch.manual_seed(2)
+    Eg = 9
+    m = torch.randperm(Eg)
+    rel = _Rel(m)
+    eid_vals = torch.randn(Eg, 4, dtype=torch.float64)
+    # 1. buf.copy_(t.detach()): t's storage and tag are untouched, buf holds edge-id order
+    t = E.wrap(eid_vals[m].clone(), rel)
+    buf = torch.zeros(Eg, 4, dtype=torch.float64)
+    buf.copy_(t.detach())
+    assert torch.equal(buf, eid_vals)
+    assert E.tag_of(t) is rel and torch.equal(t.eid_order(), eid_vals)
+    # 2. order-preserving in-place on a tagged tensor with a tagged view: both stay right
+    a = E.wrap(eid_vals[m].clone(), rel)
+    b = a.view(Eg, 4, 1)
+    a.mul_(2)
+    assert E.tag_of(a) is rel and E.tag_of(b) is rel
+    assert torch.equal(a.eid_order(), eid_vals * 2) and torch.equal(b.eid_order(), (eid_vals * 2).view(Eg, 4, 1))
+    a *= 0.5
+    assert E.tag_of(a) is rel and torch.equal(b.eid_order(), eid_vals.view(Eg, 4, 1))
+    per_edge = torch.randn(Eg, 4, dtype=torch.float64)      # edge-id ordered operand: not order-preserving
+    a.add_(per_edge)
+    assert torch.equal(E.to_eid_order(a), eid_vals + per_edge)
+    assert torch.equal(E.to_eid_order(b), (eid_vals + per_edge).view(Eg, 4, 1))   # the alias follows
+    # 3. a non-order-preserving in-place write re-lays the storage: EVERY alias drops the tag
+    a = E.wrap(eid_vals[m].clone(), rel)
+    b = a.view(Eg, 4, 1)
+    d = a.detach()
+    a[3] = 0.0
+    ev = eid_vals.clone()
+    ev[3] = 0
+    for al, want in ((a, ev), (b, ev.view(Eg, 4, 1)), (d, ev)):
+        assert E.tag_of(al) is None and torch.equal(E.raw(al), want)
+    # 4. buf.copy_(t) with t requiring grad: t is only read
+    x = eid_vals[m].clone().requires_grad_(True)
+    t = F.relu(E.wrap(x, rel))
+    buf = torch.zeros(Eg, 4, dtype=torch.float64)
+    buf.copy_(t)
+    assert torch.equal(buf.detach(), F.relu(eid_vals)) and E.tag_of(t) is rel
+    # frame[:] = attn
+    frame = torch.zeros(Eg, 4, dtype=torch.float64)
+    frame[:] = t.detach()
+    assert torch.equal(frame, F.relu(eid_vals))
+    # out= with a tagged source
+    o = torch.empty(Eg, 4, dtype=torch.float64)
+    torch.add(t.detach(), per_edge, out=o)
+    assert torch.equal(o, F.relu(eid_vals) + per_edge)
+    # 5. tagged.copy_(plain per-edge tensor): the rows go in position order, the tag stays
+    a = E.wrap(torch.zeros(Eg, 4, dtype=torch.float64), rel)
+    a.copy_(per_edge)
+    assert E.tag_of(a) is rel and torch.equal(a.eid_order(), per_edge)
+
+
+def test_casts_and_tensor_bounds(monkeypatch):
+    """t.type(dtype) is a cast (keeps the tag), clamp with a per-edge tensor bound is
+    not order-preserving."""
+    from dgl_amd import edge_order as E
+
+    _patched(monkeypatch)
+    torch.manual_seed(3)
+    Eg = 8
+    m = torch.randperm(Eg)
+    rel = _Rel(m)
+    eid_vals = torch.randn(Eg, 2, dtype=torch.float64)
+    t = E.wrap(eid_vals[m].clone(), rel)
+    assert t.type() == "torch.DoubleTensor"
+    c = t.type(torch.float32)
+    assert torch.equal(E.to_eid_order(c), eid_vals.float())
+    c = t.type("torch.FloatTensor")
+    assert torch.equal(E.to_eid_order(c), eid_vals.float())
+    lo = torch.randn(Eg, 2, dtype=torch.float64)
+    assert torch.equal(E.to_eid_order(torch.clamp(t, min=lo)), torch.clamp(eid_vals, min=lo))
+    assert torch.equal(E.to_eid_order(t.clamp(lo, lo + 1)), eid_vals.clamp(lo, lo + 1))
+    assert torch.equal(E.to_eid_order(torch.clamp(t, min=torch.tensor(0.0, dtype=torch.float64))), eid_vals.clamp(min=0))
+    k = torch.clamp(t, min=0.0)
+    assert E.tag_of(k) is rel and torch.equal(k.eid_order(), eid_vals.clamp(min=0))

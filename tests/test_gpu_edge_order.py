@@ -199,3 +199,33 @@ def test_map_free_graphs_and_blocks_do_not_start_a_handoff(dev):
     if rel.csc()[2] is None:
         assert type(out) is torch.Tensor
     assert not E.wants_handoff(rel) or rel.csc()[2] is not None
+
+
+def test_explicit_gradient_and_inplace_sources_on_the_real_kernels(dev):
+    """``edge_softmax(g, s).backward(grad)`` with a NON-uniform explicit gradient, and
+    ``buf.copy_(attn)`` / ``frame[:] = attn`` with the hand-off on, equal the plain path."""
+    import dgl_amd as dgl
+    from dgl_amd import edge_order as E
+
+    g = _graph(dev, n=2000, e=30000, seed=3)
+    torch.manual_seed(5)
+    s0 = torch.randn(g.num_edges(), 4, 1, device=dev)
+    gy = torch.randn(g.num_edges(), 4, 1, device=dev)
+    res = {}
+    for on in (False, True):
+        dgl.set_edge_order_handoff(on)
+        try:
+            s = s0.clone().requires_grad_(True)
+            a = dgl.edge_softmax(g, F.leaky_relu(s, 0.2))
+            assert (type(a) is E.PosOrdered) == on
+            buf = torch.zeros_like(s0)
+            buf.copy_(a.detach())
+            frame = torch.zeros_like(s0)
+            frame[:] = a.detach()
+            a.backward(gy)
+            (g2,) = torch.autograd.grad(dgl.edge_softmax(g, F.leaky_relu(s, 0.2)), s, grad_outputs=gy)
+            res[on] = (E.to_eid_order(a).detach(), buf, frame, s.grad.clone(), g2)
+        finally:
+            dgl.set_edge_order_handoff(True)
+    for x, y, what in zip(res[True], res[False], ("attention", "copy_", "setitem", "backward(grad)", "grad(grad_outputs)")):
+        torch.testing.assert_close(x, y, rtol=2e-5, atol=2e-6, msg=lambda m: what + ": " + m)
