@@ -70,7 +70,7 @@ def run_spmm(dev, op, reduce, n_src, n_dst, src, dst, ufeat, efeat, idtype, use_
     if reduce == "sum" and ref.dtype == np.float32:
         f64 = lambda a: None if a is None else a.astype(np.float64)
         exact = oracle.spmm_csr(op, reduce, indptr, indices, eids, f64(ufeat), f64(efeat))[0]
-    maxdeg = int(np.diff(indptr).max()) if len(indptr) > 1 else 0
+    maxdeg = np.diff(indptr)   # per-row edge counts (the plain 1e-5 bar applies to rows under 1000 edges)
     t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     keep = (t(indptr), t(indices), t(eids))
     csr = _capi.make_csr(keep[0], keep[1], keep[2], n_src)
@@ -101,7 +101,7 @@ def check_spmm(res, reduce, dtype):
         if exact is not None:
             # flat 1e-5 against the exact sum; against the reference's sequential fp32 value
             # 1e-5 or "closer to exact than the reference is" (tests/tolerance.py)
-            assert_fp32_sum(out, ref, exact)
+            assert_fp32_sum(out, ref, exact, row_len=maxdeg if out.shape[0] == len(maxdeg) else None)
         else:
             np.testing.assert_allclose(out, ref, **_tol(dtype))
     else:

@@ -127,7 +127,7 @@ def test_sharded_schedule_with_simulated_ranks(dev, variant, k):
     deg = (g["indptr"][1:] - g["indptr"][:-1]).long()
     rows = torch.repeat_interleave(torch.arange(n, device=dev), deg)
     exact = torch.zeros(n, f, dtype=torch.float64, device=dev).index_add_(0, rows, x.double()[g["indices"].long()])
-    assert_fp32_sum(got.cpu().numpy(), ref, exact.cpu().numpy())
+    assert_fp32_sum(got.cpu().numpy(), ref, exact.cpu().numpy(), row_len=deg.cpu().numpy())
 
 
 def _probe(ws, n_rows, nnz):

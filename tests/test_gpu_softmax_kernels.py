@@ -64,7 +64,10 @@ def test_merge_softmax_against_oracle(dev, kind, dim, with_eids):
     # the reference adds a row's exponentials sequentially in fp32: on the 9000-edge hub its own
     # sum is ~1e-5 off; same rule as for the SpMM sums (tests/tolerance.py)
     exact = oracle.edge_softmax_fwd(indptr.astype(np.int32), eids, score.astype(np.float64))
-    assert_fp32_sum(out.cpu().numpy(), ref, exact, rtol=1e-5, atol=1e-7)
+    deg = np.diff(indptr)
+    edge_row_len = np.empty(e, dtype=np.int64)       # softmax output is per edge: its row's length
+    edge_row_len[np.arange(e) if eids is None else eids] = np.repeat(deg, deg)
+    assert_fp32_sum(out.cpu().numpy(), ref, exact, rtol=1e-5, atol=1e-7, row_len=edge_row_len)
     sds = (rng.standard_normal((e, dim))).astype(np.float32) * ref
     back = torch.full_like(x, float("nan"))
     _capi.edge_softmax_backward(csr, out, torch.from_numpy(sds).to(dev), back, ws, plan_valid=True)
