@@ -8,7 +8,11 @@ element passes when it is within 1e-5 of the reference's fp32 value OR at least 
 exact (fp64) sum as the reference's own value is — and it must ALWAYS be within 1e-5 of the exact
 sum, flat.  The escape only exists for long rows: where the caller gives the rows' lengths, every
 element of a row with fewer than SHORT_ROW edges must meet the PLAIN bar, 1e-5 of the reference's
-value (VERDICT r3 Next #1d)."""
+value (VERDICT r3 Next #1d).  SHORT_ROW = 500, not the 1000 the verdict suggested: measured on
+test_gpu_sharded's graph (40 k rows, U(0,1)+1 features, round 4), the REFERENCE's own sequential fp32
+sum is off the exact sum by up to 1.4e-6 on rows under 100 edges, 3.7e-6 (100-250), 5.7e-6 (250-500),
+7.9e-6 (500-750), 1.14e-5 (750-1000), 1.3e-5 (1000-2000): a result that is exact to 4e-7 misses "1e-5 of
+the reference" on 19 of 4 M elements, all on rows of 750-1000 edges."""
 import numpy as np
 
 
@@ -25,7 +29,7 @@ def max_rel_err(out, ref, floor=1e-30):
 LAST = {}  # plain figures of the most recent check (read by benchmarks / printed by failures)
 
 
-SHORT_ROW = 1000
+SHORT_ROW = 500
 
 
 def assert_fp32_sum(out, ref, exact, rtol=1e-5, atol=1e-6, row_len=None):
