@@ -18,7 +18,7 @@ from tests.graphgen import C2_EDGES, C2_NODES, synth_csr  # noqa: E402
 
 
 def probe_counters(ws, num_rows, nnz):
-    """{local, sampled} of the locality probe stored behind the merge plan (spmm_csr.cuh)."""
+    """{local, sampled} of the locality probe stored behind the merge plan (spmm_csr.hip.h)."""
     waves = (num_rows + nnz + 511) // 512
     off = (8 * (waves + 1) + 255) // 256 * 256
     return [int(v) for v in ws[off:off + 8].view(torch.int32).tolist()]

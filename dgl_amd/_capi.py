@@ -209,15 +209,14 @@ def set_profile_events(before, after):
         LIB.dgla_spmm_set_profile_events(before.cuda_event, after.cuda_event)
 
 
-(TUNE_XCD, TUNE_NT_OUT, TUNE_NT_IDX, TUNE_SPLIT, TUNE_GLDS, TUNE_SPLIT_NT, TUNE_SPLIT_FORCE, TUNE_MM_F32,
- TUNE_SPLIT_CLASSIC, TUNE_TAIL_PASS, TUNE_NT_STREAM) = (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024)  # include/dgl_amd.h DGLA_TUNE_*
+(TUNE_XCD, TUNE_NT_OUT, TUNE_NT_IDX, TUNE_SPLIT, TUNE_GLDS, TUNE_SPLIT_FORCE, TUNE_MM_F32) = (
+    1, 2, 4, 8, 16, 64, 128)  # include/dgl_amd.h DGLA_TUNE_*
 
 
 def set_tuning(flags):
     """Process-wide tuning bits (include/dgl_amd.h: DGLA_TUNE_*).  The SpMM bits XCD, NT_*, SPLIT*
-    never change result bits; TAIL_PASS changes the summation order of the last four columns of
-    F = 128 k / 4 + 4 fp32 sums on large graphs (and the workspace layout: plans do not survive a
-    change of it).  The matrix-multiply bits change bits too: DGLA_TUNE_GLDS contracts fp32 k in a
+    never change result bits (SPLIT changes the workspace layout: plans do not survive a change of
+    it).  The matrix-multiply bits do change bits: DGLA_TUNE_GLDS contracts fp32 k in a
     permuted order and DGLA_TUNE_MM_F32 selects the exact fp32 MFMA instead of the default
     three-term bf16 split (same fp32-level error bound, different low-order bits)."""
     check_call(LIB.dgla_set_tuning(int(flags)))

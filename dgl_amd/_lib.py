@@ -181,10 +181,8 @@ DGLA_MEAN = 4
 DGLA_SPLIT_VALID = 8
 DGLA_SPLIT_KEEP = 16
 DGLA_TUNE_XCD, DGLA_TUNE_NT_OUT, DGLA_TUNE_NT_IDX, DGLA_TUNE_SPLIT, DGLA_TUNE_GLDS = 1, 2, 4, 8, 16
-DGLA_TUNE_SPLIT_NT, DGLA_TUNE_SPLIT_FORCE, DGLA_TUNE_MM_F32, DGLA_TUNE_SPLIT_CLASSIC = 32, 64, 128, 256
-DGLA_TUNE_TAIL_PASS = 512
-DGLA_TUNE_NT_STREAM = 1024
-DEFAULT_TUNING = DGLA_TUNE_XCD | DGLA_TUNE_SPLIT | DGLA_TUNE_GLDS | DGLA_TUNE_NT_STREAM  # csrc/common.h kDefaultTuning
+DGLA_TUNE_SPLIT_FORCE, DGLA_TUNE_MM_F32 = 64, 128   # (32, 256, 512, 1024 were retired in round 4)
+DEFAULT_TUNING = DGLA_TUNE_XCD | DGLA_TUNE_SPLIT | DGLA_TUNE_GLDS  # csrc/common.h kDefaultTuning
 
 
 def check_call(ret):

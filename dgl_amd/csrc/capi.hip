@@ -122,7 +122,7 @@ static int analyse_bcast(int op, const std::vector<int64_t>& lhs, const std::vec
     return 0;
   }
   // right-align both shapes; for dot the last axis is the reduce axis and takes no part in
-  // the offsets, which are then counted in units of reduce_size (bcast.cc:50-54, sddmm.cuh).
+  // the offsets, which are then counted in units of reduce_size (bcast.cc:50-54, sddmm.hip.h).
   std::vector<int64_t> l = lhs, r = rhs;
   if (op == kDot) {
     if (l.empty() || r.empty() || l.back() != r.back())
@@ -684,6 +684,10 @@ int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla
 }
 
 int dgla_set_tuning(uint32_t flags) {
+  if (flags & ~kTuneKnown) {
+    last_error() = "dgla_set_tuning: unknown or retired tuning bit in " + std::to_string(flags);
+    return -1;
+  }
   tuning_flags() = flags;
   return 0;
 }

@@ -173,36 +173,28 @@ struct SddmmLaunch {
   hipStream_t stream;
 };
 
-// Tuning bits of the CSR SpMM (dgla_set_tuning / dgla_get_tuning).  None changes a result bit.
+// Tuning bits (dgla_set_tuning / dgla_get_tuning).  The SpMM bits change no result bit.  Round 4 removed
+// SPLIT_NT (32), SPLIT_CLASSIC (256), TAIL_PASS (512) and NT_STREAM (1024, now a fixed rule): the values
+// of the surviving bits are unchanged.
 enum Tune : uint32_t {
   kTuneXcd = 1u,    // XCD-contiguous unit order (one contiguous eighth of the merge path per L2)
   kTuneNtOut = 2u,  // non-temporal stores of finished output rows
   kTuneNtIdx = 4u,  // non-temporal loads of the index streams (indices / indptr / eids)
-  kTuneSplit = 8u,  // split-row re-layout of ufeat when rows are not a whole number of 128-B lines
+  kTuneSplit = 8u,  // side copies of the rows' ragged ends when rows are not a whole number of 128-B lines
   kTuneGlds = 16u,  // segment_mm: LDS-direct (global_load_lds) slab rings instead of register staging
-  kTuneSplitNt = 32u,     // split-row copy: non-temporal stores of the main array
-  kTuneSplitForce = 64u,  // split-row layout whenever the shape allows, whatever the locality probe says
+  kTuneSplitForce = 64u,  // split layouts whenever the shape allows, whatever the locality probe says
   kTuneMmF32 = 128u,      // segment_mm fp32: v_mfma_f32_32x32x2_f32 instead of the 3 x bf16 split
-  kTuneSplitClassic = 256u,  // split-row layout: copy WHOLE rows (main + tail arrays, round 2) instead of
-                             // the edge layout that leaves the line-aligned interior of every row in place
-  kTuneTailPass = 512u,      // copy_u + sum, fp32 rows of 128 k + 16 bytes: the 16-byte row tails are summed
-                             // by a column-sliced pass of their own (spmm_tail.hip); changes the summation
-                             // ORDER of the last four output columns (the only SpMM bit that touches a result
-                             // bit).  Opt-in: measured +2 % on the headline graph for +1 GB of workspace
-  kTuneNtStream = 1024u,     // copy_rhs over long rows (>= 64 edges on average) without an edge-id map — a
-                             // readout-like segment reduce: non-temporal loads of the rows
 };
+constexpr uint32_t kTuneKnown = 1u | 2u | 4u | 8u | 16u | 64u | 128u;
 // Default: XCD-contiguous order (measured on C2: variant L -3 % time, variant U neutral); the
-// non-temporal bits are neutral.  Split-row (profiles/r2/tune_split_ab.jsonl, C2, F = 100 fp32):
-// the copy costs 0.33 ms (5.9 TB/s) and the gather drops 4.86 -> 4.38 ms on variant U, so the
-// step gains 3 % even when the copy is repeated on every call and 10 % when the features are
-// static (DGLA_SPLIT_KEEP / _VALID); on variant L the locality probe (81 % local edges against
-// 5 % on U) declines it unless the features are static (4.08 -> 3.75 ms) -> on.  The LDS-direct
-// segment_mm loop is 23-34 % faster at every measured shape (profiles/r1/glds_ab.jsonl) -> on.
-constexpr uint32_t kDefaultTuning = 1u | 8u | 16u | 1024u;
+// non-temporal bits are neutral.  Split layouts (C2, F = 100 fp32): the edge-layout copy costs 0.10 ms
+// and the gather drops 4.86 -> 4.35 ms on variant U; on variant L the locality probe declines it only
+// when >= 15/16 of the sampled edges are local.  The LDS-direct segment_mm loop is 23-34 % faster at
+// every measured shape (profiles/r1/glds_ab.jsonl) -> on.
+constexpr uint32_t kDefaultTuning = 1u | 8u | 16u;
 uint32_t& tuning_flags();
 
-// Merge-path geometry of the CSR SpMM (see spmm_csr.cuh).
+// Merge-path geometry of the CSR SpMM (see spmm_csr.hip.h).
 constexpr int kWaveItems = 512;     // rows + edges handled by one wavefront
 constexpr int kWavesPerBlock = 4;   // 256-thread workgroups
 
@@ -211,30 +203,6 @@ inline int64_t spmm_num_waves(int64_t num_rows, int64_t nnz) {
 }
 
 std::string& last_error();
-
-// Column-sliced tail pass (spmm_tail.hip; geometry and call sites in spmm_csr.cuh).
-constexpr int kTailWaveItems = 256;  // merge items per wavefront of the tail kernel (it has its own plan)
-struct SpmmTailLaunch {
-  const int32_t* vptr;   // [slices * num_rows + 1] row pointers of the slice-major virtual CSR
-  const int32_t* tcol;   // [nnz] column ids in virtual-CSR order
-  const int64_t* plan;   // [num_waves + 1] merge plan of the virtual CSR
-  int64_t num_rows, nnz, num_waves;
-  int slices;
-  const void* s2;        // [num_cols] 16-byte row tails of ufeat
-  void* part;            // [slices * num_rows] 16-byte partial sums
-  int64_t* carry_row;    // [num_waves]
-  void* carry_val;       // [num_waves] 16 bytes
-  void* tail_val;        // [num_waves] 16 bytes
-  const unsigned* meta;  // the locality probe's counters (NULL: always run)
-  uint32_t tune;
-  hipStream_t stream;
-};
-size_t spmm_tail_build_scratch_bytes(int64_t nnz, int slices);
-int spmm_tail_build(const CsrView& csr, int slices, int32_t* vptr, int32_t* tcol, int64_t* plan,
-                    int64_t num_waves, char* scratch, hipStream_t s);
-int spmm_tail_launch(const SpmmTailLaunch& t);
-int spmm_tail_combine(const SpmmTailLaunch& t, void* out, int64_t out_len, const void* indptr, bool mean,
-                      bool accumulate);
 
 // Optional HIP events recorded around the dominant (merge) kernel of dgla_spmm_csr, so a
 // benchmark can time that kernel alone on the launch stream (dgla_spmm_set_profile_events).

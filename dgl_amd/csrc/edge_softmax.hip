@@ -218,7 +218,7 @@ template <typename Idx>
 __global__ void esm_plan_kernel(const Idx* __restrict__ indptr, int64_t num_rows, int64_t nnz,
                                 int64_t num_units, int64_t* __restrict__ plan, int64_t* __restrict__ planj) {
   // boundary w: the merge-path point (i, j) on the diagonal w * kEsmStride — i = largest row with
-  // indptr[i] + i <= d (see spmm_csr.cuh) — moved to the end of row i when the row is cut there
+  // indptr[i] + i <= d (see spmm_csr.hip.h) — moved to the end of row i when the row is cut there
   // and has at most kEsmSlack edges left
   const int64_t w = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (w > num_units) return;

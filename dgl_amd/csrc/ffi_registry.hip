@@ -205,10 +205,10 @@ struct UnitGraph {
 };
 
 // Is the merge plan in g->ws still the one the NEXT call expects?  The tuning bits that decide
-// the workspace layout (split-row layouts, the tail pass's slice structure next to the plan) are
+// the workspace layout (the split layouts) are
 // part of what a plan is: a change of any of them since the plan was built invalidates it.
 static bool plan_ok(UnitGraph* g) {
-  const uint32_t layout = tuning_flags() & (kTuneSplit | kTuneSplitClassic | kTuneTailPass);
+  const uint32_t layout = tuning_flags() & kTuneSplit;
   if (g->plan_tune != layout) {
     g->plan_valid = false;
     g->plan_tune = layout;

@@ -1,14 +1,14 @@
 // g-SDDMM for gfx950 (MI355X): edge-parallel kernels.
 //
 // Replaces, from scratch, SDDMMCooKernel / SDDMMCooTreeReduceKernel / SDDMMCsrKernel of the
-// reference (src/array/cuda/sddmm.cuh:97-256, hosts :287-362).
+// reference (src/array/cuda/sddmm.hip.h:97-256, hosts :287-362).
 //
 // Layout: a wavefront is split into G = 64 / LPE lane groups, LPE = lanes needed to cover one
 // output row with 16-byte accesses; consecutive groups take consecutive edges so the COO
 // index loads and (for eid == position) the output rows are contiguous across the wave.
 // `dot` keeps the whole (H, D) operand row in the group: every lane multiplies its 16-byte
 // piece and the D / VEC lanes of one head finish with xor-shuffles inside the 64-wide wave
-// (the reference's tree kernel hard-codes 32-lane warps, sddmm.cuh:88,146-185).
+// (the reference's tree kernel hard-codes 32-lane warps, sddmm.hip.h:88,146-185).
 #pragma once
 #include "common.h"
 
@@ -39,7 +39,7 @@ __device__ __forceinline__ int64_t sddmm_select(int target, int64_t src, int64_t
 }
 
 // Source row of CSR position j: largest r with indptr[r] <= j (the reference's
-// BinarySearchSrc, sddmm.cuh:188-204, restated as an upper-bound search).
+// BinarySearchSrc, sddmm.hip.h:188-204, restated as an upper-bound search).
 template <typename Idx>
 __device__ __forceinline__ int64_t csr_row_of(const Idx* __restrict__ indptr, int64_t num_rows,
                                               int64_t j) {

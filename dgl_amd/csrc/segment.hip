@@ -6,7 +6,7 @@
 //
 //  * segment reduce IS a g-SpMM: offsets are a CSR indptr whose "edges" are the rows of
 //    `feat` in place (copy_rhs, edge id == position), so it runs on the merge-path kernel of
-//    spmm_csr.cuh — one wavefront per 512 items whatever the segment lengths — instead of
+//    spmm_csr.hip.h — one wavefront per 512 items whatever the segment lengths — instead of
 //    the reference's one-block-per-segment loop.  Only difference from g-SpMM: arg of an
 //    element nothing won is -1 (segment_reduce.cuh:39, cpu/segment_reduce.h:66), not 0.
 //  * scatter add: out[idx[i], :] += feat[i, :].  Small inputs: hardware float atomics, 16-byte

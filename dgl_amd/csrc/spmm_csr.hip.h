@@ -48,15 +48,16 @@ struct SpmmParams {
   int rhs_group;  // kBcRhsGroup
   BcastDims bd;   // kBcGeneral
   int accumulate;
+  int rhs_neg, rhs_div;  // sub / div on the add / mul instantiations
+  int red_min;           // min on the max instantiation
   int arg_empty;  // arg_u / arg_e of an output element no edge won: 0 (g-SpMM) or -1 (segment reduce)
   int mean;       // reduce == sum only: divide every row by max(its edge count, 1) before storing
   uint32_t tune;  // kTune* bits (common.h)
-  // split-row layout of ufeat (kTuneSplit, see spmm_split_rows_kernel): features
-  // [0, split_main) of every row live in `umain` with pitch split_main, the rest in `utail`
-  // with pitch split_tail; `ufeat` stays the caller's tensor.  split_main == 0: plain layout.
+  // split layouts of ufeat (kTuneSplit): side copies of the parts of every row that make a gather
+  // touch one 128-byte line too many; `ufeat` stays the caller's tensor.  split_main == 0: plain layout.
   // `split_meta` (device, may be NULL = always): the locality probe's counters {local, sampled}
-  // — the split copy is made and used only when the graph is not in a locality-preserving order
-  // (split_wanted(): fewer than 15/16 of the sampled edges local for the cheap layouts, 1/2 for the classic one).
+  // — the side copy is made and used only when the graph is not in a locality-preserving order
+  // (split_wanted(): fewer than 15/16 of the sampled edges local).
   const void* umain;
   const void* utail;
   const unsigned* split_meta;
@@ -72,9 +73,6 @@ struct SpmmParams {
   // than ceil(RB / 128) and is gathered from its line-aligned copy in `umain` (pitch split_main)
   int split_straddle_slack;  // -1: not in use
   int split_row_bytes, split_base_bytes;
-  // column-sliced tail pass (spmm_tail.hip): the lanes that would gather the 16-byte row tails sit
-  // this launch out — the last four output columns are produced by that pass
-  int tail_pass;
   // stacked multi-relation form (MULTI kernels only)
   const uint8_t* rel;
   const void* const* xtab;
@@ -181,67 +179,24 @@ __device__ __forceinline__ VecT<DT, VEC> load_global(const DT* src) {
   return v;
 }
 
-// Split-row re-layout (kTuneSplit).  A feature row of RB bytes that is not a multiple of the
-// 128-byte L2 line straddles ceil-ish(RB / 128) + 1 lines when gathered (F = 100 fp32: 400 B
-// -> always 4 lines = 512 B of fabric traffic per edge).  Copying X once per call into a
-// line-aligned MAIN array (pitch = RB rounded down to 128 B) and a dense TAIL array (pitch =
-// the remainder, small enough to live in the Infinity Cache) turns the gather into
-// RB_main / 128 full lines plus one cached access: 2 N RB bytes of streaming traffic buy
-// 128 B x E of gather traffic.  One thread moves K 16-byte pieces (K loads in flight); the row
-// of a piece comes from one block-uniform 64-bit division plus a 32-bit multiply-high by
-// ceil(2^32 / pieces) (exact for the < 2^16 block-local piece numbers that occur).
+// Split layouts (kTuneSplit).  A feature row of RB bytes that is not a multiple of the 128-byte L2
+// line straddles one line more than ceil(RB / 128) when gathered (F = 100 fp32: 400 B -> always 4
+// lines = 512 B of fabric traffic per edge).  Two side copies remove the extra line: the EDGE layout
+// (16-byte lanes, rows of two or more whole lines) and the STRADDLE layout (8-byte lanes).  Round 2's
+// whole-row copy ("classic" layout) and round 3's column-sliced tail pass were measured and removed in
+// round 4 (DESIGN.md §3.1 keeps the numbers: classic 0.33 ms of copy against the edge layout's 0.10;
+// tail pass -5 % .. +3.5 %).
 typedef uint32_t piece16_t __attribute__((ext_vector_type(4)));
 
-// Should this launch use the split copy?  (device side; uniform)  `cheap`: the layouts that copy only
-// the rows' ragged ends (edge layout: 0.10 ms on C2) or only the straddling rows — with them the copy
-// pays for itself even on a graph in community order (variant L, 81 % of the sampled edges local:
-// 3.81 ms with the copy against 4.03 ms without), so it is declined only when practically every
-// gather stays inside the window (>= 15/16 local); the whole-row copy of the classic layout
-// (0.33 ms) keeps round 2's rule of one half.
-__device__ __forceinline__ bool split_wanted(const unsigned* __restrict__ meta, bool cheap = false) {
+// Should this launch use the side copy?  (device side; uniform)  The copies move only the rows' ragged
+// ends (edge layout: 0.10 ms on C2) or only the straddling rows — they pay for themselves even on a
+// graph in community order (variant L, 81 % of the sampled edges local: 3.81 ms with the copy against
+// 4.03 ms without), so the copy is declined only when practically every gather stays inside the
+// window (>= 15/16 local).
+__device__ __forceinline__ bool split_wanted(const unsigned* __restrict__ meta) {
   if (meta == nullptr) return true;
   const unsigned local = meta[0], sampled = meta[1];
-  return cheap ? 16u * local < 15u * sampled : 2u * local < sampled;
-}
-
-template <int K>
-__global__ __launch_bounds__(256) void spmm_split_rows_kernel(
-    const piece16_t* __restrict__ x, piece16_t* __restrict__ main_out,
-    piece16_t* __restrict__ tail_out, int64_t num_rows, int pieces, int main_pieces,
-    unsigned magic, const unsigned* __restrict__ meta, int nt_main) {
-  if (!split_wanted(meta)) return;
-  const int64_t total = num_rows * pieces;
-  const int tail_pieces = pieces - main_pieces;
-  for (int64_t base = static_cast<int64_t>(blockIdx.x) * (256 * K); base < total;
-       base += static_cast<int64_t>(gridDim.x) * (256 * K)) {
-    const int64_t r0 = base / pieces;
-    const unsigned j0 = static_cast<unsigned>(base - r0 * pieces);
-    piece16_t v[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      int64_t i = base + k * 256 + threadIdx.x;
-      if (i >= total) i = total - 1;
-      v[k] = __builtin_nontemporal_load(x + i);  // read once
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int64_t i = base + k * 256 + threadIdx.x;
-      if (i >= total) continue;
-      const unsigned loc = j0 + static_cast<unsigned>(k * 256) + threadIdx.x;
-      const unsigned dr = __umulhi(loc, magic);
-      const unsigned j = loc - dr * static_cast<unsigned>(pieces);
-      const int64_t r = r0 + dr;
-      if (j < static_cast<unsigned>(main_pieces)) {
-        piece16_t* dst = main_out + r * main_pieces + j;
-        if (nt_main)
-          __builtin_nontemporal_store(v[k], dst);  // far larger than the caches: stream it
-        else
-          *dst = v[k];
-      } else {
-        tail_out[r * tail_pieces + (j - main_pieces)] = v[k];  // small: keep it cached
-      }
-    }
-  }
+  return 16u * local < 15u * sampled;
 }
 
 // Edge layout (round 3; default for rows of 128 k + t bytes with k >= 2).  Row r of X starts at byte
@@ -260,7 +215,7 @@ __global__ __launch_bounds__(256) void spmm_split_edges_kernel(
     const piece16_t* __restrict__ x, piece16_t* __restrict__ s1, piece16_t* __restrict__ s2,
     int64_t num_rows, int row_pieces, int t16, int interior_pieces, unsigned magic,
     const unsigned* __restrict__ meta, unsigned base16) {
-  if (!split_wanted(meta, true)) return;
+  if (!split_wanted(meta)) return;
   const int side = 8 + t16;
   const int64_t total = num_rows * side;
   for (int64_t base = static_cast<int64_t>(blockIdx.x) * (256 * K); base < total;
@@ -308,7 +263,7 @@ template <int UNUSED>  // (a template so that the header can be included by seve
 __global__ __launch_bounds__(256) void spmm_straddle_rows_kernel(
     const piece8_t* __restrict__ x, piece8_t* __restrict__ side, int64_t num_rows, int row_pieces,
     int pitch_pieces, int slack, unsigned base_bytes, const unsigned* __restrict__ meta) {
-  if (!split_wanted(meta, true)) return;
+  if (!split_wanted(meta)) return;
   const int64_t total = num_rows * row_pieces;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += stride) {
@@ -381,8 +336,11 @@ __device__ __forceinline__ typename Acc<DT>::type round_to_storage(typename Acc<
 // relations sharing a destination type, src/array/cuda/spmm_hetero.cu:150-158, fused into
 // one launch): every edge carries its relation id, and the relation's operand base pointers
 // are staged in LDS next to the column ids, so the gather loop reads (column, base) pairs.
-template <typename Idx, typename DT, int VEC, int OP, int RED, int BC, int U, bool ACCUM,
-          bool MULTI = false, bool NTR = false>
+// `sub` and `div` are run-time variants of the add / mul instantiations (p.rhs_neg: l + (-r), exact;
+// p.rhs_div: l / r instead of l * r) and `accumulate` is a run-time switch of the row store — a third
+// of the code objects for wave-uniform scalar branches (round 4).
+template <typename Idx, typename DT, int VEC, int OP, int RED, int BC, int U, bool MULTI = false,
+          bool NTR = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
     const SpmmParams<Idx> p) {
   using A = typename Acc<DT>::type;
@@ -429,7 +387,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   const int64_t w = static_cast<int64_t>(blk) * kWavesPerBlock + wib;
   const bool has_eid = p.eids != nullptr;
   const bool nt_idx = (p.tune & kTuneNtIdx) != 0;
-  // NTR (kTuneNtStream; copy_rhs over long rows without an edge-id map, i.e. a readout-like segment reduce):
+  // NTR (spmm_nt_stream(): copy_rhs over long rows without an edge-id map, i.e. a readout-like segment reduce):
   // the edge operand is loaded non-temporally.  A compile-time switch: selecting the load flavour per load at run
   // time put a branch between the prefetch loads and made the compiler drain them (vmcnt(0)) before
   // every reduction instead of waiting with a count.
@@ -544,7 +502,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   if constexpr (BC == kBcGeneral) bcast_offsets(p.bd, k0, &lo_off, &ro_off);
   const DT* __restrict__ X = static_cast<const DT*>(p.ufeat) + lo_off;
   const DT* __restrict__ Wt = static_cast<const DT*>(p.efeat) + ro_off;
-  int64_t lhs_len = p.lhs_len;
+  const int64_t lhs_len = p.lhs_len;
   const int64_t rhs_len = p.rhs_len;
   // edge layout (wave-uniform switch): per-lane constants of the address select in load_batch
   constexpr int E16 = 16 / static_cast<int>(sizeof(DT));  // elements per 16-byte piece
@@ -555,9 +513,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   [[maybe_unused]] const DT* e_side = nullptr;
   bool straddle = false;  // (wave-uniform)
   if (p.split_main > 0 && p.split_straddle_slack >= 0) {
-    if constexpr (UL && !MULTI && VEC * sizeof(DT) == 8) straddle = split_wanted(p.split_meta, true);
-  } else if (p.split_main > 0 && split_wanted(p.split_meta, p.split_edge_lines > 0)) {
-    if (p.split_edge_lines > 0) {
+    if constexpr (UL && !MULTI && VEC * sizeof(DT) == 8) straddle = split_wanted(p.split_meta);
+  } else if (p.split_main > 0 && p.split_edge_lines > 0 && split_wanted(p.split_meta)) {
+    {
       if constexpr (UL && !MULTI && VEC * sizeof(DT) == 16) {
         edge_layout = true;
         const int j = lo_off / E16, rp = p.lhs_len / E16;
@@ -574,16 +532,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
           e_piece_hi = (j - 8 * p.split_edge_lines) * E16;
         }
       }
-    } else if (lo_off < p.split_main) {
-      // classic split-row layout: this lane's piece lives in the main or the tail array
-      X = static_cast<const DT*>(p.umain) + lo_off;
-      lhs_len = p.split_main;
-    } else {
-      X = static_cast<const DT*>(p.utail) + (lo_off - p.split_main);
-      lhs_len = p.split_tail;
     }
   }
-  if (edge_layout && p.tail_pass && ej == 0x40000000u) return;  // the tail pass owns these columns
   [[maybe_unused]] const unsigned e_in_place = 8u * static_cast<unsigned>(p.split_edge_lines);
   [[maybe_unused]] const unsigned e_t16 = static_cast<unsigned>(p.split_t16);
   [[maybe_unused]] const unsigned e_base16 = static_cast<unsigned>(p.split_base16);
@@ -653,7 +603,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
 
   A acc[VEC];
   int best[ARG ? VEC : 1];
-  const A ident = red_identity<DT>(RED);
+  // RED is kSum or kMax; the kMax instantiation also runs min (p.red_min: wave-uniform compare direction)
+  const A ident = red_identity<DT>(RED == kSum ? kSum : (p.red_min ? kMin : kMax));
+  [[maybe_unused]] const bool red_min = p.red_min != 0;
   int cnt = 0;
   auto reset = [&]() {
 #pragma unroll
@@ -707,7 +659,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
     } else {
       DT* o = out + row * F + k0;
       VecT<DT, VEC> ov;
-      if constexpr (ACCUM) {
+      if (p.accumulate) {
         ov = *reinterpret_cast<VecT<DT, VEC>*>(o);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(to_acc<DT>(ov.v[v]) + acc[v]);
@@ -742,6 +694,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
 
   int t = t_s;
   int next_end = (t < R) ? rend[t + 1] : 0x7fffffff;
+  [[maybe_unused]] const bool rhs_neg = p.rhs_neg != 0, rhs_div = p.rhs_div != 0;
 
   auto reduce_batch = [&](int e, const Batch& b) {
 #pragma unroll
@@ -758,16 +711,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
           A l = A(0), r = A(0);
           if constexpr (UL) l = to_acc<DT>(b.x[u].v[v]);
           if constexpr (UR) r = to_acc<DT>(b.w[u].v[RV == 1 ? 0 : v]);
-          const A val = round_to_storage<DT>(apply_op<OP, A>(l, r));
+          A raw;
+          if constexpr (OP == kAdd)
+            raw = l + (rhs_neg ? -r : r);     // sub: l + (-r) == l - r bit for bit
+          else if constexpr (OP == kMul)
+            raw = rhs_div ? l / r : l * r;    // (wave-uniform)
+          else
+            raw = apply_op<OP, A>(l, r);
+          const A val = round_to_storage<DT>(raw);
           if constexpr (RED == kSum) {
             acc[v] += val;
-          } else if constexpr (RED == kMax) {
-            if (acc[v] < val) {
-              acc[v] = val;
-              best[v] = ee;
-            }
           } else {
-            if (acc[v] > val) {
+            if (red_min ? acc[v] > val : acc[v] < val) {  // strict, as the reference (functor.cuh:246-254)
               acc[v] = val;
               best[v] = ee;
             }
@@ -820,7 +775,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
           if (began_here) {
             DT* o = out + (i0 + tail_t) * F + k0;
             VecT<DT, VEC> ov;
-            if constexpr (ACCUM) {
+            if (p.accumulate) {
               ov = *reinterpret_cast<VecT<DT, VEC>*>(o);
 #pragma unroll
               for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(to_acc<DT>(ov.v[v]) + tot[v]);
@@ -913,12 +868,10 @@ __global__ __launch_bounds__(64) void spmm_csr_fixup_kernel(const SpmmParams<Idx
     // slot s2 holds the tail (the group in which the row ends); it always exists because a
     // row with a carry has its row-end item in a later slot.
     const int F = p.out_len;
-    // columns owned by the tail pass (same device-side decision as the merge kernel)
-    const int Fk = (p.tail_pass && p.split_main > 0 && split_wanted(p.split_meta, true)) ? F - p.split_tail : F;
     const A* cv = static_cast<const A*>(p.carry_val);
     const A* tv = static_cast<const A*>(p.tail_val);
     DT* out = static_cast<DT*>(p.out);
-    for (int k = threadIdx.x; k < Fk; k += 64) {
+    for (int k = threadIdx.x; k < F; k += 64) {
       A acc = cv[s * F + k];
       Idx au = 0, ae = 0;
       if constexpr (ARG) {
@@ -929,7 +882,7 @@ __global__ __launch_bounds__(64) void spmm_csr_fixup_kernel(const SpmmParams<Idx
         if constexpr (RED == kSum) {
           acc += val;
         } else {
-          const bool take = (RED == kMax) ? (acc < val) : (acc > val);
+          const bool take = p.red_min ? (acc > val) : (acc < val);
           if (take) {
             acc = val;
             if constexpr (UL) au = pu[idx];
@@ -983,34 +936,7 @@ struct SpmmGeometry {
   size_t off_split_main, off_split_tail;
   int split_edge_lines;  // > 0: edge layout (main = one 128-byte side line per row, k - 1 lines stay in place)
   bool split_straddle;   // straddle layout (8-byte lanes): main = line-aligned row slots of pitch split_main_bytes
-  // column-sliced tail pass (spmm_tail.hip).  tail_slices > 0: the workspace of this graph holds,
-  // next to the merge plan and as long-lived as it, the slice-major virtual CSR (vptr / col) and
-  // its merge plan; tail_pass: THIS call's shape uses it (partial sums + fix-up slots in the scratch)
-  int tail_slices;
-  bool tail_pass;
-  int64_t tail_waves;
-  size_t off_tail_vptr, off_tail_col, off_tail_plan, off_tail_part, off_tail_crow, off_tail_cval,
-      off_tail_tval, off_tail_scratch;
 };
-
-// Graph-level eligibility of the tail pass and its slice count (0 = none).  Depends on the CSR and
-// the tuning bits only — never on the operator or the feature shape — because the structure is
-// built with the merge plan and must sit at the same place for every later call on the workspace.
-// Slices of ~2.5 MB of 16-byte tails (a 4 MiB L2 minus the streams that pass through it).
-inline int spmm_tail_slices(const SpmmLaunch& L) {
-  if (!(L.tune & kTuneTailPass) || !(L.tune & kTuneSplit) || (L.tune & kTuneSplitClassic)) return 0;
-  if (L.rel != nullptr || L.csr.idbits != 32 || L.csr.indices == nullptr) return 0;
-  if (L.csr.nnz >= (int64_t(1) << 31) || L.csr.nnz < 4 * L.csr.num_cols) return 0;
-  // (both knobs are read per call so that tests can exercise small graphs and many slice counts)
-  const char* emin = getenv("DGLA_TAIL_MIN_COLS");
-  const int64_t min_cols = emin && atoll(emin) > 0 ? atoll(emin) : (int64_t(1) << 20);
-  if (L.csr.num_cols < min_cols) return 0;  // tails of under 16 MB: half of them hit in L2 anyway
-  const char* ekb = getenv("DGLA_TAIL_SLICE_KB");
-  const int64_t slice_bytes = (ekb && atoll(ekb) > 0 ? atoll(ekb) : 2560) << 10;
-  const int64_t s = (L.csr.num_cols * 16 + slice_bytes - 1) / slice_bytes;
-  if (s > 32) return 0;  // partial sums of S x rows x 16 bytes: past this the pass costs what it saves
-  return static_cast<int>(s < 2 ? 2 : s);
-}
 
 // Half-width, in rows, of the window the locality probe counts as "local": 2 x 64 Ki rows of
 // 400 bytes = 52 MB, a fifth of the 256 MiB Infinity Cache.
@@ -1041,7 +967,9 @@ inline bool spmm_split_shape_ok(const SpmmLaunch& L, size_t elem_bytes) {
     // 8-byte-aligned rows (straddle layout): only worth it when rows can straddle an extra line at
     // all, i.e. the slack is smaller than the largest start offset (120)
     const int64_t slack = (rb + 127) / 128 * 128 - rb;
-    if (slack >= 120 || (L.tune & kTuneSplitClassic)) return false;
+    if (slack >= 120) return false;
+  } else if (rb < 256) {
+    return false;  // edge layout: rows of two or more whole lines (a 144 .. 240-byte row touches 2 lines either way)
   }
   // pays off only when rows are re-read (average in-degree) and X does not fit the caches
   if (L.csr.nnz < 4 * L.csr.num_cols) return false;
@@ -1053,8 +981,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len, int vec,
                                   size_t acc_bytes, int idbytes, bool with_arg,
-                                  int64_t split_rows = 0, int64_t split_row_bytes = 0,
-                                  bool edge_layout = false, int tail_slices = 0, bool tail_pass = false) {
+                                  int64_t split_rows = 0, int64_t split_row_bytes = 0) {
   SpmmGeometry g;
   g.vec = vec;
   int64_t lanes = (out_len + vec - 1) / vec;
@@ -1085,21 +1012,6 @@ inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len
   off = align_up(off + sizeof(int64_t) * (g.num_waves + 1), 256);
   g.off_meta = off;  // locality probe counters {local, sampled}; lives and dies with the plan
   off += 256;
-  g.tail_slices = tail_slices;
-  g.tail_pass = false;
-  g.tail_waves = 0;
-  g.off_tail_vptr = g.off_tail_col = g.off_tail_plan = off;
-  if (tail_slices > 0) {  // long-lived like the plan: before anything whose size depends on the call
-    const int64_t vrows = num_rows * tail_slices;
-    g.tail_waves = (vrows + nnz + kTailWaveItems - 1) / kTailWaveItems;
-    g.off_tail_vptr = off;
-    off = align_up(off + sizeof(int32_t) * (vrows + 1), 256);
-    g.off_tail_col = off;
-    off = align_up(off + sizeof(int32_t) * nnz, 256);
-    g.off_tail_plan = off;
-    off = align_up(off + sizeof(int64_t) * (g.tail_waves + 1), 256);
-  }
-  g.off_tail_scratch = off;  // everything from here on is per-call scratch
   g.off_carry_row = off;
   off = align_up(off + sizeof(int64_t) * g.num_slots, 256);
   g.off_carry_val = off;
@@ -1125,33 +1037,14 @@ inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len
     g.off_split_main = g.off_split_tail = off;
     off = align_up(off + static_cast<size_t>(split_rows) * g.split_main_bytes, 256);
     g.off_split_tail = off;
-  } else if (split_rows > 0) {
-    g.split_main_bytes = static_cast<int>(split_row_bytes / 128 * 128);
-    g.split_tail_bytes = static_cast<int>(split_row_bytes - g.split_main_bytes);
-    if (edge_layout && split_row_bytes >= 256) {  // rows of two or more whole lines: copy the ragged ends only
-      g.split_edge_lines = g.split_main_bytes / 128 - 1;
-      g.split_main_bytes = 128;                   // the side line of a row
-    }
+  } else if (split_rows > 0) {  // edge layout (rows of two or more whole lines): copy the ragged ends only
+    g.split_tail_bytes = static_cast<int>(split_row_bytes % 128);
+    g.split_edge_lines = static_cast<int>(split_row_bytes / 128) - 1;
+    g.split_main_bytes = 128;  // the side line of a row
     g.off_split_main = off;
     off = align_up(off + static_cast<size_t>(split_rows) * g.split_main_bytes, 256);
     g.off_split_tail = off;
     off = align_up(off + static_cast<size_t>(split_rows) * g.split_tail_bytes, 256);
-  }
-  g.off_tail_part = g.off_tail_crow = g.off_tail_cval = g.off_tail_tval = off;
-  if (tail_slices > 0 && tail_pass && g.split_edge_lines > 0 && g.split_tail_bytes == 16) {
-    g.tail_pass = true;
-    g.off_tail_part = off;
-    off = align_up(off + size_t(16) * num_rows * tail_slices, 256);
-    g.off_tail_crow = off;
-    off = align_up(off + sizeof(int64_t) * g.tail_waves, 256);
-    g.off_tail_cval = off;
-    off = align_up(off + size_t(16) * g.tail_waves, 256);
-    g.off_tail_tval = off;
-    off = align_up(off + size_t(16) * g.tail_waves, 256);
-  }
-  if (tail_slices > 0) {  // the one-time build borrows the per-call scratch
-    const size_t need = g.off_tail_scratch + spmm_tail_build_scratch_bytes(nnz, tail_slices);
-    if (off < need) off = need;
   }
   g.total = off;
   return g;
@@ -1187,33 +1080,7 @@ inline int launch_plan(const SpmmLaunch& L, const SpmmGeometry& g) {
                        L.csr.num_cols, L.csr.nnz, g.num_waves, stride, window, meta, g.wave_items);
     DGLA_CHECK_HIP(hipGetLastError());
   }
-  if (g.tail_slices > 0)
-    return spmm_tail_build(L.csr, g.tail_slices, reinterpret_cast<int32_t*>(ws + g.off_tail_vptr),
-                           reinterpret_cast<int32_t*>(ws + g.off_tail_col),
-                           reinterpret_cast<int64_t*>(ws + g.off_tail_plan), g.tail_waves,
-                           ws + g.off_tail_scratch, L.stream);
   return 0;
-}
-
-inline SpmmTailLaunch make_tail_launch(const SpmmLaunch& L, const SpmmGeometry& g, const unsigned* meta) {
-  char* ws = static_cast<char*>(L.workspace);
-  SpmmTailLaunch t;
-  t.vptr = reinterpret_cast<const int32_t*>(ws + g.off_tail_vptr);
-  t.tcol = reinterpret_cast<const int32_t*>(ws + g.off_tail_col);
-  t.plan = reinterpret_cast<const int64_t*>(ws + g.off_tail_plan);
-  t.num_rows = L.csr.num_rows;
-  t.nnz = L.csr.nnz;
-  t.num_waves = g.tail_waves;
-  t.slices = g.tail_slices;
-  t.s2 = ws + g.off_split_tail;
-  t.part = ws + g.off_tail_part;
-  t.carry_row = reinterpret_cast<int64_t*>(ws + g.off_tail_crow);
-  t.carry_val = ws + g.off_tail_cval;
-  t.tail_val = ws + g.off_tail_tval;
-  t.meta = meta;
-  t.tune = L.tune;
-  t.stream = L.stream;
-  return t;
 }
 
 template <typename Idx, typename DT>
@@ -1240,6 +1107,9 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.rhs_group = L.rhs_group > 0 ? L.rhs_group : 1;
   p.bd = L.bdims;
   p.accumulate = L.accumulate ? 1 : 0;
+  p.rhs_neg = L.op == kSub ? 1 : 0;
+  p.rhs_div = L.op == kDiv ? 1 : 0;
+  p.red_min = L.red == kMin ? 1 : 0;
   p.arg_empty = L.arg_empty;
   p.mean = L.mean ? 1 : 0;
   p.tune = L.tune;
@@ -1268,7 +1138,6 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
     p.split_t16 = g.split_tail_bytes / 16;
     p.split_base16 = static_cast<int>((reinterpret_cast<uintptr_t>(L.ufeat) & 127u) >> 4);
   }
-  p.tail_pass = g.tail_pass ? 1 : 0;
   p.rel = static_cast<const uint8_t*>(L.rel);
   p.xtab = L.ufeat_tab;
   p.wtab = L.efeat_tab;
@@ -1287,12 +1156,12 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
 // Gathers in flight per lane (x2 with the prefetched batch).
 constexpr int kSpmmUnroll = 4;
 
-// kTuneNtStream: copy_rhs without an edge-id map and with LONG rows (>= 64 edges on average, e.g. a graph
+// Non-temporal edge-operand stream: copy_rhs without an edge-id map and with LONG rows (>= 64 edges on average, e.g. a graph
 // readout).  Interleaved A/B (profiles/r3/nt_stream_ab.jsonl, 15.5 M rows x 400 B): 64 segments sum -8 %,
 // max -5 %; 612 k segments (25 rows each) sum -2 %, max +9 %; 2.4 M segments (6 rows each) +7 % / +10 %:
 // next to many output rows the non-temporal stream loses.
 inline bool spmm_nt_stream(const SpmmLaunch& L) {
-  return (L.tune & kTuneNtStream) && L.csr.eids == nullptr && L.csr.nnz >= 64 * L.csr.num_rows;
+  return L.csr.eids == nullptr && L.csr.nnz >= 64 * L.csr.num_rows;
 }
 
 template <typename Idx, typename DT, int VEC, int OP, int RED, int BC>
@@ -1326,21 +1195,6 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
                        t16, 8 * g.split_edge_lines, magic, p.split_meta,
                        static_cast<unsigned>(p.split_base16));
     DGLA_CHECK_HIP(hipGetLastError());
-  } else if (g.split_main_bytes > 0 && !L.split_valid) {
-    char* ws = static_cast<char*>(L.workspace);
-    const int pieces = (g.split_main_bytes + g.split_tail_bytes) / 16;
-    const int64_t total = L.csr.num_cols * pieces;
-    constexpr int K = 4;
-    const unsigned sblocks =
-        static_cast<unsigned>(std::min<int64_t>((total + 256 * K - 1) / (256 * K), int64_t(1) << 20));
-    const unsigned magic = 0xFFFFFFFFu / static_cast<unsigned>(pieces) + 1u;
-    hipLaunchKernelGGL(spmm_split_rows_kernel<K>, dim3(sblocks), dim3(256), 0, L.stream,
-                       static_cast<const piece16_t*>(L.ufeat),
-                       reinterpret_cast<piece16_t*>(ws + g.off_split_main),
-                       reinterpret_cast<piece16_t*>(ws + g.off_split_tail), L.csr.num_cols, pieces,
-                       g.split_main_bytes / 16, magic, p.split_meta,
-                       (L.tune & kTuneSplitNt) ? 1 : 0);
-    DGLA_CHECK_HIP(hipGetLastError());
   }
   // dynamic LDS: the unit's edge ids, only when the operator reads edge features through a map
   const unsigned dyn_lds = (op_uses_rhs(OP) && L.csr.eids != nullptr)
@@ -1348,69 +1202,44 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
                                : 0u;
   const ProfileEvents pe = profile_events();
   if (pe.before) DGLA_CHECK_HIP(hipEventRecord(pe.before, L.stream));
-  if (g.tail_pass) {
-    // the row tails first (their side array was written a moment ago): tail kernel + its fix-up;
-    // the combine pass follows the main kernel.  With profile events set, the bracket covers
-    // all of it — the pair is one operator.
-    if (spmm_tail_launch(make_tail_launch(L, g, p.split_meta))) return -1;
-  }
   if (L.rel != nullptr) {
     // stacked multi-relation launch: the operator subset the fused hetero path uses
-    if constexpr (RED == kSum && (OP == kCopyLhs || OP == kCopyRhs || OP == kMul) &&
-                  BC != kBcGeneral) {
-      if (L.accumulate)
-        hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, true, true>),
-                           dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
-      else
-        hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false, true>),
-                           dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
-    } else if constexpr ((OP == kCopyLhs || OP == kCopyRhs || OP == kMul) && BC != kBcGeneral) {
-      // max / min over the stacked edges: earlier relations win ties, like the reference's
-      // running compare relation by relation (spmm.cuh:552-606); arg_e receives stacked positions
-      hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false, true>),
+    if constexpr ((OP == kCopyLhs || OP == kCopyRhs || OP == kMul) && BC != kBcGeneral) {
+      if (L.op == kDiv) {
+        last_error() = "stacked SpMM supports copy_lhs / copy_rhs / mul only";
+        return -1;
+      }
+      // (max / min over the stacked edges: earlier relations win ties, like the reference's running
+      // compare relation by relation, spmm.cuh:552-606; arg_e receives stacked positions)
+      hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, true>),
                          dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
-      DGLA_CHECK_HIP(hipGetLastError());
-      if (pe.after) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
-      hipLaunchKernelGGL((spmm_csr_fixup_kernel<Idx, DT, OP, RED, true>),
-                         dim3(static_cast<unsigned>(std::min<int64_t>(g.num_slots, int64_t(1) << 24))),
-                         dim3(64), 0, L.stream, p, g.num_slots);
-      DGLA_CHECK_HIP(hipGetLastError());
-      return 0;
+      if constexpr (RED != kSum) {
+        DGLA_CHECK_HIP(hipGetLastError());
+        if (pe.after) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
+        hipLaunchKernelGGL((spmm_csr_fixup_kernel<Idx, DT, OP, RED, true>),
+                           dim3(static_cast<unsigned>(std::min<int64_t>(g.num_slots, int64_t(1) << 24))),
+                           dim3(64), 0, L.stream, p, g.num_slots);
+        DGLA_CHECK_HIP(hipGetLastError());
+        return 0;
+      }
     } else {
       last_error() = "stacked SpMM supports copy_lhs / copy_rhs / mul only";
       return -1;
     }
-  } else if constexpr (RED == kSum) {
-    if (L.accumulate)
-      hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, true>),
-                         dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
-    else if (OP == kCopyRhs && BC == kBcNone && spmm_nt_stream(L)) {
-      if constexpr (OP == kCopyRhs && BC == kBcNone)
-        hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false, false, true>),
-                           dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
-    } else
-      hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false>),
-                         dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
-  } else if (OP == kCopyRhs && BC == kBcNone && spmm_nt_stream(L)) {
+  } else if (OP == kCopyRhs && BC == kBcNone && !L.accumulate && spmm_nt_stream(L)) {
     if constexpr (OP == kCopyRhs && BC == kBcNone)
-      hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false, false, true>),
+      hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false, true>),
                          dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
   } else {
     hipLaunchKernelGGL((spmm_csr_merge_kernel<Idx, DT, VEC, OP, RED, BC, kSpmmUnroll, false>),
                        dim3(blocks, g.chunks), dim3(64 * kWavesPerBlock), dyn_lds, L.stream, p);
   }
   DGLA_CHECK_HIP(hipGetLastError());
-  if (pe.after && !g.tail_pass) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
+  if (pe.after) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
   hipLaunchKernelGGL((spmm_csr_fixup_kernel<Idx, DT, OP, RED>),
                      dim3(static_cast<unsigned>(std::min<int64_t>(g.num_slots, int64_t(1) << 24))),
                      dim3(64), 0, L.stream, p, g.num_slots);
   DGLA_CHECK_HIP(hipGetLastError());
-  if (g.tail_pass) {
-    if (spmm_tail_combine(make_tail_launch(L, g, p.split_meta), L.out, L.out_len, L.csr.indptr, L.mean,
-                          L.accumulate))
-      return -1;
-    if (pe.after) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
-  }
   return 0;
 }
 
@@ -1434,8 +1263,8 @@ template <typename Idx, typename DT, int VEC, int OP>
 inline int launch_spmm_red(const SpmmLaunch& L, const SpmmGeometry& g) {
   switch (L.red) {
     case kSum: return launch_spmm_bc<Idx, DT, VEC, OP, kSum>(L, g);
-    case kMax: return launch_spmm_bc<Idx, DT, VEC, OP, kMax>(L, g);
-    case kMin: return launch_spmm_bc<Idx, DT, VEC, OP, kMin>(L, g);
+    case kMax:
+    case kMin: return launch_spmm_bc<Idx, DT, VEC, OP, kMax>(L, g);  // min: p.red_min
   }
   last_error() = "unsupported SpMM reducer";
   return -1;
@@ -1444,10 +1273,10 @@ inline int launch_spmm_red(const SpmmLaunch& L, const SpmmGeometry& g) {
 template <typename Idx, typename DT, int VEC>
 inline int launch_spmm_op(const SpmmLaunch& L, const SpmmGeometry& g) {
   switch (L.op) {
-    case kAdd: return launch_spmm_red<Idx, DT, VEC, kAdd>(L, g);
-    case kSub: return launch_spmm_red<Idx, DT, VEC, kSub>(L, g);
-    case kMul: return launch_spmm_red<Idx, DT, VEC, kMul>(L, g);
-    case kDiv: return launch_spmm_red<Idx, DT, VEC, kDiv>(L, g);
+    case kAdd:
+    case kSub: return launch_spmm_red<Idx, DT, VEC, kAdd>(L, g);  // sub: p.rhs_neg
+    case kMul:
+    case kDiv: return launch_spmm_red<Idx, DT, VEC, kMul>(L, g);  // div: p.rhs_div
     case kCopyLhs: return launch_spmm_red<Idx, DT, VEC, kCopyLhs>(L, g);
     case kCopyRhs: return launch_spmm_red<Idx, DT, VEC, kCopyRhs>(L, g);
   }
@@ -1495,10 +1324,8 @@ template <typename DT>
 inline int launch_spmm_csr_typed(const SpmmLaunch& L) {
   using A = typename Acc<DT>::type;
   const int vec = spmm_pick_vec<DT>(L);
-  const int tail_slices = spmm_tail_slices(L);
-  const bool tail_shape = std::is_same<DT, float>::value && L.op == kCopyLhs && L.red == kSum;
   SpmmGeometry g = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
-                                 L.csr.idbits / 8, L.red != kSum, 0, 0, false, tail_slices);
+                                 L.csr.idbits / 8, L.red != kSum);
   const int64_t rb_l = L.lhs_len * static_cast<int64_t>(sizeof(DT));
   const bool vec_ok = rb_l % 16 == 0 ? vec * sizeof(DT) == 16 : vec * sizeof(DT) == 8;
   if (vec_ok && g.chunks == 1 && spmm_split_shape_ok(L, sizeof(DT))) {
@@ -1506,8 +1333,7 @@ inline int launch_spmm_csr_typed(const SpmmLaunch& L) {
     // has room (dgla_spmm_csr_workspace_bytes accounts for it), else the plain layout runs
     const SpmmGeometry gs = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
                                           L.csr.idbits / 8, L.red != kSum, L.csr.num_cols,
-                                          L.lhs_len * static_cast<int64_t>(sizeof(DT)),
-                                          !(L.tune & kTuneSplitClassic), tail_slices, tail_shape);
+                                          L.lhs_len * static_cast<int64_t>(sizeof(DT)));
     if (L.workspace && L.workspace_bytes >= gs.total) g = gs;
   }
   if (L.workspace_bytes < g.total || (g.total && !L.workspace)) {
@@ -1531,13 +1357,10 @@ inline size_t spmm_csr_workspace_typed(const SpmmLaunch& L) {
   constexpr int full = 16 / sizeof(DT);
   size_t best = 0;
   const bool split = spmm_split_shape_ok(L, sizeof(DT));
-  const int tail_slices = spmm_tail_slices(L);
-  const bool tail_shape = std::is_same<DT, float>::value && L.op == kCopyLhs && L.red == kSum;
   for (int vec : {1, full / 2 > 1 ? full / 2 : 1, full}) {
     const size_t t = spmm_geometry(L.csr.num_rows, L.csr.nnz, L.out_len, vec, sizeof(A),
                                    L.csr.idbits / 8, L.red != kSum, split ? L.csr.num_cols : 0,
-                                   L.lhs_len * static_cast<int64_t>(sizeof(DT)),
-                                   !(L.tune & kTuneSplitClassic), tail_slices, tail_shape)
+                                   L.lhs_len * static_cast<int64_t>(sizeof(DT)))
                          .total;
     if (t > best) best = t;
   }

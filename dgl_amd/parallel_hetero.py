@@ -11,7 +11,7 @@ Design (VERDICT r2 Missing #2):
     in EVERY relation and the feature rows of its nodes of every type;
   * per destination type the rank's rows of all relations are stacked row-wise into TWO CSRs —
     own-column edges and halo-column edges — each with a relation byte per edge, so one
-    dgla_spmm_csr_stacked launch per block replaces the relation loop (csrc/spmm_csr.cuh MULTI);
+    dgla_spmm_csr_stacked launch per block replaces the relation loop (csrc/spmm_csr.hip.h MULTI);
   * halo rows are kept per SOURCE node type: the union over all relations reading that type, so a
     remote row wanted by several relations travels once per step;
   * step = [pack + all-to-all per source type (RCCL stream)] || own-column stacked launch ->

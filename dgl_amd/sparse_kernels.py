@@ -18,7 +18,7 @@ _TARGET = {"u": 0, "e": 1, "v": 2, 0: 0, 1: 1, 2: 2}
 
 # ---- static source features --------------------------------------------------------------
 # When a feature row is not a whole number of 128-byte cache lines (F = 100 fp32) the CSR SpMM
-# gathers faster from a line-aligned "split-row" copy of the features (csrc/spmm_csr.cuh); by
+# gathers faster from a line-aligned "split-row" copy of the features (csrc/spmm_csr.hip.h); by
 # default that copy is re-made on every call, because the library cannot know whether a tensor
 # changed between two calls.  A caller that KNOWS its features are static (input features of
 # full-graph training / inference) says so once, and the copy is made once per graph.

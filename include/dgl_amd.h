@@ -171,7 +171,7 @@ int dgla_spmm_coo(const char* op, const char* reduce, const dgla_coo* coo, dgla_
 /*
  * g-SDDMM:  out[eid, k] = op(lhs[sel(lhs_target), lhs_off(k)], rhs[sel(rhs_target), rhs_off(k)])
  * Replaces aten::COOSDDMM / CSRSDDMM (array.cc:1192-1233) -> SDDMMCoo / SDDMMCsr
- * (src/array/cuda/sddmm.cu:17-42, sddmm.cuh:97-362).
+ * (src/array/cuda/sddmm.cu:17-42, sddmm.hip.h:97-362).
  *   op       "add" | "sub" | "mul" | "div" | "copy_lhs" | "copy_rhs" | "dot"
  *   targets  0 = u (source node), 1 = e (edge), 2 = v (destination node)
  */
@@ -412,23 +412,20 @@ int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const voi
                              const void* local_idx, int64_t n, int part_id, void* out,
                              void* hip_stream);
 
-/* Process-wide tuning bits of the CSR SpMM.  Except DGLA_TUNE_TAIL_PASS none of them changes a
- * result bit; they select memory-system behaviour and exist so that a benchmark can A/B them:
+/* Process-wide tuning bits.  The SpMM bits change no result bit; they select memory-system behaviour
+ * and exist so that a benchmark can A/B them:
  *   DGLA_TUNE_XCD     units visit the merge path in XCD-contiguous order (block b runs on XCD
  *                     b % 8, so each XCD's L2 sees one contiguous eighth of the rows)
  *   DGLA_TUNE_NT_OUT  finished output rows are stored non-temporally
  *   DGLA_TUNE_NT_IDX  indices / indptr / eids are loaded non-temporally (read-once streams)
- *   DGLA_TUNE_SPLIT   when a ufeat row is not a whole number of 128-byte lines (F = 100 fp32:
- *                     400 B = 4 lines touched per gather) the call first copies ufeat into a
- *                     line-aligned main array + a dense tail array inside the workspace and
- *                     gathers from those (3 lines + one cached access per edge) — unless the
- *                     locality probe made with the merge plan found the graph in a locality-
- *                     preserving order: at least 15/16 of the sampled edges within 64 Ki rows of
- *                     their own row for the layouts that copy only the rows' ragged ends / the
- *                     straddling rows (the default ones: their copy costs 0.1 ms on the headline
- *                     graph and pays even at 81 % local edges), at least half for the whole-row
- *                     copy of DGLA_TUNE_SPLIT_CLASSIC
- *   DGLA_TUNE_SPLIT_NT     the copy stores the main array non-temporally
+ *   DGLA_TUNE_SPLIT   when a gathered ufeat row touches one 128-byte line more than its length needs
+ *                     (F = 100 fp32: 400 B = 4 lines per gather) the call first copies the rows' ragged
+ *                     ends (16-byte lanes, rows of >= 256 bytes: one side line per row + a dense array of
+ *                     the last bytes; the line-aligned interior is gathered in place) or the straddling
+ *                     rows (8-byte lanes, e.g. bf16 F = 100) into the workspace — unless the locality
+ *                     probe made with the merge plan found at least 15/16 of the sampled edges within
+ *                     64 Ki rows of their own row (the copy costs 0.1 ms on the headline graph and pays
+ *                     even at 81 % local edges)
  *   DGLA_TUNE_SPLIT_FORCE  ignore the locality probe
  *   DGLA_TUNE_GLDS    dgla_segment_mm / dgla_gather_mm, 16-bit and fp32 storage, operands in
  *                     whole aligned 16-byte pieces: operands go global -> LDS directly (global_load_lds,
@@ -440,45 +437,18 @@ int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const voi
  *                     three round-to-nearest bf16 terms and the six products of order <= 2 run on
  *                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation — fp32-level accuracy (dropped
  *                     terms < 2^-26 |a b|) at 2.7x less matrix-pipe time; gfx950 has no xf32 MFMA
- *   DGLA_TUNE_SPLIT_CLASSIC  split-row layout as in round 2: every row is copied (line-aligned main
- *                     array + dense tail array).  Default (bit off) for rows of two or more whole
- *                     lines: only the two ragged ENDS of every row are copied (one 128-byte line
- *                     per row + the dense tail); the line-aligned interior is gathered in place
- *   DGLA_TUNE_TAIL_PASS  copy_lhs + sum (also mean / accumulate) on fp32 rows of 128 k + 16 bytes
- *                     (F = 100), int32 ids, graphs of >= 2^20 columns with the split layout in use: the
- *                     16-byte row tails are summed by a pass of their own over a column-sliced copy of
- *                     the graph structure, in which they hit in the XCD's L2, and the main kernel
- *                     gathers three whole lines per edge instead of four requests.  The structure
- *                     (4 x (S x rows + nnz) bytes, S = slices of ~2.5 MB of tails) is built WITH THE
- *                     MERGE PLAN of every such graph and lives next to it in the workspace.  The last
- *                     four output columns are then summed in (slice, CSR position) order instead of
- *                     CSR position: deterministic, different low-order bits.  OPT-IN (default off): measured
- *                     4.61 -> 4.51 ms on the headline graph (the pass's own L2 gathers and partial sums
- *                     cost most of what the fourth request did) for +1 GB of workspace.  Changing
- *                     this bit changes the workspace layout: do not pass DGLA_PLAN_VALID across it.
- *   DGLA_TUNE_NT_STREAM  copy_rhs WITHOUT an edge-id map over long rows (nnz >= 64 num_rows: a readout-like
- *                     dgla_segment_reduce, copy_e on a graph of hubs): the edge operand — read exactly once, in
- *                     position order — is loaded non-temporally.  On the load shape of the merge kernel a pure
- *                     in-order stream runs at 6.3 TB/s with default loads and 6.9-7.1 TB/s with these
- *                     (benchmarks/micro/seq_rows.hip); segment sum of 15.5 M x 400 B rows into 64 segments
- *                     1.10 -> 1.01 ms, max 1.34 -> 1.26.  Next to many output rows the hint LOSES (612 k
- *                     segments: sum -2 %, max +9 %; 2.4 M segments: +7 % / +10 %), hence the row-length rule;
- *                     random gathers are indifferent to it (operands behind an edge-id map keep default loads).
- *                     The load flavour is a compile-time variant of the kernel: chosen per load at run time it
- *                     put branches between the prefetch loads and the compiler drained them before every
- *                     reduction.  Default on.
- * The reference has no counterpart (its kernels take no hints). */
+ * Removed in round 4 (values retired, dgla_set_tuning rejects them): SPLIT_NT 32, SPLIT_CLASSIC 256
+ * (whole-row copy: 0.33 ms against 0.10), TAIL_PASS 512 (column-sliced pass over the 16-byte row tails:
+ * -5 % .. +3.5 %), NT_STREAM 1024 (now a fixed rule: copy_rhs without an edge-id map over rows of >= 64
+ * edges on average loads the edge operand non-temporally; measured 1.10 -> 1.01 ms on a 64-segment sum,
+ * +7 .. 10 % on short rows, hence the rule).  The reference has no counterpart (its kernels take no hints). */
 #define DGLA_TUNE_XCD 1u
 #define DGLA_TUNE_NT_OUT 2u
 #define DGLA_TUNE_NT_IDX 4u
 #define DGLA_TUNE_SPLIT 8u
 #define DGLA_TUNE_GLDS 16u
-#define DGLA_TUNE_SPLIT_NT 32u
 #define DGLA_TUNE_SPLIT_FORCE 64u
 #define DGLA_TUNE_MM_F32 128u
-#define DGLA_TUNE_SPLIT_CLASSIC 256u
-#define DGLA_TUNE_TAIL_PASS 512u
-#define DGLA_TUNE_NT_STREAM 1024u
 int dgla_set_tuning(uint32_t flags);
 uint32_t dgla_get_tuning(void);
 

@@ -1,6 +1,6 @@
 """Host-side geometry of dgla_spmm_csr_workspace_bytes (no GPU: the function is arithmetic over
 shapes): what each layout adds to the scratch of a call, and the unit size of small graphs.
-Mirrors the decisions of csrc/spmm_csr.cuh::spmm_geometry / spmm_split_shape_ok / spmm_tail_slices."""
+Mirrors the decisions of csrc/spmm_csr.hip.h::spmm_geometry / spmm_split_shape_ok / spmm_tail_slices."""
 import ctypes
 import os
 
@@ -44,10 +44,14 @@ def test_split_layouts_add_what_they_copy(tuning):
     LIB.dgla_set_tuning(tuning)
     edge = ws_bytes(n, n, e, 100)                      # edge layout: one 128-byte side line + 16-byte tail per row
     assert n * 144 <= edge - plain < n * 144 + (1 << 20)
-    LIB.dgla_set_tuning(tuning | _lib.DGLA_TUNE_SPLIT_CLASSIC)
-    classic = ws_bytes(n, n, e, 100)                   # classic: whole rows (384 + 16 bytes)
-    assert n * 400 <= classic - plain < n * 400 + (1 << 20)
+    # rows under two whole lines (144 .. 240 bytes) are gathered in place (they touch 2 lines either way)
+    LIB.dgla_set_tuning(tuning & ~_lib.DGLA_TUNE_SPLIT)
+    p48 = ws_bytes(n, n, e, 48)
     LIB.dgla_set_tuning(tuning)
+    assert ws_bytes(n, n, e, 48) == p48
+    # retired bits are refused
+    for bit in (32, 256, 512, 1024):
+        assert LIB.dgla_set_tuning(tuning | bit) != 0 and int(LIB.dgla_get_tuning()) == tuning
     # whole lines (512-byte rows): nothing to split
     LIB.dgla_set_tuning(tuning & ~_lib.DGLA_TUNE_SPLIT)
     p128 = ws_bytes(n, n, e, 128)
@@ -61,40 +65,6 @@ def test_split_layouts_add_what_they_copy(tuning):
     assert n * 256 <= sb - pb < n * 256 + (1 << 20)
     # a graph whose features fit the caches never splits
     assert ws_bytes(1000, 1000, 30_000, 100) < (8 << 20)
-
-
-def test_tail_pass_structure_is_part_of_every_shape_on_an_eligible_graph(tuning):
-    n, e = 2_449_029, 61_859_140
-    old = {k: os.environ.pop(k, None) for k in ("DGLA_TAIL_MIN_COLS", "DGLA_TAIL_SLICE_KB")}
-    try:
-        LIB.dgla_set_tuning(tuning | _lib.DGLA_TUNE_TAIL_PASS)
-        with_f100 = ws_bytes(n, n, e, 100)
-        with_f128 = ws_bytes(n, n, e, 128)
-        LIB.dgla_set_tuning(tuning)
-        base_f100 = ws_bytes(n, n, e, 100)
-        base_f128 = ws_bytes(n, n, e, 128)
-        slices = -(-n * 16 // (2560 << 10))            # 16 slices of ~2.5 MB of tails
-        structure = 4 * (slices * n + 1) + 4 * e        # virtual row pointers + column ids (+ a small plan)
-        # long-lived structure in EVERY shape's workspace (it must sit at one place for all calls) ...
-        assert with_f128 - base_f128 >= structure
-        # ... and the partial sums only where the pass runs
-        assert with_f100 - base_f100 >= structure + 16 * slices * n
-        # int64 ids and small graphs never carry it
-        LIB.dgla_set_tuning(tuning | _lib.DGLA_TUNE_TAIL_PASS)
-        assert ws_bytes(n, n, e, 100, idbits=64) == _ws64(n, e, tuning)
-        assert ws_bytes(200_000, 200_000, 2_000_000, 100) < base_f100
-    finally:
-        LIB.dgla_set_tuning(tuning)
-        for k, v in old.items():
-            if v is not None:
-                os.environ[k] = v
-
-
-def _ws64(n, e, tuning):
-    LIB.dgla_set_tuning(tuning)
-    v = ws_bytes(n, n, e, 100, idbits=64)
-    LIB.dgla_set_tuning(tuning | _lib.DGLA_TUNE_TAIL_PASS)
-    return v
 
 
 def test_small_graphs_run_shorter_units(tuning):
