@@ -268,6 +268,20 @@ def backward_segment_cmp(feat, arg, out):
                                              arg.data_ptr(), ctypes.byref(to), _stream(out)))
 
 
+def spmm_cmp_backward(dz, arg, out, other=None, arg_other=None, other_group=1, atomic=True):
+    """out[arg[i, k], k] (+)= dz[i, k] * other[arg_other[i, k], (k // other_group) % row_len(other)]
+    where arg >= 0 (dgla_spmm_cmp_backward; `out` is not zeroed)."""
+    keep = []
+    tz, to = _tensor(dz, keep), _tensor(out, keep)
+    _require_gpu(arg)
+    tother = _tensor(other, keep) if other is not None else None
+    check_call(LIB.dgla_spmm_cmp_backward(_idbits(arg), _DTYPES[out.dtype], ctypes.byref(tz), arg.data_ptr(),
+                                          ctypes.byref(tother) if tother is not None else None,
+                                          arg_other.data_ptr() if arg_other is not None else None, int(other_group),
+                                          ctypes.byref(to), 1 if atomic else 0, _stream(out)))
+    return out
+
+
 def _mm_check(*ts):
     for t in ts:
         if t is None:

@@ -104,6 +104,9 @@ LIB.dgla_scatter_add.restype = c_int
 LIB.dgla_scatter_add.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
 LIB.dgla_update_grad_minmax.restype = c_int
 LIB.dgla_update_grad_minmax.argtypes = [c_int, c_int, P(Tensor), c_void_p, c_void_p, c_int64, P(Tensor), c_void_p]
+LIB.dgla_spmm_cmp_backward.restype = c_int
+LIB.dgla_spmm_cmp_backward.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p, c_int64, P(Tensor),
+                                       c_int, c_void_p]
 LIB.dgla_backward_segment_cmp.restype = c_int
 LIB.dgla_backward_segment_cmp.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
 LIB.dgla_segment_mm_workspace_bytes.restype = c_size_t

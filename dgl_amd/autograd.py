@@ -44,6 +44,57 @@ def _keep_for_spmm_backward(op, reduce_op, need_dx, need_dy):
     return keep_x, keep_y, keep_arg
 
 
+def _bcast_group(other_shape, dz_shape):
+    """(row length of `other`, group) such that element k of a dz row pairs with element
+    (k // group) % len of the other operand's row, or None when the broadcast is neither
+    "leading dims then ones" nor "ones then trailing dims"."""
+    s = tuple(int(d) for d in dz_shape)
+    t = tuple(int(d) for d in other_shape)
+    t = (1,) * (len(s) - len(t)) + t
+    if len(t) != len(s) or any(a != b and a != 1 for a, b in zip(t, s)):
+        return None
+    n = 1
+    for d in t:
+        n *= d
+    a = 0
+    while a < len(s) and t[a] == s[a]:
+        a += 1
+    if all(d == 1 for d in t[a:]):                       # leading dims of dz, then ones
+        g = 1
+        for d in s[a:]:
+            g *= d
+        return n, max(g, 1)
+    b = len(s)
+    while b > 0 and t[b - 1] == s[b - 1]:
+        b -= 1
+    if all(d == 1 for d in t[:b]):                       # ones, then trailing dims of dz
+        return n, 1
+    return None
+
+
+def _cmp_backward(dZ, arg, rows, other, arg_other, atomic):
+    """Gradient of a max / min g-SpMM operand: ``out[arg[i, k], k] += dZ[i, k] * other[arg_other[i, k], k']``
+    in ONE launch reading the winners in the graph's idtype (dgla_spmm_cmp_backward); the reference is two
+    ``.long()`` casts, a ``gather`` and a ``scatter_add_`` (python/dgl/backend/pytorch/sparse.py:217-244)."""
+    from . import _capi
+
+    out = torch.zeros((rows,) + tuple(dZ.shape[1:]), dtype=dZ.dtype, device=dZ.device)
+    if dZ.numel() == 0 or rows == 0:
+        return out
+    if not dZ.is_cuda:
+        raise _capi._lib.DGLAMDError("dgl_amd kernels run on a ROCm GPU (no CPU fallback)")
+    grp = (0, 1)
+    if other is not None:
+        grp = _bcast_group(other.shape[1:], dZ.shape[1:])
+        if grp is None:
+            # a broadcast in the middle of the feature shape: compose (rare; still no host round trip)
+            g = other.expand(-1, *dZ.shape[1:]).gather(0, arg_other.long()) * dZ
+            return _capi.spmm_cmp_backward(g.contiguous(), arg.contiguous(), out, atomic=atomic)
+        other = other.contiguous()
+    return _capi.spmm_cmp_backward(dZ, arg.contiguous(), out, other,
+                                   None if other is None else arg_other.contiguous(), grp[1], atomic=atomic)
+
+
 class GSpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gidx, op, reduce_op, X, Y):
@@ -73,12 +124,8 @@ class GSpMM(torch.autograd.Function):
                 else:  # add, copy_lhs: the message is linear in X with coefficient 1
                     dX = gspmm(rev, "copy_lhs", "sum", dZ, None)
             else:
-                dX = torch.zeros((x_shape[0],) + tuple(dZ.shape[1:]), dtype=dtype, device=device)
-                if op == "mul":
-                    g = Y.expand(-1, *dZ.shape[1:]).gather(0, argY.long()) * dZ
-                    dX.scatter_add_(0, argX.long(), g)
-                else:
-                    dX.scatter_add_(0, argX.long(), dZ)
+                # a source node can win at many destinations: atomic sum (as the reference's scatter_add_)
+                dX = _cmp_backward(dZ, argX, x_shape[0], Y if op == "mul" else None, argY, atomic=True)
             dX = _reduce_grad(dX, x_shape)
         if op != "copy_lhs" and ctx.needs_input_grad[4]:
             if reduce_op == "sum":
@@ -87,12 +134,8 @@ class GSpMM(torch.autograd.Function):
                 else:  # add, copy_rhs
                     dY = gsddmm(gidx, "copy_rhs", X, dZ, _handoff=False)
             else:
-                dY = torch.zeros((y_shape[0],) + tuple(dZ.shape[1:]), dtype=dtype, device=device)
-                if op == "mul":
-                    g = X.expand(-1, *dZ.shape[1:]).gather(0, argX.long()) * dZ
-                    dY.scatter_add_(0, argY.long(), g)
-                else:
-                    dY.scatter_add_(0, argY.long(), dZ)
+                # an edge has ONE destination: every (edge, k) is written at most once — plain stores
+                dY = _cmp_backward(dZ, argY, y_shape[0], X if op == "mul" else None, argX, atomic=False)
             dY = _reduce_grad(dY, y_shape)
         return None, None, None, dX, dY
 

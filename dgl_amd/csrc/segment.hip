@@ -180,6 +180,61 @@ int run_update_grad_minmax(const void* feat, const void* idx, const void* idx_ty
   return 0;
 }
 
+// Backward of g-SpMM max / min (python/dgl/backend/pytorch/sparse.py:217-244): the gradient of output
+// element (i, k) goes to the operand row that WON it — arg[i, k], read in the graph's own idtype — times,
+// for `mul`, the other operand's winning row (other[arg_other[i, k], (k / group) % other_len]: the
+// broadcast forms "leading dims then ones" and "ones then trailing dims").  One pass over dz where the
+// reference makes four (two .long() casts, a gather, a scatter_add_).
+//   ATOMIC = false: the target is the EDGE operand — an edge has one destination, so (arg[i, k], k) is
+//                   written at most once: plain stores, deterministic;
+//   ATOMIC = true:  the target is the NODE operand — a source node can win at many destinations, the
+//                   sum over them is a hardware float atomic (as the reference's scatter_add_ / its
+//                   UpdateGradMinMaxHeteroKernel, segment_reduce.cuh:73-92).
+template <typename Idx, typename DT, bool MUL, bool ATOMIC>
+__global__ __launch_bounds__(256) void spmm_cmp_backward_kernel(
+    const DT* __restrict__ dz, const Idx* __restrict__ arg, const DT* __restrict__ other,
+    const Idx* __restrict__ arg_other, DT* __restrict__ out, int64_t total, int dim, int other_len,
+    int group, int64_t out_rows) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < total; t += stride) {
+    const int64_t w = static_cast<int64_t>(arg[t]);
+    if (w < 0 || w >= out_rows) continue;
+    const int k = static_cast<int>(t % dim);
+    DT g = dz[t];
+    if constexpr (MUL) {
+      const int64_t wo = static_cast<int64_t>(arg_other[t]);
+      const DT o = other[wo * other_len + (k / group) % other_len];
+      g = from_acc<DT>(to_acc<DT>(g) * to_acc<DT>(o));
+    }
+    if constexpr (ATOMIC)
+      atomic_add_elem<DT>(out + w * dim + k, g);
+    else
+      out[w * dim + k] = g;
+  }
+}
+
+template <typename Idx, typename DT>
+int run_spmm_cmp_backward(const void* dz, const void* arg, const void* other, const void* arg_other,
+                          void* out, int64_t n, int64_t dim, int64_t other_len, int64_t group,
+                          int64_t out_rows, bool atomic, hipStream_t s) {
+  const int64_t total = n * dim;
+  const unsigned blocks = static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 256 * 64));
+#define DGLA_CMPB(M, A)                                                                          \
+  hipLaunchKernelGGL((spmm_cmp_backward_kernel<Idx, DT, M, A>), dim3(blocks), dim3(256), 0, s,    \
+                     static_cast<const DT*>(dz), static_cast<const Idx*>(arg),                   \
+                     static_cast<const DT*>(other), static_cast<const Idx*>(arg_other),          \
+                     static_cast<DT*>(out), total, static_cast<int>(dim),                        \
+                     static_cast<int>(other_len), static_cast<int>(group), out_rows)
+  if (other) {
+    if (atomic) DGLA_CMPB(true, true); else DGLA_CMPB(true, false);
+  } else {
+    if (atomic) DGLA_CMPB(false, true); else DGLA_CMPB(false, false);
+  }
+#undef DGLA_CMPB
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 #define DGLA_IDX_DTYPE_SWITCH(idbits, dtype, FN, ...)                                   \
   do {                                                                                  \
     if ((idbits) == 32) {                                                               \
@@ -398,6 +453,31 @@ int dgla_update_grad_minmax(int idtype_bits, dgla_dtype dtype, const dgla_tensor
   const DeviceGuard dev(s, out->data);
   DGLA_IDX_DTYPE_SWITCH(idtype_bits, dtype, run_update_grad_minmax, feat->data, idx, idx_type, out->data,
                         n, dim, type, out->shape[0], s);
+  return sfail("unsupported feature dtype");
+}
+
+int dgla_spmm_cmp_backward(int idtype_bits, dgla_dtype dtype, const dgla_tensor* dz, const void* arg,
+                           const dgla_tensor* other, const void* arg_other, int64_t other_group,
+                           const dgla_tensor* out, int atomic, void* hip_stream) {
+  if (idtype_bits != 32 && idtype_bits != 64) return sfail("idtype must be int32 or int64");
+  if (dtype < DGLA_F32 || dtype > DGLA_BF16) return sfail("unsupported feature dtype");
+  if (!dz || !out || dz->ndim < 1 || out->ndim < 1 || !dz->shape || !out->shape) return sfail("dz / out is null");
+  if (row_len(dz) != row_len(out)) return sfail("dz and out have different feature shapes");
+  const int64_t n = dz->shape[0], dim = row_len(out);
+  if (n == 0 || dim == 0 || out->shape[0] == 0) return 0;
+  if (!dz->data || !out->data || !arg) return sfail("dz / arg / out data is null");
+  int64_t other_len = 1;
+  if (other && other->data) {
+    if (!arg_other) return sfail("arg_other is required with `other`");
+    if (other->ndim < 1 || !other->shape) return sfail("other has no shape");
+    other_len = row_len(other);
+    if (other_group < 1 || other_group > dim || other_len < 1) return sfail("other_group out of range");
+  }
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, out->data);
+  const void* od = (other && other->data) ? other->data : nullptr;
+  DGLA_IDX_DTYPE_SWITCH(idtype_bits, dtype, run_spmm_cmp_backward, dz->data, arg, od, arg_other, out->data, n, dim,
+                        other_len, other_group < 1 ? 1 : other_group, out->shape[0], atomic != 0, s);
   return sfail("unsupported feature dtype");
 }
 

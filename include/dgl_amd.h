@@ -220,7 +220,14 @@ int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla
  *   one relation's share of the max / min gradient on a heterograph
  *   (UpdateGradMinMax_hetero<kDGLCUDA,…>, src/array/cuda/segment_reduce.cuh:73-92,184-225):
  *   idx = the winning node / edge ids the forward pass recorded, idx_type = the node / edge type
- *   of every winner (-1: nothing won), both [n, dim] of idtype; out is NOT zeroed (atomic). */
+ *   of every winner (-1: nothing won), both [n, dim] of idtype; out is NOT zeroed (atomic).
+ * dgla_spmm_cmp_backward: backward of g-SpMM max / min on one relation, ONE pass
+ *   (python/dgl/backend/pytorch/sparse.py:217-244 is two .long() casts, a gather and an atomic
+ *   scatter_add_): out[arg[i, k], k] (+)= dz[i, k] * (other ? other[arg_other[i, k], (k / other_group) %
+ *   row_len(other)] : 1) wherever arg[i, k] >= 0; arg / arg_other = the winners the forward pass recorded
+ *   ([n, dim] of idtype_bits).  atomic = 0 for the EDGE operand (an edge has one destination: every
+ *   target element is written at most once, plain stores, deterministic), 1 for the NODE operand (a node
+ *   can win at many destinations: hardware float atomics, like the reference).  out is NOT zeroed. */
 size_t dgla_segment_reduce_workspace_bytes(const char* reduce, int idtype_bits, dgla_dtype dtype,
                                            const dgla_tensor* feat, int64_t num_segments,
                                            const dgla_tensor* out);
@@ -235,6 +242,9 @@ int dgla_update_grad_minmax(int idtype_bits, dgla_dtype dtype, const dgla_tensor
                             const dgla_tensor* out, void* hip_stream);
 int dgla_backward_segment_cmp(int idtype_bits, dgla_dtype dtype, const dgla_tensor* feat,
                               const void* arg, const dgla_tensor* out, void* hip_stream);
+int dgla_spmm_cmp_backward(int idtype_bits, dgla_dtype dtype, const dgla_tensor* dz, const void* arg,
+                           const dgla_tensor* other, const void* arg_other, int64_t other_group,
+                           const dgla_tensor* out, int atomic, void* hip_stream);
 
 /* ---- segment / gather matrix multiply --------------------------------------
  * Replace SegmentMM / SegmentMMBackwardB / GatherMM / GatherMMScatter<kDGLCUDA,…>
