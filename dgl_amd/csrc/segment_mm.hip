@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 
@@ -60,18 +61,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <typename Idx>
 __global__ void segment_plan_kernel(const Idx* __restrict__ seglen, int64_t num_rel,
                                     int rows_per_tile, int64_t num_rows,
-                                    int64_t* __restrict__ plan) {
+                                    int64_t* __restrict__ plan, int64_t* __restrict__ tile32) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int64_t t = 0, r0 = 0;
+  int64_t t = 0, r0 = 0, t32 = 0;
   for (int64_t r = 0; r < num_rel; ++r) {
     plan[r] = t;
     plan[num_rel + 1 + r] = r0;
+    if (tile32) tile32[r] = t32;  // 32-row tiles of the weights-stationary forward kernel
     int64_t len = static_cast<int64_t>(seglen[r]);
     if (len < 0) len = 0;
     if (len > num_rows - r0) len = num_rows - r0;
     t += (len + rows_per_tile - 1) / rows_per_tile;
+    t32 += (len + 31) / 32;
     r0 += len;
   }
+  if (tile32) tile32[num_rel] = t32;
   plan[num_rel] = t;
   plan[2 * num_rel + 1] = r0;
   plan[3 * num_rel + 2] = 0;  // NaN flag of the X3 (fp32 as 3 x bf16) kernels, behind the staged seglen
@@ -716,6 +720,324 @@ __global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(con
   }
 }
 
+
+// ---- forward, WEIGHTS-STATIONARY persistent kernel (round 4; VERDICT r3 Next #3) -----------------------
+// The LDS-direct kernel above streams BOTH operands through LDS for every 128-row tile: at 10 M x 256 x 256
+// bf16 the weights (128 KB per tile, from L2) are two thirds of its LDS-DMA traffic and the kernel runs at
+// the DMA rate (15.4 GB / 2.33 ms = 6.6 TB/s), not at the HBM rate of A + C (10.2 GB).  This kernel keeps
+// the weights where they are re-used and gives A the path that needs no LDS at all:
+//   * ONE workgroup of 8 waves per CU for the whole launch; it owns a contiguous chunk of 32-row tiles.
+//   * The relation's weights are loaded into LDS ONCE per (workgroup, relation) by global_load_lds —
+//     column n of the K-contiguous weights at LDS row (n % NJ) * 32 + n / NJ (see the epilogue), rows
+//     padded to an ODD number of 16-byte pieces so the 16 lanes of a ds_read_b128 group fall into
+//     distinct bank groups.  256 x 256 x 2 B = 132 KB with the pad: the reason A cannot live in LDS too.
+//   * Every WAVE runs its own 32-row tiles with no barrier in between: the A operand goes from global
+//     memory straight into the MFMA fragment layout (lane = row, 16 bytes of K per lane: one
+//     global_load_dwordx4 per k-step), through a ring of 8 fragments that is refilled in place — k-step
+//     u of the NEXT round (or of the wave's next tile) is requested the moment k-step u has been
+//     multiplied, so 8 KB per wave = 64 KB per CU are in flight at all times, counted by the compiler's
+//     own vmcnt bookkeeping.
+//   * Epilogue from registers: MFMA block jj multiplies weight columns {NJ * l + jj}, so lane l holds NJ
+//     CONSECUTIVE output columns of a row; they leave as one 16-byte (NJ = 8) store per row and lane —
+//     a half-wave writes 512 contiguous bytes.  No LDS staging, no barrier.
+//   * fp32 (X3: operands as three bf16 terms, see split3): the weights are split ONCE per call into three
+//     bf16 planes (split_weights_kernel) and a workgroup holds 64 columns x 3 planes; only the A fragment
+//     is split in the loop (44 VALU operations against 12 MFMAs of 32 cycles; the LDS-direct kernel split
+//     the weight fragments too, in every wave and tile: VALU 49 % beside MFMA 50 %, not overlapped).
+//     N / 64 workgroups of the SAME XCD walk the same row chunk, one column group each, so the A rows come
+//     from HBM once and from that XCD's L2 afterwards.
+// Contraction order: k-steps of 16 in increasing k, inside a k-step the MFMA's own order — results equal the
+// LDS-direct kernel's to fp32 rounding, not bit for bit (same contract as every GEMM here: tolerance).
+template <typename DT, int V>
+__device__ __forceinline__ void store_nt_vec(DT* dst, const VecT<DT, V>& v) {
+  constexpr int B = sizeof(DT) * V;
+  if constexpr (B == 16) {
+    __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(&v), reinterpret_cast<u32x4*>(dst));
+  } else if constexpr (B == 8) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(&v), reinterpret_cast<u32x2*>(dst));
+  } else if constexpr (B == 4) {
+    __builtin_nontemporal_store(*reinterpret_cast<const uint32_t*>(&v), reinterpret_cast<uint32_t*>(dst));
+  } else {
+    *reinterpret_cast<VecT<DT, V>*>(dst) = v;
+  }
+}
+
+template <typename DT>
+struct WsFrag;
+template <>
+struct WsFrag<bf16_t> {
+  typedef b16x8 type;
+  __device__ static __forceinline__ f32x16 mma(type a, type b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct WsFrag<f16_t> {
+  typedef h16x8 type;
+  __device__ static __forceinline__ f32x16 mma(type a, type b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int kWsWaves = 8;        // waves per workgroup (one workgroup per CU)
+constexpr int kWsMaxK = 256;       // contraction length the LDS image is sized for
+constexpr int kWsPitchPieces = kWsMaxK / 8 + 1;  // 16-byte pieces per LDS row at K = 256 (odd)
+
+struct WsParams {
+  MmParams m;
+  const void* planes;        // X3: [3][R, N, Kp] bf16 (h, m, l), Kp = K rounded up to 8, zero padded
+  const int64_t* tile32_off; // [R + 1] exclusive prefix of ceil(len / 32)
+  int ncg;                   // column groups (workgroups sharing a row chunk)
+  int kp;                    // X3: row pitch of the planes in elements
+};
+
+// Three bf16 planes of the K-contiguous fp32 weights: out[pl][row][k], row pitch kp, zero padded.
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ bt, bf16_t* __restrict__ out,
+                                                            int64_t rows, int K, int kp) {
+  const int64_t total = rows * kp;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t r = i / kp;
+    const int k = static_cast<int>(i - r * kp);
+    float x = k < K ? bt[r * K + k] : 0.f;
+    const bf16_t h = from_acc<bf16_t>(x);
+    const float r1 = x - to_acc<bf16_t>(h);
+    const bf16_t m = from_acc<bf16_t>(r1);
+    const bf16_t l = from_acc<bf16_t>(r1 - to_acc<bf16_t>(m));
+    out[i] = h;
+    out[total + i] = m;
+    out[2 * total + i] = l;
+  }
+}
+
+template <typename DT, int NJ, bool X3, bool INDEXED>
+__global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const WsParams wp) {
+  const MmParams& p = wp.m;
+  constexpr int ES = sizeof(DT);
+  constexpr int PL = X3 ? 3 : 1;
+  constexpr int ROWS = PL * NJ * 32;
+  constexpr int AV = X3 ? 2 : 1;  // 16-byte vectors of A per lane and k-step (fp32: 8 floats)
+  static_assert(X3 == (ES == 4), "X3 is the fp32 path");
+  __shared__ __attribute__((aligned(1024))) char smem[ROWS * kWsPitchPieces * 16 + 1024];  // (+ the last DMA instruction's overhang)
+
+  const int K = p.K, N = p.N;
+  const int nks = (K + 15) >> 4;   // k-steps of 16
+  const int nround = (nks + 7) >> 3;
+  const int pp = 2 * nks + 1;      // LDS row pitch in 16-byte pieces (odd)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l = lane & 31, khalf = lane >> 5;
+
+  const int64_t* __restrict__ tile_off = wp.tile32_off;
+  const int64_t* __restrict__ row_off = p.plan + p.num_rel + 1;
+  // workgroup -> (row chunk, column group): the ncg groups of a chunk are workgroups of ONE XCD
+  const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
+  const int cg = qq % wp.ncg;
+  const int nchunks = (static_cast<int>(gridDim.x) >> 3) / wp.ncg * 8;
+  const int chunk = (qq / wp.ncg) * 8 + xcd;
+  if (chunk >= nchunks) return;
+  const int64_t T = tile_off[p.num_rel];
+  const int64_t t0 = uniform64(T * chunk / nchunks), t1 = uniform64(T * (chunk + 1) / nchunks);
+  const int n0 = cg * 32 * NJ;
+
+  const char* __restrict__ A = static_cast<const char*>(p.a);
+  DT* __restrict__ C = static_cast<DT*>(p.c);
+  typedef typename WsFrag<typename std::conditional<X3, bf16_t, DT>::type>::type frag_t;
+
+  int64_t t = t0;
+  while (t < t1) {
+    const int64_t rel = uniform64(find_segment(tile_off, p.num_rel, t));
+    const int64_t rel_t0 = uniform64(tile_off[rel]);
+    int64_t rel_end = uniform64(tile_off[rel + 1]);
+    if (rel_end > t1) rel_end = t1;
+    const int64_t rel_row0 = uniform64(row_off[rel]), row_end = uniform64(row_off[rel + 1]);
+
+    // ---- this relation's weights -> LDS ----------------------------------------------------------------
+    __syncthreads();  // nobody still multiplies from the previous relation's image
+    {
+      const int total = ROWS * pp, ninst = (total + 63) >> 6;
+      const int kpieces = X3 ? (wp.kp >> 3) : (K >> 3);      // 16-byte pieces with data per weight row
+      const int64_t rpitch = X3 ? static_cast<int64_t>(wp.kp) * 2 : static_cast<int64_t>(K) * ES;
+      const int64_t plane_bytes = X3 ? static_cast<int64_t>(p.num_rel) * N * rpitch : 0;
+      const char* __restrict__ W = X3 ? static_cast<const char*>(wp.planes) : static_cast<const char*>(p.bt);
+      for (int i = wave; i < ninst; i += kWsWaves) {
+        const int j = i * 64 + lane;
+        const int rho = j / pp, pc = j - rho * pp;
+        const int pl = rho / (NJ * 32), jj = (rho >> 5) % NJ, ll = rho & 31;
+        const int n = n0 + NJ * ll + jj;
+        const bool valid = j < total && pc < kpieces && n < N;
+        const char* src = valid ? W + pl * plane_bytes + (rel * N + n) * rpitch + pc * 16 : g_mm_zero_page;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(smem + i * 1024), 16, 0, 0);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces have landed
+    }
+    __syncthreads();
+
+    // ---- this wave's tiles of the relation: t + wave, t + wave + 8, ... ------------------------------------
+    const int64_t first = t + wave;
+    auto lane_ptr = [&](int64_t tt) -> const char* {
+      int64_t row = rel_row0 + (tt - rel_t0) * 32 + l;
+      if (row >= row_end) row = row_end - 1;
+      if constexpr (INDEXED) row = p.row_index[row];
+      return A + row * (static_cast<int64_t>(K) * ES) + khalf * (16 * AV);
+    };
+    struct AFrag {
+      u32x4 v[AV];
+    };
+    // Branch-free: a lane whose piece lies past the end of the row (K not a multiple of 16), and every lane of a
+    // refill that has nothing left to fetch, reads the zero page instead — a predicated load would sit in a
+    // divergent block and the compiler then waits for vmcnt(0) at every use (seen in the first build).
+    auto load_a = [&](const char* base, int ks, bool on) -> AFrag {
+      AFrag f;
+      const int e0 = ks * 16 + khalf * 8;  // first element of the lane's piece
+#pragma unroll
+      for (int h = 0; h < AV; ++h) {
+        const int e = X3 ? e0 + h * 4 : e0;  // (X3: 4 floats per vector)
+        const char* src = (on && e < K) ? base + static_cast<int64_t>(ks) * (32 * AV) + h * 16
+                                        : reinterpret_cast<const char*>(g_mm_zero_page);
+        f.v[h] = *reinterpret_cast<const u32x4*>(src);
+      }
+      return f;
+    };
+
+    if (first < rel_end) {
+      const char* cur = lane_ptr(first);
+      AFrag ar[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        ar[u] = load_a(cur, u, u < nks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      for (int64_t tt = first; tt < rel_end; tt += kWsWaves) {
+        const bool more = tt + kWsWaves < rel_end;
+        const char* nxt = more ? lane_ptr(tt + kWsWaves) : cur;
+        f32x16 acc[NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
+        for (int q = 0; q < nround; ++q) {
+          const bool last = q + 1 == nround;
+          const char* rp = last ? nxt : cur;
+          const int rk0 = last ? 0 : (q + 1) * 8;
+          const bool refill = !last || more;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int ks = q * 8 + u;
+            if (ks < nks) {  // (uniform)
+              const char* brow = smem + (l * pp + 2 * ks + khalf) * 16;
+              if constexpr (!X3) {
+                frag_t bf[NJ];
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj)
+                  bf[jj] = *reinterpret_cast<const frag_t*>(brow + jj * 32 * pp * 16);
+                const frag_t af = __builtin_bit_cast(frag_t, ar[u].v[0]);
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) acc[jj] = WsFrag<DT>::mma(af, bf[jj], acc[jj]);
+              } else {
+                b16x8 ah, am, al;
+                split3(__builtin_bit_cast(f32x4, ar[u].v[0]), __builtin_bit_cast(f32x4, ar[u].v[AV - 1]), ah, am, al);
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                  const b16x8 bh = *reinterpret_cast<const b16x8*>(brow + (0 * NJ + jj) * 32 * pp * 16);
+                  const b16x8 bm = *reinterpret_cast<const b16x8*>(brow + (1 * NJ + jj) * 32 * pp * 16);
+                  const b16x8 bl = *reinterpret_cast<const b16x8*>(brow + (2 * NJ + jj) * 32 * pp * 16);
+                  f32x16 c = acc[jj];  // small terms first
+                  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+                  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                  acc[jj] = c;
+                }
+              }
+            }
+            ar[u] = load_a(rp, rk0 + u, refill && rk0 + u < nks);  // in place: 8 fragments stay in flight
+            // keep program order = source order: hoisting the refill above the slot's own multiply makes the
+            // compiler rotate the ring's registers and (fp32 kernel) drain the ring with vmcnt(0) once per round
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // ---- epilogue: registers -> global, NJ consecutive columns per lane --------------------------------
+        if constexpr (X3) {
+          bool bad = false;
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bad |= acc[jj][r] != acc[jj][r];
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0) && lane == 0) atomicOr(p.nan_flag, 1u);
+        }
+        const int64_t trow0 = rel_row0 + (tt - rel_t0) * 32;
+        const int col = n0 + NJ * l;
+        const bool nt_c = (p.tune & kTuneNtOut) != 0;
+        // the usual tile — all 32 rows inside the segment, all of the group's columns inside N — stores without a
+        // predicate (wave-uniform test); ragged tiles take the element-wise path
+        const bool whole = trow0 + 32 <= row_end && n0 + 32 * NJ <= N;
+        if (whole) {
+          int64_t prow[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = trow0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if constexpr (INDEXED)
+              prow[r] = p.row_index[row];
+            else
+              prow[r] = row;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            DT* dst = C + prow[r] * N + col;
+            if constexpr (ES == 2) {
+              typedef uint32_t u32xh __attribute__((ext_vector_type(NJ >= 2 ? NJ / 2 : 1)));
+              if constexpr (NJ == 1) {
+                *dst = from_acc<DT>(acc[0][r]);
+              } else {
+                u32xh w;
+#pragma unroll
+                for (int h = 0; h < NJ / 2; ++h) {
+                  DT t2[2] = {from_acc<DT>(acc[2 * h][r]), from_acc<DT>(acc[2 * h + 1][r])};
+                  uint32_t bits;
+                  __builtin_memcpy(&bits, t2, 4);
+                  if constexpr (NJ == 2)
+                    w = bits;
+                  else
+                    w[h] = bits;
+                }
+                if (nt_c)
+                  __builtin_nontemporal_store(w, reinterpret_cast<u32xh*>(dst));
+                else
+                  *reinterpret_cast<u32xh*>(dst) = w;
+              }
+            } else {
+              typedef float f32xn __attribute__((ext_vector_type(NJ)));
+              f32xn w;
+#pragma unroll
+              for (int jj = 0; jj < NJ; ++jj) w[jj] = acc[jj][r];
+              if (nt_c)
+                __builtin_nontemporal_store(w, reinterpret_cast<f32xn*>(dst));
+              else
+                *reinterpret_cast<f32xn*>(dst) = w;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = trow0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (row >= row_end) continue;
+            int64_t pr = row;
+            if constexpr (INDEXED) pr = p.row_index[row];
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+              if (col + jj < N) C[pr * N + col + jj] = from_acc<DT>(acc[jj][r]);
+          }
+        }
+        cur = nxt;
+      }
+    }
+    t = rel_end;
+  }
+}
+
 // fp64 (and any shape the MFMA path does not take): one thread per output element.
 template <typename DT>
 __global__ __launch_bounds__(256) void segment_mm_plain_kernel(const MmParams p, int64_t M) {
@@ -984,17 +1306,21 @@ __global__ __launch_bounds__(256) void gather_mm_kernel(const DT* __restrict__ a
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 struct MmScratch {
-  size_t off_plan, off_bt, off_acc, total;
+  size_t off_plan, off_t32, off_bt, off_planes, off_acc, total;
 };
 
 MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool need_bt,
-                     bool need_acc) {
+                     bool need_acc, bool forward = false) {
   MmScratch s;
   size_t off = 0;
   s.off_plan = off;
   off = align256(off + sizeof(int64_t) * (2 * num_rel + 2) + /* staged seglen */ 8 * num_rel + /* NaN flag */ 8);
+  s.off_t32 = off;
+  if (forward) off = align256(off + sizeof(int64_t) * (num_rel + 1));
   s.off_bt = off;
   if (need_bt) off = align256(off + static_cast<size_t>(num_rel) * K * N * elem);
+  s.off_planes = off;  // fp32 forward: the weights as three bf16 planes (weights-stationary kernel)
+  if (forward && elem == 4) off = align256(off + static_cast<size_t>(3) * num_rel * N * ((K + 7) / 8 * 8) * 2);
   s.off_acc = off;
   if (need_acc) off = align256(off + static_cast<size_t>(num_rel) * K * N * sizeof(float));
   s.total = off;
@@ -1018,8 +1344,10 @@ __global__ __launch_bounds__(256) void segment_zero_tail_kernel(
 }
 
 int stage_plan(int idbits, const void* seglen, int seglen_on_host, int64_t num_rel,
-               int rows_per_tile, int64_t num_rows, char* ws, const MmScratch& sc, hipStream_t s) {
+               int rows_per_tile, int64_t num_rows, char* ws, const MmScratch& sc, hipStream_t s,
+               bool forward = false) {
   int64_t* plan = reinterpret_cast<int64_t*>(ws + sc.off_plan);
+  int64_t* t32 = forward ? reinterpret_cast<int64_t*>(ws + sc.off_t32) : nullptr;
   const void* dev_seglen = seglen;
   if (seglen_on_host) {
     // the reference hands seglen over in host memory (it loops over it on the CPU,
@@ -1031,10 +1359,10 @@ int stage_plan(int idbits, const void* seglen, int seglen_on_host, int64_t num_r
   }
   if (idbits == 32)
     hipLaunchKernelGGL(segment_plan_kernel<int32_t>, dim3(1), dim3(64), 0, s,
-                       static_cast<const int32_t*>(dev_seglen), num_rel, rows_per_tile, num_rows, plan);
+                       static_cast<const int32_t*>(dev_seglen), num_rel, rows_per_tile, num_rows, plan, t32);
   else
     hipLaunchKernelGGL(segment_plan_kernel<int64_t>, dim3(1), dim3(64), 0, s,
-                       static_cast<const int64_t*>(dev_seglen), num_rel, rows_per_tile, num_rows, plan);
+                       static_cast<const int64_t*>(dev_seglen), num_rel, rows_per_tile, num_rows, plan, t32);
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1061,6 +1389,69 @@ int mm_num_cus() {
 // (whole 16-byte pieces of K in both operands; 16-bit results also leave as 16-byte pieces)
 bool glds_eligible(size_t elem, int64_t K, int64_t N, bool vec_ab, bool vec_c) {
   return (elem == 2 || elem == 4) && vec_ab && (vec_c || elem == 4) && (tuning_flags() & kTuneGlds);
+}
+
+// Weights-stationary persistent forward kernel: whole 16-byte pieces, K <= 256 (the LDS image), and enough rows
+// that loading a relation's weights once per (workgroup, relation) is small beside streaming A:
+// M rows >= 8 x (workgroups + relations) weight images' worth of rows (DGLA_MM_WS=0 / 1 forces it off / on).
+bool ws_eligible(size_t elem, int64_t M, int64_t K, int64_t N, int64_t num_rel, bool vec_ab, bool vec_c) {
+  const char* e = getenv("DGLA_MM_WS");  // read per call: tests switch it inside one process
+  const int force = e && *e ? atoi(e) : -1;
+  if (force == 0 || !(tuning_flags() & kTuneGlds)) return false;
+  if (!(elem == 2 || (elem == 4 && !(tuning_flags() & kTuneMmF32))) || !vec_ab || !vec_c) return false;
+  if (K > kWsMaxK || K < 8 || N < 8) return false;
+  if (force == 1) return true;
+  return M >= 8 * (mm_num_cus() + num_rel) * std::max<int64_t>(N, 32);
+}
+
+template <typename DT>
+int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipStream_t s) {
+  WsParams wp;
+  wp.m = p;
+  wp.planes = nullptr;
+  wp.tile32_off = reinterpret_cast<const int64_t*>(ws + sc.off_t32);
+  wp.kp = 0;
+  const int N = p.N;
+  const int cus = mm_num_cus();
+  const dim3 block(64 * kWsWaves);
+  if constexpr (sizeof(DT) == 4) {
+    // fp32: three bf16 planes of the weights, once per call; 64 columns per workgroup
+    wp.kp = (p.K + 7) / 8 * 8;
+    bf16_t* planes = reinterpret_cast<bf16_t*>(ws + sc.off_planes);
+    const int64_t rows = p.num_rel * static_cast<int64_t>(N);
+    hipLaunchKernelGGL(split_weights_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((rows * wp.kp + 255) / 256, 4096))),
+                       dim3(256), 0, s, static_cast<const float*>(p.bt), planes, rows, p.K, wp.kp);
+    wp.planes = planes;
+    wp.ncg = (N + 63) / 64;
+    const int groups = std::max(1, cus / 8 / wp.ncg);  // row chunks per XCD
+    const dim3 grid(static_cast<unsigned>(groups * wp.ncg * 8));
+    if (p.row_index)
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, true>), grid, block, 0, s, wp);
+    else
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, false>), grid, block, 0, s, wp);
+    hipLaunchKernelGGL(x3_repair_fwd_kernel, dim3(1024), dim3(256), 0, s, p);  // no-op unless a NaN came out
+  } else {
+    const int nj = N <= 32 ? 1 : (N <= 64 ? 2 : (N <= 128 ? 4 : 8));
+    wp.ncg = (N + 32 * nj - 1) / (32 * nj);
+    const int groups = std::max(1, cus / 8 / wp.ncg);
+    const dim3 grid(static_cast<unsigned>(groups * wp.ncg * 8));
+#define DGLA_WS(NJV)                                                                                   \
+  do {                                                                                                 \
+    if (p.row_index)                                                                                   \
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, true>), grid, block, 0, s, wp);         \
+    else                                                                                               \
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, false>), grid, block, 0, s, wp);        \
+  } while (0)
+    switch (nj) {
+      case 1: DGLA_WS(1); break;
+      case 2: DGLA_WS(2); break;
+      case 4: DGLA_WS(4); break;
+      default: DGLA_WS(8); break;
+    }
+#undef DGLA_WS
+  }
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 template <typename DT>
@@ -1106,6 +1497,8 @@ int run_segment_mm(const void* a, const void* b, void* c, int64_t M, int64_t K, 
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
     const bool vec = p.vec_a && p.vec_b && p.vec_c;
     {
+      if (ws_eligible(sizeof(DT), M, K, N, num_rel, p.vec_a && p.vec_b, p.vec_c != 0))
+        return launch_segment_mm_ws<DT>(p, ws, sc, s);
       if (glds_eligible(sizeof(DT), K, N, p.vec_a && p.vec_b, p.vec_c != 0)) {
         if constexpr (sizeof(DT) == 4) {
           if (!(p.tune & kTuneMmF32)) {  // fp32 operands as three bf16 terms (default)
@@ -1597,7 +1990,7 @@ extern "C" {
 
 size_t dgla_segment_mm_workspace_bytes(dgla_dtype dtype, int64_t num_rel, int64_t d1, int64_t d2) {
   const size_t elem = dtype == DGLA_F64 ? 8 : (dtype == DGLA_F32 ? 4 : 2);
-  return mm_scratch(num_rel, d1, d2, elem, true, true).total;
+  return mm_scratch(num_rel, d1, d2, elem, true, true, true).total;
 }
 
 int dgla_segment_mm_indexed(int idtype_bits, dgla_dtype dtype, const void* a, const void* b, void* c,
@@ -1610,14 +2003,14 @@ int dgla_segment_mm_indexed(int idtype_bits, dgla_dtype dtype, const void* a, co
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const DeviceGuard dev(s, c);
   const size_t elem = dtype == DGLA_F64 ? 8 : (dtype == DGLA_F32 ? 4 : 2);
-  const MmScratch sc = mm_scratch(num_rel, k, n, elem, !b_trans, false);
+  const MmScratch sc = mm_scratch(num_rel, k, n, elem, !b_trans, false, true);
   void* owned = nullptr;
   if (!workspace || workspace_bytes < sc.total) {
     DGLA_CHECK_HIP(hipMallocAsync(&owned, sc.total, s));
     workspace = owned;
   }
   char* ws = static_cast<char*>(workspace);
-  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, BM, num_rows, ws, sc, s);
+  int rc = stage_plan(idtype_bits, seglen, seglen_on_host, num_rel, BM, num_rows, ws, sc, s, true);
   if (rc == 0) {
     hipLaunchKernelGGL(segment_zero_tail_kernel, dim3(256), dim3(256), 0, s,
                        reinterpret_cast<const int64_t*>(ws + sc.off_plan), num_rel, row_index,
