@@ -104,6 +104,14 @@ LIB.dgla_scatter_add.restype = c_int
 LIB.dgla_scatter_add.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
 LIB.dgla_update_grad_minmax.restype = c_int
 LIB.dgla_update_grad_minmax.argtypes = [c_int, c_int, P(Tensor), c_void_p, c_void_p, c_int64, P(Tensor), c_void_p]
+for _n, _a in (("dgla_peer_alloc", [ctypes.c_size_t, c_int, P(c_void_p)]), ("dgla_peer_free", [c_void_p]),
+               ("dgla_ipc_export", [c_void_p, c_void_p]), ("dgla_ipc_import", [c_void_p, P(c_void_p)]),
+               ("dgla_ipc_release", [c_void_p]),
+               ("dgla_peer_push", [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, ctypes.c_uint64, c_void_p,
+                                   c_void_p]),
+               ("dgla_peer_wait", [c_void_p, c_int, ctypes.c_uint64, c_void_p, c_int64, c_void_p])):
+    getattr(LIB, _n).restype = c_int
+    getattr(LIB, _n).argtypes = _a
 LIB.dgla_spmm_cmp_backward.restype = c_int
 LIB.dgla_spmm_cmp_backward.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p, c_int64, P(Tensor),
                                        c_int, c_void_p]

@@ -13,6 +13,8 @@
 // a binary search over the (<= a few hundred) range boundaries otherwise.
 #include "../../include/dgl_amd.h"
 
+#include <cstring>
+
 #include "common.h"
 
 namespace dgla {
@@ -178,6 +180,92 @@ unsigned grid_for(int64_t n) {
   return static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 256 * 32));
 }
 
+
+// ---- peer-mapped halo exchange (round 4; VERDICT r3 Next #2a) ---------------------------------------------
+// The reference pulls halo rows with three NCCL all-to-alls per call (python/dgl/cuda/nccl.py:98-183); round 3
+// here packed rows into a send buffer and called all_to_all_single.  With every GPU of the node mapped into
+// every process (hipIpcOpenMemHandle over xGMI) the pack kernel can write the rows where the CONSUMER reads
+// them: no send buffer, no collective, no host-side wait.
+//   * segment = (destination rank, chunk): rows serve_rows[begin, end) of the local features go to
+//     dst + (i - begin) * row_bytes inside that rank's halo buffer;
+//   * ONE launch covers all segments (blocks of 64 rows; an empty segment still gets a block so that its flag
+//     moves); a block's last thread publishes with a system-scope release, the LAST block of a segment
+//     (device-scope arrival counter) stores the step number into the segment's flag in the consumer's memory;
+//   * the consumer runs dgla_peer_wait — one wavefront polling its flags with system-scope loads and a
+//     bounded spin (a stuck peer turns into an error code, not a hung GPU) — in front of the launch that reads
+//     the halo rows; the kernel boundary behind it carries the system-scope acquire.
+//   Flags are monotone step counters: no reset, no race between "set" and "clear".  Two halo buffers per rank
+//   (step parity) cover the write-after-read hazard: a peer starts writing buffer s % 2 for step s + 2 only
+//   after it has consumed this rank's step-(s + 1) rows, which this rank sent after reading buffer s % 2.
+struct PeerSegment {
+  int64_t row_begin, row_end;  // range of serve_rows
+  char* dst;                   // where row_begin lands (peer memory)
+  uint64_t* flag;              // the consumer's flag for this (owner, chunk)
+  int64_t blk_begin;           // first block of this segment in the launch
+};
+
+template <typename Piece>
+__global__ __launch_bounds__(256) void peer_push_kernel(const char* __restrict__ x, const int64_t* __restrict__ serve_rows,
+                                                        const PeerSegment* __restrict__ segs, int nseg,
+                                                        int64_t row_bytes, uint64_t epoch, unsigned* __restrict__ arrive) {
+  // which segment does this block belong to?  (<= a few dozen segments: linear scan by one thread)
+  __shared__ int s_seg;
+  if (threadIdx.x == 0) {
+    int sg = 0;
+    while (sg + 1 < nseg && static_cast<int64_t>(blockIdx.x) >= segs[sg + 1].blk_begin) ++sg;
+    s_seg = sg;
+  }
+  __syncthreads();
+  const PeerSegment sg = segs[s_seg];
+  const int64_t nblk = (s_seg + 1 < nseg ? segs[s_seg + 1].blk_begin : static_cast<int64_t>(gridDim.x)) - sg.blk_begin;
+  const int pieces = static_cast<int>(row_bytes / sizeof(Piece));
+  const int64_t r0 = sg.row_begin + (static_cast<int64_t>(blockIdx.x) - sg.blk_begin) * 64;
+  const int64_t r1 = r0 + 64 < sg.row_end ? r0 + 64 : sg.row_end;
+  const int64_t total = (r1 > r0 ? r1 - r0 : 0) * pieces;
+  constexpr int K = 4;
+  for (int64_t base = 0; base < total; base += 256 * K) {
+    Piece v[K];
+    int64_t at[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      int64_t i = base + k * 256 + threadIdx.x;
+      if (i >= total) i = total - 1;
+      const int64_t r = i / pieces;
+      at[k] = r * pieces + (i - r * pieces);
+      v[k] = reinterpret_cast<const Piece*>(x + serve_rows[r0 + r] * row_bytes)[i - r * pieces];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (base + k * 256 + threadIdx.x < total)
+        reinterpret_cast<Piece*>(sg.dst + (r0 - sg.row_begin) * row_bytes)[at[k]] = v[k];
+  }
+  __threadfence_system();  // this thread's rows are visible to the peer before anything that follows
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(arrive + s_seg, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == static_cast<unsigned>(nblk)) {  // every block of the segment has published
+      __hip_atomic_store(arrive + s_seg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next step
+      __threadfence_system();
+      __hip_atomic_store(sg.flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void peer_wait_kernel(const uint64_t* __restrict__ flags, int n, uint64_t epoch,
+                                                       int* __restrict__ status, int64_t max_spins) {
+  for (int i = threadIdx.x; i < n; i += 64) {
+    int64_t spins = 0;
+    while (__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+      __builtin_amdgcn_s_sleep(32);
+      if (++spins > max_spins) {
+        atomicExch(status, 1);  // a peer never wrote: reported by dgla_peer_status, the GPU moves on
+        break;
+      }
+    }
+  }
+  __threadfence_system();
+}
+
 }  // namespace
 }  // namespace dgla
 
@@ -274,6 +362,84 @@ int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const voi
                        mode, num_parts, static_cast<const int64_t*>(range),
                        static_cast<const int64_t*>(local_idx), n, part_id,
                        static_cast<int64_t*>(out));
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+/* ---- peer-mapped halo exchange (see the comment above peer_push_kernel) ---- */
+int dgla_peer_alloc(size_t bytes, int kind, void** out) {
+  if (!out) return xfail("dgla_peer_alloc: null result");
+  *out = nullptr;
+  if (bytes == 0) bytes = 256;
+  hipError_t e = hipErrorUnknown;
+  if (kind == 1) e = hipExtMallocWithFlags(out, bytes, hipDeviceMallocFinegrained);
+  if (kind == 2) e = hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipMalloc(out, bytes);
+  }
+  if (e != hipSuccess) return xfail(std::string("dgla_peer_alloc: ") + hipGetErrorString(e));
+  DGLA_CHECK_HIP(hipMemset(*out, 0, bytes));
+  DGLA_CHECK_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+int dgla_peer_free(void* ptr) {
+  if (ptr) DGLA_CHECK_HIP(hipFree(ptr));
+  return 0;
+}
+
+int dgla_ipc_export(void* ptr, void* handle64) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handles travel as 64 bytes");
+  if (!ptr || !handle64) return xfail("dgla_ipc_export: null argument");
+  hipIpcMemHandle_t h;
+  DGLA_CHECK_HIP(hipIpcGetMemHandle(&h, ptr));
+  memcpy(handle64, &h, 64);
+  return 0;
+}
+
+int dgla_ipc_import(const void* handle64, void** out) {
+  if (!handle64 || !out) return xfail("dgla_ipc_import: null argument");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, 64);
+  DGLA_CHECK_HIP(hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess));
+  return 0;
+}
+
+int dgla_ipc_release(void* ptr) {
+  if (ptr) DGLA_CHECK_HIP(hipIpcCloseMemHandle(ptr));
+  return 0;
+}
+
+int dgla_peer_push(const void* x_local, int64_t row_bytes, const int64_t* serve_rows, const void* segments,
+                   int num_segments, int64_t num_blocks, uint64_t epoch, void* arrive, void* hip_stream) {
+  if (num_segments <= 0 || num_blocks <= 0) return 0;
+  if (!x_local || !segments || !arrive) return xfail("dgla_peer_push: null argument");
+  if (row_bytes <= 0 || row_bytes % 4) return xfail("dgla_peer_push: rows must be a whole number of 4-byte words");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, x_local);
+  const dim3 grid(static_cast<unsigned>(num_blocks));
+  const bool wide = row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(x_local) & 15) == 0;
+  if (wide)
+    hipLaunchKernelGGL(peer_push_kernel<u32x4>, grid, dim3(256), 0, s, static_cast<const char*>(x_local), serve_rows,
+                       static_cast<const PeerSegment*>(segments), num_segments, row_bytes, epoch,
+                       static_cast<unsigned*>(arrive));
+  else
+    hipLaunchKernelGGL(peer_push_kernel<uint32_t>, grid, dim3(256), 0, s, static_cast<const char*>(x_local), serve_rows,
+                       static_cast<const PeerSegment*>(segments), num_segments, row_bytes, epoch,
+                       static_cast<unsigned*>(arrive));
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int dgla_peer_wait(const void* flags, int num_flags, uint64_t epoch, void* status, int64_t max_spins,
+                   void* hip_stream) {
+  if (num_flags <= 0) return 0;
+  if (!flags || !status) return xfail("dgla_peer_wait: null argument");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, flags);
+  hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, static_cast<const uint64_t*>(flags), num_flags, epoch,
+                     static_cast<int*>(status), max_spins > 0 ? max_spins : (int64_t(1) << 24));
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
 }

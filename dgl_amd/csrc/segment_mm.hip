@@ -782,6 +782,7 @@ struct WsFrag<f16_t> {
 
 constexpr int kWsWaves = 8;        // waves per workgroup (one workgroup per CU)
 constexpr int kWsMaxK = 256;       // contraction length the LDS image is sized for
+constexpr int kWsSkew = 1;         // tiles a wave may be ahead of its slowest sibling wave (column groups > 1)
 constexpr int kWsPitchPieces = kWsMaxK / 8 + 1;  // 16-byte pieces per LDS row at K = 256 (odd)
 
 struct WsParams {
@@ -790,6 +791,7 @@ struct WsParams {
   const int64_t* tile32_off; // [R + 1] exclusive prefix of ceil(len / 32)
   int ncg;                   // column groups (workgroups sharing a row chunk)
   int kp;                    // X3: row pitch of the planes in elements
+  int* prog;                 // ncg > 1: [chunk][wave][ncg] tiles STARTED by each sibling wave (zeroed per launch)
 };
 
 // Three bf16 planes of the K-contiguous fp32 weights: out[pl][row][k], row pitch kp, zero padded.
@@ -811,20 +813,21 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   }
 }
 
-template <typename DT, int NJ, bool X3, bool INDEXED>
+template <typename DT, int NJ, bool X3, bool INDEXED, int RS, bool NTA>
 __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const WsParams wp) {
   const MmParams& p = wp.m;
   constexpr int ES = sizeof(DT);
   constexpr int PL = X3 ? 3 : 1;
   constexpr int ROWS = PL * NJ * 32;
-  constexpr int AV = X3 ? 2 : 1;  // 16-byte vectors of A per lane and k-step (fp32: 8 floats)
+  constexpr int KSS = X3 ? 2 : 4;  // k-steps fed by one ring slot (one 128-byte line of the A row)
   static_assert(X3 == (ES == 4), "X3 is the fp32 path");
   __shared__ __attribute__((aligned(1024))) char smem[ROWS * kWsPitchPieces * 16 + 1024];  // (+ the last DMA instruction's overhang)
 
   const int K = p.K, N = p.N;
-  const int nks = (K + 15) >> 4;   // k-steps of 16
-  const int nround = (nks + 7) >> 3;
-  const int pp = 2 * nks + 1;      // LDS row pitch in 16-byte pieces (odd)
+  const int nss = (K * ES + 127) >> 7;          // ring slots (128-byte lines) per A row
+  const int nround = (nss + RS - 1) / RS;
+  const int pp = (X3 ? 4 : 8) * nss + 1;        // LDS row pitch in 16-byte pieces (odd)
+  const int kpieces = X3 ? (wp.kp >> 3) : (K >> 3);  // 16-byte pieces with data per weight row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l = lane & 31, khalf = lane >> 5;
 
@@ -845,6 +848,8 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
   typedef typename WsFrag<typename std::conditional<X3, bf16_t, DT>::type>::type frag_t;
 
   int64_t t = t0;
+  int started = 1;       // tiles this wave has started (+ 1), across the relations of its chunk
+  bool gave_up = false;
   while (t < t1) {
     const int64_t rel = uniform64(find_segment(tile_off, p.num_rel, t));
     const int64_t rel_t0 = uniform64(tile_off[rel]);
@@ -856,7 +861,6 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
     __syncthreads();  // nobody still multiplies from the previous relation's image
     {
       const int total = ROWS * pp, ninst = (total + 63) >> 6;
-      const int kpieces = X3 ? (wp.kp >> 3) : (K >> 3);      // 16-byte pieces with data per weight row
       const int64_t rpitch = X3 ? static_cast<int64_t>(wp.kp) * 2 : static_cast<int64_t>(K) * ES;
       const int64_t plane_bytes = X3 ? static_cast<int64_t>(p.num_rel) * N * rpitch : 0;
       const char* __restrict__ W = X3 ? static_cast<const char*>(wp.planes) : static_cast<const char*>(p.bt);
@@ -879,36 +883,71 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
       int64_t row = rel_row0 + (tt - rel_t0) * 32 + l;
       if (row >= row_end) row = row_end - 1;
       if constexpr (INDEXED) row = p.row_index[row];
-      return A + row * (static_cast<int64_t>(K) * ES) + khalf * (16 * AV);
+      return A + row * (static_cast<int64_t>(K) * ES) + khalf * 64;
     };
-    struct AFrag {
-      u32x4 v[AV];
+    // One ring slot = the lane's half (64 bytes) of one 128-byte LINE of its A row: four 16-byte loads
+    // issued back to back, so the two lanes of a row ask for the whole line within a few cycles and the
+    // vector cache sees ONE miss per line (k-steps of 32 bytes per row, requested a k-step apart, made every
+    // line four separate requests: 100 G requests/s at 5 TB/s).  16-bit: the slot feeds 4 k-steps (k-step i
+    // multiplies elements 64 ss + 32 h + 8 i ..+8); fp32: 2 k-steps of 8 floats per lane.  The weights'
+    // piece for (slot ss, half h, k-step i) is 8 ss + 4 h + i (16-bit) / 4 ss + 2 h + i (bf16 planes): the
+    // contraction index is permuted identically on both operands.
+    struct ASlot {
+      u32x4 v[4];
     };
-    // Branch-free: a lane whose piece lies past the end of the row (K not a multiple of 16), and every lane of a
-    // refill that has nothing left to fetch, reads the zero page instead — a predicated load would sit in a
-    // divergent block and the compiler then waits for vmcnt(0) at every use (seen in the first build).
-    auto load_a = [&](const char* base, int ks, bool on) -> AFrag {
-      AFrag f;
-      const int e0 = ks * 16 + khalf * 8;  // first element of the lane's piece
+    // Branch-free: a piece past the end of the row (K not a multiple of the line), and every lane of a refill
+    // that has nothing left to fetch, reads the zero page instead — a predicated load would sit in a divergent
+    // block and the compiler then waits for vmcnt(0) at every use (seen in the first build).
+    auto load_slot = [&](const char* base, int ss, bool on) -> ASlot {
+      ASlot f;
 #pragma unroll
-      for (int h = 0; h < AV; ++h) {
-        const int e = X3 ? e0 + h * 4 : e0;  // (X3: 4 floats per vector)
-        const char* src = (on && e < K) ? base + static_cast<int64_t>(ks) * (32 * AV) + h * 16
-                                        : reinterpret_cast<const char*>(g_mm_zero_page);
-        f.v[h] = *reinterpret_cast<const u32x4*>(src);
+      for (int i = 0; i < 4; ++i) {
+        const int e = (ss * 128 + khalf * 64 + i * 16) / ES;  // first element of the piece
+        const char* src = (on && e < K) ? base + ss * 128 + i * 16 : reinterpret_cast<const char*>(g_mm_zero_page);
+        if constexpr (NTA)
+          f.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+        else
+          f.v[i] = *reinterpret_cast<const u32x4*>(src);
       }
       return f;
     };
 
     if (first < rel_end) {
       const char* cur = lane_ptr(first);
-      AFrag ar[8];
+      ASlot ar[RS];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        ar[u] = load_a(cur, u, u < nks);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int u = 0; u < RS; ++u) {
+        ar[u] = load_slot(cur, u, u < nss);
+        __builtin_amdgcn_sched_barrier(0);  // same issue order as the refills below (else: vmcnt(0) in the fp32 kernel)
       }
       for (int64_t tt = first; tt < rel_end; tt += kWsWaves) {
+        if (wp.ncg > 1 && !gave_up) {
+          // ---- keep the sibling waves of the other column groups within kWsSkew tiles ------------------------
+          // The ncg workgroups of a row chunk (same XCD) read the SAME A rows; the rows come from HBM once only
+          // if the siblings touch them while they are still in that XCD's L2 (4 MiB shared by 8 such groups:
+          // about two tiles per wave).  Unpaced, the groups drift apart and A is read ncg times from HBM
+          // (measured: 9.25 ms = 50 GB at the copy rate instead of 20 GB).  Soft barrier: every wave publishes
+          // the number of tiles it has STARTED and waits (bounded) while it is more than kWsSkew ahead of its
+          // slowest sibling.  Progress words are relaxed agent-scope atomics (L2-coherent); nothing else is
+          // communicated, so a stale or late value costs time, never correctness.
+          int* pw = wp.prog + (static_cast<int64_t>(chunk) * kWsWaves + wave) * wp.ncg;
+          if (lane == 0) __hip_atomic_store(pw + cg, started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int spins = 0;; ++spins) {
+            int slowest = started;
+            for (int j = 0; j < wp.ncg; ++j) {
+              const int v = __hip_atomic_load(pw + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              slowest = v < slowest ? v : slowest;
+            }
+            slowest = __builtin_amdgcn_readfirstlane(slowest);
+            if (started - slowest <= kWsSkew) break;
+            if (spins > (1 << 16)) {  // a sibling that is not resident (CU masks, co-running kernels): stop pacing
+              gave_up = true;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+          }
+          ++started;
+        }
         const bool more = tt + kWsWaves < rel_end;
         const char* nxt = more ? lane_ptr(tt + kWsWaves) : cur;
         f32x16 acc[NJ];
@@ -919,41 +958,46 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
         for (int q = 0; q < nround; ++q) {
           const bool last = q + 1 == nround;
           const char* rp = last ? nxt : cur;
-          const int rk0 = last ? 0 : (q + 1) * 8;
+          const int rk0 = last ? 0 : (q + 1) * RS;
           const bool refill = !last || more;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int ks = q * 8 + u;
-            if (ks < nks) {  // (uniform)
-              const char* brow = smem + (l * pp + 2 * ks + khalf) * 16;
-              if constexpr (!X3) {
-                frag_t bf[NJ];
+          for (int u = 0; u < RS; ++u) {
+            const int ss = q * RS + u;
+            if (ss < nss) {  // (uniform)
 #pragma unroll
-                for (int jj = 0; jj < NJ; ++jj)
-                  bf[jj] = *reinterpret_cast<const frag_t*>(brow + jj * 32 * pp * 16);
-                const frag_t af = __builtin_bit_cast(frag_t, ar[u].v[0]);
+              for (int i = 0; i < KSS; ++i) {
+                const int piece0 = (X3 ? 4 : 8) * ss + i;  // the h = 0 lanes' piece of this k-step
+                if (piece0 >= kpieces) continue;            // (uniform) a k-step wholly past the end of the row
+                const char* brow = smem + (l * pp + piece0 + (X3 ? 2 : 4) * khalf) * 16;
+                if constexpr (!X3) {
+                  frag_t bf[NJ];
 #pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) acc[jj] = WsFrag<DT>::mma(af, bf[jj], acc[jj]);
-              } else {
-                b16x8 ah, am, al;
-                split3(__builtin_bit_cast(f32x4, ar[u].v[0]), __builtin_bit_cast(f32x4, ar[u].v[AV - 1]), ah, am, al);
+                  for (int jj = 0; jj < NJ; ++jj)
+                    bf[jj] = *reinterpret_cast<const frag_t*>(brow + jj * 32 * pp * 16);
+                  const frag_t af = __builtin_bit_cast(frag_t, ar[u].v[i]);
 #pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) {
-                  const b16x8 bh = *reinterpret_cast<const b16x8*>(brow + (0 * NJ + jj) * 32 * pp * 16);
-                  const b16x8 bm = *reinterpret_cast<const b16x8*>(brow + (1 * NJ + jj) * 32 * pp * 16);
-                  const b16x8 bl = *reinterpret_cast<const b16x8*>(brow + (2 * NJ + jj) * 32 * pp * 16);
-                  f32x16 c = acc[jj];  // small terms first
-                  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-                  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-                  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
-                  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
-                  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
-                  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-                  acc[jj] = c;
+                  for (int jj = 0; jj < NJ; ++jj) acc[jj] = WsFrag<DT>::mma(af, bf[jj], acc[jj]);
+                } else {
+                  b16x8 ah, am, al;
+                  split3(__builtin_bit_cast(f32x4, ar[u].v[2 * i]), __builtin_bit_cast(f32x4, ar[u].v[2 * i + 1]), ah, am, al);
+#pragma unroll
+                  for (int jj = 0; jj < NJ; ++jj) {
+                    const b16x8 bh = *reinterpret_cast<const b16x8*>(brow + (0 * NJ + jj) * 32 * pp * 16);
+                    const b16x8 bm = *reinterpret_cast<const b16x8*>(brow + (1 * NJ + jj) * 32 * pp * 16);
+                    const b16x8 bl = *reinterpret_cast<const b16x8*>(brow + (2 * NJ + jj) * 32 * pp * 16);
+                    f32x16 c = acc[jj];  // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                    acc[jj] = c;
+                  }
                 }
               }
             }
-            ar[u] = load_a(rp, rk0 + u, refill && rk0 + u < nks);  // in place: 8 fragments stay in flight
+            ar[u] = load_slot(rp, rk0 + u, refill && rk0 + u < nss);  // in place: the ring stays in flight
             // keep program order = source order: hoisting the refill above the slot's own multiply makes the
             // compiler rotate the ring's registers and (fp32 kernel) drain the ring with vmcnt(0) once per round
             __builtin_amdgcn_sched_barrier(0);
@@ -970,7 +1014,7 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
         }
         const int64_t trow0 = rel_row0 + (tt - rel_t0) * 32;
         const int col = n0 + NJ * l;
-        const bool nt_c = (p.tune & kTuneNtOut) != 0;
+        constexpr bool nt_c = true;  // C is written once and never re-read here (1.94 -> 1.90 ms at the R-GCN shape)
         // the usual tile — all 32 rows inside the segment, all of the group's columns inside N — stores without a
         // predicate (wave-uniform test); ragged tiles take the element-wise path
         const bool whole = trow0 + 32 <= row_end && n0 + 32 * NJ <= N;
@@ -1304,9 +1348,10 @@ __global__ __launch_bounds__(256) void gather_mm_kernel(const DT* __restrict__ a
 
 // ---- host side ------------------------------------------------------------------------------
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+constexpr size_t kWsProgWords = 64 * 1024;  // >= chunks x 8 waves x column groups
 
 struct MmScratch {
-  size_t off_plan, off_t32, off_bt, off_planes, off_acc, total;
+  size_t off_plan, off_t32, off_prog, off_bt, off_planes, off_acc, total;
 };
 
 MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool need_bt,
@@ -1317,6 +1362,8 @@ MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool ne
   off = align256(off + sizeof(int64_t) * (2 * num_rel + 2) + /* staged seglen */ 8 * num_rel + /* NaN flag */ 8);
   s.off_t32 = off;
   if (forward) off = align256(off + sizeof(int64_t) * (num_rel + 1));
+  s.off_prog = off;  // pacing words of the weights-stationary kernel: [row chunk][wave][column group]
+  if (forward) off = align256(off + sizeof(int) * kWsProgWords);
   s.off_bt = off;
   if (need_bt) off = align256(off + static_cast<size_t>(num_rel) * K * N * elem);
   s.off_planes = off;  // fp32 forward: the weights as three bf16 planes (weights-stationary kernel)
@@ -1411,9 +1458,16 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
   wp.planes = nullptr;
   wp.tile32_off = reinterpret_cast<const int64_t*>(ws + sc.off_t32);
   wp.kp = 0;
+  wp.prog = reinterpret_cast<int*>(ws + sc.off_prog);
   const int N = p.N;
-  const int cus = mm_num_cus();
+  int cus = mm_num_cus();
+  if (const char* ew = getenv("DGLA_MM_WS_WGS")) {  // experiment: fewer workgroups than CUs
+    if (atoi(ew) >= 8) cus = atoi(ew);
+  }
   const dim3 block(64 * kWsWaves);
+  // experiment switch (round 4 A/B): bit 0 = non-temporal A loads, bit 1 = ring of 4 slots
+  const char* ev = getenv("DGLA_MM_WS_VARIANT");
+  const int variant = ev && *ev ? atoi(ev) : 0;
   if constexpr (sizeof(DT) == 4) {
     // fp32: three bf16 planes of the weights, once per call; 64 columns per workgroup
     wp.kp = (p.K + 7) / 8 * 8;
@@ -1425,22 +1479,34 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
     wp.ncg = (N + 63) / 64;
     const int groups = std::max(1, cus / 8 / wp.ncg);  // row chunks per XCD
     const dim3 grid(static_cast<unsigned>(groups * wp.ncg * 8));
+    if (static_cast<size_t>(groups) * 8 * kWsWaves * wp.ncg > kWsProgWords) return mfail("segment_mm: too many column groups");
+    if (wp.ncg > 1) DGLA_CHECK_HIP(hipMemsetAsync(wp.prog, 0, sizeof(int) * groups * 8 * kWsWaves * wp.ncg, s));
     if (p.row_index)
-      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, true>), grid, block, 0, s, wp);
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, true, 4, false>), grid, block, 0, s, wp);
+    else if (variant & 1)
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, false, 4, true>), grid, block, 0, s, wp);
     else
-      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, false>), grid, block, 0, s, wp);
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, false, 4, false>), grid, block, 0, s, wp);
     hipLaunchKernelGGL(x3_repair_fwd_kernel, dim3(1024), dim3(256), 0, s, p);  // no-op unless a NaN came out
   } else {
     const int nj = N <= 32 ? 1 : (N <= 64 ? 2 : (N <= 128 ? 4 : 8));
     wp.ncg = (N + 32 * nj - 1) / (32 * nj);
     const int groups = std::max(1, cus / 8 / wp.ncg);
     const dim3 grid(static_cast<unsigned>(groups * wp.ncg * 8));
+    if (static_cast<size_t>(groups) * 8 * kWsWaves * wp.ncg > kWsProgWords) return mfail("segment_mm: too many column groups");
+    if (wp.ncg > 1) DGLA_CHECK_HIP(hipMemsetAsync(wp.prog, 0, sizeof(int) * groups * 8 * kWsWaves * wp.ncg, s));
 #define DGLA_WS(NJV)                                                                                   \
   do {                                                                                                 \
     if (p.row_index)                                                                                   \
-      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, true>), grid, block, 0, s, wp);         \
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, true, 2, false>), grid, block, 0, s, wp);  \
+    else if ((variant & 3) == 1)                                                                       \
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, false, 2, true>), grid, block, 0, s, wp);  \
+    else if ((variant & 3) == 2)                                                                       \
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, false, 4, false>), grid, block, 0, s, wp); \
+    else if ((variant & 3) == 3)                                                                       \
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, false, 4, true>), grid, block, 0, s, wp);  \
     else                                                                                               \
-      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, false>), grid, block, 0, s, wp);        \
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, false, 2, false>), grid, block, 0, s, wp); \
   } while (0)
     switch (nj) {
       case 1: DGLA_WS(1); break;

@@ -23,6 +23,37 @@ import torch.distributed as dist
 _FORCE_COLLECTIVES = os.environ.get("DGLA_FORCE_COLLECTIVES", "0") == "1"
 
 
+class _KernelRows:
+    """Row kernels of the exchange: the library's HIP kernels (csrc/exchange.hip, csrc/segment.hip).  There
+    is no CPU implementation in the package; the gloo / CPU flow tests install torch stand-ins from
+    tests/cpu_backends.py through :func:`set_row_backend`."""
+
+    @staticmethod
+    def gather(src, idx, out=None):
+        from . import _capi
+        return _capi.gather_rows(src, idx, out=out)
+
+    @staticmethod
+    def scatter_add(src, idx, out):
+        from . import _capi
+        return _capi.scatter_add(src, idx, out)
+
+    @staticmethod
+    def scatter_rows(src, idx, out):
+        from . import _capi
+        return _capi.scatter_rows(src, idx, out)
+
+
+_ROWS = [_KernelRows]
+
+
+def set_row_backend(backend):
+    """Install the row-kernel backend (``None`` = the library's kernels); returns the previous one."""
+    old = _ROWS[0]
+    _ROWS[0] = _KernelRows if backend is None else backend
+    return old
+
+
 def _host_staged(t, group):
     """Device tensors under the gloo backend (flow tests of the multi-process code on one GPU):
     gloo's all-to-all only takes host tensors, so the exchange is staged through host memory.
@@ -156,12 +187,8 @@ class HaloExchange:
             s0, s1 = self.serve_bounds[c], self.serve_bounds[c + 1]
             h0, h1 = self.chunk_bounds[c], self.chunk_bounds[c + 1]
             rows, send = self.serve_rows[s0:s1], buf[s0:s1]
-            if s1 > s0:  # pack this chunk (csrc/exchange.hip on the GPU; torch on CPU tensors under gloo)
-                if xl.is_cuda:
-                    from . import _capi
-                    _capi.gather_rows(xl, rows, out=send)
-                else:
-                    torch.index_select(xl, 0, rows, out=send)
+            if s1 > s0:  # pack this chunk (csrc/exchange.hip)
+                _ROWS[0].gather(xl, rows, out=send)
             if _host_staged(halo_out, self.group):
                 _all_to_all(halo_out[h0:h1], send, self.recv_pieces[c], self.send_pieces[c], self.group)
                 works.append(None)
@@ -197,11 +224,7 @@ class HaloExchange:
             s0, s1 = self.serve_bounds[c], self.serve_bounds[c + 1]
             h0, h1 = self.chunk_bounds[c], self.chunk_bounds[c + 1]
             _all_to_all(self._recv_buf[s0:s1], hg[h0:h1], self.send_pieces[c], self.recv_pieces[c], self.group)
-        if local_grad.is_cuda:
-            from . import _capi
-            _capi.scatter_add(self._recv_buf, self.serve_rows, local_grad)
-        else:
-            local_grad.index_add_(0, self.serve_rows, self._recv_buf)
+        _ROWS[0].scatter_add(self._recv_buf, self.serve_rows, local_grad)
         return local_grad
 
     def bytes_per_step(self, elem_size=4):
@@ -455,10 +478,7 @@ def _splits_to_host(*tensors):
 
 
 def _take_rows(value, idx):
-    if value.is_cuda:
-        from . import _capi
-        return _capi.gather_rows(value.contiguous(), idx)
-    return value[idx.long()]
+    return _ROWS[0].gather(value.contiguous(), idx)
 
 
 def sparse_all_to_all_push(idx, value, partition, group=None):
@@ -500,11 +520,7 @@ def sparse_all_to_all_pull(req_idx, value, partition, group=None):
                             device=value.device)
     _all_to_all(req_value, _take_rows(value, resp_idx), req_l, resp_l, group)
     out = torch.empty_like(req_value)
-    if req_value.is_cuda:  # back into the requested order: out[perm[i]] = req_value[i]
-        from . import _capi
-        _capi.scatter_rows(req_value, perm.contiguous(), out)
-    else:
-        out[perm.long()] = req_value
+    _ROWS[0].scatter_rows(req_value, perm.contiguous(), out)  # back into the requested order: out[perm[i]] = req_value[i]
     return out
 
 
@@ -690,12 +706,19 @@ class ShardedSpMM:
         self.shard = shard
         self.n_local, self.n_halo = shard["n_local"], shard["n_halo"]
         self.device = torch.device(device)
-        self.halo = torch.empty((self.n_halo,) + tuple(feat_shape), dtype=dtype, device=self.device)
         self.rank = rank
-        if exchange is None:
+        if exchange == "peer":   # peer-mapped halo buffers (dgl_amd/peer_exchange.py): the pack kernel writes into them
+            from .peer_exchange import PeerHaloExchange
+            exchange = PeerHaloExchange(self.n_local, self.n_halo, feat_shape, dtype, self.device,
+                                        requests=shard["requests"], group=group, chunks=chunks)
+        elif exchange is None:
             exchange = HaloExchange(self.n_local, self.n_halo, int(torch.tensor(feat_shape).prod()),
                                     self.device, requests=shard["requests"], group=group, chunks=chunks)
         self.exchange = exchange
+        self.peer = hasattr(exchange, "begin_step")
+        # (the peer exchange owns the halo buffers: they are what the other ranks write into)
+        self.halo = None if self.peer else torch.empty((self.n_halo,) + tuple(feat_shape), dtype=dtype,
+                                                       device=self.device)
         # chunked pipeline: the halo-column block is split by chunk of the (chunk-major) halo buffer;
         # chunk c's launch is queued as soon as chunk c's all-to-all has landed, while c + 1 travels
         self.chunks = int(getattr(exchange, "chunks", 1))
@@ -715,6 +738,17 @@ class ShardedSpMM:
 
     def step(self, x_local, out_local):
         assert x_local.shape[0] == self.n_local and out_local.shape[0] == self.n_local
+        if self.peer:
+            # push (one launch) || own-column launch, then per chunk: flag wait (one wavefront) -> halo launch
+            halo = self.exchange.begin_step(x_local)
+            self.spmm("local", self.shard["local"], self.n_local, x_local, out_local, False)
+            if self.n_halo:
+                for c, blk in enumerate(self.halo_blocks):
+                    self.exchange.wait_chunk(c)
+                    self.spmm("halo" if c == 0 else "halo%d" % c, blk, self.n_halo, halo, out_local, True)
+            else:
+                self.exchange.wait()   # still consume the peers' (empty) flags: keeps the ranks in step
+            return out_local
         work = None
         if isinstance(self.exchange, SimulatedExchange):
             self.exchange.pull_into(self.rank, self.halo)

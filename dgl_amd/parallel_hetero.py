@@ -147,35 +147,25 @@ def _gpu_stacked_factory(device):
             if not accumulate:
                 out.zero_()
             return
-        key = (tag, tuple(int(x.data_ptr()) for x in xs))
-        ent = state.get(key)
+        # ONE csr + workspace per block (keyed by the tag alone: activations get new addresses every layer
+        # and step, a key made of data_ptr values grew without bound and pinned a workspace per entry,
+        # ADVICE r3); only the small pointer table is rebuilt when the operand pointers change
+        ptrs = tuple(int(x.data_ptr()) for x in xs)
+        ent = state.get(tag)
         if ent is None:
             csr = _capi.make_csr(indptr, indices, None, n_cols)
             ws = torch.empty(_capi.spmm_csr_stacked_workspace_bytes("copy_lhs", csr, xs[0], None, out),
                              dtype=torch.uint8, device=out.device)
             tabs = _capi.spmm_csr_stacked("copy_lhs", csr, relid, xs, None, out, ws, accumulate=accumulate)
-            state[key] = [csr, ws, tabs[0]]
+            state[tag] = [csr, ws, tabs[0], ptrs]
             return
-        csr, ws, tab = ent
-        _capi.spmm_csr_stacked("copy_lhs", csr, relid, xs, None, out, ws, u_table=tab, accumulate=accumulate,
-                               plan_valid=True)
+        csr, ws, tab, old = ent
+        if old != ptrs:
+            tab = None   # rebuilt by the call below
+        tabs = _capi.spmm_csr_stacked("copy_lhs", csr, relid, xs, None, out, ws, u_table=tab, accumulate=accumulate,
+                                      plan_valid=True)
+        ent[2], ent[3] = tabs[0], ptrs
 
-    return run
-
-
-def torch_stacked_backend():
-    """Kernel stand-in for the gloo / CPU tests (host logic only): the same stacked block
-    evaluated with torch index_add in the tensors' own dtype."""
-    def run(tag, block, n_cols, xs, out, accumulate):
-        indptr, indices, relid = block
-        if not accumulate:
-            out.zero_()
-        ip = indptr.long()
-        row_of = torch.repeat_interleave(torch.arange(ip.numel() - 1, device=ip.device), ip[1:] - ip[:-1])
-        for r, x in enumerate(xs):
-            m = relid == r
-            if bool(m.any()):
-                out.index_add_(0, row_of[m], x[indices[m].long()])
     return run
 
 

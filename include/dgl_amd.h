@@ -422,6 +422,28 @@ int dgla_partition_to_global(int idtype_bits, int mode, int num_parts, const voi
                              const void* local_idx, int64_t n, int part_id, void* out,
                              void* hip_stream);
 
+/* ---- peer-mapped halo exchange (replaces the value exchange of sparse_all_to_all_pull,
+ * python/dgl/cuda/nccl.py:98-183, when every GPU of the node can map every other GPU's memory) ----
+ * dgla_peer_alloc: device memory that can be exported (kind 0 = hipMalloc, 1 = fine-grained, 2 = uncached;
+ *   falls back to hipMalloc when the flavour is refused), zero filled.  dgla_ipc_export / _import / _release =
+ *   hipIpcGetMemHandle / OpenMemHandle / CloseMemHandle on 64-byte handles.
+ * dgla_peer_push: ONE launch writes rows serve_rows[seg.row_begin .. seg.row_end) of x_local into every
+ *   segment's destination (a peer's halo buffer) and then stores `epoch` into the segment's flag in the peer's
+ *   memory.  `segments` = DEVICE array of num_segments records {int64 row_begin, row_end; void* dst;
+ *   uint64* flag; int64 blk_begin} with blk_begin = exclusive prefix of max(1, ceil(rows / 64)), num_blocks
+ *   its total; `arrive` = num_segments zeroed uint32 counters in device memory (kept zero between calls).
+ * dgla_peer_wait: one wavefront on the stream polls flags[0 .. num_flags) until each is >= epoch (bounded:
+ *   after max_spins polls *status (device int) becomes 1 and the stream continues). */
+int dgla_peer_alloc(size_t bytes, int kind, void** out);
+int dgla_peer_free(void* ptr);
+int dgla_ipc_export(void* ptr, void* handle64);
+int dgla_ipc_import(const void* handle64, void** out);
+int dgla_ipc_release(void* ptr);
+int dgla_peer_push(const void* x_local, int64_t row_bytes, const int64_t* serve_rows, const void* segments,
+                   int num_segments, int64_t num_blocks, uint64_t epoch, void* arrive, void* hip_stream);
+int dgla_peer_wait(const void* flags, int num_flags, uint64_t epoch, void* status, int64_t max_spins,
+                   void* hip_stream);
+
 /* Process-wide tuning bits.  The SpMM bits change no result bit; they select memory-system behaviour
  * and exist so that a benchmark can A/B them:
  *   DGLA_TUNE_XCD     units visit the merge path in XCD-contiguous order (block b runs on XCD
