@@ -292,6 +292,16 @@ def single_gpu(args, dev, n, e, f):
     return step, ctx
 
 
+def close_exchange(ctx, dist):
+    """Unmap / free the peer-mapped halo buffers of a finished run (all ranks together)."""
+    ex = getattr(ctx.get("op"), "exchange", None) if ctx else None
+    if ex is not None and hasattr(ex, "close"):
+        torch.cuda.synchronize()
+        dist.barrier()
+        ex.check()
+        ex.close()
+
+
 def multi_gpu(args, dev, n, e, f, rank, world, dist, spmm=None):
     """N > 1: STRONG scaling of the one graph.  Every rank builds the same graph and features
     from the same seeds, rank 0 partitions the nodes (native k-way partitioner standing where
@@ -338,7 +348,8 @@ def multi_gpu(args, dev, n, e, f, rank, world, dist, spmm=None):
 
             def work():
                 try:
-                    box["r"] = partition_assignment(g["indptr"], g["indices"], world, seed=1)
+                    # objtype="vol": what the exchange moves is DISTINCT remote rows, not cut edges
+                    box["r"] = partition_assignment(g["indptr"], g["indices"], world, seed=1, objtype="vol")
                 except BaseException as ex:  # re-raised on the main thread
                     box["e"] = ex
 
@@ -357,14 +368,19 @@ def multi_gpu(args, dev, n, e, f, rank, world, dist, spmm=None):
                     pass
             else:
                 stats = {"fallback": "k-way partitioner exceeded %.0f s: contiguous ranges used" % budget}
+                print("bench.py: WARNING: %s (the line's config.partitioner_used says so too)" % stats["fallback"],
+                      file=sys.stderr, flush=True)
         if done is None:
             bounds = partition_rows(g["indptr"].cpu(), world)
             part.copy_(torch.searchsorted(bounds[1:].contiguous(), torch.arange(n), right=True))
     dist.broadcast(part, src=0)
     t_part = time.perf_counter() - t0
     sh = shard_from_partition(g["indptr"], g["indices"], part, world, rank)
+    # exchange: peer-mapped halo buffers written by the pack kernel (dgl_amd/peer_exchange.py; all ranks of one
+    # node) unless --exchange alltoall asks for the RCCL all_to_all_single path (CPU flow tests pass spmm=...)
+    use_peer = getattr(args, "exchange", "peer") == "peer" and spmm is None and dev.type == "cuda"
     op = ShardedSpMM(sh, (f,), x_full.dtype, dev, spmm=spmm,  # spmm=None: the library's kernels
-                     chunks=max(1, int(getattr(args, "chunks", 1))))
+                     chunks=max(1, int(getattr(args, "chunks", 1))), exchange="peer" if use_peer else None)
     x_loc = x_full[sh["rows"]].contiguous()
     out = torch.empty(sh["n_local"], f, device=dev)
 
@@ -385,7 +401,7 @@ def multi_gpu(args, dev, n, e, f, rank, world, dist, spmm=None):
     dist.all_gather_object(infos, info)
     ctx = {"g": g, "x": x_full, "out": out, "shard": sh, "op": op, "x_loc": x_loc, "edges": sh["nnz"],
            "rows": sh["n_local"], "alg_bytes": algorithmic_bytes(sh["n_local"], sh["nnz"], f),
-           "profile_in_step": False, "infos": infos, "partition_s": t_part,
+           "profile_in_step": False, "infos": infos, "partition_s": t_part, "exchange": "peer" if use_peer else "alltoall",
            "partition_stats": stats, "step_replicated": step_replicated, "out_replicated": out_rep}
     return step, ctx
 
@@ -404,6 +420,9 @@ def main():
     ap.add_argument("--chunks", type=int, default=2,
                     help="N > 1: pipeline chunks of the halo exchange (chunk c's halo-column launch is queued "
                          "when chunk c has landed, while chunk c + 1 travels); 1 = one all-to-all per step")
+    ap.add_argument("--exchange", default="peer", choices=["peer", "alltoall"],
+                    help="N > 1: halo exchange — peer = the pack kernel writes into the peers' IPC-mapped halo buffers "
+                         "and flags (no collective); alltoall = pack + all_to_all_single over RCCL")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-peak", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
@@ -498,7 +517,8 @@ def main():
         scratch = torch.empty_like(ctx["out"])  # (the halo launch accumulates: keep the step's result intact)
         t_loc = merge_kernel_ms(lambda: op.spmm("local", sh["local"], sh["n_local"], ctx["x_loc"],
                                                 scratch, False))
-        t_halo = merge_kernel_ms(lambda: op.spmm("halo", sh["halo"], sh["n_halo"], op.halo,
+        halo_t = op.halo if op.halo is not None else op.exchange._halo[op.exchange.epoch & 1]
+        t_halo = merge_kernel_ms(lambda: op.spmm("halo", sh["halo"], sh["n_halo"], halo_t,
                                                  scratch, True)) if sh["n_halo"] else 0.0
         del scratch
         kern_avg = kern_min = t_loc + t_halo
@@ -507,6 +527,12 @@ def main():
     result = None
     if rank == 0:
         achieved = ctx["alg_bytes"] / (kern_avg * 1e-3) / 1e9
+        kernel_only = achieved
+        if world > 1:
+            # N > 1: the roofline of the WHOLE STEP — exchange included: the job's algorithmic bytes over the
+            # max-over-ranks step time, per GPU (VERDICT r3 Weak #7: "two launches timed alone" looked healthy
+            # whatever the exchange cost)
+            achieved = algorithmic_bytes(n, e, f) / (ms_per_step * 1e-3) / 1e9 / world
         result = {
             "metric": "edges/sec for g-SpMM copy_u+sum (feat=100); % HBM roofline",
             "value": e / (ms_per_step * 1e-3),
@@ -525,12 +551,16 @@ def main():
                 "step": "one dgla_spmm_csr call over the whole graph, X treated as new on every "
                         "step (split-row copy of X when the locality probe wants it, merge kernel, "
                         "fix-up kernel)" if world == 1 else
-                        "ShardedSpMM.step on every rank: pack + halo all-to-all (RCCL, %d pipeline chunk(s)) "
-                        "overlapped with the own-column launch, then the halo-column launch(es) accumulate"
+                        ("ShardedSpMM.step on every rank: ONE pack launch writes the requested rows into the peers' "
+                         "IPC-mapped halo buffers (%d chunk(s), flags), own-column launch, then per chunk a one-wavefront "
+                         "flag wait + halo-column launch (accumulate)" if ctx.get("exchange") == "peer" else
+                         "ShardedSpMM.step on every rank: pack + halo all-to-all (RCCL, %d pipeline chunk(s)) "
+                         "overlapped with the own-column launch, then the halo-column launch(es) accumulate")
                         % max(1, int(getattr(args, "chunks", 1))),
                 "parallelism": "1 GPU" if world == 1 else
-                               "%d-way node partition (%s), destination rows + features sharded, "
-                               "halo pull by all_to_all_single over RCCL" % (world, args.partitioner),
+                               "%d-way node partition (%s), destination rows + features sharded, halo rows %s"
+                               % (world, args.partitioner, "written peer-to-peer into IPC-mapped buffers"
+                                  if ctx.get("exchange") == "peer" else "pulled by all_to_all_single over RCCL"),
                 "tuning_flags": _capi.get_tuning(),
             },
             "roofline": {
@@ -552,7 +582,14 @@ def main():
                 "halo_rows_max": max(i["halo_rows"] for i in infos),
                 "exchange_bytes_per_step_max_rank": max(i["halo_bytes"] for i in infos),
             })
-            result["roofline"]["note"] = "rank 0's shard: its algorithmic bytes / its two merge launches"
+            result["config"]["partitioner_used"] = (ctx["partition_stats"] or {}).get(
+                "fallback", (ctx["partition_stats"] or {}).get("method", args.partitioner))
+            result["config"]["exchange"] = ctx.get("exchange")
+            result["roofline"]["note"] = ("whole step, exchange included: the job's algorithmic bytes / max-over-ranks "
+                                          "step time / n_gpus; `kernel` fields = rank 0's two merge launches timed alone")
+            result["roofline"]["kernel_only_achieved_rank0"] = kernel_only
+            result["roofline"]["kernel_only_frac_rank0"] = kernel_only / HBM_PEAK_GBPS
+            result["roofline"]["algorithmic_bytes_per_launch"] = algorithmic_bytes(n, e, f)
 
     if rank == 0 and world == 1 and args.scale == 1 and args.variant == "U":
         t, src = pmc_traffic()
@@ -644,6 +681,7 @@ def main():
         if args.variant == "U" and not args.no_variants:
             import copy
 
+            close_exchange(ctx, dist)
             del ctx, step, rep
             torch.cuda.empty_cache()
             a2 = copy.copy(args)
@@ -670,6 +708,7 @@ def main():
                     "exchange_bytes_per_step_max_rank": max(i["halo_bytes"] for i in infos),
                     "note": "variant L, contiguous row ranges, the same ShardedSpMM.step (halo all-to-all "
                             "overlapped with the own-column launch)"}
+            close_exchange(ctx_l, dist)
             del ctx_l, step_l
 
     # ---- extras on rank 0, outside the timed region ----------------------------------

@@ -165,6 +165,9 @@ LIB.dgla_sample_neighbors_padded.argtypes = [c_void_p, c_void_p, c_int, c_void_p
 LIB.dgla_to_block_padded.restype = c_int
 LIB.dgla_to_block_padded.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+LIB.dgla_partition_kway_ex.restype = c_int
+LIB.dgla_partition_kway_ex.argtypes = [c_int, c_int64, c_void_p, c_void_p, c_int, ctypes.c_double, c_int, ctypes.c_uint64,
+                                       c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
 LIB.dgla_partition_kway.restype = c_int
 LIB.dgla_partition_kway.argtypes = [c_int, c_int64, c_void_p, c_void_p, c_int, ctypes.c_double, c_int,
                                     ctypes.c_uint64, c_void_p, c_void_p]

@@ -302,51 +302,64 @@ def shard_csr(indptr, indices, eids, bounds, rank):
 # Node-cut partitioning (the reference: metis_partition_assignment + reshuffle,
 # python/dgl/partition.py:278-397, python/dgl/distributed/partition.py reshuffle=True)
 # ---------------------------------------------------------------------------------------
-def partition_assignment(indptr, indices, k, balance_edges=True, imbalance=0.03, seed=0, order_aware=True):
+def partition_assignment(indptr, indices, k, balance_edges=True, imbalance=0.03, seed=0, order_aware=True,
+                         objtype="cut", balance_ntypes=None):
     """Part id of every node of a square graph given as a CSR (rows = destination nodes), from
     the native multilevel partitioner in libdgl_amd.so (csrc/partition.cc), which stands where
-    METIS stands in the reference.  Host-side preprocessing: tensors are taken on the CPU.
+    METIS stands in the reference (``metis_partition_assignment``, python/dgl/partition.py:278-397).
+    Host-side preprocessing: tensors are taken on the CPU.
 
-    Returns ``(node_part int64[N], stats)`` with ``stats`` = cut edges, cut fraction,
-    heaviest / average part weight and the number of multilevel levels."""
+    ``objtype``: ``"cut"`` minimises cut edges, ``"vol"`` the total communication volume — the number of
+    DISTINCT remote columns the parts read, i.e. the rows a row-sharded SpMM pulls per step.
+    ``balance_ntypes``: optional node-type vector; every type is balanced across the parts on its own.
+    ``order_aware``: also try contiguous edge-balanced ranges (a graph whose vertex ORDER already reflects
+    its structure is cut best by ranges, which label-propagation coarsening does not find), refine that
+    candidate under the same objective and keep the better of the two.
+
+    Returns ``(node_part int64[N], stats)`` with ``stats`` = cut edges / fraction, total volume (halo rows
+    summed over the parts) and the largest part's halo, part weights, levels, method."""
     import ctypes
 
     from ._lib import LIB, check_call
 
+    if objtype not in ("cut", "vol"):
+        raise ValueError("objtype must be 'cut' or 'vol'")
     ip = indptr.detach().cpu().contiguous()
     ix = indices.detach().cpu().to(ip.dtype).contiguous()
     n = ip.numel() - 1
     bits = {torch.int32: 32, torch.int64: 64}[ip.dtype]
-    part = torch.empty(n, dtype=torch.int64)
-    st = (ctypes.c_int64 * 4)()
-    check_call(LIB.dgla_partition_kway(bits, n, ip.data_ptr(), ix.data_ptr(), int(k),
-                                       float(imbalance), 1 if balance_edges else 0, int(seed),
-                                       part.data_ptr(), ctypes.cast(st, ctypes.c_void_p)))
+    nt, num_nt = None, 0
+    if balance_ntypes is not None:
+        nt = torch.as_tensor(balance_ntypes).detach().cpu().to(torch.int32).contiguous()
+        assert nt.numel() == n, "balance_ntypes needs one entry per node"
+        num_nt = int(nt.max()) + 1 if n else 0
     nnz = max(int(ix.numel()), 1)
-    stats = {"cut_edges": int(st[0]), "cut_fraction": int(st[0]) / nnz,
-             "max_part_weight": int(st[1]), "avg_part_weight": int(st[2]), "levels": int(st[3]),
-             "method": "multilevel"}
+
+    def run(init):
+        part = torch.empty(n, dtype=torch.int64)
+        st = (ctypes.c_int64 * 8)()
+        check_call(LIB.dgla_partition_kway_ex(bits, n, ip.data_ptr(), ix.data_ptr(), int(k), float(imbalance),
+                                              1 if balance_edges else 0, int(seed), 1 if objtype == "vol" else 0,
+                                              num_nt, None if nt is None else nt.data_ptr(),
+                                              None if init is None else init.data_ptr(), part.data_ptr(),
+                                              ctypes.cast(st, ctypes.c_void_p)))
+        return part, {"cut_edges": int(st[0]), "cut_fraction": int(st[0]) / nnz, "max_part_weight": int(st[1]),
+                      "avg_part_weight": int(st[2]), "levels": int(st[3]), "volume": int(st[4]),
+                      "max_halo_rows": int(st[5]), "ntype_excess": int(st[6]), "refine_moves": int(st[7]),
+                      "objtype": objtype, "method": "multilevel" if init is None else "ranges (vertex order) + refinement"}
+
+    part, stats = run(None)
     if order_aware and balance_edges and k > 1 and n > 0:
-        # A graph whose vertex ORDER already reflects its structure (ids assigned by community,
-        # time or a space-filling curve: 1-D band structure) is cut best by contiguous ranges, which
-        # the label-propagation coarsening does not find; METIS would.  Evaluate that candidate
-        # (edge-balanced ranges, one pass over the edges) and keep the better of the two.
         bounds = partition_rows(ip, k)
-        rng_part = torch.searchsorted(bounds[1:].contiguous(), torch.arange(n), right=True)
-        deg = (ip[1:] - ip[:-1]).long()
-        cut = 0
-        step = 1 << 22  # rows per block: bounded temporaries
-        for r0 in range(0, n, step):
-            r1 = min(n, r0 + step)
-            rows = torch.repeat_interleave(rng_part[r0:r1], deg[r0:r1])
-            cols = ix[int(ip[r0]):int(ip[r1])].long()
-            cut += int((rows != rng_part[cols]).sum())
-        if cut < stats["cut_edges"]:
-            w = torch.bincount(rng_part, weights=(deg + 1).double(), minlength=k)
-            part = rng_part.to(torch.int64)
-            stats = {"cut_edges": cut, "cut_fraction": cut / nnz, "max_part_weight": int(w.max()),
-                     "avg_part_weight": int(w.sum() / k), "levels": 0, "method": "ranges (vertex order)",
-                     "multilevel_cut_fraction": stats["cut_fraction"]}
+        rng_part = torch.searchsorted(bounds[1:].contiguous(), torch.arange(n), right=True).to(torch.int64).contiguous()
+        part2, stats2 = run(rng_part)
+        key = "volume" if objtype == "vol" else "cut_edges"
+        if stats2[key] < stats[key]:
+            stats2["multilevel_" + key] = stats[key]
+            stats2["multilevel_cut_fraction"] = stats["cut_fraction"]
+            part, stats = part2, stats2
+        else:
+            stats["ranges_" + key] = stats2[key]
     return part, stats
 
 
@@ -748,6 +761,7 @@ class ShardedSpMM:
                     self.spmm("halo" if c == 0 else "halo%d" % c, blk, self.n_halo, halo, out_local, True)
             else:
                 self.exchange.wait()   # still consume the peers' (empty) flags: keeps the ranks in step
+            self.exchange.finish_step()
             return out_local
         work = None
         if isinstance(self.exchange, SimulatedExchange):

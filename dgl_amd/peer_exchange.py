@@ -161,6 +161,9 @@ class PeerHaloExchange:
                       for q in (0, 1)]
         self.epoch = 0
         self.max_spins = int(max_spins)
+        self._push_stream = torch.cuda.Stream(self.device)
+        self._push_done = torch.cuda.Event()
+        self._pending = False
         dist.barrier(group=group)   # every rank has opened every buffer before anyone writes
 
     def _alloc(self, nbytes, kind):
@@ -179,11 +182,22 @@ class PeerHaloExchange:
         self.epoch += 1
         parity = self.epoch & 1
         if self._nseg:
-            stream = torch.cuda.current_stream(self.device).cuda_stream
+            # the push runs on a stream of its own, ordered after the producer of x_local: it is bound by the
+            # xGMI links, not by this GPU, and overlaps the own-column launch the caller queues next
+            cur = torch.cuda.current_stream(self.device)
+            self._push_stream.wait_stream(cur)
             check_call(LIB.dgla_peer_push(x_local.data_ptr(), self.row_bytes, self.serve_rows.data_ptr(),
                                           self._segs[parity].data_ptr(), self._nseg, self._nblk, self.epoch,
-                                          self._arrive.data_ptr(), stream))
+                                          self._arrive.data_ptr(), self._push_stream.cuda_stream))
+            self._push_done.record(self._push_stream)
+            self._pending = True
         return self._halo[parity]
+
+    def finish_step(self):
+        """Order the current stream after this step's push: x_local may be overwritten from here on."""
+        if self._pending:
+            torch.cuda.current_stream(self.device).wait_event(self._push_done)
+            self._pending = False
 
     def wait_chunk(self, c):
         """Order the current stream after chunk ``c`` of every peer for the step begun last."""

@@ -392,6 +392,21 @@ int dgla_to_block_padded(int idtype_bits, const void* seeds, int64_t num_seeds, 
 int dgla_partition_kway(int idtype_bits, int64_t num_nodes, const void* indptr,
                         const void* indices, int num_parts, double imbalance, int balance_edges,
                         uint64_t seed, int64_t* out_part, int64_t* stats);
+/* The reference's other METIS options (python/dgl/partition.py:278-397 -> src/graph/metis_partition.cc:60-90):
+ *   objtype     0 = "cut" (edge cut), 1 = "vol" (total communication volume: the number of distinct remote
+ *               columns the parts read = the rows a row-sharded SpMM exchanges per step);
+ *   ntype       (may be NULL) node type of every node, values in [0, num_ntypes): balance_ntypes — every node
+ *               type is balanced across the parts by its own constraint;
+ *   init_part   (may be NULL) an assignment to REFINE instead of running the multilevel scheme (e.g. contiguous
+ *               ranges of a graph whose vertex order already reflects its structure).
+ * Refinement under either objective is a greedy k-way pass over the directed CSR with exact gains from a
+ * per-(column, part) reference-count table.  stats8 = {cut edges, heaviest part, average part, levels, total
+ * volume, largest halo (distinct remote columns of one part), largest (part, type) excess over its limit,
+ * refinement moves}. */
+int dgla_partition_kway_ex(int idtype_bits, int64_t num_nodes, const void* indptr, const void* indices,
+                           int num_parts, double imbalance, int balance_edges, uint64_t seed, int objtype,
+                           int num_ntypes, const int32_t* ntype, const int64_t* init_part, int64_t* out_part,
+                           int64_t* stats8);
 
 /* ---- multi-GPU exchange step -----------------------------------------
  * Device side of the halo all-to-all: the collective itself is RCCL (torch.distributed), these
