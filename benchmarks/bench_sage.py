@@ -61,21 +61,50 @@ def reduce_host(values, op, dist, dev):
 
 class FeatureStore:
     """Input features of the mini-batch: ``replicated`` (every GPU holds all N rows — what 288 GB of
-    HBM make natural) or ``sharded`` (row i lives on rank i % world, local row i // world — the
+    HBM make natural), ``sharded`` (row i lives on rank i % world, local row i // world — the
     reference's NDArrayPartition 'remainder' mode, python/dgl/partition.py:474-640 — and every
-    batch pulls its input rows with sparse_all_to_all_pull, python/dgl/cuda/nccl.py:98-183)."""
+    batch pulls its input rows with sparse_all_to_all_pull, python/dgl/cuda/nccl.py:98-183) or ``owner``
+    (BASELINE configs[3] as worded: a node partition — here the native partitioner under the
+    communication-volume objective — every rank trains on the seeds it OWNS, features live with their owner
+    (reshuffled to contiguous ranges, python/dgl/partition.py:139-186 ``partition_graph_with_halo`` /
+    python/dgl/distributed/partition.py:114-130 ``inner_node``) and a batch pulls only its NON-owned input rows)."""
 
-    def __init__(self, feat_full, mode, rank, world):
+    def __init__(self, feat_full, mode, rank, world, node_part=None, range_partition=None):
         from dgl_amd.parallel import NDArrayPartition
 
-        self.mode, self.world = mode, world
+        self.mode, self.world, self.rank = mode, world, rank
+        self.remote_rows = self.total_rows = 0
+        self.owned = None
         if mode == "sharded" and world > 1:
             self.part = NDArrayPartition(feat_full.shape[0], world, mode="remainder")
             self.local = feat_full[rank::world].contiguous()
+        elif mode == "owner" and world > 1:
+            from dgl_amd.parallel import reshuffle
+            orig_id, new_id, bounds = reshuffle(node_part.cpu(), world)
+            dev = feat_full.device
+            self.new_id = new_id.to(dev)
+            self.lo, self.hi = int(bounds[rank]), int(bounds[rank + 1])
+            self.owned = orig_id[self.lo:self.hi].to(dev)                    # old ids of my nodes, in new order
+            self.local = feat_full[self.owned].contiguous()                  # my rows only
+            self.part = range_partition(bounds) if range_partition is not None else \
+                NDArrayPartition(feat_full.shape[0], world, mode="range", part_ranges=bounds)
         else:
             self.part, self.local = None, feat_full
 
     def fetch(self, ids):
+        if self.mode == "owner" and self.part is not None:
+            from dgl_amd.parallel import sparse_all_to_all_pull
+
+            nid = self.new_id[ids]
+            mine = (nid >= self.lo) & (nid < self.hi)
+            out = torch.empty((ids.shape[0],) + tuple(self.local.shape[1:]), dtype=self.local.dtype,
+                              device=self.local.device)
+            out[mine] = self.local[nid[mine] - self.lo]
+            remote = nid[~mine].contiguous()
+            out[~mine] = sparse_all_to_all_pull(remote, self.local, self.part)   # (a collective: every rank calls it)
+            self.remote_rows += int(remote.numel())
+            self.total_rows += int(ids.numel())
+            return out
         if self.part is None:
             if ids.numel() >= 32768 and self.local.is_cuda:   # the library's row gather: 29 vs 45 us at 180 k rows
                 from dgl_amd import _capi
@@ -93,8 +122,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scale", type=int, default=1)
     ap.add_argument("--hidden", type=int, default=256)
-    ap.add_argument("--features", default="replicated", choices=["replicated", "sharded"],
-                    help="sharded: features partitioned over the ranks, pulled per batch (the reference's layout)")
+    ap.add_argument("--features", default="replicated", choices=["replicated", "sharded", "owner"],
+                    help="sharded: features partitioned over the ranks by id %% world, pulled per batch; owner: node "
+                         "partition, every rank trains on the seeds it owns and pulls only the non-owned input rows "
+                         "(BASELINE configs[3] as worded)")
     ap.add_argument("--shape", default="products", choices=["products", "papers100m"],
                     help="papers100m: BASELINE configs[3]'s own size — 111 M nodes, 1.6 G edges, F = 128, 172 classes "
                          "(13 GB of int64 CSC + 57 GB of fp32 features resident on the one GPU)")
@@ -137,7 +168,20 @@ def main():
     rel = Relation(n, n, csc=(gs["indptr"], gs["indices"], None), idtype=torch.int64, device=dev)
     g = DGLGraph(GraphIndex([n], [(0, 0)], [rel]), ["_N"], [("_N", "_E", "_N")])
     torch.manual_seed(0)
-    store = FeatureStore(torch.rand(n, f, device=dev), args.features, rank, world)
+    node_part, part_stats = None, None
+    if args.features == "owner" and world > 1:
+        from dgl_amd.parallel import partition_assignment
+        node_part = torch.empty(n, dtype=torch.int64, device=dev)
+        if rank == 0:   # host code, once per graph; the order-aware entry keeps contiguous ranges when they are better
+            p0, part_stats = partition_assignment(gs["indptr"], gs["indices"], world, seed=1, objtype="vol")
+            node_part.copy_(p0)
+        if gloo:
+            h = node_part.cpu()
+            dist.broadcast(h, src=0)
+            node_part = h.to(dev)
+        else:
+            dist.broadcast(node_part, src=0)
+    store = FeatureStore(torch.rand(n, f, device=dev), args.features, rank, world, node_part=node_part)
     labels = torch.randint(0, classes, (n,), device=dev)
     params = [torch.randn(f, args.hidden, device=dev) * 0.05, torch.randn(f, args.hidden, device=dev) * 0.05,
               torch.randn(args.hidden, classes, device=dev) * 0.05, torch.randn(args.hidden, classes, device=dev) * 0.05]
@@ -154,8 +198,13 @@ def main():
 
     edges = [0]
 
+    def draw_seeds():
+        if store.owned is not None:   # owner mode: a rank trains on the seeds its partition owns
+            return store.owned[torch.randint(0, store.owned.numel(), (args.batch,), device=dev, generator=gen)]
+        return torch.randint(0, n, (args.batch,), device=dev, generator=gen)
+
     def step():
-        seeds = torch.randint(0, n, (args.batch,), device=dev, generator=gen).unique()
+        seeds = draw_seeds().unique()
         inp, out, blocks = sampler.sample_blocks(g, seeds)
         edges[0] += sum(b.num_edges() for b in blocks)
         h = store.fetch(inp)
@@ -227,7 +276,7 @@ def main():
         return time.perf_counter() - t0, loss
 
     results = {}
-    if args.features == "sharded" and world > 1:
+    if args.features in ("sharded", "owner") and world > 1:
         # the per-batch feature pull is a collective with data-dependent split sizes: not capturable
         if args.mode == "graph":
             raise SystemExit("--mode graph needs --features replicated (the sharded pull is not capturable)")
@@ -251,12 +300,19 @@ def main():
         hi = reduce_host(chk, dist.ReduceOp.MAX, dist, dev)
         lo = reduce_host(chk, dist.ReduceOp.MIN, dist, dev)
         spread = max(abs(a - b) / max(abs(a), 1e-30) for a, b in zip(hi, lo))
+    remote_frac = None
+    if dist is not None and args.features == "owner":
+        tot = reduce_host([float(store.remote_rows), float(store.total_rows)], dist.ReduceOp.SUM, dist, dev)
+        remote_frac = tot[0] / max(tot[1], 1.0)
     if rank == 0:
         print(json.dumps({
             "workload": "2-layer GraphSAGE-mean mini-batch training step, fanouts (15, 10), batch %d per GPU, "
                         "graph N=%d E=%d (variant L), F=%d -> %d -> %d, fp32; graph replicated per GPU"
                         % (args.batch, n, e, f, args.hidden, classes),
             "features": args.features if world > 1 else "local",
+            "remote_input_row_fraction": (remote_frac if world > 1 and args.features == "owner" else None),
+            "remote_input_row_fraction_if_seeds_and_rows_were_spread_uniformly": ((world - 1) / world if world > 1 else None),
+            "partition": part_stats,
             "resident_GB": {"csc": round((gs["indptr"].numel() + gs["indices"].numel()) * 8 / 1e9, 1),
                             "features": round(store.local.numel() * store.local.element_size() / 1e9, 1)},
             "param_checksum_rel_spread_across_ranks": spread,

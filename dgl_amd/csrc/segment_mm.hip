@@ -782,7 +782,6 @@ struct WsFrag<f16_t> {
 
 constexpr int kWsWaves = 8;        // waves per workgroup (one workgroup per CU)
 constexpr int kWsMaxK = 256;       // contraction length the LDS image is sized for
-constexpr int kWsSkew = 1;         // tiles a wave may be ahead of its slowest sibling wave (column groups > 1)
 constexpr int kWsPitchPieces = kWsMaxK / 8 + 1;  // 16-byte pieces per LDS row at K = 256 (odd)
 
 struct WsParams {
@@ -791,7 +790,6 @@ struct WsParams {
   const int64_t* tile32_off; // [R + 1] exclusive prefix of ceil(len / 32)
   int ncg;                   // column groups (workgroups sharing a row chunk)
   int kp;                    // X3: row pitch of the planes in elements
-  int* prog;                 // ncg > 1: [chunk][wave][ncg] tiles STARTED by each sibling wave (zeroed per launch)
 };
 
 // Three bf16 planes of the K-contiguous fp32 weights: out[pl][row][k], row pitch kp, zero padded.
@@ -813,7 +811,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   }
 }
 
-template <typename DT, int NJ, bool X3, bool INDEXED, int RS, bool NTA>
+template <typename DT, int NJ, bool X3, bool INDEXED, int RS, bool PIPE>
 __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const WsParams wp) {
   const MmParams& p = wp.m;
   constexpr int ES = sizeof(DT);
@@ -835,9 +833,15 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
   const int64_t* __restrict__ row_off = p.plan + p.num_rel + 1;
   // workgroup -> (row chunk, column group): the ncg groups of a chunk are workgroups of ONE XCD
   const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
-  const int cg = qq % wp.ncg;
-  const int nchunks = (static_cast<int>(gridDim.x) >> 3) / wp.ncg * 8;
-  const int chunk = (qq / wp.ncg) * 8 + xcd;
+  // Column groups > 1 (fp32: 64 columns per workgroup; N > 256 for 16-bit): the ncg sibling workgroups of a row
+  // chunk sit on ONE XCD and read the same A rows.  Measured at 10 M x 256 x 256 fp32: unpaced,
+  // the siblings drift and A comes from HBM up to ncg times (7.6-8.0 ms); a soft barrier on per-wave progress
+  // words (any slack) cost more than it saved (9.3-9.9 ms: the progress loads drain the A ring once per tile),
+  // and walking the lines of a row in per-sibling rotated orders changed nothing.  Left unpaced.
+  const int ncg = wp.ncg;
+  const int cg = qq % ncg;
+  const int nchunks = (static_cast<int>(gridDim.x) >> 3) / ncg * 8;
+  const int chunk = (qq / ncg) * 8 + xcd;
   if (chunk >= nchunks) return;
   const int64_t T = tile_off[p.num_rel];
   const int64_t t0 = uniform64(T * chunk / nchunks), t1 = uniform64(T * (chunk + 1) / nchunks);
@@ -848,8 +852,6 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
   typedef typename WsFrag<typename std::conditional<X3, bf16_t, DT>::type>::type frag_t;
 
   int64_t t = t0;
-  int started = 1;       // tiles this wave has started (+ 1), across the relations of its chunk
-  bool gave_up = false;
   while (t < t1) {
     const int64_t rel = uniform64(find_segment(tile_off, p.num_rel, t));
     const int64_t rel_t0 = uniform64(tile_off[rel]);
@@ -903,11 +905,12 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int e = (ss * 128 + khalf * 64 + i * 16) / ES;  // first element of the piece
-        const char* src = (on && e < K) ? base + ss * 128 + i * 16 : reinterpret_cast<const char*>(g_mm_zero_page);
-        if constexpr (NTA)
-          f.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
-        else
-          f.v[i] = *reinterpret_cast<const u32x4*>(src);
+        // PIPE: every piece of every line exists (K a whole number of lines) and a refill with nothing left to
+        // fetch just re-reads the current tile — no select, no compare: the loop body stays free of the
+        // branches and copies that made the compiler keep TWO copies of the accumulators (64 v_mov per k-step)
+        const char* src = PIPE ? base + ss * 128 + i * 16
+                               : ((on && e < K) ? base + ss * 128 + i * 16 : reinterpret_cast<const char*>(g_mm_zero_page));
+        f.v[i] = *reinterpret_cast<const u32x4*>(src);  // (non-temporal loads measured: 2.06 -> 2.55 ms, bf16)
       }
       return f;
     };
@@ -920,34 +923,19 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
         ar[u] = load_slot(cur, u, u < nss);
         __builtin_amdgcn_sched_barrier(0);  // same issue order as the refills below (else: vmcnt(0) in the fp32 kernel)
       }
+      // PIPE (fp32, K a whole number of lines and of rounds): the three planes' weight fragments of k-step e + 1
+      // are read from LDS while k-step e multiplies (double buffer bq[e & 1]); without it every fragment read was
+      // followed by its own lgkmcnt(0) wait — five exposed LDS latencies per k-step, more than its 12 MFMAs
+      [[maybe_unused]] b16x8 bq[2][3][NJ];
+      [[maybe_unused]] auto load_b = [&](int piece0, b16x8 (&bf)[3][NJ]) {
+        const char* brow = smem + (l * pp + piece0 + 2 * khalf) * 16;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) bf[pl][jj] = *reinterpret_cast<const b16x8*>(brow + (pl * NJ + jj) * 32 * pp * 16);
+      };
+      if constexpr (PIPE) load_b(0, bq[0]);
       for (int64_t tt = first; tt < rel_end; tt += kWsWaves) {
-        if (wp.ncg > 1 && !gave_up) {
-          // ---- keep the sibling waves of the other column groups within kWsSkew tiles ------------------------
-          // The ncg workgroups of a row chunk (same XCD) read the SAME A rows; the rows come from HBM once only
-          // if the siblings touch them while they are still in that XCD's L2 (4 MiB shared by 8 such groups:
-          // about two tiles per wave).  Unpaced, the groups drift apart and A is read ncg times from HBM
-          // (measured: 9.25 ms = 50 GB at the copy rate instead of 20 GB).  Soft barrier: every wave publishes
-          // the number of tiles it has STARTED and waits (bounded) while it is more than kWsSkew ahead of its
-          // slowest sibling.  Progress words are relaxed agent-scope atomics (L2-coherent); nothing else is
-          // communicated, so a stale or late value costs time, never correctness.
-          int* pw = wp.prog + (static_cast<int64_t>(chunk) * kWsWaves + wave) * wp.ncg;
-          if (lane == 0) __hip_atomic_store(pw + cg, started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          for (int spins = 0;; ++spins) {
-            int slowest = started;
-            for (int j = 0; j < wp.ncg; ++j) {
-              const int v = __hip_atomic_load(pw + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              slowest = v < slowest ? v : slowest;
-            }
-            slowest = __builtin_amdgcn_readfirstlane(slowest);
-            if (started - slowest <= kWsSkew) break;
-            if (spins > (1 << 16)) {  // a sibling that is not resident (CU masks, co-running kernels): stop pacing
-              gave_up = true;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-          }
-          ++started;
-        }
         const bool more = tt + kWsWaves < rel_end;
         const char* nxt = more ? lane_ptr(tt + kWsWaves) : cur;
         f32x16 acc[NJ];
@@ -963,11 +951,11 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
 #pragma unroll
           for (int u = 0; u < RS; ++u) {
             const int ss = q * RS + u;
-            if (ss < nss) {  // (uniform)
+            if (PIPE || ss < nss) {  // (uniform)
 #pragma unroll
               for (int i = 0; i < KSS; ++i) {
                 const int piece0 = (X3 ? 4 : 8) * ss + i;  // the h = 0 lanes' piece of this k-step
-                if (piece0 >= kpieces) continue;            // (uniform) a k-step wholly past the end of the row
+                if (!PIPE && piece0 >= kpieces) continue;   // (uniform) a k-step wholly past the end of the row
                 const char* brow = smem + (l * pp + piece0 + (X3 ? 2 : 4) * khalf) * 16;
                 if constexpr (!X3) {
                   frag_t bf[NJ];
@@ -977,6 +965,22 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
                   const frag_t af = __builtin_bit_cast(frag_t, ar[u].v[i]);
 #pragma unroll
                   for (int jj = 0; jj < NJ; ++jj) acc[jj] = WsFrag<DT>::mma(af, bf[jj], acc[jj]);
+                } else if constexpr (PIPE) {
+                  constexpr int kE = RS * KSS;  // k-steps per round (even: the buffer parity carries over)
+                  const int e = u * KSS + i;    // (compile-time after unrolling)
+                  const int next_piece = (i + 1 < KSS) ? piece0 + 1
+                                         : 4 * ((u + 1 < RS) ? ss + 1 : (last ? 0 : (q + 1) * RS));
+                  static_assert(kE % 2 == 0, "even number of k-steps per round");
+                  load_b(next_piece, bq[(e + 1) & 1]);
+                  b16x8 at[3];  // h, m, l
+                  split3(__builtin_bit_cast(f32x4, ar[u].v[2 * i]), __builtin_bit_cast(f32x4, ar[u].v[2 * i + 1]), at[0], at[1], at[2]);
+                  // small terms first; consecutive MFMAs go to DIFFERENT accumulators
+                  constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                  for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int jj = 0; jj < NJ; ++jj)
+                      acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[ta[term]], bq[e & 1][tb[term]][jj], acc[jj], 0, 0, 0);
                 } else {
                   b16x8 ah, am, al;
                   split3(__builtin_bit_cast(f32x4, ar[u].v[2 * i]), __builtin_bit_cast(f32x4, ar[u].v[2 * i + 1]), ah, am, al);
@@ -1348,10 +1352,9 @@ __global__ __launch_bounds__(256) void gather_mm_kernel(const DT* __restrict__ a
 
 // ---- host side ------------------------------------------------------------------------------
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
-constexpr size_t kWsProgWords = 64 * 1024;  // >= chunks x 8 waves x column groups
 
 struct MmScratch {
-  size_t off_plan, off_t32, off_prog, off_bt, off_planes, off_acc, total;
+  size_t off_plan, off_t32, off_bt, off_planes, off_acc, total;
 };
 
 MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool need_bt,
@@ -1362,8 +1365,6 @@ MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool ne
   off = align256(off + sizeof(int64_t) * (2 * num_rel + 2) + /* staged seglen */ 8 * num_rel + /* NaN flag */ 8);
   s.off_t32 = off;
   if (forward) off = align256(off + sizeof(int64_t) * (num_rel + 1));
-  s.off_prog = off;  // pacing words of the weights-stationary kernel: [row chunk][wave][column group]
-  if (forward) off = align256(off + sizeof(int) * kWsProgWords);
   s.off_bt = off;
   if (need_bt) off = align256(off + static_cast<size_t>(num_rel) * K * N * elem);
   s.off_planes = off;  // fp32 forward: the weights as three bf16 planes (weights-stationary kernel)
@@ -1458,14 +1459,13 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
   wp.planes = nullptr;
   wp.tile32_off = reinterpret_cast<const int64_t*>(ws + sc.off_t32);
   wp.kp = 0;
-  wp.prog = reinterpret_cast<int*>(ws + sc.off_prog);
   const int N = p.N;
   int cus = mm_num_cus();
   if (const char* ew = getenv("DGLA_MM_WS_WGS")) {  // experiment: fewer workgroups than CUs
     if (atoi(ew) >= 8) cus = atoi(ew);
   }
   const dim3 block(64 * kWsWaves);
-  // experiment switch (round 4 A/B): bit 0 = non-temporal A loads, bit 1 = ring of 4 slots
+  // experiment switch (round 4 A/B): bit 0 = fp32 without the fragment double buffer
   const char* ev = getenv("DGLA_MM_WS_VARIANT");
   const int variant = ev && *ev ? atoi(ev) : 0;
   if constexpr (sizeof(DT) == 4) {
@@ -1479,32 +1479,28 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
     wp.ncg = (N + 63) / 64;
     const int groups = std::max(1, cus / 8 / wp.ncg);  // row chunks per XCD
     const dim3 grid(static_cast<unsigned>(groups * wp.ncg * 8));
-    if (static_cast<size_t>(groups) * 8 * kWsWaves * wp.ncg > kWsProgWords) return mfail("segment_mm: too many column groups");
-    if (wp.ncg > 1) DGLA_CHECK_HIP(hipMemsetAsync(wp.prog, 0, sizeof(int) * groups * 8 * kWsWaves * wp.ncg, s));
-    if (p.row_index)
-      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, true, 4, false>), grid, block, 0, s, wp);
-    else if (variant & 1)
+    // PIPE needs every k-step whole and rounds of exactly 4 lines: K a multiple of 128 floats' worth of lines
+    const bool pipe = p.K % 32 == 0 && (p.K / 32) % 4 == 0 && !(variant & 1);
+    if (p.row_index) {
+      if (pipe)
+        hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, true, 4, true>), grid, block, 0, s, wp);
+      else
+        hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, true, 4, false>), grid, block, 0, s, wp);
+    } else if (pipe) {
       hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, false, 4, true>), grid, block, 0, s, wp);
-    else
+    } else {
       hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, false, 4, false>), grid, block, 0, s, wp);
+    }
     hipLaunchKernelGGL(x3_repair_fwd_kernel, dim3(1024), dim3(256), 0, s, p);  // no-op unless a NaN came out
   } else {
     const int nj = N <= 32 ? 1 : (N <= 64 ? 2 : (N <= 128 ? 4 : 8));
     wp.ncg = (N + 32 * nj - 1) / (32 * nj);
     const int groups = std::max(1, cus / 8 / wp.ncg);
     const dim3 grid(static_cast<unsigned>(groups * wp.ncg * 8));
-    if (static_cast<size_t>(groups) * 8 * kWsWaves * wp.ncg > kWsProgWords) return mfail("segment_mm: too many column groups");
-    if (wp.ncg > 1) DGLA_CHECK_HIP(hipMemsetAsync(wp.prog, 0, sizeof(int) * groups * 8 * kWsWaves * wp.ncg, s));
 #define DGLA_WS(NJV)                                                                                   \
   do {                                                                                                 \
     if (p.row_index)                                                                                   \
       hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, true, 2, false>), grid, block, 0, s, wp);  \
-    else if ((variant & 3) == 1)                                                                       \
-      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, false, 2, true>), grid, block, 0, s, wp);  \
-    else if ((variant & 3) == 2)                                                                       \
-      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, false, 4, false>), grid, block, 0, s, wp); \
-    else if ((variant & 3) == 3)                                                                       \
-      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, false, 4, true>), grid, block, 0, s, wp);  \
     else                                                                                               \
       hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, false, false, 2, false>), grid, block, 0, s, wp); \
   } while (0)

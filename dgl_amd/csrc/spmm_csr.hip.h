@@ -82,6 +82,9 @@ struct SpmmParams {
   // (sum reducer, two lane groups per wave), ONE slot per wave: the two groups settle the row that
   // crosses between them in registers (see the end of spmm_csr_merge_kernel)
   int wave_slots;
+  // in-kernel fix-up (round 4): arrival counters, one per slot, all zero between launches; NULL = the
+  // separate fix-up kernel runs (feature chunks > 1, or more lane groups per wave than the counters cover)
+  unsigned* fix_count;
   int64_t* carry_row;  // row id of the slot's carry-out, or -1
   void* carry_val;     // [slots, out_len] accumulator type: head part of a straddling row
   void* tail_val;      // [slots, out_len] accumulator type: tail part of a straddling row
@@ -635,6 +638,31 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   [[maybe_unused]] bool have_tail = false;
   [[maybe_unused]] int tail_t = 0;    // its local row
 
+  // ---- partial results of rows that straddle slots -------------------------------------------------------
+  // Separate fix-up kernel (fix_count == NULL): plain stores, combined after the launch.  In-kernel fix-up:
+  // the partials are written THROUGH (relaxed agent-scope stores = `sc1`), every slot that holds a part of
+  // row R takes a ticket on the counter of the slot R ends in (after `s_waitcnt vmcnt(0)`: its part is out),
+  // and the slot that draws the last ticket reads the parts back (`sc1` loads) IN SLOT ORDER — the same
+  // order, hence the same bits, as the fix-up kernel — and writes the row.  (MI355X_MICROARCH.md, "valid
+  // forms": sc1 payload -> vmcnt(0) -> agent atomic; consumer sc1 loads.)  No waiting anywhere.
+  const bool fuse = p.fix_count != nullptr;
+  [[maybe_unused]] int64_t tail_pending = -1;  // row whose tail part this slot has stored
+  auto put_part = [&](A* dst, const A (&vals)[VEC]) {
+    if (fuse) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) __hip_atomic_store(dst + v, vals[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) dst[v] = vals[v];
+    }
+  };
+  auto put_arg = [&](Idx* dst, Idx val) {
+    if (fuse)
+      __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      *dst = val;
+  };
+
   auto flush = [&](int t) {
     const int64_t row = i0 + t;
     if (first_is_tail && RED == kSum && wslots && g == 1) {
@@ -644,17 +672,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
       tail_t = t;
       first_is_tail = false;
     } else if (first_is_tail) {
-      A* tv = static_cast<A*>(p.tail_val) + slot * F + k0;
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) tv[v] = acc[v];
+      put_part(static_cast<A*>(p.tail_val) + slot * F + k0, acc);
       if constexpr (ARG) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           const int bi = best[v];
-          if constexpr (TU) p.tail_argu[slot * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : static_cast<Idx>(p.arg_empty);
-          if constexpr (TE) p.tail_arge[slot * F + k0 + v] = edge_name(bi);
+          if constexpr (TU) put_arg(p.tail_argu + slot * F + k0 + v, bi >= 0 ? static_cast<Idx>(cols[bi]) : static_cast<Idx>(p.arg_empty));
+          if constexpr (TE) put_arg(p.tail_arge + slot * F + k0 + v, edge_name(bi));
         }
       }
+      tail_pending = row;
       first_is_tail = false;
     } else {
       DT* o = out + row * F + k0;
@@ -690,6 +717,80 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
       }
     }
     reset();
+  };
+
+  // Take this slot's ticket for row R (its part is stored); the last ticket of the run combines and writes.
+  auto finish_run = [&](int64_t R) {
+    const int64_t ra = static_cast<int64_t>(p.indptr[R]), rb = static_cast<int64_t>(p.indptr[R + 1]);
+    const int sh_w = 31 - __builtin_clz(static_cast<unsigned>(p.wave_items));
+    auto slot_of = [&](int64_t pos) -> int64_t {  // slot that holds merge position `pos`
+      const int64_t u = pos >> sh_w;
+      if (wslots) return u;
+      const int sh_g = 31 - __builtin_clz(static_cast<unsigned>(Tg));
+      return u * G + ((pos - (u << sh_w)) >> sh_g);
+    };
+    const int64_t s_first = slot_of(ra + R), s_last = slot_of(rb + R);  // first edge / row-end item of R
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's written-through parts have left
+    unsigned ticket = 0;
+    if (lg == 0)
+      ticket = __hip_atomic_fetch_add(p.fix_count + s_last, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __shfl(ticket, lane - lg, 64);
+    if (ticket != static_cast<unsigned>(s_last - s_first)) return;  // somebody else draws the last ticket
+    if (lg == 0) __hip_atomic_store(p.fix_count + s_last, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const A* cv = static_cast<const A*>(p.carry_val);
+    const A* tv = static_cast<const A*>(p.tail_val);
+    auto get = [&](const A* src) { return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto geti = [&](const Idx* src) { return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    A tot[VEC];
+    [[maybe_unused]] Idx au[VEC], ae[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      tot[v] = get(cv + s_first * F + k0 + v);
+      if constexpr (ARG) {
+        if constexpr (TU) au[v] = geti(p.carry_argu + s_first * F + k0 + v);
+        if constexpr (TE) ae[v] = geti(p.carry_arge + s_first * F + k0 + v);
+      }
+    }
+    auto combine = [&](const A* vals, const Idx* pu, const Idx* pe, int64_t base) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const A val = get(vals + base + v);
+        if constexpr (RED == kSum) {
+          tot[v] += val;
+        } else {
+          if (red_min ? tot[v] > val : tot[v] < val) {
+            tot[v] = val;
+            if constexpr (TU) au[v] = geti(pu + base + v);
+            if constexpr (TE) ae[v] = geti(pe + base + v);
+          }
+        }
+      }
+    };
+    for (int64_t q = s_first + 1; q < s_last; ++q) combine(cv, p.carry_argu, p.carry_arge, q * F + k0);
+    combine(tv, p.tail_argu, p.tail_arge, s_last * F + k0);
+    DT* o = out + R * F + k0;
+    VecT<DT, VEC> ov;
+    if (RED == kSum && p.mean) {
+      const int64_t deg = rb - ra;
+      const A den = round_to_storage<DT>(static_cast<A>(deg > 1 ? deg : 1));
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(round_to_storage<DT>(tot[v]) / den);
+    } else if (p.accumulate) {
+      ov = *reinterpret_cast<VecT<DT, VEC>*>(o);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(to_acc<DT>(ov.v[v]) + tot[v]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(tot[v]);
+    }
+    *reinterpret_cast<VecT<DT, VEC>*>(o) = ov;
+    if constexpr (ARG) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        if constexpr (TU) p.arg_u[R * F + k0 + v] = au[v];
+        if constexpr (TE) p.arg_e[R * F + k0 + v] = ae[v];
+      }
+    }
   };
 
   int t = t_s;
@@ -793,44 +894,46 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
             else
               *reinterpret_cast<VecT<DT, VEC>*>(o) = ov;
           } else {
-            A* tv = static_cast<A*>(p.tail_val) + slot * F + k0;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) tv[v] = tot[v];
+            put_part(static_cast<A*>(p.tail_val) + slot * F + k0, tot);
+            tail_pending = i0 + tail_t;
           }
           if (cnt > 0) {  // group 1's own unfinished last row
             crow = i0 + t;
-            A* cv = static_cast<A*>(p.carry_val) + slot * F + k0;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) cv[v] = acc[v];
+            put_part(static_cast<A*>(p.carry_val) + slot * F + k0, acc);
           }
         } else if (g0_carry || cnt > 0) {
           // no crossing row closed in group 1: either group 0 ended on a row end (then this is group
           // 1's own carry) or the row runs through all of group 1 (then its parts add up, in order)
           crow = i0 + t;
-          A* cv = static_cast<A*>(p.carry_val) + slot * F + k0;
+          A cvv[VEC];
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) cv[v] = g0_carry ? (cnt > 0 ? c0[v] + acc[v] : c0[v]) : acc[v];
+          for (int v = 0; v < VEC; ++v) cvv[v] = g0_carry ? (cnt > 0 ? c0[v] + acc[v] : c0[v]) : acc[v];
+          put_part(static_cast<A*>(p.carry_val) + slot * F + k0, cvv);
         }
-        if (lg == 0) p.carry_row[slot] = crow;
+        if (!fuse && lg == 0) p.carry_row[slot] = crow;
+        if (fuse && crow >= 0) finish_run(crow);
       }
+      if (fuse && tail_pending >= 0) finish_run(tail_pending);
       return;
     }
   }
   // ---- carry-out: head part of the row that continues in the next group ---------------
   const bool has_carry = cnt > 0;
-  if (lg == 0 && blockIdx.y == 0) p.carry_row[slot] = has_carry ? i0 + t : int64_t(-1);
+  if (!fuse && lg == 0 && blockIdx.y == 0) p.carry_row[slot] = has_carry ? i0 + t : int64_t(-1);
   if (has_carry) {
-    A* cv = static_cast<A*>(p.carry_val) + slot * F + k0;
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) cv[v] = acc[v];
+    put_part(static_cast<A*>(p.carry_val) + slot * F + k0, acc);
     if constexpr (ARG) {
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         const int bi = best[v];
-        if constexpr (TU) p.carry_argu[slot * F + k0 + v] = bi >= 0 ? static_cast<Idx>(cols[bi]) : static_cast<Idx>(p.arg_empty);
-        if constexpr (TE) p.carry_arge[slot * F + k0 + v] = edge_name(bi);
+        if constexpr (TU) put_arg(p.carry_argu + slot * F + k0 + v, bi >= 0 ? static_cast<Idx>(cols[bi]) : static_cast<Idx>(p.arg_empty));
+        if constexpr (TE) put_arg(p.carry_arge + slot * F + k0 + v, edge_name(bi));
       }
     }
+  }
+  if (fuse) {
+    if (tail_pending >= 0) finish_run(tail_pending);
+    if (has_carry) finish_run(i0 + t);
   }
 }
 
@@ -921,6 +1024,15 @@ __global__ __launch_bounds__(64) void spmm_csr_fixup_kernel(const SpmmParams<Idx
 // ---------------------------------------------------------------------------------------
 // Host side: workspace carving and launch.
 // ---------------------------------------------------------------------------------------
+// Lane groups per wave the in-kernel fix-up's counters cover (F >= 29 fp32 / 57 16-bit columns: 8+ lanes per row)
+constexpr int kFuseMaxGroups = 8;
+
+// In-kernel fix-up (round 4): on unless DGLA_SPMM_FUSE_FIXUP=0 (A/B switch, read per call)
+inline bool spmm_fuse_fixup_enabled() {
+  const char* e = getenv("DGLA_SPMM_FUSE_FIXUP");
+  return !(e && e[0] == '0');
+}
+
 struct SpmmGeometry {
   int vec;       // elements per lane access
   int log2_lpe;  // lanes per feature row
@@ -929,7 +1041,7 @@ struct SpmmGeometry {
   int wave_slots;  // one fix-up slot per wave (see SpmmParams::wave_slots)
   int wave_items;  // merge items per wavefront (see below)
   int64_t num_waves, num_slots;
-  size_t off_plan, off_meta, off_carry_row, off_carry_val, off_tail_val, off_carry_argu,
+  size_t off_plan, off_meta, off_fixcnt, off_carry_row, off_carry_val, off_tail_val, off_carry_argu,
       off_carry_arge, off_tail_argu, off_tail_arge, total;
   // split-row layout (0 = not used): bytes of a row kept in the main / tail array
   int split_main_bytes, split_tail_bytes;
@@ -1012,6 +1124,10 @@ inline SpmmGeometry spmm_geometry(int64_t num_rows, int64_t nnz, int64_t out_len
   off = align_up(off + sizeof(int64_t) * (g.num_waves + 1), 256);
   g.off_meta = off;  // locality probe counters {local, sampled}; lives and dies with the plan
   off += 256;
+  // arrival counters of the in-kernel fix-up: one per slot for up to kFuseMaxGroups lane groups per wave; a
+  // function of (rows, nnz) alone like the plan, zeroed with it, and left zero by every launch
+  g.off_fixcnt = off;
+  off = align_up(off + sizeof(unsigned) * g.num_waves * kFuseMaxGroups, 256);
   g.off_carry_row = off;
   off = align_up(off + sizeof(int64_t) * g.num_slots, 256);
   g.off_carry_val = off;
@@ -1061,6 +1177,7 @@ inline int launch_plan(const SpmmLaunch& L, const SpmmGeometry& g) {
                      static_cast<const Idx*>(L.csr.indptr), L.csr.num_rows, L.csr.nnz,
                      g.num_waves, reinterpret_cast<int64_t*>(ws + g.off_plan), g.wave_items);
   DGLA_CHECK_HIP(hipGetLastError());
+  DGLA_CHECK_HIP(hipMemsetAsync(ws + g.off_fixcnt, 0, sizeof(unsigned) * g.num_waves * kFuseMaxGroups, L.stream));
   {
     // locality probe over ~4096 evenly spaced units, made with every plan (a later call on the
     // same workspace may be the first one whose shape is eligible for the split-row layout)
@@ -1143,6 +1260,9 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.wtab = L.efeat_tab;
   p.num_rel = L.num_rel;
   p.wave_slots = g.wave_slots;
+  p.fix_count = (g.chunks == 1 && (g.wave_slots || g.groups <= kFuseMaxGroups) && spmm_fuse_fixup_enabled())
+                    ? reinterpret_cast<unsigned*>(ws + g.off_fixcnt)
+                    : nullptr;
   p.carry_row = reinterpret_cast<int64_t*>(ws + g.off_carry_row);
   p.carry_val = ws + g.off_carry_val;
   p.tail_val = ws + g.off_tail_val;
@@ -1216,6 +1336,7 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
       if constexpr (RED != kSum) {
         DGLA_CHECK_HIP(hipGetLastError());
         if (pe.after) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
+        if (p.fix_count) return 0;  // straddling rows were finished inside the launch
         hipLaunchKernelGGL((spmm_csr_fixup_kernel<Idx, DT, OP, RED, true>),
                            dim3(static_cast<unsigned>(std::min<int64_t>(g.num_slots, int64_t(1) << 24))),
                            dim3(64), 0, L.stream, p, g.num_slots);
@@ -1236,6 +1357,7 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
   }
   DGLA_CHECK_HIP(hipGetLastError());
   if (pe.after) DGLA_CHECK_HIP(hipEventRecord(pe.after, L.stream));
+  if (p.fix_count) return 0;  // straddling rows were finished inside the launch
   hipLaunchKernelGGL((spmm_csr_fixup_kernel<Idx, DT, OP, RED>),
                      dim3(static_cast<unsigned>(std::min<int64_t>(g.num_slots, int64_t(1) << 24))),
                      dim3(64), 0, L.stream, p, g.num_slots);

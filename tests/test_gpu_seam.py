@@ -709,3 +709,57 @@ def test_position_ordered_operand_nontemporal_loads_same_bits(dev, feat, tdtype,
         host = [t.cpu().numpy() for t in (g["indptr"], g["indices"])]
         ref, _, _ = oracle.spmm_csr("mul", "sum", host[0], host[1], None, x.cpu().numpy(), w.cpu().numpy())
         np.testing.assert_allclose(got[1][1].cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("feat,tdtype", [(100, torch.float32), (32, torch.float32), (64, torch.bfloat16), (128, torch.float16),
+                                         (40, torch.float64), (300, torch.float32), (8, torch.float32)])
+@pytest.mark.parametrize("op,reduce", [("copy_lhs", "sum"), ("mul", "sum"), ("copy_lhs", "max"), ("mul", "min"),
+                                       ("copy_rhs", "sum")])
+def test_in_kernel_fixup_gives_the_bits_of_the_fixup_kernel(dev, feat, tdtype, op, reduce, monkeypatch):
+    """Round 4: rows that straddle slots are finished INSIDE the merge launch by the slot that draws the last
+    ticket, combining the parts in slot order — the order of the separate fix-up kernel, so the results must be
+    bit-identical to it (DGLA_SPMM_FUSE_FIXUP=0), values and winners, on a graph with hub rows that span many
+    slots, over repeated launches on one workspace (the arrival counters must come back to zero), with mean and
+    accumulate.  Shapes cover one slot per wave (F = 100 fp32), several lane groups, and the shapes that keep the
+    separate kernel (feature chunks > 1: F = 300; more lane groups than counters: F = 8)."""
+    from dgl_amd import _capi
+
+    n_dst, n_src, e = 6_000, 9_000, 400_000
+    g = synth_csr(n_dst, n_src, e, "U", seed=91, device=dev, with_eids=True)
+    ip = g["indptr"].clone()
+    # two hub rows of ~60 k edges: rows 10 and 4000 swallow their neighbours' edges (indptr stays monotone)
+    ip[11:1200] = ip[1200]
+    ip[4001:5500] = ip[5500]
+    torch.manual_seed(7)
+    x = (torch.rand(n_src, feat, device=dev) + 1).to(tdtype)
+    w = (torch.rand(e, 1, device=dev) + 1).to(tdtype) if op in ("mul",) else \
+        ((torch.rand(e, feat, device=dev) + 1).to(tdtype) if op == "copy_rhs" else None)
+    u = None if op == "copy_rhs" else x
+    csr = _capi.make_csr(ip, g["indices"], g["eids"], n_src)
+    res = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("DGLA_SPMM_FUSE_FIXUP", fuse)
+        out = torch.full((n_dst, feat), -3.0, dtype=tdtype, device=dev)
+        au = torch.full((n_dst, feat), -9, dtype=torch.int32, device=dev) if reduce != "sum" else None
+        ae = torch.full((n_dst, feat), -9, dtype=torch.int32, device=dev) if reduce != "sum" else None
+        ws = torch.empty(_capi.spmm_csr_workspace_bytes(op, reduce, csr, tdtype, u, w, out), dtype=torch.uint8, device=dev)
+        _capi.spmm_csr(op, reduce, csr, u, w, out, au, ae, ws)
+        outs = [out.clone()]
+        for _ in range(2):                       # cached plan: the counters were left at zero
+            _capi.spmm_csr(op, reduce, csr, u, w, out, au, ae, ws, plan_valid=True)
+            outs.append(out.clone())
+        extra = []
+        if reduce == "sum":
+            acc = torch.full((n_dst, feat), 0.5, dtype=tdtype, device=dev)
+            _capi.spmm_csr(op, reduce, csr, u, w, acc, None, None, ws, accumulate=True, plan_valid=True)
+            extra.append(acc)
+            if op == "copy_lhs":
+                mean = torch.empty((n_dst, feat), dtype=tdtype, device=dev)
+                _capi.spmm_csr(op, reduce, csr, u, w, mean, None, None, ws, plan_valid=True, mean=True)
+                extra.append(mean)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        res[fuse] = [outs[0]] + extra + ([au, ae] if au is not None else [])
+    for a, b in zip(res["0"], res["1"]):
+        assert torch.equal(a.view(torch.uint8) if a.dtype.is_floating_point else a,
+                           b.view(torch.uint8) if b.dtype.is_floating_point else b)
