@@ -779,6 +779,14 @@ def variants(dev, ctx, n, e, f, args, reps=10):
         call()
         torch.cuda.synchronize()
         res["U_static_features"] = line(time_events(call, reps), merge_kernel_ms(call))
+        # the same consumer call when the PRODUCER of X prepared the operand (DGLA_PREPARE_ONLY on its own stream, as
+        # part of finishing the tensor): what the producer pays is reported next to it
+        prep = lambda: _capi.spmm_csr("copy_lhs", "sum", ctx["csr"], x, None, out, None, None, ctx["ws"],
+                                      plan_valid=True, split_keep=True, prepare_only=True)
+        prep()
+        torch.cuda.synchronize()
+        res["U_operand_prepared_by_producer"] = dict(res["U_static_features"],
+                                                     producer_prepare_ms=float(np.median(time_events(prep, reps))))
         # leave `out` as the per-call path produced it (bit-identical anyway)
     gl = synth_csr(n, n, e, "L" if args.variant == "U" else "U", seed=20250824, device=dev)
     csr = _capi.make_csr(gl["indptr"], gl["indices"], None, n)

@@ -79,17 +79,19 @@ def spmm_csr_workspace_bytes(op, reduce, csr, dtype, ufeat, efeat, out):
 
 
 def spmm_csr(op, reduce, csr, ufeat, efeat, out, arg_u=None, arg_e=None, workspace=None,
-             accumulate=False, plan_valid=False, mean=False, split_keep=False, split_valid=False):
+             accumulate=False, plan_valid=False, mean=False, split_keep=False, split_valid=False,
+             prepare_only=False):
     """out = g-SpMM over `csr` (rows = destination nodes).  `workspace` is a uint8 tensor of
     at least spmm_csr_workspace_bytes(); it also caches the merge plan between calls.
     `split_keep`: `ufeat` is static (the caller will pass the same unchanged tensor again), so
     the split-row copy is made whatever the locality probe says; `split_valid`: the workspace
-    still holds that copy of this very `ufeat` — only for callers that own the tensor."""
+    still holds that copy of this very `ufeat` — only for callers that own the tensor;
+    `prepare_only` (with `split_keep`): plan + side copy only, for the PRODUCER of `ufeat`."""
     keep = []
     tu, te, to = _tensor(ufeat, keep), _tensor(efeat, keep), _tensor(out, keep)
     flags = (_lib.DGLA_ACCUMULATE if accumulate else 0) | (_lib.DGLA_PLAN_VALID if plan_valid else 0) | \
         (_lib.DGLA_MEAN if mean else 0) | (_lib.DGLA_SPLIT_VALID if split_valid else 0) | \
-        (_lib.DGLA_SPLIT_KEEP if split_keep else 0)
+        (_lib.DGLA_SPLIT_KEEP if split_keep else 0) | (_lib.DGLA_PREPARE_ONLY if prepare_only else 0)
     check_call(LIB.dgla_spmm_csr(
         op.encode(), reduce.encode(), ctypes.byref(csr), _DTYPES[out.dtype], ctypes.byref(tu),
         ctypes.byref(te), ctypes.byref(to), _ptr(arg_u), _ptr(arg_e), _ptr(workspace),

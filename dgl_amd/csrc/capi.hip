@@ -356,6 +356,8 @@ int dgla_spmm_csr(const char* op, const char* reduce, const dgla_csr* csr, dgla_
   L.plan_valid = (flags & DGLA_PLAN_VALID) != 0;
   L.split_valid = (flags & DGLA_SPLIT_VALID) != 0 && L.plan_valid;
   L.split_keep = L.split_valid || (flags & DGLA_SPLIT_KEEP) != 0;
+  L.prepare_only = (flags & DGLA_PREPARE_ONLY) != 0;
+  if (L.prepare_only && !(flags & DGLA_SPLIT_KEEP)) return fail("DGLA_PREPARE_ONLY needs DGLA_SPLIT_KEEP");
   L.workspace = workspace;
   L.workspace_bytes = workspace_bytes;
   L.stream = static_cast<hipStream_t>(hip_stream);

@@ -152,6 +152,7 @@ struct SpmmLaunch {
   bool plan_valid;  // workspace already holds the merge plan of this CSR
   bool split_valid; // workspace already holds the split-row copy of this ufeat (DGLA_SPLIT_VALID)
   bool split_keep;  // static ufeat: use the split-row layout whatever the probe says (DGLA_SPLIT_KEEP)
+  bool prepare_only;  // plan + side copy only (DGLA_PREPARE_ONLY)
   void* workspace;
   size_t workspace_bytes;
   hipStream_t stream;

@@ -1316,6 +1316,7 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
                        static_cast<unsigned>(p.split_base16));
     DGLA_CHECK_HIP(hipGetLastError());
   }
+  if (L.prepare_only) return 0;  // the producer's half of the call: plan + side copy are in the workspace
   // dynamic LDS: the unit's edge ids, only when the operator reads edge features through a map
   const unsigned dyn_lds = (op_uses_rhs(OP) && L.csr.eids != nullptr)
                                ? static_cast<unsigned>(kWavesPerBlock * kWaveItems * sizeof(Idx))

@@ -763,3 +763,27 @@ def test_in_kernel_fixup_gives_the_bits_of_the_fixup_kernel(dev, feat, tdtype, o
     for a, b in zip(res["0"], res["1"]):
         assert torch.equal(a.view(torch.uint8) if a.dtype.is_floating_point else a,
                            b.view(torch.uint8) if b.dtype.is_floating_point else b)
+
+
+def test_prepare_only_is_the_producers_half_of_a_call(dev):
+    """DGLA_PREPARE_ONLY: plan + side copy of the operand's ragged row ends, no output; the consumer's call with
+    DGLA_SPLIT_VALID then launches the merge kernel alone and gives the bits of an ordinary call."""
+    from dgl_amd import _capi
+
+    n_dst, n_src, e, feat = 50_000, 180_000, 800_000, 100
+    g = synth_csr(n_dst, n_src, e, "U", seed=77, device=dev)
+    torch.manual_seed(5)
+    x = torch.rand(n_src, feat, device=dev) + 1
+    csr = _capi.make_csr(g["indptr"], g["indices"], None, n_src)
+    out = torch.full((n_dst, feat), -3.0, device=dev)
+    ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, x.dtype, x, None, out), dtype=torch.uint8, device=dev)
+    want = torch.empty_like(out)
+    ws2 = torch.empty_like(ws)
+    _capi.spmm_csr("copy_lhs", "sum", csr, x, None, want, None, None, ws2)
+    _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, split_keep=True, prepare_only=True)
+    torch.cuda.synchronize()
+    assert bool((out == -3.0).all())                                   # nothing written
+    _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, plan_valid=True, split_keep=True, split_valid=True)
+    assert torch.equal(out, want)
+    with pytest.raises(Exception):
+        _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out, None, None, ws, prepare_only=True)   # needs split_keep
