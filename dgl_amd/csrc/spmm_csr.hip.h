@@ -1027,10 +1027,16 @@ __global__ __launch_bounds__(64) void spmm_csr_fixup_kernel(const SpmmParams<Idx
 // Lane groups per wave the in-kernel fix-up's counters cover (F >= 29 fp32 / 57 16-bit columns: 8+ lanes per row)
 constexpr int kFuseMaxGroups = 8;
 
-// In-kernel fix-up (round 4): on unless DGLA_SPMM_FUSE_FIXUP=0 (A/B switch, read per call)
-inline bool spmm_fuse_fixup_enabled() {
+// In-kernel fix-up (round 4): for graphs of fewer than kFuseMaxWaves units, where a g-SpMM call is launch-bound
+// and one launch fewer is worth more than what the tickets cost (mini-batch step, eager: 1.66 -> 1.54 ms).
+// On the headline graph (121 k units) every wave pays two returning device-scope atomics and a drained store
+// queue at its end: merge kernel 4.37 -> 4.51 ms against 0.053 ms for the separate kernel — measured, so large
+// graphs keep the second launch.  DGLA_SPMM_FUSE_FIXUP=0 / 1 forces either (A/B and tests; read per call).
+constexpr int64_t kFuseMaxWaves = 32768;
+inline bool spmm_fuse_fixup_enabled(int64_t num_waves) {
   const char* e = getenv("DGLA_SPMM_FUSE_FIXUP");
-  return !(e && e[0] == '0');
+  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  return num_waves < kFuseMaxWaves;
 }
 
 struct SpmmGeometry {
@@ -1260,7 +1266,7 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.wtab = L.efeat_tab;
   p.num_rel = L.num_rel;
   p.wave_slots = g.wave_slots;
-  p.fix_count = (g.chunks == 1 && (g.wave_slots || g.groups <= kFuseMaxGroups) && spmm_fuse_fixup_enabled())
+  p.fix_count = (g.chunks == 1 && (g.wave_slots || g.groups <= kFuseMaxGroups) && spmm_fuse_fixup_enabled(g.num_waves))
                     ? reinterpret_cast<unsigned*>(ws + g.off_fixcnt)
                     : nullptr;
   p.carry_row = reinterpret_cast<int64_t*>(ws + g.off_carry_row);
