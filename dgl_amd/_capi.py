@@ -211,12 +211,11 @@ def set_profile_events(before, after):
         LIB.dgla_spmm_set_profile_events(before.cuda_event, after.cuda_event)
 
 
-(TUNE_XCD, TUNE_NT_OUT, TUNE_NT_IDX, TUNE_SPLIT, TUNE_GLDS, TUNE_SPLIT_FORCE, TUNE_MM_F32) = (
-    1, 2, 4, 8, 16, 64, 128)  # include/dgl_amd.h DGLA_TUNE_*
+(TUNE_XCD, TUNE_SPLIT, TUNE_GLDS, TUNE_SPLIT_FORCE, TUNE_MM_F32) = (1, 8, 16, 64, 128)  # include/dgl_amd.h DGLA_TUNE_*
 
 
 def set_tuning(flags):
-    """Process-wide tuning bits (include/dgl_amd.h: DGLA_TUNE_*).  The SpMM bits XCD, NT_*, SPLIT*
+    """Process-wide tuning bits (include/dgl_amd.h: DGLA_TUNE_*).  The SpMM bits XCD, SPLIT*
     never change result bits (SPLIT changes the workspace layout: plans do not survive a change of
     it).  The matrix-multiply bits do change bits: DGLA_TUNE_GLDS contracts fp32 k in a
     permuted order and DGLA_TUNE_MM_F32 selects the exact fp32 MFMA instead of the default

@@ -175,20 +175,18 @@ struct SddmmLaunch {
 };
 
 // Tuning bits (dgla_set_tuning / dgla_get_tuning).  The SpMM bits change no result bit.  Round 4 removed
-// SPLIT_NT (32), SPLIT_CLASSIC (256), TAIL_PASS (512) and NT_STREAM (1024, now a fixed rule): the values
-// of the surviving bits are unchanged.
+// NT_OUT (2), NT_IDX (4) — both measured neutral —, SPLIT_NT (32), SPLIT_CLASSIC (256), TAIL_PASS (512) and
+// NT_STREAM (1024, now a fixed rule): the values of the surviving bits are unchanged.
 enum Tune : uint32_t {
   kTuneXcd = 1u,    // XCD-contiguous unit order (one contiguous eighth of the merge path per L2)
-  kTuneNtOut = 2u,  // non-temporal stores of finished output rows
-  kTuneNtIdx = 4u,  // non-temporal loads of the index streams (indices / indptr / eids)
   kTuneSplit = 8u,  // side copies of the rows' ragged ends when rows are not a whole number of 128-B lines
   kTuneGlds = 16u,  // segment_mm: LDS-direct (global_load_lds) slab rings instead of register staging
   kTuneSplitForce = 64u,  // split layouts whenever the shape allows, whatever the locality probe says
   kTuneMmF32 = 128u,      // segment_mm fp32: v_mfma_f32_32x32x2_f32 instead of the 3 x bf16 split
 };
-constexpr uint32_t kTuneKnown = 1u | 2u | 4u | 8u | 16u | 64u | 128u;
+constexpr uint32_t kTuneKnown = 1u | 8u | 16u | 64u | 128u;
 // Default: XCD-contiguous order (measured on C2: variant L -3 % time, variant U neutral); the
-// non-temporal bits are neutral.  Split layouts (C2, F = 100 fp32): the edge-layout copy costs 0.10 ms
+// Split layouts (C2, F = 100 fp32): the edge-layout copy costs 0.10 ms
 // and the gather drops 4.86 -> 4.35 ms on variant U; on variant L the locality probe declines it only
 // when >= 15/16 of the sampled edges are local.  The LDS-direct segment_mm loop is 23-34 % faster at
 // every measured shape (profiles/r1/glds_ab.jsonl) -> on.

@@ -513,7 +513,6 @@ __global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(con
     if (bn >= N) bn = N - 1;
     srcB[i] = Bt + static_cast<int64_t>(bn) * K * ES + src_chunk * 16;
   }
-  const bool nt_c = (p.tune & kTuneNtOut) != 0;
   // K need not be a whole number of slabs: in the last slab, the lanes whose 16-byte chunk starts
   // at or past the end of the row read the zero page instead (both operands).
   const int kbytes = K * ES;
@@ -712,10 +711,7 @@ __global__ __launch_bounds__(2 * BMT, 256 / BMT) void segment_mm_glds_kernel(con
     if (prow[h] >= 0 && col < N) {
       u32x4* dstp = reinterpret_cast<u32x4*>(C + prow[h] * N + col);
       const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * kCPitch + chunk * 16);
-      if (nt_c)
-        __builtin_nontemporal_store(v, dstp);
-      else
-        *dstp = v;
+      *dstp = v;
     }
   }
 }

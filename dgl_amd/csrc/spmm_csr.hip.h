@@ -335,6 +335,18 @@ __device__ __forceinline__ typename Acc<DT>::type round_to_storage(typename Acc<
     return v;
 }
 
+// Written-through ("sc1") accesses of the in-kernel fix-up, on EXPLICIT global pointers: as generic pointers
+// (values that travelled through lambda parameters) some instantiations turned them into flat_ instructions
+// (tests/test_isa_audit.py).
+template <typename T>
+__device__ __forceinline__ T ld_sc1(const T* p) {
+  return __hip_atomic_load((const __attribute__((address_space(1))) T*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void st_sc1(T* p, T v) {
+  __hip_atomic_store((__attribute__((address_space(1))) T*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // MULTI: the CSR is a row-wise concatenation of several relations (SpMMCsrHetero's sum over
 // relations sharing a destination type, src/array/cuda/spmm_hetero.cu:150-158, fused into
 // one launch): every edge carries its relation id, and the relation's operand base pointers
@@ -389,7 +401,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   }
   const int64_t w = static_cast<int64_t>(blk) * kWavesPerBlock + wib;
   const bool has_eid = p.eids != nullptr;
-  const bool nt_idx = (p.tune & kTuneNtIdx) != 0;
   // NTR (spmm_nt_stream(): copy_rhs over long rows without an edge-id map, i.e. a readout-like segment reduce):
   // the edge operand is loaded non-temporally.  A compile-time switch: selecting the load flavour per load at run
   // time put a branch between the prefetch loads and made the compiler drain them (vmcnt(0)) before
@@ -426,12 +437,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
         // segment reduce never reads them (p.indices may be NULL there)
         const Idx* src = p.indptr + (i0 + 1 + (it < nE ? 0 : it - nE));
         if constexpr (UL) src = it < nE ? p.indices + (j0 + it) : src;
-        itemv[k] = nt_idx ? __builtin_nontemporal_load(src) : *src;  // read-once stream
+        itemv[k] = *src;  // (non-temporal loads of the index streams measured neutral: the bit was removed in round 4)
         if constexpr (MULTI) relv[k] = it < nE ? p.rel[j0 + it] : uint8_t(0);
         if constexpr (UR) {
           if (has_eid) {
             const int ie = it < nE ? it : (nE > 0 ? nE - 1 : 0);
-            eidv[k] = nE > 0 ? p.eids[j0 + ie] : static_cast<Idx>(p.arg_empty);
+            // (explicit global load: as `cond ? p.eids[..] : p.arg_empty` the compiler selected between a global and a
+            // kernel-argument ADDRESS and loaded through a flat pointer — tests/test_isa_audit.py)
+            eidv[k] = nE > 0 ? load_global<Idx, 1>(p.eids + (j0 + ie)).v[0] : static_cast<Idx>(p.arg_empty);
           }
         }
       }
@@ -650,7 +663,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   auto put_part = [&](A* dst, const A (&vals)[VEC]) {
     if (fuse) {
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) __hip_atomic_store(dst + v, vals[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int v = 0; v < VEC; ++v) st_sc1(dst + v, vals[v]);
     } else {
 #pragma unroll
       for (int v = 0; v < VEC; ++v) dst[v] = vals[v];
@@ -658,7 +671,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   };
   auto put_arg = [&](Idx* dst, Idx val) {
     if (fuse)
-      __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      st_sc1(dst, val);
     else
       *dst = val;
   };
@@ -703,10 +716,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
 #pragma unroll
         for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(acc[v]);
       }
-      if (p.tune & kTuneNtOut)
-        store_nt(o, ov);  // written once, never re-read by this launch: keep X in the caches
-      else
-        *reinterpret_cast<VecT<DT, VEC>*>(o) = ov;
+      *reinterpret_cast<VecT<DT, VEC>*>(o) = ov;  // (non-temporal row stores measured neutral: bit removed in round 4)
       if constexpr (ARG) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -733,14 +743,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's written-through parts have left
     unsigned ticket = 0;
     if (lg == 0)
-      ticket = __hip_atomic_fetch_add(p.fix_count + s_last, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ticket = __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned*)(p.fix_count + s_last), 1u,
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __shfl(ticket, lane - lg, 64);
     if (ticket != static_cast<unsigned>(s_last - s_first)) return;  // somebody else draws the last ticket
-    if (lg == 0) __hip_atomic_store(p.fix_count + s_last, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lg == 0) st_sc1(p.fix_count + s_last, 0u);
     const A* cv = static_cast<const A*>(p.carry_val);
     const A* tv = static_cast<const A*>(p.tail_val);
-    auto get = [&](const A* src) { return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    auto geti = [&](const Idx* src) { return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto get = [&](const A* src) { return ld_sc1(src); };
+    auto geti = [&](const Idx* src) { return ld_sc1(src); };
     A tot[VEC];
     [[maybe_unused]] Idx au[VEC], ae[VEC];
 #pragma unroll
@@ -889,10 +900,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
 #pragma unroll
               for (int v = 0; v < VEC; ++v) ov.v[v] = from_acc<DT>(tot[v]);
             }
-            if (p.tune & kTuneNtOut)
-              store_nt(o, ov);
-            else
-              *reinterpret_cast<VecT<DT, VEC>*>(o) = ov;
+            *reinterpret_cast<VecT<DT, VEC>*>(o) = ov;
           } else {
             put_part(static_cast<A*>(p.tail_val) + slot * F + k0, tot);
             tail_pending = i0 + tail_t;

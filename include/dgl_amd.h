@@ -469,8 +469,6 @@ int dgla_peer_wait(const void* flags, int num_flags, uint64_t epoch, void* statu
  * and exist so that a benchmark can A/B them:
  *   DGLA_TUNE_XCD     units visit the merge path in XCD-contiguous order (block b runs on XCD
  *                     b % 8, so each XCD's L2 sees one contiguous eighth of the rows)
- *   DGLA_TUNE_NT_OUT  finished output rows are stored non-temporally
- *   DGLA_TUNE_NT_IDX  indices / indptr / eids are loaded non-temporally (read-once streams)
  *   DGLA_TUNE_SPLIT   when a gathered ufeat row touches one 128-byte line more than its length needs
  *                     (F = 100 fp32: 400 B = 4 lines per gather) the call first copies the rows' ragged
  *                     ends (16-byte lanes, rows of >= 256 bytes: one side line per row + a dense array of
@@ -490,14 +488,13 @@ int dgla_peer_wait(const void* flags, int num_flags, uint64_t epoch, void* statu
  *                     three round-to-nearest bf16 terms and the six products of order <= 2 run on
  *                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation — fp32-level accuracy (dropped
  *                     terms < 2^-26 |a b|) at 2.7x less matrix-pipe time; gfx950 has no xf32 MFMA
- * Removed in round 4 (values retired, dgla_set_tuning rejects them): SPLIT_NT 32, SPLIT_CLASSIC 256
+ * Removed in round 4 (values retired, dgla_set_tuning rejects them): NT_OUT 2 and NT_IDX 4 (non-temporal
+ * output-row stores / index-stream loads: measured neutral), SPLIT_NT 32, SPLIT_CLASSIC 256
  * (whole-row copy: 0.33 ms against 0.10), TAIL_PASS 512 (column-sliced pass over the 16-byte row tails:
  * -5 % .. +3.5 %), NT_STREAM 1024 (now a fixed rule: copy_rhs without an edge-id map over rows of >= 64
  * edges on average loads the edge operand non-temporally; measured 1.10 -> 1.01 ms on a 64-segment sum,
  * +7 .. 10 % on short rows, hence the rule).  The reference has no counterpart (its kernels take no hints). */
 #define DGLA_TUNE_XCD 1u
-#define DGLA_TUNE_NT_OUT 2u
-#define DGLA_TUNE_NT_IDX 4u
 #define DGLA_TUNE_SPLIT 8u
 #define DGLA_TUNE_GLDS 16u
 #define DGLA_TUNE_SPLIT_FORCE 64u

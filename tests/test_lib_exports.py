@@ -144,8 +144,8 @@ def test_tuning_constants_match_header_and_library_default():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     text = open(os.path.join(root, "include", "dgl_amd.h")).read()
     defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (DGLA_TUNE_\w+) (\d+)u", text)}
-    assert defs == {"DGLA_TUNE_XCD": 1, "DGLA_TUNE_NT_OUT": 2, "DGLA_TUNE_NT_IDX": 4, "DGLA_TUNE_SPLIT": 8,
-                    "DGLA_TUNE_GLDS": 16, "DGLA_TUNE_SPLIT_FORCE": 64, "DGLA_TUNE_MM_F32": 128}
+    assert defs == {"DGLA_TUNE_XCD": 1, "DGLA_TUNE_SPLIT": 8, "DGLA_TUNE_GLDS": 16, "DGLA_TUNE_SPLIT_FORCE": 64,
+                    "DGLA_TUNE_MM_F32": 128}
     for name, value in defs.items():
         assert getattr(_lib, name) == value
     default = int(_lib.LIB.dgla_get_tuning())
@@ -154,6 +154,6 @@ def test_tuning_constants_match_header_and_library_default():
     bits = re.search(r"constexpr uint32_t kDefaultTuning = ([^;]+);", common).group(1)
     assert default == eval(bits.replace("u", "")) == _lib.DEFAULT_TUNING
     try:
-        assert _lib.LIB.dgla_set_tuning(5) == 0 and int(_lib.LIB.dgla_get_tuning()) == 5
+        assert _lib.LIB.dgla_set_tuning(9) == 0 and int(_lib.LIB.dgla_get_tuning()) == 9
     finally:
         _lib.LIB.dgla_set_tuning(default)

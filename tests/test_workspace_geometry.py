@@ -50,7 +50,7 @@ def test_split_layouts_add_what_they_copy(tuning):
     LIB.dgla_set_tuning(tuning)
     assert ws_bytes(n, n, e, 48) == p48
     # retired bits are refused
-    for bit in (32, 256, 512, 1024):
+    for bit in (2, 4, 32, 256, 512, 1024):
         assert LIB.dgla_set_tuning(tuning | bit) != 0 and int(LIB.dgla_get_tuning()) == tuning
     # whole lines (512-byte rows): nothing to split
     LIB.dgla_set_tuning(tuning & ~_lib.DGLA_TUNE_SPLIT)
