@@ -786,6 +786,9 @@ struct WsParams {
   const int64_t* tile32_off; // [R + 1] exclusive prefix of ceil(len / 32)
   int ncg;                   // column groups (workgroups sharing a row chunk)
   int kp;                    // X3: row pitch of the planes in elements
+  char* dummy;               // 512 bytes nobody reads (the held stores of a wave that holds nothing)
+  int* prog;                 // PIPE kernels: [chunk][wave][4] tiles STARTED by each sibling wave (zeroed per launch)
+  int rot;                   // ncg > 1: 1 = sibling c starts every row at line c * nss / ncg, 0 = paced only, -1 = neither
 };
 
 // Three bf16 planes of the K-contiguous fp32 weights: out[pl][row][k], row pitch kp, zero padded.
@@ -822,7 +825,9 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
   const int nround = (nss + RS - 1) / RS;
   const int pp = (X3 ? 4 : 8) * nss + 1;        // LDS row pitch in 16-byte pieces (odd)
   const int kpieces = X3 ? (wp.kp >> 3) : (K >> 3);  // 16-byte pieces with data per weight row
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform by construction: tell the compiler, it then keeps the
+                                                              // tile loop and the epilogue's whole / ragged choice SCALAR)
   const int l = lane & 31, khalf = lane >> 5;
 
   const int64_t* __restrict__ tile_off = wp.tile32_off;
@@ -830,12 +835,20 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
   // workgroup -> (row chunk, column group): the ncg groups of a chunk are workgroups of ONE XCD
   const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
   // Column groups > 1 (fp32: 64 columns per workgroup; N > 256 for 16-bit): the ncg sibling workgroups of a row
-  // chunk sit on ONE XCD and read the same A rows.  Measured at 10 M x 256 x 256 fp32: unpaced,
-  // the siblings drift and A comes from HBM up to ncg times (7.6-8.0 ms); a soft barrier on per-wave progress
-  // words (any slack) cost more than it saved (9.3-9.9 ms: the progress loads drain the A ring once per tile),
-  // and walking the lines of a row in per-sibling rotated orders changed nothing.  Left unpaced.
+  // chunk sit on ONE XCD and read the same A rows; HBM sees A about once (PMC: 1.16 x).  Two measures keep the
+  // siblings' misses apart, together worth 3-4 % at 10 M x 256 x 256 (fp32, pipelined kernel only): (a) sibling c
+  // walks the lines of a row in a ROTATED order (starts at line c * nss / ncg), so in step the siblings miss on
+  // DIFFERENT lines and hit in their XCD's L2 on the lines the others fetched; (b) a soft barrier keeps them in
+  // step: every wave publishes the tiles it has started, asks for its siblings' counts at the START of a tile and
+  // looks at them before the LAST slot refill of the tile's last round — by then they have long arrived, so the check
+  // costs no drain of the A ring (checking at once did: 9.3-9.9 ms instead of 7.6-8.0); a wave more than one
+  // tile ahead of the slowest waits (bounded).  What bounds this kernel is not the A stream: with A always hitting
+  // the cache and no stores it still runs 6.1 ms (MFMA pipe time of its 240 M instructions: 3.1 ms at 2.4 GHz) —
+  // DESIGN.md §3.7 has the breakdown.
   const int ncg = wp.ncg;
   const int cg = qq % ncg;
+  const bool pace = PIPE && wp.rot >= 0 && ncg > 1 && ncg <= 4;   // (rot < 0: pacing off, the words are still read)
+  const int rot = (wp.rot > 0 && ncg > 1) ? cg * (((K * ES + 127) >> 7) / ncg) : 0;
   const int nchunks = (static_cast<int>(gridDim.x) >> 3) / ncg * 8;
   const int chunk = (qq / ncg) * 8 + xcd;
   if (chunk >= nchunks) return;
@@ -848,6 +861,9 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
   typedef typename WsFrag<typename std::conditional<X3, bf16_t, DT>::type>::type frag_t;
 
   int64_t t = t0;
+  int started = 0;       // tiles this wave has started, across the relations of its chunk
+  bool gave_up = false;
+  int* const pw = wp.prog + (static_cast<int64_t>(chunk) * kWsWaves + wave) * 4;
   while (t < t1) {
     const int64_t rel = uniform64(find_segment(tile_off, p.num_rel, t));
     const int64_t rel_t0 = uniform64(tile_off[rel]);
@@ -896,7 +912,12 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
     // Branch-free: a piece past the end of the row (K not a multiple of the line), and every lane of a refill
     // that has nothing left to fetch, reads the zero page instead — a predicated load would sit in a divergent
     // block and the compiler then waits for vmcnt(0) at every use (seen in the first build).
-    auto load_slot = [&](const char* base, int ss, bool on) -> ASlot {
+    auto phys = [&](int ss) {  // (uniform) line visited at ring position ss
+      const int q = ss + rot;
+      return q >= nss ? q - nss : q;
+    };
+    auto load_slot = [&](const char* base, int ss_ring, bool on) -> ASlot {
+      const int ss = phys(ss_ring < nss ? ss_ring : 0);
       ASlot f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -930,8 +951,52 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
 #pragma unroll
           for (int jj = 0; jj < NJ; ++jj) bf[pl][jj] = *reinterpret_cast<const b16x8*>(brow + (pl * NJ + jj) * 32 * pp * 16);
       };
-      if constexpr (PIPE) load_b(0, bq[0]);
+      // ... and so is the A side: k-step e + 1's fp32 -> (h, m, l) split (36 VALU) is computed BETWEEN the MFMAs of
+      // k-step e (at[e & 1]), four VALU per MFMA gap: an in-order wave hides about five single-issue instructions
+      // behind one 32-cycle MFMA, and a split sitting in one clump in front of its own 12 MFMAs had no cover
+      [[maybe_unused]] b16x8 at[2][3];
+      if constexpr (PIPE) {
+        load_b(4 * phys(0), bq[0]);
+        split3(__builtin_bit_cast(f32x4, ar[0].v[0]), __builtin_bit_cast(f32x4, ar[0].v[1]), at[0][0], at[0][1], at[0][2]);
+      }
+      // (once per relation: drain here, so that the tile loop's waits are counted against the loop's own back edge —
+      // loads, then the 16 stores of the epilogue — and not against this store-free entry)
+      // (a USE of the youngest load: the compiler places — and, unlike a hand-written s_waitcnt, models — the drain)
+      asm volatile("" ::"v"(ar[RS - 1].v[0]), "v"(ar[RS - 1].v[1]), "v"(ar[RS - 1].v[2]), "v"(ar[RS - 1].v[3]));
+      // HELD stores (fp32 pipelined kernel, rows not indexed): a whole tile's accumulators are not stored in its own
+      // epilogue but copied aside and stored four rows per slot during the NEXT tile's first round.  gfx9 counts stores
+      // in vmcnt, in order with the loads: a burst of 16 stores right behind the ring's loads made the first round's
+      // counted waits ("at most 12 operations in flight") wait for the stores' acknowledgements as well — once per
+      // tile, 1.1 ms of 8.1 (the kernel with its stores removed ran 7.0 ms).  Spread over the round the stores are
+      // long acknowledged when a wait reaches back to them.  The held stores are UNCONDITIONAL (nothing held: they go
+      // to a dummy line) — a conditional store would count as zero stores in the compiler's waits.
+      constexpr bool HOLD = PIPE && !INDEXED;
+      [[maybe_unused]] f32x16 held[NJ];
+      [[maybe_unused]] char* hbase = wp.dummy + lane * 8;   // lane's address of (row 4 khalf, column col) of the held tile
+      [[maybe_unused]] int64_t hstep = 0;                   // bytes between its rows; 0 = nothing held
+      if constexpr (HOLD) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) held[jj][r] = 0.f;
+      }
+      [[maybe_unused]] auto store_held = [&](const int r) {  // accumulator register r = row (r & 3) + 8 (r >> 2) + 4 khalf
+        static_assert(!HOLD || NJ == 2, "held stores: two fp32 columns per lane");
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 w = {held[0][r], held[NJ - 1][r]};
+        __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(hbase + ((r & 3) + 8 * (r >> 2)) * hstep));
+      };
       for (int64_t tt = first; tt < rel_end; tt += kWsWaves) {
+        ++started;
+        // PIPE kernels: publish my count, ask for the siblings' (four words, always — unconditional loads with an
+        // unconditional position in the instruction stream are what lets the compiler wait for them with a COUNTED
+        // vmcnt later instead of draining the A ring; see the check in the last round)
+        [[maybe_unused]] int sib[4];
+        if constexpr (PIPE) {
+          if (lane == 0) __hip_atomic_store(pw + cg, started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sib[j] = __hip_atomic_load(pw + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const bool more = tt + kWsWaves < rel_end;
         const char* nxt = more ? lane_ptr(tt + kWsWaves) : cur;
         f32x16 acc[NJ];
@@ -939,70 +1004,155 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
         for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
-        for (int q = 0; q < nround; ++q) {
+        // One round = RS slots.  The body exists TWICE (the tag only forces a second instantiation): the first round
+        // of a tile runs right behind the previous tile's 16 stores, and gfx9 counts stores in vmcnt — with one
+        // shared body the compiler's counted waits ("at most 12 younger loads in flight") also waited for those
+        // stores to be acknowledged, once per tile (measured: the kernel without its stores 7.0 ms, with 8.1).
+        // In its own copy the first round's waits count the stores as younger operations.
+        auto do_round = [&](const int q, [[maybe_unused]] auto first_tag) __attribute__((always_inline)) {
           const bool last = q + 1 == nround;
           const char* rp = last ? nxt : cur;
           const int rk0 = last ? 0 : (q + 1) * RS;
           const bool refill = !last || more;
+if constexpr (PIPE) {
+            static_assert(!PIPE || (X3 && KSS == 2), "the pipelined body is the fp32 one");
 #pragma unroll
-          for (int u = 0; u < RS; ++u) {
-            const int ss = q * RS + u;
-            if (PIPE || ss < nss) {  // (uniform)
+            for (int u = 0; u < RS; ++u) {
+              const int ss = q * RS + u;
 #pragma unroll
-              for (int i = 0; i < KSS; ++i) {
-                const int piece0 = (X3 ? 4 : 8) * ss + i;  // the h = 0 lanes' piece of this k-step
-                if (!PIPE && piece0 >= kpieces) continue;   // (uniform) a k-step wholly past the end of the row
-                const char* brow = smem + (l * pp + piece0 + (X3 ? 2 : 4) * khalf) * 16;
-                if constexpr (!X3) {
-                  frag_t bf[NJ];
+              for (int i = 0; i < 2; ++i) {
+                const int e = 2 * u + i;  // (compile-time after unrolling) k-step of the round
+                if (i == 1) {
+                  // both halves of slot u have been split (one and two k-steps ago): refill it now, in place
+                  if (u == RS - 1 && last && pace && !gave_up) {
+                    // the siblings' counts asked for at the start of this tile: 4 (RS - 1) younger loads are in flight
+                    // behind them, so the wait is vmcnt(12), not a drain.  More than a tile ahead of the slowest: wait.
+                    // (the empty asm pins the first USE here: left alone the compiler combines the four words right
+                    // behind their loads, and waits for them there)
+                    int slowest = started;
 #pragma unroll
-                  for (int jj = 0; jj < NJ; ++jj)
-                    bf[jj] = *reinterpret_cast<const frag_t*>(brow + jj * 32 * pp * 16);
-                  const frag_t af = __builtin_bit_cast(frag_t, ar[u].v[i]);
+                    for (int j = 0; j < 4; ++j) {
+                      asm volatile("" : "+v"(sib[j]));
+                      slowest = (j < ncg && sib[j] < slowest) ? sib[j] : slowest;
+                    }
+                    slowest = __builtin_amdgcn_readfirstlane(slowest);
+                    for (int spins = 0; started - slowest > 1; ++spins) {
+                      if (spins > (1 << 14)) {  // a sibling that is not resident (CU masks, co-running kernels): stop pacing
+                        gave_up = true;
+                        break;
+                      }
+                      __builtin_amdgcn_s_sleep(4);
+                      slowest = started;
 #pragma unroll
-                  for (int jj = 0; jj < NJ; ++jj) acc[jj] = WsFrag<DT>::mma(af, bf[jj], acc[jj]);
-                } else if constexpr (PIPE) {
-                  constexpr int kE = RS * KSS;  // k-steps per round (even: the buffer parity carries over)
-                  const int e = u * KSS + i;    // (compile-time after unrolling)
-                  const int next_piece = (i + 1 < KSS) ? piece0 + 1
-                                         : 4 * ((u + 1 < RS) ? ss + 1 : (last ? 0 : (q + 1) * RS));
-                  static_assert(kE % 2 == 0, "even number of k-steps per round");
-                  load_b(next_piece, bq[(e + 1) & 1]);
-                  b16x8 at[3];  // h, m, l
-                  split3(__builtin_bit_cast(f32x4, ar[u].v[2 * i]), __builtin_bit_cast(f32x4, ar[u].v[2 * i + 1]), at[0], at[1], at[2]);
-                  // small terms first; consecutive MFMAs go to DIFFERENT accumulators
-                  constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};
+                      for (int j = 0; j < 4; ++j) {
+                        const int v = __hip_atomic_load(pw + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        slowest = (j < ncg && v < slowest) ? v : slowest;
+                      }
+                      slowest = __builtin_amdgcn_readfirstlane(slowest);
+                    }
+                  }
+                  ar[u] = load_slot(rp, rk0 + u, true);
+                }
+                const int next_piece = (i == 0) ? 4 * phys(ss) + 1
+                                                : 4 * phys((u + 1 < RS) ? ss + 1 : (last ? 0 : (q + 1) * RS));
+                load_b(next_piece, bq[(e + 1) & 1]);
+                // A of k-step e + 1: the second half of this slot, or the first half of the next slot (the next
+                // round's / tile's slot 0 after the last one — refilled earlier in this round)
+                const ASlot& an = ar[i == 0 ? u : (u + 1) % RS];
+                const f32x4 xlo = __builtin_bit_cast(f32x4, an.v[i == 0 ? 2 : 0]);
+                const f32x4 xhi = __builtin_bit_cast(f32x4, an.v[i == 0 ? 3 : 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                // MFMA g, then a third of one element pair's split (2-4 VALU), nothing allowed across: the compiler's
+                // own order was [36 VALU][12 MFMA] (sched_group_barrier patterns were not honoured either)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+                constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};  // small terms first
+                f32x2 xr[4];
+                uint32_t hp[4], mp[4], lp[4];
 #pragma unroll
-                  for (int term = 0; term < 6; ++term)
+                for (int g = 0; g < 6 * NJ; ++g) {
+                  const int term = g / NJ, jj = g % NJ;  // consecutive MFMAs go to DIFFERENT accumulators
+                  acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[e & 1][ta[term]], bq[e & 1][tb[term]][jj], acc[jj], 0, 0, 0);
+                  constexpr int kStages = 12;
+                  // stage st of the split rides behind MFMA st * (6 NJ) / 12
+                  if ((g * kStages) % (6 * NJ) == 0) {
+                    const int st = g * kStages / (6 * NJ), pr = st / 3;  // element pair pr: elements 2 pr, 2 pr + 1 of the 8
+                    if (st % 3 == 0) {
+                      const f32x2 x = pr < 2 ? f32x2{xlo[2 * pr], xlo[2 * pr + 1]} : f32x2{xhi[2 * pr - 4], xhi[2 * pr - 3]};
+                      const b16x2 hb = __builtin_convertvector(x, b16x2);
+                      hp[pr] = __builtin_bit_cast(uint32_t, hb);
+                      xr[pr] = x - __builtin_convertvector(hb, f32x2);
+                    } else if (st % 3 == 1) {
+                      const b16x2 mb = __builtin_convertvector(xr[pr], b16x2);
+                      mp[pr] = __builtin_bit_cast(uint32_t, mb);
+                      xr[pr] = xr[pr] - __builtin_convertvector(mb, f32x2);
+                    } else {
+                      lp[pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(xr[pr], b16x2));
+                    }
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (HOLD && decltype(first_tag)::value) {
+                  if (u < 2) {  // eight rows behind each of the first four k-steps' MFMAs... early, so that the second
+                                // round's waits (counted against its own loop, without the stores) find them done
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) store_held(8 * u + 4 * i + rr);
+                  }
+                }
+                typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                at[(e + 1) & 1][0] = __builtin_bit_cast(b16x8, (u32x4_t{hp[0], hp[1], hp[2], hp[3]}));
+                at[(e + 1) & 1][1] = __builtin_bit_cast(b16x8, (u32x4_t{mp[0], mp[1], mp[2], mp[3]}));
+                at[(e + 1) & 1][2] = __builtin_bit_cast(b16x8, (u32x4_t{lp[0], lp[1], lp[2], lp[3]}));
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < RS; ++u) {
+              const int ss = q * RS + u;
+              if (ss < nss) {  // (uniform)
+#pragma unroll
+                for (int i = 0; i < KSS; ++i) {
+                  const int piece0 = (X3 ? 4 : 8) * phys(ss) + i;  // the h = 0 lanes' piece of this k-step
+                  if (piece0 >= kpieces) continue;   // (uniform) a k-step wholly past the end of the row
+                  const char* brow = smem + (l * pp + piece0 + (X3 ? 2 : 4) * khalf) * 16;
+                  if constexpr (!X3) {
+                    frag_t bf[NJ];
 #pragma unroll
                     for (int jj = 0; jj < NJ; ++jj)
-                      acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[ta[term]], bq[e & 1][tb[term]][jj], acc[jj], 0, 0, 0);
-                } else {
-                  b16x8 ah, am, al;
-                  split3(__builtin_bit_cast(f32x4, ar[u].v[2 * i]), __builtin_bit_cast(f32x4, ar[u].v[2 * i + 1]), ah, am, al);
+                      bf[jj] = *reinterpret_cast<const frag_t*>(brow + jj * 32 * pp * 16);
+                    const frag_t af = __builtin_bit_cast(frag_t, ar[u].v[i]);
 #pragma unroll
-                  for (int jj = 0; jj < NJ; ++jj) {
-                    const b16x8 bh = *reinterpret_cast<const b16x8*>(brow + (0 * NJ + jj) * 32 * pp * 16);
-                    const b16x8 bm = *reinterpret_cast<const b16x8*>(brow + (1 * NJ + jj) * 32 * pp * 16);
-                    const b16x8 bl = *reinterpret_cast<const b16x8*>(brow + (2 * NJ + jj) * 32 * pp * 16);
-                    f32x16 c = acc[jj];  // small terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-                    acc[jj] = c;
+                    for (int jj = 0; jj < NJ; ++jj) acc[jj] = WsFrag<DT>::mma(af, bf[jj], acc[jj]);
+                  } else {
+                    b16x8 ah, am, al;
+                    split3(__builtin_bit_cast(f32x4, ar[u].v[2 * i]), __builtin_bit_cast(f32x4, ar[u].v[2 * i + 1]), ah, am, al);
+#pragma unroll
+                    for (int jj = 0; jj < NJ; ++jj) {
+                      const b16x8 bh = *reinterpret_cast<const b16x8*>(brow + (0 * NJ + jj) * 32 * pp * 16);
+                      const b16x8 bm = *reinterpret_cast<const b16x8*>(brow + (1 * NJ + jj) * 32 * pp * 16);
+                      const b16x8 bl = *reinterpret_cast<const b16x8*>(brow + (2 * NJ + jj) * 32 * pp * 16);
+                      f32x16 c = acc[jj];  // small terms first
+                      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+                      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                      acc[jj] = c;
+                    }
                   }
                 }
               }
+              ar[u] = load_slot(rp, rk0 + u, refill && rk0 + u < nss);  // in place: the ring stays in flight
+              // keep program order = source order: hoisting the refill above the slot's own multiply makes the
+              // compiler rotate the ring's registers and (fp32 kernel) drain the ring with vmcnt(0) once per round
+              __builtin_amdgcn_sched_barrier(0);
             }
-            ar[u] = load_slot(rp, rk0 + u, refill && rk0 + u < nss);  // in place: the ring stays in flight
-            // keep program order = source order: hoisting the refill above the slot's own multiply makes the
-            // compiler rotate the ring's registers and (fp32 kernel) drain the ring with vmcnt(0) once per round
-            __builtin_amdgcn_sched_barrier(0);
           }
-        }
+        };
+        do_round(0, std::true_type{});
+        for (int q = 1; q < nround; ++q) do_round(q, std::false_type{});
         // ---- epilogue: registers -> global, NJ consecutive columns per lane --------------------------------
         if constexpr (X3) {
           bool bad = false;
@@ -1017,8 +1167,13 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
         constexpr bool nt_c = true;  // C is written once and never re-read here (1.94 -> 1.90 ms at the R-GCN shape)
         // the usual tile — all 32 rows inside the segment, all of the group's columns inside N — stores without a
         // predicate (wave-uniform test); ragged tiles take the element-wise path
-        const bool whole = trow0 + 32 <= row_end && n0 + 32 * NJ <= N;
-        if (whole) {
+        const bool whole = uniform64(trow0) + 32 <= row_end && n0 + 32 * NJ <= N;
+        if (HOLD && whole) {
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) held[jj] = acc[jj];
+          hstep = static_cast<int64_t>(N) * ES;
+          hbase = reinterpret_cast<char*>(C + (trow0 + 4 * khalf) * N + col);
+        } else if (whole) {
           int64_t prow[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -1053,14 +1208,19 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
                   *reinterpret_cast<u32xh*>(dst) = w;
               }
             } else {
-              typedef float f32xn __attribute__((ext_vector_type(NJ)));
-              f32xn w;
+              if constexpr ((NJ & (NJ - 1)) == 0) {
+                typedef float f32xn __attribute__((ext_vector_type(NJ)));
+                f32xn w;
 #pragma unroll
-              for (int jj = 0; jj < NJ; ++jj) w[jj] = acc[jj][r];
-              if (nt_c)
-                __builtin_nontemporal_store(w, reinterpret_cast<f32xn*>(dst));
-              else
-                *reinterpret_cast<f32xn*>(dst) = w;
+                for (int jj = 0; jj < NJ; ++jj) w[jj] = acc[jj][r];
+                if (nt_c)
+                  __builtin_nontemporal_store(w, reinterpret_cast<f32xn*>(dst));
+                else
+                  *reinterpret_cast<f32xn*>(dst) = w;
+              } else {  // NJ = 3: three consecutive dwords per lane (a half-wave still writes 384 contiguous bytes)
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) __builtin_nontemporal_store(acc[jj][r], reinterpret_cast<float*>(dst) + jj);
+              }
             }
           }
         } else {
@@ -1074,8 +1234,17 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
             for (int jj = 0; jj < NJ; ++jj)
               if (col + jj < N) C[pr * N + col + jj] = from_acc<DT>(acc[jj][r]);
           }
+          // (rare path: wait for the whole ring here — through a USE, which the compiler models — so that behind the
+          // join the counts are those of the usual path above, 16 stores younger than the ring)
+          asm volatile("" ::"v"(ar[RS - 1].v[0]), "v"(ar[RS - 1].v[1]), "v"(ar[RS - 1].v[2]), "v"(ar[RS - 1].v[3]));
         }
         cur = nxt;
+      }
+      if constexpr (HOLD) {
+        if (hstep != 0) {  // the wave's last whole tile of this relation
+#pragma unroll
+          for (int r = 0; r < 16; ++r) store_held(r);
+        }
       }
     }
     t = rel_end;
@@ -1099,7 +1268,7 @@ __global__ __launch_bounds__(256) void segment_mm_plain_kernel(const MmParams p,
     else
       hi = mid - 1;
   }
-  if (row >= row_off[p.num_rel]) return;  // rows beyond sum(seglen) are left untouched
+  if (row >= row_off[p.num_rel]) return;  // rows beyond sum(seglen): zeroed by segment_zero_tail_kernel, not here
   const int64_t prow = p.row_index ? p.row_index[row] : row;
   const DT* a = static_cast<const DT*>(p.a) + prow * p.K;
   const DT* b = static_cast<const DT*>(p.bt) + (lo * p.N + col) * static_cast<int64_t>(p.K);
@@ -1348,9 +1517,10 @@ __global__ __launch_bounds__(256) void gather_mm_kernel(const DT* __restrict__ a
 
 // ---- host side ------------------------------------------------------------------------------
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+constexpr size_t kWsProgWords = 16 * 1024;  // >= row chunks (<= CUs) x 8 waves x 4 words
 
 struct MmScratch {
-  size_t off_plan, off_t32, off_bt, off_planes, off_acc, total;
+  size_t off_plan, off_t32, off_prog, off_bt, off_planes, off_acc, total;
 };
 
 MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool need_bt,
@@ -1361,6 +1531,8 @@ MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool ne
   off = align256(off + sizeof(int64_t) * (2 * num_rel + 2) + /* staged seglen */ 8 * num_rel + /* NaN flag */ 8);
   s.off_t32 = off;
   if (forward) off = align256(off + sizeof(int64_t) * (num_rel + 1));
+  s.off_prog = off;  // pacing words of the weights-stationary kernel: [row chunk][wave][column group]
+  if (forward) off = align256(off + sizeof(int) * kWsProgWords + 1024);  // (+ the dummy line of the held stores)
   s.off_bt = off;
   if (need_bt) off = align256(off + static_cast<size_t>(num_rel) * K * N * elem);
   s.off_planes = off;  // fp32 forward: the weights as three bf16 planes (weights-stationary kernel)
@@ -1455,13 +1627,17 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
   wp.planes = nullptr;
   wp.tile32_off = reinterpret_cast<const int64_t*>(ws + sc.off_t32);
   wp.kp = 0;
+  wp.prog = nullptr;
+  wp.dummy = nullptr;
+  wp.rot = 0;
   const int N = p.N;
   int cus = mm_num_cus();
   if (const char* ew = getenv("DGLA_MM_WS_WGS")) {  // experiment: fewer workgroups than CUs
     if (atoi(ew) >= 8) cus = atoi(ew);
   }
+  cus = std::min(cus, 512);
   const dim3 block(64 * kWsWaves);
-  // experiment switch (round 4 A/B): bit 0 = fp32 without the fragment double buffer
+  // experiment switch (round 4 A/B): bit 0 = fp32 without the fragment double buffer, bit 2 = siblings unpaced, bit 3 = paced but every sibling walks the lines in order
   const char* ev = getenv("DGLA_MM_WS_VARIANT");
   const int variant = ev && *ev ? atoi(ev) : 0;
   if constexpr (sizeof(DT) == 4) {
@@ -1472,21 +1648,35 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
     hipLaunchKernelGGL(split_weights_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((rows * wp.kp + 255) / 256, 4096))),
                        dim3(256), 0, s, static_cast<const float*>(p.bt), planes, rows, p.K, wp.kp);
     wp.planes = planes;
+    // 64 columns per workgroup (NJ = 2, 101 KB of LDS).  96 (NJ = 3, 152 KB, three column groups at N = 256 instead
+    // of four) was built and measured: 9.41 ms against 7.85 ms at 10 M x 256 x 256 — the time follows the MFMA work
+    // per workgroup (x 1.2 with 240 instead of 256 workgroups busy), not the A bytes read.
     wp.ncg = (N + 63) / 64;
     const int groups = std::max(1, cus / 8 / wp.ncg);  // row chunks per XCD
     const dim3 grid(static_cast<unsigned>(groups * wp.ncg * 8));
+    // (the PIPE kernels read their pacing words whether they pace or not: always there, always zeroed)
+    wp.prog = reinterpret_cast<int*>(ws + sc.off_prog);
+    wp.dummy = ws + sc.off_prog + sizeof(int) * kWsProgWords;
+    wp.rot = (variant & 4) ? -1 : (variant & 8) ? 0 : 1;
+    static_assert(kWsProgWords >= 64 * 8 * kWsWaves * 4, "pacing words for up to 512 workgroups");
+    DGLA_CHECK_HIP(hipMemsetAsync(wp.prog, 0, sizeof(int) * groups * 8 * kWsWaves * 4, s));
     // PIPE needs every k-step whole and rounds of exactly 4 lines: K a multiple of 128 floats' worth of lines
     const bool pipe = p.K % 32 == 0 && (p.K / 32) % 4 == 0 && !(variant & 1);
-    if (p.row_index) {
-      if (pipe)
-        hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, true, 4, true>), grid, block, 0, s, wp);
-      else
-        hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, true, 4, false>), grid, block, 0, s, wp);
-    } else if (pipe) {
-      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, false, 4, true>), grid, block, 0, s, wp);
-    } else {
-      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, 2, true, false, 4, false>), grid, block, 0, s, wp);
-    }
+#define DGLA_WS3(NJV)                                                                                       \
+  do {                                                                                                      \
+    if (p.row_index) {                                                                                      \
+      if (pipe)                                                                                             \
+        hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, true, true, 4, true>), grid, block, 0, s, wp);     \
+      else                                                                                                  \
+        hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, true, true, 4, false>), grid, block, 0, s, wp);    \
+    } else if (pipe) {                                                                                      \
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, true, false, 4, true>), grid, block, 0, s, wp);      \
+    } else {                                                                                                \
+      hipLaunchKernelGGL((segment_mm_ws_kernel<DT, NJV, true, false, 4, false>), grid, block, 0, s, wp);     \
+    }                                                                                                       \
+  } while (0)
+    DGLA_WS3(2);
+#undef DGLA_WS3
     hipLaunchKernelGGL(x3_repair_fwd_kernel, dim3(1024), dim3(256), 0, s, p);  // no-op unless a NaN came out
   } else {
     const int nj = N <= 32 ? 1 : (N <= 64 ? 2 : (N <= 128 ? 4 : 8));

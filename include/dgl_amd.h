@@ -263,7 +263,8 @@ int dgla_spmm_cmp_backward(int idtype_bits, dgla_dtype dtype, const dgla_tensor*
  *     b_trans == 0:  C[rows] = A[rows] (m x k) . B[r] (k x n),  B is [num_rel, k, n]
  *     b_trans != 0:  C[rows] = A[rows] (m x k) . B[r]^T,        B is [num_rel, n, k]
  *   ONE grouped launch on the MFMA units (fp32 accumulate; fp64 on the vector ALUs).  Rows
- *   beyond sum(seglen) are not written.
+ *   beyond sum(seglen) come back ZERO, as the reference's do (its output starts as th.zeros,
+ *   python/dgl/backend/pytorch/sparse.py:975).
  * dgla_segment_mm_backward_b:  dB[r] (d1 x d2) = A[rows_r]^T (d1 x m) . dC[rows_r] (m x d2);
  *   relations without rows get zeros.
  * dgla_gather_mm:  C[idx_c ? idx_c[i] : i] = A[idx_a ? idx_a[i] : i] (1 x k) . B[idx_b ? idx_b[i] : i]
