@@ -200,15 +200,29 @@ def c2(dev, args):
         o = dgl.ops.copy_u_max(dg, xg)
         o.backward(up)
 
-    fwd_bwd_max()
+    fwd_bwd_max()  # (builds the out-edge CSR and the position map of the gather backward once, like the forward CSC)
     ms, mn = timeit(fwd_bwd_max, reps=5)
-    bwd_bytes = n * f * (4 + 4 + 4) + n * f * 4     # dZ, arg_u, atomics into dX, + the zero fill of dX
-    emit("C2", "copy_u_max forward + backward (backward = one dgla_spmm_cmp_backward launch)", e, ms, mn,
-         spmm_bytes(n, e, f, f, 4, 4) + n * f * 4 + bwd_bytes)
+    words = (f + 31) // 32
+    # backward = winner bits (arg_u, the CSC's column ids -> 4 B x words per edge) + a g-SpMM over the reverse graph that
+    # reads a dZ row and the bit words per edge
+    bwd_bytes = n * f * 8 + e * 4 + e * 4 * words + spmm_bytes(n, e, f, f, 4, 4) + e * (4 * words + 4)
+    emit("C2", "copy_u_max forward + backward (backward = winner bits + masked g-SpMM over the reverse graph, no atomics)",
+         e, ms, mn, spmm_bytes(n, e, f, f, 4, 4) + n * f * 4 + bwd_bytes)
     g1 = xg.grad.clone()
     fwd_bwd_max()
-    emit("C2", "copy_u_max backward: bits equal across two runs (atomics on node rows)", e, 0.0, 0.0, 1,
-         deterministic=bool(torch.equal(g1, xg.grad)))
+    print(json.dumps({"config": "C2", "op": "copy_u_max backward (gather path): bits equal across two runs",
+                      "deterministic": bool(torch.equal(g1, xg.grad))}), flush=True)
+    os.environ["DGLA_CMP_BACKWARD"] = "atomic"
+    fwd_bwd_max()
+    ms, mn = timeit(fwd_bwd_max, reps=5)
+    emit("C2", "copy_u_max forward + backward, DGLA_CMP_BACKWARD=atomic (one dgla_spmm_cmp_backward launch, float atomics)",
+         e, ms, mn, spmm_bytes(n, e, f, f, 4, 4) + n * f * 4 + n * f * 16)
+    g2 = xg.grad.clone()
+    fwd_bwd_max()
+    print(json.dumps({"config": "C2", "op": "copy_u_max backward (atomic path): bits equal across two runs",
+                      "deterministic": bool(torch.equal(g2, xg.grad)),
+                      "max_abs_diff_gather_vs_atomic": float((g1 - g2).abs().max())}), flush=True)
+    del os.environ["DGLA_CMP_BACKWARD"]
     from dgl_amd import _capi as _c
     argu = torch.randint(0, n, (n, f), device=dev, dtype=torch.int32)
     dx = torch.zeros(n, f, device=dev)

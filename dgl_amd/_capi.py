@@ -283,6 +283,40 @@ def spmm_cmp_backward(dz, arg, out, other=None, arg_other=None, other_group=1, a
     return out
 
 
+def spmm_cmp_mask_words(dtype, feat_len):
+    return int(LIB.dgla_spmm_cmp_mask_words(_DTYPES[dtype], int(feat_len)))
+
+
+def spmm_cmp_mask(csr, arg, dz, mask, dx, by_edge=False):
+    """Winner bits of a max / min g-SpMM over the FORWARD matrix `csr` (dgla_spmm_cmp_mask): for every edge in
+    position order, one bit per output column; elements no edge claims go to ``dx[arg]`` here (``dx`` zeroed by
+    the caller)."""
+    keep = []
+    tz, tx = _tensor(dz, keep), _tensor(dx, keep)
+    _require_gpu(arg)
+    check_call(LIB.dgla_spmm_cmp_mask(ctypes.byref(csr), _DTYPES[dz.dtype], arg.data_ptr(), 1 if by_edge else 0,
+                                      ctypes.byref(tz), _ptr(mask), ctypes.byref(tx), _stream(dx)))
+
+
+def spmm_csr_masked_workspace_bytes(csr, ufeat, out):
+    keep = []
+    tu, to = _tensor(ufeat, keep), _tensor(out, keep)
+    return LIB.dgla_spmm_csr_masked_workspace_bytes(ctypes.byref(csr), _DTYPES[out.dtype], ctypes.byref(tu),
+                                                    ctypes.byref(to))
+
+
+def spmm_csr_masked(csr, ufeat, mask, out, workspace=None, accumulate=False, plan_valid=False):
+    """out (+)= sum over the edges of every row of `csr` of ufeat[col] gated per (edge, column) by `mask`, which is
+    indexed through the CSR's edge-id map (dgla_spmm_csr_masked)."""
+    keep = []
+    tu, to = _tensor(ufeat, keep), _tensor(out, keep)
+    flags = (_lib.DGLA_ACCUMULATE if accumulate else 0) | (_lib.DGLA_PLAN_VALID if plan_valid else 0)
+    check_call(LIB.dgla_spmm_csr_masked(ctypes.byref(csr), _DTYPES[out.dtype], ctypes.byref(tu), _ptr(mask),
+                                        ctypes.byref(to), _ptr(workspace),
+                                        0 if workspace is None else workspace.numel() * workspace.element_size(), flags,
+                                        _stream(out)))
+
+
 def _mm_check(*ts):
     for t in ts:
         if t is None:

@@ -115,6 +115,15 @@ for _n, _a in (("dgla_peer_alloc", [ctypes.c_size_t, c_int, P(c_void_p)]), ("dgl
 LIB.dgla_spmm_cmp_backward.restype = c_int
 LIB.dgla_spmm_cmp_backward.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p, c_int64, P(Tensor),
                                        c_int, c_void_p]
+LIB.dgla_spmm_cmp_mask_words.restype = c_int64
+LIB.dgla_spmm_cmp_mask_words.argtypes = [c_int, c_int64]
+LIB.dgla_spmm_cmp_mask.restype = c_int
+LIB.dgla_spmm_cmp_mask.argtypes = [P(CSR), c_int, c_void_p, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
+LIB.dgla_spmm_csr_masked_workspace_bytes.restype = c_size_t
+LIB.dgla_spmm_csr_masked_workspace_bytes.argtypes = [P(CSR), c_int, P(Tensor), P(Tensor)]
+LIB.dgla_spmm_csr_masked.restype = c_int
+LIB.dgla_spmm_csr_masked.argtypes = [P(CSR), c_int, P(Tensor), c_void_p, P(Tensor), c_void_p, c_size_t, c_uint32,
+                                     c_void_p]
 LIB.dgla_backward_segment_cmp.restype = c_int
 LIB.dgla_backward_segment_cmp.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
 LIB.dgla_segment_mm_workspace_bytes.restype = c_size_t

@@ -95,6 +95,55 @@ def _cmp_backward(dZ, arg, rows, other, arg_other, atomic):
                                    None if other is None else arg_other.contiguous(), grp[1], atomic=atomic)
 
 
+def _cmp_backward_node_gather(gidx, dZ, arg_u, rows):
+    """dX of a max / min g-SpMM whose message is X itself (copy_lhs, add) WITHOUT atomics: winner bits per
+    (edge, column) over the forward CSC (dgla_spmm_cmp_mask), then one merge-path g-SpMM over the reverse matrix
+    gated by them (dgla_spmm_csr_masked) — the reference's ``dX.scatter_add_(0, argX.long(), dZ)``
+    (python/dgl/backend/pytorch/sparse.py:216-224) as a gather, same bits on every run.  Returns None when this
+    relation should take the atomic kernel instead (a sampled block rebuilt every step: the CSR it needs would
+    be built for one use; ``DGLA_CMP_BACKWARD=atomic``)."""
+    import os
+    from . import _capi
+
+    rel = gidx.relations[0]
+    if (rel.transient or not rel.allowed("csr") or not rel.allowed("csc") or rel.num_edges == 0 or
+            os.environ.get("DGLA_CMP_BACKWARD", "") == "atomic" or not dZ.is_cuda):
+        return None
+    n_edges = rel.num_edges
+    feat = 1
+    for d in dZ.shape[1:]:
+        feat *= d
+    if feat == 0 or dZ.shape[0] == 0 or rows == 0:
+        return None
+    cache = rel.__dict__.setdefault("_cmp_gather", {})
+    if "csr" not in cache:
+        ip, idx, eids = rel.csc()        # forward: rows = destinations
+        rip, ridx, reids = rel.csr()     # its transpose: rows = sources (built once per graph, like the sum's backward)
+        pos = torch.arange(n_edges, dtype=rel.idtype, device=rel.device)
+        if eids is None:
+            inv = pos
+        else:
+            inv = torch.empty_like(pos)
+            inv[eids.long()] = pos       # forward position of every edge id
+        pmap = inv if reids is None else inv[reids.long()]
+        cache["fwd"] = _capi.make_csr(ip, idx, eids, rel.num_src)
+        cache["csr"] = _capi.make_csr(rip, ridx, pmap.contiguous(), rel.num_dst)
+        cache["ws"] = {}
+    dz2 = dZ.reshape(dZ.shape[0], feat)
+    dX = torch.zeros(rows, feat, dtype=dZ.dtype, device=dZ.device)
+    words = _capi.spmm_cmp_mask_words(dZ.dtype, feat)
+    mask = torch.empty(n_edges, words, dtype=dZ.dtype, device=dZ.device)
+    _capi.spmm_cmp_mask(cache["fwd"], arg_u.reshape(arg_u.shape[0], feat).contiguous(), dz2, mask, dX)
+    key = (dZ.dtype, feat)
+    ws = cache["ws"].get(key)
+    fresh = ws is None
+    if fresh:
+        ws = cache["ws"][key] = torch.empty(max(int(_capi.spmm_csr_masked_workspace_bytes(cache["csr"], dz2, dX)), 1),
+                                            dtype=torch.uint8, device=dZ.device)
+    _capi.spmm_csr_masked(cache["csr"], dz2, mask, dX, workspace=ws, accumulate=True, plan_valid=not fresh)
+    return dX.reshape((rows,) + tuple(dZ.shape[1:]))
+
+
 class GSpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gidx, op, reduce_op, X, Y):
@@ -124,8 +173,11 @@ class GSpMM(torch.autograd.Function):
                 else:  # add, copy_lhs: the message is linear in X with coefficient 1
                     dX = gspmm(rev, "copy_lhs", "sum", dZ, None)
             else:
-                # a source node can win at many destinations: atomic sum (as the reference's scatter_add_)
-                dX = _cmp_backward(dZ, argX, x_shape[0], Y if op == "mul" else None, argY, atomic=True)
+                # a source node can win at many destinations: a gather over the reverse graph gated by winner bits
+                # (deterministic) when the message is X itself, else the atomic sum (as the reference's scatter_add_)
+                dX = _cmp_backward_node_gather(gidx, dZ, argX, x_shape[0]) if op != "mul" else None
+                if dX is None:
+                    dX = _cmp_backward(dZ, argX, x_shape[0], Y if op == "mul" else None, argY, atomic=True)
             dX = _reduce_grad(dX, x_shape)
         if op != "copy_lhs" and ctx.needs_input_grad[4]:
             if reduce_op == "sum":

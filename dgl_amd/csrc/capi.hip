@@ -372,6 +372,72 @@ int dgla_spmm_csr(const char* op, const char* reduce, const dgla_csr* csr, dgla_
   return fail("unsupported feature dtype");
 }
 
+// g-SpMM (copy_lhs, sum) gated per edge and output column by bit masks (dgla_spmm_cmp_mask writes them): the merge-path
+// kernel's `mul` with a grouped rhs, the rhs word read as bits (spmm_csr.hip.h: rhs_mask).
+static int build_masked_launch(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* ufeat, const void* mask,
+                               const dgla_tensor* out, int64_t* shapes, dgla_tensor* views, SpmmLaunch* L) {
+  if (!csr) return fail("csr is null");
+  if (!present(ufeat) || !out || !out->data || out->ndim < 1 || !out->shape) return fail("ufeat / out is null");
+  int64_t f = 1, fo = 1;
+  for (int d = 1; d < ufeat->ndim; ++d) f *= ufeat->shape[d];
+  for (int d = 1; d < out->ndim; ++d) fo *= out->shape[d];
+  if (f != fo) return fail("ufeat and out have different feature shapes");
+  shapes[0] = ufeat->shape[0]; shapes[1] = f;
+  shapes[2] = out->shape[0];   shapes[3] = f;
+  shapes[4] = csr->nnz;        shapes[5] = 1;
+  views[0] = dgla_tensor{ufeat->data, 2, shapes};
+  views[1] = dgla_tensor{out->data, 2, shapes + 2};
+  views[2] = dgla_tensor{const_cast<void*>(mask), 2, shapes + 4};
+  if (csr->nnz && !mask) return fail("mask is null");
+  if (build_spmm_launch("mul", "sum", csr, dtype, &views[0], &views[2], &views[1], L)) return -1;
+  const int bits = dtype == DGLA_F64 ? 64 : (dtype == DGLA_F32 ? 32 : 16);
+  L->bcast = kBcRhsGroup;
+  L->rhs_group = bits;
+  L->rhs_len = (f + bits - 1) / bits;
+  L->rhs_mask = true;
+  return 0;
+}
+
+size_t dgla_spmm_csr_masked_workspace_bytes(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* ufeat,
+                                            const dgla_tensor* out) {
+  SpmmLaunch L{};
+  int64_t shapes[6];
+  dgla_tensor views[3];
+  static const char dummy = 0;
+  if (build_masked_launch(csr, dtype, ufeat, &dummy, out, shapes, views, &L)) return 0;
+  switch (dtype) {
+    case DGLA_F32: return spmm_csr_workspace_f32(L);
+    case DGLA_F64: return spmm_csr_workspace_f64(L);
+    case DGLA_F16: return spmm_csr_workspace_f16(L);
+    case DGLA_BF16: return spmm_csr_workspace_bf16(L);
+  }
+  return 0;
+}
+
+int dgla_spmm_csr_masked(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* ufeat, const void* mask,
+                         const dgla_tensor* out, void* workspace, size_t workspace_bytes, uint32_t flags,
+                         void* hip_stream) {
+  SpmmLaunch L{};
+  int64_t shapes[6];
+  dgla_tensor views[3];
+  if (build_masked_launch(csr, dtype, ufeat, mask, out, shapes, views, &L)) return -1;
+  if (flags & ~(DGLA_ACCUMULATE | DGLA_PLAN_VALID)) return fail("dgla_spmm_csr_masked: DGLA_ACCUMULATE | DGLA_PLAN_VALID only");
+  L.accumulate = (flags & DGLA_ACCUMULATE) != 0;
+  L.plan_valid = (flags & DGLA_PLAN_VALID) != 0;
+  L.workspace = workspace;
+  L.workspace_bytes = workspace_bytes;
+  L.stream = static_cast<hipStream_t>(hip_stream);
+  if (csr->num_rows == 0 || L.out_len == 0) return 0;
+  const DeviceGuard dev(L.stream, L.out);
+  switch (dtype) {
+    case DGLA_F32: return launch_spmm_csr_f32(L);
+    case DGLA_F64: return launch_spmm_csr_f64(L);
+    case DGLA_F16: return launch_spmm_csr_f16(L);
+    case DGLA_BF16: return launch_spmm_csr_bf16(L);
+  }
+  return fail("unsupported feature dtype");
+}
+
 // Shapes are taken from relation 0's operands; every relation must use the same feature
 // shape (src/array/kernel.cc:194-199).  The first dimensions of ufeat0 / efeat0 are not
 // comparable with the stacked matrix (each relation has its own node and edge counts), so

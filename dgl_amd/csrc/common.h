@@ -153,6 +153,7 @@ struct SpmmLaunch {
   bool split_valid; // workspace already holds the split-row copy of this ufeat (DGLA_SPLIT_VALID)
   bool split_keep;  // static ufeat: use the split-row layout whatever the probe says (DGLA_SPLIT_KEEP)
   bool prepare_only;  // plan + side copy only (DGLA_PREPARE_ONLY)
+  bool rhs_mask = false;  // mul + kBcRhsGroup: efeat holds bit masks (dgla_spmm_csr_masked)
   void* workspace;
   size_t workspace_bytes;
   hipStream_t stream;

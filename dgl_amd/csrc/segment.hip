@@ -361,6 +361,151 @@ int scatter_add_sorted(int idbits, dgla_dtype dtype, const dgla_tensor* feat, co
 
 using namespace dgla;
 
+// ---- max / min backward of the NODE operand without atomics: winner masks (dgla_spmm_cmp_mask) ------------------------
+// The reference adds dZ[v][k] to dX[arg_u[v][k]][k] with scatter_add_ (python/dgl/backend/pytorch/sparse.py:216-224:
+// float atomics, 25 G/s on this chip whatever the footprint, a different sum order on every run).  Turned around it is a
+// g-SpMM over the REVERSE graph: dX[u][k] = sum over out-edges e = (u -> v) of [e delivered the winner of (v, k)] dZ[v][k].
+// This kernel writes the bracket: one BIT per (edge, output column), in the edge's position order of the forward CSR,
+// packed into words of the feature type's width; dgla_spmm_csr_masked then runs the merge-path kernel over the reverse CSR
+// with those bits as its edge operand (416 instead of 800 bytes per edge of a compare against arg_u rows; deterministic).
+//   by_edge == 0: `arg` = arg_u; the FIRST edge of row v whose source is arg_u[v][k] gets the bit (parallel edges carry
+//                 equal values: any one of them is the winner, and all of them lead to the same dX row);
+//   by_edge != 0: `arg` = arg_e; the edge whose id it names gets the bit.
+// An element no edge of its row claims (no in-edges, or nothing beat the identity: arg = 0) keeps the reference's
+// behaviour — dZ goes to row arg = 0 of dX all the same — summed in a fixed order (per wave in row order, then over the
+// waves' slots by spmm_cmp_leak_kernel); dX must be zeroed BEFORE this kernel and the masked SpMM must ACCUMULATE into it.
+// One wavefront per (row, 64 columns): lane = column; 64 edges at a time are loaded with one instruction and their keys
+// broadcast from registers; every edge's 64-bit ballot is parked in lane j of the batch and the batch's words leave with
+// one store.
+__device__ __forceinline__ int32_t bcast_lane(int32_t v, int j) { return __builtin_amdgcn_readlane(v, j); }
+__device__ __forceinline__ int64_t bcast_lane(int64_t v, int j) {
+  return (static_cast<int64_t>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), j)) << 32) |
+         static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), j));
+}
+
+template <typename Idx, typename W, typename DT>
+__global__ __launch_bounds__(256) void spmm_cmp_mask_kernel(
+    const Idx* __restrict__ indptr, const Idx* __restrict__ indices, const Idx* __restrict__ eids,
+    const Idx* __restrict__ arg, int by_edge, int64_t rows, int F, int words, W* __restrict__ mask,
+    const DT* __restrict__ dz, DT* __restrict__ dx, int64_t dx_rows, typename Acc<DT>::type* __restrict__ leak) {
+  using A = typename Acc<DT>::type;
+  constexpr int BITS = 8 * static_cast<int>(sizeof(W));
+  constexpr int WPC = 64 / BITS;  // words per 64-column chunk
+  const int chunks = (F + 63) >> 6;
+  const int lane = threadIdx.x & 63;
+  // wave -> (fixed chunk c, rows slot, slot + slots, ...): the grid is a whole number of chunk groups, so a wave's
+  // unclaimed elements all belong to the same 64 columns and can be summed in registers in ROW order
+  const int64_t nw = static_cast<int64_t>(gridDim.x) * (blockDim.x >> 6);
+  const int64_t wid = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t slots = nw / chunks;
+  const int c = static_cast<int>(wid % chunks);
+  const int64_t slot = wid / chunks;
+  if (slot >= slots) return;
+  const int f = c * 64 + lane;
+  const bool live = f < F;
+  A leaked = A(0);
+  __shared__ uint64_t s_bits[4][64];
+  uint64_t* const wb = s_bits[threadIdx.x >> 6];  // this wave's 64 words: edge j of the batch -> its column bits
+  for (int64_t row = slot; row < rows; row += slots) {
+    const int64_t b = static_cast<int64_t>(indptr[row]), e = static_cast<int64_t>(indptr[row + 1]);
+    const Idx a = live ? arg[row * F + f] : static_cast<Idx>(-1);
+    bool found = !live;
+    for (int64_t p0 = b; p0 < e; p0 += 64) {
+      const int nb = static_cast<int>(e - p0 < 64 ? e - p0 : 64);
+      Idx key = static_cast<Idx>(-2);  // (never equal to a column's winner: ids are >= 0, a dead lane asks for -1)
+      if (lane < nb) {
+        if (by_edge)
+          key = eids ? eids[p0 + lane] : static_cast<Idx>(p0 + lane);
+        else
+          key = indices[p0 + lane];
+      }
+      // lane = column: scan the batch's keys from the LAST edge to the first, so the first match stays — three
+      // vector instructions per edge (broadcast, compare, select); the per-edge ballot + park-in-lane-j form of the
+      // first version cost ten and made this kernel 5 ms at 62 M edges
+      int pos = -1;
+#pragma unroll
+      for (int j8 = 56; j8 >= 0; j8 -= 8) {
+        if (j8 < nb) {  // (uniform) lanes >= nb hold the never-matching key: whole groups of eight, lane numbers constant
+#pragma unroll
+          for (int j = 7; j >= 0; --j) pos = (a == bcast_lane(key, j8 + j)) ? j8 + j : pos;
+        }
+      }
+      // column -> edge: every winning column ORs its bit into its edge's word (one LDS atomic per lane), then lane j
+      // picks up the word of edge j.  One wave's LDS operations execute in order; the wave barriers keep the
+      // compiler from re-ordering them.
+      wb[lane] = 0;
+      __builtin_amdgcn_wave_barrier();
+      if (!found && pos >= 0) atomicOr(reinterpret_cast<unsigned long long*>(wb + pos), 1ull << lane);
+      found |= pos >= 0;
+      __builtin_amdgcn_wave_barrier();
+      const uint64_t m = wb[lane];
+      __builtin_amdgcn_wave_barrier();
+      if (lane < nb) {
+        W* dst = mask + (p0 + lane) * words + c * WPC;
+#pragma unroll
+        for (int w = 0; w < WPC; ++w)
+          if (c * WPC + w < words) dst[w] = static_cast<W>(m >> (w * BITS));
+      }
+    }
+    if (live && !found) {
+      // nothing of the row claimed this element.  From the library's own forward that means arg = 0 (the value an
+      // element without a winner gets): summed here in row order, added to dX[0] by spmm_cmp_leak_kernel in slot
+      // order — the same bits on every run.  Any other target (a hand-made arg): one atomic add, like the scatter.
+      const int64_t a64 = static_cast<int64_t>(a);
+      if (a64 == 0)
+        leaked += to_acc<DT>(dz[row * F + f]);
+      else if (a64 > 0 && a64 < dx_rows)
+        atomic_add_elem<DT>(dx + a64 * F + f, dz[row * F + f]);
+    }
+  }
+  if (live) leak[slot * F + f] = leaked;
+}
+
+// dX[0][k] += sum over the mask kernel's slots in a FIXED order: one workgroup per column, thread t sums slots
+// t, t + 256, ... in order, then a fixed tree over the 256 partial sums.
+template <typename DT>
+__global__ __launch_bounds__(256) void spmm_cmp_leak_kernel(const typename Acc<DT>::type* __restrict__ leak,
+                                                            int64_t slots, int F, DT* __restrict__ dx) {
+  using A = typename Acc<DT>::type;
+  __shared__ A part[256];
+  const int k = blockIdx.x;
+  A s = A(0);
+  for (int64_t i = threadIdx.x; i < slots; i += 256) s += leak[i * F + k];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dx[k] = from_acc<DT>(to_acc<DT>(dx[k]) + part[0]);
+}
+
+template <typename Idx, typename DT>
+int run_spmm_cmp_mask(const void* indptr, const void* indices, const void* eids, const void* arg, int by_edge,
+                      int64_t rows, int64_t F, void* mask, const void* dz, void* dx, int64_t dx_rows, hipStream_t s) {
+  typedef typename std::conditional<sizeof(DT) == 2, uint16_t, typename std::conditional<sizeof(DT) == 4, uint32_t, uint64_t>::type>::type W;
+  using A = typename Acc<DT>::type;
+  const int bits = 8 * static_cast<int>(sizeof(W));
+  const int words = static_cast<int>((F + bits - 1) / bits);
+  const int64_t chunks = (F + 63) / 64;
+  // waves: a whole number of chunk groups (every wave keeps ONE chunk), at most 8192 of them
+  int64_t slots = std::min<int64_t>(rows, std::max<int64_t>(1, 8192 / chunks));
+  int64_t waves = slots * chunks;
+  const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
+  slots = static_cast<int64_t>(blocks) * 4 / chunks;  // what the kernel derives from its grid
+  A* leak = nullptr;
+  DGLA_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&leak), sizeof(A) * slots * F, s));
+  hipLaunchKernelGGL((spmm_cmp_mask_kernel<Idx, W, DT>), dim3(blocks), dim3(256), 0, s, static_cast<const Idx*>(indptr),
+                     static_cast<const Idx*>(indices), static_cast<const Idx*>(eids), static_cast<const Idx*>(arg), by_edge,
+                     rows, static_cast<int>(F), words, static_cast<W*>(mask), static_cast<const DT*>(dz),
+                     static_cast<DT*>(dx), dx_rows, leak);
+  hipLaunchKernelGGL((spmm_cmp_leak_kernel<DT>), dim3(static_cast<unsigned>(F)), dim3(256), 0, s, leak,
+                     std::min<int64_t>(slots, rows), static_cast<int>(F), static_cast<DT*>(dx));
+  (void)hipFreeAsync(leak, s);
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" {
 
 size_t dgla_segment_reduce_workspace_bytes(const char* reduce, int idtype_bits, dgla_dtype dtype,
@@ -478,6 +623,31 @@ int dgla_spmm_cmp_backward(int idtype_bits, dgla_dtype dtype, const dgla_tensor*
   const void* od = (other && other->data) ? other->data : nullptr;
   DGLA_IDX_DTYPE_SWITCH(idtype_bits, dtype, run_spmm_cmp_backward, dz->data, arg, od, arg_other, out->data, n, dim,
                         other_len, other_group < 1 ? 1 : other_group, out->shape[0], atomic != 0, s);
+  return sfail("unsupported feature dtype");
+}
+
+int64_t dgla_spmm_cmp_mask_words(dgla_dtype dtype, int64_t feat_len) {
+  const int64_t bits = dtype == DGLA_F64 ? 64 : (dtype == DGLA_F32 ? 32 : 16);
+  return (feat_len + bits - 1) / bits;
+}
+
+int dgla_spmm_cmp_mask(const dgla_csr* csr, dgla_dtype dtype, const void* arg, int by_edge, const dgla_tensor* dz,
+                       void* mask, const dgla_tensor* dx, void* hip_stream) {
+  if (!csr) return sfail("csr is null");
+  if (csr->idtype_bits != 32 && csr->idtype_bits != 64) return sfail("idtype must be int32 or int64");
+  if (dtype < DGLA_F32 || dtype > DGLA_BF16) return sfail("unsupported feature dtype");
+  if (!dz || !dx || dz->ndim < 1 || dx->ndim < 1 || !dz->shape || !dx->shape) return sfail("dz / dx is null");
+  if (row_len(dz) != row_len(dx)) return sfail("dz and dx have different feature shapes");
+  if (dz->shape[0] != csr->num_rows) return sfail("dz must have one row per row of the CSR");
+  const int64_t F = row_len(dz);
+  if (csr->num_rows == 0 || F == 0 || dx->shape[0] == 0) return 0;
+  if (F > (1 << 20)) return sfail("feature rows too long");
+  if (!csr->indptr || (csr->nnz && !csr->indices) || !arg || !dz->data || !dx->data || (csr->nnz && !mask))
+    return sfail("csr / arg / dz / dx / mask data is null");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const DeviceGuard dev(s, dx->data);
+  DGLA_IDX_DTYPE_SWITCH(csr->idtype_bits, dtype, run_spmm_cmp_mask, csr->indptr, csr->indices, csr->data, arg, by_edge,
+                        csr->num_rows, F, mask, dz->data, dx->data, dx->shape[0], s);
   return sfail("unsupported feature dtype");
 }
 

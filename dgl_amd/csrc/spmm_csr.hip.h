@@ -49,6 +49,7 @@ struct SpmmParams {
   BcastDims bd;   // kBcGeneral
   int accumulate;
   int rhs_neg, rhs_div;  // sub / div on the add / mul instantiations
+  int rhs_mask;          // mul on kBcRhsGroup: rhs words are BIT masks, bit (k mod bits-per-word) gates output column k
   int red_min;           // min on the max instantiation
   int arg_empty;  // arg_u / arg_e of an output element no edge won: 0 (g-SpMM) or -1 (segment reduce)
   int mean;       // reduce == sum only: divide every row by max(its edge count, 1) before storing
@@ -351,6 +352,24 @@ __device__ __forceinline__ void st_sc1(T* p, T v) {
 // relations sharing a destination type, src/array/cuda/spmm_hetero.cu:150-158, fused into
 // one launch): every edge carries its relation id, and the relation's operand base pointers
 // are staged in LDS next to the column ids, so the gather loop reads (column, base) pairs.
+// Bit k (mod the word's width) of a mask word stored in a feature-typed slot (dgla_spmm_cmp_mask writes them).
+template <typename DT>
+__device__ __forceinline__ bool mask_bit(DT w, int k) {
+  if constexpr (sizeof(DT) == 2) {
+    uint16_t b;
+    __builtin_memcpy(&b, &w, 2);
+    return (b >> (k & 15)) & 1;
+  } else if constexpr (sizeof(DT) == 4) {
+    uint32_t b;
+    __builtin_memcpy(&b, &w, 4);
+    return (b >> (k & 31)) & 1;
+  } else {
+    uint64_t b;
+    __builtin_memcpy(&b, &w, 8);
+    return (b >> (k & 63)) & 1;
+  }
+}
+
 // `sub` and `div` are run-time variants of the add / mul instantiations (p.rhs_neg: l + (-r), exact;
 // p.rhs_div: l / r instead of l * r) and `accumulate` is a run-time switch of the row store — a third
 // of the code objects for wave-uniform scalar branches (round 4).
@@ -806,7 +825,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
 
   int t = t_s;
   int next_end = (t < R) ? rend[t + 1] : 0x7fffffff;
-  [[maybe_unused]] const bool rhs_neg = p.rhs_neg != 0, rhs_div = p.rhs_div != 0;
+  [[maybe_unused]] const bool rhs_neg = p.rhs_neg != 0, rhs_div = p.rhs_div != 0, rhs_mask = p.rhs_mask != 0;
 
   auto reduce_batch = [&](int e, const Batch& b) {
 #pragma unroll
@@ -826,6 +845,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
           A raw;
           if constexpr (OP == kAdd)
             raw = l + (rhs_neg ? -r : r);     // sub: l + (-r) == l - r bit for bit
+          else if constexpr (OP == kMul && BC == kBcRhsGroup)
+            // rhs_mask (dgla_spmm_csr_masked, wave-uniform): the lane's rhs word holds one bit per output column
+            // of its group; a cleared bit drops the edge for that column (a select, not a product: inf and NaN
+            // of a dropped edge must not reach the sum)
+            raw = rhs_mask ? (mask_bit<DT>(b.w[u].v[0], k0 + v) ? l : A(0)) : (rhs_div ? l / r : l * r);
           else if constexpr (OP == kMul)
             raw = rhs_div ? l / r : l * r;    // (wave-uniform)
           else
@@ -1240,6 +1264,7 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.accumulate = L.accumulate ? 1 : 0;
   p.rhs_neg = L.op == kSub ? 1 : 0;
   p.rhs_div = L.op == kDiv ? 1 : 0;
+  p.rhs_mask = L.rhs_mask ? 1 : 0;
   p.red_min = L.red == kMin ? 1 : 0;
   p.arg_empty = L.arg_empty;
   p.mean = L.mean ? 1 : 0;

@@ -251,6 +251,27 @@ int dgla_backward_segment_cmp(int idtype_bits, dgla_dtype dtype, const dgla_tens
 int dgla_spmm_cmp_backward(int idtype_bits, dgla_dtype dtype, const dgla_tensor* dz, const void* arg,
                            const dgla_tensor* other, const void* arg_other, int64_t other_group,
                            const dgla_tensor* out, int atomic, void* hip_stream);
+/* The NODE operand's max / min gradient for copy_lhs / add WITHOUT atomics — the same scatter_add_ of
+ * python/dgl/backend/pytorch/sparse.py:216-224 turned into a gather over the reverse graph, so that the result has the
+ * same bits on every run:  dX[u, k] = sum over the out-edges e = (u -> v) of [e delivered the winner of (v, k)] dZ[v, k].
+ *   dgla_spmm_cmp_mask    `csr` = the FORWARD matrix (rows = destinations); `arg` [num_rows, F] of idtype = arg_u
+ *       (by_edge = 0: the first edge of row v whose source is arg_u[v, k] gets bit k) or arg_e (by_edge != 0: the
+ *       edge whose id it names).  Writes, for every edge in the CSR's POSITION order, dgla_spmm_cmp_mask_words(dtype, F)
+ *       words of the feature type's width (16 / 32 / 64 bits), bit (k mod width) of word k / width = column k.  An
+ *       element no edge of its row claims (empty row, or nothing beat the identity: arg = 0) goes to dX[0, k] here,
+ *       exactly where the reference's scatter sends it, summed in a fixed order: `dx` must be ZEROED before this call.
+ *   dgla_spmm_csr_masked  `csr` = the REVERSE matrix (rows = sources) whose `data` maps each of ITS positions to the
+ *       forward position of the same edge (always present); `ufeat` = dZ, `mask` from above, `out` = dX with
+ *       DGLA_ACCUMULATE (the atomics above are already in it).  One merge-path launch of the g-SpMM kernel.
+ */
+int64_t dgla_spmm_cmp_mask_words(dgla_dtype dtype, int64_t feat_len);
+int dgla_spmm_cmp_mask(const dgla_csr* csr, dgla_dtype dtype, const void* arg, int by_edge, const dgla_tensor* dz,
+                       void* mask, const dgla_tensor* dx, void* hip_stream);
+size_t dgla_spmm_csr_masked_workspace_bytes(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* ufeat,
+                                            const dgla_tensor* out);
+int dgla_spmm_csr_masked(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* ufeat, const void* mask,
+                         const dgla_tensor* out, void* workspace, size_t workspace_bytes, uint32_t flags,
+                         void* hip_stream);
 
 /* ---- segment / gather matrix multiply --------------------------------------
  * Replace SegmentMM / SegmentMMBackwardB / GatherMM / GatherMMScatter<kDGLCUDA,…>
