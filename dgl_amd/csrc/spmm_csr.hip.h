@@ -1064,11 +1064,14 @@ constexpr int kFuseMaxGroups = 8;
 // On the headline graph (121 k units) every wave pays two returning device-scope atomics and a drained store
 // queue at its end: merge kernel 4.37 -> 4.51 ms against 0.053 ms for the separate kernel — measured, so large
 // graphs keep the second launch.  DGLA_SPMM_FUSE_FIXUP=0 / 1 forces either (A/B and tests; read per call).
+// LONG rows (>= 64 edges on average: a readout-like segment reduce, 15 M rows into 64 segments) keep the second
+// launch too: a row that spans hundreds of units is combined by ONE wave walking all of its slots (segment sum
+// 1.04 -> 1.23 ms, max 1.29 -> 2.24 ms with the in-kernel form; the fix-up kernel spreads that over a workgroup).
 constexpr int64_t kFuseMaxWaves = 32768;
-inline bool spmm_fuse_fixup_enabled(int64_t num_waves) {
+inline bool spmm_fuse_fixup_enabled(int64_t num_waves, int64_t rows, int64_t nnz) {
   const char* e = getenv("DGLA_SPMM_FUSE_FIXUP");
   if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-  return num_waves < kFuseMaxWaves;
+  return num_waves < kFuseMaxWaves && nnz < 64 * rows;
 }
 
 struct SpmmGeometry {
@@ -1299,7 +1302,7 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.wtab = L.efeat_tab;
   p.num_rel = L.num_rel;
   p.wave_slots = g.wave_slots;
-  p.fix_count = (g.chunks == 1 && (g.wave_slots || g.groups <= kFuseMaxGroups) && spmm_fuse_fixup_enabled(g.num_waves))
+  p.fix_count = (g.chunks == 1 && (g.wave_slots || g.groups <= kFuseMaxGroups) && spmm_fuse_fixup_enabled(g.num_waves, L.csr.num_rows, L.csr.nnz))
                     ? reinterpret_cast<unsigned*>(ws + g.off_fixcnt)
                     : nullptr;
   p.carry_row = reinterpret_cast<int64_t*>(ws + g.off_carry_row);

@@ -182,8 +182,11 @@ class NeighborSampler:
         are real.  Layer by layer (output side first) a block has D destination SLOTS + 64 SINK rows
         and D + D * fanout source slots: real picks first, then the sink rows' edges (pointing at the
         real destination nodes in turn); source slots past the block's ``num_src`` (device tensor) are
-        padding holding node 0.  Real rows are exactly what :meth:`sample_blocks` builds for the same
-        draw counter; padded / sink rows produce values nobody reads.  Returns ``(input_nodes,
+        padding holding node 0.  Real rows are built exactly as :meth:`sample_blocks` builds them (same picks
+        for the FIRST call of a fresh sampler; afterwards this method draws from its device-side counter's
+        stream, :meth:`sample_blocks` from its host-side one); padded / sink rows produce values nobody reads.
+        Every layer needs at least 64 pick slots (``slots * fanout >= 64``) — the sink rows' edges live there;
+        a smaller batch is refused.  Returns ``(input_nodes,
         num_input, output_nodes, blocks)``; ``blocks[i].num_src_valid`` / ``.num_dst_valid`` are the
         device-side counts.  Each call advances a DEVICE-side draw counter (``self.counter``), so a
         replayed graph samples fresh neighbours."""
@@ -207,6 +210,11 @@ class NeighborSampler:
         blocks = []
         for layer, fanout in enumerate(reversed(self.fanouts)):
             rng = (self.seed * 1000003) * 64 + layer
+            if seeds.shape[0] * fanout < _capi.SINK_ROWS:
+                raise _DGLError("sample_blocks_padded: %d slots x fanout %d leave fewer than %d pick slots for the "
+                                "sink rows (a block would have more destination than source slots); use at least "
+                                "%d seed slots" % (seeds.shape[0], fanout, _capi.SINK_ROWS,
+                                                   -(-_capi.SINK_ROWS // fanout)))
             indptr, src, eids = _capi.sample_neighbors_padded(csr, seeds, nv, fanout, self.replace, rng,
                                                               self.counter, prob=p)
             local, src_nodes, num_src = _capi.to_block_padded(seeds, nv, src, node_map, num_nodes=rel.num_src)

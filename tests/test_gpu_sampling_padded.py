@@ -199,3 +199,17 @@ def test_padded_blocks_aggregate_like_a_dense_reference_and_replay_in_a_hipgraph
     body()
     torch.cuda.synchronize()
     assert torch.equal(out_buf, replayed)
+
+
+def test_padded_sampler_refuses_a_batch_too_small_for_its_sink_rows(dev):
+    """slots x fanout < 64 would give a block more destination than source slots: refused with the
+    minimum batch in the message; 64 pick slots exactly are fine."""
+    import dgl_amd as dgl
+    from dgl_amd._lib import DGLAMDError
+
+    g, _ = _graph(dev, torch.int64)
+    sampler = dgl.NeighborSampler([3], seed=2)
+    with pytest.raises(DGLAMDError, match="at least 22 seed slots"):
+        sampler.sample_blocks_padded(g, torch.arange(21, device=dev))
+    inp, n_inp, out_nodes, blocks = sampler.sample_blocks_padded(g, torch.arange(22, device=dev))
+    assert blocks[0].num_dst_nodes() <= blocks[0].num_src_nodes()
