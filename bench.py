@@ -379,8 +379,21 @@ def multi_gpu(args, dev, n, e, f, rank, world, dist, spmm=None):
     # exchange: peer-mapped halo buffers written by the pack kernel (dgl_amd/peer_exchange.py; all ranks of one
     # node) unless --exchange alltoall asks for the RCCL all_to_all_single path (CPU flow tests pass spmm=...)
     use_peer = getattr(args, "exchange", "peer") == "peer" and spmm is None and dev.type == "cuda"
-    op = ShardedSpMM(sh, (f,), x_full.dtype, dev, spmm=spmm,  # spmm=None: the library's kernels
-                     chunks=max(1, int(getattr(args, "chunks", 1))), exchange="peer" if use_peer else None)
+    peer_note = None
+    try:
+        op = ShardedSpMM(sh, (f,), x_full.dtype, dev, spmm=spmm,  # spmm=None: the library's kernels
+                         chunks=max(1, int(getattr(args, "chunks", 1))), exchange="peer" if use_peer else None)
+    except Exception as e:  # noqa: BLE001
+        if not use_peer:
+            raise
+        # the peer set-up fails on EVERY rank together (dgl_amd/peer_exchange.py: agreement after each local step),
+        # e.g. a driver without dmabuf IPC or GPUs that are not peers: run the RCCL all-to-all path and say so
+        peer_note = "peer set-up failed, all_to_all_single used instead: %s" % (str(e)[:300],)
+        if rank == 0:
+            print("bench.py: WARNING: " + peer_note, file=sys.stderr, flush=True)
+        use_peer = False
+        op = ShardedSpMM(sh, (f,), x_full.dtype, dev, spmm=spmm, chunks=max(1, int(getattr(args, "chunks", 1))),
+                         exchange=None)
     x_loc = x_full[sh["rows"]].contiguous()
     out = torch.empty(sh["n_local"], f, device=dev)
 
@@ -401,7 +414,7 @@ def multi_gpu(args, dev, n, e, f, rank, world, dist, spmm=None):
     dist.all_gather_object(infos, info)
     ctx = {"g": g, "x": x_full, "out": out, "shard": sh, "op": op, "x_loc": x_loc, "edges": sh["nnz"],
            "rows": sh["n_local"], "alg_bytes": algorithmic_bytes(sh["n_local"], sh["nnz"], f),
-           "profile_in_step": False, "infos": infos, "partition_s": t_part, "exchange": "peer" if use_peer else "alltoall",
+           "profile_in_step": False, "infos": infos, "partition_s": t_part, "exchange": "peer" if use_peer else "alltoall", "exchange_note": peer_note,
            "partition_stats": stats, "step_replicated": step_replicated, "out_replicated": out_rep}
     return step, ctx
 
@@ -585,6 +598,8 @@ def main():
             result["config"]["partitioner_used"] = (ctx["partition_stats"] or {}).get(
                 "fallback", (ctx["partition_stats"] or {}).get("method", args.partitioner))
             result["config"]["exchange"] = ctx.get("exchange")
+            if ctx.get("exchange_note"):
+                result["config"]["exchange_note"] = ctx["exchange_note"]
             result["roofline"]["note"] = ("whole step, exchange included: the job's algorithmic bytes / max-over-ranks "
                                           "step time / n_gpus; `kernel` fields = rank 0's two merge launches timed alone")
             result["roofline"]["kernel_only_achieved_rank0"] = kernel_only

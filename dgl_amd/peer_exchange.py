@@ -61,6 +61,11 @@ def _gather_bytes(payload, device, group):
     return [bytes(o.cpu().numpy().tobytes()) for o in outs]
 
 
+def _err_field(err):
+    """Fixed-size status field of the set-up agreements: one flag byte + up to 200 bytes of message."""
+    return (b"\x01" if err else b"\x00") + err.encode("utf-8", "replace")[:200].ljust(200, b"\0")
+
+
 class PeerHaloExchange:
     """Same role as :class:`dgl_amd.parallel.HaloExchange` for ``ShardedSpMM``; the halo buffers belong to
     the exchange (they are what the peers write into).  ``begin_step(x_local)`` starts the push of this
@@ -101,41 +106,57 @@ class PeerHaloExchange:
         _all_to_all(t_dev, m_dev, None, None, group)
         theirs = t_dev.cpu().reshape(W, C)       # theirs[p, c] = row offset of MY block of chunk c in p's halo buffer
         # ---- allocate + export + import ------------------------------------------------------------------
+        # Every step that can fail LOCALLY (allocation, hipIpcGetMemHandle, hipIpcOpenMemHandle: a driver without
+        # dmabuf IPC, GPUs that are not peers) is followed by an agreement over the group, so that all ranks raise
+        # together — a rank that raised alone would leave the others inside the next collective — and the caller
+        # (bench.py) can fall back to the all-to-all path on every rank.
         kind = {"plain": 0, "finegrained": 1, "uncached": 2}[os.environ.get("DGLA_PEER_ALLOC", "finegrained")]
         self._halo_bytes = max(self.n_halo * self.row_bytes, 256)
         self._halo_bytes = (self._halo_bytes + 255) // 256 * 256
         self._owned = []
-        halo_ptr = self._alloc(2 * self._halo_bytes, kind)
-        flag_ptr = self._alloc(8 * C * W + 256, kind)
-        self._halo_ptr, self._flag_ptr = halo_ptr, flag_ptr
-        self._flags = _view(flag_ptr, (C * W,), torch.int64, self.device)
-        self._flags.zero_()
-        self._flags.view(C, W)[:, self.rank] = _SELF_FLAG      # nobody writes my own column: never waited for
-        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
-        torch.cuda.synchronize(self.device)
-        handles = bytearray(128)
-        buf = (ctypes.c_char * 128).from_buffer(handles)
-        check_call(LIB.dgla_ipc_export(ctypes.c_void_p(halo_ptr), ctypes.addressof(buf)))
-        check_call(LIB.dgla_ipc_export(ctypes.c_void_p(flag_ptr), ctypes.addressof(buf) + 64))
-        del buf
-        everyone = _gather_bytes(bytes(handles) + os.getpid().to_bytes(8, "little") +
-                                 self._halo_bytes.to_bytes(8, "little"), self.device, group)
         self._imported = []
+        handles = bytearray(128)
+        err = ""
+        halo_ptr = flag_ptr = 0
+        try:
+            if os.environ.get("DGLA_PEER_FAIL_RANK", "") == str(self.rank):      # fault injection for the tests
+                raise DGLAMDError("injected failure (DGLA_PEER_FAIL_RANK)")
+            halo_ptr = self._alloc(2 * self._halo_bytes, kind)
+            flag_ptr = self._alloc(8 * C * W + 256, kind)
+            self._flags = _view(flag_ptr, (C * W,), torch.int64, self.device)
+            self._flags.zero_()
+            self._flags.view(C, W)[:, self.rank] = _SELF_FLAG      # nobody writes my own column: never waited for
+            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            torch.cuda.synchronize(self.device)
+            buf = (ctypes.c_char * 128).from_buffer(handles)
+            check_call(LIB.dgla_ipc_export(ctypes.c_void_p(halo_ptr), ctypes.addressof(buf)))
+            check_call(LIB.dgla_ipc_export(ctypes.c_void_p(flag_ptr), ctypes.addressof(buf) + 64))
+            del buf
+        except Exception as e:  # noqa: BLE001 — reported to every rank below
+            err = "rank %d: %s" % (self.rank, e)
+        self._halo_ptr, self._flag_ptr = halo_ptr, flag_ptr
+        everyone = _gather_bytes(bytes(handles) + os.getpid().to_bytes(8, "little") +
+                                 self._halo_bytes.to_bytes(8, "little") + _err_field(err), self.device, group)
+        self._agree([e[144:] for e in everyone], "allocating / exporting the halo buffers")
         peer_halo, peer_flag = [0] * W, [0] * W
         # (every rank sizes its halo buffers by ITS halo: the second buffer of rank p starts peer_half[p] bytes in)
         peer_half = [int.from_bytes(everyone[p][136:144], "little") for p in range(W)]
-        for p in range(W):
-            if p == self.rank:
-                peer_halo[p], peer_flag[p] = halo_ptr, flag_ptr
-                continue
-            if int.from_bytes(everyone[p][128:136], "little") == os.getpid():
-                raise DGLAMDError("peer exchange: two ranks in one process")
-            for off, dst in ((0, peer_halo), (64, peer_flag)):
-                out = ctypes.c_void_p()
-                h = (ctypes.c_char * 64).from_buffer_copy(everyone[p][off:off + 64])
-                check_call(LIB.dgla_ipc_import(ctypes.addressof(h), ctypes.byref(out)))
-                dst[p] = int(out.value)
-                self._imported.append(int(out.value))
+        try:
+            for p in range(W):
+                if p == self.rank:
+                    peer_halo[p], peer_flag[p] = halo_ptr, flag_ptr
+                    continue
+                if int.from_bytes(everyone[p][128:136], "little") == os.getpid():
+                    raise DGLAMDError("peer exchange: two ranks in one process")
+                for off, dst in ((0, peer_halo), (64, peer_flag)):
+                    out = ctypes.c_void_p()
+                    h = (ctypes.c_char * 64).from_buffer_copy(everyone[p][off:off + 64])
+                    check_call(LIB.dgla_ipc_import(ctypes.addressof(h), ctypes.byref(out)))
+                    dst[p] = int(out.value)
+                    self._imported.append(int(out.value))
+        except Exception as e:  # noqa: BLE001
+            err = "rank %d: %s" % (self.rank, e)
+        self._agree(_gather_bytes(_err_field(err), self.device, group), "opening the peers' halo buffers")
         # ---- segment tables, one per step parity: chunk-major, destination ranks ascending ------------------
         rows, blk = [], 0
         for c in range(C):
@@ -165,6 +186,20 @@ class PeerHaloExchange:
         self._push_done = torch.cuda.Event()
         self._pending = False
         dist.barrier(group=group)   # every rank has opened every buffer before anyone writes
+
+    def _agree(self, fields, what):
+        """All ranks raise together — with every failing rank's message — when any of them failed `what`."""
+        bad = [(p, f[1:].rstrip(b"\0").decode("utf-8", "replace")) for p, f in enumerate(fields) if f[0]]
+        if bad:
+            self.close_quiet()
+            raise DGLAMDError("peer exchange: %s failed on rank(s) %s: %s" % (what, [p for p, _ in bad],
+                                                                                "; ".join(m for _, m in bad)))
+
+    def close_quiet(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def _alloc(self, nbytes, kind):
         out = ctypes.c_void_p()

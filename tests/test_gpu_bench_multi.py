@@ -43,6 +43,26 @@ def test_bench_two_ranks_on_one_gpu():
     assert 0 < line["roofline"]["frac"] < 1.5
 
 
+@pytest.mark.timeout(900)
+def test_bench_falls_back_to_all_to_all_when_the_peer_setup_fails_on_one_rank():
+    """A rank whose IPC export fails (injected: DGLA_PEER_FAIL_RANK=1) must not leave the others inside a collective:
+    every rank raises together, bench.py warns and runs the all_to_all_single path — same parity, and the JSON line
+    says which exchange ran (a driver-side multi-GPU run must not die on a node without dmabuf IPC)."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["DGLA_BENCH_BACKEND"] = "gloo"
+    env["DGLA_PEER_FAIL_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--scale", "64"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, cwd=ROOT, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert line["config"]["exchange"] == "alltoall"
+    assert "injected failure" in line["config"]["exchange_note"] and "rank(s) [1]" in line["config"]["exchange_note"]
+    assert line["parity_max_rel_err_vs_single_gpu_launch"] < 1e-5
+    assert "WARNING" in p.stderr
+
+
 @pytest.mark.timeout(300)
 def test_bench_refuses_more_ranks_than_gpus():
     import torch
