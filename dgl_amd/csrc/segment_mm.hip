@@ -787,6 +787,8 @@ struct WsParams {
   int ncg;                   // column groups (workgroups sharing a row chunk)
   int kp;                    // X3: row pitch of the planes in elements
   char* dummy;               // 512 bytes nobody reads (the held stores of a wave that holds nothing)
+  int* queue;                // one column group only: ticket of the chunk queue (zeroed per launch); NULL = static chunks
+  int qsplit;                // dynamic chunks per static one
   int* prog;                 // PIPE kernels: [chunk][wave][4] tiles STARTED by each sibling wave (zeroed per launch)
   int rot;                   // ncg > 1: 1 = sibling c starts every row at line c * nss / ncg, 0 = paced only, -1 = neither
 };
@@ -849,21 +851,39 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
   const int cg = qq % ncg;
   const bool pace = PIPE && wp.rot >= 0 && ncg > 1 && ncg <= 4;   // (rot < 0: pacing off, the words are still read)
   const int rot = (wp.rot > 0 && ncg > 1) ? cg * (((K * ES + 127) >> 7) / ncg) : 0;
-  const int nchunks = (static_cast<int>(gridDim.x) >> 3) / ncg * 8;
-  const int chunk = (qq / ncg) * 8 + xcd;
-  if (chunk >= nchunks) return;
+  // Row chunks.  Static: one contiguous share of the tiles per group of ncg sibling workgroups.  Dynamic (wp.queue, one
+  // column group only): qsplit times as many, smaller chunks handed out by a ticket — the workgroups do not run at one
+  // speed, and the HBM-bound 16-bit kernels end 2.7 % sooner (2.09 -> 2.03 ms at 10 M x 256 x 256).  With sibling
+  // column groups (fp32, wide N) a shared queue was built too (the first sibling drew, the others read a write-once
+  // log) and changed nothing (8.07-8.20 against 8.04-8.15 ms): those keep the static split, and no spin.
+  const int ngroups = (static_cast<int>(gridDim.x) >> 3) / ncg * 8;
+  const int group = (qq / ncg) * 8 + xcd;
+  if (group >= ngroups) return;
+  const int nchunks = wp.queue ? ngroups * wp.qsplit : ngroups;
+  __shared__ int s_chunk;
   const int64_t T = tile_off[p.num_rel];
-  const int64_t t0 = uniform64(T * chunk / nchunks), t1 = uniform64(T * (chunk + 1) / nchunks);
   const int n0 = cg * 32 * NJ;
 
   const char* __restrict__ A = static_cast<const char*>(p.a);
   DT* __restrict__ C = static_cast<DT*>(p.c);
   typedef typename WsFrag<typename std::conditional<X3, bf16_t, DT>::type>::type frag_t;
 
-  int64_t t = t0;
-  int started = 0;       // tiles this wave has started, across the relations of its chunk
+  int started = 0;       // tiles this wave has started, across all of its group's chunks
   bool gave_up = false;
-  int* const pw = wp.prog + (static_cast<int64_t>(chunk) * kWsWaves + wave) * 4;
+  int* const pw = wp.prog + (static_cast<int64_t>(group) * kWsWaves + wave) * 4;
+  for (int gen = 0;; ++gen) {
+  int chunk = group;
+  if (wp.queue) {
+    __syncthreads();  // everybody has read the previous s_chunk
+    if (tid == 0) s_chunk = __hip_atomic_fetch_add(wp.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    chunk = s_chunk;
+  } else if (gen > 0) {
+    break;
+  }
+  if (chunk >= nchunks) break;
+  const int64_t t0 = uniform64(T * chunk / nchunks), t1 = uniform64(T * (chunk + 1) / nchunks);
+  int64_t t = t0;
   while (t < t1) {
     const int64_t rel = uniform64(find_segment(tile_off, p.num_rel, t));
     const int64_t rel_t0 = uniform64(tile_off[rel]);
@@ -1249,6 +1269,7 @@ if constexpr (PIPE) {
     }
     t = rel_end;
   }
+  }  // chunks
 }
 
 // fp64 (and any shape the MFMA path does not take): one thread per output element.
@@ -1518,6 +1539,8 @@ __global__ __launch_bounds__(256) void gather_mm_kernel(const DT* __restrict__ a
 // ---- host side ------------------------------------------------------------------------------
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 constexpr size_t kWsProgWords = 16 * 1024;  // >= row chunks (<= CUs) x 8 waves x 4 words
+constexpr int kWsQueueSplit = 8;            // dynamic chunks per group (chunk queue of the weights-stationary kernels)
+constexpr size_t kWsQueueWords = 64;         // the queue's ticket, on a line of its own
 
 struct MmScratch {
   size_t off_plan, off_t32, off_prog, off_bt, off_planes, off_acc, total;
@@ -1532,7 +1555,7 @@ MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool ne
   s.off_t32 = off;
   if (forward) off = align256(off + sizeof(int64_t) * (num_rel + 1));
   s.off_prog = off;  // pacing words of the weights-stationary kernel: [row chunk][wave][column group]
-  if (forward) off = align256(off + sizeof(int) * kWsProgWords + 1024);  // (+ the dummy line of the held stores)
+  if (forward) off = align256(off + sizeof(int) * (kWsProgWords + kWsQueueWords) + 1024);  // (+ chunk queue, + the dummy line of the held stores)
   s.off_bt = off;
   if (need_bt) off = align256(off + static_cast<size_t>(num_rel) * K * N * elem);
   s.off_planes = off;  // fp32 forward: the weights as three bf16 planes (weights-stationary kernel)
@@ -1629,6 +1652,8 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
   wp.kp = 0;
   wp.prog = nullptr;
   wp.dummy = nullptr;
+  wp.queue = nullptr;
+  wp.qsplit = kWsQueueSplit;
   wp.rot = 0;
   const int N = p.N;
   int cus = mm_num_cus();
@@ -1637,9 +1662,17 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
   }
   cus = std::min(cus, 512);
   const dim3 block(64 * kWsWaves);
-  // experiment switch (round 4 A/B): bit 0 = fp32 without the fragment double buffer, bit 2 = siblings unpaced, bit 3 = paced but every sibling walks the lines in order
+  // experiment switch (round 4 A/B): bit 0 = fp32 without the fragment double buffer, bit 2 = siblings unpaced, bit 3 = paced but every sibling walks the lines in order, bit 4 = static row chunks (no queue)
   const char* ev = getenv("DGLA_MM_WS_VARIANT");
   const int variant = ev && *ev ? atoi(ev) : 0;
+  // chunk queue (one column group only; variant bit 4 = static chunks): one ticket word, zeroed per launch
+  auto arm_queue = [&](int ncg) -> int {
+    if ((variant & 16) || ncg != 1) return 0;
+    int* q = reinterpret_cast<int*>(ws + sc.off_prog) + kWsProgWords;
+    DGLA_CHECK_HIP(hipMemsetAsync(q, 0, sizeof(int) * 64, s));
+    wp.queue = q;
+    return 0;
+  };
   if constexpr (sizeof(DT) == 4) {
     // fp32: three bf16 planes of the weights, once per call; 64 columns per workgroup
     wp.kp = (p.K + 7) / 8 * 8;
@@ -1656,10 +1689,11 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
     const dim3 grid(static_cast<unsigned>(groups * wp.ncg * 8));
     // (the PIPE kernels read their pacing words whether they pace or not: always there, always zeroed)
     wp.prog = reinterpret_cast<int*>(ws + sc.off_prog);
-    wp.dummy = ws + sc.off_prog + sizeof(int) * kWsProgWords;
+    wp.dummy = ws + sc.off_prog + sizeof(int) * (kWsProgWords + kWsQueueWords);
     wp.rot = (variant & 4) ? -1 : (variant & 8) ? 0 : 1;
     static_assert(kWsProgWords >= 64 * 8 * kWsWaves * 4, "pacing words for up to 512 workgroups");
     DGLA_CHECK_HIP(hipMemsetAsync(wp.prog, 0, sizeof(int) * groups * 8 * kWsWaves * 4, s));
+    if (int rc = arm_queue(wp.ncg)) return rc;
     // PIPE needs every k-step whole and rounds of exactly 4 lines: K a multiple of 128 floats' worth of lines
     const bool pipe = p.K % 32 == 0 && (p.K / 32) % 4 == 0 && !(variant & 1);
 #define DGLA_WS3(NJV)                                                                                       \
@@ -1683,6 +1717,7 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
     wp.ncg = (N + 32 * nj - 1) / (32 * nj);
     const int groups = std::max(1, cus / 8 / wp.ncg);
     const dim3 grid(static_cast<unsigned>(groups * wp.ncg * 8));
+    if (int rc = arm_queue(wp.ncg)) return rc;
 #define DGLA_WS(NJV)                                                                                   \
   do {                                                                                                 \
     if (p.row_index)                                                                                   \
