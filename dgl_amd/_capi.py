@@ -287,6 +287,11 @@ def spmm_cmp_mask_words(dtype, feat_len):
     return int(LIB.dgla_spmm_cmp_mask_words(_DTYPES[dtype], int(feat_len)))
 
 
+def spmm_cmp_mask_bytes(dtype, num_rows, nnz, feat_len):
+    """Size of the `mask` buffer of :func:`spmm_cmp_mask` (edge words + the pass's partial sums)."""
+    return int(LIB.dgla_spmm_cmp_mask_bytes(_DTYPES[dtype], int(num_rows), int(nnz), int(feat_len)))
+
+
 def spmm_cmp_mask(csr, arg, dz, mask, dx, by_edge=False):
     """Winner bits of a max / min g-SpMM over the FORWARD matrix `csr` (dgla_spmm_cmp_mask): for every edge in
     position order, one bit per output column; elements no edge claims go to ``dx[arg]`` here (``dx`` zeroed by

@@ -117,6 +117,8 @@ LIB.dgla_spmm_cmp_backward.argtypes = [c_int, c_int, P(Tensor), c_void_p, P(Tens
                                        c_int, c_void_p]
 LIB.dgla_spmm_cmp_mask_words.restype = c_int64
 LIB.dgla_spmm_cmp_mask_words.argtypes = [c_int, c_int64]
+LIB.dgla_spmm_cmp_mask_bytes.restype = c_size_t
+LIB.dgla_spmm_cmp_mask_bytes.argtypes = [c_int, c_int64, c_int64, c_int64]
 LIB.dgla_spmm_cmp_mask.restype = c_int
 LIB.dgla_spmm_cmp_mask.argtypes = [P(CSR), c_int, c_void_p, c_int, P(Tensor), c_void_p, P(Tensor), c_void_p]
 LIB.dgla_spmm_csr_masked_workspace_bytes.restype = c_size_t

@@ -131,8 +131,7 @@ def _cmp_backward_node_gather(gidx, dZ, arg_u, rows):
         cache["ws"] = {}
     dz2 = dZ.reshape(dZ.shape[0], feat)
     dX = torch.zeros(rows, feat, dtype=dZ.dtype, device=dZ.device)
-    words = _capi.spmm_cmp_mask_words(dZ.dtype, feat)
-    mask = torch.empty(n_edges, words, dtype=dZ.dtype, device=dZ.device)
+    mask = torch.empty(_capi.spmm_cmp_mask_bytes(dZ.dtype, dZ.shape[0], n_edges, feat), dtype=torch.uint8, device=dZ.device)
     _capi.spmm_cmp_mask(cache["fwd"], arg_u.reshape(arg_u.shape[0], feat).contiguous(), dz2, mask, dX)
     key = (dZ.dtype, feat)
     ws = cache["ws"].get(key)

@@ -480,28 +480,39 @@ __global__ __launch_bounds__(256) void spmm_cmp_leak_kernel(const typename Acc<D
   if (threadIdx.x == 0) dx[k] = from_acc<DT>(to_acc<DT>(dx[k]) + part[0]);
 }
 
+// Launch shape of the mask kernel: every wave keeps ONE 64-column chunk; at most 8192 waves.
+struct CmpMaskShape {
+  int64_t chunks, slots;
+  unsigned blocks;
+};
+inline CmpMaskShape cmp_mask_shape(int64_t rows, int64_t F) {
+  CmpMaskShape m;
+  m.chunks = (F + 63) / 64;
+  int64_t slots = std::min<int64_t>(rows, std::max<int64_t>(1, 8192 / m.chunks));
+  m.blocks = static_cast<unsigned>((slots * m.chunks + 3) / 4);
+  m.slots = static_cast<int64_t>(m.blocks) * 4 / m.chunks;  // what the kernel derives from its grid
+  return m;
+}
+inline size_t cmp_mask_align(size_t x) { return (x + 255) / 256 * 256; }
+
 template <typename Idx, typename DT>
 int run_spmm_cmp_mask(const void* indptr, const void* indices, const void* eids, const void* arg, int by_edge,
-                      int64_t rows, int64_t F, void* mask, const void* dz, void* dx, int64_t dx_rows, hipStream_t s) {
+                      int64_t rows, int64_t nnz, int64_t F, void* mask, const void* dz, void* dx, int64_t dx_rows,
+                      hipStream_t s) {
   typedef typename std::conditional<sizeof(DT) == 2, uint16_t, typename std::conditional<sizeof(DT) == 4, uint32_t, uint64_t>::type>::type W;
   using A = typename Acc<DT>::type;
   const int bits = 8 * static_cast<int>(sizeof(W));
   const int words = static_cast<int>((F + bits - 1) / bits);
-  const int64_t chunks = (F + 63) / 64;
-  // waves: a whole number of chunk groups (every wave keeps ONE chunk), at most 8192 of them
-  int64_t slots = std::min<int64_t>(rows, std::max<int64_t>(1, 8192 / chunks));
-  int64_t waves = slots * chunks;
-  const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
-  slots = static_cast<int64_t>(blocks) * 4 / chunks;  // what the kernel derives from its grid
-  A* leak = nullptr;
-  DGLA_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&leak), sizeof(A) * slots * F, s));
-  hipLaunchKernelGGL((spmm_cmp_mask_kernel<Idx, W, DT>), dim3(blocks), dim3(256), 0, s, static_cast<const Idx*>(indptr),
+  const CmpMaskShape m = cmp_mask_shape(rows, F);
+  // the per-slot partial sums of unclaimed elements live BEHIND the mask words in the caller's buffer
+  // (dgla_spmm_cmp_mask_bytes): no allocation in here, so the call can be captured in a hipGraph
+  A* leak = reinterpret_cast<A*>(static_cast<char*>(mask) + cmp_mask_align(sizeof(W) * static_cast<size_t>(nnz) * words));
+  hipLaunchKernelGGL((spmm_cmp_mask_kernel<Idx, W, DT>), dim3(m.blocks), dim3(256), 0, s, static_cast<const Idx*>(indptr),
                      static_cast<const Idx*>(indices), static_cast<const Idx*>(eids), static_cast<const Idx*>(arg), by_edge,
                      rows, static_cast<int>(F), words, static_cast<W*>(mask), static_cast<const DT*>(dz),
                      static_cast<DT*>(dx), dx_rows, leak);
   hipLaunchKernelGGL((spmm_cmp_leak_kernel<DT>), dim3(static_cast<unsigned>(F)), dim3(256), 0, s, leak,
-                     std::min<int64_t>(slots, rows), static_cast<int>(F), static_cast<DT*>(dx));
-  (void)hipFreeAsync(leak, s);
+                     std::min<int64_t>(m.slots, rows), static_cast<int>(F), static_cast<DT*>(dx));
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -631,6 +642,15 @@ int64_t dgla_spmm_cmp_mask_words(dgla_dtype dtype, int64_t feat_len) {
   return (feat_len + bits - 1) / bits;
 }
 
+size_t dgla_spmm_cmp_mask_bytes(dgla_dtype dtype, int64_t num_rows, int64_t nnz, int64_t feat_len) {
+  if (dtype < DGLA_F32 || dtype > DGLA_BF16 || num_rows < 0 || nnz < 0 || feat_len <= 0) return 0;
+  const size_t wsize = dtype == DGLA_F64 ? 8 : (dtype == DGLA_F32 ? 4 : 2);
+  const size_t asize = dtype == DGLA_F64 ? 8 : 4;  // accumulator type of the partial sums
+  const CmpMaskShape m = cmp_mask_shape(num_rows > 0 ? num_rows : 1, feat_len);
+  return cmp_mask_align(wsize * static_cast<size_t>(nnz) * dgla_spmm_cmp_mask_words(dtype, feat_len)) +
+         asize * static_cast<size_t>(m.slots) * feat_len;
+}
+
 int dgla_spmm_cmp_mask(const dgla_csr* csr, dgla_dtype dtype, const void* arg, int by_edge, const dgla_tensor* dz,
                        void* mask, const dgla_tensor* dx, void* hip_stream) {
   if (!csr) return sfail("csr is null");
@@ -642,12 +662,12 @@ int dgla_spmm_cmp_mask(const dgla_csr* csr, dgla_dtype dtype, const void* arg, i
   const int64_t F = row_len(dz);
   if (csr->num_rows == 0 || F == 0 || dx->shape[0] == 0) return 0;
   if (F > (1 << 20)) return sfail("feature rows too long");
-  if (!csr->indptr || (csr->nnz && !csr->indices) || !arg || !dz->data || !dx->data || (csr->nnz && !mask))
+  if (!csr->indptr || (csr->nnz && !csr->indices) || !arg || !dz->data || !dx->data || !mask)
     return sfail("csr / arg / dz / dx / mask data is null");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const DeviceGuard dev(s, dx->data);
   DGLA_IDX_DTYPE_SWITCH(csr->idtype_bits, dtype, run_spmm_cmp_mask, csr->indptr, csr->indices, csr->data, arg, by_edge,
-                        csr->num_rows, F, mask, dz->data, dx->data, dx->shape[0], s);
+                        csr->num_rows, csr->nnz, F, mask, dz->data, dx->data, dx->shape[0], s);
   return sfail("unsupported feature dtype");
 }
 

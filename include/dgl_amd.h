@@ -265,6 +265,9 @@ int dgla_spmm_cmp_backward(int idtype_bits, dgla_dtype dtype, const dgla_tensor*
  *       DGLA_ACCUMULATE (the atomics above are already in it).  One merge-path launch of the g-SpMM kernel.
  */
 int64_t dgla_spmm_cmp_mask_words(dgla_dtype dtype, int64_t feat_len);
+/* bytes of `mask`: the words of every edge + the mask pass's own partial sums behind them (no allocation inside the
+ * call: it can be captured in a hipGraph) */
+size_t dgla_spmm_cmp_mask_bytes(dgla_dtype dtype, int64_t num_rows, int64_t nnz, int64_t feat_len);
 int dgla_spmm_cmp_mask(const dgla_csr* csr, dgla_dtype dtype, const void* arg, int by_edge, const dgla_tensor* dz,
                        void* mask, const dgla_tensor* dx, void* hip_stream);
 size_t dgla_spmm_csr_masked_workspace_bytes(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* ufeat,

@@ -204,10 +204,12 @@ def test_mask_kernel_by_edge_and_long_rows(dev):
     dz = torch.randn(rows, f, device=dev, generator=gen)
     dx = torch.zeros(30, f, device=dev)
     words = _capi.spmm_cmp_mask_words(torch.float32, f)
-    mask = torch.full((e, words), float("nan"), device=dev)
+    nbytes = _capi.spmm_cmp_mask_bytes(torch.float32, rows, e, f)
+    assert nbytes >= e * words * 4
+    mask = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device=dev)
     csr = _capi.make_csr(indptr, indices, eids, 30)
     _capi.spmm_cmp_mask(csr, arg_e, dz, mask, dx, by_edge=True)
-    bits = mask.view(torch.int32).cpu().numpy().astype("uint32")
+    bits = mask[: e * words * 4].view(torch.int32).reshape(e, words).cpu().numpy().astype("uint32")
     import numpy as np
     want = np.zeros((e, words), dtype="uint32")
     posc, degc = pos.cpu().numpy(), deg.cpu().numpy()
