@@ -221,3 +221,40 @@ def test_mask_kernel_by_edge_and_long_rows(dev):
     assert (bits == want).all()
     # nothing claimed in the empty row only: its dz went to dx[0]
     assert torch.equal(dx[0], dz[3]) and float(dx[1:].abs().max()) == 0.0
+
+
+def test_gather_backward_replays_inside_a_hipgraph(dev):
+    """copy_u_max forward + backward captured in ONE hipGraph (no allocation, no read-back inside the two backward
+    kernels): replays give the eager gradient for new inputs."""
+    import dgl_amd as dgl
+
+    n, e = 500, 6000
+    g, src, dst = _graph(dev, n, e, torch.int32, seed=21)
+    x = torch.randn(n, 20, device=dev, requires_grad=True)
+    up = torch.randn(n, 20, device=dev)
+    for _ in range(2):   # warm-up: formats, position map, workspaces
+        x.grad = None
+        dgl.ops.copy_u_max(g, x).backward(up)
+    torch.cuda.synchronize()
+    sx, sup = torch.randn(n, 20, device=dev, requires_grad=True), torch.randn(n, 20, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            sx.grad = None
+            dgl.ops.copy_u_max(g, sx).backward(sup)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    sx.grad = None
+    with torch.cuda.graph(graph):
+        dgl.ops.copy_u_max(g, sx).backward(sup)
+    for seed in (1, 2):
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        with torch.no_grad():
+            sx.copy_(torch.randn(n, 20, device=dev, generator=gen))
+            sup.copy_(torch.randn(n, 20, device=dev, generator=gen))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = sx.grad.clone()
+        ex = sx.detach().clone().requires_grad_()
+        dgl.ops.copy_u_max(g, ex).backward(sup)
+        assert torch.equal(got, ex.grad)
