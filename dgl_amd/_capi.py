@@ -169,14 +169,18 @@ def _ws_args(workspace, plan_valid):
             _lib.DGLA_PLAN_VALID if plan_valid else 0)
 
 
-def edge_softmax_forward(csr, score, out, workspace=None, plan_valid=False):
+def edge_softmax_forward(csr, score, out, workspace=None, plan_valid=False, out_position=False):
     """`workspace` (uint8 tensor of edge_softmax_workspace_bytes) selects the degree-balanced
-    merge-path kernels; None runs the scratch-free lane-group kernel."""
+    merge-path kernels; None runs the scratch-free lane-group kernel.  `out_position` (merge-path only):
+    scores are read through the CSR's edge-id map, `out` is written in position order
+    (DGLA_ESM_OUT_POSITION)."""
     keep = []
     ts, to = _tensor(score, keep), _tensor(out, keep)
+    wp, wn, fl = _ws_args(workspace, plan_valid)
+    if out_position:
+        fl |= _lib.DGLA_ESM_OUT_POSITION
     check_call(LIB.dgla_edge_softmax_forward(ctypes.byref(csr), _DTYPES[out.dtype],
-                                             ctypes.byref(ts), ctypes.byref(to),
-                                             *_ws_args(workspace, plan_valid), _stream(out)))
+                                             ctypes.byref(ts), ctypes.byref(to), wp, wn, fl, _stream(out)))
 
 
 def edge_softmax_backward(csr, out, sds, back, workspace=None, plan_valid=False):

@@ -44,7 +44,7 @@ int launch_stream_copy(void*, const void*, size_t, int, hipStream_t);
 int launch_spmm_coo(const CooView&, int, int, int, const void*, const void*, void*, void*, void*,
                     int64_t, int64_t, int64_t, bool, const BcastDims&, hipStream_t);
 int launch_edge_softmax(const CsrView&, int, const void*, const void*, void*, int64_t, bool,
-                        void*, size_t, bool, hipStream_t);
+                        void*, size_t, bool, hipStream_t, bool out_pos = false);
 size_t edge_softmax_workspace_bytes(int64_t, int64_t, int, int64_t);
 
 static int fail(const std::string& msg) {
@@ -729,7 +729,7 @@ int dgla_edge_softmax_forward(const dgla_csr* csr, dgla_dtype dtype, const dgla_
   const DeviceGuard dev(static_cast<hipStream_t>(hip_stream), out->data);
   return launch_edge_softmax(v, dtype, score->data, nullptr, out->data, feat_len(score), false,
                              workspace, workspace_bytes, (flags & DGLA_PLAN_VALID) != 0,
-                             static_cast<hipStream_t>(hip_stream));
+                             static_cast<hipStream_t>(hip_stream), (flags & DGLA_ESM_OUT_POSITION) != 0);
 }
 
 int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* out,

@@ -209,6 +209,7 @@ struct EsmParams {
   int vec4;  // fp32, dim % 4 == 0 == padded width, 16-byte aligned operands: rows move as 16-byte pieces
   int xcd;   // units in XCD-contiguous order (kTuneXcd): neighbouring units share an L2
   int region_bytes;  // LDS bytes of the tables / row-transposition slices in front of the rest
+  int out_pos;       // forward: `c` is written in POSITION order (DGLA_ESM_OUT_POSITION) while `a` is read through eids
   int64_t* carry_row;  // [num_units] row continued in the next unit, or -1
   void* carry_stat;    // [num_units, 2 * dim] accumulators: (m | s) forward, (sum | -) backward
   void* tail_stat;     // [num_units, 2 * dim]
@@ -881,6 +882,9 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
     if (e >= u.nE) continue;
     const bool partial = e < tail_end || e >= carry_begin;
     if (partial) continue;  // written by the fix-up kernel, which knows the whole row's statistics
+    // store offset: the edge's id like the loads, or its position (scores gathered in, softmax handed on in
+    // position order: one pass instead of a gather pass in front of a map-free softmax)
+    const int64_t so = (!BWD && p.out_pos) ? (u.j0 + e) * dim : off[j];
     bool done = false;
     if constexpr (std::is_same<DT, float>::value && HP >= 4) {
       if (p.vec4) {
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
         for (int q = 0; q < HP / 4; ++q) {
           f32x4 t;
           t.x = v[j][4 * q], t.y = v[j][4 * q + 1], t.z = v[j][4 * q + 2], t.w = v[j][4 * q + 3];
-          *reinterpret_cast<f32x4*>(pc + off[j] + 4 * q) = t;
+          *reinterpret_cast<f32x4*>(pc + so + 4 * q) = t;
         }
         done = true;
       }
@@ -897,7 +901,7 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
     if (!done) {
 #pragma unroll
       for (int h = 0; h < HP; ++h)
-        if (h < dim) pc[off[j] + h] = from_acc<DT>(v[j][h]);
+        if (h < dim) pc[so + h] = from_acc<DT>(v[j][h]);
     }
   }
 }
@@ -998,11 +1002,12 @@ __device__ __forceinline__ void edge_softmax_fixup_boundary(const EsmParams<Idx>
         }
         for (int64_t tb = t0 + slot; tb < t1; tb += per * kFixU) {
           f32x4 xc[kFixU];
-          int64_t off[kFixU];
+          int64_t off[kFixU], so[kFixU];
 #pragma unroll
           for (int k = 0; k < kFixU; ++k) {
             const int64_t j = tb + k * per < t1 ? tb + k * per : tb;
             off[k] = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + 4 * q;
+            so[k] = p.out_pos ? j * dim + 4 * q : off[k];
           }
 #pragma unroll
           for (int k = 0; k < kFixU; ++k) xc[k] = ld4(fa + off[k]);
@@ -1012,7 +1017,7 @@ __device__ __forceinline__ void edge_softmax_fixup_boundary(const EsmParams<Idx>
               f32x4 o;
 #pragma unroll
               for (int c = 0; c < 4; ++c) o[c] = esm_expx<float, PRECISE>(xc[k][c] - M[c]) * inv[c];
-              *reinterpret_cast<f32x4*>(fc + off[k]) = o;
+              *reinterpret_cast<f32x4*>(fc + so[k]) = o;
             }
         }
       }
@@ -1060,18 +1065,19 @@ __device__ __forceinline__ void edge_softmax_fixup_boundary(const EsmParams<Idx>
       // costs what re-reading an un-normalised output would, and the main kernel saves the write)
       const A inv = esm_recip<A>(S);
       for (int64_t tb = t0 + (lane >> p.log2_hp); tb < t1; tb += es * kFixU) {
-        int64_t off[kFixU];
+        int64_t off[kFixU], so[kFixU];
         A xc[kFixU];
 #pragma unroll
         for (int k = 0; k < kFixU; ++k) {
           const int64_t j = tb + k * es < t1 ? tb + k * es : tb;
           off[k] = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + h;
+          so[k] = p.out_pos ? j * dim + h : off[k];
         }
 #pragma unroll
         for (int k = 0; k < kFixU; ++k) xc[k] = to_acc<DT>(pa[off[k]]);
 #pragma unroll
         for (int k = 0; k < kFixU; ++k)
-          if (tb + k * es < t1) pc[off[k]] = from_acc<DT>(esm_expx<A, PRECISE>(xc[k] - M) * inv);
+          if (tb + k * es < t1) pc[so[k]] = from_acc<DT>(esm_expx<A, PRECISE>(xc[k] - M) * inv);
       }
     }
   }
@@ -1132,7 +1138,7 @@ constexpr int kEsmMaxDim = 16;
 template <typename Idx, typename DT>
 static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void* b, void* c,
                                   int dim, bool backward, void* ws, bool plan_valid,
-                                  hipStream_t s) {
+                                  hipStream_t s, bool out_pos) {
   using A = typename Acc<DT>::type;
   const EsmGeometry g = esm_geometry(csr.num_rows, csr.nnz, dim, sizeof(A));
   char* wsp = static_cast<char*>(ws);
@@ -1155,6 +1161,7 @@ static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void*
               (!backward || al(b))) ? 1 : 0;
   }
   p.xcd = (tuning_flags() & kTuneXcd) ? 1 : 0;
+  p.out_pos = (out_pos && !backward && csr.eids) ? 1 : 0;
   p.carry_row = reinterpret_cast<int64_t*>(wsp + g.off_carry_row);
   p.carry_stat = wsp + g.off_carry_stat;
   p.tail_stat = wsp + g.off_tail_stat;
@@ -1246,15 +1253,19 @@ static int edge_softmax_run(const CsrView& csr, const void* a, const void* b, vo
 
 int launch_edge_softmax(const CsrView& csr, int dtype, const void* a, const void* b, void* c,
                         int64_t dim, bool backward, void* ws, size_t ws_bytes, bool plan_valid,
-                        hipStream_t s) {
+                        hipStream_t s, bool out_pos) {
   const int d = static_cast<int>(dim);
   const size_t need = edge_softmax_workspace_bytes(csr.num_rows, csr.nnz, dtype, dim);
   const bool merge = need > 0 && ws != nullptr && ws_bytes >= need;
+  if (out_pos && (!merge || backward)) {
+    last_error() = "DGLA_ESM_OUT_POSITION: forward only, and only with the merge-path kernels (workspace given, feature length <= 16)";
+    return -1;
+  }
 #define DGLA_ES(DT)                                                                          \
   if (merge)                                                                                 \
     return csr.idbits == 32                                                                  \
-               ? edge_softmax_merge_run<int32_t, DT>(csr, a, b, c, d, backward, ws, plan_valid, s) \
-               : edge_softmax_merge_run<int64_t, DT>(csr, a, b, c, d, backward, ws, plan_valid, s); \
+               ? edge_softmax_merge_run<int32_t, DT>(csr, a, b, c, d, backward, ws, plan_valid, s, out_pos) \
+               : edge_softmax_merge_run<int64_t, DT>(csr, a, b, c, d, backward, ws, plan_valid, s, out_pos); \
   return csr.idbits == 32 ? edge_softmax_run<int32_t, DT>(csr, a, b, c, d, backward, s)     \
                           : edge_softmax_run<int64_t, DT>(csr, a, b, c, d, backward, s)
   switch (dtype) {

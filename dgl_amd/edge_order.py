@@ -587,6 +587,29 @@ def softmax_pos_forward(rel, score):
     return out
 
 
+def softmax_gather_pos_forward(rel, score, edge_map):
+    """Edge softmax of EDGE-ID-ordered scores, result in position order, in ONE pass: the merge-path kernel reads
+    through the CSC's edge-id map and writes by position (DGLA_ESM_OUT_POSITION) — instead of a gather pass in front
+    of the map-free softmax.  None when the shape has no merge-path kernel (long feature rows): the caller
+    falls back to gather + softmax."""
+    dim = 1
+    for d in score.shape[1:]:
+        dim *= int(d)
+    if not rel.num_edges or not score.numel():
+        return None
+    c = _ctx(rel)
+    if not int(_capi.edge_softmax_workspace_bytes(c["csr"], score.dtype, dim)):
+        return None          # no merge-path kernel for this (feature length, dtype)
+    if "csr_map" not in c:
+        indptr, indices, _ = rel.csc()
+        c["csr_map"] = _capi.make_csr(indptr, indices, edge_map, rel.num_src)
+    _, ent = _esm_ws(rel, score)          # the plan depends on indptr only: shared with the map-free calls
+    out = torch.empty_like(score)
+    _capi.edge_softmax_forward(c["csr_map"], score, out, ent[0], plan_valid=ent[1], out_position=True)
+    ent[1] = True
+    return out
+
+
 def softmax_pos_backward(rel, out, sds):
     back = torch.empty_like(out)
     if rel.num_edges and out.numel():
@@ -719,10 +742,15 @@ class PosEdgeSoftmax(torch.autograd.Function):
         s = raw(score)
         s, expand = _unsq(s)
         s = s.contiguous()
+        out = None
         if not tagged:
             m = rel.csc()[2]
-            s = s if m is None else _capi.gather_rows(s, m)
-        out = softmax_pos_forward(rel, s)
+            if m is not None:
+                out = softmax_gather_pos_forward(rel, s, m)
+                if out is None:
+                    s = _capi.gather_rows(s, m)
+        if out is None:
+            out = softmax_pos_forward(rel, s)
         ctx.rel, ctx.tagged, ctx.expand = rel, tagged, expand
         ctx.save_for_backward(out)
         return wrap(out.squeeze(-1) if expand else out, rel)

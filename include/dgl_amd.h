@@ -58,6 +58,7 @@ typedef enum { DGLA_F32 = 0, DGLA_F64 = 1, DGLA_F16 = 2, DGLA_BF16 = 3 } dgla_dt
                               DGLA_SPLIT_KEEP) made of THIS ufeat, whose contents have not
                               changed since: the re-layout copy is skipped.  Needs
                               DGLA_PLAN_VALID.  Never set it for a tensor you do not own. */
+#define DGLA_ESM_OUT_POSITION 128u /* dgla_edge_softmax_forward: see there */
 #define DGLA_PREPARE_ONLY 32u /* (with DGLA_SPLIT_KEEP) build the merge plan if needed and make the side copy of
                               ufeat's ragged row ends — nothing else: no output is written.  For the PRODUCER of
                               ufeat (the previous layer's epilogue, a feature loader): it prepares the operand on
@@ -200,6 +201,9 @@ int dgla_sddmm_csr(const char* op, const dgla_csr* csr, dgla_dtype dtype,
  *              hub rows cost no more than any other 256 edges; without it (NULL / 0) a
  *              row-per-lane-group kernel needing no scratch is used.  DGLA_PLAN_VALID in
  *              `flags`: the workspace still holds the plan of an earlier call on this csr.
+ *   DGLA_ESM_OUT_POSITION (forward, merge-path kernels only): `score` is read by edge id through the CSR's map as
+ *              ever, `out` is written in the CSR's POSITION order — the hand-off to a consumer that runs map-free
+ *              (dgl_amd/edge_order.py) in one pass instead of a gather pass in front of a map-free softmax.
  */
 size_t dgla_edge_softmax_workspace_bytes(const dgla_csr* csr, dgla_dtype dtype, int64_t dim);
 int dgla_edge_softmax_forward(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* score,

@@ -229,3 +229,47 @@ def test_explicit_gradient_and_inplace_sources_on_the_real_kernels(dev):
             dgl.set_edge_order_handoff(True)
     for x, y, what in zip(res[True], res[False], ("attention", "copy_", "setitem", "backward(grad)", "grad(grad_outputs)")):
         torch.testing.assert_close(x, y, rtol=2e-5, atol=2e-6, msg=lambda m: what + ": " + m)
+
+
+def mapped_of(indptr, indices, eids, n):
+    from dgl_amd import _capi
+    return _capi.make_csr(indptr, indices, eids, n)
+
+
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(1,), (3,), (8,), (4, 4), (16,)])
+def test_softmax_reads_by_edge_id_and_writes_by_position_in_one_pass(dev, idtype, dtype, shape):
+    """DGLA_ESM_OUT_POSITION: the merge-path softmax over a CSC WITH an edge-id map, output in position order ==
+    gather_rows through the map followed by the map-free softmax, bit for bit — rows cut by unit boundaries (a hub of
+    60 k in-edges: the fix-up kernel's path), empty rows, every vector width of the kernel."""
+    from dgl_amd import _capi
+
+    n, e = 3000, 200000
+    g0 = torch.Generator().manual_seed(12)
+    src = torch.randint(0, n, (e,), generator=g0)
+    dst = torch.randint(n // 8, n, (e,), generator=g0)
+    dst[: 60000] = n - 3
+    indptr, indices, eids = _capi.coo_to_csr(dst.to(dev).to(idtype), src.to(dev).to(idtype), None, n, n)
+    assert eids is not None and not torch.equal(eids.long(), torch.arange(e, device=dev))
+    score = (torch.randn((e,) + shape, device=dev) * 3).to(dtype)
+    dim = 1
+    for d in shape:
+        dim *= d
+    plain = _capi.make_csr(indptr, indices, None, n)
+    mapped = _capi.make_csr(indptr, indices, eids, n)
+    need = int(_capi.edge_softmax_workspace_bytes(plain, dtype, dim))
+    if need == 0:   # no merge-path kernel for this shape (fp64 with 16 columns): the flag is refused
+        with pytest.raises(Exception, match="DGLA_ESM_OUT_POSITION"):
+            _capi.edge_softmax_forward(mapped_of(indptr, indices, eids, n), score, torch.empty_like(score), None,
+                                       out_position=True)
+        return
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    want = torch.empty_like(score)
+    _capi.edge_softmax_forward(plain, _capi.gather_rows(score, eids), want, ws)
+    got = torch.full_like(score, float("nan"))
+    _capi.edge_softmax_forward(mapped, score, got, ws, plan_valid=True, out_position=True)
+    assert torch.equal(got, want)
+    # and the flag is refused where it cannot be honoured
+    with pytest.raises(Exception, match="DGLA_ESM_OUT_POSITION"):
+        _capi.edge_softmax_forward(mapped, score, got, None, out_position=True)
