@@ -183,13 +183,17 @@ def edge_softmax_forward(csr, score, out, workspace=None, plan_valid=False, out_
                                              ctypes.byref(ts), ctypes.byref(to), wp, wn, fl, _stream(out)))
 
 
-def edge_softmax_backward(csr, out, sds, back, workspace=None, plan_valid=False):
+def edge_softmax_backward(csr, out, sds, back, workspace=None, plan_valid=False, sds_is_grad=False):
+    """`sds_is_grad` (merge-path kernels only): `sds` is the upstream gradient itself, the product with `out` is
+    formed inside the kernel (DGLA_ESM_B_IS_GRAD)."""
     keep = []
     to, ts, tb = _tensor(out, keep), _tensor(sds, keep), _tensor(back, keep)
+    wp, wn, fl = _ws_args(workspace, plan_valid)
+    if sds_is_grad:
+        fl |= _lib.DGLA_ESM_B_IS_GRAD
     check_call(LIB.dgla_edge_softmax_backward(ctypes.byref(csr), _DTYPES[out.dtype],
                                               ctypes.byref(to), ctypes.byref(ts),
-                                              ctypes.byref(tb), *_ws_args(workspace, plan_valid),
-                                              _stream(back)))
+                                              ctypes.byref(tb), wp, wn, fl, _stream(back)))
 
 
 def stream_copy(dst, src):

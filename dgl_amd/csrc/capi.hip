@@ -44,7 +44,7 @@ int launch_stream_copy(void*, const void*, size_t, int, hipStream_t);
 int launch_spmm_coo(const CooView&, int, int, int, const void*, const void*, void*, void*, void*,
                     int64_t, int64_t, int64_t, bool, const BcastDims&, hipStream_t);
 int launch_edge_softmax(const CsrView&, int, const void*, const void*, void*, int64_t, bool,
-                        void*, size_t, bool, hipStream_t, bool out_pos = false);
+                        void*, size_t, bool, hipStream_t, bool out_pos = false, bool b_is_grad = false);
 size_t edge_softmax_workspace_bytes(int64_t, int64_t, int, int64_t);
 
 static int fail(const std::string& msg) {
@@ -748,7 +748,7 @@ int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla
   const DeviceGuard dev(static_cast<hipStream_t>(hip_stream), back->data);
   return launch_edge_softmax(v, dtype, out->data, sds->data, back->data, feat_len(out), true,
                              workspace, workspace_bytes, (flags & DGLA_PLAN_VALID) != 0,
-                             static_cast<hipStream_t>(hip_stream));
+                             static_cast<hipStream_t>(hip_stream), false, (flags & DGLA_ESM_B_IS_GRAD) != 0);
 }
 
 int dgla_set_tuning(uint32_t flags) {

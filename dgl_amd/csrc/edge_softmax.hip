@@ -210,6 +210,7 @@ struct EsmParams {
   int xcd;   // units in XCD-contiguous order (kTuneXcd): neighbouring units share an L2
   int region_bytes;  // LDS bytes of the tables / row-transposition slices in front of the rest
   int out_pos;       // forward: `c` is written in POSITION order (DGLA_ESM_OUT_POSITION) while `a` is read through eids
+  int b_is_grad;     // backward: `b` holds the upstream gradient g, not out * g (DGLA_ESM_B_IS_GRAD): the product is formed here
   int64_t* carry_row;  // [num_units] row continued in the next unit, or -1
   void* carry_stat;    // [num_units, 2 * dim] accumulators: (m | s) forward, (sum | -) backward
   void* tail_stat;     // [num_units, 2 * dim]
@@ -430,6 +431,12 @@ __device__ __forceinline__ int esm_swz(int i) { return i ^ ((i >> 4) & 15); }
 constexpr int kEsmEpl = kEsmItems / kEsmThreads;
 static_assert(kEsmEpl == 4, "the sweeps below are written out for four edges per lane");
 
+// accumulator value rounded to what a DT store + load would give back (fp32 / fp64: itself)
+template <typename DT>
+__device__ __forceinline__ typename Acc<DT>::type esm_round(typename Acc<DT>::type v) {
+  return to_acc<DT>(from_acc<DT>(v));
+}
+
 template <typename Idx, typename DT, bool BWD, bool PRECISE, int HP>
 __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1 : 4) void edge_softmax_merge_kernel(const EsmParams<Idx> p) {
   using A = typename Acc<DT>::type;
@@ -633,6 +640,17 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
           v[j][h] = BWD ? A(0) : -static_cast<A>(__builtin_huge_valf());
           if constexpr (BWD) v2[j][h] = A(0);
         }
+  }
+
+  if constexpr (BWD) {
+    if (p.b_is_grad) {
+      // b = the upstream gradient: form sds = out * g here (rounded to the storage type, as the separate elementwise
+      // kernel of python/dgl/backend/pytorch/sparse.py:709-713 leaves it) instead of reading a product somebody wrote
+#pragma unroll
+      for (int j = 0; j < kEsmEpl; ++j)
+#pragma unroll
+        for (int h = 0; h < HP; ++h) v[j][h] = esm_round<DT>(v[j][h] * v2[j][h]);
+    }
   }
 
   // segment bounds
@@ -975,7 +993,10 @@ __device__ __forceinline__ void edge_softmax_fixup_boundary(const EsmParams<Idx>
             off[k] = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + 4 * q;
           }
 #pragma unroll
-          for (int k = 0; k < kFixU; ++k) xb[k] = ld4(fb + off[k]), xa[k] = ld4(fa + off[k]);
+          for (int k = 0; k < kFixU; ++k) {
+            xb[k] = ld4(fb + off[k]), xa[k] = ld4(fa + off[k]);
+            if (p.b_is_grad) xb[k] = xb[k] * xa[k];
+          }
 #pragma unroll
           for (int k = 0; k < kFixU; ++k)
             if (tb + k * per < t1) *reinterpret_cast<f32x4*>(fc + off[k]) = xb[k] - sum * xa[k];
@@ -1043,6 +1064,7 @@ __device__ __forceinline__ void edge_softmax_fixup_boundary(const EsmParams<Idx>
         for (int k = 0; k < kFixU; ++k) {
           xb[k] = to_acc<DT>(pb[off[k]]);
           xa[k] = to_acc<DT>(pa[off[k]]);
+          if (p.b_is_grad) xb[k] = esm_round<DT>(xb[k] * xa[k]);
         }
 #pragma unroll
         for (int k = 0; k < kFixU; ++k)
@@ -1138,7 +1160,7 @@ constexpr int kEsmMaxDim = 16;
 template <typename Idx, typename DT>
 static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void* b, void* c,
                                   int dim, bool backward, void* ws, bool plan_valid,
-                                  hipStream_t s, bool out_pos) {
+                                  hipStream_t s, bool out_pos, bool b_is_grad) {
   using A = typename Acc<DT>::type;
   const EsmGeometry g = esm_geometry(csr.num_rows, csr.nnz, dim, sizeof(A));
   char* wsp = static_cast<char*>(ws);
@@ -1162,6 +1184,7 @@ static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void*
   }
   p.xcd = (tuning_flags() & kTuneXcd) ? 1 : 0;
   p.out_pos = (out_pos && !backward && csr.eids) ? 1 : 0;
+  p.b_is_grad = (b_is_grad && backward) ? 1 : 0;
   p.carry_row = reinterpret_cast<int64_t*>(wsp + g.off_carry_row);
   p.carry_stat = wsp + g.off_carry_stat;
   p.tail_stat = wsp + g.off_tail_stat;
@@ -1253,10 +1276,14 @@ static int edge_softmax_run(const CsrView& csr, const void* a, const void* b, vo
 
 int launch_edge_softmax(const CsrView& csr, int dtype, const void* a, const void* b, void* c,
                         int64_t dim, bool backward, void* ws, size_t ws_bytes, bool plan_valid,
-                        hipStream_t s, bool out_pos) {
+                        hipStream_t s, bool out_pos, bool b_is_grad) {
   const int d = static_cast<int>(dim);
   const size_t need = edge_softmax_workspace_bytes(csr.num_rows, csr.nnz, dtype, dim);
   const bool merge = need > 0 && ws != nullptr && ws_bytes >= need;
+  if (b_is_grad && (!merge || !backward)) {
+    last_error() = "DGLA_ESM_B_IS_GRAD: backward only, and only with the merge-path kernels (workspace given, feature length <= 16)";
+    return -1;
+  }
   if (out_pos && (!merge || backward)) {
     last_error() = "DGLA_ESM_OUT_POSITION: forward only, and only with the merge-path kernels (workspace given, feature length <= 16)";
     return -1;
@@ -1264,8 +1291,8 @@ int launch_edge_softmax(const CsrView& csr, int dtype, const void* a, const void
 #define DGLA_ES(DT)                                                                          \
   if (merge)                                                                                 \
     return csr.idbits == 32                                                                  \
-               ? edge_softmax_merge_run<int32_t, DT>(csr, a, b, c, d, backward, ws, plan_valid, s, out_pos) \
-               : edge_softmax_merge_run<int64_t, DT>(csr, a, b, c, d, backward, ws, plan_valid, s, out_pos); \
+               ? edge_softmax_merge_run<int32_t, DT>(csr, a, b, c, d, backward, ws, plan_valid, s, out_pos, b_is_grad) \
+               : edge_softmax_merge_run<int64_t, DT>(csr, a, b, c, d, backward, ws, plan_valid, s, out_pos, b_is_grad); \
   return csr.idbits == 32 ? edge_softmax_run<int32_t, DT>(csr, a, b, c, d, backward, s)     \
                           : edge_softmax_run<int64_t, DT>(csr, a, b, c, d, backward, s)
   switch (dtype) {

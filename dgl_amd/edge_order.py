@@ -619,6 +619,25 @@ def softmax_pos_backward(rel, out, sds):
     return back
 
 
+def softmax_pos_backward_from_grad(rel, out, grad):
+    """grad_score = out * grad - out * sum_row(out * grad) from the UPSTREAM gradient: the merge-path kernel forms
+    the product itself (DGLA_ESM_B_IS_GRAD; same bits as multiplying first, one elementwise pass less); shapes
+    without a merge-path kernel multiply first."""
+    if not rel.num_edges or not out.numel():
+        return torch.empty_like(out)
+    dim = 1
+    for d in out.shape[1:]:
+        dim *= int(d)
+    c = _ctx(rel)
+    if not int(_capi.edge_softmax_workspace_bytes(c["csr"], out.dtype, dim)):
+        return softmax_pos_backward(rel, out, (out * grad).contiguous())
+    back = torch.empty_like(out)
+    csr, ent = _esm_ws(rel, out)
+    _capi.edge_softmax_backward(csr, out, grad.contiguous(), back, ent[0], plan_valid=ent[1], sds_is_grad=True)
+    ent[1] = True
+    return back
+
+
 # ---------------------------------------------------------------------------------------------
 # differentiable operators in position space
 # ---------------------------------------------------------------------------------------------
@@ -762,7 +781,7 @@ class PosEdgeSoftmax(torch.autograd.Function):
         g = raw(grad_out)
         if ctx.expand:
             g = g.unsqueeze(-1)
-        back = softmax_pos_backward(rel, out, (out * g).contiguous())
+        back = softmax_pos_backward_from_grad(rel, out, g.to(out.dtype))
         if not ctx.tagged:
             m = rel.csc()[2]
             if m is not None:

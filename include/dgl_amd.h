@@ -59,6 +59,7 @@ typedef enum { DGLA_F32 = 0, DGLA_F64 = 1, DGLA_F16 = 2, DGLA_BF16 = 3 } dgla_dt
                               changed since: the re-layout copy is skipped.  Needs
                               DGLA_PLAN_VALID.  Never set it for a tensor you do not own. */
 #define DGLA_ESM_OUT_POSITION 128u /* dgla_edge_softmax_forward: see there */
+#define DGLA_ESM_B_IS_GRAD 256u    /* dgla_edge_softmax_backward: see there */
 #define DGLA_PREPARE_ONLY 32u /* (with DGLA_SPLIT_KEEP) build the merge plan if needed and make the side copy of
                               ufeat's ragged row ends — nothing else: no output is written.  For the PRODUCER of
                               ufeat (the previous layer's epilogue, a feature loader): it prepares the operand on
@@ -204,6 +205,9 @@ int dgla_sddmm_csr(const char* op, const dgla_csr* csr, dgla_dtype dtype,
  *   DGLA_ESM_OUT_POSITION (forward, merge-path kernels only): `score` is read by edge id through the CSR's map as
  *              ever, `out` is written in the CSR's POSITION order — the hand-off to a consumer that runs map-free
  *              (dgl_amd/edge_order.py) in one pass instead of a gather pass in front of a map-free softmax.
+ *   DGLA_ESM_B_IS_GRAD (backward, merge-path kernels only): `sds` holds the upstream gradient g itself; the product
+ *              out * g of python/dgl/backend/pytorch/sparse.py:709-713 is formed inside the kernel (rounded to the
+ *              storage type as the separate elementwise kernel leaves it: same bits, 6 bytes per element less traffic).
  */
 size_t dgla_edge_softmax_workspace_bytes(const dgla_csr* csr, dgla_dtype dtype, int64_t dim);
 int dgla_edge_softmax_forward(const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* score,

@@ -273,3 +273,42 @@ def test_softmax_reads_by_edge_id_and_writes_by_position_in_one_pass(dev, idtype
     # and the flag is refused where it cannot be honoured
     with pytest.raises(Exception, match="DGLA_ESM_OUT_POSITION"):
         _capi.edge_softmax_forward(mapped, score, got, None, out_position=True)
+
+
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(1,), (3,), (8,), (4, 4)])
+def test_softmax_backward_forms_out_times_grad_inside_the_kernel(dev, idtype, dtype, shape):
+    """DGLA_ESM_B_IS_GRAD: backward(out, g) with the flag == backward(out, out * g) without it, bit for bit (the
+    product is rounded to the storage type exactly as torch's elementwise kernel leaves it) — map-free CSC (the
+    transposing fast path), CSC with an edge-id map, a hub row through the fix-up kernel."""
+    from dgl_amd import _capi
+
+    n, e = 3000, 200000
+    g0 = torch.Generator().manual_seed(13)
+    src = torch.randint(0, n, (e,), generator=g0)
+    dst = torch.randint(n // 8, n, (e,), generator=g0)
+    dst[: 60000] = n - 3
+    indptr, indices, eids = _capi.coo_to_csr(dst.to(dev).to(idtype), src.to(dev).to(idtype), None, n, n)
+    dim = 1
+    for d in shape:
+        dim *= d
+    for m in (None, eids):
+        csr = _capi.make_csr(indptr, indices, m, n)
+        need = int(_capi.edge_softmax_workspace_bytes(csr, dtype, dim))
+        if need == 0:
+            continue
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        score = (torch.randn((e,) + shape, device=dev) * 2).to(dtype)
+        out = torch.empty_like(score)
+        _capi.edge_softmax_forward(csr, score, out, ws)
+        g = torch.randn((e,) + shape, device=dev).to(dtype)
+        want, got = torch.empty_like(out), torch.full_like(out, float("nan"))
+        _capi.edge_softmax_backward(csr, out, (out * g).contiguous(), want, ws, plan_valid=True)
+        _capi.edge_softmax_backward(csr, out, g, got, ws, plan_valid=True, sds_is_grad=True)
+        assert torch.equal(got, want)
+    # no workspace = the lane-group kernel: the flag is refused
+    score = torch.randn((e,) + shape, device=dev).to(dtype)
+    with pytest.raises(Exception, match="DGLA_ESM_B_IS_GRAD"):
+        _capi.edge_softmax_backward(_capi.make_csr(indptr, indices, None, n), score, score, torch.empty_like(score), None,
+                                    sds_is_grad=True)
