@@ -53,8 +53,11 @@ __device__ __forceinline__ void atomic_add_elem(T* p, T v) {
 // 16-bit storage: compare-and-swap on the enclosing aligned 32-bit word
 template <typename T>
 __device__ __forceinline__ void atomic_add_16(T* p, float v) {
+  // (an explicit GLOBAL pointer: through uintptr_t the address space is lost and the compiler emits flat loads and
+  // flat atomics, which count in both vmcnt and lgkmcnt — tools/isa_audit.py listed them)
+  typedef __attribute__((address_space(1))) uint32_t gword_t;
   const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-  uint32_t* word = reinterpret_cast<uint32_t*>(a & ~uintptr_t(3));
+  gword_t* word = (gword_t*)(a & ~uintptr_t(3));
   const int shift = (a & 2) ? 16 : 0;
   uint32_t old = *word;
   while (true) {
@@ -65,9 +68,9 @@ __device__ __forceinline__ void atomic_add_16(T* p, float v) {
     uint16_t nb;
     __builtin_memcpy(&nb, &nv, 2);
     const uint32_t want = (old & ~(0xffffu << shift)) | (static_cast<uint32_t>(nb) << shift);
-    const uint32_t seen = atomicCAS(word, old, want);
-    if (seen == old) break;
-    old = seen;
+    // (on failure `old` is replaced by the value seen)
+    if (__hip_atomic_compare_exchange_strong(word, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      break;
   }
 }
 template <>

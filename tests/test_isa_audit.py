@@ -59,3 +59,11 @@ def test_matrix_multiply_and_softmax_kernels_have_no_flat_or_stray_scratch():
     assert all(c["flat"] == 0 for c in esm.values())
     # one 8-byte spill pair in the fp32 8-head forward kernel is known and harmless; anything more is a regression
     assert sum(c["scratch"] for c in esm.values()) <= 8
+
+
+def test_segment_kernels_reach_memory_through_global_instructions_only():
+    """segment.o (segment reduce glue, scatter add, max / min backward, winner masks): the 16-bit atomic add is a
+    compare-and-swap on the enclosing word — through a plain pointer it compiled to flat loads and flat atomics
+    (both counters, conservative waits); it now names the global address space."""
+    seg = _stats("segment.o")
+    assert seg and all(c["flat"] == 0 and c["scratch"] == 0 for c in seg.values())
