@@ -614,7 +614,7 @@ def edge_order(dev, args):
             emit(tag, "edge_softmax fwd + bwd via API, random edge-id map, hand-off %s" % ("ON" if on else "off"),
                  e, ms, mn, nb_fb)
             del xg, up
-        dgl.set_edge_order_handoff(True)
+        dgl.set_edge_order_handoff(False)
         # the GAT forward layer (H = 8) and one training step of it
         for d in (8, 32):
             ft = torch.randn(n, h, d, device=dev)
@@ -649,7 +649,7 @@ def edge_order(dev, args):
                 ms, mn = timeit(train, reps=10, warm=3)
                 emit(tag, "GATConv forward + backward H=8 D=%d via API, random edge-id map, hand-off %s" % (d, "ON" if on else "off"),
                      e, ms, mn, 3 * nb)
-            dgl.set_edge_order_handoff(True)
+            dgl.set_edge_order_handoff(False)
             del ft, el, er
         del g, dg, dg0, rel, rel0, x
 

@@ -21,7 +21,7 @@ from .mm import gather_mm, segment_mm  # noqa: E402,F401
 from .segment import scatter_add, segment_reduce, segment_softmax  # noqa: E402,F401
 from .sparse_kernels import release_static, set_auto_edge_operand, static_features  # noqa: E402,F401
 
-from .edge_order import set_edge_order_handoff  # noqa: E402,F401
+from .edge_order import edge_order_handoff, set_edge_order_handoff  # noqa: E402,F401
 from .capture import CapturedStep  # noqa: E402,F401
 
 DGLError = DGLAMDError

@@ -189,7 +189,10 @@ int run_update_grad_minmax(const void* feat, const void* idx, const void* idx_ty
 // broadcast forms "leading dims then ones" and "ones then trailing dims").  One pass over dz where the
 // reference makes four (two .long() casts, a gather, a scatter_add_).
 //   ATOMIC = false: the target is the EDGE operand — an edge has one destination, so (arg[i, k], k) is
-//                   written at most once: plain stores, deterministic;
+//                   written at most once: plain stores, deterministic.  The ONE ambiguous target is row 0:
+//                   the forward records arg = 0 for every destination without in-edges, so edge 0 can be
+//                   named by many rows; row 0 therefore ADDS (out is zero-filled), exactly the reference's
+//                   scatter_add_ — the empty rows contribute their dz (0 after update_all's inf -> 0);
 //   ATOMIC = true:  the target is the NODE operand — a source node can win at many destinations, the
 //                   sum over them is a hardware float atomic (as the reference's scatter_add_ / its
 //                   UpdateGradMinMaxHeteroKernel, segment_reduce.cuh:73-92).
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void spmm_cmp_backward_kernel(
       const DT o = other[wo * other_len + (k / group) % other_len];
       g = from_acc<DT>(to_acc<DT>(g) * to_acc<DT>(o));
     }
-    if constexpr (ATOMIC)
+    if (ATOMIC || w == 0)
       atomic_add_elem<DT>(out + w * dim + k, g);
     else
       out[w * dim + k] = g;

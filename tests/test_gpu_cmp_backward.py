@@ -69,6 +69,64 @@ def test_edge_operand_path_is_deterministic_and_exact(dev, idtype):
     assert torch.equal(outs[0], want)
 
 
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+def test_edge_operand_row0_is_shared_with_empty_destinations(dev, idtype):
+    """the forward records arg_e = 0 for every destination WITHOUT in-edges, so edge 0 is named
+    by its real winner AND by every empty row.  The reference adds (scatter_add_, sparse.py:217-244): row 0 of the
+    edge gradient = the winner's dz + the empty rows' dz, on every run (no store race)."""
+    from dgl_amd import _capi
+
+    n, e, f = 4096, 9000, 8
+    g = torch.Generator(device=dev).manual_seed(11)
+    dz = torch.randn(n, f, device=dev, generator=g)
+    arg = (torch.arange(n, device=dev).unsqueeze(1) * 2 + 1).expand(n, f).clone()     # injective, never 0
+    arg[7] = 0                                                                        # edge 0 wins row 7, every column
+    empty = torch.arange(n, device=dev) % 5 == 3                                      # ~ 800 empty rows: arg 0
+    arg[empty] = 0
+    arg = arg.to(idtype).contiguous()
+    want = torch.zeros(e, f, device=dev, dtype=torch.float64).scatter_add_(0, arg.long(), dz.double())
+    outs = []
+    for _ in range(3):
+        out = torch.zeros(e, f, device=dev)
+        _capi.spmm_cmp_backward(dz, arg, out, None, None, 1, atomic=False)
+        outs.append(out)
+    for out in outs:
+        assert torch.equal(out[1:], want[1:].float())                                 # single writers: exact
+        torch.testing.assert_close(out[0].double(), want[0], rtol=1e-5, atol=1e-4)    # the shared row: the sum
+    # what update_all produces (empty rows' dz = 0 after inf -> 0): row 0 is exactly the true winner's gradient
+    dz0 = torch.where(empty.unsqueeze(1), torch.zeros_like(dz), dz)
+    out = torch.zeros(e, f, device=dev)
+    _capi.spmm_cmp_backward(dz0, arg, out, None, None, 1, atomic=False)
+    assert torch.equal(out[0], dz[7])
+
+
+def test_autograd_edge_gradient_with_isolated_destinations_and_edge0_winning(dev):
+    """End to end: u_mul_e_max on a graph whose rows 0..49 have no in-edges and where edge id 0 wins; dW[0] must be
+    the true winner's gradient on every run (it used to race with the empty rows' zero stores)."""
+    import dgl_amd as dgl
+
+    n, e = 200, 3000
+    g0 = torch.Generator().manual_seed(5)
+    src = torch.randint(0, n, (e,), generator=g0)
+    dst = torch.randint(50, n, (e,), generator=g0)
+    g = dgl.graph((src.to(dev), dst.to(dev)), num_nodes=n, idtype=torch.int32, device=dev)
+    x = (torch.rand(n, 6, generator=g0) + 1).to(dev)
+    w0 = (torch.rand(e, 6, generator=g0) + 1)
+    w0[0] = 100.0                                                                       # edge 0 wins all its columns
+    up = torch.randn(n, 6, generator=g0).to(dev)
+    grads = []
+    for _ in range(4):
+        w = w0.clone().to(dev).requires_grad_()
+        out = dgl.ops.u_mul_e_max(g, x, w)
+        out = torch.where(torch.isinf(out), torch.zeros_like(out), out)
+        (out * up).sum().backward()
+        grads.append(w.grad)
+    want0 = up[dst[0]] * x[src[0]]
+    for gr in grads:
+        torch.testing.assert_close(gr[0], want0, rtol=1e-6, atol=1e-6)
+        assert torch.equal(gr, grads[0])
+
+
 def test_autograd_max_min_backward_runs_on_the_library_kernel(dev, monkeypatch):
     """dgl.ops.copy_u_max / u_mul_e_min gradients == a dense torch evaluation, and the library entry is the
     one that ran."""

@@ -120,14 +120,20 @@ def test_c3_edge_softmax_forward_plain_bar(dev, c3):
     ref = oracle.edge_softmax_fwd(ip, ei, _h(score).reshape(c3["e"], HEADS))
     err = max_rel_err(_h(a).reshape(ref.shape), ref)
     assert err <= 1e-5, "edge softmax forward: plain max rel err vs the oracle %.3g" % err
-    # and through the public operator with the position-ordered hand-off on (what GATConv users run)
+    # and through the public operator default (plain) and with the opt-in position-ordered hand-off
     import dgl_amd as dgl
     from dgl_amd import edge_order as E
 
     g = dgl.graph((c3["src"], c3["dst"]), num_nodes=c3["n"], idtype=torch.int32, device=dev)
-    got = E.to_eid_order(dgl.edge_softmax(g, score))
+    got = dgl.edge_softmax(g, score)
+    assert type(got) is torch.Tensor                              # default: plain edge-id order
     err = max_rel_err(_h(got).reshape(ref.shape), ref)
     assert err <= 1e-5, "dgl.edge_softmax: plain max rel err vs the oracle %.3g" % err
+    with dgl.edge_order_handoff():                                # opt-in hand-off: same values
+        got = dgl.edge_softmax(g, score)
+    assert type(got) is E.PosOrdered
+    err = max_rel_err(_h(E.to_eid_order(got)).reshape(ref.shape), ref)
+    assert err <= 1e-5, "dgl.edge_softmax (hand-off): plain max rel err vs the oracle %.3g" % err
 
 
 @pytest.mark.parametrize("d", [8, 32])

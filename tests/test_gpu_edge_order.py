@@ -61,7 +61,7 @@ def test_gat_pipeline_handoff_equals_plain_path(dev, idtype, heads, d):
             (out * up).sum().backward()
             res[on] = (out.detach(), E.to_eid_order(a).detach(), el.grad, er.grad, ft.grad)
         finally:
-            dgl.set_edge_order_handoff(True)
+            dgl.set_edge_order_handoff(False)
     for x, y, what in zip(res[True], res[False], ("out", "attention", "d el", "d er", "d ft")):
         torch.testing.assert_close(x, y, rtol=2e-5, atol=2e-6, msg=lambda m: what + ": " + m)
     # and the plain path itself against a dense evaluation of the same layer (independent check)
@@ -88,25 +88,26 @@ def test_user_visible_values_are_edge_id_ordered(dev):
     el, er = torch.randn(n, 4, 1, device=dev), torch.randn(n, 4, 1, device=dev)
     src, dst = g.edges()
     want = el[src.long()] + er[dst.long()]
-    got = dgl.ops.u_add_v(g, el, er)
+    assert type(dgl.ops.u_add_v(g, el, er)) is torch.Tensor        # the default: plain tensors, as the reference
+    with dgl.edge_order_handoff():
+        got = dgl.ops.u_add_v(g, el, er)
     assert type(got) is E.PosOrdered and got.shape == want.shape
+    assert not E.handoff_enabled()
     assert torch.equal(got.cpu(), want.cpu())
     assert torch.equal(got[torch.tensor([5, 0, e_cnt - 1], device=dev)], want[[5, 0, e_cnt - 1]])
     assert torch.equal(got + torch.zeros_like(want), want)
     assert torch.equal(torch.as_tensor(got.cpu().numpy()), want.cpu())
     mask = torch.rand(e_cnt, 1, 1, device=dev) > 0.5
     assert torch.equal(got * mask, want * mask)
-    sm = dgl.edge_softmax(g, got)
-    dgl.set_edge_order_handoff(False)
-    try:
-        sm_plain = dgl.edge_softmax(g, want)
-    finally:
-        dgl.set_edge_order_handoff(True)
+    sm = dgl.edge_softmax(g, got)             # a tag that arrives is honoured outside the scope too
+    sm_plain = dgl.edge_softmax(g, want)
     assert type(sm) is E.PosOrdered and type(sm_plain) is torch.Tensor
     torch.testing.assert_close(sm.eid_order(), sm_plain, rtol=1e-6, atol=1e-8)
     # a tagged tensor of ANOTHER graph with the same shape is not mistaken for this graph's layout
     g2 = _graph(dev, n=500, e=6000, seed=4)
-    other = dgl.ops.u_add_v(g2, el, er)
+    with dgl.edge_order_handoff():
+        other = dgl.ops.u_add_v(g2, el, er)
+    assert type(other) is E.PosOrdered
     out = dgl.ops.copy_e_sum(g, other)
     s2, d2 = g2.edges()
     # (fp64 reference: an fp32 index_add_ runs on atomics in a different order every time, and with
@@ -151,7 +152,7 @@ def test_edge_softmax_standalone_and_with_mask(dev, plain_in):
                 (out * up).sum().backward()
                 res[on] = (out.detach(), el.grad, er.grad, ft.grad)
         finally:
-            dgl.set_edge_order_handoff(True)
+            dgl.set_edge_order_handoff(False)
     for x, y in zip(res[True], res[False]):
         torch.testing.assert_close(x, y, rtol=2e-5, atol=2e-6)
 
@@ -180,7 +181,7 @@ def test_u_dot_v_attention_and_1d_features(dev):
             o1.sum().backward()
             res[on] = (out.detach(), qq.grad, kk.grad, vv.grad, o1.detach(), x1.grad)
         finally:
-            dgl.set_edge_order_handoff(True)
+            dgl.set_edge_order_handoff(False)
     for x, y in zip(res[True], res[False]):
         torch.testing.assert_close(x, y, rtol=5e-5, atol=5e-6)
 
@@ -226,7 +227,7 @@ def test_explicit_gradient_and_inplace_sources_on_the_real_kernels(dev):
             (g2,) = torch.autograd.grad(dgl.edge_softmax(g, F.leaky_relu(s, 0.2)), s, grad_outputs=gy)
             res[on] = (E.to_eid_order(a).detach(), buf, frame, s.grad.clone(), g2)
         finally:
-            dgl.set_edge_order_handoff(True)
+            dgl.set_edge_order_handoff(False)
     for x, y, what in zip(res[True], res[False], ("attention", "copy_", "setitem", "backward(grad)", "grad(grad_outputs)")):
         torch.testing.assert_close(x, y, rtol=2e-5, atol=2e-6, msg=lambda m: what + ": " + m)
 
