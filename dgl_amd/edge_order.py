@@ -593,7 +593,7 @@ _TARGET = {"u": 0, "e": 1, "v": 2}
 
 def wants_handoff(rel):
     """Should an operator on `rel` START a hand-off (produce a tagged tensor)?"""
-    if not _ENABLED[0] or rel.transient or not rel.allowed("csc") or rel.num_edges < max(MIN_EDGES, 1):
+    if not handoff_enabled() or rel.transient or not rel.allowed("csc") or rel.num_edges < max(MIN_EDGES, 1):
         return False
     if not rel.device.type == "cuda":
         return False

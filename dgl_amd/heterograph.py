@@ -14,11 +14,14 @@ import torch
 
 from . import function as fn
 from . import ops
+from . import udf as _udf
 from ._lib import DGLAMDError
 from .graph_index import GraphIndex, Relation
 
 __all__ = ["DGLGraph", "graph", "heterograph", "rand_graph", "rand_bipartite", "create_block",
-           "reverse"]
+           "reverse", "to_homogeneous", "to_heterogeneous", "from_networkx", "NID", "EID", "NTYPE", "ETYPE"]
+
+NID, EID, NTYPE, ETYPE = "_ID", "_ID", "_TYPE", "_TYPE"   # python/dgl/base.py:14-17
 
 
 class _Frame(dict):
@@ -79,6 +82,13 @@ class _TypedView(MutableMapping):
 class _TypeIndexer:
     def __init__(self, g, kind):
         self._g, self._kind = g, kind
+
+    def __call__(self, ntype=None):
+        """``g.nodes()`` / ``g.srcnodes()`` / ``g.dstnodes()``: the node ids of one type."""
+        g = self._g
+        tid = {"node": g.get_ntype_id, "srcnode": g.get_ntype_id_from_src,
+               "dstnode": g.get_ntype_id_from_dst}[self._kind](ntype)
+        return torch.arange(g._graph.num_nodes(tid), dtype=g.idtype, device=g.device)
 
     def __getitem__(self, key):
         g = self._g
@@ -348,13 +358,55 @@ class DGLGraph:
                         [self._edge_frames[et]], [0], [1])
 
     # ---- message passing -----------------------------------------------------------------
+    def _ids(self, x):
+        """Node / edge ids given as int, list or tensor -> 1-D tensor in the graph's idtype on its device."""
+        if isinstance(x, torch.Tensor):
+            t = x.to(device=self.device, dtype=self.idtype)
+        else:
+            t = torch.as_tensor(x, dtype=self.idtype, device=self.device)
+        return t.reshape(-1)
+
+    def _set_n_repr(self, ntid, rows, data):
+        """Write columns of node type ``ntid``: whole columns (``rows`` None) or the given rows — missing
+        columns start from the zero initializer, rows are written out of place (frame.update_row)."""
+        frame = self._node_frames[ntid]
+        for k, v in data.items():
+            if rows is None:
+                frame[k] = v
+            else:
+                col = frame.get(k)
+                if col is None or col.shape[1:] != v.shape[1:] or col.dtype != v.dtype:
+                    col = torch.zeros((frame.num_rows,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+                frame[k] = col.index_copy(0, rows.long(), v)
+
+    def _set_e_repr(self, etid, rows, data):
+        frame = self._edge_frames[etid]
+        for k, v in data.items():
+            if rows is None:
+                frame[k] = v
+            else:
+                col = frame.get(k)
+                if col is None or col.shape[1:] != v.shape[1:] or col.dtype != v.dtype:
+                    col = torch.zeros((frame.num_rows,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+                frame[k] = col.index_copy(0, rows.long(), v)
+
+    def apply_nodes(self, func, v=None, ntype=None):
+        """Update node features with a user-defined function (python/dgl/heterograph.py:4533-4595)."""
+        ntid = self.get_ntype_id(ntype)
+        rows = None if v is None else self._ids(v)
+        self._set_n_repr(ntid, rows, _udf.invoke_node_udf(self, func, ntid, nodes=rows))
+
     def apply_edges(self, func, edges=None, etype=None):
         """Write ``func`` of the end points / edge features of every edge into ``edata``
-        (python/dgl/heterograph.py:4597-4712, built-in functions only)."""
-        if edges is not None:
-            raise DGLAMDError("apply_edges on an edge subset is outside the accelerated path")
-        _require_builtin(func)
+        (python/dgl/heterograph.py:4597-4712).  Built-in functions run the g-SDDMM kernels, any other
+        callable is invoked on an :class:`dgl_amd.udf.EdgeBatch`."""
+        builtin = _udf.is_builtin(func)
         if etype is None and len(self._canonical_etypes) > 1:
+            if not builtin:
+                raise DGLAMDError("User defined functions are not yet supported in apply_edges for heterogeneous "
+                                  "graphs. Please use (apply_edges(func), etype = rel) instead.")
+            if edges is not None:
+                raise DGLAMDError("apply_edges on an edge subset of a multi-relation graph needs an edge type")
             out = _invoke_gsddmm(self, func)
             for et, cet in enumerate(self._canonical_etypes):
                 for k, v in out.items():
@@ -362,17 +414,25 @@ class DGLGraph:
                         self._edge_frames[et][k] = v[et]
             return
         g = self if len(self._canonical_etypes) == 1 else self[etype]
-        for k, v in _invoke_gsddmm(g, func).items():
-            g._edge_frames[0][k] = v
+        eid = None if edges is None else g._parse_edges(edges)
+        if builtin:
+            if eid is None:
+                edata = _invoke_gsddmm(g, func)
+            else:
+                edata = _invoke_gsddmm(g._edge_subgraph(eid), func)
+        else:
+            edata = _udf.invoke_edge_udf(g, func, eid)
+        g._set_e_repr(0, eid, edata)
 
     def update_all(self, message_func, reduce_func, apply_node_func=None, etype=None):
         """Send messages along all edges and reduce them at the destination nodes
-        (python/dgl/heterograph.py:5018-5158)."""
-        if apply_node_func is not None:
-            raise DGLAMDError("apply_node_func (a user-defined function) is outside the accelerated path")
-        _require_builtin(message_func)
-        _require_builtin(reduce_func)
+        (python/dgl/heterograph.py:5018-5158).  A pair of built-in functions runs the fused kernels; any
+        other callable takes the reference's edge-batch / degree-bucketing route (:mod:`dgl_amd.udf`)."""
+        builtin = _udf.is_builtin(message_func) and _udf.is_builtin(reduce_func)
         if etype is None and len(self._canonical_etypes) > 1:
+            if not builtin:
+                raise DGLAMDError("User defined functions are not yet supported in update_all for heterogeneous "
+                                  "graphs. Please use multi_update_all instead.")
             if reduce_func.name == "mean":
                 raise NotImplementedError(
                     "Cannot set both intra-type and inter-type reduce operators as 'mean' using "
@@ -385,43 +445,246 @@ class DGLGraph:
                     if reduce_func.name in ("max", "min"):
                         val = _replace_inf_with_zero(val)
                     self._node_frames[d][key] = val
+            if apply_node_func is not None:
+                for d in sorted({self._graph.metagraph.find_edge(et)[1] for et in range(len(self._canonical_etypes))}):
+                    self.apply_nodes(apply_node_func, None, self._ntypes[d])
             return
         g = self if len(self._canonical_etypes) == 1 else self[etype]
-        ndata = _message_passing(g, message_func, reduce_func)
-        dst_frame = g._node_frames[g.get_ntype_id_from_dst(None)]
-        for k, v in ndata.items():
-            if reduce_func.name in ("max", "min"):
-                v = _replace_inf_with_zero(v)  # heterograph.py:5115-5122
-            dst_frame[k] = v
+        ndata = _udf.message_passing(g, message_func, reduce_func, apply_node_func, _message_passing)
+        if _udf.is_builtin(reduce_func) and reduce_func.name in ("max", "min") and ndata:
+            key = next(iter(ndata))
+            ndata[key] = _replace_inf_with_zero(ndata[key])   # heterograph.py:5115-5122 (the first key, as there)
+        g._set_n_repr(g.get_ntype_id_from_dst(None), None, ndata)
 
     def multi_update_all(self, etype_dict, cross_reducer, apply_node_func=None):
         """Per-relation update_all followed by a cross-relation reducer
-        (python/dgl/heterograph.py multi_update_all); built-ins only."""
-        if apply_node_func is not None:
-            raise DGLAMDError("apply_node_func is outside the accelerated path")
-        if cross_reducer not in ("sum", "min", "max", "mean", "stack"):
+        (python/dgl/heterograph.py multi_update_all)."""
+        if not callable(cross_reducer) and cross_reducer not in ("sum", "min", "max", "mean", "stack"):
             raise DGLAMDError("Invalid cross type reducer. Must be one of 'sum', 'min', 'max', 'mean' or 'stack'.")
-        collected = {}
-        for etype, (mfunc, rfunc) in etype_dict.items():
+        collected, last_rfunc = {}, None
+        for etype, args in etype_dict.items():
+            args = tuple(args)
+            if len(args) not in (2, 3):
+                raise DGLAMDError('Invalid arguments for edge type "{}". Should be (msg_func, reduce_func, '
+                                  "[apply_node_func])".format(etype))
+            mfunc, rfunc, afunc = (args + (None,))[:3]
+            last_rfunc = rfunc
             g = self[etype]
             cet = self.to_canonical_etype(etype)
             d = self.get_ntype_id(cet[2])
-            nd = _message_passing(g, mfunc, rfunc)
+            nd = _udf.message_passing(g, mfunc, rfunc, afunc, _message_passing)
             for k, v in nd.items():
-                if rfunc.name in ("max", "min"):
-                    v = _replace_inf_with_zero(v)
-                collected.setdefault((d, k), []).append(v)
+                collected.setdefault((d, k), []).append((self.get_etype_id(etype), v))
+        touched = set()
         for (d, k), vals in collected.items():
-            st = torch.stack(vals, 0 if cross_reducer != "stack" else 1)
-            if cross_reducer == "sum":
-                st = st.sum(0)
-            elif cross_reducer == "mean":
-                st = st.mean(0)
-            elif cross_reducer == "max":
-                st = st.max(0)[0]
-            elif cross_reducer == "min":
-                st = st.min(0)[0]
+            vals = [v for _, v in (sorted(vals, key=lambda t: t[0]) if cross_reducer == "stack" else vals)]
+            if callable(cross_reducer):
+                st = cross_reducer(vals)
+            elif cross_reducer == "stack":
+                st = torch.stack(vals, 1)
+            elif len(vals) == 1:
+                st = vals[0]
+            else:
+                st = torch.stack(vals, 0)
+                if cross_reducer == "sum":
+                    st = st.sum(0)
+                elif cross_reducer == "mean":
+                    st = st.mean(0)
+                elif cross_reducer == "max":
+                    st = st.max(0)[0]
+                else:
+                    st = st.min(0)[0]
+            if _udf.is_builtin(last_rfunc) and last_rfunc.name in ("max", "min"):
+                st = _replace_inf_with_zero(st)
             self._node_frames[d][k] = st
+            touched.add(d)
+        if apply_node_func is not None:
+            for d in sorted(touched):
+                self.apply_nodes(apply_node_func, None, self._ntypes[d])
+
+    # ---- partial message passing: pull / push / send_and_recv (heterograph.py:4714-5016) ----------
+    def _parse_edges(self, edges):
+        """Edge ids from ``eid`` tensor / list or an ``(u, v)`` pair (utils.parse_edges_arg_to_eid)."""
+        if isinstance(edges, tuple) and len(edges) == 2:
+            return self.edge_ids(edges[0], edges[1])
+        return self._ids(edges)
+
+    def _edge_subgraph(self, eid):
+        """Same nodes, the given edges (in that order), their edge features; shares node frames."""
+        u, v = self.edges()
+        sel = eid.long()
+        rel0 = self._graph.relations[0]
+        rel = Relation(rel0.num_src, rel0.num_dst, u[sel].contiguous(), v[sel].contiguous(), idtype=self.idtype,
+                       device=self.device)
+        rel.transient = True
+        gidx = GraphIndex([self._graph.num_nodes(i) for i in range(len(self._ntypes))], self._graph.metagraph.edges,
+                          [rel])
+        ef = _Frame(int(sel.shape[0]))
+        for k, col in self._edge_frames[0].items():
+            dict.__setitem__(ef, k, col[sel])
+        return DGLGraph(gidx, self._ntypes, self._canonical_etypes, self._node_frames, [ef],
+                        self._src_ntype_ids, self._dst_ntype_ids)
+
+    def _compute_graph(self, u, v, eid, recv_nodes=None):
+        """The bipartite graph of the ACTIVE edges with relabelled end points and the matching feature rows
+        (``_create_compute_graph``, heterograph.py:6679-6750): original ids in ``srcdata[NID]`` / ``dstdata[NID]`` /
+        ``edata[EID]``.  Returns (graph, receiving node ids)."""
+        uniq_s, new_u = torch.unique(u, return_inverse=True)
+        base = v if recv_nodes is None else recv_nodes
+        uniq_d = torch.unique(base)
+        new_v = torch.searchsorted(uniq_d, v)
+        rel = Relation(int(uniq_s.shape[0]), int(uniq_d.shape[0]), new_u.to(self.idtype).contiguous(),
+                       new_v.to(self.idtype).contiguous(), idtype=self.idtype, device=self.device)
+        rel.transient = True
+        gidx = GraphIndex([rel.num_src, rel.num_dst], [(0, 1)], [rel])
+        s_t, d_t = self.get_ntype_id_from_src(None), self.get_ntype_id_from_dst(None)
+
+        def sub(frame, rows, key):
+            f = _Frame(int(rows.shape[0]))
+            for k, col in frame.items():
+                dict.__setitem__(f, k, col[rows.long()])
+            dict.__setitem__(f, key, rows)
+            return f
+
+        cet = self._canonical_etypes[0]
+        cg = DGLGraph(gidx, [cet[0], cet[2]], [cet],
+                      [sub(self._node_frames[s_t], uniq_s, NID), sub(self._node_frames[d_t], uniq_d, NID)],
+                      [sub(self._edge_frames[0], eid, EID)], [0], [1])
+        return cg, uniq_d
+
+    def _partial_message_passing(self, g, u, v, eid, recv, mfunc, rfunc, afunc):
+        cg, dstnodes = g._compute_graph(u, v, eid, recv)
+        ndata = _udf.message_passing(cg, mfunc, rfunc, afunc, _message_passing)
+        ndata.pop(NID, None)
+        g._set_n_repr(g.get_ntype_id_from_dst(None), dstnodes, ndata)
+
+    def pull(self, v, message_func, reduce_func, apply_node_func=None, etype=None):
+        """Pull messages from the predecessors of ``v`` and update ``v`` (heterograph.py:4842-4938)."""
+        v = self._ids(v)
+        if v.numel() == 0:
+            return
+        g = self if len(self._canonical_etypes) == 1 else self[etype]
+        src, dst, eid = g.in_edges(v, form="all")
+        self._partial_message_passing(g, src, dst, eid, v, message_func, reduce_func, apply_node_func)
+
+    def push(self, u, message_func, reduce_func, apply_node_func=None, etype=None):
+        """Send messages from ``u`` along their out-edges and update the successors (heterograph.py:4940-5016)."""
+        u = self._ids(u)
+        if u.numel() == 0:
+            return
+        g = self if len(self._canonical_etypes) == 1 else self[etype]
+        src, dst, eid = g.out_edges(u, form="all")
+        if eid.numel() == 0:
+            return
+        self._partial_message_passing(g, src, dst, eid, None, message_func, reduce_func, apply_node_func)
+
+    def send_and_recv(self, edges, message_func, reduce_func, apply_node_func=None, etype=None):
+        """Message passing along the given edges only (heterograph.py:4714-4840)."""
+        g = self if len(self._canonical_etypes) == 1 else self[etype]
+        eid = g._parse_edges(edges)
+        if eid.numel() == 0:
+            return
+        u, v = g.find_edges(eid)
+        self._partial_message_passing(g, u, v, eid, None, message_func, reduce_func, apply_node_func)
+
+    # ---- structure queries used by the calls above ------------------------------------------------
+    def _gather_ranges(self, fmt, ids):
+        """All (position, owner) pairs of rows ``ids`` of a compressed format."""
+        indptr, indices, emap = fmt
+        ids_l = ids.long()
+        ip = indptr.long()
+        degs = ip[ids_l + 1] - ip[ids_l]
+        total = int(degs.sum())
+        owner = torch.repeat_interleave(torch.arange(ids_l.shape[0], device=ids.device), degs, output_size=total)
+        start_excl = torch.cumsum(degs, 0) - degs
+        pos = ip[ids_l][owner] + (torch.arange(total, device=ids.device) - start_excl[owner])
+        other = indices[pos]
+        eid = pos.to(self.idtype) if emap is None else emap[pos]
+        return other, ids[owner], eid
+
+    def in_edges(self, v, form="uv", etype=None):
+        g = self if len(self._canonical_etypes) == 1 else self[etype]
+        src, dst, eid = g._gather_ranges(g._graph.relations[0].csc(), g._ids(v))
+        return {"uv": (src, dst), "eid": eid, "all": (src, dst, eid)}[form]
+
+    def out_edges(self, u, form="uv", etype=None):
+        g = self if len(self._canonical_etypes) == 1 else self[etype]
+        dst, src, eid = g._gather_ranges(g._graph.relations[0].csr(), g._ids(u))
+        return {"uv": (src, dst), "eid": eid, "all": (src, dst, eid)}[form]
+
+    def find_edges(self, eid, etype=None):
+        u, v = self.edges(etype=etype)
+        sel = self._ids(eid).long()
+        return u[sel], v[sel]
+
+    def edge_ids(self, u, v, etype=None):
+        """The id of ONE edge between each (u, v) pair (the smallest, if there are several)."""
+        g = self if len(self._canonical_etypes) == 1 else self[etype]
+        u, v = g._ids(u), g._ids(v)
+        src, dst = g.edges()
+        n_dst = g._graph.relations[0].num_dst
+        key = src.long() * max(n_dst, 1) + dst.long()
+        order = torch.argsort(key, stable=True)
+        want = u.long() * max(n_dst, 1) + v.long()
+        at = torch.searchsorted(key[order], want)
+        ok = (at < key.numel()) & (key[order][at.clamp(max=max(key.numel() - 1, 0))] == want) if key.numel() else \
+            torch.zeros_like(want, dtype=torch.bool)
+        if not bool(ok.all()):
+            raise DGLAMDError("edge_ids: some (u, v) pairs are not edges of the graph")
+        return order[at].to(g.idtype)
+
+    # ---- mutation (used by the reference's suites to build their inputs) -------------------------------
+    def _grow_frame(self, frame, extra, data=None):
+        nf = _Frame(frame.num_rows + extra)
+        for k, col in frame.items():
+            add = data[k] if data is not None and k in data else \
+                torch.zeros((extra,) + tuple(col.shape[1:]), dtype=col.dtype, device=col.device)
+            dict.__setitem__(nf, k, torch.cat([col, add.to(col.device)], 0))
+        if data is not None:
+            for k, add in data.items():
+                if k not in frame:
+                    pad = torch.zeros((frame.num_rows,) + tuple(add.shape[1:]), dtype=add.dtype, device=add.device)
+                    dict.__setitem__(nf, k, torch.cat([pad, add], 0))
+        return nf
+
+    def _rebuild(self, num_nodes, pairs):
+        rels = []
+        for et, (s, d) in enumerate(self._graph.metagraph.edges):
+            u, v = pairs[et]
+            rels.append(Relation(num_nodes[s], num_nodes[d], u.contiguous(), v.contiguous(), idtype=self.idtype,
+                                 device=self.device))
+        self._graph = GraphIndex(num_nodes, self._graph.metagraph.edges, rels)
+
+    def add_nodes(self, num, data=None, ntype=None):
+        """Append ``num`` nodes of one type, in place (heterograph.py add_nodes); new feature rows are zero."""
+        ntid = self.get_ntype_id(ntype)
+        counts = [self._graph.num_nodes(i) for i in range(len(self._ntypes))]
+        counts[ntid] += int(num)
+        pairs = [self.edges(etype=c) for c in self._canonical_etypes]
+        self._rebuild(counts, pairs)
+        self._node_frames[ntid] = self._grow_frame(self._node_frames[ntid], int(num), data)
+
+    def add_edges(self, u, v, data=None, etype=None):
+        """Append edges ``u -> v`` of one type, in place (heterograph.py add_edges); nodes are added as needed."""
+        etid = self.get_etype_id(etype)
+        u, v = self._ids(u), self._ids(v)
+        if u.numel() == 1 and v.numel() > 1:
+            u = u.expand(v.numel())
+        if v.numel() == 1 and u.numel() > 1:
+            v = v.expand(u.numel())
+        s, d = self._graph.metagraph.find_edge(etid)
+        counts = [self._graph.num_nodes(i) for i in range(len(self._ntypes))]
+        old = list(counts)
+        if u.numel():
+            counts[s] = max(counts[s], int(u.max()) + 1)
+            counts[d] = max(counts[d], int(v.max()) + 1)
+        pairs = [list(self.edges(etype=c)) for c in self._canonical_etypes]
+        pairs[etid] = [torch.cat([pairs[etid][0], u]), torch.cat([pairs[etid][1], v])]
+        self._rebuild(counts, pairs)
+        for i, (a, b) in enumerate(zip(old, counts)):
+            if b > a:
+                self._node_frames[i] = self._grow_frame(self._node_frames[i], b - a)
+        self._edge_frames[etid] = self._grow_frame(self._edge_frames[etid], int(u.numel()), data)
 
     def __repr__(self):
         return "DGLGraph(num_nodes={}, num_edges={}, ntypes={}, etypes={})".format(
@@ -434,24 +697,21 @@ class _EdgeView:
     def __init__(self, g):
         self._g = g
 
-    def __call__(self, etype=None):
+    def __call__(self, form="uv", order="eid", etype=None):
         g = self._g
+        if form not in ("uv", "eid", "all"):        # g.edges(etype) — positional edge type (older call sites)
+            form, etype = "uv", form
         row, col, old = g._graph.relations[g.get_etype_id(etype)].coo()
         if old is not None:
-            order = torch.argsort(old)
-            return row[order], col[order]
-        return row, col
+            perm = torch.argsort(old)
+            row, col = row[perm], col[perm]
+        if form == "uv":
+            return row, col
+        eid = torch.arange(row.shape[0], dtype=g.idtype, device=row.device)
+        return eid if form == "eid" else (row, col, eid)
 
     def __getitem__(self, key):
         return self._g._edge_indexer()[key]
-
-
-def _require_builtin(func):
-    if not isinstance(func, fn.BuiltinFunction):
-        raise DGLAMDError(
-            "Only built-in functions (dgl_amd.function.*) are supported on the accelerated "
-            "message-passing path; user-defined functions use the reference's degree-bucketing "
-            "executor (python/dgl/core.py:99-174), which is out of scope here.")
 
 
 def _replace_inf_with_zero(x):
@@ -535,7 +795,11 @@ def _as_index(x, idtype, device):
 
 
 def graph(data, num_nodes=None, idtype=None, device=None):
-    """Homogeneous graph from ``(src, dst)`` (dgl.graph)."""
+    """Homogeneous graph from ``(src, dst)`` or a list of ``(u, v)`` pairs (dgl.graph)."""
+    if isinstance(data, list) and (len(data) == 0 or (len(data) != 2 or all(
+            isinstance(p, (tuple, list)) and len(p) == 2 and not isinstance(p[0], (list, tuple, torch.Tensor))
+            for p in data)) and all(isinstance(p, (tuple, list)) and len(p) == 2 for p in data)):
+        data = ([p[0] for p in data], [p[1] for p in data])       # list of pairs (possibly empty)
     u, v = data
     if idtype is None:
         idtype = u.dtype if isinstance(u, torch.Tensor) and u.dtype in (torch.int32, torch.int64) else torch.int64
@@ -625,3 +889,91 @@ def reverse(g, copy_ndata=True, copy_edata=False):
     cets = [(c[2], c[1], c[0]) for c in g.canonical_etypes]
     return DGLGraph(gidx, g.ntypes, cets, g._node_frames if copy_ndata else None,
                     g._edge_frames if copy_edata else None, g._dst_ntype_ids, g._src_ntype_ids)
+
+
+# ---- the few transforms the reference's suites use to build inputs (python/dgl/convert.py) ------------------
+def from_networkx(nx_graph, idtype=None, device=None):
+    """Graph from a networkx(-like) graph: ``number_of_nodes()``, ``edges()``, ``is_directed()``; an undirected
+    graph gives both directions of every edge (dgl.from_networkx on ``nx.Graph``)."""
+    pairs = [(int(a), int(b)) for a, b in nx_graph.edges()]
+    if not nx_graph.is_directed():
+        pairs = pairs + [(b, a) for a, b in pairs if a != b]
+    u = torch.tensor([p[0] for p in pairs], dtype=torch.int64)
+    v = torch.tensor([p[1] for p in pairs], dtype=torch.int64)
+    return graph((u, v), num_nodes=int(nx_graph.number_of_nodes()), idtype=idtype or torch.int64,
+                 device=device or torch.device("cpu"))
+
+
+def to_homogeneous(G, ndata=None, edata=None):
+    """One node / edge type: nodes concatenated in node-type order, edges in edge-type order; ``ndata[NTYPE]`` /
+    ``ndata[NID]`` / ``edata[ETYPE]`` / ``edata[EID]`` remember the origin (dgl.to_homogeneous); ``ndata`` /
+    ``edata`` name the feature fields to carry over (concatenated)."""
+    counts = [G._graph.num_nodes(i) for i in range(len(G._ntypes))]
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    dev, it = G.device, G.idtype
+    us, vs, ety, eid = [], [], [], []
+    for et, cet in enumerate(G._canonical_etypes):
+        s, d = G._graph.metagraph.find_edge(et)
+        u, v = G.edges(etype=cet)
+        us.append(u + offs[s])
+        vs.append(v + offs[d])
+        ety.append(torch.full((u.shape[0],), et, dtype=it, device=dev))
+        eid.append(torch.arange(u.shape[0], dtype=it, device=dev))
+    cat = lambda xs: torch.cat(xs) if xs else torch.zeros(0, dtype=it, device=dev)
+    hg = graph((cat(us), cat(vs)), num_nodes=offs[-1], idtype=it, device=dev)
+    hg.ndata[NTYPE] = torch.cat([torch.full((c,), i, dtype=it, device=dev) for i, c in enumerate(counts)]) \
+        if counts else torch.zeros(0, dtype=it, device=dev)
+    nid = torch.cat([torch.arange(c, dtype=it, device=dev) for c in counts]) if counts else torch.zeros(0, dtype=it, device=dev)
+    hg._node_frames[0][NID] = nid
+    hg._edge_frames[0][ETYPE] = cat(ety)
+    hg._edge_frames[0][EID] = cat(eid)
+    for k in (ndata or []):
+        hg._node_frames[0][k] = torch.cat([f[k] for f in G._node_frames])
+    for k in (edata or []):
+        hg._edge_frames[0][k] = torch.cat([f[k] for f in G._edge_frames])
+    return hg
+
+
+def to_heterogeneous(G, ntypes, etypes, ntype_field=NTYPE, etype_field=ETYPE, metagraph=None):
+    """Split a homogeneous graph by ``ndata[ntype_field]`` / ``edata[etype_field]`` (dgl.to_heterogeneous): node ids
+    inside a type follow their order in ``G``; every other feature field is sliced along (autograd kept)."""
+    ntype_ids = G.ndata[ntype_field].long()
+    etype_ids = G.edata[etype_field].long()
+    dev, it = G.device, G.idtype
+    # new node id of every node inside its type
+    local = torch.zeros_like(ntype_ids)
+    node_sel = []
+    for i in range(len(ntypes)):
+        m = (ntype_ids == i).nonzero(as_tuple=True)[0]
+        local[m] = torch.arange(m.shape[0], device=dev)
+        node_sel.append(m)
+    u, v = G.edges()
+    u, v = u.long(), v.long()
+    data, edge_sel, cets = {}, {}, []
+    for ei, et in enumerate(etypes):
+        m = (etype_ids == ei).nonzero(as_tuple=True)[0]
+        if m.numel() == 0:
+            continue
+        st = ntype_ids[u[m]]
+        dt = ntype_ids[v[m]]
+        combos = torch.unique(torch.stack([st, dt], 1), dim=0).tolist()
+        for s_i, d_i in combos:
+            mm = m[(st == s_i) & (dt == d_i)]
+            cet = (ntypes[s_i], et, ntypes[d_i])
+            data[cet] = (local[u[mm]].to(it), local[v[mm]].to(it))
+            edge_sel[cet] = mm
+            cets.append(cet)
+    hg = heterograph(data, {nt: int(node_sel[i].shape[0]) for i, nt in enumerate(ntypes)}, idtype=it, device=dev)
+    for i, nt in enumerate(ntypes):
+        f = hg._node_frames[hg.get_ntype_id(nt)]
+        for k, col in G._node_frames[0].items():
+            if k not in (ntype_field, NID):
+                f[k] = col[node_sel[i]]
+    for cet, mm in edge_sel.items():
+        f = hg._edge_frames[hg.get_etype_id(cet)]
+        for k, col in G._edge_frames[0].items():
+            if k not in (etype_field, EID):
+                f[k] = col[mm]
+    return hg

@@ -109,15 +109,39 @@ def edge_softmax(graph, logits, eids=None, norm_by="dst"):
     if norm_by not in ("dst", "src"):
         raise DGLAMDError("norm_by must be 'dst' or 'src'")
     gidx = graph._graph
-    if eids is not None and not isinstance(eids, torch.Tensor):
-        eids = torch.as_tensor(eids)
     if gidx.number_of_etypes() == 1:
+        if eids is not None and not isinstance(eids, torch.Tensor):
+            eids = torch.as_tensor(eids)
         return _F.edge_softmax(gidx, logits, eids, norm_by)
     # several relations: the normaliser runs over ALL incoming edges of a node regardless of
     # relation (EdgeSoftmax_hetero, sparse.py:750-850): concatenate per destination type
-    if eids is not None:
-        raise DGLAMDError("eids is not supported on graphs with several relations")
     scores = _to_type_tuple(graph, logits, "etype")
+    if eids is not None:
+        # the reference hands ``eids`` to ``gidx.edge_subgraph([eids], True)`` (sparse.py:771-772), i.e. ONE id array
+        # per relation: here a dict {etype: ids} / a sequence in edge-type order (None = all edges of that type); a
+        # single tensor is accepted when exactly one relation carries a score.  The softmax then runs on the
+        # edge-induced subgraph (same nodes), scores listed in the order of the ids.
+        if isinstance(eids, torch.Tensor):
+            with_score = [et for et, sc in enumerate(scores) if sc is not None]
+            if len(with_score) != 1:
+                raise DGLAMDError("edge_softmax on a graph with several relations: give eids as a dict "
+                                  "{edge type: ids} (a single id tensor is ambiguous)")
+            per = [None] * len(scores)
+            per[with_score[0]] = eids
+        elif isinstance(eids, dict):
+            per = [None] * len(scores)
+            for k, v in eids.items():
+                per[graph.get_etype_id(k)] = v
+        else:
+            per = list(eids) + [None] * (len(scores) - len(eids))
+        full = []
+        for et, ids in enumerate(per):
+            if ids is None:
+                ids = torch.arange(gidx.num_edges(et), dtype=gidx.dtype, device=gidx.ctx)
+            elif not isinstance(ids, torch.Tensor):
+                ids = torch.as_tensor(ids)
+            full.append(ids.to(device=gidx.ctx, dtype=gidx.dtype))
+        gidx = gidx.edge_subgraph(full)
     outs = _F.edge_softmax_hetero(gidx, None, norm_by, *scores)
     if isinstance(logits, dict):
         return {graph.canonical_etypes[et]: o for et, o in enumerate(outs) if o is not None}
