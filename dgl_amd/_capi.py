@@ -183,14 +183,18 @@ def edge_softmax_forward(csr, score, out, workspace=None, plan_valid=False, out_
                                              ctypes.byref(ts), ctypes.byref(to), wp, wn, fl, _stream(out)))
 
 
-def edge_softmax_backward(csr, out, sds, back, workspace=None, plan_valid=False, sds_is_grad=False):
+def edge_softmax_backward(csr, out, sds, back, workspace=None, plan_valid=False, sds_is_grad=False,
+                          out_position=False):
     """`sds_is_grad` (merge-path kernels only): `sds` is the upstream gradient itself, the product with `out` is
-    formed inside the kernel (DGLA_ESM_B_IS_GRAD)."""
+    formed inside the kernel (DGLA_ESM_B_IS_GRAD).  `out_position` (merge-path only): `out` is read and `back` written
+    in the CSR's position order, `sds` is read through the edge-id map (DGLA_ESM_OUT_POSITION)."""
     keep = []
     to, ts, tb = _tensor(out, keep), _tensor(sds, keep), _tensor(back, keep)
     wp, wn, fl = _ws_args(workspace, plan_valid)
     if sds_is_grad:
         fl |= _lib.DGLA_ESM_B_IS_GRAD
+    if out_position:
+        fl |= _lib.DGLA_ESM_OUT_POSITION
     check_call(LIB.dgla_edge_softmax_backward(ctypes.byref(csr), _DTYPES[out.dtype],
                                               ctypes.byref(to), ctypes.byref(ts),
                                               ctypes.byref(tb), wp, wn, fl, _stream(back)))

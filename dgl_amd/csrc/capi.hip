@@ -748,7 +748,8 @@ int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla
   const DeviceGuard dev(static_cast<hipStream_t>(hip_stream), back->data);
   return launch_edge_softmax(v, dtype, out->data, sds->data, back->data, feat_len(out), true,
                              workspace, workspace_bytes, (flags & DGLA_PLAN_VALID) != 0,
-                             static_cast<hipStream_t>(hip_stream), false, (flags & DGLA_ESM_B_IS_GRAD) != 0);
+                             static_cast<hipStream_t>(hip_stream), (flags & DGLA_ESM_OUT_POSITION) != 0,
+                             (flags & DGLA_ESM_B_IS_GRAD) != 0);
 }
 
 int dgla_set_tuning(uint32_t flags) {

@@ -209,7 +209,8 @@ struct EsmParams {
   int vec4;  // fp32, dim % 4 == 0 == padded width, 16-byte aligned operands: rows move as 16-byte pieces
   int xcd;   // units in XCD-contiguous order (kTuneXcd): neighbouring units share an L2
   int region_bytes;  // LDS bytes of the tables / row-transposition slices in front of the rest
-  int out_pos;       // forward: `c` is written in POSITION order (DGLA_ESM_OUT_POSITION) while `a` is read through eids
+  int out_pos;       // DGLA_ESM_OUT_POSITION.  forward: `c` is written in POSITION order while `a` is read through eids;
+                     // backward: `a` (the saved softmax) is READ and `c` written in position order, `b` read through eids
   int b_is_grad;     // backward: `b` holds the upstream gradient g, not out * g (DGLA_ESM_B_IS_GRAD): the product is formed here
   int64_t* carry_row;  // [num_units] row continued in the next unit, or -1
   void* carry_stat;    // [num_units, 2 * dim] accumulators: (m | s) forward, (sum | -) backward
@@ -480,6 +481,7 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
   A v[kEsmEpl][HP];
   A v2[BWD ? kEsmEpl : 1][BWD ? HP : 1];  // backward: out values
   int64_t off[kEsmEpl];
+  int64_t offa[BWD ? kEsmEpl : 1];  // backward: where `a` (the saved softmax) is read — by edge id like b, or by position
 
   // this lane's edges with all their features (edges past the unit's end re-load the last one)
 #define DGLA_ESM_LOAD()                                                                              \
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
             const f32x4 t = *reinterpret_cast<const f32x4*>((BWD ? pb : pa) + off[j] + 4 * q);        \
             v[j][4 * q] = t.x, v[j][4 * q + 1] = t.y, v[j][4 * q + 2] = t.z, v[j][4 * q + 3] = t.w;   \
             if constexpr (BWD) {                                                                      \
-              const f32x4 t2 = *reinterpret_cast<const f32x4*>(pa + off[j] + 4 * q);                  \
+              const f32x4 t2 = *reinterpret_cast<const f32x4*>(pa + offa[j] + 4 * q);                 \
               v2[j][4 * q] = t2.x, v2[j][4 * q + 1] = t2.y, v2[j][4 * q + 2] = t2.z,                  \
               v2[j][4 * q + 3] = t2.w;                                                                \
             }                                                                                         \
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
         _Pragma("unroll") for (int h = 0; h < HP; ++h) {                                              \
           const int hh = h < dim ? h : dim - 1; /* padded features load a valid element */           \
           v[j][h] = to_acc<DT>((BWD ? pb : pa)[off[j] + hh]);                                         \
-          if constexpr (BWD) v2[j][h] = to_acc<DT>(pa[off[j] + hh]);                                  \
+          if constexpr (BWD) v2[j][h] = to_acc<DT>(pa[offa[j] + hh]);                                 \
         }                                                                                             \
     }                                                                                                 \
   }
@@ -525,6 +527,7 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
       int e = e0 + j;
       if (e >= u.nE) e = u.nE > 0 ? u.nE - 1 : 0;
       off[j] = (u.j0 + e) * dim;
+      if constexpr (BWD) offa[j] = off[j];
     }
     if constexpr (std::is_same<DT, float>::value && (HP == 4 || HP == 8)) {
       if (tr) {  // lane-linear pieces of the wave's slice; in flight together with the index loads below
@@ -627,6 +630,7 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
       int e = e0 + j;
       if (e >= u.nE) e = u.nE > 0 ? u.nE - 1 : 0;
       off[j] = (u.nE > 0 ? eid[e] : 0) * dim;
+      if constexpr (BWD) offa[j] = p.out_pos ? (u.j0 + e) * dim : off[j];
     }
     DGLA_ESM_LOAD()
   }
@@ -902,7 +906,7 @@ __global__ __launch_bounds__(kEsmThreads, (BWD || HP > 8 || sizeof(DT) == 8) ? 1
     if (partial) continue;  // written by the fix-up kernel, which knows the whole row's statistics
     // store offset: the edge's id like the loads, or its position (scores gathered in, softmax handed on in
     // position order: one pass instead of a gather pass in front of a map-free softmax)
-    const int64_t so = (!BWD && p.out_pos) ? (u.j0 + e) * dim : off[j];
+    const int64_t so = p.out_pos ? (u.j0 + e) * dim : off[j];
     bool done = false;
     if constexpr (std::is_same<DT, float>::value && HP >= 4) {
       if (p.vec4) {
@@ -986,20 +990,21 @@ __device__ __forceinline__ void edge_softmax_fixup_boundary(const EsmParams<Idx>
         for (int64_t u = sa; u < s2; ++u) sum += ld4(cs4 + u * 2 * dim);
         for (int64_t tb = t0 + slot; tb < t1; tb += per * kFixU) {
           f32x4 xb[kFixU], xa[kFixU];
-          int64_t off[kFixU];
+          int64_t off[kFixU], so[kFixU];
 #pragma unroll
           for (int k = 0; k < kFixU; ++k) {
             const int64_t j = tb + k * per < t1 ? tb + k * per : tb;
             off[k] = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + 4 * q;
+            so[k] = p.out_pos ? j * dim + 4 * q : off[k];   // the saved softmax and the result: by position
           }
 #pragma unroll
           for (int k = 0; k < kFixU; ++k) {
-            xb[k] = ld4(fb + off[k]), xa[k] = ld4(fa + off[k]);
+            xb[k] = ld4(fb + off[k]), xa[k] = ld4(fa + so[k]);
             if (p.b_is_grad) xb[k] = xb[k] * xa[k];
           }
 #pragma unroll
           for (int k = 0; k < kFixU; ++k)
-            if (tb + k * per < t1) *reinterpret_cast<f32x4*>(fc + off[k]) = xb[k] - sum * xa[k];
+            if (tb + k * per < t1) *reinterpret_cast<f32x4*>(fc + so[k]) = xb[k] - sum * xa[k];
         }
       } else {
         const f32x4 mt = ld4(ts4 + s2 * 2 * dim), st = ld4(ts4 + s2 * 2 * dim + dim);
@@ -1053,22 +1058,23 @@ __device__ __forceinline__ void edge_softmax_fixup_boundary(const EsmParams<Idx>
       sum += ts[s2 * 2 * dim + h];
       // kFixU edges in flight per lane: the loop is a chain of HBM round trips otherwise
       for (int64_t tb = t0 + (lane >> p.log2_hp); tb < t1; tb += es * kFixU) {
-        int64_t off[kFixU];
+        int64_t off[kFixU], so[kFixU];
         A xb[kFixU], xa[kFixU];
 #pragma unroll
         for (int k = 0; k < kFixU; ++k) {
           const int64_t j = tb + k * es < t1 ? tb + k * es : tb;
           off[k] = (p.eids ? static_cast<int64_t>(p.eids[j]) : j) * dim + h;
+          so[k] = p.out_pos ? j * dim + h : off[k];
         }
 #pragma unroll
         for (int k = 0; k < kFixU; ++k) {
           xb[k] = to_acc<DT>(pb[off[k]]);
-          xa[k] = to_acc<DT>(pa[off[k]]);
+          xa[k] = to_acc<DT>(pa[so[k]]);
           if (p.b_is_grad) xb[k] = esm_round<DT>(xb[k] * xa[k]);
         }
 #pragma unroll
         for (int k = 0; k < kFixU; ++k)
-          if (tb + k * es < t1) pc[off[k]] = from_acc<DT>(xb[k] - sum * xa[k]);
+          if (tb + k * es < t1) pc[so[k]] = from_acc<DT>(xb[k] - sum * xa[k]);
       }
     } else {
       A M = ts[s2 * 2 * dim + h];
@@ -1183,7 +1189,7 @@ static int edge_softmax_merge_run(const CsrView& csr, const void* a, const void*
               (!backward || al(b))) ? 1 : 0;
   }
   p.xcd = (tuning_flags() & kTuneXcd) ? 1 : 0;
-  p.out_pos = (out_pos && !backward && csr.eids) ? 1 : 0;
+  p.out_pos = (out_pos && csr.eids) ? 1 : 0;
   p.b_is_grad = (b_is_grad && backward) ? 1 : 0;
   p.carry_row = reinterpret_cast<int64_t*>(wsp + g.off_carry_row);
   p.carry_stat = wsp + g.off_carry_stat;
@@ -1284,8 +1290,8 @@ int launch_edge_softmax(const CsrView& csr, int dtype, const void* a, const void
     last_error() = "DGLA_ESM_B_IS_GRAD: backward only, and only with the merge-path kernels (workspace given, feature length <= 16)";
     return -1;
   }
-  if (out_pos && (!merge || backward)) {
-    last_error() = "DGLA_ESM_OUT_POSITION: forward only, and only with the merge-path kernels (workspace given, feature length <= 16)";
+  if (out_pos && !merge) {
+    last_error() = "DGLA_ESM_OUT_POSITION: only with the merge-path kernels (workspace given, feature length <= 16)";
     return -1;
   }
 #define DGLA_ES(DT)                                                                          \

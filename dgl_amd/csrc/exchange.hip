@@ -53,7 +53,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const Piece* __restric
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int64_t i = base + k * 256 + threadIdx.x;
-      if (i < total) dst[i] = v[k];
+      if (i < total) {
+        if constexpr (K > 4)
+          __builtin_nontemporal_store(v[k], dst + i);  // short rows: the output is a pure stream, keep L2 for the reads
+        else
+          dst[i] = v[k];
+      }
     }
   }
 }
@@ -61,16 +66,28 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const Piece* __restric
 template <typename Idx, typename Piece>
 int run_gather(const void* src, const void* idx, void* dst, int64_t n, int64_t row_bytes,
                hipStream_t s) {
-  constexpr int K = 4;
   const int64_t pieces = row_bytes / static_cast<int64_t>(sizeof(Piece));
   if (pieces > 0xffff) return xfail("gather_rows: rows longer than 65535 pieces are not supported");
   const int64_t total = n * pieces;
-  const unsigned blocks =
-      static_cast<unsigned>(std::min<int64_t>((total + 256 * K - 1) / (256 * K), int64_t(1) << 20));
   const unsigned magic = 0xFFFFFFFFu / static_cast<unsigned>(pieces) + 1u;
-  hipLaunchKernelGGL((gather_rows_kernel<Idx, Piece, K>), dim3(blocks), dim3(256), 0, s,
-                     static_cast<const Piece*>(src), static_cast<const Idx*>(idx),
-                     static_cast<Piece*>(dst), n, static_cast<int>(pieces), magic);
+  if (pieces <= 4 && n >= (int64_t(1) << 20)) {
+    // a permutation of SHORT rows (edge tensors: 16 - 64 bytes a row, tens of millions of rows) is bound by the
+    // number of independent scattered reads in flight, not by bytes: twice the loads per thread (round 5: the edge
+    // softmax hands edge-id order out through this kernel)
+    constexpr int K = 8;
+    const unsigned blocks =
+        static_cast<unsigned>(std::min<int64_t>((total + 256 * K - 1) / (256 * K), int64_t(1) << 20));
+    hipLaunchKernelGGL((gather_rows_kernel<Idx, Piece, K>), dim3(blocks), dim3(256), 0, s,
+                       static_cast<const Piece*>(src), static_cast<const Idx*>(idx),
+                       static_cast<Piece*>(dst), n, static_cast<int>(pieces), magic);
+  } else {
+    constexpr int K = 4;
+    const unsigned blocks =
+        static_cast<unsigned>(std::min<int64_t>((total + 256 * K - 1) / (256 * K), int64_t(1) << 20));
+    hipLaunchKernelGGL((gather_rows_kernel<Idx, Piece, K>), dim3(blocks), dim3(256), 0, s,
+                       static_cast<const Piece*>(src), static_cast<const Idx*>(idx),
+                       static_cast<Piece*>(dst), n, static_cast<int>(pieces), magic);
+  }
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -371,14 +388,22 @@ int dgla_peer_alloc(size_t bytes, int kind, void** out) {
   if (!out) return xfail("dgla_peer_alloc: null result");
   *out = nullptr;
   if (bytes == 0) bytes = 256;
-  hipError_t e = hipErrorUnknown;
+  // kind 1 / 2: memory a REMOTE GPU's stores become visible in while a kernel here polls it (fine-grained / uncached).
+  // There is NO fall-back to plain hipMalloc: coarse-grained memory is not coherent for a peer's writes
+  // during a kernel — a wait kernel polling it sees stale flags, a halo row read from it may be an old one.  A failed
+  // allocation is an error the caller agrees on over the process group (every rank then takes the all-to-all path).
+  // kind 0 (plain hipMalloc) exists for ranks that share ONE device (the single-GPU tests); the Python side refuses it
+  // when the ranks sit on different devices.
+  hipError_t e = hipErrorInvalidValue;
+  if (kind == 0) e = hipMalloc(out, bytes);
   if (kind == 1) e = hipExtMallocWithFlags(out, bytes, hipDeviceMallocFinegrained);
   if (kind == 2) e = hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached);
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    e = hipMalloc(out, bytes);
+    *out = nullptr;
+    return xfail(std::string("dgla_peer_alloc(kind ") + std::to_string(kind) + "): " + hipGetErrorString(e) +
+                 " (no fall-back to coarse-grained memory: it is not coherent for peer writes)");
   }
-  if (e != hipSuccess) return xfail(std::string("dgla_peer_alloc: ") + hipGetErrorString(e));
   DGLA_CHECK_HIP(hipMemset(*out, 0, bytes));
   DGLA_CHECK_HIP(hipDeviceSynchronize());
   return 0;

@@ -749,19 +749,105 @@ class ShardedSpMM:
             spmm = _gpu_spmm_factory(self.device)
         self.spmm = spmm
 
+    check_every = 64   # steps between two looks at the peer exchange's status word (0: only in close())
+
+    def check(self):
+        """Raise if a flag wait of the peer-mapped exchange ever timed out (synchronises; see PeerHaloExchange.check)."""
+        if self.peer:
+            self.exchange.check()
+
+    def close(self):
+        """Last status check, then release the peer mappings (IPC handles are a per-process resource)."""
+        if self.peer and getattr(self, "exchange", None) is not None:
+            try:
+                self.exchange.check()
+            finally:
+                self.exchange.close()
+
+    # ---- step profile: where a step's time goes on THIS rank (bench.py's N > 1 line; VERDICT r4 Next #8) ----------
+    def profile(self, on=True):
+        """Record HIP events inside the following ``step`` calls (the caller's stream; the peer exchange adds a pair
+        on its push stream): ``profile_summary()`` turns them into milliseconds.  Profiled steps are for diagnosis —
+        the events cost a few microseconds each — and are kept OUT of timed regions by the callers."""
+        self._prof = [] if on else None
+        if self.peer:
+            self.exchange._prof = [] if on else None
+
+    class _HostStamp:
+        """Stand-in for a HIP event when the shard lives in host memory (the gloo flow tests)."""
+
+        def __init__(self):
+            import time
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    def _mark(self, rec, name):
+        if rec is not None:
+            if self.device.type == "cuda":
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+            else:
+                ev = ShardedSpMM._HostStamp()
+            rec.append((name, ev))
+
+    def profile_summary(self):
+        """Averages over the profiled steps, in ms: ``step`` (first to last event of the caller's stream), ``local``
+        (own-column launch), ``wait`` (time the caller's stream sat in front of the halo: flag-wait kernels / the
+        collective's completion = the EXPOSED part of the exchange), ``halo`` (halo-column launches) and, with the peer
+        exchange, ``push`` (the pack-and-write kernel on its own stream = the exchange as the links see it)."""
+        steps = getattr(self, "_prof", None) or []
+        if not steps:
+            return {}
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        acc = {"step": 0.0, "local": 0.0, "wait": 0.0, "halo": 0.0}
+        for rec in steps:
+            ev = dict(rec)
+            acc["step"] += ev["start"].elapsed_time(ev["end"])
+            acc["local"] += ev["start"].elapsed_time(ev["local_done"])
+            c = 0
+            while ("wait%d_begin" % c) in ev:
+                acc["wait"] += ev["wait%d_begin" % c].elapsed_time(ev["wait%d_end" % c])
+                acc["halo"] += ev["wait%d_end" % c].elapsed_time(ev["halo%d_done" % c])
+                c += 1
+        out = {k: v / len(steps) for k, v in acc.items()}
+        pushes = getattr(self.exchange, "_prof", None) if self.peer else None
+        if pushes:
+            out["push"] = sum(a.elapsed_time(b) for a, b in pushes) / len(pushes)
+        out["profiled_steps"] = len(steps)
+        return out
+
     def step(self, x_local, out_local):
         assert x_local.shape[0] == self.n_local and out_local.shape[0] == self.n_local
+        rec = None
+        if getattr(self, "_prof", None) is not None:
+            rec = []
+            self._prof.append(rec)
+        self._mark(rec, "start")
         if self.peer:
+            self._steps = getattr(self, "_steps", 0) + 1
+            if self.check_every and self._steps % self.check_every == 0 and not torch.cuda.is_current_stream_capturing():
+                self.exchange.check()   # (one read-back per check_every steps; results since the last check are suspect)
             # push (one launch) || own-column launch, then per chunk: flag wait (one wavefront) -> halo launch
             halo = self.exchange.begin_step(x_local)
             self.spmm("local", self.shard["local"], self.n_local, x_local, out_local, False)
+            self._mark(rec, "local_done")
             if self.n_halo:
                 for c, blk in enumerate(self.halo_blocks):
+                    self._mark(rec, "wait%d_begin" % c)
                     self.exchange.wait_chunk(c)
+                    self._mark(rec, "wait%d_end" % c)
                     self.spmm("halo" if c == 0 else "halo%d" % c, blk, self.n_halo, halo, out_local, True)
+                    self._mark(rec, "halo%d_done" % c)
             else:
+                self._mark(rec, "wait0_begin")
                 self.exchange.wait()   # still consume the peers' (empty) flags: keeps the ranks in step
+                self._mark(rec, "wait0_end")
+                self._mark(rec, "halo0_done")
             self.exchange.finish_step()
+            self._mark(rec, "end")
             return out_local
         work = None
         if isinstance(self.exchange, SimulatedExchange):
@@ -769,15 +855,36 @@ class ShardedSpMM:
         elif self.n_halo or self.exchange.world > 1:
             work = self.exchange.pull_async(x_local, self.halo)
         self.spmm("local", self.shard["local"], self.n_local, x_local, out_local, False)
+        self._mark(rec, "local_done")
         if not self.n_halo:
+            self._mark(rec, "wait0_begin")
             if work is not None:
                 work.wait()
+            self._mark(rec, "wait0_end")
+            self._mark(rec, "halo0_done")
+            self._mark(rec, "end")
             return out_local
         for c, blk in enumerate(self.halo_blocks):
+            self._mark(rec, "wait%d_begin" % c)
             if work is not None:
                 if len(self.halo_blocks) > 1:
                     work.wait_chunk(c)
                 else:
                     work.wait()
+            self._mark(rec, "wait%d_end" % c)
             self.spmm("halo" if c == 0 else "halo%d" % c, blk, self.n_halo, self.halo, out_local, True)
+            self._mark(rec, "halo%d_done" % c)
+        self._mark(rec, "end")
         return out_local
+
+    def exchange_alone(self, x_local):
+        """ONE exchange with nothing to hide behind (no SpMM launch between its start and its completion) on the
+        caller's stream: what the step would wait for if nothing overlapped."""
+        if self.peer:
+            self.exchange.begin_step(x_local)
+            self.exchange.wait()
+            self.exchange.finish_step()
+        elif not isinstance(self.exchange, SimulatedExchange) and (self.n_halo or self.exchange.world > 1):
+            work = self.exchange.pull_async(x_local, self.halo)
+            if work is not None:
+                work.wait()

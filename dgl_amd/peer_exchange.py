@@ -121,6 +121,9 @@ class PeerHaloExchange:
         try:
             if os.environ.get("DGLA_PEER_FAIL_RANK", "") == str(self.rank):      # fault injection for the tests
                 raise DGLAMDError("injected failure (DGLA_PEER_FAIL_RANK)")
+            if kind == 0 and not self._ranks_share_one_device(group):
+                raise DGLAMDError("DGLA_PEER_ALLOC=plain (coarse-grained hipMalloc) is only coherent between ranks "
+                                  "that share ONE GPU; these ranks sit on different devices")
             halo_ptr = self._alloc(2 * self._halo_bytes, kind)
             flag_ptr = self._alloc(8 * C * W + 256, kind)
             self._flags = _view(flag_ptr, (C * W,), torch.int64, self.device)
@@ -187,6 +190,13 @@ class PeerHaloExchange:
         self._pending = False
         dist.barrier(group=group)   # every rank has opened every buffer before anyone writes
 
+    def _ranks_share_one_device(self, group):
+        """True when every rank of the group drives the same physical GPU (the single-GPU test set-up)."""
+        props = torch.cuda.get_device_properties(self.device)
+        ident = ("%s|%s" % (getattr(props, "uuid", ""), getattr(props, "pci_bus_id", self.device.index))).encode()
+        ident = (ident + b"\0" * 96)[:96]
+        return len(set(_gather_bytes(ident, self.device, group))) == 1
+
     def _agree(self, fields, what):
         """All ranks raise together — with every failing rank's message — when any of them failed `what`."""
         bad = [(p, f[1:].rstrip(b"\0").decode("utf-8", "replace")) for p, f in enumerate(fields) if f[0]]
@@ -221,9 +231,17 @@ class PeerHaloExchange:
             # xGMI links, not by this GPU, and overlaps the own-column launch the caller queues next
             cur = torch.cuda.current_stream(self.device)
             self._push_stream.wait_stream(cur)
+            prof = getattr(self, "_prof", None)
+            if prof is not None:       # ShardedSpMM.profile(): the push as the links see it, on its own stream
+                a = torch.cuda.Event(enable_timing=True)
+                a.record(self._push_stream)
             check_call(LIB.dgla_peer_push(x_local.data_ptr(), self.row_bytes, self.serve_rows.data_ptr(),
                                           self._segs[parity].data_ptr(), self._nseg, self._nblk, self.epoch,
                                           self._arrive.data_ptr(), self._push_stream.cuda_stream))
+            if prof is not None:
+                b = torch.cuda.Event(enable_timing=True)
+                b.record(self._push_stream)
+                prof.append((a, b))
             self._push_done.record(self._push_stream)
             self._pending = True
         return self._halo[parity]
@@ -246,9 +264,13 @@ class PeerHaloExchange:
             self.wait_chunk(c)
 
     def check(self):
-        """Raise if a wait ever gave up on a peer (synchronises)."""
+        """Raise if a wait ever gave up on a peer (synchronises).  A wait that gives up lets the GPU move on with
+        STALE halo rows (and breaks the two-buffer write-after-read argument for the steps after it), so results
+        produced since the last check must not be used when this raises: ``ShardedSpMM.step`` calls it every
+        ``check_every`` steps and ``ShardedSpMM.close`` at the end; callers driving the exchange themselves must too."""
         if int(self._status.item()):
-            raise DGLAMDError("peer exchange: a peer never delivered its rows (flag wait timed out)")
+            raise DGLAMDError("peer exchange: a peer never delivered its rows (flag wait timed out); the results of "
+                              "the steps since the last check were computed on stale halo rows")
 
     def bytes_per_step(self, elem_size=None):
         return self.n_halo * self.row_bytes

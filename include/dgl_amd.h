@@ -202,9 +202,12 @@ int dgla_sddmm_csr(const char* op, const dgla_csr* csr, dgla_dtype dtype,
  *              hub rows cost no more than any other 256 edges; without it (NULL / 0) a
  *              row-per-lane-group kernel needing no scratch is used.  DGLA_PLAN_VALID in
  *              `flags`: the workspace still holds the plan of an earlier call on this csr.
- *   DGLA_ESM_OUT_POSITION (forward, merge-path kernels only): `score` is read by edge id through the CSR's map as
- *              ever, `out` is written in the CSR's POSITION order — the hand-off to a consumer that runs map-free
- *              (dgl_amd/edge_order.py) in one pass instead of a gather pass in front of a map-free softmax.
+ *   DGLA_ESM_OUT_POSITION (merge-path kernels only).  Forward: `score` is read by edge id through the CSR's map as
+ *              ever, `out` is written in the CSR's POSITION order — a softmax kept in position order costs one
+ *              scattered 32-byte READ per edge instead of a scattered read and a scattered WRITE.  Backward: `out`
+ *              (that position-ordered softmax) is read and `back` written by position, `sds` (the caller's gradient)
+ *              is read by edge id through the map.  The Python side keeps the position-ordered tensors to itself and
+ *              hands out edge-id order through one gather by the inverse map (dgl_amd/autograd.py EdgeSoftmax).
  *   DGLA_ESM_B_IS_GRAD (backward, merge-path kernels only): `sds` holds the upstream gradient g itself; the product
  *              out * g of python/dgl/backend/pytorch/sparse.py:709-713 is formed inside the kernel (rounded to the
  *              storage type as the separate elementwise kernel leaves it: same bits, 6 bytes per element less traffic).

@@ -313,3 +313,79 @@ def test_softmax_backward_forms_out_times_grad_inside_the_kernel(dev, idtype, dt
     with pytest.raises(Exception, match="DGLA_ESM_B_IS_GRAD"):
         _capi.edge_softmax_backward(_capi.make_csr(indptr, indices, None, n), score, score, torch.empty_like(score), None,
                                     sds_is_grad=True)
+
+
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(1,), (3,), (8,), (4, 4), (16,)])
+@pytest.mark.parametrize("is_grad", [False, True])
+def test_softmax_backward_with_the_saved_softmax_in_position_order(dev, idtype, dtype, shape, is_grad):
+    """DGLA_ESM_OUT_POSITION in the BACKWARD pass (round 5): `out` read and `back` written by position, `sds` read
+    by edge id through the map == the all-edge-id backward, bit for bit, permuted — with and without
+    DGLA_ESM_B_IS_GRAD, a hub row through the fix-up kernel, empty rows, every vector width."""
+    from dgl_amd import _capi
+
+    n, e = 3000, 200000
+    g0 = torch.Generator().manual_seed(14)
+    src = torch.randint(0, n, (e,), generator=g0)
+    dst = torch.randint(n // 8, n, (e,), generator=g0)
+    dst[: 60000] = n - 3
+    indptr, indices, eids = _capi.coo_to_csr(dst.to(dev).to(idtype), src.to(dev).to(idtype), None, n, n)
+    dim = 1
+    for d in shape:
+        dim *= d
+    mapped = _capi.make_csr(indptr, indices, eids, n)
+    need = int(_capi.edge_softmax_workspace_bytes(mapped, dtype, dim))
+    if need == 0:
+        with pytest.raises(Exception, match="DGLA_ESM_OUT_POSITION"):
+            z = torch.zeros((e,) + shape, device=dev, dtype=dtype)
+            _capi.edge_softmax_backward(mapped, z, z, torch.empty_like(z), None, out_position=True)
+        return
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    score = (torch.randn((e,) + shape, device=dev) * 2).to(dtype)
+    out = torch.empty_like(score)
+    _capi.edge_softmax_forward(mapped, score, out, ws)                       # edge-id order in and out
+    out_pos = _capi.gather_rows(out, eids)                                    # the same softmax, by position
+    g = torch.randn((e,) + shape, device=dev).to(dtype)
+    sds = g if is_grad else (out * g).contiguous()
+    want = torch.empty_like(out)
+    _capi.edge_softmax_backward(mapped, out, sds, want, ws, plan_valid=True, sds_is_grad=is_grad)
+    got = torch.full_like(out, float("nan"))
+    _capi.edge_softmax_backward(mapped, out_pos, sds, got, ws, plan_valid=True, sds_is_grad=is_grad, out_position=True)
+    assert torch.equal(got, _capi.gather_rows(want, eids))
+
+
+@pytest.mark.parametrize("norm_by", ["dst", "src"])
+@pytest.mark.parametrize("shape", [(), (8, 1), (3,)])
+def test_plain_edge_softmax_keeps_position_order_to_itself(dev, shape, norm_by):
+    """The default (plain) ``dgl.edge_softmax`` behind an edge-id map: forward and gradient equal the dense evaluation
+    and the map-through route it replaces, nothing but plain tensors leaves, the saved tensor is the position-ordered one."""
+    import dgl_amd as dgl
+    from dgl_amd import autograd, edge_order as E
+    from dgl_amd.sparse_kernels import _edge_softmax_backward, _edge_softmax_forward
+
+    g = _graph(dev, n=2500, e=50000, seed=8)
+    rel = g._graph.relations[0] if norm_by == "dst" else g._graph.reverse().relations[0]
+    assert rel.csc()[2] is not None
+    torch.manual_seed(6)
+    s0 = torch.randn((g.num_edges(),) + shape, device=dev) * 2
+    up = torch.randn((g.num_edges(),) + shape, device=dev)
+    s = s0.clone().requires_grad_(True)
+    a = dgl.edge_softmax(g, s, norm_by=norm_by)
+    assert type(a) is torch.Tensor and E.plain_softmax_route(rel, s0)
+    a.backward(up)
+    assert type(s.grad) is torch.Tensor
+    gi = g._graph if norm_by == "dst" else g._graph.reverse()
+    want = _edge_softmax_forward(gi, s0)                                      # reads and writes through the map
+    assert torch.equal(a.detach(), want)
+    want_back = _edge_softmax_backward(gi, want, want * up)
+    assert torch.equal(s.grad, want_back)
+    # dense evaluation
+    src, dst = g.edges()
+    key = (dst if norm_by == "dst" else src).long()
+    sd = s0.double().reshape(g.num_edges(), -1)
+    mx = torch.full((g.num_nodes(), sd.shape[1]), float("-inf"), dtype=torch.float64, device=dev).index_reduce_(
+        0, key, sd, "amax", include_self=True)
+    ex = torch.exp(sd - mx[key])
+    den = torch.zeros_like(mx).index_add_(0, key, ex)
+    torch.testing.assert_close(a.detach().double().reshape(sd.shape), ex / den[key], rtol=1e-5, atol=1e-7)
