@@ -857,8 +857,29 @@ def variants(dev, ctx, n, e, f, args, reps=10):
                                       plan_valid=True, split_keep=True, prepare_only=True)
         prep()
         torch.cuda.synchronize()
-        res["U_operand_prepared_by_producer"] = dict(res["U_static_features"],
-                                                     producer_prepare_ms=float(np.median(time_events(prep, reps))))
+        # MEASURED as the sequence it is: the producer's prepare on a stream of its own, then — ordered
+        # after it — the consumer's split_valid call on the caller's stream; both durations from HIP events
+        side = torch.cuda.Stream()
+        cons_ms, prep_ms = [], []
+        for _ in range(reps):
+            p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                p0.record()
+                prep()
+                p1.record()
+            torch.cuda.current_stream().wait_stream(side)
+            c0.record()
+            call()
+            c1.record()
+            torch.cuda.synchronize()
+            prep_ms.append(p0.elapsed_time(p1))
+            cons_ms.append(c0.elapsed_time(c1))
+        res["U_operand_prepared_by_producer"] = dict(line(cons_ms, merge_kernel_ms(call)),
+                                                     producer_prepare_ms=float(np.median(prep_ms)),
+                                                     note="consumer call timed after a prepare_only call on a producer "
+                                                          "stream, every repetition")
         # leave `out` as the per-call path produced it (bit-identical anyway)
     gl = synth_csr(n, n, e, "L" if args.variant == "U" else "U", seed=20250824, device=dev)
     csr = _capi.make_csr(gl["indptr"], gl["indices"], None, n)
