@@ -223,7 +223,7 @@ def set_profile_events(before, after):
         LIB.dgla_spmm_set_profile_events(before.cuda_event, after.cuda_event)
 
 
-(TUNE_XCD, TUNE_SPLIT, TUNE_GLDS, TUNE_SPLIT_FORCE, TUNE_MM_F32) = (1, 8, 16, 64, 128)  # include/dgl_amd.h DGLA_TUNE_*
+(TUNE_XCD, TUNE_SPLIT, TUNE_GLDS, TUNE_SPLIT_FORCE, TUNE_MM_F32, TUNE_MM_X3) = (1, 8, 16, 64, 128, 2048)  # include/dgl_amd.h DGLA_TUNE_*
 
 
 def set_tuning(flags):
@@ -231,7 +231,8 @@ def set_tuning(flags):
     never change result bits (SPLIT changes the workspace layout: plans do not survive a change of
     it).  The matrix-multiply bits do change bits: DGLA_TUNE_GLDS contracts fp32 k in a
     permuted order and DGLA_TUNE_MM_F32 selects the exact fp32 MFMA instead of the default
-    three-term bf16 split (same fp32-level error bound, different low-order bits)."""
+    split-operand kernels (same fp32-level error bound, different low-order bits); DGLA_TUNE_MM_X3 keeps the
+    weights-stationary fp32 forward on three bf16 terms instead of two scaled fp16 terms."""
     check_call(LIB.dgla_set_tuning(int(flags)))
     from . import sparse_kernels
     sparse_kernels._tuning_epoch[0] = int(flags)  # scratch sizes remembered per relation depend on the bits

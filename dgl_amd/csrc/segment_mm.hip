@@ -1272,6 +1272,440 @@ if constexpr (PIPE) {
   }  // chunks
 }
 
+// ---- fp32 as TWO fp16 terms under per-row / per-column power-of-two scales (round 5; VERDICT r4 Next #4) -----------
+// The X3 kernels above pay six bf16 MFMAs per 16 k of fp32 work and sit on the matrix pipe at the clock the chip gives
+// a kernel that dense (1.59 GHz): 8.0 ms at 10 M x 256 x 256.  fp16 has three more significand bits than bf16: TWO
+// terms, x s = h + l with h = fp16(x s), l = fp16(x s - h) (round to nearest; the difference is exact in fp32), carry
+// 22 bits of x, and a b = (ah + al)(bh + bl) needs THREE products (hh, hl, lh; the dropped ll term is < 2^-22 |a b|):
+// half the matrix-pipe work.  What fp16 lacks is bf16's exponent range, so every row of A and every column of the
+// weights is multiplied by a power of two that puts its largest magnitude into [2^14, 2^15) — exact, and undone exactly
+// on the accumulator (two power-of-two factors) in the epilogue:
+//   * weights: h2_prep_weights_kernel, once per call — column maximum / minimum over k, the two planes, 1 / scale;
+//   * A: a row's scale needs the whole row BEFORE its first element is split.  A first version read every tile twice
+//     (range pass, then the multiply pass through a 4-slot ring): the second read missed L2 — 256 waves x 32 KB in
+//     flight per XCD against 4 MB — and the kernel ran at the memory's rate for 4 x A + C (8.96 ms, slower than X3).
+//     Now the WHOLE row (K <= 256: the lane's 64-byte half of 8 lines = 128 VGPRs) sits in the register ring; every
+//     slot is refilled in place with the next tile's line behind its own k-steps, so the next row has been under way
+//     for a whole tile when its range pass (|x| maximum as a float max, smallest non-zero magnitude as an integer
+//     minimum of (bits << 1) - 1: 2 operations per element) asks for it.  A is read once per column group.
+// Accuracy: an element within 2^18 of its row's (column's) maximum keeps a relative error <= 2^-21 (both terms normal
+// or the second one's subnormal spacing 2^-24 against a first term >= 2^-4); smaller elements lose precision
+// gracefully — absolute error 2^-25 / scale.  A row whose non-zero magnitudes span MORE than h2_spread_limit(K) binades, or
+// whose maximum is Inf / NaN-adjacent / outside 2^+-60 (the unscaling could over- or underflow on the way), is not
+// trusted to the split at all: the wave recomputes it as the plain fp32 dot product (sequential fmaf over k, what
+// IEEE arithmetic defines, like x3_repair_fwd_kernel) right after the tile — rare for real features (a Gaussian row of
+// 256 has a 2^19 spread with probability 1e-3), a 1.5 x slowdown against X3 if EVERY row is like that.  A weight
+// column like that raises a flag and every row takes the exact path (weights are not like that).
+// 128 columns per workgroup (2 planes x 128 x 528 B = 132 KB of LDS), so N = 256 reads A through two column groups
+// instead of X3's four.  DGLA_TUNE_MM_X3 selects the three-term kernels instead.
+// Binades between a row's largest and smallest non-zero magnitude the split accepts: 16 + floor(log2(K) / 2).  An
+// element 2^j below a maximum scaled into [2^14, 2^15) keeps an absolute error <= 2^-25 (the second term's subnormal
+// spacing), i.e. a relative error 2^(j - 39); tests/test_mm.py's component-wise bound is 4 sqrt(K) 2^-24 sum |a||b|, so
+// half of it, 2^(1 + log2(K) / 2 - 24), is the budget per element: j <= 16 + log2(K) / 2 (K = 256: 20, K = 16: 18).
+__host__ __device__ inline int h2_spread_limit(int K) {
+  int lg = 0;
+  while ((2 << lg) <= K) ++lg;
+  return 16 + lg / 2;
+}
+constexpr int kH2MinExp = 127 - 60, kH2MaxExp = 127 + 60;   // biased exponent range of a row / column maximum
+
+struct H2Params {
+  MmParams m;
+  const _Float16* planes;    // [2][R * N][kp] fp16 (h, l) of the scaled, K-contiguous weights; zero padded
+  const float* colinv;       // [R * N] 1 / column scale
+  uint32_t* flags;           // [0] != 0: some weight column is not splittable -> every row takes the exact path; [1]: exact rows (statistics)
+  const int64_t* tile32_off; // [R + 1] exclusive prefix of ceil(len / 32)
+  int ncg;                   // column groups (workgroups sharing a row chunk)
+  int kp;                    // row pitch of the planes in elements (K rounded up to 8)
+};
+
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (largest magnitude, smallest non-zero magnitude) of a set of fp32 values, on the raw bits: zero contributes
+// 0 to the maximum and 0xffffffff to the minimum key (bits << 1) - 1
+struct H2Range {
+  uint32_t amax;   // bits of the largest |x| (sign cleared)
+  uint32_t kmin;   // min over x != 0 of (bits(x) << 1) - 1; 0xffffffff if all zero
+};
+__device__ __forceinline__ void h2_range_add(H2Range& r, uint32_t bits) {
+  const uint32_t a = bits & 0x7fffffffu;
+  r.amax = a > r.amax ? a : r.amax;
+  const uint32_t k = (bits << 1) - 1u;
+  r.kmin = k < r.kmin ? k : r.kmin;
+}
+// scale (as float bits), 1 / scale and "do not split this one" from a range
+__device__ __forceinline__ bool h2_scale(const H2Range& r, const int spread, float& scale, float& inv) {
+  const int e = static_cast<int>(r.amax >> 23);             // biased exponent of the maximum (0 for zero / denormal)
+  if (r.amax == 0u) {                                        // all zero: any scale does
+    scale = 1.f;
+    inv = 1.f;
+    return false;
+  }
+  const int emin = static_cast<int>(((r.kmin + 1u) >> 1) >> 23);
+  const bool bad = e < kH2MinExp || e > kH2MaxExp || e - emin > spread;
+  const int ec = e < kH2MinExp ? kH2MinExp : (e > kH2MaxExp ? kH2MaxExp : e);   // (keeps the bit patterns below valid)
+  scale = __builtin_bit_cast(float, static_cast<uint32_t>(127 + 14 + 127 - ec) << 23);   // 2^(14 - (e - 127))
+  inv = __builtin_bit_cast(float, static_cast<uint32_t>(ec - 14) << 23);                   // 2^((e - 127) - 14)
+  return bad;
+}
+
+// Weights: one wave per K-contiguous row (relation, column) of Bt.
+__global__ __launch_bounds__(256) void h2_prep_weights_kernel(const float* __restrict__ bt, _Float16* __restrict__ planes,
+                                                              float* __restrict__ colinv, uint32_t* __restrict__ flags,
+                                                              int64_t rows, int K, int kp) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = static_cast<int64_t>(gridDim.x) * (blockDim.x >> 6);
+  const int64_t total = rows * kp;
+  for (int64_t row = blockIdx.x * static_cast<int64_t>(blockDim.x >> 6) + (threadIdx.x >> 6); row < rows; row += nw) {
+    const float* src = bt + row * K;
+    H2Range r{0u, 0xffffffffu};
+    for (int k = lane; k < K; k += 64) h2_range_add(r, __builtin_bit_cast(uint32_t, src[k]));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const uint32_t om = __shfl_xor(r.amax, d, 64), ok = __shfl_xor(r.kmin, d, 64);
+      r.amax = om > r.amax ? om : r.amax;
+      r.kmin = ok < r.kmin ? ok : r.kmin;
+    }
+    float sc, inv;
+    const bool bad = h2_scale(r, h2_spread_limit(K), sc, inv);
+    for (int k = lane; k < kp; k += 64) {
+      const float x = k < K ? src[k] * sc : 0.f;
+      const _Float16 h = static_cast<_Float16>(x);
+      const _Float16 l = static_cast<_Float16>(x - static_cast<float>(h));
+      planes[row * kp + k] = h;
+      planes[total + row * kp + k] = l;
+    }
+    if (lane == 0) {
+      colinv[row] = inv;
+      if (bad) atomicOr(flags, 1u);
+    }
+  }
+}
+
+// 8 floats of a row (two 16-byte pieces) -> the MFMA fragments of their two fp16 terms
+__device__ __forceinline__ void split2(const f32x4 lo4, const f32x4 hi4, const float s, h16x8& h, h16x8& l) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  uint32_t hp[4], lp[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // elements 2q, 2q + 1 of the 8
+    const f32x2 x = q < 2 ? f32x2{lo4[2 * q], lo4[2 * q + 1]} : f32x2{hi4[2 * q - 4], hi4[2 * q - 3]};
+    const f32x2 xs = x * s;                                   // exact: s is a power of two
+    const h16x2 hb = __builtin_convertvector(xs, h16x2);       // round to nearest
+    const f32x2 r = xs - __builtin_convertvector(hb, f32x2);   // exact
+    const h16x2 lb = __builtin_convertvector(r, h16x2);
+    hp[q] = __builtin_bit_cast(uint32_t, hb);
+    lp[q] = __builtin_bit_cast(uint32_t, lb);
+  }
+  h = __builtin_bit_cast(h16x8, (u32x4_t{hp[0], hp[1], hp[2], hp[3]}));
+  l = __builtin_bit_cast(h16x8, (u32x4_t{lp[0], lp[1], lp[2], lp[3]}));
+}
+
+// FOUR waves per workgroup, one per SIMD: the ring (128) + the accumulators (64) + one plane's fragments (16) + the split
+// leave no room inside the 256 registers two waves per SIMD would get (first build: 55 VGPRs spilled); with 512 the
+// kernel has no spill, and one wave keeps its SIMD's matrix pipe busy on its own — twelve independent MFMAs per k-step.
+constexpr int kH2Waves = 4;
+
+template <int NJ, bool INDEXED>
+__global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Params hp) {
+  const MmParams& p = hp.m;
+  constexpr int ES = 4;
+  constexpr int ROWS = 2 * NJ * 32;
+  __shared__ __attribute__((aligned(1024))) char smem[ROWS * kWsPitchPieces * 16 + 1024];  // (+ the last DMA instruction's overhang)
+
+  const int K = p.K, N = p.N;
+  const int nss = (K * ES + 127) >> 7;          // 128-byte lines per A row
+  const int pp = 4 * nss + 1;                   // LDS row pitch in 16-byte pieces (odd): 8 fp16 per piece, 32 k per line
+  const int kpieces = hp.kp >> 3;               // 16-byte pieces with data per weight row
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = lane & 31, khalf = lane >> 5;
+
+  const int64_t* __restrict__ tile_off = hp.tile32_off;
+  const int64_t* __restrict__ row_off = p.plan + p.num_rel + 1;
+  const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
+  const int ncg = hp.ncg;
+  const int cg = qq % ncg;
+  const int ngroups = (static_cast<int>(gridDim.x) >> 3) / ncg * 8;
+  const int group = (qq / ncg) * 8 + xcd;
+  if (group >= ngroups) return;
+  const int64_t T = tile_off[p.num_rel];
+  const int n0 = cg * 32 * NJ;
+  const bool all_exact = __builtin_amdgcn_readfirstlane(static_cast<int>(hp.flags[0])) != 0;
+  const int spread = h2_spread_limit(K);
+
+  const char* __restrict__ A = static_cast<const char*>(p.a);
+  const float* __restrict__ Bt = static_cast<const float*>(p.bt);
+  float* __restrict__ C = static_cast<float*>(p.c);
+
+  const int64_t t0 = uniform64(T * group / ngroups), t1 = uniform64(T * (group + 1) / ngroups);
+  int64_t t = t0;
+  while (t < t1) {
+    const int64_t rel = uniform64(find_segment(tile_off, p.num_rel, t));
+    const int64_t rel_t0 = uniform64(tile_off[rel]);
+    int64_t rel_end = uniform64(tile_off[rel + 1]);
+    if (rel_end > t1) rel_end = t1;
+    const int64_t rel_row0 = uniform64(row_off[rel]), row_end = uniform64(row_off[rel + 1]);
+
+    // ---- this relation's two weight planes -> LDS (row rho = plane * NJ * 32 + jj * 32 + ll <-> column n0 + NJ ll + jj) ----
+    __syncthreads();  // nobody still multiplies from the previous relation's image
+    {
+      const int total = ROWS * pp, ninst = (total + 63) >> 6;
+      const int64_t rpitch = static_cast<int64_t>(hp.kp) * 2;
+      const int64_t plane_bytes = static_cast<int64_t>(p.num_rel) * N * rpitch;
+      const char* __restrict__ W = reinterpret_cast<const char*>(hp.planes);
+      for (int i = wave; i < ninst; i += kH2Waves) {
+        const int j = i * 64 + lane;
+        const int rho = j / pp, pc = j - rho * pp;
+        const int pl = rho / (NJ * 32), jj = (rho >> 5) % NJ, ll = rho & 31;
+        const int n = n0 + NJ * ll + jj;
+        const bool valid = j < total && pc < kpieces && n < N;
+        const char* src = valid ? W + pl * plane_bytes + (rel * N + n) * rpitch + pc * 16 : g_mm_zero_page;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(smem + i * 1024), 16, 0, 0);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces have landed
+    }
+    // 1 / scale of this lane's NJ output columns
+    float cinv[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int n = n0 + NJ * l + jj;
+      cinv[jj] = n < N ? hp.colinv[rel * N + n] : 0.f;
+    }
+    __syncthreads();
+
+    auto row_ptr = [&](int64_t tt) -> const char* {   // this lane's row of tile tt (clamped to the segment)
+      int64_t row = rel_row0 + (tt - rel_t0) * 32 + l;
+      if (row >= row_end) row = row_end - 1;
+      if constexpr (INDEXED) row = p.row_index[row];
+      return A + row * (static_cast<int64_t>(K) * ES);
+    };
+    struct ASlot {
+      u32x4 v[4];
+    };
+    auto load_slot = [&](const char* base, int ss, bool on) -> ASlot {   // the lane's 64-byte half of line ss
+      ASlot f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = (ss * 128 + khalf * 64 + i * 16) / ES;
+        const char* src = (on && e < K) ? base + ss * 128 + khalf * 64 + i * 16 : reinterpret_cast<const char*>(g_mm_zero_page);
+        f.v[i] = *reinterpret_cast<const u32x4*>(src);
+      }
+      return f;
+    };
+
+    // The whole row lives in the register ring: 8 slots = the lane's 64-byte half of every 128-byte line of a row of up
+    // to 256 floats (32 loads in flight per lane, 16 KB per wave).  A slot is refilled IN PLACE with the next tile's
+    // line the moment it has been multiplied, so when a tile's last k-step is done the next tile's row has been under
+    // way for a whole tile: its range pass (which needs every element before the first split) finds it there.  A is
+    // read ONCE per column group; the two groups of a row chunk run on one XCD and share its L2.
+    constexpr int NS = kWsMaxK * ES / 128;   // 8 ring slots
+    const int64_t first = t + wave;
+    if (first < rel_end) {
+    const char* cur = row_ptr(first);
+    ASlot ar[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) ar[u] = load_slot(cur, u, u < nss);
+    for (int64_t tt = first; tt < rel_end; tt += kH2Waves) {
+      const bool more = tt + kH2Waves < rel_end;
+      const char* nxt = more ? row_ptr(tt + kH2Waves) : cur;
+      // ---- the row's range (this lane's half, then both halves): largest magnitude as a float maximum (|x| is a
+      // source modifier, NaN is ignored, Inf wins), smallest non-zero magnitude as an integer minimum of (bits << 1) - 1 ----
+      float fmax_ = 0.f;
+      uint32_t kmin = 0xffffffffu;
+#pragma unroll
+      for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const u32x4 w = ar[u].v[i];
+          const f32x4 x = __builtin_bit_cast(f32x4, w);
+          fmax_ = __builtin_fmaxf(__builtin_fmaxf(fmax_, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));
+          fmax_ = __builtin_fmaxf(__builtin_fmaxf(fmax_, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
+          const uint32_t k0 = (w[0] << 1) - 1u, k1 = (w[1] << 1) - 1u, k2 = (w[2] << 1) - 1u, k3 = (w[3] << 1) - 1u;
+          const uint32_t m01 = k0 < k1 ? k0 : k1;
+          kmin = kmin < m01 ? kmin : m01;
+          const uint32_t m23 = k2 < k3 ? k2 : k3;
+          kmin = kmin < m23 ? kmin : m23;
+        }
+      H2Range rg{__builtin_bit_cast(uint32_t, fmax_), kmin};
+      {
+        const uint32_t om = __shfl_xor(rg.amax, 32, 64), ok = __shfl_xor(rg.kmin, 32, 64);
+        rg.amax = om > rg.amax ? om : rg.amax;
+        rg.kmin = ok < rg.kmin ? ok : rg.kmin;
+      }
+      float sc, rinv;
+      const bool row_bad = h2_scale(rg, spread, sc, rinv) || all_exact;
+      const int64_t trow0 = rel_row0 + (tt - rel_t0) * 32;
+      // rows of the tile that take the exact path (bit rho = row trow0 + rho; rows past the segment's end are clamped copies)
+      uint32_t badmask = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(row_bad && khalf == 0));
+      {
+        const int64_t left = row_end - uniform64(trow0);
+        if (left < 32) badmask &= (1u << left) - 1u;
+      }
+      badmask = __builtin_amdgcn_readfirstlane(badmask);
+
+      // ---- scaled, split, multiplied: slot by slot, each refilled with the next tile's line behind its k-steps ------
+      // One wave per SIMD and an in-order issue: what keeps the matrix pipe busy is the ORDER of the instruction stream.
+      // The split of k-step e + 1 (four element pairs x three stages, 4-5 VALU each) and the LDS reads of its weight
+      // fragments are issued BETWEEN the twelve MFMAs of k-step e, one stage behind each MFMA (32 pipe cycles cover
+      // them), pinned with sched_barrier — left to itself the compiler emits [split][reads][12 MFMAs] and the pipe
+      // idles through the first two (7.7 ms instead of the two-read version's 9.0, but no better than X3).
+      f32x16 acc[NJ];
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
+      h16x8 sh[2], sl[2];          // the two terms of k-step e (index e & 1)
+      h16x8 bq[2][2][NJ];          // weight fragments of k-step e: [e & 1][plane: 0 = h, 1 = l][column block]
+      auto load_b1 = [&](int piece0, int pl, int jj) -> h16x8 {
+        return *reinterpret_cast<const h16x8*>(smem + ((pl * NJ + jj) * 32 + l) * pp * 16 + (piece0 + 2 * khalf) * 16);
+      };
+      split2(__builtin_bit_cast(f32x4, ar[0].v[0]), __builtin_bit_cast(f32x4, ar[0].v[1]), sc, sh[0], sl[0]);
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) bq[0][pl][jj] = load_b1(0, pl, jj);
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        if (u < nss) {  // (uniform)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int e = 2 * u + i;                     // (compile-time after unrolling)
+            const int piece0 = 4 * u + i;                // the khalf = 0 lanes' piece of this k-step
+            // k-step e + 1: the second half of this slot, or the first half of the next one (past the row's end: zeros)
+            const ASlot& an = ar[i == 0 ? u : (u + 1 < NS ? u + 1 : u)];
+            const f32x4 xlo = __builtin_bit_cast(f32x4, an.v[i == 0 ? 2 : 0]);
+            const f32x4 xhi = __builtin_bit_cast(f32x4, an.v[i == 0 ? 3 : 1]);
+            const int npiece = i == 0 ? piece0 + 1 : 4 * (u + 1);
+            const bool nread = npiece < 4 * nss;         // (uniform) fragments of a k-step past the last line are not read
+            f32x2 xs[4];
+            uint32_t hw[4], lw[4];
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int NM = 3 * NJ;                   // MFMAs of a k-step
+#pragma unroll
+            for (int g = 0; g < NM; ++g) {
+              const int term = g / NJ, jj = g % NJ;      // consecutive MFMAs go to DIFFERENT accumulators; small terms first
+              if (piece0 < kpieces) {                    // (uniform) a k-step wholly past the end of the row multiplies nothing
+                if (term == 0)
+                  acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[e & 1], bq[e & 1][1][jj], acc[jj], 0, 0, 0);
+                else if (term == 1)
+                  acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl[e & 1], bq[e & 1][0][jj], acc[jj], 0, 0, 0);
+                else
+                  acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[e & 1], bq[e & 1][0][jj], acc[jj], 0, 0, 0);
+              }
+              // behind MFMA g: stages [g * 12 / NM, (g + 1) * 12 / NM) of the next k-step's split, and one or two of
+              // its 2 NJ fragment reads
+#pragma unroll
+              for (int st = g * 12 / NM; st < (g + 1) * 12 / NM; ++st) {
+                const int pr = st / 3;                   // element pair pr: elements 2 pr, 2 pr + 1 of the 8
+                if (st % 3 == 0) {
+                  const f32x2 x = pr < 2 ? f32x2{xlo[2 * pr], xlo[2 * pr + 1]} : f32x2{xhi[2 * pr - 4], xhi[2 * pr - 3]};
+                  xs[pr] = x * sc;                                        // exact: a power of two
+                } else if (st % 3 == 1) {
+                  const h16x2 hb = __builtin_convertvector(xs[pr], h16x2);  // round to nearest
+                  hw[pr] = __builtin_bit_cast(uint32_t, hb);
+                  xs[pr] = xs[pr] - __builtin_convertvector(hb, f32x2);     // exact
+                } else {
+                  lw[pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(xs[pr], h16x2));
+                }
+              }
+#pragma unroll
+              for (int rd = g * 2 * NJ / NM; rd < (g + 1) * 2 * NJ / NM; ++rd)
+                if (nread) bq[(e + 1) & 1][rd / NJ][rd % NJ] = load_b1(npiece, rd / NJ, rd % NJ);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            sh[(e + 1) & 1] = __builtin_bit_cast(h16x8, (u32x4_t{hw[0], hw[1], hw[2], hw[3]}));
+            sl[(e + 1) & 1] = __builtin_bit_cast(h16x8, (u32x4_t{lw[0], lw[1], lw[2], lw[3]}));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        ar[u] = load_slot(nxt, u, more && u < nss);   // in place: the next tile's row is under way from here on
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- epilogue: undo the scales (exact), registers -> global, NJ consecutive columns per lane ----------------
+      const int col = n0 + NJ * l;
+      const bool whole = uniform64(trow0) + 32 <= row_end && n0 + 32 * NJ <= N && badmask == 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        const float ri = __shfl(rinv, rho, 64);    // lane rho (< 32) holds row rho's 1 / scale
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) acc[jj][r] = acc[jj][r] * ri * cinv[jj];
+      }
+      if (whole) {
+        // (addresses from ONE base: sixteen 64-bit row pointers held at once cost 32 VGPRs this kernel does not have)
+        float* const cbase = C + (trow0 + 4 * khalf) * N + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* dst;
+          if constexpr (INDEXED)
+            dst = C + p.row_index[trow0 + (r & 3) + 8 * (r >> 2) + 4 * khalf] * N + col;
+          else
+            dst = cbase + static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * N;
+          if constexpr (NJ == 4) {
+            const f32x4 w = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+            __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(dst));
+          } else if constexpr (NJ == 2) {
+            const f32x2 w = {acc[0][r], acc[1][r]};
+            __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(dst));
+          } else {
+            __builtin_nontemporal_store(acc[0][r], dst);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rho = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+          const int64_t row = trow0 + rho;
+          if (row >= row_end || ((badmask >> rho) & 1u)) continue;
+          int64_t pr = row;
+          if constexpr (INDEXED) pr = p.row_index[row];
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj)
+            if (col + jj < N) C[pr * N + col + jj] = acc[jj][r];
+        }
+        // ---- rows the split is not trusted with: the fp32 dot product IEEE arithmetic defines, column pairs per lane ----
+        if (badmask != 0u && lane == 0 && cg == 0) atomicAdd(hp.flags + 1, static_cast<uint32_t>(__builtin_popcount(badmask)));
+        // (lanes split K — every weight row is one coalesced 1 KB read — and a butterfly adds the 64 partial sums: a
+        // first version gave every lane its own column and walked k: 64 cache lines per load, 50 us per row)
+        for (uint32_t m = badmask; m != 0u; m &= m - 1u) {
+          const int rho = __builtin_ctz(m);
+          int64_t pr = trow0 + rho;
+          if constexpr (INDEXED) pr = p.row_index[pr];
+          const float* __restrict__ arow = reinterpret_cast<const float*>(A + pr * (static_cast<int64_t>(K) * ES));
+          float av[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) av[j] = 4 * lane + j < K ? arow[4 * lane + j] : 0.f;
+          const int ncols = (N - n0) < 32 * NJ ? (N - n0) : 32 * NJ;
+          for (int c0 = 0; c0 < ncols; c0 += 4) {
+            float part[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int n = n0 + (c0 + q < ncols ? c0 + q : ncols - 1);
+              const float* __restrict__ brow = Bt + (rel * N + n) * static_cast<int64_t>(K);
+              float sacc = 0.f;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) sacc = __builtin_fmaf(av[j], 4 * lane + j < K ? brow[4 * lane + j] : 0.f, sacc);
+              part[q] = sacc;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) part[q] += __shfl_xor(part[q], d, 64);
+            if (lane < 4 && c0 + lane < ncols) C[pr * N + n0 + c0 + lane] = part[lane & 3];
+          }
+        }
+      }
+      cur = nxt;
+    }
+    }
+    t = rel_end;
+  }
+}
+
 // fp64 (and any shape the MFMA path does not take): one thread per output element.
 template <typename DT>
 __global__ __launch_bounds__(256) void segment_mm_plain_kernel(const MmParams p, int64_t M) {
@@ -1559,7 +1993,12 @@ MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool ne
   s.off_bt = off;
   if (need_bt) off = align256(off + static_cast<size_t>(num_rel) * K * N * elem);
   s.off_planes = off;  // fp32 forward: the weights as three bf16 planes (weights-stationary kernel)
-  if (forward && elem == 4) off = align256(off + static_cast<size_t>(3) * num_rel * N * ((K + 7) / 8 * 8) * 2);
+  if (forward && elem == 4) {
+    const size_t kp = (K + 7) / 8 * 8, rows = static_cast<size_t>(num_rel) * N;
+    const size_t x3 = static_cast<size_t>(3) * rows * kp * 2;                                        // three bf16 planes
+    const size_t h2 = align256(static_cast<size_t>(2) * rows * kp * 2) + align256(sizeof(float) * rows) + 256;  // two fp16 planes, 1 / column scale, flags
+    off = align256(off + std::max(x3, h2));
+  }
   s.off_acc = off;
   if (need_acc) off = align256(off + static_cast<size_t>(num_rel) * K * N * sizeof(float));
   s.total = off;
@@ -1674,6 +2113,43 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
     return 0;
   };
   if constexpr (sizeof(DT) == 4) {
+    if (!(p.tune & kTuneMmX3) && !(variant & 32)) {
+      // fp32 as two scaled fp16 terms (round 5, default): weights prepared once per call, 128 columns per workgroup
+      H2Params hp;
+      hp.m = p;
+      hp.kp = (p.K + 7) / 8 * 8;
+      const int64_t rows = p.num_rel * static_cast<int64_t>(N);
+      char* base = ws + sc.off_planes;
+      hp.planes = reinterpret_cast<const _Float16*>(base);
+      float* colinv = reinterpret_cast<float*>(base + align256(static_cast<size_t>(2) * rows * hp.kp * 2));
+      uint32_t* flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(colinv) + align256(sizeof(float) * rows));
+      hp.colinv = colinv;
+      hp.flags = flags;
+      hp.tile32_off = wp.tile32_off;
+      DGLA_CHECK_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(uint32_t), s));
+      hipLaunchKernelGGL(h2_prep_weights_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((rows + 3) / 4, 4096))), dim3(256), 0, s,
+                         static_cast<const float*>(p.bt), const_cast<_Float16*>(hp.planes), colinv, flags, rows, p.K, hp.kp);
+      const int nj = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
+      hp.ncg = (N + 32 * nj - 1) / (32 * nj);
+      const int groups = std::max(1, cus / 8 / hp.ncg);
+      const dim3 grid(static_cast<unsigned>(groups * hp.ncg * 8));
+      const dim3 block(64 * kH2Waves);
+#define DGLA_H2(NJV)                                                                                  \
+  do {                                                                                                \
+    if (p.row_index)                                                                                  \
+      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, true>), grid, block, 0, s, hp);                    \
+    else                                                                                              \
+      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, false>), grid, block, 0, s, hp);                   \
+  } while (0)
+      switch (nj) {
+        case 1: DGLA_H2(1); break;
+        case 2: DGLA_H2(2); break;
+        default: DGLA_H2(4); break;
+      }
+#undef DGLA_H2
+      DGLA_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
     // fp32: three bf16 planes of the weights, once per call; 64 columns per workgroup
     wp.kp = (p.K + 7) / 8 * 8;
     bf16_t* planes = reinterpret_cast<bf16_t*>(ws + sc.off_planes);

@@ -524,6 +524,11 @@ int dgla_peer_wait(const void* flags, int num_flags, uint64_t epoch, void* statu
  *                     three round-to-nearest bf16 terms and the six products of order <= 2 run on
  *                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation — fp32-level accuracy (dropped
  *                     terms < 2^-26 |a b|) at 2.7x less matrix-pipe time; gfx950 has no xf32 MFMA
+ *   DGLA_TUNE_MM_X3   dgla_segment_mm / dgla_gather_mm forward, fp32, weights-stationary kernel (long inputs, K <= 256):
+ *                     the three-bf16-term split above.  Default (bit off, round 5): TWO fp16 terms under exact per-row /
+ *                     per-column power-of-two scales — three products (hh, hl, lh) instead of six, dropped term
+ *                     < 2^-22 |a b|; a row whose non-zero magnitudes span more than 2^18, or whose maximum is not finite
+ *                     or outside 2^+-60, is recomputed as the plain fp32 dot product inside the same launch
  * Removed in round 4 (values retired, dgla_set_tuning rejects them): NT_OUT 2 and NT_IDX 4 (non-temporal
  * output-row stores / index-stream loads: measured neutral), SPLIT_NT 32, SPLIT_CLASSIC 256
  * (whole-row copy: 0.33 ms against 0.10), TAIL_PASS 512 (column-sliced pass over the 16-byte row tails:
@@ -535,6 +540,7 @@ int dgla_peer_wait(const void* flags, int num_flags, uint64_t epoch, void* statu
 #define DGLA_TUNE_GLDS 16u
 #define DGLA_TUNE_SPLIT_FORCE 64u
 #define DGLA_TUNE_MM_F32 128u
+#define DGLA_TUNE_MM_X3 2048u
 int dgla_set_tuning(uint32_t flags);
 uint32_t dgla_get_tuning(void);
 
