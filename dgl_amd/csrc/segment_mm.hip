@@ -1405,18 +1405,28 @@ __device__ __forceinline__ void split2(const f32x4 lo4, const f32x4 hi4, const f
 // leave no room inside the 256 registers two waves per SIMD would get (first build: 55 VGPRs spilled); with 512 the
 // kernel has no spill, and one wave keeps its SIMD's matrix pipe busy on its own — twelve independent MFMAs per k-step.
 constexpr int kH2Waves = 4;
+// Scales per row: 1 = one for the whole contraction; 2 = one per half, each half with its own accumulators — built to turn
+// the top-of-tile wait for the whole next row into two counted waits.  The compiler keeps draining (s_waitcnt vmcnt(0) at
+// the loop header whatever the younger operations: it parks part of the 128-register ring in AGPRs across the back edge and
+// every such copy needs its load), so two scales measured 5.75 ms against 5.56 ms for one: kept as a switch, off.
+constexpr int kH2Halves = 1;
 
-template <int NJ, bool INDEXED>
+// NSS > 0: K is exactly NSS whole 128-byte lines (K = 32 NSS) — every guard below is a compile-time constant.  The generic
+// form (NSS = 0: K, the number of lines and of weight pieces at run time) keeps uniform branches around every MFMA, LDS
+// read and refill; the compiler then neither interleaves the split with the MFMAs nor keeps the guards in scalar
+// registers (200 SGPRs spilled through v_writelane inside the loop): 6.3 ms against the specialised form's time.
+template <int NJ, bool INDEXED, int NSS>
 __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Params hp) {
+  constexpr bool FULL = NSS > 0;
   const MmParams& p = hp.m;
   constexpr int ES = 4;
   constexpr int ROWS = 2 * NJ * 32;
   __shared__ __attribute__((aligned(1024))) char smem[ROWS * kWsPitchPieces * 16 + 1024];  // (+ the last DMA instruction's overhang)
 
-  const int K = p.K, N = p.N;
-  const int nss = (K * ES + 127) >> 7;          // 128-byte lines per A row
+  const int K = FULL ? 32 * NSS : p.K, N = p.N;
+  const int nss = FULL ? NSS : (K * ES + 127) >> 7;          // 128-byte lines per A row
   const int pp = 4 * nss + 1;                   // LDS row pitch in 16-byte pieces (odd): 8 fp16 per piece, 32 k per line
-  const int kpieces = hp.kp >> 3;               // 16-byte pieces with data per weight row
+  const int kpieces = FULL ? 4 * NSS : hp.kp >> 3;   // 16-byte pieces with data per weight row
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = lane & 31, khalf = lane >> 5;
@@ -1488,7 +1498,10 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int e = (ss * 128 + khalf * 64 + i * 16) / ES;
-        const char* src = (on && e < K) ? base + ss * 128 + khalf * 64 + i * 16 : reinterpret_cast<const char*>(g_mm_zero_page);
+        // FULL: every piece of every line exists and a refill with nothing left to fetch re-reads the current row — no
+        // select, no compare in the loop
+        const char* src = FULL ? base + ss * 128 + khalf * 64 + i * 16
+                               : ((on && e < K) ? base + ss * 128 + khalf * 64 + i * 16 : reinterpret_cast<const char*>(g_mm_zero_page));
         f.v[i] = *reinterpret_cast<const u32x4*>(src);
       }
       return f;
@@ -1499,7 +1512,7 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
     // line the moment it has been multiplied, so when a tile's last k-step is done the next tile's row has been under
     // way for a whole tile: its range pass (which needs every element before the first split) finds it there.  A is
     // read ONCE per column group; the two groups of a row chunk run on one XCD and share its L2.
-    constexpr int NS = kWsMaxK * ES / 128;   // 8 ring slots
+    constexpr int NS = FULL ? NSS : kWsMaxK * ES / 128;   // ring slots: the row's lines (8 when K is only known at run time)
     const int64_t first = t + wave;
     if (first < rel_end) {
     const char* cur = row_ptr(first);
@@ -1509,40 +1522,43 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
     for (int64_t tt = first; tt < rel_end; tt += kH2Waves) {
       const bool more = tt + kH2Waves < rel_end;
       const char* nxt = more ? row_ptr(tt + kH2Waves) : cur;
-      // ---- the row's range (this lane's half, then both halves): largest magnitude as a float maximum (|x| is a
-      // source modifier, NaN is ignored, Inf wins), smallest non-zero magnitude as an integer minimum of (bits << 1) - 1 ----
-      float fmax_ = 0.f;
-      uint32_t kmin = 0xffffffffu;
+      // ---- the row's range: largest magnitude as a float maximum (|x| is a source modifier, NaN is ignored, Inf wins),
+      // smallest non-zero magnitude as an integer minimum of (bits << 1) - 1; this lane's half, then both lanes of the row.
+      // TWO scales per row, one per half of the contraction (slots [0, NH) and [NH, NS)), each with its own accumulators:
+      // with one scale the range pass needed the WHOLE next row at the top of a tile — `s_waitcnt vmcnt(0)` right behind
+      // the previous tile's last refill and its 16 stores (stores count in vmcnt): a memory round trip per tile with
+      // nothing to hide behind, 37 % of the wave's cycles (SQ_WAIT_INST_ANY; 5.6 ms).  The first half's slots were
+      // refilled in the first half of the previous tile and the second half's are not asked for before the middle of
+      // this one: both waits are COUNTED (32 younger operations may stay in flight) and find their data there.
+      constexpr int NH = NS / kH2Halves;
+      static_assert(NS % kH2Halves == 0, "whole halves");
+      auto range_half = [&](auto half_tag, float& sc_out, float& rinv_out) -> bool {
+        constexpr int H = decltype(half_tag)::value;
+        float fmax_ = 0.f;
+        uint32_t kmin = 0xffffffffu;
 #pragma unroll
-      for (int u = 0; u < NS; ++u)
+        for (int u = H * NH; u < (H + 1) * NH; ++u)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const u32x4 w = ar[u].v[i];
-          const f32x4 x = __builtin_bit_cast(f32x4, w);
-          fmax_ = __builtin_fmaxf(__builtin_fmaxf(fmax_, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));
-          fmax_ = __builtin_fmaxf(__builtin_fmaxf(fmax_, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
-          const uint32_t k0 = (w[0] << 1) - 1u, k1 = (w[1] << 1) - 1u, k2 = (w[2] << 1) - 1u, k3 = (w[3] << 1) - 1u;
-          const uint32_t m01 = k0 < k1 ? k0 : k1;
-          kmin = kmin < m01 ? kmin : m01;
-          const uint32_t m23 = k2 < k3 ? k2 : k3;
-          kmin = kmin < m23 ? kmin : m23;
-        }
-      H2Range rg{__builtin_bit_cast(uint32_t, fmax_), kmin};
-      {
+          for (int i = 0; i < 4; ++i) {
+            const u32x4 w = ar[u].v[i];
+            const f32x4 x = __builtin_bit_cast(f32x4, w);
+            fmax_ = __builtin_fmaxf(__builtin_fmaxf(fmax_, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));
+            fmax_ = __builtin_fmaxf(__builtin_fmaxf(fmax_, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
+            const uint32_t k0 = (w[0] << 1) - 1u, k1 = (w[1] << 1) - 1u, k2 = (w[2] << 1) - 1u, k3 = (w[3] << 1) - 1u;
+            const uint32_t m01 = k0 < k1 ? k0 : k1;
+            kmin = kmin < m01 ? kmin : m01;
+            const uint32_t m23 = k2 < k3 ? k2 : k3;
+            kmin = kmin < m23 ? kmin : m23;
+          }
+        H2Range rg{__builtin_bit_cast(uint32_t, fmax_), kmin};
         const uint32_t om = __shfl_xor(rg.amax, 32, 64), ok = __shfl_xor(rg.kmin, 32, 64);
         rg.amax = om > rg.amax ? om : rg.amax;
         rg.kmin = ok < rg.kmin ? ok : rg.kmin;
-      }
-      float sc, rinv;
-      const bool row_bad = h2_scale(rg, spread, sc, rinv) || all_exact;
+        return h2_scale(rg, spread, sc_out, rinv_out);
+      };
+      float sc0, rinv0, sc1 = 1.f, rinv1 = 1.f;
+      bool row_bad = range_half(std::integral_constant<int, 0>{}, sc0, rinv0) || all_exact;
       const int64_t trow0 = rel_row0 + (tt - rel_t0) * 32;
-      // rows of the tile that take the exact path (bit rho = row trow0 + rho; rows past the segment's end are clamped copies)
-      uint32_t badmask = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(row_bad && khalf == 0));
-      {
-        const int64_t left = row_end - uniform64(trow0);
-        if (left < 32) badmask &= (1u << left) - 1u;
-      }
-      badmask = __builtin_amdgcn_readfirstlane(badmask);
 
       // ---- scaled, split, multiplied: slot by slot, each refilled with the next tile's line behind its k-steps ------
       // One wave per SIMD and an in-order issue: what keeps the matrix pipe busy is the ORDER of the instruction stream.
@@ -1550,36 +1566,47 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
       // fragments are issued BETWEEN the twelve MFMAs of k-step e, one stage behind each MFMA (32 pipe cycles cover
       // them), pinned with sched_barrier — left to itself the compiler emits [split][reads][12 MFMAs] and the pipe
       // idles through the first two (7.7 ms instead of the two-read version's 9.0, but no better than X3).
-      f32x16 acc[NJ];
+      f32x16 acc[kH2Halves][NJ];   // [half of the contraction][column block]
 #pragma unroll
-      for (int jj = 0; jj < NJ; ++jj)
+      for (int h = 0; h < kH2Halves; ++h)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[h][jj][r] = 0.f;
       h16x8 sh[2], sl[2];          // the two terms of k-step e (index e & 1)
-      h16x8 bq[2][2][NJ];          // weight fragments of k-step e: [e & 1][plane: 0 = h, 1 = l][column block]
+      // weight fragments [plane: 0 = h, 1 = l][column block], ONE buffer: a fragment's register is re-loaded with the next
+      // k-step's right behind the last MFMA that reads it (plane l: term 0; plane h: term 2) — seven MFMAs before its
+      // next use.  (A double buffer put the kernel over 256 architectural VGPRs: the compiler parked part of the ring
+      // in AGPRs, and every copy there needs its load to have landed: s_waitcnt vmcnt(3) behind the stores.)
+      h16x8 bq[2][NJ];
       auto load_b1 = [&](int piece0, int pl, int jj) -> h16x8 {
         return *reinterpret_cast<const h16x8*>(smem + ((pl * NJ + jj) * 32 + l) * pp * 16 + (piece0 + 2 * khalf) * 16);
       };
-      split2(__builtin_bit_cast(f32x4, ar[0].v[0]), __builtin_bit_cast(f32x4, ar[0].v[1]), sc, sh[0], sl[0]);
+      split2(__builtin_bit_cast(f32x4, ar[0].v[0]), __builtin_bit_cast(f32x4, ar[0].v[1]), sc0, sh[0], sl[0]);
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) bq[0][pl][jj] = load_b1(0, pl, jj);
+        for (int jj = 0; jj < NJ; ++jj) bq[pl][jj] = load_b1(0, pl, jj);
 #pragma unroll
       for (int u = 0; u < NS; ++u) {
-        if (u < nss) {  // (uniform)
+        if (FULL || u < nss) {  // (uniform)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int e = 2 * u + i;                     // (compile-time after unrolling)
             const int piece0 = 4 * u + i;                // the khalf = 0 lanes' piece of this k-step
+            const int hf = (kH2Halves == 1 || e < NS) ? 0 : 1;   // k-steps [0, NS) belong to the first half of the contraction
+            if (kH2Halves == 2 && e == NS - 1) {
+              // the second half's scales, just before the stage that splits its first k-step: its slots have been on
+              // their way since the second half of the previous tile
+              row_bad |= range_half(std::integral_constant<int, 1>{}, sc1, rinv1);
+            }
+            const float scn = (kH2Halves == 1 || e + 1 < NS) ? sc0 : sc1;    // scale of k-step e + 1
             // k-step e + 1: the second half of this slot, or the first half of the next one (past the row's end: zeros)
             const ASlot& an = ar[i == 0 ? u : (u + 1 < NS ? u + 1 : u)];
             const f32x4 xlo = __builtin_bit_cast(f32x4, an.v[i == 0 ? 2 : 0]);
             const f32x4 xhi = __builtin_bit_cast(f32x4, an.v[i == 0 ? 3 : 1]);
             const int npiece = i == 0 ? piece0 + 1 : 4 * (u + 1);
-            const bool nread = npiece < 4 * nss;         // (uniform) fragments of a k-step past the last line are not read
+            const bool nread = FULL ? (4 * u + i + 1 < 4 * NSS) : npiece < 4 * nss;   // (uniform) fragments of a k-step past the last line are not read
             f32x2 xs[4];
             uint32_t hw[4], lw[4];
             __builtin_amdgcn_sched_barrier(0);
@@ -1587,13 +1614,13 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
 #pragma unroll
             for (int g = 0; g < NM; ++g) {
               const int term = g / NJ, jj = g % NJ;      // consecutive MFMAs go to DIFFERENT accumulators; small terms first
-              if (piece0 < kpieces) {                    // (uniform) a k-step wholly past the end of the row multiplies nothing
+              if (FULL || piece0 < kpieces) {            // (uniform) a k-step wholly past the end of the row multiplies nothing
                 if (term == 0)
-                  acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[e & 1], bq[e & 1][1][jj], acc[jj], 0, 0, 0);
+                  acc[hf][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[e & 1], bq[1][jj], acc[hf][jj], 0, 0, 0);
                 else if (term == 1)
-                  acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl[e & 1], bq[e & 1][0][jj], acc[jj], 0, 0, 0);
+                  acc[hf][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl[e & 1], bq[0][jj], acc[hf][jj], 0, 0, 0);
                 else
-                  acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[e & 1], bq[e & 1][0][jj], acc[jj], 0, 0, 0);
+                  acc[hf][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[e & 1], bq[0][jj], acc[hf][jj], 0, 0, 0);
               }
               // behind MFMA g: stages [g * 12 / NM, (g + 1) * 12 / NM) of the next k-step's split, and one or two of
               // its 2 NJ fragment reads
@@ -1602,7 +1629,7 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
                 const int pr = st / 3;                   // element pair pr: elements 2 pr, 2 pr + 1 of the 8
                 if (st % 3 == 0) {
                   const f32x2 x = pr < 2 ? f32x2{xlo[2 * pr], xlo[2 * pr + 1]} : f32x2{xhi[2 * pr - 4], xhi[2 * pr - 3]};
-                  xs[pr] = x * sc;                                        // exact: a power of two
+                  xs[pr] = x * scn;                                       // exact: a power of two
                 } else if (st % 3 == 1) {
                   const h16x2 hb = __builtin_convertvector(xs[pr], h16x2);  // round to nearest
                   hw[pr] = __builtin_bit_cast(uint32_t, hb);
@@ -1611,9 +1638,8 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
                   lw[pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(xs[pr], h16x2));
                 }
               }
-#pragma unroll
-              for (int rd = g * 2 * NJ / NM; rd < (g + 1) * 2 * NJ / NM; ++rd)
-                if (nread) bq[(e + 1) & 1][rd / NJ][rd % NJ] = load_b1(npiece, rd / NJ, rd % NJ);
+              if (nread && term == 0) bq[1][jj] = load_b1(npiece, 1, jj);   // this MFMA was the fragment's last reader
+              if (nread && term == 2) bq[0][jj] = load_b1(npiece, 0, jj);
               __builtin_amdgcn_sched_barrier(0);
             }
             typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -1626,33 +1652,45 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- epilogue: undo the scales (exact), registers -> global, NJ consecutive columns per lane ----------------
+      // rows of the tile that take the exact path (bit rho = row trow0 + rho; rows past the segment's end are clamped copies)
+      uint32_t badmask = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(row_bad && khalf == 0));
+      {
+        const int64_t left = row_end - uniform64(trow0);
+        if (left < 32) badmask &= (1u << left) - 1u;
+      }
+      badmask = __builtin_amdgcn_readfirstlane(badmask);
       const int col = n0 + NJ * l;
       const bool whole = uniform64(trow0) + 32 <= row_end && n0 + 32 * NJ <= N && badmask == 0u;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      // one output row-register at a time: 2 NJ accumulator reads, the two exact unscalings, one store — computing the
+      // whole tile first held 64 more VGPRs over the ring's 128 and the compiler parked ring registers in AGPRs, each
+      // copy waiting for its load (s_waitcnt vmcnt(0) at the top of every tile)
+      auto out_row = [&](const int r, float (&o)[NJ]) {
         const int rho = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        const float ri = __shfl(rinv, rho, 64);    // lane rho (< 32) holds row rho's 1 / scale
+        const float r0 = __shfl(rinv0, rho, 64), r1 = __shfl(rinv1, rho, 64);   // lane rho (< 32) holds row rho's 1 / scales
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) acc[jj][r] = acc[jj][r] * ri * cinv[jj];
-      }
+        for (int jj = 0; jj < NJ; ++jj)
+          o[jj] = (kH2Halves == 2 ? __builtin_fmaf(acc[kH2Halves - 1][jj][r], r1, acc[0][jj][r] * r0) : acc[0][jj][r] * r0) * cinv[jj];
+      };
       if (whole) {
         // (addresses from ONE base: sixteen 64-bit row pointers held at once cost 32 VGPRs this kernel does not have)
         float* const cbase = C + (trow0 + 4 * khalf) * N + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          float o[NJ];
+          out_row(r, o);
           float* dst;
           if constexpr (INDEXED)
             dst = C + p.row_index[trow0 + (r & 3) + 8 * (r >> 2) + 4 * khalf] * N + col;
           else
             dst = cbase + static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * N;
           if constexpr (NJ == 4) {
-            const f32x4 w = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+            const f32x4 w = {o[0], o[1], o[2], o[3]};
             __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(dst));
           } else if constexpr (NJ == 2) {
-            const f32x2 w = {acc[0][r], acc[1][r]};
+            const f32x2 w = {o[0], o[1]};
             __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(dst));
           } else {
-            __builtin_nontemporal_store(acc[0][r], dst);
+            __builtin_nontemporal_store(o[0], dst);
           }
         }
       } else {
@@ -1660,12 +1698,14 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
         for (int r = 0; r < 16; ++r) {
           const int rho = (r & 3) + 8 * (r >> 2) + 4 * khalf;
           const int64_t row = trow0 + rho;
+          float o[NJ];
+          out_row(r, o);
           if (row >= row_end || ((badmask >> rho) & 1u)) continue;
           int64_t pr = row;
           if constexpr (INDEXED) pr = p.row_index[row];
 #pragma unroll
           for (int jj = 0; jj < NJ; ++jj)
-            if (col + jj < N) C[pr * N + col + jj] = acc[jj][r];
+            if (col + jj < N) C[pr * N + col + jj] = o[jj];
         }
         // ---- rows the split is not trusted with: the fp32 dot product IEEE arithmetic defines, column pairs per lane ----
         if (badmask != 0u && lane == 0 && cg == 0) atomicAdd(hp.flags + 1, static_cast<uint32_t>(__builtin_popcount(badmask)));
@@ -1698,6 +1738,10 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
             if (lane < 4 && c0 + lane < ncols) C[pr * N + n0 + c0 + lane] = part[lane & 3];
           }
         }
+        // (rare path: wait for the whole ring here — through a USE of the youngest load, which the compiler models —
+        // so that behind the join the counts are those of the usual path above: 16 stores younger than the ring, and
+        // the top of the next tile waits with a COUNT instead of draining everything)
+        asm volatile("" ::"v"(ar[NS - 1].v[0]), "v"(ar[NS - 1].v[1]), "v"(ar[NS - 1].v[2]), "v"(ar[NS - 1].v[3]));
       }
       cur = nxt;
     }
@@ -2134,12 +2178,22 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
       const int groups = std::max(1, cus / 8 / hp.ncg);
       const dim3 grid(static_cast<unsigned>(groups * hp.ncg * 8));
       const dim3 block(64 * kH2Waves);
+      const int full = (p.K == 256) ? 8 : (p.K == 128 ? 4 : 0);   // K = a whole number of lines the kernel is specialised for
+#define DGLA_H2I(NJV, IDX)                                                                            \
+  do {                                                                                                \
+    if (full == 8)                                                                                    \
+      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 8>), grid, block, 0, s, hp);                  \
+    else if (full == 4)                                                                               \
+      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 4>), grid, block, 0, s, hp);                  \
+    else                                                                                              \
+      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 0>), grid, block, 0, s, hp);                  \
+  } while (0)
 #define DGLA_H2(NJV)                                                                                  \
   do {                                                                                                \
     if (p.row_index)                                                                                  \
-      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, true>), grid, block, 0, s, hp);                    \
+      DGLA_H2I(NJV, true);                                                                            \
     else                                                                                              \
-      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, false>), grid, block, 0, s, hp);                   \
+      DGLA_H2I(NJV, false);                                                                           \
   } while (0)
       switch (nj) {
         case 1: DGLA_H2(1); break;
@@ -2147,6 +2201,7 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
         default: DGLA_H2(4); break;
       }
 #undef DGLA_H2
+#undef DGLA_H2I
       DGLA_CHECK_HIP(hipGetLastError());
       return 0;
     }

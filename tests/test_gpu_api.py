@@ -284,8 +284,12 @@ def test_update_all_unfused_message(dev):
     with g.local_scope():
         g.ndata["tmp"] = torch.ones(30, 1, device=dev)
     assert "tmp" not in g.ndata
-    with pytest.raises(dgl.DGLError, match="built-in"):
-        g.update_all(lambda edges: {"m": edges.src["x"]}, fn.sum("m", "o"))
+    # a user-defined message function takes the reference's plain-tensor route (dgl_amd/udf.py) next to a built-in reduce
+    g.update_all(lambda edges: {"m": edges.src["x"]}, fn.sum("m", "o"))
+    g.update_all(fn.copy_u("x", "m"), fn.sum("m", "o_builtin"))
+    assert torch.allclose(g.ndata["o"], g.ndata["o_builtin"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(dgl.DGLError, match="return a dict"):
+        g.update_all(lambda edges: edges.src["x"], fn.sum("m", "o"))
 
 
 def test_gat_layer_pipeline(dev):
