@@ -1288,35 +1288,43 @@ if constexpr (PIPE) {
 //     slot is refilled in place with the next tile's line behind its own k-steps, so the next row has been under way
 //     for a whole tile when its range pass (|x| maximum as a float max, smallest non-zero magnitude as an integer
 //     minimum of (bits << 1) - 1: 2 operations per element) asks for it.  A is read once per column group.
-// Accuracy: an element within 2^18 of its row's (column's) maximum keeps a relative error <= 2^-21 (both terms normal
-// or the second one's subnormal spacing 2^-24 against a first term >= 2^-4); smaller elements lose precision
-// gracefully — absolute error 2^-25 / scale.  A row whose non-zero magnitudes span MORE than h2_spread_limit(K) binades, or
-// whose maximum is Inf / NaN-adjacent / outside 2^+-60 (the unscaling could over- or underflow on the way), is not
-// trusted to the split at all: the wave recomputes it as the plain fp32 dot product (sequential fmaf over k, what
-// IEEE arithmetic defines, like x3_repair_fwd_kernel) right after the tile — rare for real features (a Gaussian row of
-// 256 has a 2^19 spread with probability 1e-3), a 1.5 x slowdown against X3 if EVERY row is like that.  A weight
-// column like that raises a flag and every row takes the exact path (weights are not like that).
+// The LOW term is stored pre-scaled, l = fp16((x s - h) 2^11): |x s - h| <= 2^-11 |x s| would be subnormal in fp16 for
+// every element below 2^-3 of the row's maximum (and cost those elements their low bits: a first version accepted 16 +
+// log2(K) / 2 binades only, and any weight tensor of 0.5 M uniform elements holds an element smaller than that with
+// probability 0.4 — one such element sent EVERY row down the exact path: 153 ms instead of 4.3).  Pre-scaled, l is
+// normal whenever h is, and when it is not its spacing is 2^-25 against a residual that is itself < 2^-25: an element
+// keeps a relative error <= 2^-21 down to 2^28 below its row's (column's) maximum.  The two cross products then carry
+// 2^11 and get an accumulator of their own: acc0 += ah bh; acc1 += ah bl' + al' bh; result = acc0 + 2^-11 acc1 (exact
+// scaling, one fma per output element).  Three MFMAs per 16 k as before.
+// What the split is still not trusted with (kH2Spread = 28 binades, any K):
+//   * a ROW of A whose non-zero magnitudes span more, or whose maximum is Inf or outside 2^+-60 (the unscaling could
+//     over- or underflow on the way): the wave recomputes it as the plain fp32 dot product right after the tile (lanes
+//     split K, coalesced weight rows, butterfly sum; Inf / NaN as IEEE arithmetic gives them) — for continuous data one
+//     row in 10^6 (2.5 G elements x 2^-28);
+//   * single weight ELEMENTS more than 2^28 below their column's maximum: zeroed in the planes and kept in a short
+//     list (relation, k, column, value); h2_fix_weights_kernel, launched behind the main kernel and idle unless the
+//     list is non-empty, adds a[row][k] * value to the outputs of that relation's rows in fp32.  A list that overflows,
+//     or a column whose maximum is Inf / outside 2^+-60, raises the flag that sends every row down the exact path.
 // 128 columns per workgroup (2 planes x 128 x 528 B = 132 KB of LDS), so N = 256 reads A through two column groups
 // instead of X3's four.  DGLA_TUNE_MM_X3 selects the three-term kernels instead.
-// Binades between a row's largest and smallest non-zero magnitude the split accepts: 16 + floor(log2(K) / 2).  An
-// element 2^j below a maximum scaled into [2^14, 2^15) keeps an absolute error <= 2^-25 (the second term's subnormal
-// spacing), i.e. a relative error 2^(j - 39); tests/test_mm.py's component-wise bound is 4 sqrt(K) 2^-24 sum |a||b|, so
-// half of it, 2^(1 + log2(K) / 2 - 24), is the budget per element: j <= 16 + log2(K) / 2 (K = 256: 20, K = 16: 18).
-__host__ __device__ inline int h2_spread_limit(int K) {
-  int lg = 0;
-  while ((2 << lg) <= K) ++lg;
-  return 16 + lg / 2;
-}
+constexpr int kH2Spread = 28;          // binades between a row's / column's maximum and the smallest magnitude the split keeps exact to 2^-21
+constexpr int kH2FixCap = 4096;        // weight elements below that the correction list holds
 constexpr int kH2MinExp = 127 - 60, kH2MaxExp = 127 + 60;   // biased exponent range of a row / column maximum
 
 struct H2Params {
   MmParams m;
   const _Float16* planes;    // [2][R * N][kp] fp16 (h, l) of the scaled, K-contiguous weights; zero padded
   const float* colinv;       // [R * N] 1 / column scale
-  uint32_t* flags;           // [0] != 0: some weight column is not splittable -> every row takes the exact path; [1]: exact rows (statistics)
+  uint32_t* flags;           // [0] != 0: the weights cannot be split -> every row takes the exact path; [1]: exact rows (statistics); [2]: entries in `fix`
+  struct H2Fix* fix;         // [kH2FixCap] weight elements too small for their column's scale (zeroed in the planes)
   const int64_t* tile32_off; // [R + 1] exclusive prefix of ceil(len / 32)
   int ncg;                   // column groups (workgroups sharing a row chunk)
   int kp;                    // row pitch of the planes in elements (K rounded up to 8)
+};
+
+struct H2Fix {
+  int rel, k, n;
+  float value;
 };
 
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
@@ -1335,7 +1343,7 @@ __device__ __forceinline__ void h2_range_add(H2Range& r, uint32_t bits) {
   r.kmin = k < r.kmin ? k : r.kmin;
 }
 // scale (as float bits), 1 / scale and "do not split this one" from a range
-__device__ __forceinline__ bool h2_scale(const H2Range& r, const int spread, float& scale, float& inv) {
+__device__ __forceinline__ bool h2_scale(const H2Range& r, float& scale, float& inv, bool check_spread = true) {
   const int e = static_cast<int>(r.amax >> 23);             // biased exponent of the maximum (0 for zero / denormal)
   if (r.amax == 0u) {                                        // all zero: any scale does
     scale = 1.f;
@@ -1343,7 +1351,7 @@ __device__ __forceinline__ bool h2_scale(const H2Range& r, const int spread, flo
     return false;
   }
   const int emin = static_cast<int>(((r.kmin + 1u) >> 1) >> 23);
-  const bool bad = e < kH2MinExp || e > kH2MaxExp || e - emin > spread;
+  const bool bad = e < kH2MinExp || e > kH2MaxExp || (check_spread && e - emin > kH2Spread);
   const int ec = e < kH2MinExp ? kH2MinExp : (e > kH2MaxExp ? kH2MaxExp : e);   // (keeps the bit patterns below valid)
   scale = __builtin_bit_cast(float, static_cast<uint32_t>(127 + 14 + 127 - ec) << 23);   // 2^(14 - (e - 127))
   inv = __builtin_bit_cast(float, static_cast<uint32_t>(ec - 14) << 23);                   // 2^((e - 127) - 14)
@@ -1353,7 +1361,7 @@ __device__ __forceinline__ bool h2_scale(const H2Range& r, const int spread, flo
 // Weights: one wave per K-contiguous row (relation, column) of Bt.
 __global__ __launch_bounds__(256) void h2_prep_weights_kernel(const float* __restrict__ bt, _Float16* __restrict__ planes,
                                                               float* __restrict__ colinv, uint32_t* __restrict__ flags,
-                                                              int64_t rows, int K, int kp) {
+                                                              H2Fix* __restrict__ fix, int64_t rows, int N, int K, int kp) {
   const int lane = threadIdx.x & 63;
   const int64_t nw = static_cast<int64_t>(gridDim.x) * (blockDim.x >> 6);
   const int64_t total = rows * kp;
@@ -1368,17 +1376,47 @@ __global__ __launch_bounds__(256) void h2_prep_weights_kernel(const float* __res
       r.kmin = ok < r.kmin ? ok : r.kmin;
     }
     float sc, inv;
-    const bool bad = h2_scale(r, h2_spread_limit(K), sc, inv);
+    const bool bad = h2_scale(r, sc, inv, /*check_spread=*/false);   // (too-small ELEMENTS are handled one by one below)
+    const float tiny = 6.103515625e-05f;                               // 2^-14: the smallest normal fp16
     for (int k = lane; k < kp; k += 64) {
-      const float x = k < K ? src[k] * sc : 0.f;
+      float x = k < K ? src[k] * sc : 0.f;
+      if (x != 0.f && __builtin_fabsf(x) < tiny && !bad) {
+        // more than 2^28 below the column's maximum: not in the planes; added in fp32 by h2_fix_weights_kernel
+        const uint32_t at = atomicAdd(flags + 2, 1u);
+        if (at < static_cast<uint32_t>(kH2FixCap))
+          fix[at] = H2Fix{static_cast<int>(row / N), k, static_cast<int>(row % N), src[k]};
+        else
+          atomicOr(flags, 1u);
+        x = 0.f;
+      }
       const _Float16 h = static_cast<_Float16>(x);
-      const _Float16 l = static_cast<_Float16>(x - static_cast<float>(h));
+      const _Float16 l = static_cast<_Float16>((x - static_cast<float>(h)) * 2048.f);
       planes[row * kp + k] = h;
       planes[total + row * kp + k] = l;
     }
     if (lane == 0) {
       colinv[row] = inv;
       if (bad) atomicOr(flags, 1u);
+    }
+  }
+}
+
+// out[row][n] += a[row][k] * value for every listed weight element and every row of its relation (fp32; the main kernel
+// multiplied a zero there).  Idle — one load per thread — unless the list is non-empty.
+__global__ __launch_bounds__(256) void h2_fix_weights_kernel(const MmParams p, const uint32_t* __restrict__ flags,
+                                                             const H2Fix* __restrict__ fix) {
+  if (flags[0] != 0u) return;                       // every row went down the exact path with the true weights
+  const uint32_t cnt = flags[2] < static_cast<uint32_t>(kH2FixCap) ? flags[2] : static_cast<uint32_t>(kH2FixCap);
+  if (cnt == 0u) return;
+  const int64_t* row_off = p.plan + p.num_rel + 1;
+  const float* A = static_cast<const float*>(p.a);
+  float* C = static_cast<float*>(p.c);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (uint32_t i = 0; i < cnt; ++i) {              // (entries of one output element are added one after the other: no race)
+    const H2Fix f = fix[i];
+    for (int64_t r = row_off[f.rel] + blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; r < row_off[f.rel + 1]; r += stride) {
+      const int64_t pr = p.row_index ? p.row_index[r] : r;
+      C[pr * p.N + f.n] = __builtin_fmaf(A[pr * p.K + f.k], f.value, C[pr * p.N + f.n]);
     }
   }
 }
@@ -1392,7 +1430,7 @@ __device__ __forceinline__ void split2(const f32x4 lo4, const f32x4 hi4, const f
     const f32x2 x = q < 2 ? f32x2{lo4[2 * q], lo4[2 * q + 1]} : f32x2{hi4[2 * q - 4], hi4[2 * q - 3]};
     const f32x2 xs = x * s;                                   // exact: s is a power of two
     const h16x2 hb = __builtin_convertvector(xs, h16x2);       // round to nearest
-    const f32x2 r = xs - __builtin_convertvector(hb, f32x2);   // exact
+    const f32x2 r = (xs - __builtin_convertvector(hb, f32x2)) * 2048.f;   // exact difference, exact scaling
     const h16x2 lb = __builtin_convertvector(r, h16x2);
     hp[q] = __builtin_bit_cast(uint32_t, hb);
     lp[q] = __builtin_bit_cast(uint32_t, lb);
@@ -1405,11 +1443,6 @@ __device__ __forceinline__ void split2(const f32x4 lo4, const f32x4 hi4, const f
 // leave no room inside the 256 registers two waves per SIMD would get (first build: 55 VGPRs spilled); with 512 the
 // kernel has no spill, and one wave keeps its SIMD's matrix pipe busy on its own — twelve independent MFMAs per k-step.
 constexpr int kH2Waves = 4;
-// Scales per row: 1 = one for the whole contraction; 2 = one per half, each half with its own accumulators — built to turn
-// the top-of-tile wait for the whole next row into two counted waits.  The compiler keeps draining (s_waitcnt vmcnt(0) at
-// the loop header whatever the younger operations: it parks part of the 128-register ring in AGPRs across the back edge and
-// every such copy needs its load), so two scales measured 5.75 ms against 5.56 ms for one: kept as a switch, off.
-constexpr int kH2Halves = 1;
 
 // NSS > 0: K is exactly NSS whole 128-byte lines (K = 32 NSS) — every guard below is a compile-time constant.  The generic
 // form (NSS = 0: K, the number of lines and of weight pieces at run time) keeps uniform branches around every MFMA, LDS
@@ -1442,7 +1475,6 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
   const int64_t T = tile_off[p.num_rel];
   const int n0 = cg * 32 * NJ;
   const bool all_exact = __builtin_amdgcn_readfirstlane(static_cast<int>(hp.flags[0])) != 0;
-  const int spread = h2_spread_limit(K);
 
   const char* __restrict__ A = static_cast<const char*>(p.a);
   const float* __restrict__ Bt = static_cast<const float*>(p.bt);
@@ -1524,40 +1556,34 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
       const char* nxt = more ? row_ptr(tt + kH2Waves) : cur;
       // ---- the row's range: largest magnitude as a float maximum (|x| is a source modifier, NaN is ignored, Inf wins),
       // smallest non-zero magnitude as an integer minimum of (bits << 1) - 1; this lane's half, then both lanes of the row.
-      // TWO scales per row, one per half of the contraction (slots [0, NH) and [NH, NS)), each with its own accumulators:
-      // with one scale the range pass needed the WHOLE next row at the top of a tile — `s_waitcnt vmcnt(0)` right behind
-      // the previous tile's last refill and its 16 stores (stores count in vmcnt): a memory round trip per tile with
-      // nothing to hide behind, 37 % of the wave's cycles (SQ_WAIT_INST_ANY; 5.6 ms).  The first half's slots were
-      // refilled in the first half of the previous tile and the second half's are not asked for before the middle of
-      // this one: both waits are COUNTED (32 younger operations may stay in flight) and find their data there.
-      constexpr int NH = NS / kH2Halves;
-      static_assert(NS % kH2Halves == 0, "whole halves");
-      auto range_half = [&](auto half_tag, float& sc_out, float& rinv_out) -> bool {
-        constexpr int H = decltype(half_tag)::value;
-        float fmax_ = 0.f;
-        uint32_t kmin = 0xffffffffu;
+      // (Two scales per row — one per half of the contraction, each with its own accumulators, so that both range passes
+      // could wait for their slots with a COUNT — were built and measured: 5.56 -> 5.75 ms.  The compiler keeps draining
+      // at the loop header: it parks part of the 128-register ring in AGPRs across the back edge, and every such copy
+      // needs its load.  One scale per row it is.)
+      float fmax_ = 0.f;
+      uint32_t kmin = 0xffffffffu;
 #pragma unroll
-        for (int u = H * NH; u < (H + 1) * NH; ++u)
+      for (int u = 0; u < NS; ++u)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const u32x4 w = ar[u].v[i];
-            const f32x4 x = __builtin_bit_cast(f32x4, w);
-            fmax_ = __builtin_fmaxf(__builtin_fmaxf(fmax_, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));
-            fmax_ = __builtin_fmaxf(__builtin_fmaxf(fmax_, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
-            const uint32_t k0 = (w[0] << 1) - 1u, k1 = (w[1] << 1) - 1u, k2 = (w[2] << 1) - 1u, k3 = (w[3] << 1) - 1u;
-            const uint32_t m01 = k0 < k1 ? k0 : k1;
-            kmin = kmin < m01 ? kmin : m01;
-            const uint32_t m23 = k2 < k3 ? k2 : k3;
-            kmin = kmin < m23 ? kmin : m23;
-          }
-        H2Range rg{__builtin_bit_cast(uint32_t, fmax_), kmin};
+        for (int i = 0; i < 4; ++i) {
+          const u32x4 w = ar[u].v[i];
+          const f32x4 x = __builtin_bit_cast(f32x4, w);
+          fmax_ = __builtin_fmaxf(__builtin_fmaxf(fmax_, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));
+          fmax_ = __builtin_fmaxf(__builtin_fmaxf(fmax_, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
+          const uint32_t k0 = (w[0] << 1) - 1u, k1 = (w[1] << 1) - 1u, k2 = (w[2] << 1) - 1u, k3 = (w[3] << 1) - 1u;
+          const uint32_t m01 = k0 < k1 ? k0 : k1;
+          kmin = kmin < m01 ? kmin : m01;
+          const uint32_t m23 = k2 < k3 ? k2 : k3;
+          kmin = kmin < m23 ? kmin : m23;
+        }
+      H2Range rg{__builtin_bit_cast(uint32_t, fmax_), kmin};
+      {
         const uint32_t om = __shfl_xor(rg.amax, 32, 64), ok = __shfl_xor(rg.kmin, 32, 64);
         rg.amax = om > rg.amax ? om : rg.amax;
         rg.kmin = ok < rg.kmin ? ok : rg.kmin;
-        return h2_scale(rg, spread, sc_out, rinv_out);
-      };
-      float sc0, rinv0, sc1 = 1.f, rinv1 = 1.f;
-      bool row_bad = range_half(std::integral_constant<int, 0>{}, sc0, rinv0) || all_exact;
+      }
+      float sc0, rinv0;
+      const bool row_bad = h2_scale(rg, sc0, rinv0) || all_exact;
       const int64_t trow0 = rel_row0 + (tt - rel_t0) * 32;
 
       // ---- scaled, split, multiplied: slot by slot, each refilled with the next tile's line behind its k-steps ------
@@ -1566,9 +1592,9 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
       // fragments are issued BETWEEN the twelve MFMAs of k-step e, one stage behind each MFMA (32 pipe cycles cover
       // them), pinned with sched_barrier — left to itself the compiler emits [split][reads][12 MFMAs] and the pipe
       // idles through the first two (7.7 ms instead of the two-read version's 9.0, but no better than X3).
-      f32x16 acc[kH2Halves][NJ];   // [half of the contraction][column block]
+      f32x16 acc[2][NJ];           // [0: ah bh | 1: ah bl' + al' bh, both carrying the low terms' 2^11][column block]
 #pragma unroll
-      for (int h = 0; h < kH2Halves; ++h)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
@@ -1594,13 +1620,6 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
           for (int i = 0; i < 2; ++i) {
             const int e = 2 * u + i;                     // (compile-time after unrolling)
             const int piece0 = 4 * u + i;                // the khalf = 0 lanes' piece of this k-step
-            const int hf = (kH2Halves == 1 || e < NS) ? 0 : 1;   // k-steps [0, NS) belong to the first half of the contraction
-            if (kH2Halves == 2 && e == NS - 1) {
-              // the second half's scales, just before the stage that splits its first k-step: its slots have been on
-              // their way since the second half of the previous tile
-              row_bad |= range_half(std::integral_constant<int, 1>{}, sc1, rinv1);
-            }
-            const float scn = (kH2Halves == 1 || e + 1 < NS) ? sc0 : sc1;    // scale of k-step e + 1
             // k-step e + 1: the second half of this slot, or the first half of the next one (past the row's end: zeros)
             const ASlot& an = ar[i == 0 ? u : (u + 1 < NS ? u + 1 : u)];
             const f32x4 xlo = __builtin_bit_cast(f32x4, an.v[i == 0 ? 2 : 0]);
@@ -1616,11 +1635,11 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
               const int term = g / NJ, jj = g % NJ;      // consecutive MFMAs go to DIFFERENT accumulators; small terms first
               if (FULL || piece0 < kpieces) {            // (uniform) a k-step wholly past the end of the row multiplies nothing
                 if (term == 0)
-                  acc[hf][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[e & 1], bq[1][jj], acc[hf][jj], 0, 0, 0);
+                  acc[1][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[e & 1], bq[1][jj], acc[1][jj], 0, 0, 0);
                 else if (term == 1)
-                  acc[hf][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl[e & 1], bq[0][jj], acc[hf][jj], 0, 0, 0);
+                  acc[1][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl[e & 1], bq[0][jj], acc[1][jj], 0, 0, 0);
                 else
-                  acc[hf][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[e & 1], bq[0][jj], acc[hf][jj], 0, 0, 0);
+                  acc[0][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh[e & 1], bq[0][jj], acc[0][jj], 0, 0, 0);
               }
               // behind MFMA g: stages [g * 12 / NM, (g + 1) * 12 / NM) of the next k-step's split, and one or two of
               // its 2 NJ fragment reads
@@ -1629,11 +1648,11 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
                 const int pr = st / 3;                   // element pair pr: elements 2 pr, 2 pr + 1 of the 8
                 if (st % 3 == 0) {
                   const f32x2 x = pr < 2 ? f32x2{xlo[2 * pr], xlo[2 * pr + 1]} : f32x2{xhi[2 * pr - 4], xhi[2 * pr - 3]};
-                  xs[pr] = x * scn;                                       // exact: a power of two
+                  xs[pr] = x * sc0;                                       // exact: a power of two
                 } else if (st % 3 == 1) {
                   const h16x2 hb = __builtin_convertvector(xs[pr], h16x2);  // round to nearest
                   hw[pr] = __builtin_bit_cast(uint32_t, hb);
-                  xs[pr] = xs[pr] - __builtin_convertvector(hb, f32x2);     // exact
+                  xs[pr] = (xs[pr] - __builtin_convertvector(hb, f32x2)) * 2048.f;   // exact difference, exact scaling
                 } else {
                   lw[pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(xs[pr], h16x2));
                 }
@@ -1666,10 +1685,9 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
       // copy waiting for its load (s_waitcnt vmcnt(0) at the top of every tile)
       auto out_row = [&](const int r, float (&o)[NJ]) {
         const int rho = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        const float r0 = __shfl(rinv0, rho, 64), r1 = __shfl(rinv1, rho, 64);   // lane rho (< 32) holds row rho's 1 / scales
+        const float r0 = __shfl(rinv0, rho, 64);   // lane rho (< 32) holds row rho's 1 / scale
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
-          o[jj] = (kH2Halves == 2 ? __builtin_fmaf(acc[kH2Halves - 1][jj][r], r1, acc[0][jj][r] * r0) : acc[0][jj][r] * r0) * cinv[jj];
+        for (int jj = 0; jj < NJ; ++jj) o[jj] = __builtin_fmaf(acc[1][jj][r], 0x1p-11f, acc[0][jj][r]) * r0 * cinv[jj];
       };
       if (whole) {
         // (addresses from ONE base: sixteen 64-bit row pointers held at once cost 32 VGPRs this kernel does not have)
@@ -2040,7 +2058,7 @@ MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool ne
   if (forward && elem == 4) {
     const size_t kp = (K + 7) / 8 * 8, rows = static_cast<size_t>(num_rel) * N;
     const size_t x3 = static_cast<size_t>(3) * rows * kp * 2;                                        // three bf16 planes
-    const size_t h2 = align256(static_cast<size_t>(2) * rows * kp * 2) + align256(sizeof(float) * rows) + 256;  // two fp16 planes, 1 / column scale, flags
+    const size_t h2 = align256(static_cast<size_t>(2) * rows * kp * 2) + align256(sizeof(float) * rows) + 256 + 16 * 4096;  // two fp16 planes, 1 / column scale, flags, correction list (kH2FixCap entries)
     off = align256(off + std::max(x3, h2));
   }
   s.off_acc = off;
@@ -2170,9 +2188,11 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
       hp.colinv = colinv;
       hp.flags = flags;
       hp.tile32_off = wp.tile32_off;
-      DGLA_CHECK_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(uint32_t), s));
+      DGLA_CHECK_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), s));
+      H2Fix* fix = reinterpret_cast<H2Fix*>(reinterpret_cast<char*>(flags) + 256);
+      hp.fix = fix;
       hipLaunchKernelGGL(h2_prep_weights_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((rows + 3) / 4, 4096))), dim3(256), 0, s,
-                         static_cast<const float*>(p.bt), const_cast<_Float16*>(hp.planes), colinv, flags, rows, p.K, hp.kp);
+                         static_cast<const float*>(p.bt), const_cast<_Float16*>(hp.planes), colinv, flags, fix, rows, N, p.K, hp.kp);
       const int nj = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
       hp.ncg = (N + 32 * nj - 1) / (32 * nj);
       const int groups = std::max(1, cus / 8 / hp.ncg);
@@ -2202,6 +2222,7 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
       }
 #undef DGLA_H2
 #undef DGLA_H2I
+      hipLaunchKernelGGL(h2_fix_weights_kernel, dim3(static_cast<unsigned>(2 * cus)), dim3(256), 0, s, p, flags, fix);  // idle unless a weight element was too small for its column
       DGLA_CHECK_HIP(hipGetLastError());
       return 0;
     }
