@@ -732,10 +732,18 @@ def softmax_gather_pos_forward(rel, score, edge_map):
     return out
 
 
+# Below this many edges the plain edge softmax reads AND writes through the map in one kernel: the extra gather pass of
+# the position route is a launch of its own, and at GAT-on-arxiv size (2.5 M edges) launches are what a step is made
+# of (forward 0.110 ms in one kernel against 0.163 ms as kernel + gather; at 62 M edges 4.58 against 3.8 ms).
+PLAIN_SOFTMAX_POS_MIN_EDGES = 1 << 23
+
+
 def plain_softmax_route(rel, score):
     """May a PLAIN edge softmax on ``rel`` keep its result in position order internally?  (A CSC with an edge-id
-    map, built once and kept: not a sampled block; a feature length the merge-path kernels take.)"""
-    if rel.transient or not rel.allowed("csc") or not score.is_cuda or rel.num_edges == 0 or score.numel() == 0:
+    map, built once and kept: not a sampled block; a feature length the merge-path kernels take; enough edges for
+    the scattered write it saves to outweigh the gather launch it adds.)"""
+    if rel.transient or not rel.allowed("csc") or not score.is_cuda or rel.num_edges < max(PLAIN_SOFTMAX_POS_MIN_EDGES, 1) \
+            or score.numel() == 0:
         return False
     if rel.csc()[2] is None:
         return False

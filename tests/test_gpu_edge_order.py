@@ -357,13 +357,14 @@ def test_softmax_backward_with_the_saved_softmax_in_position_order(dev, idtype, 
 
 @pytest.mark.parametrize("norm_by", ["dst", "src"])
 @pytest.mark.parametrize("shape", [(), (8, 1), (3,)])
-def test_plain_edge_softmax_keeps_position_order_to_itself(dev, shape, norm_by):
+def test_plain_edge_softmax_keeps_position_order_to_itself(dev, shape, norm_by, monkeypatch):
     """The default (plain) ``dgl.edge_softmax`` behind an edge-id map: forward and gradient equal the dense evaluation
     and the map-through route it replaces, nothing but plain tensors leaves, the saved tensor is the position-ordered one."""
     import dgl_amd as dgl
     from dgl_amd import autograd, edge_order as E
     from dgl_amd.sparse_kernels import _edge_softmax_backward, _edge_softmax_forward
 
+    monkeypatch.setattr(E, "PLAIN_SOFTMAX_POS_MIN_EDGES", 0)     # (the route is reserved for large graphs: force it here)
     g = _graph(dev, n=2500, e=50000, seed=8)
     rel = g._graph.relations[0] if norm_by == "dst" else g._graph.reverse().relations[0]
     assert rel.csc()[2] is not None
