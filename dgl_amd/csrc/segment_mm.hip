@@ -2193,19 +2193,23 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
       hp.fix = fix;
       hipLaunchKernelGGL(h2_prep_weights_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((rows + 3) / 4, 4096))), dim3(256), 0, s,
                          static_cast<const float*>(p.bt), const_cast<_Float16*>(hp.planes), colinv, flags, fix, rows, N, p.K, hp.kp);
-      const int nj = N <= 32 ? 1 : (N <= 64 ? 2 : 4);
+      const int full = (p.K == 256) ? 8 : (p.K == 128 ? 4 : (p.K == 64 ? 2 : 0));   // K = a whole number of lines the kernel is specialised for (the usual hidden sizes)
+      // (the generic form — K, lines and pieces at run time — keeps 64 columns per workgroup: with 128 its two accumulator
+      // sets and the guards' live values spill to scratch; tools/isa_audit.py holds this file to zero scratch instructions)
+      const int nj = N <= 32 ? 1 : ((N <= 64 || full == 0) ? 2 : 4);
       hp.ncg = (N + 32 * nj - 1) / (32 * nj);
       const int groups = std::max(1, cus / 8 / hp.ncg);
       const dim3 grid(static_cast<unsigned>(groups * hp.ncg * 8));
       const dim3 block(64 * kH2Waves);
-      const int full = (p.K == 256) ? 8 : (p.K == 128 ? 4 : 0);   // K = a whole number of lines the kernel is specialised for
 #define DGLA_H2I(NJV, IDX)                                                                            \
   do {                                                                                                \
     if (full == 8)                                                                                    \
       hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 8>), grid, block, 0, s, hp);                  \
     else if (full == 4)                                                                               \
       hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 4>), grid, block, 0, s, hp);                  \
-    else                                                                                              \
+    else if (full == 2)                                                                               \
+      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 2>), grid, block, 0, s, hp);                  \
+    else if constexpr (NJV <= 2)                                                                      \
       hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 0>), grid, block, 0, s, hp);                  \
   } while (0)
 #define DGLA_H2(NJV)                                                                                  \
