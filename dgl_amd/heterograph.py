@@ -796,10 +796,16 @@ def _as_index(x, idtype, device):
 
 def graph(data, num_nodes=None, idtype=None, device=None):
     """Homogeneous graph from ``(src, dst)`` or a list of ``(u, v)`` pairs (dgl.graph)."""
-    if isinstance(data, list) and (len(data) == 0 or (len(data) != 2 or all(
-            isinstance(p, (tuple, list)) and len(p) == 2 and not isinstance(p[0], (list, tuple, torch.Tensor))
-            for p in data)) and all(isinstance(p, (tuple, list)) and len(p) == 2 for p in data)):
-        data = ([p[0] for p in data], [p[1] for p in data])       # list of pairs (possibly empty)
+    if isinstance(data, list):
+        # the reference takes a LIST as (u, v) pairs and a TUPLE as (src ids, dst ids); a two-element list whose
+        # elements are themselves id sequences / tensors is read as (src ids, dst ids) too
+        def is_scalar_pair(p):
+            return isinstance(p, (tuple, list)) and len(p) == 2 and not isinstance(p[0], (list, tuple, torch.Tensor)) \
+                and not isinstance(p[1], (list, tuple, torch.Tensor))
+        if len(data) == 0 or all(is_scalar_pair(p) for p in data):
+            data = ([p[0] for p in data], [p[1] for p in data])
+        elif len(data) != 2:
+            raise DGLAMDError("dgl.graph: expected (src ids, dst ids) or a list of (u, v) pairs")
     u, v = data
     if idtype is None:
         idtype = u.dtype if isinstance(u, torch.Tensor) and u.dtype in (torch.int32, torch.int64) else torch.int64
