@@ -14,6 +14,7 @@ from . import ops  # noqa: E402,F401
 from .heterograph import (DGLGraph, ETYPE, NTYPE, create_block, from_networkx, graph, heterograph,  # noqa: E402,F401
                           rand_bipartite, rand_graph, reverse, to_heterogeneous, to_homogeneous)
 from . import udf  # noqa: E402,F401
+from . import nn  # noqa: E402,F401
 from . import sampling  # noqa: E402,F401
 from . import sparse  # noqa: E402,F401
 from .ops import edge_softmax  # noqa: E402,F401
