@@ -5,8 +5,8 @@ Timing A/B (one run, HIP events):
   shared    8 relations gather from ONE 5-GB table (what bench_ops measures; R-GCN's layer input is one node type)
   distinct  8 relations, 8 tables (41 GB): the address-translation hypothesis of DESIGN §3.2 predicts a slowdown
   single    the SAME 100 M edges as one relation through the plain merge-path kernel (no relation byte, no
-            pointer table in LDS): what stacking itself costs
-  single_f32acc  ... (the same launch with F halved / doubled would change the row length: not here)
+            pointer table in LDS): what stacking itself costs; plus the XCD unit order toggled, and fp32 rows of the
+            same BYTE length (F = 128): is it the bf16 arithmetic or the memory system?
 PMC mode (--mode X --pmc): runs only the timed launch of that mode a few times, for `rocprofv3 --pmc ...`.
 """
 import argparse

@@ -1710,6 +1710,7 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
           } else {
             __builtin_nontemporal_store(o[0], dst);
           }
+          __builtin_amdgcn_sched_barrier(0);   // one row at a time: hoisting all 2 x 64 accumulator reads is 128 VGPRs over the ring's 128
         }
       } else {
 #pragma unroll
