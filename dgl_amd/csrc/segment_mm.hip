@@ -1298,25 +1298,31 @@ if constexpr (PIPE) {
 // scaling, one fma per output element).  Three MFMAs per 16 k as before.
 // What the split is still not trusted with (kH2Spread = 28 binades, any K):
 //   * a ROW of A whose non-zero magnitudes span more, or whose maximum is Inf or outside 2^+-60 (the unscaling could
-//     over- or underflow on the way): the wave recomputes it as the plain fp32 dot product right after the tile (lanes
-//     split K, coalesced weight rows, butterfly sum; Inf / NaN as IEEE arithmetic gives them) — for continuous data one
-//     row in 10^6 (2.5 G elements x 2^-28);
+//     over- or underflow on the way): the main kernel writes it down in a short list and h2_exact_rows_kernel, launched
+//     behind it and idle unless the list is non-empty, overwrites the row with the plain fp32 dot product (lanes split
+//     K, coalesced weight rows, butterfly sum; Inf / NaN as IEEE arithmetic gives them) — for continuous data one row
+//     in 10^6 (2.5 G elements x 2^-28).  A list that overflows makes that kernel go over every row and apply the same
+//     test itself.  (Through round 5's first form the wave recomputed such rows in place, right after the tile: the
+//     rare path's loops then shared the register allocation of the main loop, which parked 36 registers of the ring in
+//     AGPRs — every such copy waits for its load.)
 //   * single weight ELEMENTS more than 2^28 below their column's maximum: zeroed in the planes and kept in a short
 //     list (relation, k, column, value); h2_fix_weights_kernel, launched behind the main kernel and idle unless the
 //     list is non-empty, adds a[row][k] * value to the outputs of that relation's rows in fp32.  A list that overflows,
-//     or a column whose maximum is Inf / outside 2^+-60, raises the flag that sends every row down the exact path.
+//     or a column whose maximum is Inf / outside 2^+-60, raises the flag that makes h2_exact_rows_kernel redo every row.
 // 128 columns per workgroup (2 planes x 128 x 528 B = 132 KB of LDS), so N = 256 reads A through two column groups
 // instead of X3's four.  DGLA_TUNE_MM_X3 selects the three-term kernels instead.
 constexpr int kH2Spread = 28;          // binades between a row's / column's maximum and the smallest magnitude the split keeps exact to 2^-21
 constexpr int kH2FixCap = 4096;        // weight elements below that the correction list holds
+constexpr int kH2RowCap = 16384;       // rows of A the exact-row list holds
 constexpr int kH2MinExp = 127 - 60, kH2MaxExp = 127 + 60;   // biased exponent range of a row / column maximum
 
 struct H2Params {
   MmParams m;
   const _Float16* planes;    // [2][R * N][kp] fp16 (h, l) of the scaled, K-contiguous weights; zero padded
   const float* colinv;       // [R * N] 1 / column scale
-  uint32_t* flags;           // [0] != 0: the weights cannot be split -> every row takes the exact path; [1]: exact rows (statistics); [2]: entries in `fix`
+  uint32_t* flags;           // [0] != 0: the weights cannot be split -> every row is recomputed exactly; [1]: rows listed in `rows` (more than kH2RowCap: overflow); [2]: entries in `fix`
   struct H2Fix* fix;         // [kH2FixCap] weight elements too small for their column's scale (zeroed in the planes)
+  struct H2Row* rows;        // [kH2RowCap] rows of A the split is not trusted with
   const int64_t* tile32_off; // [R + 1] exclusive prefix of ceil(len / 32)
   int ncg;                   // column groups (workgroups sharing a row chunk)
   int kp;                    // row pitch of the planes in elements (K rounded up to 8)
@@ -1325,6 +1331,10 @@ struct H2Params {
 struct H2Fix {
   int rel, k, n;
   float value;
+};
+struct H2Row {
+  int64_t row;   // physical row of A and C
+  int64_t rel;
 };
 
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
@@ -1421,6 +1431,77 @@ __global__ __launch_bounds__(256) void h2_fix_weights_kernel(const MmParams p, c
   }
 }
 
+// Rows of A the split is not trusted with: out[row][:] = the plain fp32 dot products.  One wave per row; lanes split K
+// — every weight row is one coalesced read of up to 1 KB — and a butterfly adds the 64 partial sums (a first version
+// gave every lane its own column and walked k: 64 cache lines per load, 50 us per row).  Idle — two loads per thread —
+// unless the main kernel listed a row.  With flags[0] set (weights that cannot be split) or a list that overflowed it
+// goes over EVERY row instead; after an overflow it applies the main kernel's own test to each.
+__global__ __launch_bounds__(256) void h2_exact_rows_kernel(const MmParams p, const uint32_t* __restrict__ flags,
+                                                            const H2Row* __restrict__ rows) {
+  const bool all = flags[0] != 0u;
+  const uint32_t listed = flags[1];
+  if (!all && listed == 0u) return;
+  const bool scan = all || listed > static_cast<uint32_t>(kH2RowCap);
+  const int lane = threadIdx.x & 63;
+  const int K = p.K, N = p.N;
+  const int64_t* row_off = p.plan + p.num_rel + 1;
+  const float* A = static_cast<const float*>(p.a);
+  const float* Bt = static_cast<const float*>(p.bt);
+  float* C = static_cast<float*>(p.c);
+  const int64_t nw = static_cast<int64_t>(gridDim.x) * (blockDim.x >> 6);
+  const int64_t count = scan ? row_off[p.num_rel] : static_cast<int64_t>(listed);
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x >> 6) + (threadIdx.x >> 6); i < count; i += nw) {
+    int64_t pr, rel;
+    if (scan) {
+      rel = find_segment(row_off, p.num_rel, i);
+      pr = p.row_index ? p.row_index[i] : i;
+    } else {
+      pr = rows[i].row;
+      rel = rows[i].rel;
+    }
+    const float* __restrict__ arow = A + pr * K;
+    float av[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) av[j] = 4 * lane + j < K ? arow[4 * lane + j] : 0.f;
+    if (scan && !all) {  // the main kernel's test (its list overflowed)
+      float fmax_ = 0.f;
+      uint32_t kmin = 0xffffffffu;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        fmax_ = __builtin_fmaxf(fmax_, __builtin_fabsf(av[j]));
+        const uint32_t k = (__builtin_bit_cast(uint32_t, av[j]) << 1) - 1u;
+        kmin = k < kmin ? k : kmin;
+      }
+      H2Range rg{__builtin_bit_cast(uint32_t, fmax_), kmin};
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t om = __shfl_xor(rg.amax, d, 64), ok = __shfl_xor(rg.kmin, d, 64);
+        rg.amax = om > rg.amax ? om : rg.amax;
+        rg.kmin = ok < rg.kmin ? ok : rg.kmin;
+      }
+      float sc, inv;
+      if (!h2_scale(rg, sc, inv)) continue;
+    }
+    for (int c0 = 0; c0 < N; c0 += 4) {
+      float part[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = c0 + q < N ? c0 + q : N - 1;
+        const float* __restrict__ brow = Bt + (rel * N + n) * static_cast<int64_t>(K);
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sacc = __builtin_fmaf(av[j], 4 * lane + j < K ? brow[4 * lane + j] : 0.f, sacc);
+        part[q] = sacc;
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part[q] += __shfl_xor(part[q], d, 64);
+      if (lane < 4 && c0 + lane < N) C[pr * N + c0 + lane] = part[lane & 3];
+    }
+  }
+}
+
 // 8 floats of a row (two 16-byte pieces) -> the MFMA fragments of their two fp16 terms
 __device__ __forceinline__ void split2(const f32x4 lo4, const f32x4 hi4, const float s, h16x8& h, h16x8& l) {
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -1448,7 +1529,9 @@ constexpr int kH2Waves = 4;
 // form (NSS = 0: K, the number of lines and of weight pieces at run time) keeps uniform branches around every MFMA, LDS
 // read and refill; the compiler then neither interleaves the split with the MFMAs nor keeps the guards in scalar
 // registers (200 SGPRs spilled through v_writelane inside the loop): 6.3 ms against the specialised form's time.
-template <int NJ, bool INDEXED, int NSS>
+// COLW: N is a multiple of the workgroup's 32 NJ columns — the store loop then has no predicate at all (a per-lane
+// `column < N` around the stores was enough for the compiler to park 40 ring registers in AGPRs again).
+template <int NJ, bool INDEXED, int NSS, bool COLW>
 __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Params hp) {
   constexpr bool FULL = NSS > 0;
   const MmParams& p = hp.m;
@@ -1474,7 +1557,6 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
   if (group >= ngroups) return;
   const int64_t T = tile_off[p.num_rel];
   const int n0 = cg * 32 * NJ;
-  const bool all_exact = __builtin_amdgcn_readfirstlane(static_cast<int>(hp.flags[0])) != 0;
 
   const char* __restrict__ A = static_cast<const char*>(p.a);
   const float* __restrict__ Bt = static_cast<const float*>(p.bt);
@@ -1551,6 +1633,11 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
     ASlot ar[NS];
 #pragma unroll
     for (int u = 0; u < NS; ++u) ar[u] = load_slot(cur, u, u < nss);
+    // (the first row is waited for HERE, through a use of every load: at the loop header the compiler merges what
+    // is outstanding on the way in with what is on the back edge — 16 stores younger than the ring — and with 32 fresh
+    // loads on the way in it drained the counter at the top of EVERY tile, stores included)
+#pragma unroll
+    for (int u = 0; u < NS; ++u) asm volatile("" ::"v"(ar[u].v[0]), "v"(ar[u].v[1]), "v"(ar[u].v[2]), "v"(ar[u].v[3]));
     for (int64_t tt = first; tt < rel_end; tt += kH2Waves) {
       const bool more = tt + kH2Waves < rel_end;
       const char* nxt = more ? row_ptr(tt + kH2Waves) : cur;
@@ -1583,7 +1670,7 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
         rg.kmin = ok < rg.kmin ? ok : rg.kmin;
       }
       float sc0, rinv0;
-      const bool row_bad = h2_scale(rg, sc0, rinv0) || all_exact;
+      const bool row_bad = h2_scale(rg, sc0, rinv0);
       const int64_t trow0 = rel_row0 + (tt - rel_t0) * 32;
 
       // ---- scaled, split, multiplied: slot by slot, each refilled with the next tile's line behind its k-steps ------
@@ -1671,15 +1758,17 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- epilogue: undo the scales (exact), registers -> global, NJ consecutive columns per lane ----------------
-      // rows of the tile that take the exact path (bit rho = row trow0 + rho; rows past the segment's end are clamped copies)
-      uint32_t badmask = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(row_bad && khalf == 0));
-      {
-        const int64_t left = row_end - uniform64(trow0);
-        if (left < 32) badmask &= (1u << left) - 1u;
+      // rows the split is not trusted with go on the list (lane l < 32 holds row trow0 + l; rows past the segment's
+      // end are clamped copies); what is stored for them below is overwritten by h2_exact_rows_kernel
+      if (row_bad && khalf == 0 && cg == 0 && trow0 + l < row_end) {
+        const uint32_t at = atomicAdd(hp.flags + 1, 1u);
+        if (at < static_cast<uint32_t>(kH2RowCap)) {
+          int64_t pr = trow0 + l;
+          if constexpr (INDEXED) pr = p.row_index[pr];
+          hp.rows[at] = H2Row{pr, rel};
+        }
       }
-      badmask = __builtin_amdgcn_readfirstlane(badmask);
       const int col = n0 + NJ * l;
-      const bool whole = uniform64(trow0) + 32 <= row_end && n0 + 32 * NJ <= N && badmask == 0u;
       // one output row-register at a time: 2 NJ accumulator reads, the two exact unscalings, one store — computing the
       // whole tile first held 64 more VGPRs over the ring's 128 and the compiler parked ring registers in AGPRs, each
       // copy waiting for its load (s_waitcnt vmcnt(0) at the top of every tile)
@@ -1689,18 +1778,25 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) o[jj] = __builtin_fmaf(acc[1][jj][r], 0x1p-11f, acc[0][jj][r]) * r0 * cinv[jj];
       };
-      if (whole) {
-        // (addresses from ONE base: sixteen 64-bit row pointers held at once cost 32 VGPRs this kernel does not have)
-        float* const cbase = C + (trow0 + 4 * khalf) * N + col;
+      // A segment's last tile needs no predicate: its rows past the end were READ as copies of the last row (row_ptr
+      // clamps), so their accumulators hold the last row's result bit for bit, and they are STORED to the last row as
+      // well — several lanes writing one value to one address.  One store path for whole and ragged tiles: a second,
+      // predicated path here (and the exact-row loops behind it, through round 5's first form) shared the main loop's
+      // register allocation and cost it 36 ring registers parked in AGPRs.
+      const int last = static_cast<int>(uniform64(row_end - trow0 < 32 ? row_end - trow0 : 32)) - 1;
+      auto row_of = [&](const int r) -> int64_t {
+        const int rho = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        int64_t row = trow0 + (rho < last ? rho : last);
+        if constexpr (INDEXED) row = p.row_index[row];
+        return row;
+      };
+      const bool vec = COLW || col + NJ <= N;    // (all lanes but those of the last column group of a ragged N)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float o[NJ];
-          out_row(r, o);
-          float* dst;
-          if constexpr (INDEXED)
-            dst = C + p.row_index[trow0 + (r & 3) + 8 * (r >> 2) + 4 * khalf] * N + col;
-          else
-            dst = cbase + static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * N;
+      for (int r = 0; r < 16; ++r) {
+        float o[NJ];
+        out_row(r, o);
+        float* dst = C + row_of(r) * N + col;
+        if (vec) {
           if constexpr (NJ == 4) {
             const f32x4 w = {o[0], o[1], o[2], o[3]};
             __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(dst));
@@ -1710,57 +1806,12 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
           } else {
             __builtin_nontemporal_store(o[0], dst);
           }
-          __builtin_amdgcn_sched_barrier(0);   // one row at a time: hoisting all 2 x 64 accumulator reads is 128 VGPRs over the ring's 128
+        } else if constexpr (NJ > 1) {            // the lane that straddles column N
+#pragma unroll
+          for (int jj = 0; jj < NJ - 1; ++jj)
+            if (col + jj < N) dst[jj] = o[jj];
         }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rho = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-          const int64_t row = trow0 + rho;
-          float o[NJ];
-          out_row(r, o);
-          if (row >= row_end || ((badmask >> rho) & 1u)) continue;
-          int64_t pr = row;
-          if constexpr (INDEXED) pr = p.row_index[row];
-#pragma unroll
-          for (int jj = 0; jj < NJ; ++jj)
-            if (col + jj < N) C[pr * N + col + jj] = o[jj];
-        }
-        // ---- rows the split is not trusted with: the fp32 dot product IEEE arithmetic defines, column pairs per lane ----
-        if (badmask != 0u && lane == 0 && cg == 0) atomicAdd(hp.flags + 1, static_cast<uint32_t>(__builtin_popcount(badmask)));
-        // (lanes split K — every weight row is one coalesced 1 KB read — and a butterfly adds the 64 partial sums: a
-        // first version gave every lane its own column and walked k: 64 cache lines per load, 50 us per row)
-        for (uint32_t m = badmask; m != 0u; m &= m - 1u) {
-          const int rho = __builtin_ctz(m);
-          int64_t pr = trow0 + rho;
-          if constexpr (INDEXED) pr = p.row_index[pr];
-          const float* __restrict__ arow = reinterpret_cast<const float*>(A + pr * (static_cast<int64_t>(K) * ES));
-          float av[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) av[j] = 4 * lane + j < K ? arow[4 * lane + j] : 0.f;
-          const int ncols = (N - n0) < 32 * NJ ? (N - n0) : 32 * NJ;
-          for (int c0 = 0; c0 < ncols; c0 += 4) {
-            float part[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int n = n0 + (c0 + q < ncols ? c0 + q : ncols - 1);
-              const float* __restrict__ brow = Bt + (rel * N + n) * static_cast<int64_t>(K);
-              float sacc = 0.f;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) sacc = __builtin_fmaf(av[j], 4 * lane + j < K ? brow[4 * lane + j] : 0.f, sacc);
-              part[q] = sacc;
-            }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) part[q] += __shfl_xor(part[q], d, 64);
-            if (lane < 4 && c0 + lane < ncols) C[pr * N + n0 + c0 + lane] = part[lane & 3];
-          }
-        }
-        // (rare path: wait for the whole ring here — through a USE of the youngest load, which the compiler models —
-        // so that behind the join the counts are those of the usual path above: 16 stores younger than the ring, and
-        // the top of the next tile waits with a COUNT instead of draining everything)
-        asm volatile("" ::"v"(ar[NS - 1].v[0]), "v"(ar[NS - 1].v[1]), "v"(ar[NS - 1].v[2]), "v"(ar[NS - 1].v[3]));
+        __builtin_amdgcn_sched_barrier(0);   // one row at a time: hoisting all 2 x 64 accumulator reads is 128 VGPRs over the ring's 128
       }
       cur = nxt;
     }
@@ -2059,7 +2110,7 @@ MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool ne
   if (forward && elem == 4) {
     const size_t kp = (K + 7) / 8 * 8, rows = static_cast<size_t>(num_rel) * N;
     const size_t x3 = static_cast<size_t>(3) * rows * kp * 2;                                        // three bf16 planes
-    const size_t h2 = align256(static_cast<size_t>(2) * rows * kp * 2) + align256(sizeof(float) * rows) + 256 + 16 * 4096;  // two fp16 planes, 1 / column scale, flags, correction list (kH2FixCap entries)
+    const size_t h2 = align256(static_cast<size_t>(2) * rows * kp * 2) + align256(sizeof(float) * rows) + 256 + 16 * 4096 + 16 * 16384;  // two fp16 planes, 1 / column scale, flags, correction list (kH2FixCap entries), exact-row list (kH2RowCap)
     off = align256(off + std::max(x3, h2));
   }
   s.off_acc = off;
@@ -2192,6 +2243,8 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
       DGLA_CHECK_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), s));
       H2Fix* fix = reinterpret_cast<H2Fix*>(reinterpret_cast<char*>(flags) + 256);
       hp.fix = fix;
+      H2Row* exact_rows = reinterpret_cast<H2Row*>(reinterpret_cast<char*>(fix) + sizeof(H2Fix) * kH2FixCap);
+      hp.rows = exact_rows;
       hipLaunchKernelGGL(h2_prep_weights_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((rows + 3) / 4, 4096))), dim3(256), 0, s,
                          static_cast<const float*>(p.bt), const_cast<_Float16*>(hp.planes), colinv, flags, fix, rows, N, p.K, hp.kp);
       const int full = (p.K == 256) ? 8 : (p.K == 128 ? 4 : (p.K == 64 ? 2 : 0));   // K = a whole number of lines the kernel is specialised for (the usual hidden sizes)
@@ -2202,16 +2255,23 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
       const int groups = std::max(1, cus / 8 / hp.ncg);
       const dim3 grid(static_cast<unsigned>(groups * hp.ncg * 8));
       const dim3 block(64 * kH2Waves);
-#define DGLA_H2I(NJV, IDX)                                                                            \
+#define DGLA_H2C(NJV, IDX, CW)                                                                        \
   do {                                                                                                \
     if (full == 8)                                                                                    \
-      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 8>), grid, block, 0, s, hp);                  \
+      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 8, CW>), grid, block, 0, s, hp);              \
     else if (full == 4)                                                                               \
-      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 4>), grid, block, 0, s, hp);                  \
+      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 4, CW>), grid, block, 0, s, hp);              \
     else if (full == 2)                                                                               \
-      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 2>), grid, block, 0, s, hp);                  \
-    else if constexpr (NJV <= 2)                                                                      \
-      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 0>), grid, block, 0, s, hp);                  \
+      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 2, CW>), grid, block, 0, s, hp);              \
+    else if constexpr (NJV <= 2 && !CW)                                                               \
+      hipLaunchKernelGGL((segment_mm_h2_kernel<NJV, IDX, 0, false>), grid, block, 0, s, hp);           \
+  } while (0)
+#define DGLA_H2I(NJV, IDX)                                                                            \
+  do {                                                                                                \
+    if (full != 0 && N % (32 * NJV) == 0)                                                             \
+      DGLA_H2C(NJV, IDX, true);                                                                       \
+    else                                                                                              \
+      DGLA_H2C(NJV, IDX, false);                                                                      \
   } while (0)
 #define DGLA_H2(NJV)                                                                                  \
   do {                                                                                                \
@@ -2227,7 +2287,9 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
       }
 #undef DGLA_H2
 #undef DGLA_H2I
+#undef DGLA_H2C
       hipLaunchKernelGGL(h2_fix_weights_kernel, dim3(static_cast<unsigned>(2 * cus)), dim3(256), 0, s, p, flags, fix);  // idle unless a weight element was too small for its column
+      hipLaunchKernelGGL(h2_exact_rows_kernel, dim3(static_cast<unsigned>(4 * cus)), dim3(256), 0, s, p, flags, exact_rows);  // idle unless a row was listed
       DGLA_CHECK_HIP(hipGetLastError());
       return 0;
     }

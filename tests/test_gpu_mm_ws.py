@@ -201,6 +201,46 @@ def test_h2_weight_column_that_cannot_be_split_sends_every_row_down_the_exact_pa
     assert not bool((err > _bound(a, b, seglen) + 2.0 ** -24 * want.abs()).any())
 
 
+@pytest.mark.parametrize("indexed", [False, True], ids=["rows-in-place", "row_index"])
+@pytest.mark.parametrize("n_wide", [300, 30000], ids=["listed", "list-overflows"])
+def test_h2_exact_row_list_and_its_overflow(n_wide, indexed):
+    """Rows the split is not trusted with are written down by the main kernel and recomputed by h2_exact_rows_kernel
+    behind it.  300 such rows fit its list; 30000 do not (16384 entries): the kernel then goes over every row and
+    applies the main kernel's test itself.  With ``row_index`` the list holds PHYSICAL rows."""
+    from dgl_amd import _capi
+    dev = torch.device("cuda:0")
+    seglen = torch.tensor([25000, 0, 14000, 1531], dtype=torch.int64)       # the last tiles of the segments are ragged
+    m, r, k, n = int(seglen.sum()), len(seglen), 256, 128
+    g = torch.Generator(device=dev).manual_seed(n_wide + int(indexed))
+    a = torch.randn(m, k, device=dev, generator=g)
+    b = torch.randn(r, k, n, device=dev, generator=g)
+    pick = torch.randperm(m, device=dev, generator=g)[:n_wide]
+    a[pick, 5] = 1e-14                                   # 2^-46 below the row's maximum: the row takes the exact path
+    a[pick[: n_wide // 3]] *= 1e22                       # ... and a third of them also leave 2^+-60
+    perm = torch.randperm(m, device=dev, generator=g) if indexed else None
+    if indexed:
+        phys_a = torch.empty_like(a)
+        phys_a[perm] = a                                 # logical row i lives at physical row perm[i]
+    else:
+        phys_a = a
+    c = torch.full((m, n), 7.0, device=dev)
+    _capi.segment_mm(phys_a, b, c, seglen, row_index=perm)
+    got = c[perm] if indexed else c
+    want = _want(a, b, seglen, False)
+    err = (got.double() - want).abs()
+    bad = err > _bound(a, b, seglen) + 2.0 ** -24 * want.abs() + 1e-45
+    assert not bool(bad.any()), (int(bad.sum()), int(bad.any(dim=1).sum()))
+    # the listed rows are the plain fp32 dot product: the element 2^-46 below the maximum is IN the sum (a one-hot weight
+    # column selecting it returns it exactly)
+    b2 = torch.zeros(r, k, n, device=dev)
+    b2[:, 5, 0] = 1.0
+    c2 = torch.empty(m, n, device=dev)
+    _capi.segment_mm(phys_a, b2, c2, seglen, row_index=perm)
+    got2 = (c2[perm] if indexed else c2)[:, 0]
+    assert torch.equal(got2[pick], a[pick, 5])
+    assert bool(((got2 - a[:, 5]).abs() <= 2.0 ** -21 * a[:, 5].abs()).all())
+
+
 def test_h2_is_the_default_and_x3_is_selectable():
     """DGLA_TUNE_MM_X3 keeps the three-bf16-term kernel; both agree to fp32 level, neither is the other's bits."""
     from dgl_amd import _capi
