@@ -23,7 +23,13 @@ from . import function as fn
 from ._lib import DGLAMDError
 from .ops import edge_softmax
 
-__all__ = ["GraphConv", "SAGEConv", "GATConv"]
+__all__ = ["GraphConv", "SAGEConv", "GATConv", "functional"]
+
+
+class functional:  # noqa: N801  (a namespace: python/dgl/nn/functional/__init__.py exports exactly this)
+    """``dgl.nn.functional``."""
+    edge_softmax = staticmethod(edge_softmax)
+
 
 _ZERO_IN_DEGREE = ("There are 0-in-degree nodes in the graph, output for those nodes will be invalid. This is harmful "
                    "for some applications, causing silent performance regression. Adding self-loop on the input graph "

@@ -34,6 +34,10 @@ FILES = [
     "utils/__init__.py", "utils/checks.py", "utils/graph_cases.py",
     "backend/__init__.py", "backend/backend_unittest.py", "backend/pytorch/__init__.py",
 ]
+SPARSE_FILES = ["python/pytorch/sparse/" + f for f in (
+    "__init__.py", "utils.py", "test_broadcast.py", "test_elementwise_op.py", "test_elementwise_op_sp.py", "test_matmul.py",
+    "test_matrix_op.py", "test_reduction.py", "test_sddmm.py", "test_softmax.py", "test_sparse_matrix.py",
+    "test_unary_op.py")]
 SELECT = {
     "python/common/ops/test_ops.py": ["test_spmm", "test_half_spmm", "test_sddmm", "test_segment_reduce",
                                       "test_segment_mm", "test_gather_mm_idx_b"],
@@ -44,11 +48,11 @@ SELECT = {
 
 
 def prepare(src):
-    for f in FILES:
+    for f in FILES + SPARSE_FILES:
         d = os.path.join(DEST, f)
         os.makedirs(os.path.dirname(d), exist_ok=True)
         shutil.copyfile(os.path.join(src, f), d)
-    print("copied %d files from %s to %s" % (len(FILES), src, DEST))
+    print("copied %d files from %s to %s" % (len(FILES + SPARSE_FILES), src, DEST))
 
 
 class _NxGraph:
@@ -104,6 +108,7 @@ def install_aliases():
     dgl.backend = shim_backend
     dgl.nn = types.ModuleType("dgl.nn")
     dgl.nn.__all__ = []
+    dgl.nn.functional = dgl_amd.nn.functional
     base = types.ModuleType("dgl.base")
     base.is_internal_column = lambda name: name.startswith("_")
     base.DGLError, base.NID, base.EID, base.NTYPE, base.ETYPE = dgl_amd.DGLError, "_ID", "_ID", "_TYPE", "_TYPE"
@@ -121,8 +126,15 @@ def install_aliases():
 
     dgl.seed = seed
     shim_backend.cuda = lambda: torch.device("cuda:0")
+    dgl.sparse = dgl_amd.sparse                       # one module here, a package of thin wrappers there
+    if not hasattr(dgl_amd.sparse, "__path__"):
+        dgl_amd.sparse.__path__ = []
+    for sub in ("matmul", "sparse_matrix", "sddmm", "softmax", "reduction", "elementwise_op", "elementwise_op_sp",
+                "broadcast", "unary_op"):
+        sys.modules["dgl.sparse." + sub] = dgl_amd.sparse
     for name, mod in (("dgl", dgl), ("dgl.backend", shim_backend), ("dgl.nn", dgl.nn), ("dgl.base", base),
-                      ("dgl.convert", convert), ("dgl.ops", ops), ("dgl.function", dgl_amd.function)):
+                      ("dgl.convert", convert), ("dgl.ops", ops), ("dgl.function", dgl_amd.function),
+                      ("dgl.sparse", dgl_amd.sparse)):
         sys.modules[name] = mod
     return _install_networkx_stub()
 
@@ -143,6 +155,8 @@ def main():
     ap.add_argument("--src", default="/root/reference/tests")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ref_suite.jsonl"))
     ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"])
+    ap.add_argument("--suite", default="ops", choices=["ops", "sparse"],
+                    help="ops: the operator suites (SELECT); sparse: tests/python/pytorch/sparse/*, every test")
     ap.add_argument("-k", default=None)
     ap.add_argument("--maxfail", type=int, default=0)
     args = ap.parse_args()
@@ -160,9 +174,12 @@ def main():
 
     rep = _Report(args.out)
     targets = []
-    for f, names in SELECT.items():
-        for n in names:
-            targets.append("%s::%s" % (os.path.join(DEST, f), n))
+    if args.suite == "sparse":
+        targets = [os.path.join(DEST, f) for f in SPARSE_FILES if os.path.basename(f).startswith("test_")]
+    else:
+        for f, names in SELECT.items():
+            for n in names:
+                targets.append("%s::%s" % (os.path.join(DEST, f), n))
     t0 = time.time()
     extra = ["-k", args.k] if args.k else []
     if args.maxfail:
