@@ -16,6 +16,7 @@ from .heterograph import (DGLGraph, ETYPE, NTYPE, create_block, from_networkx, g
 from . import udf  # noqa: E402,F401
 from . import nn  # noqa: E402,F401
 from . import sampling  # noqa: E402,F401
+from . import dataloading  # noqa: E402,F401
 from . import sparse  # noqa: E402,F401
 from .ops import edge_softmax  # noqa: E402,F401
 from .sampling import EID, NID, NeighborSampler, to_block  # noqa: E402,F401

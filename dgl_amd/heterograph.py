@@ -471,7 +471,7 @@ class DGLGraph:
             last_rfunc = rfunc
             g = self[etype]
             cet = self.to_canonical_etype(etype)
-            d = self.get_ntype_id(cet[2])
+            d = self.get_ntype_id_from_dst(cet[2])     # (on a block the destination side has its own node frames)
             nd = _udf.message_passing(g, mfunc, rfunc, afunc, _message_passing)
             for k, v in nd.items():
                 collected.setdefault((d, k), []).append((self.get_etype_id(etype), v))

@@ -1,11 +1,13 @@
 """Uniform neighbour sampling and message-flow blocks for mini-batch training.
 
-Mirror of ``dgl.sampling.sample_neighbors`` (python/dgl/sampling/neighbor.py:222-395, uniform /
-single relation / edge_dir='in'), ``dgl.to_block`` (python/dgl/transforms/functional.py) and
-``dgl.dataloading.NeighborSampler.sample_blocks`` (python/dgl/dataloading/neighbor_sampler.py):
-the steps that run in front of the g-SpMM for every mini-batch of GraphSAGE (BASELINE config 4).
-The kernels are in csrc/sampling.hip; the blocks come out with their in-edge CSR already
-built (rows = seeds), i.e. in the format the SpMM consumes — no COO round trip.
+Mirror of ``dgl.sampling.sample_neighbors`` (python/dgl/sampling/neighbor.py:222-395), ``dgl.to_block``
+(python/dgl/transforms/functional.py) and ``dgl.dataloading.NeighborSampler.sample_blocks``
+(python/dgl/dataloading/neighbor_sampler.py): the steps that run in front of the g-SpMM for every
+mini-batch of GraphSAGE (BASELINE config 4).  The kernels are in csrc/sampling.hip; the blocks come out
+with their in-edge CSR already built (rows = seeds), i.e. in the format the SpMM consumes — no COO
+round trip.  Graphs with several relations (round 5): ``nodes`` / ``fanout`` / ``dst_nodes`` are given per
+node / edge type as in the reference, every relation goes through the same two kernels, and a
+block keeps one source and one destination node set per node type (R-GCN mini-batches).
 """
 import torch
 
@@ -24,13 +26,97 @@ def _csc_of(g):
     return rel, _capi.make_csr(indptr, indices, eids, rel.num_src), (indptr, indices, eids)
 
 
-def _node_map(g, device):
-    """Per-graph dense node -> local-id scratch (int32, all -1 between calls)."""
-    m = getattr(g, "_sampling_node_map", None)
+def _node_map(g, device, ntid=None):
+    """Per-graph (per node type) dense node -> local-id scratch (int32, all -1 between calls)."""
+    if ntid is None:
+        m = getattr(g, "_sampling_node_map", None)
+        if m is None or m.device != device:
+            m = torch.full((g.num_nodes(),), -1, dtype=torch.int32, device=device)
+            g._sampling_node_map = m
+        return m
+    maps = g.__dict__.setdefault("_sampling_node_maps", {})
+    m = maps.get(ntid)
     if m is None or m.device != device:
-        m = torch.full((g.num_nodes(),), -1, dtype=torch.int32, device=device)
-        g._sampling_node_map = m
+        m = maps[ntid] = torch.full((max(1, g._graph.num_nodes(ntid)),), -1, dtype=torch.int32, device=device)
     return m
+
+
+def _prob_of(prob, frame, rel, who):
+    """The sampling weights of one relation as a contiguous float vector (None: uniform)."""
+    if prob is None:
+        return None
+    p = frame[prob] if isinstance(prob, str) else prob
+    # the kernels index `prob` by EDGE ID of g: anything else is an out-of-bounds device read
+    # (reference: CHECK on the probability array's length, src/array/array.cc RowWiseSampling)
+    if p.dim() == 0 or p.shape[0] != rel.num_edges or p.numel() != rel.num_edges:
+        raise _DGLError("%s: prob must hold one value per edge of the graph (%d), got shape %s"
+                        % (who, rel.num_edges, tuple(p.shape)))
+    p = p.to(rel.device)
+    return (p if p.dtype in (torch.float32, torch.float64) else p.float()).contiguous().reshape(-1)
+
+
+def _per_etype(g, value, what):
+    """``value`` (an int, or a dict keyed by edge type name / canonical edge type) -> one entry per relation."""
+    if not isinstance(value, dict):
+        return [value] * len(g.canonical_etypes)
+    out = []
+    for c in g.canonical_etypes:
+        if c in value:
+            out.append(value[c])
+        elif c[1] in value:
+            out.append(value[c[1]])
+        else:
+            raise _DGLError("%s is not given for edge type %s (a dict must name every edge type, neighbor.py:330-340)"
+                            % (what, (c,)))
+    return out
+
+
+def _sample_neighbors_hetero(g, nodes, fanout, edge_dir, prob, replace, seed):
+    """sample_neighbors on a graph with several relations (python/dgl/sampling/neighbor.py:300-395): relation by
+    relation through the same kernels; a relation whose seed side has no nodes in ``nodes``, or whose fanout is 0, comes
+    out empty.  The result keeps every node type and node count of ``g``."""
+    if not isinstance(nodes, dict):
+        if len(g.ntypes) != 1:
+            raise _DGLError("Must specify node type when the graph is not homogeneous.")
+        nodes = {g.ntypes[0]: nodes}
+    for n in nodes:
+        if n not in g.ntypes:
+            raise _DGLError('Node type "{}" does not exist.'.format(n))
+    fanouts = _per_etype(g, fanout, "fanout")
+    rels = []
+    picked = []
+    for etid, (s_t, _, d_t) in enumerate(g.canonical_etypes):
+        rel = g._graph.relations[etid]
+        dev, idt = rel.device, rel.idtype
+        seeds = nodes.get(d_t if edge_dir == "in" else s_t)
+        f = int(fanouts[etid])
+        if seeds is None or f == 0 or rel.num_edges == 0 or len(seeds) == 0:
+            empty = torch.empty(0, dtype=idt, device=dev)
+            rels.append(Relation(rel.num_src, rel.num_dst, empty, empty, idtype=idt, device=dev))
+            picked.append(empty)
+            continue
+        seeds = torch.as_tensor(seeds).to(device=dev, dtype=idt).contiguous()
+        fmt = rel.csc() if edge_dir == "in" else rel.csr()
+        csr = _capi.make_csr(fmt[0], fmt[1], fmt[2], rel.num_src if edge_dir == "in" else rel.num_dst)
+        p = _prob_of(prob, g._edge_frames[etid], rel, "sample_neighbors")
+        rng = int(seed) * 131 + etid
+        if p is None:
+            indptr, nbr, eids = _capi.sample_neighbors(csr, seeds, f, replace, rng)
+        else:
+            if f < 0:
+                raise ValueError("weighted sampling needs a positive fanout")
+            indptr, nbr, eids = _capi.sample_neighbors_weighted(csr, p, seeds, f, replace, rng)
+        n_e = int(indptr[-1])
+        own = torch.repeat_interleave(seeds, (indptr[1:] - indptr[:-1]).long(), output_size=n_e)
+        src, dst = (nbr[:n_e].contiguous(), own) if edge_dir == "in" else (own, nbr[:n_e].contiguous())
+        rels.append(Relation(rel.num_src, rel.num_dst, src, dst, idtype=idt, device=dev))
+        picked.append(eids[:n_e])
+    gi = g._graph
+    out = DGLGraph(GraphIndex([gi.num_nodes(i) for i in range(len(g._ntypes))], list(gi.metagraph.edges), rels),
+                   g._ntypes, g.canonical_etypes, src_ntypes=g._src_ntype_ids, dst_ntypes=g._dst_ntype_ids)
+    for etid, e in enumerate(picked):
+        out._edge_frames[etid][EID] = e
+    return out
 
 
 def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, seed=None):
@@ -45,16 +131,16 @@ def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, 
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     if edge_dir not in ("in", "out"):
         raise ValueError("edge_dir must be 'in' or 'out'")
-    if isinstance(prob, str):  # name of an edge feature, as in the reference
-        prob = g.edata[prob]
-    if len(g.canonical_etypes) != 1:
-        raise NotImplementedError("dgl_amd.sampling: single-relation graphs only")
+    if len(g.canonical_etypes) != 1 or isinstance(nodes, dict) or isinstance(fanout, dict):
+        return _sample_neighbors_hetero(g, nodes, fanout, edge_dir, prob, replace, seed)
     if edge_dir == "in":
         rel, csr, keep = _csc_of(g)
     else:  # outbound edges: the same kernel over the out-edge CSR (rows = source nodes)
         rel = g._graph.relations[0]
         keep = rel.csr()
         csr = _capi.make_csr(keep[0], keep[1], keep[2], rel.num_dst)
+    if isinstance(prob, str):  # name of an edge feature, as in the reference
+        prob = g.edata[prob]
     nodes = nodes.to(device=rel.device, dtype=rel.idtype).contiguous()
     if prob is None:
         indptr, nbr, eids = _capi.sample_neighbors(csr, nodes, int(fanout), replace, int(seed))
@@ -94,6 +180,8 @@ def to_block(g, dst_nodes):
     the block's destination nodes are ``dst_nodes`` in the given order and its source nodes start
     with them (include_dst_in_src); ``srcdata / dstdata[dgl.NID]`` and ``edata[dgl.EID]`` map back
     to ``g``.  Every edge of ``g`` must point at one of ``dst_nodes``."""
+    if len(g.canonical_etypes) != 1 or len(g.ntypes) != 1 or isinstance(dst_nodes, dict):
+        return _to_block_hetero(g, dst_nodes)
     rel = g._graph.relations[0]
     dev, idt = rel.device, rel.idtype
     dst_nodes = dst_nodes.to(device=dev, dtype=idt).contiguous()
@@ -118,6 +206,85 @@ def to_block(g, dst_nodes):
     return blk
 
 
+def _rows_of(rel, dst_nodes):
+    """In-edges of ``dst_nodes`` (in that order) out of the relation's in-edge CSR: (block indptr, CSC positions)."""
+    dev, idt = rel.device, rel.idtype
+    indptr = rel.csc()[0]
+    deg = (indptr[1:] - indptr[:-1])[dst_nodes.long()]
+    total = int(deg.sum())
+    if total != rel.num_edges:
+        raise ValueError("to_block: some edges of the frontier do not end in dst_nodes")
+    blk_ptr = torch.zeros(dst_nodes.shape[0] + 1, dtype=idt, device=dev)
+    blk_ptr[1:] = torch.cumsum(deg, 0)
+    starts = indptr[:-1][dst_nodes.long()].long()
+    pos = torch.repeat_interleave(starts - blk_ptr[:-1].long(), deg.long(), output_size=total) + \
+        torch.arange(total, device=dev)
+    return blk_ptr, pos
+
+
+def _to_block_hetero(g, dst_nodes):
+    """``dgl.to_block`` on a frontier with several node / edge types (python/dgl/transforms/functional.py to_block,
+    src/graph/transform/cuda/cuda_to_block.cu): ``dst_nodes`` = {node type: ids}; per node type the block's source nodes
+    start with that type's destination nodes (include_dst_in_src), followed by the new sources of EVERY relation leaving
+    that type; one relation per edge type, rows = the destination nodes of its destination type."""
+    if not isinstance(dst_nodes, dict):
+        if len(g.ntypes) != 1:
+            raise _DGLError("to_block: dst_nodes must be a dict of node type -> ids on a graph with several node types")
+        dst_nodes = {g.ntypes[0]: dst_nodes}
+    if g.is_unibipartite:
+        raise _DGLError("to_block: the frontier must have one node space per type (not itself a block)")
+    nts, cets = g.ntypes, g.canonical_etypes
+    dev, idt = g.device, g.idtype
+    dst = {n: torch.as_tensor(dst_nodes[n]).to(device=dev, dtype=idt).contiguous() if n in dst_nodes
+           else torch.empty(0, dtype=idt, device=dev) for n in nts}
+    rows, src_global, orig = [], [], []
+    for etid, (s_t, _, d_t) in enumerate(cets):
+        rel = g._graph.relations[etid]
+        if rel.num_edges == 0:
+            ptr = torch.zeros(dst[d_t].shape[0] + 1, dtype=idt, device=dev)
+            pos = torch.empty(0, dtype=torch.long, device=dev)
+        else:
+            ptr, pos = _rows_of(rel, dst[d_t])
+        indices, eids = rel.csc()[1], rel.csc()[2]
+        rows.append(ptr)
+        src_global.append(indices[pos].contiguous())
+        o = pos.to(idt) if eids is None else eids[pos]
+        f = g._edge_frames[etid]
+        orig.append(f[EID][o.long()] if EID in f else o)
+    src_nodes, local = {}, [None] * len(cets)
+    for ntid, n in enumerate(nts):
+        ets = [i for i, c in enumerate(cets) if c[0] == n]
+        cat = torch.cat([src_global[i] for i in ets]) if ets else torch.empty(0, dtype=idt, device=dev)
+        if dst[n].shape[0] == 0 and cat.shape[0] == 0:
+            src_nodes[n] = dst[n]
+            for i in ets:
+                local[i] = cat
+            continue
+        loc, sn, _ = _capi.to_block(dst[n], cat, _node_map(g, dev, ntid))
+        src_nodes[n] = sn
+        off = 0
+        for i in ets:
+            k = src_global[i].shape[0]
+            local[i] = loc[off:off + k].contiguous()
+            off += k
+    t = len(nts)
+    rels = []
+    for etid, (s_t, _, d_t) in enumerate(cets):
+        r = Relation(src_nodes[s_t].shape[0], dst[d_t].shape[0], csc=(rows[etid], local[etid], None), idtype=idt, device=dev)
+        r.transient = True
+        rels.append(r)
+    meta = [(nts.index(c[0]), t + nts.index(c[2])) for c in cets]
+    gidx = GraphIndex([src_nodes[n].shape[0] for n in nts] + [dst[n].shape[0] for n in nts], meta, rels)
+    blk = DGLGraph(gidx, nts + nts, cets, src_ntypes=list(range(t)), dst_ntypes=list(range(t, 2 * t)))
+    blk.is_block = True
+    for i, n in enumerate(nts):
+        blk._node_frames[i][NID] = src_nodes[n]
+        blk._node_frames[t + i][NID] = dst[n]
+    for etid in range(len(cets)):
+        blk._edge_frames[etid][EID] = orig[etid]
+    return blk
+
+
 class NeighborSampler:
     """``NeighborSampler([15, 10])``: one block per layer, built from the output nodes inwards
     (neighbor_sampler.py: sample_blocks).  ``sample_blocks(g, seed_nodes)`` returns
@@ -125,13 +292,34 @@ class NeighborSampler:
     ``dstdata[dgl.NID]`` / ``edata[dgl.EID]`` hold the original ids."""
 
     def __init__(self, fanouts, replace=False, seed=0, prob=None):
-        self.fanouts = [int(f) for f in fanouts]
+        self.fanouts = [f if isinstance(f, dict) else int(f) for f in fanouts]
         self.replace = bool(replace)
         self.seed = int(seed)
         self.prob = prob  # name of an edge feature holding sampling weights (the reference's `prob`)
         self._calls = 0
 
+    def _sample_blocks_hetero(self, g, seed_nodes):
+        """Several relations: ``sample_neighbors`` + ``to_block`` per layer, as neighbor_sampler.py:150-175 composes
+        them; fanouts may be dicts keyed by edge type."""
+        if not isinstance(seed_nodes, dict):
+            if len(g.ntypes) != 1:
+                raise _DGLError("seed_nodes must be a dict of node type -> ids on a graph with several node types")
+            seed_nodes = {g.ntypes[0]: seed_nodes}
+        seeds = {n: torch.as_tensor(v).to(device=g.device, dtype=g.idtype).contiguous() for n, v in seed_nodes.items()}
+        output_nodes = dict(seeds)
+        blocks = []
+        for layer, fanout in enumerate(reversed(self.fanouts)):
+            rng = (self.seed * 1000003 + self._calls) * 64 + layer
+            frontier = sample_neighbors(g, seeds, fanout, prob=self.prob, replace=self.replace, seed=rng)
+            blk = to_block(frontier, seeds)
+            blocks.insert(0, blk)
+            seeds = {n: blk.srcnodes[n].data[NID] for n in g.ntypes}
+        self._calls += 1
+        return seeds, output_nodes, blocks
+
     def sample_blocks(self, g, seed_nodes):
+        if len(g.canonical_etypes) != 1 or len(g.ntypes) != 1 or isinstance(seed_nodes, dict):
+            return self._sample_blocks_hetero(g, seed_nodes)
         rel, csr, keep = _csc_of(g)
         dev, idt = rel.device, rel.idtype
         node_map = _node_map(g, dev)
@@ -190,6 +378,8 @@ class NeighborSampler:
         num_input, output_nodes, blocks)``; ``blocks[i].num_src_valid`` / ``.num_dst_valid`` are the
         device-side counts.  Each call advances a DEVICE-side draw counter (``self.counter``), so a
         replayed graph samples fresh neighbours."""
+        if len(g.canonical_etypes) != 1 or any(isinstance(f, dict) for f in self.fanouts):
+            raise _DGLError("sample_blocks_padded: single-relation graphs only (one static shape per layer)")
         if min(self.fanouts) < 1:
             raise _DGLError("sample_blocks_padded needs positive fanouts")
         rel, csr, keep = _csc_of(g)
