@@ -1773,8 +1773,14 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
       // whole tile first held 64 more VGPRs over the ring's 128 and the compiler parked ring registers in AGPRs, each
       // copy waiting for its load (s_waitcnt vmcnt(0) at the top of every tile)
       auto out_row = [&](const int r, float (&o)[NJ]) {
-        const int rho = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        const float r0 = __shfl(rinv0, rho, 64);   // lane rho (< 32) holds row rho's 1 / scale
+        // lane rho (< 32) holds row rho's 1 / scale; this lane's row is rho_a (lanes 0-31) or rho_a + 4 (lanes 32-63): two
+        // scalar lane reads and a select — a ds_bpermute per row was an LDS round trip the store behind it waited for
+        // (s_waitcnt lgkmcnt(0) sixteen times per tile)
+        const int rho_a = (r & 3) + 8 * (r >> 2);
+        const int ibits = __builtin_bit_cast(int, rinv0);
+        const float ra = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ibits, rho_a));
+        const float rb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ibits, rho_a + 4));
+        const float r0 = khalf ? rb : ra;
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) o[jj] = __builtin_fmaf(acc[1][jj][r], 0x1p-11f, acc[0][jj][r]) * r0 * cinv[jj];
       };
@@ -1784,18 +1790,21 @@ __global__ __launch_bounds__(64 * kH2Waves) void segment_mm_h2_kernel(const H2Pa
       // predicated path here (and the exact-row loops behind it, through round 5's first form) shared the main loop's
       // register allocation and cost it 36 ring registers parked in AGPRs.
       const int last = static_cast<int>(uniform64(row_end - trow0 < 32 ? row_end - trow0 : 32)) - 1;
-      auto row_of = [&](const int r) -> int64_t {
+      float* const cbase = C + trow0 * N + col;   // (one 64-bit base per tile; a row costs a 32-bit multiply and one add)
+      auto row_ptr_c = [&](const int r) -> float* {
         const int rho = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        int64_t row = trow0 + (rho < last ? rho : last);
-        if constexpr (INDEXED) row = p.row_index[row];
-        return row;
+        const int rc = rho < last ? rho : last;
+        if constexpr (INDEXED)
+          return C + p.row_index[trow0 + rc] * N + col;
+        else
+          return cbase + static_cast<uint32_t>(rc) * static_cast<uint32_t>(N);
       };
       const bool vec = COLW || col + NJ <= N;    // (all lanes but those of the last column group of a ragged N)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float o[NJ];
         out_row(r, o);
-        float* dst = C + row_of(r) * N + col;
+        float* dst = row_ptr_c(r);
         if (vec) {
           if constexpr (NJ == 4) {
             const f32x4 w = {o[0], o[1], o[2], o[3]};
