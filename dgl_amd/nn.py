@@ -1,7 +1,9 @@
 """The three layers BASELINE.json's configs are quoted on, as CALLERS of the hot path (SURVEY.md §8 "who calls it").
 
 ``GraphConv`` (configs[0]; python/dgl/nn/pytorch/conv/graphconv.py:262-470), ``SAGEConv`` with the mean / gcn / pool
-aggregators (configs[3]; sageconv.py:100-290) and ``GATConv`` (configs[2]; gatconv.py:135-370): constructor arguments,
+aggregators (configs[3]; sageconv.py:100-290), ``GATConv`` (configs[2]; gatconv.py:135-370) and, for configs[4] (R-GCN),
+``TypedLinear`` (linear.py:13-225 — the caller of ``segment_mm`` / ``gather_mm``), ``RelGraphConv``
+(relgraphconv.py:10-215) and ``HeteroGraphConv`` / ``HeteroLinear`` / ``HeteroEmbedding`` (hetero.py): constructor arguments,
 parameter names and shapes, forward semantics and error cases follow the reference, the message passing goes through
 ``DGLGraph.update_all`` / ``apply_edges`` / ``dgl_amd.ops.edge_softmax`` — nothing here is a kernel.
 
@@ -23,7 +25,8 @@ from . import function as fn
 from ._lib import DGLAMDError
 from .ops import edge_softmax
 
-__all__ = ["GraphConv", "SAGEConv", "GATConv", "functional"]
+__all__ = ["GraphConv", "SAGEConv", "GATConv", "TypedLinear", "RelGraphConv", "HeteroGraphConv", "HeteroLinear",
+           "HeteroEmbedding", "functional"]
 
 
 class functional:  # noqa: N801  (a namespace: python/dgl/nn/functional/__init__.py exports exactly this)
@@ -305,3 +308,222 @@ class GATConv(nn.Module):
             if self.activation:
                 rst = self.activation(rst)
             return (rst, attention) if get_attention else rst
+
+
+class TypedLinear(nn.Module):
+    """``y_i = x_i W_{t_i}`` with an optional basis / block-diagonal decomposition of the weights (linear.py:13-225).
+    Unsorted types go through ``gather_mm`` (rows grouped by type through a permutation the MFMA kernels read through),
+    sorted ones through ``segment_mm`` with the segment lengths kept on the device (the reference reads them back:
+    linear.py:203-207 "cause device synchronize")."""
+
+    def __init__(self, in_size, out_size, num_types, regularizer=None, num_bases=None):
+        super().__init__()
+        self.in_size, self.out_size, self.num_types = in_size, out_size, num_types
+        if regularizer is None:
+            self.W = nn.Parameter(torch.empty(num_types, in_size, out_size))
+        elif regularizer == "basis":
+            if num_bases is None:
+                raise ValueError('Missing "num_bases" for basis regularization.')
+            self.W = nn.Parameter(torch.empty(num_bases, in_size, out_size))
+            self.coeff = nn.Parameter(torch.empty(num_types, num_bases))
+            self.num_bases = num_bases
+        elif regularizer == "bdd":
+            if num_bases is None:
+                raise ValueError('Missing "num_bases" for bdd regularization.')
+            if in_size % num_bases != 0 or out_size % num_bases != 0:
+                raise ValueError("Input and output sizes must be divisible by num_bases.")
+            self.submat_in, self.submat_out = in_size // num_bases, out_size // num_bases
+            self.W = nn.Parameter(torch.empty(num_types, num_bases * self.submat_in * self.submat_out))
+            self.num_bases = num_bases
+        else:
+            raise ValueError('Supported regularizer options: "basis", "bdd", but got {}'.format(regularizer))
+        self.regularizer = regularizer
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            fan = self.submat_in if self.regularizer == "bdd" else self.in_size
+            nn.init.uniform_(self.W, -1 / fan ** 0.5, 1 / fan ** 0.5)
+            if self.regularizer == "basis":
+                nn.init.xavier_uniform_(self.coeff, gain=nn.init.calculate_gain("relu"))
+
+    def get_weight(self):
+        if self.regularizer == "basis":
+            W = self.W.view(self.num_bases, self.in_size * self.out_size)
+            return (self.coeff @ W).view(self.num_types, self.in_size, self.out_size)
+        return self.W
+
+    def forward(self, x, x_type, sorted_by_type=False):
+        from .mm import gather_mm, segment_mm
+
+        w = self.get_weight()
+        if self.regularizer == "bdd":
+            w = w.index_select(0, x_type.long()).view(-1, self.submat_in, self.submat_out)
+            return torch.bmm(x.reshape(-1, 1, self.submat_in), w).view(-1, self.out_size)
+        if sorted_by_type:
+            pos_l = torch.searchsorted(x_type, torch.arange(self.num_types, device=x.device, dtype=x_type.dtype))
+            pos_r = torch.cat([pos_l[1:], torch.tensor([len(x_type)], device=x.device, dtype=pos_l.dtype)])
+            return segment_mm(x, w, seglen_a=pos_r - pos_l)          # (lengths stay on the device)
+        return gather_mm(x, w, idx_b=x_type)
+
+    def __repr__(self):
+        extra = "" if self.regularizer is None else ", regularizer={}, num_bases={}".format(self.regularizer, self.num_bases)
+        return "TypedLinear(in_size={}, out_size={}, num_types={}{})".format(self.in_size, self.out_size, self.num_types, extra)
+
+
+class RelGraphConv(nn.Module):
+    """R-GCN layer on a homogeneous graph with an edge-type vector: ``h_i = sum_r sum_{j in N_r(i)} e_ji W_r h_j + W_0 h_i``
+    (relgraphconv.py:10-215).  The message is the reference's own — the typed linear map of the gathered source rows,
+    a user-defined function over the edge batch — and the reduce is the built-in sum (g-SpMM ``copy_e``)."""
+
+    def __init__(self, in_feat, out_feat, num_rels, regularizer=None, num_bases=None, bias=True, activation=None,
+                 self_loop=True, dropout=0.0, layer_norm=False):
+        super().__init__()
+        if regularizer is not None and num_bases is None:
+            num_bases = num_rels
+        self.linear_r = TypedLinear(in_feat, out_feat, num_rels, regularizer, num_bases)
+        self.bias, self.activation, self.self_loop, self.layer_norm = bias, activation, self_loop, layer_norm
+        if self.bias:
+            self.h_bias = nn.Parameter(torch.zeros(out_feat))
+        if self.layer_norm:
+            self.layer_norm_weight = nn.LayerNorm(out_feat, elementwise_affine=True)
+        if self.self_loop:
+            self.loop_weight = nn.Parameter(torch.empty(in_feat, out_feat))
+            nn.init.xavier_uniform_(self.loop_weight, gain=nn.init.calculate_gain("relu"))
+        self.dropout = nn.Dropout(dropout)
+
+    def message(self, edges):
+        m = self.linear_r(edges.src["h"], edges.data["etype"], self.presorted)
+        if "norm" in edges.data:
+            m = m * edges.data["norm"]
+        return {"m": m}
+
+    def forward(self, g, feat, etypes, norm=None, *, presorted=False):
+        self.presorted = presorted
+        with g.local_scope():
+            g.srcdata["h"] = feat
+            if norm is not None:
+                g.edata["norm"] = norm
+            g.edata["etype"] = etypes if isinstance(etypes, torch.Tensor) else torch.as_tensor(etypes, device=feat.device)
+            g.update_all(self.message, fn.sum("m", "h"))
+            h = g.dstdata["h"]
+            if self.layer_norm:
+                h = self.layer_norm_weight(h)
+            if self.bias:
+                h = h + self.h_bias
+            if self.self_loop:
+                h = h + feat[: g.num_dst_nodes()] @ self.loop_weight
+            if self.activation:
+                h = self.activation(h)
+            return self.dropout(h)
+
+
+def _max_reduce(inputs, dim):
+    return torch.max(inputs, dim=dim)[0]
+
+
+def _min_reduce(inputs, dim):
+    return torch.min(inputs, dim=dim)[0]
+
+
+def _sum_reduce(inputs, dim):
+    return torch.sum(inputs, dim=dim)
+
+
+def _mean_reduce(inputs, dim):
+    return torch.mean(inputs, dim=dim)
+
+
+def _stack_agg(inputs, dsttype):      # noqa: ARG001
+    return torch.stack(inputs, dim=1) if inputs else None
+
+
+def _agg(inputs, dsttype, fn_):       # noqa: ARG001
+    return fn_(torch.stack(inputs, dim=0), 0) if inputs else None
+
+
+def get_aggregate_fn(agg):
+    """hetero.py:253-287 (module-level functions + ``partial``: the layer pickles)."""
+    from functools import partial
+
+    table = {"sum": _sum_reduce, "max": _max_reduce, "min": _min_reduce, "mean": _mean_reduce}
+    if agg == "stack":
+        return _stack_agg
+    if agg in table:
+        return partial(_agg, fn_=table[agg])
+    raise DGLAMDError('Invalid cross type aggregator. Must be one of "sum", "max", "min", "mean" or "stack". '
+                      "But got {!r}".format(agg))
+
+
+class HeteroGraphConv(nn.Module):
+    """One module per relation, run on that relation's slice of the graph, results aggregated per destination type
+    (hetero.py:12-222).  With the layers of this file every slice ends in one g-SpMM launch."""
+
+    def __init__(self, mods, aggregate="sum"):
+        super().__init__()
+        self.mod_dict = mods
+        self.mods = nn.ModuleDict({str(k): v for k, v in mods.items()})
+        for v in self.mods.values():
+            setter = getattr(v, "set_allow_zero_in_degree", None)
+            if callable(setter):
+                setter(True)
+        self.agg_fn = get_aggregate_fn(aggregate) if isinstance(aggregate, str) else aggregate
+
+    def _get_module(self, etype):
+        mod = self.mod_dict.get(etype, None)
+        if mod is not None:
+            return mod
+        if isinstance(etype, tuple):
+            return self.mod_dict[etype[1]]
+        raise KeyError("Cannot find module with edge type %s" % (etype,))
+
+    def forward(self, g, inputs, mod_args=None, mod_kwargs=None):
+        mod_args, mod_kwargs = mod_args or {}, mod_kwargs or {}
+        outputs = {nty: [] for nty in g.dsttypes}
+        if isinstance(inputs, tuple) or g.is_block:
+            if isinstance(inputs, tuple):
+                src_inputs, dst_inputs = inputs
+            else:
+                src_inputs = inputs
+                dst_inputs = {k: v[: g.number_of_dst_nodes(k)] for k, v in inputs.items()}
+        else:
+            src_inputs = dst_inputs = inputs
+        for stype, etype, dtype in g.canonical_etypes:
+            if stype not in src_inputs or dtype not in dst_inputs:
+                continue
+            rel_graph = g[stype, etype, dtype]
+            dstdata = self._get_module((stype, etype, dtype))(rel_graph, (src_inputs[stype], dst_inputs[dtype]),
+                                                              *mod_args.get(etype, ()), **mod_kwargs.get(etype, {}))
+            outputs[dtype].append(dstdata)
+        return {nty: self.agg_fn(alist, nty) for nty, alist in outputs.items() if len(alist) != 0}
+
+
+class HeteroLinear(nn.Module):
+    """One linear map per key (hetero.py:290-342)."""
+
+    def __init__(self, in_size, out_size, bias=True):
+        super().__init__()
+        self.linears = nn.ModuleDict({str(typ): nn.Linear(size, out_size, bias=bias) for typ, size in in_size.items()})
+
+    def forward(self, feat):
+        return {typ: self.linears[str(typ)](typ_feat) for typ, typ_feat in feat.items()}
+
+
+class HeteroEmbedding(nn.Module):
+    """One embedding table per key (hetero.py:345-430)."""
+
+    def __init__(self, num_embeddings, embedding_dim):
+        super().__init__()
+        self.embeds = nn.ModuleDict({str(k): nn.Embedding(n, embedding_dim) for k, n in num_embeddings.items()})
+        self.raw_keys = {str(k): k for k in num_embeddings}
+
+    @property
+    def weight(self):
+        return {self.raw_keys[typ]: emb.weight for typ, emb in self.embeds.items()}
+
+    def reset_parameters(self):
+        for emb in self.embeds.values():
+            nn.init.xavier_uniform_(emb.weight)
+
+    def forward(self, input_ids):
+        return {typ: self.embeds[str(typ)](ids) for typ, ids in input_ids.items()}
