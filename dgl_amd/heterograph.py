@@ -263,30 +263,40 @@ class DGLGraph:
             rels.append(nr)
         gidx = GraphIndex([self._graph.num_nodes(i) for i in range(len(self._ntypes))],
                           self._graph.metagraph.edges, rels)
-        return DGLGraph(gidx, self._ntypes, self._canonical_etypes, self._node_frames,
-                        self._edge_frames, self._src_ntype_ids, self._dst_ntype_ids)
+        return self._same_kind(DGLGraph(gidx, self._ntypes, self._canonical_etypes, self._node_frames,
+                                        self._edge_frames, self._src_ntype_ids, self._dst_ntype_ids))
 
     def to(self, device):
         device = torch.device(device)
         gidx = GraphIndex([self._graph.num_nodes(i) for i in range(len(self._ntypes))],
                           self._graph.metagraph.edges, [r.to(device) for r in self._graph.relations])
         mv = lambda frames: [self._copy_frame(f, lambda t: t.to(device)) for f in frames]
-        return DGLGraph(gidx, self._ntypes, self._canonical_etypes, mv(self._node_frames),
-                        mv(self._edge_frames), self._src_ntype_ids, self._dst_ntype_ids)
+        return self._same_kind(DGLGraph(gidx, self._ntypes, self._canonical_etypes, mv(self._node_frames),
+                                        mv(self._edge_frames), self._src_ntype_ids, self._dst_ntype_ids))
 
     def astype(self, idtype):
         if idtype == self.idtype:
             return self
         gidx = GraphIndex([self._graph.num_nodes(i) for i in range(len(self._ntypes))],
                           self._graph.metagraph.edges, [r.astype(idtype) for r in self._graph.relations])
-        return DGLGraph(gidx, self._ntypes, self._canonical_etypes, self._node_frames,
-                        self._edge_frames, self._src_ntype_ids, self._dst_ntype_ids)
+        return self._same_kind(DGLGraph(gidx, self._ntypes, self._canonical_etypes, self._node_frames,
+                                        self._edge_frames, self._src_ntype_ids, self._dst_ntype_ids))
 
     def int(self):
         return self.astype(torch.int32)
 
     def long(self):
         return self.astype(torch.int64)
+
+    def _same_kind(self, other):
+        """``other`` — a re-hosted / re-typed copy of this graph — is a block / a batch if this one is."""
+        if self.is_block:
+            other.is_block = True
+        for a in ("_batch_num_nodes", "_batch_num_edges", "batch_size"):
+            if hasattr(self, a):
+                v = getattr(self, a)
+                setattr(other, a, {k: t.to(other.device) for k, t in v.items()} if isinstance(v, dict) else v)
+        return other
 
     @staticmethod
     def _copy_frame(f, fn_=lambda t: t):
@@ -340,11 +350,26 @@ class DGLGraph:
         finally:
             self._node_frames, self._edge_frames = old_n, old_e
 
+    def adj_external(self, transpose=False, ctx=None, scipy_fmt=None, etype=None):
+        from .transforms import adj_external
+        return adj_external(self, transpose, ctx, scipy_fmt, etype)
+
+    def batch_num_nodes(self, ntype=None):
+        """Nodes per batched graph (``dgl.batch``); a graph that is not a batch is a batch of one."""
+        b = getattr(self, "_batch_num_nodes", None)
+        n = self._ntypes[self.get_ntype_id(ntype)]
+        return b[n] if b is not None else torch.tensor([self.num_nodes(n)], dtype=self.idtype, device=self.device)
+
+    def batch_num_edges(self, etype=None):
+        b = getattr(self, "_batch_num_edges", None)
+        c = self.to_canonical_etype(etype)
+        return b[c] if b is not None else torch.tensor([self.num_edges(c)], dtype=self.idtype, device=self.device)
+
     def local_var(self):
-        return DGLGraph(self._graph, self._ntypes, self._canonical_etypes,
-                        [self._copy_frame(f) for f in self._node_frames],
-                        [self._copy_frame(f) for f in self._edge_frames],
-                        self._src_ntype_ids, self._dst_ntype_ids)
+        return self._same_kind(DGLGraph(self._graph, self._ntypes, self._canonical_etypes,
+                                        [self._copy_frame(f) for f in self._node_frames],
+                                        [self._copy_frame(f) for f in self._edge_frames],
+                                        self._src_ntype_ids, self._dst_ntype_ids))
 
     def __getitem__(self, key):
         """``g[etype]``: the relation slice sharing feature storage (heterograph.py __getitem__)."""
@@ -794,8 +819,10 @@ def _as_index(x, idtype, device):
     return t.to(device=device, dtype=idtype).contiguous()
 
 
-def graph(data, num_nodes=None, idtype=None, device=None):
-    """Homogeneous graph from ``(src, dst)`` or a list of ``(u, v)`` pairs (dgl.graph)."""
+def graph(data, num_nodes=None, idtype=None, device=None, row_sorted=False, col_sorted=False):  # noqa: ARG001
+    """Homogeneous graph from ``(src, dst)`` or a list of ``(u, v)`` pairs (dgl.graph).  ``row_sorted`` / ``col_sorted``
+    are the reference's hints about the order of the ids (python/dgl/convert.py:69-75); the formats are built by a stable
+    sort either way, so they change nothing here."""
     if isinstance(data, list):
         # the reference takes a LIST as (u, v) pairs and a TUPLE as (src ids, dst ids); a two-element list whose
         # elements are themselves id sequences / tensors is read as (src ids, dst ids) too

@@ -26,7 +26,7 @@ from ._lib import DGLAMDError
 from .ops import edge_softmax
 
 __all__ = ["GraphConv", "SAGEConv", "GATConv", "TypedLinear", "RelGraphConv", "HeteroGraphConv", "HeteroLinear",
-           "HeteroEmbedding", "functional"]
+           "HeteroEmbedding", "EdgeWeightNorm", "functional"]
 
 
 class functional:  # noqa: N801  (a namespace: python/dgl/nn/functional/__init__.py exports exactly this)
@@ -129,20 +129,22 @@ class GraphConv(nn.Module):
 
 
 class SAGEConv(nn.Module):
-    """GraphSAGE layer, aggregators 'mean', 'gcn' and 'pool' (sageconv.py; 'lstm' — a recurrent reducer over a node's
-    mailbox — is a user-defined reduce function in the reference and is not offered here)."""
+    """GraphSAGE layer, aggregators 'mean', 'gcn', 'pool' (one g-SpMM each) and 'lstm' (sageconv.py: a recurrent reducer
+    over a node's mailbox — a user-defined reduce function there and here: degree bucketing, dgl_amd/udf.py)."""
 
     def __init__(self, in_feats, out_feats, aggregator_type, feat_drop=0.0, bias=True, norm=None, activation=None):
         super().__init__()
-        if aggregator_type not in ("mean", "gcn", "pool"):
+        if aggregator_type not in ("mean", "gcn", "pool", "lstm"):
             raise DGLAMDError("Invalid aggregator_type. Must be one of {}. But got {!r} instead.".format(
-                ("mean", "gcn", "pool"), aggregator_type))
+                {"mean", "gcn", "pool", "lstm"}, aggregator_type))
         self._in_src_feats, self._in_dst_feats = (in_feats if isinstance(in_feats, tuple) else (in_feats, in_feats))
         self._out_feats, self._aggre_type = out_feats, aggregator_type
         self.norm, self.activation = norm, activation
         self.feat_drop = nn.Dropout(feat_drop)
         if aggregator_type == "pool":
             self.fc_pool = nn.Linear(self._in_src_feats, self._in_src_feats)
+        if aggregator_type == "lstm":
+            self.lstm = nn.LSTM(self._in_src_feats, self._in_src_feats, batch_first=True)
         self.fc_neigh = nn.Linear(self._in_src_feats, out_feats, bias=False)
         if aggregator_type != "gcn":
             self.fc_self = nn.Linear(self._in_dst_feats, out_feats, bias=bias)
@@ -156,9 +158,17 @@ class SAGEConv(nn.Module):
         gain = nn.init.calculate_gain("relu")
         if self._aggre_type == "pool":
             nn.init.xavier_uniform_(self.fc_pool.weight, gain=gain)
+        if self._aggre_type == "lstm":
+            self.lstm.reset_parameters()
         if self._aggre_type != "gcn":
             nn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
         nn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
+
+    def _lstm_reducer(self, nodes):
+        m = nodes.mailbox["m"]                                   # (nodes of one in-degree, that degree, D)
+        h = (m.new_zeros((1, m.shape[0], self._in_src_feats)), m.new_zeros((1, m.shape[0], self._in_src_feats)))
+        _, (rst, _) = self.lstm(m, h)
+        return {"neigh": rst.squeeze(0)}
 
     def forward(self, graph, feat, edge_weight=None):
         with graph.local_scope():
@@ -192,9 +202,13 @@ class SAGEConv(nn.Module):
                 h_neigh = (graph.dstdata["neigh"] + graph.dstdata["h"]) / (degs.unsqueeze(-1) + 1)
                 if not lin_before_mp:
                     h_neigh = self.fc_neigh(h_neigh)
-            else:   # pool
+            elif self._aggre_type == "pool":
                 graph.srcdata["h"] = F.relu(self.fc_pool(feat_src))
                 graph.update_all(msg_fn, fn.max("m", "neigh"))
+                h_neigh = self.fc_neigh(graph.dstdata["neigh"])
+            else:   # lstm
+                graph.srcdata["h"] = feat_src
+                graph.update_all(msg_fn, self._lstm_reducer)
                 h_neigh = self.fc_neigh(graph.dstdata["neigh"])
             if self._aggre_type == "gcn":
                 rst = h_neigh
@@ -527,3 +541,6 @@ class HeteroEmbedding(nn.Module):
 
     def forward(self, input_ids):
         return {typ: self.embeds[str(typ)](ids) for typ, ids in input_ids.items()}
+
+
+from .transforms import EdgeWeightNorm  # noqa: E402,F401  (graphconv.py:17-130; lives with the other graph helpers)

@@ -175,11 +175,38 @@ def _make_block(indptr, local_src, num_src, num_dst, idtype, device):
     return blk
 
 
-def to_block(g, dst_nodes):
+def _renumber(seeds, src, g, dev, ntid=None):
+    """Block-local ids of ``src`` with ``seeds`` first and the new sources after them in ascending order: the
+    ``dgla_to_block`` kernel on the GPU; for a graph that lives on the CPU (graph construction in tests and data
+    pipelines, where the reference runs its own CPU ``ToBlock``) the same convention in torch index arithmetic."""
+    if dev.type == "cuda":
+        return _capi.to_block(seeds, src, _node_map(g, dev, ntid))
+    n_nodes = g.num_nodes() if ntid is None else g._graph.num_nodes(ntid)
+    mark = torch.full((max(1, n_nodes),), -1, dtype=torch.long)
+    mark[seeds.long()] = torch.arange(seeds.shape[0])
+    new = torch.unique(src[mark[src.long()] < 0])
+    mark[new.long()] = seeds.shape[0] + torch.arange(new.shape[0])
+    return mark[src.long()].to(seeds.dtype), torch.cat([seeds, new.to(seeds.dtype)]), int(seeds.shape[0] + new.shape[0])
+
+
+def _default_dst_nodes(g):
+    """``to_block(g)`` without destination nodes: per node type the nodes with an inbound edge, ascending
+    (transforms/functional.py to_block: ``F.unique`` of the relations' destination ids)."""
+    out = {}
+    for c in g.canonical_etypes:
+        out.setdefault(c[2], []).append(g.edges(etype=c)[1])
+    return {n: (torch.unique(torch.cat(v)) if v else torch.empty(0, dtype=g.idtype, device=g.device)) for n, v in out.items()}
+
+
+def to_block(g, dst_nodes=None):
     """``dgl.to_block`` for a homogeneous frontier graph (python/dgl/transforms/functional.py):
     the block's destination nodes are ``dst_nodes`` in the given order and its source nodes start
     with them (include_dst_in_src); ``srcdata / dstdata[dgl.NID]`` and ``edata[dgl.EID]`` map back
     to ``g``.  Every edge of ``g`` must point at one of ``dst_nodes``."""
+    if dst_nodes is None:
+        dst_nodes = _default_dst_nodes(g)
+        if len(g.ntypes) == 1:
+            dst_nodes = dst_nodes.get(g.ntypes[0], torch.empty(0, dtype=g.idtype, device=g.device))
     if len(g.canonical_etypes) != 1 or len(g.ntypes) != 1 or isinstance(dst_nodes, dict):
         return _to_block_hetero(g, dst_nodes)
     rel = g._graph.relations[0]
@@ -197,7 +224,7 @@ def to_block(g, dst_nodes):
     pos = torch.repeat_interleave(starts - blk_ptr[:-1].long(), deg.long(), output_size=total) + \
         torch.arange(total, device=dev)
     src = indices[pos].contiguous()
-    local, src_nodes, num_src = _capi.to_block(dst_nodes, src, _node_map(g, dev))
+    local, src_nodes, num_src = _renumber(dst_nodes, src, g, dev)
     blk = _make_block(blk_ptr, local, num_src, dst_nodes.shape[0], idt, dev)
     blk.srcdata[NID] = src_nodes
     blk.dstdata[NID] = dst_nodes
@@ -260,7 +287,7 @@ def _to_block_hetero(g, dst_nodes):
             for i in ets:
                 local[i] = cat
             continue
-        loc, sn, _ = _capi.to_block(dst[n], cat, _node_map(g, dev, ntid))
+        loc, sn, _ = _renumber(dst[n], cat, g, dev, ntid)
         src_nodes[n] = sn
         off = 0
         for i in ets:

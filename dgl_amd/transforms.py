@@ -1,0 +1,242 @@
+"""Graph construction helpers around the hot path, in torch index arithmetic on the caller's device.
+
+``add_self_loop`` / ``remove_self_loop`` / ``remove_edges`` / ``reorder_graph`` (python/dgl/transforms/functional.py),
+``batch`` (python/dgl/batch.py), ``from_scipy`` / ``bipartite_from_scipy`` (python/dgl/convert.py), ``adj_external``
+(heterograph.py) and ``EdgeWeightNorm`` (nn/pytorch/conv/graphconv.py:17-130): the handful the reference's own layer tests
+(tests/python/pytorch/nn/test_nn.py, tests/utils/graph_cases.py) build their graphs with — tools/ref_suite runs those
+files unmodified.  None of this is a kernel and none of it is timed; every graph these return builds its CSR / CSC with
+the library's COO -> CSR kernel the first time an operator asks for it, like any other graph.
+"""
+import torch
+
+from . import function as fn
+from ._lib import DGLAMDError
+from .graph_index import GraphIndex, Relation
+from .heterograph import DGLGraph, _Frame, graph, heterograph
+
+EID = NID = "_ID"
+
+
+def _single(g, what):
+    if len(g.canonical_etypes) != 1:
+        raise DGLAMDError("%s: an edge type must be given on a graph with several edge types" % what)
+
+
+def _with_edges(g, etid, u, v, edge_frame):
+    """Copy of ``g`` whose relation ``etid`` has the edges (u, v) and the given edge frame; everything else shared."""
+    rels = list(g._graph.relations)
+    old = rels[etid]
+    rels[etid] = Relation(old.num_src, old.num_dst, u.contiguous(), v.contiguous(), idtype=g.idtype, device=g.device)
+    gidx = GraphIndex([g._graph.num_nodes(i) for i in range(len(g._ntypes))], list(g._graph.metagraph.edges), rels)
+    eframes = [g._copy_frame(f) for f in g._edge_frames]
+    eframes[etid] = edge_frame
+    return DGLGraph(gidx, g._ntypes, g._canonical_etypes, [g._copy_frame(f) for f in g._node_frames], eframes,
+                    g._src_ntype_ids, g._dst_ntype_ids)
+
+
+def add_self_loop(g, edge_feat_names=None, fill_data=1.0, etype=None):
+    """One edge i -> i per node, appended behind the existing edges; their features are ``fill_data`` — a number, or
+    'sum' / 'mean' / 'max' / 'min' of the node's incoming edges' features (transforms/functional.py add_self_loop)."""
+    etid = g.get_etype_id(etype)
+    s, d = g._graph.metagraph.find_edge(etid)
+    if s != d:
+        raise DGLAMDError("add_self_loop does not support unidirectional bipartite graphs: {}. Please make sure the types "
+                          "of head node and tail node are identical.".format(g.canonical_etypes[etid]))
+    n = g._graph.num_nodes(s)
+    u, v = g.edges(etype=g.canonical_etypes[etid])
+    loop = torch.arange(n, dtype=g.idtype, device=g.device)
+    old = g._edge_frames[etid]
+    frame = _Frame(int(u.shape[0]) + n)
+    for k, col in old.items():
+        if edge_feat_names is not None and k not in edge_feat_names:
+            continue
+        shape = (n,) + tuple(col.shape[1:])
+        if isinstance(fill_data, str):
+            if fill_data not in ("sum", "mean", "max", "min"):
+                raise DGLAMDError("Unsupported aggregation: {}".format(fill_data))
+            idx = v.long().view((-1,) + (1,) * (col.dim() - 1)).expand_as(col)
+            op = {"sum": "sum", "mean": "mean", "max": "amax", "min": "amin"}[fill_data]
+            add = torch.zeros(shape, dtype=col.dtype, device=col.device).scatter_reduce(0, idx, col, op, include_self=False)
+        else:
+            add = torch.full(shape, fill_data, dtype=col.dtype, device=col.device)
+        dict.__setitem__(frame, k, torch.cat([col, add], 0))
+    return _with_edges(g, etid, torch.cat([u, loop]), torch.cat([v, loop]), frame)
+
+
+def remove_edges(g, eids, etype=None, store_ids=False):
+    """Copy of ``g`` without the given edges of one type; the others keep their relative order (functional.py)."""
+    etid = g.get_etype_id(etype)
+    u, v = g.edges(etype=g.canonical_etypes[etid])
+    keep = torch.ones(u.shape[0], dtype=torch.bool, device=g.device)
+    keep[torch.as_tensor(eids, device=g.device).long()] = False
+    sel = torch.nonzero(keep).reshape(-1)
+    frame = _Frame(int(sel.shape[0]))
+    for k, col in g._edge_frames[etid].items():
+        dict.__setitem__(frame, k, col[sel])
+    if store_ids:
+        dict.__setitem__(frame, EID, sel.to(g.idtype))
+    out = _with_edges(g, etid, u[sel], v[sel], frame)
+    if store_ids:
+        for i in range(len(out._ntypes)):
+            out._node_frames[i][NID] = torch.arange(out._graph.num_nodes(i), dtype=g.idtype, device=g.device)
+    return out
+
+
+def remove_self_loop(g, etype=None):
+    etid = g.get_etype_id(etype)
+    u, v = g.edges(etype=g.canonical_etypes[etid])
+    return remove_edges(g, torch.nonzero(u == v).reshape(-1), etype=etype)
+
+
+def reorder_graph(g, node_permute_algo=None, edge_permute_algo="src", store_ids=True, permute_config=None):
+    """Edges re-ordered by source / destination id or by a given permutation (functional.py reorder_graph; node
+    re-ordering — rcmk / metis — is the reference's graph-partitioning tool chain and is not offered)."""
+    if node_permute_algo is not None:
+        raise DGLAMDError("reorder_graph: node_permute_algo is not supported (only edges are re-ordered)")
+    _single(g, "reorder_graph")
+    u, v = g.edges()
+    if edge_permute_algo == "src":
+        perm = torch.argsort(u, stable=True)
+    elif edge_permute_algo == "dst":
+        perm = torch.argsort(v, stable=True)
+    elif edge_permute_algo == "custom":
+        if not permute_config or "edges_perm" not in permute_config:
+            raise DGLAMDError("edge_permute_algo='custom' needs permute_config['edges_perm']")
+        perm = torch.as_tensor(permute_config["edges_perm"], device=g.device)
+        if perm.shape[0] != u.shape[0]:
+            raise DGLAMDError("edges_perm must hold one entry per edge")
+    else:
+        raise DGLAMDError("Unexpected edge_permute_algo is specified: {}. Expected algos: ['src', 'dst', 'custom']"
+                          .format(edge_permute_algo))
+    perm = perm.long()
+    frame = _Frame(int(u.shape[0]))
+    for k, col in g._edge_frames[0].items():
+        dict.__setitem__(frame, k, col[perm])
+    if store_ids:
+        dict.__setitem__(frame, EID, perm.to(g.idtype))
+    return _with_edges(g, 0, u[perm], v[perm], frame)
+
+
+def batch(graphs, ndata="__ALL__", edata="__ALL__"):
+    """Disjoint union with node / edge ids shifted graph by graph (python/dgl/batch.py); ``batch_num_nodes()`` /
+    ``batch_num_edges()`` give the pieces."""
+    if len(graphs) == 0:
+        raise DGLAMDError("The input list of graphs cannot be empty.")
+    g0 = graphs[0]
+    for g in graphs[1:]:
+        if g.ntypes != g0.ntypes or g.canonical_etypes != g0.canonical_etypes:
+            raise DGLAMDError("All graphs should have the same node types and edge types to be batched.")
+    nts, cets = g0.ntypes, g0.canonical_etypes
+    counts = {n: [g.num_nodes(n) for g in graphs] for n in nts}
+    offs = {n: [sum(counts[n][:i]) for i in range(len(graphs))] for n in nts}
+    data = {}
+    for c in cets:
+        us, vs = [], []
+        for i, g in enumerate(graphs):
+            u, v = g.edges(etype=c)
+            us.append(u + offs[c[0]][i])
+            vs.append(v + offs[c[2]][i])
+        data[c] = (torch.cat(us), torch.cat(vs))
+    total = {n: sum(counts[n]) for n in nts}
+    if len(cets) == 1 and len(nts) == 1:
+        out = graph(data[cets[0]], num_nodes=total[nts[0]], idtype=g0.idtype, device=g0.device)
+    else:
+        out = heterograph(data, total, idtype=g0.idtype, device=g0.device)
+    def merge(frames, keys):
+        merged = {}
+        names = list(frames[0].keys()) if keys == "__ALL__" else (keys or [])
+        for k in names:
+            if all(k in f for f in frames):
+                merged[k] = torch.cat([f[k] for f in frames], 0)
+        return merged
+    for i, n in enumerate(out._ntypes):
+        for k, val in merge([g._node_frames[g.get_ntype_id(n)] for g in graphs], ndata).items():
+            out._node_frames[i][k] = val
+    for i, c in enumerate(out._canonical_etypes):
+        for k, val in merge([g._edge_frames[g.get_etype_id(c)] for g in graphs], edata).items():
+            out._edge_frames[i][k] = val
+    out._batch_num_nodes = {n: torch.tensor(counts[n], dtype=g0.idtype, device=g0.device) for n in nts}
+    out._batch_num_edges = {c: torch.tensor([g.num_edges(c) for g in graphs], dtype=g0.idtype, device=g0.device) for c in cets}
+    out.batch_size = len(graphs)
+    return out
+
+
+def from_scipy(sp_mat, eweight_name=None, idtype=None, device=None):
+    """Graph with an edge row -> column per nonzero of a square scipy sparse matrix (convert.py from_scipy)."""
+    if sp_mat.shape[0] != sp_mat.shape[1]:
+        raise DGLAMDError("Expect the number of rows to be the same as the number of columns for sp_mat, got {:d} and {:d}."
+                          .format(sp_mat.shape[0], sp_mat.shape[1]))
+    coo = sp_mat.tocoo()
+    g = graph((torch.as_tensor(coo.row).long(), torch.as_tensor(coo.col).long()), num_nodes=sp_mat.shape[0],
+              idtype=idtype or torch.int64, device=device or torch.device("cpu"))
+    if eweight_name is not None:
+        g.edata[eweight_name] = torch.as_tensor(coo.data).to(g.device)
+    return g
+
+
+def bipartite_from_scipy(sp_mat, utype, etype, vtype, eweight_name=None, idtype=None, device=None):
+    coo = sp_mat.tocoo()
+    g = heterograph({(utype, etype, vtype): (torch.as_tensor(coo.row).long(), torch.as_tensor(coo.col).long())},
+                    {utype: sp_mat.shape[0], vtype: sp_mat.shape[1]}, idtype=idtype or torch.int64,
+                    device=device or torch.device("cpu"))
+    if eweight_name is not None:
+        g.edata[eweight_name] = torch.as_tensor(coo.data).to(g.device)
+    return g
+
+
+def adj_external(g, transpose=False, ctx=None, scipy_fmt=None, etype=None):
+    """Adjacency matrix as a torch sparse COO tensor — rows = source nodes unless ``transpose`` — or a scipy matrix
+    (heterograph.py adj_external)."""
+    c = g.to_canonical_etype(etype)
+    u, v = g.edges(etype=c)
+    n_src, n_dst = g.num_src_nodes(c[0]) if g.is_unibipartite else g.num_nodes(c[0]), \
+        g.num_dst_nodes(c[2]) if g.is_unibipartite else g.num_nodes(c[2])
+    if scipy_fmt is not None:
+        import numpy as np
+        import scipy.sparse as sp
+
+        rows, cols, shape = (v, u, (n_dst, n_src)) if transpose else (u, v, (n_src, n_dst))
+        mat = sp.coo_matrix((np.ones(int(u.shape[0])), (rows.cpu().numpy(), cols.cpu().numpy())), shape=shape)
+        return mat.asformat(scipy_fmt)
+    idx = torch.stack([v, u] if transpose else [u, v]).long()
+    shape = (n_dst, n_src) if transpose else (n_src, n_dst)
+    out = torch.sparse_coo_tensor(idx, torch.ones(idx.shape[1], device=idx.device), shape)
+    return out.to(ctx) if ctx is not None else out
+
+
+class EdgeWeightNorm(torch.nn.Module):
+    """Edge weights normalised as GraphConv normalises by degrees: ``c_ji = e_ji / sqrt(D_j D_i)`` ('both'), ``/ D_i``
+    ('right') or none, with D the weighted degrees (nn/pytorch/conv/graphconv.py:17-130)."""
+
+    def __init__(self, norm="both", eps=0.0):
+        super().__init__()
+        self._norm, self._eps = norm, eps
+
+    def forward(self, graph, edge_weight):
+        with graph.local_scope():
+            if isinstance(edge_weight, tuple):
+                raise DGLAMDError("edge_weight should be a tensor")
+            if edge_weight.dim() != 1:
+                raise DGLAMDError("Currently the normalization is only defined on scalar edge weight. Please customize the "
+                                  "normalization for your high-dimensional weights.")
+            if self._norm == "both" and bool((edge_weight <= 0).any()):
+                raise DGLAMDError('Non-positive edge weight detected with `norm="both"`. This leads to square root of '
+                                  "zero or negative values.")
+            dev = edge_weight.device
+            graph.srcdata["_src_out_w"] = torch.ones(graph.num_src_nodes(), device=dev, dtype=edge_weight.dtype)
+            graph.dstdata["_dst_in_w"] = torch.ones(graph.num_dst_nodes(), device=dev, dtype=edge_weight.dtype)
+            graph.edata["_edge_w"] = edge_weight
+            if self._norm == "both":
+                u = graph.edges()[0].long()
+                out_w = torch.zeros(graph.num_src_nodes(), device=dev, dtype=edge_weight.dtype).index_add(0, u, edge_weight)
+                graph.srcdata["_src_out_w"] = torch.pow(out_w + self._eps, -0.5)
+            if self._norm != "none":
+                graph.update_all(fn.copy_e("_edge_w", "m"), fn.sum("m", "in_weight"))
+                deg = graph.dstdata["in_weight"] + self._eps
+                graph.dstdata["_dst_in_w"] = torch.pow(deg, -0.5) if self._norm == "both" else 1.0 / deg
+            graph.apply_edges(lambda e: {"_norm_edge_weights": e.src["_src_out_w"] * e.dst["_dst_in_w"] * e.data["_edge_w"]})
+            return graph.edata["_norm_edge_weights"]
+
+
+__all__ = ["add_self_loop", "remove_self_loop", "remove_edges", "reorder_graph", "batch", "from_scipy", "bipartite_from_scipy",
+           "adj_external", "EdgeWeightNorm"]
