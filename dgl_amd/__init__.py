@@ -18,7 +18,8 @@ from . import nn  # noqa: E402,F401
 from . import sampling  # noqa: E402,F401
 from . import dataloading  # noqa: E402,F401
 from .transforms import (add_self_loop, batch, bipartite_from_scipy, from_scipy, remove_edges,  # noqa: E402,F401
-                         remove_self_loop, reorder_graph)
+                         remove_self_loop, reorder_graph, unbatch)
+from .readout import *  # noqa: E402,F401,F403
 from . import sparse  # noqa: E402,F401
 from .ops import edge_softmax  # noqa: E402,F401
 from .sampling import EID, NID, NeighborSampler, to_block  # noqa: E402,F401

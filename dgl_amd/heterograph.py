@@ -105,6 +105,7 @@ class _TypeIndexer:
 
 class DGLGraph:
     is_block = False
+    batch_size = 1          # (``dgl.batch`` sets the number of graphs on its result)
 
     def __init__(self, gidx, ntypes, canonical_etypes, node_frames=None, edge_frames=None,
                  src_ntypes=None, dst_ntypes=None):
@@ -293,7 +294,7 @@ class DGLGraph:
         if self.is_block:
             other.is_block = True
         for a in ("_batch_num_nodes", "_batch_num_edges", "batch_size"):
-            if hasattr(self, a):
+            if a in self.__dict__:
                 v = getattr(self, a)
                 setattr(other, a, {k: t.to(other.device) for k, t in v.items()} if isinstance(v, dict) else v)
         return other
@@ -750,6 +751,15 @@ def _field(g, code, name):
 
 def _as_tuple(g, data, target):
     """Feature of a multi-relation graph as a tuple in type-id order (core.data_dict_to_list)."""
+    if isinstance(data, torch.Tensor) and target != "e":
+        # a side with ONE node type hands out a tensor, not a dict (g.srcdata on a graph whose relations all leave
+        # the same type): it belongs to that type's slot
+        side = (g._src_ntype_ids if target == "u" else g._dst_ntype_ids) if g.is_unibipartite else range(len(g.ntypes))
+        side = list(side)
+        if len(side) == 1:
+            out = [None] * len(g.ntypes)
+            out[side[0]] = data
+            return tuple(out)
     if not isinstance(data, dict):
         return data
     if target == "e":

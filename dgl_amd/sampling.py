@@ -258,7 +258,7 @@ def _to_block_hetero(g, dst_nodes):
         if len(g.ntypes) != 1:
             raise _DGLError("to_block: dst_nodes must be a dict of node type -> ids on a graph with several node types")
         dst_nodes = {g.ntypes[0]: dst_nodes}
-    if g.is_unibipartite:
+    if g.is_block or len(set(g.ntypes)) != len(g.ntypes):
         raise _DGLError("to_block: the frontier must have one node space per type (not itself a block)")
     nts, cets = g.ntypes, g.canonical_etypes
     dev, idt = g.device, g.idtype

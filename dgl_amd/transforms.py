@@ -161,6 +161,40 @@ def batch(graphs, ndata="__ALL__", edata="__ALL__"):
     return out
 
 
+def unbatch(g, node_split=None, edge_split=None):
+    """The graphs a batch was made of, with their slices of the features (python/dgl/batch.py unbatch)."""
+    nts, cets = g.ntypes, g.canonical_etypes
+    nsplit = {n: (g.batch_num_nodes(n) if node_split is None else torch.as_tensor(
+        node_split[n] if isinstance(node_split, dict) else node_split)).tolist() for n in nts}
+    esplit = {c: (g.batch_num_edges(c) if edge_split is None else torch.as_tensor(
+        edge_split[c] if isinstance(edge_split, dict) else edge_split)).tolist() for c in cets}
+    k = len(nsplit[nts[0]])
+    noff = {n: [sum(nsplit[n][:i]) for i in range(k + 1)] for n in nts}
+    eoff = {c: [sum(esplit[c][:i]) for i in range(k + 1)] for c in cets}
+    out = []
+    for i in range(k):
+        data = {}
+        for c in cets:
+            u, v = g.edges(etype=c)
+            a, b = eoff[c][i], eoff[c][i + 1]
+            data[c] = (u[a:b] - noff[c[0]][i], v[a:b] - noff[c[2]][i])
+        counts = {n: nsplit[n][i] for n in nts}
+        if len(cets) == 1 and len(nts) == 1:
+            sg = graph(data[cets[0]], num_nodes=counts[nts[0]], idtype=g.idtype, device=g.device)
+        else:
+            sg = heterograph(data, counts, idtype=g.idtype, device=g.device)
+        for n in nts:
+            fr = g._node_frames[g.get_ntype_id(n)]
+            for key, val in fr.items():
+                sg._node_frames[sg.get_ntype_id(n)][key] = val[noff[n][i]:noff[n][i + 1]]
+        for c in cets:
+            fr = g._edge_frames[g.get_etype_id(c)]
+            for key, val in fr.items():
+                sg._edge_frames[sg.get_etype_id(c)][key] = val[eoff[c][i]:eoff[c][i + 1]]
+        out.append(sg)
+    return out
+
+
 def from_scipy(sp_mat, eweight_name=None, idtype=None, device=None):
     """Graph with an edge row -> column per nonzero of a square scipy sparse matrix (convert.py from_scipy)."""
     if sp_mat.shape[0] != sp_mat.shape[1]:
@@ -238,5 +272,5 @@ class EdgeWeightNorm(torch.nn.Module):
             return graph.edata["_norm_edge_weights"]
 
 
-__all__ = ["add_self_loop", "remove_self_loop", "remove_edges", "reorder_graph", "batch", "from_scipy", "bipartite_from_scipy",
+__all__ = ["add_self_loop", "remove_self_loop", "remove_edges", "reorder_graph", "batch", "unbatch", "from_scipy", "bipartite_from_scipy",
            "adj_external", "EdgeWeightNorm"]

@@ -38,6 +38,8 @@ SPARSE_FILES = ["python/pytorch/sparse/" + f for f in (
     "__init__.py", "utils.py", "test_broadcast.py", "test_elementwise_op.py", "test_elementwise_op_sp.py", "test_matmul.py",
     "test_matrix_op.py", "test_reduction.py", "test_sddmm.py", "test_softmax.py", "test_sparse_matrix.py",
     "test_unary_op.py")]
+MP_FILES = ["python/common/test_heterograph-update-all.py", "python/common/test_heterograph-apply-edges.py",
+            "python/common/test_heterograph-specialization.py", "python/common/test_readout.py"]
 NN_FILE = "python/pytorch/nn/test_nn.py"
 NN_SELECT = ["test_graph_conv0", "test_graph_conv", "test_graph_conv_e_weight", "test_graph_conv_e_weight_norm",
              "test_graph_conv_bi", "test_sage_conv", "test_sage_conv_bi", "test_sage_conv2", "test_gat_conv",
@@ -53,7 +55,7 @@ SELECT = {
 
 
 def prepare(src):
-    for f in FILES + SPARSE_FILES + [NN_FILE]:
+    for f in FILES + SPARSE_FILES + [NN_FILE] + MP_FILES:
         d = os.path.join(DEST, f)
         os.makedirs(os.path.dirname(d), exist_ok=True)
         shutil.copyfile(os.path.join(src, f), d)
@@ -176,7 +178,7 @@ def main():
     ap.add_argument("--src", default="/root/reference/tests")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ref_suite.jsonl"))
     ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"])
-    ap.add_argument("--suite", default="ops", choices=["ops", "sparse", "nn"],
+    ap.add_argument("--suite", default="ops", choices=["ops", "sparse", "nn", "mp"],
                     help="ops: the operator suites (SELECT); sparse: tests/python/pytorch/sparse/*, every test")
     ap.add_argument("-k", default=None)
     ap.add_argument("--maxfail", type=int, default=0)
@@ -197,6 +199,8 @@ def main():
     targets = []
     if args.suite == "sparse":
         targets = [os.path.join(DEST, f) for f in SPARSE_FILES if os.path.basename(f).startswith("test_")]
+    elif args.suite == "mp":     # message passing on heterographs: update_all / apply_edges / pull / send_and_recv
+        targets = [os.path.join(DEST, f) for f in MP_FILES]
     elif args.suite == "nn":
         targets = ["%s::%s" % (os.path.join(DEST, NN_FILE), n) for n in NN_SELECT]
     else:
