@@ -150,6 +150,9 @@ class DGLGraph:
             if len(self._ntypes) != 1:
                 raise DGLAMDError("Node type name must be specified if there are more than one node types.")
             return 0
+        if self.is_unibipartite and isinstance(ntype, str) and ntype[:4] in ("SRC/", "DST/"):
+            # "SRC/<type>" / "DST/<type>" name one side of a block (python/dgl/heterograph.py get_ntype_id)
+            return (self.get_ntype_id_from_src if ntype[:4] == "SRC/" else self.get_ntype_id_from_dst)(ntype[4:])
         if ntype not in self._ntypes:
             raise DGLAMDError('Node type "{}" does not exist.'.format(ntype))
         if self.is_unibipartite and self._ntypes.count(ntype) > 1:
@@ -246,6 +249,10 @@ class DGLGraph:
     def edges(self):
         """``g.edges(etype=...)`` -> (src, dst) in edge-id order; ``g.edges[etype].data`` -> frame."""
         return _EdgeView(self)
+
+    def all_edges(self, form="uv", order="eid", etype=None):
+        """``g.edges(form, order, etype)`` under its older name (heterograph.py all_edges)."""
+        return self.edges(form, order, etype)
 
     def formats(self, formats=None):
         """Restrict the allowed sparse formats (``g.formats(['csr'])``), like the reference."""

@@ -189,6 +189,35 @@ def _renumber(seeds, src, g, dev, ntid=None):
     return mark[src.long()].to(seeds.dtype), torch.cat([seeds, new.to(seeds.dtype)]), int(seeds.shape[0] + new.shape[0])
 
 
+def _renumber_into(src_nodes, src, n_nodes):
+    """Block-local ids of ``src`` when the block's source nodes are GIVEN (``to_block(..., src_nodes=)``)."""
+    mark = torch.full((max(1, n_nodes),), -1, dtype=torch.long, device=src.device)
+    mark[src_nodes.long()] = torch.arange(src_nodes.shape[0], device=src.device)
+    local = mark[src.long()]
+    if bool((local < 0).any()):
+        raise _DGLError("to_block: src_nodes does not hold every source node of the frontier")
+    return local.to(src_nodes.dtype), src_nodes, int(src_nodes.shape[0])
+
+
+def _copy_block_features(g, blk, src_nodes, dst_nodes, induced):
+    """Node / edge features of the frontier follow its nodes and edges into the block, behind the ids
+    (utils.extract_node_subframes_for_block / extract_edge_subframes; the ids win over a feature of the same name)."""
+    t = len(g.ntypes)
+    for i, n in enumerate(g.ntypes):
+        fr = g._node_frames[i]
+        for key, val in fr.items():
+            if key == NID:
+                continue
+            blk._node_frames[i][key] = val[src_nodes[n].long()]
+            blk._node_frames[t + i][key] = val[dst_nodes[n].long()]
+    for etid in range(len(g.canonical_etypes)):
+        fr = g._edge_frames[etid]
+        for key, val in fr.items():
+            if key == EID:
+                continue
+            blk._edge_frames[etid][key] = val[induced[etid].long()]
+
+
 def _default_dst_nodes(g):
     """``to_block(g)`` without destination nodes: per node type the nodes with an inbound edge, ascending
     (transforms/functional.py to_block: ``F.unique`` of the relations' destination ids)."""
@@ -198,39 +227,18 @@ def _default_dst_nodes(g):
     return {n: (torch.unique(torch.cat(v)) if v else torch.empty(0, dtype=g.idtype, device=g.device)) for n, v in out.items()}
 
 
-def to_block(g, dst_nodes=None):
-    """``dgl.to_block`` for a homogeneous frontier graph (python/dgl/transforms/functional.py):
-    the block's destination nodes are ``dst_nodes`` in the given order and its source nodes start
-    with them (include_dst_in_src); ``srcdata / dstdata[dgl.NID]`` and ``edata[dgl.EID]`` map back
-    to ``g``.  Every edge of ``g`` must point at one of ``dst_nodes``."""
+def to_block(g, dst_nodes=None, include_dst_in_src=True, src_nodes=None):
+    """``dgl.to_block`` (python/dgl/transforms/functional.py to_block): the block's destination nodes are ``dst_nodes``
+    in the given order (default: per type the nodes with an inbound edge, ascending); its source nodes start with them
+    (``include_dst_in_src``) followed by the other sources in ascending order, or are ``src_nodes`` as given.
+    ``srcdata / dstdata[dgl.NID]`` and ``edata[dgl.EID]`` hold the ids in ``g``; the features of ``g`` follow its nodes
+    and edges into the block.  Every edge of ``g`` must point at one of ``dst_nodes``.  (:class:`NeighborSampler` then
+    replaces ``edata[dgl.EID]`` by the ORIGINAL graph's edge ids, like neighbor_sampler.py:170-172.)"""
     if dst_nodes is None:
         dst_nodes = _default_dst_nodes(g)
         if len(g.ntypes) == 1:
             dst_nodes = dst_nodes.get(g.ntypes[0], torch.empty(0, dtype=g.idtype, device=g.device))
-    if len(g.canonical_etypes) != 1 or len(g.ntypes) != 1 or isinstance(dst_nodes, dict):
-        return _to_block_hetero(g, dst_nodes)
-    rel = g._graph.relations[0]
-    dev, idt = rel.device, rel.idtype
-    dst_nodes = dst_nodes.to(device=dev, dtype=idt).contiguous()
-    indptr, indices, eids = rel.csc()                       # rows = every node of g
-    deg = (indptr[1:] - indptr[:-1])[dst_nodes.long()]
-    total = int(deg.sum())  # the one read-back of this function
-    if total != rel.num_edges:
-        raise ValueError("to_block: some edges of the frontier do not end in dst_nodes")
-    blk_ptr = torch.zeros(dst_nodes.shape[0] + 1, dtype=idt, device=dev)
-    blk_ptr[1:] = torch.cumsum(deg, 0)
-    # positions of the kept CSC entries, row by row in dst_nodes order
-    starts = indptr[:-1][dst_nodes.long()].long()
-    pos = torch.repeat_interleave(starts - blk_ptr[:-1].long(), deg.long(), output_size=total) + \
-        torch.arange(total, device=dev)
-    src = indices[pos].contiguous()
-    local, src_nodes, num_src = _renumber(dst_nodes, src, g, dev)
-    blk = _make_block(blk_ptr, local, num_src, dst_nodes.shape[0], idt, dev)
-    blk.srcdata[NID] = src_nodes
-    blk.dstdata[NID] = dst_nodes
-    orig = pos.to(idt) if eids is None else eids[pos]  # no map: edge id == CSC position
-    blk.edata[EID] = g.edata[EID][orig.long()] if EID in g.edata else orig
-    return blk
+    return _to_block_hetero(g, dst_nodes, include_dst_in_src, src_nodes)
 
 
 def _rows_of(rel, dst_nodes):
@@ -249,7 +257,7 @@ def _rows_of(rel, dst_nodes):
     return blk_ptr, pos
 
 
-def _to_block_hetero(g, dst_nodes):
+def _to_block_hetero(g, dst_nodes, include_dst_in_src=True, given_src=None):
     """``dgl.to_block`` on a frontier with several node / edge types (python/dgl/transforms/functional.py to_block,
     src/graph/transform/cuda/cuda_to_block.cu): ``dst_nodes`` = {node type: ids}; per node type the block's source nodes
     start with that type's destination nodes (include_dst_in_src), followed by the new sources of EVERY relation leaving
@@ -267,7 +275,9 @@ def _to_block_hetero(g, dst_nodes):
     rows, src_global, orig = [], [], []
     for etid, (s_t, _, d_t) in enumerate(cets):
         rel = g._graph.relations[etid]
-        if rel.num_edges == 0:
+        if rel.num_edges == 0 or dst[d_t].shape[0] == 0:
+            # no destination node of this relation's destination type: the relation comes out empty and its sources are
+            # not collected (src/graph/transform/to_block.cc:271-277)
             ptr = torch.zeros(dst[d_t].shape[0] + 1, dtype=idt, device=dev)
             pos = torch.empty(0, dtype=torch.long, device=dev)
         else:
@@ -275,19 +285,22 @@ def _to_block_hetero(g, dst_nodes):
         indices, eids = rel.csc()[1], rel.csc()[2]
         rows.append(ptr)
         src_global.append(indices[pos].contiguous())
-        o = pos.to(idt) if eids is None else eids[pos]
-        f = g._edge_frames[etid]
-        orig.append(f[EID][o.long()] if EID in f else o)
+        orig.append(pos.to(idt) if eids is None else eids[pos])     # ids in g (no map: edge id == CSC position)
     src_nodes, local = {}, [None] * len(cets)
     for ntid, n in enumerate(nts):
         ets = [i for i, c in enumerate(cets) if c[0] == n]
         cat = torch.cat([src_global[i] for i in ets]) if ets else torch.empty(0, dtype=idt, device=dev)
-        if dst[n].shape[0] == 0 and cat.shape[0] == 0:
+        if given_src is not None:
+            gs = given_src[n] if isinstance(given_src, dict) else given_src
+            loc, sn, _ = _renumber_into(torch.as_tensor(gs).to(device=dev, dtype=idt), cat, g._graph.num_nodes(ntid))
+        elif dst[n].shape[0] == 0 and cat.shape[0] == 0:
             src_nodes[n] = dst[n]
             for i in ets:
                 local[i] = cat
             continue
-        loc, sn, _ = _renumber(dst[n], cat, g, dev, ntid)
+        else:
+            first = dst[n] if include_dst_in_src else dst[n][:0]
+            loc, sn, _ = _renumber(first, cat, g, dev, ntid)
         src_nodes[n] = sn
         off = 0
         for i in ets:
@@ -309,6 +322,7 @@ def _to_block_hetero(g, dst_nodes):
         blk._node_frames[t + i][NID] = dst[n]
     for etid in range(len(cets)):
         blk._edge_frames[etid][EID] = orig[etid]
+    _copy_block_features(g, blk, src_nodes, dst, orig)
     return blk
 
 
@@ -339,6 +353,9 @@ class NeighborSampler:
             rng = (self.seed * 1000003 + self._calls) * 64 + layer
             frontier = sample_neighbors(g, seeds, fanout, prob=self.prob, replace=self.replace, seed=rng)
             blk = to_block(frontier, seeds)
+            for etid in range(len(g.canonical_etypes)):          # ids of the ORIGINAL graph (neighbor_sampler.py:170-172)
+                fe = frontier._edge_frames[etid][EID]
+                blk._edge_frames[etid][EID] = fe[blk._edge_frames[etid][EID].long()]
             blocks.insert(0, blk)
             seeds = {n: blk.srcnodes[n].data[NID] for n in g.ntypes}
         self._calls += 1

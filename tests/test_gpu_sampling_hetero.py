@@ -99,13 +99,18 @@ def test_to_block_keeps_one_node_set_per_type(dev):
         bu, bv = _edge_keys(blk, c)
         u = blk.srcnodes[c[0]].data[NID].long()[bu]
         v = blk.dstnodes[c[2]].data[NID].long()[bv]
-        eid = blk.edges[c].data[EID].long()
+        ind = blk.edges[c].data[EID].long()                  # ids in the FRONTIER (the reference's convention)
+        fu, fv = _edge_keys(f, c)
+        assert blk.num_edges(c) == f.num_edges(c) and torch.equal(fu[ind], u) and torch.equal(fv[ind], v)
+        assert torch.equal(torch.sort(ind)[0], torch.arange(f.num_edges(c), device=dev))
+        eid = f.edges[c].data[EID].long()[ind]               # ... and through the frontier, of the graph
         gu, gv = _edge_keys(g, c)
-        assert blk.num_edges(c) == f.num_edges(c) and torch.equal(gu[eid], u) and torch.equal(gv[eid], v)
-        fe = f.edges[c].data[EID].long()
-        assert torch.equal(torch.sort(eid)[0], torch.sort(fe)[0])
+        assert torch.equal(gu[eid], u) and torch.equal(gv[eid], v)
     with pytest.raises(ValueError):
-        dgl.to_block(f, {"user": seeds["user"]})            # the item-bound edges have no destination
+        dgl.to_block(f, {"user": seeds["user"], "item": seeds["item"][:2]})     # item-bound edges outside the given items
+    only_users = dgl.to_block(f, {"user": seeds["user"]})  # NO item destination at all: those relations come out empty
+    assert only_users.num_edges(("user", "buys", "item")) == 0 and only_users.num_dst_nodes("item") == 0
+    assert only_users.num_edges(("user", "follows", "user")) == f.num_edges(("user", "follows", "user"))
 
 
 def test_two_layer_blocks_carry_an_rgcn_step(dev):

@@ -172,7 +172,9 @@ def test_sample_neighbors_out_direction_and_to_block(dev):
     assert blk.num_dst_nodes() == seeds.numel() and torch.equal(blk.srcdata[dgl.NID][: seeds.numel()], seeds)
     bs, bd = blk.edges()
     fs, fd = fi.edges()
-    got = torch.stack([blk.srcdata[dgl.NID][bs.long()], blk.dstdata[dgl.NID][bd.long()], blk.edata[dgl.EID]])
+    # (to_block's edge ids are ids IN THE FRONTIER, as in the reference; the sampler maps them on to the original graph)
+    got = torch.stack([blk.srcdata[dgl.NID][bs.long()], blk.dstdata[dgl.NID][bd.long()], fi.edata[dgl.EID][blk.edata[dgl.EID].long()]])
+    assert torch.equal(fs[blk.edata[dgl.EID].long()], blk.srcdata[dgl.NID][bs.long()])
     want = torch.stack([fs, fd, fi.edata[dgl.EID]])
     key = lambda t: t[:, torch.argsort(t[2])]
     assert torch.equal(key(got), key(want))
