@@ -666,6 +666,19 @@ class DGLGraph:
             raise DGLAMDError("edge_ids: some (u, v) pairs are not edges of the graph")
         return order[at].to(g.idtype)
 
+    def has_edges_between(self, u, v, etype=None):
+        """Whether an edge u -> v exists, pair by pair (heterograph.py has_edges_between)."""
+        g = self if len(self._canonical_etypes) == 1 else self[etype]
+        u, v = g._ids(u), g._ids(v)
+        src, dst = g.edges()
+        n_dst = max(g._graph.relations[0].num_dst, 1)
+        key = torch.sort(src.long() * n_dst + dst.long())[0]
+        want = u.long() * n_dst + v.long()
+        if key.numel() == 0:
+            return torch.zeros_like(want, dtype=torch.bool)
+        at = torch.searchsorted(key, want).clamp(max=key.numel() - 1)
+        return key[at] == want
+
     # ---- mutation (used by the reference's suites to build their inputs) -------------------------------
     def _grow_frame(self, frame, extra, data=None):
         nf = _Frame(frame.num_rows + extra)

@@ -90,27 +90,31 @@ def _sample_neighbors_hetero(g, nodes, fanout, edge_dir, prob, replace, seed):
         dev, idt = rel.device, rel.idtype
         seeds = nodes.get(d_t if edge_dir == "in" else s_t)
         f = int(fanouts[etid])
-        if seeds is None or f == 0 or rel.num_edges == 0 or len(seeds) == 0:
+        if seeds is None or f == 0 or rel.num_edges == 0 or torch.as_tensor(seeds).numel() == 0:
             empty = torch.empty(0, dtype=idt, device=dev)
             rels.append(Relation(rel.num_src, rel.num_dst, empty, empty, idtype=idt, device=dev))
             picked.append(empty)
             continue
-        seeds = torch.as_tensor(seeds).to(device=dev, dtype=idt).contiguous()
+        seeds = torch.as_tensor(seeds).reshape(-1).to(device=dev, dtype=idt).contiguous()
         fmt = rel.csc() if edge_dir == "in" else rel.csr()
         csr = _capi.make_csr(fmt[0], fmt[1], fmt[2], rel.num_src if edge_dir == "in" else rel.num_dst)
         p = _prob_of(prob, g._edge_frames[etid], rel, "sample_neighbors")
         rng = int(seed) * 131 + etid
         if p is None:
             indptr, nbr, eids = _capi.sample_neighbors(csr, seeds, f, replace, rng)
+        elif f < 0:         # every edge that CAN be picked: all of them, minus those of zero weight
+            indptr, nbr, eids = _capi.sample_neighbors(csr, seeds, -1, False, rng)
         else:
-            if f < 0:
-                raise ValueError("weighted sampling needs a positive fanout")
             indptr, nbr, eids = _capi.sample_neighbors_weighted(csr, p, seeds, f, replace, rng)
         n_e = int(indptr[-1])
         own = torch.repeat_interleave(seeds, (indptr[1:] - indptr[:-1]).long(), output_size=n_e)
-        src, dst = (nbr[:n_e].contiguous(), own) if edge_dir == "in" else (own, nbr[:n_e].contiguous())
+        nbr, eids = nbr[:n_e], eids[:n_e]
+        if p is not None and f < 0:
+            keep_e = p[eids.long()] > 0
+            own, nbr, eids = own[keep_e], nbr[keep_e], eids[keep_e]
+        src, dst = (nbr.contiguous(), own) if edge_dir == "in" else (own, nbr.contiguous())
         rels.append(Relation(rel.num_src, rel.num_dst, src, dst, idtype=idt, device=dev))
-        picked.append(eids[:n_e])
+        picked.append(eids)
     gi = g._graph
     out = DGLGraph(GraphIndex([gi.num_nodes(i) for i in range(len(g._ntypes))], list(gi.metagraph.edges), rels),
                    g._ntypes, g.canonical_etypes, src_ntypes=g._src_ntype_ids, dst_ntypes=g._dst_ntype_ids)
@@ -141,12 +145,10 @@ def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, 
         csr = _capi.make_csr(keep[0], keep[1], keep[2], rel.num_dst)
     if isinstance(prob, str):  # name of an edge feature, as in the reference
         prob = g.edata[prob]
-    nodes = nodes.to(device=rel.device, dtype=rel.idtype).contiguous()
+    nodes = torch.as_tensor(nodes).reshape(-1).to(device=rel.device, dtype=rel.idtype).contiguous()   # (ids, a list or one id)
     if prob is None:
         indptr, nbr, eids = _capi.sample_neighbors(csr, nodes, int(fanout), replace, int(seed))
     else:
-        if fanout < 0:
-            raise ValueError("weighted sampling needs a positive fanout")
         # the kernels index `prob` by EDGE ID of g: anything else is an out-of-bounds device read
         # (reference: CHECK on the probability array's length, src/array/array.cc RowWiseSampling)
         if prob.dim() == 0 or prob.shape[0] != rel.num_edges or prob.numel() != rel.num_edges:
@@ -155,15 +157,41 @@ def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, 
         p = prob.to(rel.device)
         if p.dtype not in (torch.float32, torch.float64):
             p = p.float()
-        indptr, nbr, eids = _capi.sample_neighbors_weighted(csr, p.contiguous().reshape(-1), nodes, int(fanout),
-                                                            replace, int(seed))
+        p = p.contiguous().reshape(-1)
+        if fanout < 0:      # every edge that CAN be picked: all of them, minus those of zero weight
+            indptr, nbr, eids = _capi.sample_neighbors(csr, nodes, -1, False, int(seed))
+        else:
+            indptr, nbr, eids = _capi.sample_neighbors_weighted(csr, p, nodes, int(fanout), replace, int(seed))
     n_e = int(indptr[-1])
     own = torch.repeat_interleave(nodes, (indptr[1:] - indptr[:-1]).long(), output_size=n_e)
+    nbr, eids = nbr[:n_e], eids[:n_e]
+    if prob is not None and fanout < 0:
+        keep_e = p[eids.long()] > 0
+        own, nbr, eids = own[keep_e], nbr[keep_e], eids[keep_e]
+        n_e = int(eids.shape[0])
     src, dst = (nbr[:n_e].contiguous(), own) if edge_dir == "in" else (own, nbr[:n_e].contiguous())
     r = Relation(rel.num_src, rel.num_dst, src, dst, idtype=rel.idtype, device=rel.device)
     out = DGLGraph(GraphIndex([g.num_nodes()], [(0, 0)], [r]), ["_N"], [("_N", "_E", "_N")])
     out.edata[EID] = eids[:n_e]
     return out
+
+
+def sample_neighbors_fused(g, nodes, fanout, edge_dir="in", prob=None, replace=False, seed=None):
+    """``sample_neighbors`` followed by ``to_block`` on the seeds (python/dgl/sampling/neighbor.py
+    sample_neighbors_fused, a CPU-only fusion of the two there): the block of one sampling step, its edge ids those of
+    ``g``."""
+    if edge_dir != "in":
+        raise _DGLError("sample_neighbors_fused: only inbound sampling yields a block whose destinations are the seeds")
+    frontier = sample_neighbors(g, nodes, fanout, edge_dir=edge_dir, prob=prob, replace=replace, seed=seed)
+    if isinstance(nodes, dict):
+        seeds = {n: torch.as_tensor(v, device=g.device).reshape(-1) for n, v in nodes.items()}
+    else:
+        seeds = torch.as_tensor(nodes, device=g.device).reshape(-1)
+    blk = to_block(frontier, seeds)
+    for etid in range(len(g.canonical_etypes)):
+        fe = frontier._edge_frames[etid][EID]
+        blk._edge_frames[etid][EID] = fe[blk._edge_frames[etid][EID].long()]
+    return blk
 
 
 def _make_block(indptr, local_src, num_src, num_dst, idtype, device):

@@ -41,6 +41,9 @@ SPARSE_FILES = ["python/pytorch/sparse/" + f for f in (
 MP_FILES = ["python/common/test_heterograph-update-all.py", "python/common/test_heterograph-apply-edges.py",
             "python/common/test_heterograph-specialization.py", "python/common/test_readout.py",
             "python/common/transforms/test_to_block.py"]
+SAMPLING_FILE = "python/common/sampling/test_sampling.py"
+SAMPLING_SELECT = ["test_sample_neighbors_noprob", "test_sample_neighbors_prob", "test_sample_neighbors_outedge",
+                   "test_sample_neighbors_with_0deg"]
 NN_FILE = "python/pytorch/nn/test_nn.py"
 NN_SELECT = ["test_graph_conv0", "test_graph_conv", "test_graph_conv_e_weight", "test_graph_conv_e_weight_norm",
              "test_graph_conv_bi", "test_sage_conv", "test_sage_conv_bi", "test_sage_conv2", "test_gat_conv",
@@ -56,7 +59,7 @@ SELECT = {
 
 
 def prepare(src):
-    for f in FILES + SPARSE_FILES + [NN_FILE] + MP_FILES:
+    for f in FILES + SPARSE_FILES + [NN_FILE, SAMPLING_FILE] + MP_FILES:
         d = os.path.join(DEST, f)
         os.makedirs(os.path.dirname(d), exist_ok=True)
         shutil.copyfile(os.path.join(src, f), d)
@@ -182,7 +185,7 @@ def main():
     ap.add_argument("--src", default="/root/reference/tests")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ref_suite.jsonl"))
     ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"])
-    ap.add_argument("--suite", default="ops", choices=["ops", "sparse", "nn", "mp"],
+    ap.add_argument("--suite", default="ops", choices=["ops", "sparse", "nn", "mp", "sampling"],
                     help="ops: the operator suites (SELECT); sparse: tests/python/pytorch/sparse/*, every test")
     ap.add_argument("-k", default=None)
     ap.add_argument("--maxfail", type=int, default=0)
@@ -205,6 +208,8 @@ def main():
         targets = [os.path.join(DEST, f) for f in SPARSE_FILES if os.path.basename(f).startswith("test_")]
     elif args.suite == "mp":     # message passing on heterographs: update_all / apply_edges / pull / send_and_recv
         targets = [os.path.join(DEST, f) for f in MP_FILES]
+    elif args.suite == "sampling":
+        targets = ["%s::%s" % (os.path.join(DEST, SAMPLING_FILE), n) for n in SAMPLING_SELECT]
     elif args.suite == "nn":
         targets = ["%s::%s" % (os.path.join(DEST, NN_FILE), n) for n in NN_SELECT]
     else:

@@ -143,6 +143,34 @@ def arange(start, stop, dtype=th.int64, ctx=None):
     return th.arange(start, stop, dtype=dtype, device=ctx)
 
 
+def unique(x, return_inverse=False, return_counts=False):
+    return th.unique(x, return_inverse=return_inverse, return_counts=return_counts)
+
+
+def boolean_mask(x, mask):
+    return x[mask]
+
+
+def nonzero_1d(x):
+    return th.nonzero(x, as_tuple=False).squeeze(-1)
+
+
+def sort_1d(x):
+    return th.sort(x)
+
+
+def equal(x, y):
+    return x == y
+
+
+def logical_not(x):
+    return ~x
+
+
+def count_nonzero(x):
+    return int((x != 0).sum())
+
+
 def abs(x):
     return x.abs()
 
