@@ -216,7 +216,13 @@ def test_gather_backward_equals_the_scatter_of_the_reference(dev, monkeypatch, i
     x.grad = None
     getattr(dgl.ops, "copy_u_" + red)(g, x).backward(up)
     assert ran == ["mask", "spmm"] * 2
-    torch.testing.assert_close(x.grad.double(), want, rtol=tol, atol=tol * 4)
+    # the atomic kernel adds in the tensor's own type, in whatever order the atomics land (as the reference's
+    # scatter_add_ does): node 0 collects the gradient of every destination without an in-edge — dozens of 16-bit
+    # additions — so its row is held to the bound of that many roundings, the others to the plain tolerance
+    torch.testing.assert_close(x.grad.double()[1:], want[1:], rtol=tol, atol=tol * 4)
+    addends = int((arg_u.reshape(n, -1)[:, 0] == 0).sum())
+    wide = tol * 4 * max(1.0, addends ** 0.5) if dtype in (torch.bfloat16, torch.float16) else tol * 4
+    torch.testing.assert_close(x.grad.double()[:1], want[:1], rtol=tol, atol=wide)
 
 
 def test_gather_backward_u_add_e_max(dev):
