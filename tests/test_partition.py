@@ -230,3 +230,24 @@ def test_balance_ntypes_balances_every_type():
     plain, _ = partition_assignment(indptr, indices, k, imbalance=0.05, seed=2)
     cnt = torch.bincount(plain[ntype == 1], minlength=k).double()
     assert float(cnt.max()) > 1.5 * float(cnt.sum()) / k      # without the constraint type 1 sits in two parts
+
+
+def test_counter_table_cap_skips_the_directed_refinement(monkeypatch):
+    """The k-way refiner's dense n x k counter table is capped (DGLA_PARTITION_TABLE_MAX_BYTES): above the cap the
+    multilevel result stands and the volume statistics are reported as unknown, instead of an allocation the size of the
+    graph times k."""
+    import torch
+    from dgl_amd.parallel import partition_assignment
+
+    g = torch.Generator().manual_seed(0)
+    n, e = 4000, 40000
+    row = torch.sort(torch.randint(n, (e,), generator=g))[0]
+    indptr = torch.zeros(n + 1, dtype=torch.int64)
+    indptr[1:] = torch.cumsum(torch.bincount(row, minlength=n), 0)
+    indices = torch.randint(n, (e,), generator=g)
+    part, stats = partition_assignment(indptr, indices, 4, seed=1, objtype="vol")
+    assert stats["volume"] > 0
+    monkeypatch.setenv("DGLA_PARTITION_TABLE_MAX_BYTES", "1000")
+    part2, stats2 = partition_assignment(indptr, indices, 4, seed=1, objtype="vol")
+    assert stats2["volume"] == -1 and part2.shape == part.shape and int(part2.max()) == 3
+    assert torch.bincount(part2, minlength=4).max() <= 1.1 * n / 4 + 2
