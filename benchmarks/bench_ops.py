@@ -713,6 +713,37 @@ def fmt(dev, args):
         del src, dst
 
 
+def sparse_front(dev, args):
+    """The dgl.sparse front end on the C2-shaped matrix (2.45 M x 2.45 M, 61.9 M nonzeros): the same kernels as the
+    operator API.  A matrix made from CSR keeps its values in CSR order (no map); one made from COO indices — how
+    dgl.sparse users usually make them — reads its values through the value-index permutation, like an edge-id map."""
+    import dgl_amd.sparse as dglsp
+
+    n, e, f = C2_NODES // args.scale, C2_EDGES // args.scale, C2_FEAT
+    g = synth_csr(n, n, e, "U", device=dev, with_eids=True)
+    torch.manual_seed(2)
+    x = torch.rand(n, f, device=dev) + 1
+    val = torch.rand(e, device=dev) + 1
+    a_csr = dglsp.from_csr(g["indptr"].long(), g["indices"].long(), val, (n, n))
+    row = torch.repeat_interleave(torch.arange(n, device=dev), (g["indptr"][1:] - g["indptr"][:-1]).long())
+    perm = torch.randperm(e, device=dev)
+    a_coo = dglsp.from_coo(row[perm], g["indices"].long()[perm], val[perm], (n, n))
+    a_coo.csr()                                     # (built once, like a graph's formats)
+    nb = spmm_bytes(n, e, f, f, 4, 8, 1)
+    for name, a, extra in (("made from CSR (values in CSR order)", a_csr, 0), ("made from COO indices (value-index map)", a_coo, e * 8)):
+        ms, mn = timeit(lambda: dglsp.spmm(a, x))
+        emit("SP", "dgl.sparse.spmm, int64 indices, F=100, matrix " + name, e, ms, mn, nb + extra)
+    x1, x2 = torch.rand(n, 16, device=dev), torch.rand(16, n, device=dev)
+    ms, mn = timeit(lambda: dglsp.sddmm(a_csr, x1, x2))
+    emit("SP", "dgl.sparse.sddmm (K=16), matrix made from CSR", e, ms, mn, e * (2 * 16 * 4 + 8 + 8))
+    ms, mn = timeit(lambda: a_csr.softmax(1))
+    emit("SP", "dgl.sparse softmax over rows, matrix made from CSR", e, ms, mn, e * (4 + 4 + 8))
+    ms, mn = timeit(lambda: a_coo.softmax(1))
+    emit("SP", "dgl.sparse softmax over rows, matrix made from COO indices", e, ms, mn, e * (4 + 4 + 8 + 8))
+    ms, mn = timeit(lambda: a_csr.smax(1))
+    emit("SP", "dgl.sparse smax along rows (g-SpMM copy_e max), matrix made from CSR", e, ms, mn, e * (4 + 8) + n * 12)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -724,7 +755,7 @@ def main():
     global VERIFY
     VERIFY = args.verify
     dev = torch.device("cuda:0")
-    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("C5MAX", c5max), ("SEG", seg), ("MM", mm), ("SAMPLE", sample), ("GAT", gat_graph), ("EO", edge_order), ("FMT", fmt)):
+    for name, fn in (("C2", c2), ("C3", c3), ("C5", c5), ("C5MAX", c5max), ("SEG", seg), ("MM", mm), ("SAMPLE", sample), ("GAT", gat_graph), ("EO", edge_order), ("FMT", fmt), ("SP", sparse_front)):
         if args.only and name not in args.only.split(","):
             continue
         fn(dev, args)
