@@ -242,6 +242,11 @@ def get_tuning():
     return int(LIB.dgla_get_tuning())
 
 
+def narrow_reduce_calls():
+    """dgla_spmm_csr calls served by the narrow-feature copy_e kernels so far (dgla_narrow_reduce_calls)."""
+    return int(LIB.dgla_narrow_reduce_calls())
+
+
 def segment_reduce(reduce, feat, offsets, out, arg=None, workspace=None, plan_valid=False):
     """out[i] = reduce(feat[offsets[i]:offsets[i+1]]) (dgla_segment_reduce).  `workspace` may
     be None (stream-ordered scratch inside the call) or a uint8 tensor of

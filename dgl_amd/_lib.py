@@ -195,6 +195,8 @@ LIB.dgla_partition_to_global.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p
 LIB.dgla_set_tuning.restype = c_int
 LIB.dgla_set_tuning.argtypes = [c_uint32]
 LIB.dgla_get_tuning.restype = c_uint32
+LIB.dgla_narrow_reduce_calls.restype = c_int64
+LIB.dgla_narrow_reduce_calls.argtypes = []
 LIB.dgla_stream_copy.restype = c_int
 LIB.dgla_stream_copy.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
 LIB.dgla_stream_copy_variant.restype = c_int

@@ -28,6 +28,10 @@ ProfileEvents& profile_events() {
 }
 
 // per-dtype launchers (spmm_<dtype>.hip, sddmm_<dtype>.hip, aux_kernels.hip)
+bool narrow_reduce_eligible(const SpmmLaunch&);          // narrow_reduce.hip: copy_e with 1 ... 8 fp32 columns
+size_t narrow_reduce_workspace_bytes(const SpmmLaunch&);
+int launch_narrow_reduce(const SpmmLaunch&, void* ws);
+int64_t narrow_reduce_calls();
 int launch_spmm_csr_f32(const SpmmLaunch&);
 int launch_spmm_csr_f64(const SpmmLaunch&);
 int launch_spmm_csr_f16(const SpmmLaunch&);
@@ -320,6 +324,7 @@ __global__ void stacked_args_kernel(Idx* __restrict__ pos_buf, const Idx* __rest
 extern "C" {
 
 const char* dgla_last_error(void) { return last_error().c_str(); }
+int64_t dgla_narrow_reduce_calls(void) { return narrow_reduce_calls(); }
 int dgla_abi_version(void) { return DGLA_ABI_VERSION; }
 
 size_t dgla_spmm_csr_workspace_bytes(const char* op, const char* reduce, const dgla_csr* csr,
@@ -327,6 +332,10 @@ size_t dgla_spmm_csr_workspace_bytes(const char* op, const char* reduce, const d
                                      const dgla_tensor* efeat, const dgla_tensor* out) {
   SpmmLaunch L{};
   if (build_spmm_launch(op, reduce, csr, dtype, ufeat, efeat, out, &L)) return 0;
+  // narrow copy_e (narrow_reduce.hip): its records go BEHIND what the merge kernel would take for this call, so that the
+  // merge plan at the front of a workspace shared by all the operators of a graph stays valid
+  if (narrow_reduce_eligible(L))
+    return ((spmm_csr_workspace_f32(L) + 255) & ~static_cast<size_t>(255)) + narrow_reduce_workspace_bytes(L);
   switch (dtype) {
     case DGLA_F32: return spmm_csr_workspace_f32(L);
     case DGLA_F64: return spmm_csr_workspace_f64(L);
@@ -363,6 +372,20 @@ int dgla_spmm_csr(const char* op, const char* reduce, const dgla_csr* csr, dgla_
   L.stream = static_cast<hipStream_t>(hip_stream);
   if (csr->num_rows == 0 || L.out_len == 0) return 0;
   const DeviceGuard dev(L.stream, L.out);
+  if (narrow_reduce_eligible(L)) {
+    const size_t front = (spmm_csr_workspace_f32(L) + 255) & ~static_cast<size_t>(255);
+    if (workspace && workspace_bytes >= front + narrow_reduce_workspace_bytes(L)) {
+      // the contract of this entry point: after a successful call the workspace holds the graph's merge plan (callers
+      // pass DGLA_PLAN_VALID from then on, whatever operator comes next) — so a first call builds it here as well
+      if (!L.plan_valid) {
+        SpmmLaunch P = L;
+        P.prepare_only = true;
+        if (const int rc = launch_spmm_csr_f32(P)) return rc;
+      }
+      L.arg_empty = 0;
+      return launch_narrow_reduce(L, static_cast<char*>(workspace) + front);
+    }   // (a caller that sized its workspace before this route existed: the merge kernel takes the call)
+  }
   switch (dtype) {
     case DGLA_F32: return launch_spmm_csr_f32(L);
     case DGLA_F64: return launch_spmm_csr_f64(L);

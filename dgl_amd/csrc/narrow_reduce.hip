@@ -1,0 +1,434 @@
+// g-SpMM copy_e with NARROW edge features (1 ... 8 fp32 columns per edge) over the in-edge CSR, for gfx950.
+//
+// Same arithmetic as SpMMCsrKernel with the CopyRhs operator (src/array/cuda/spmm.cuh:440-520 — one edge feature row per
+// edge, reduced into its destination row; winners' edge ids for max / min).  The merge kernel (spmm_csr.hip.h) gives a
+// feature COLUMN to a lane: below 16 columns most of a wave idles and the kernel is bound by issue — 30 G edges/s on the
+// ogbn-products-shaped graph whatever the width, 1.84 ms for 250 MB of scalars (profiles/r5/narrow_feature_reductions.jsonl).
+// Here a lane owns four consecutive EDGES with all their columns, a wave 256 consecutive CSR positions (a "unit"):
+//   1. the row holding the unit's first position by one wave-uniform binary search; the row starts that fall inside the
+//      unit are marked in LDS by the lanes reading indptr[r_first + 1 + lane ...] (start bits + the id of the row that
+//      starts there; empty rows in between cost nothing: the largest id wins);
+//   2. every lane reduces its four edges into runs; a run that begins and ends inside a lane is stored at once;
+//   3. a segmented scan over the lanes (the open run at a lane's end is carried to the lane that closes it);
+//   4. a row cut by a unit boundary leaves its pieces in the workspace — (head: the piece at the start of a unit, tail:
+//      the piece at its end) — and a second, tiny kernel adds the pieces of each such row in position order.
+// Deterministic: the order of the additions depends on the CSR alone.  Rows without an edge keep the reducer's identity
+// (0, -inf, +inf) and argument 0, written by a fill kernel in front, as the merge kernel leaves them.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+
+#include "common.h"
+
+namespace dgla {
+namespace {
+
+constexpr int kNrLaneEdges = 4;
+constexpr int kNrUnit = 64 * kNrLaneEdges;   // CSR positions per wave
+constexpr int kNrWaves = 4;                  // waves (units) per workgroup
+constexpr uint8_t kNrHead = 1, kNrHeadClosed = 2, kNrTail = 4;
+
+template <int RED, int F>
+struct Run {               // partial result of a run of edges: F values (+ the winners' CSR positions for max / min)
+  float v[F];
+  int64_t p[RED == kSum ? 1 : F];
+};
+
+template <int RED, int F>
+__device__ __forceinline__ void run_reset(Run<RED, F>& r) {
+#pragma unroll
+  for (int c = 0; c < F; ++c) {
+    r.v[c] = RED == kSum ? 0.f : (RED == kMax ? -__builtin_huge_valf() : __builtin_huge_valf());
+    if constexpr (RED != kSum) r.p[c] = -1;
+  }
+}
+
+// a = a (+) b with a the EARLIER positions: sums add in that order, max / min keep the earlier winner on a tie
+template <int RED, int F>
+__device__ __forceinline__ void run_append(Run<RED, F>& a, const Run<RED, F>& b) {
+#pragma unroll
+  for (int c = 0; c < F; ++c) {
+    if constexpr (RED == kSum) {
+      a.v[c] += b.v[c];
+    } else {
+      const bool take = RED == kMax ? b.v[c] > a.v[c] : b.v[c] < a.v[c];
+      if (take || a.p[c] < 0) {
+        if (b.p[c] >= 0) {
+          a.v[c] = b.v[c];
+          a.p[c] = b.p[c];
+        }
+      }
+    }
+  }
+}
+
+template <int RED, int F>
+__device__ __forceinline__ Run<RED, F> run_shfl_up(const Run<RED, F>& r, int d) {
+  Run<RED, F> o;
+#pragma unroll
+  for (int c = 0; c < F; ++c) {
+    o.v[c] = __shfl_up(r.v[c], d, 64);
+    if constexpr (RED != kSum) {
+      const int lo = __shfl_up(static_cast<int>(r.p[c] & 0xffffffffLL), d, 64);
+      const int hi = __shfl_up(static_cast<int>(r.p[c] >> 32), d, 64);
+      o.p[c] = (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+    }
+  }
+  return o;
+}
+
+struct NrWorkspace {       // per unit: records of the rows it shares with its neighbours
+  float* head_v;           // [units][F]
+  float* tail_v;
+  int64_t* head_p;         // [units][F] (max / min)
+  int64_t* tail_p;
+  int64_t* head_row;       // [units]
+  int64_t* tail_row;
+  int64_t* first_row;      // [units] row holding the unit's first position (narrow_plan_kernel)
+  uint8_t* flags;          // [units]
+};
+
+// The row that holds a unit's first position — the largest r with indptr[r] <= position: one thread per unit (a search
+// per WAVE inside the reduce kernel was 22 dependent loads in front of every unit: 59 rounds of them on this chip).
+template <typename Idx>
+__global__ __launch_bounds__(256) void narrow_plan_kernel(const Idx* __restrict__ indptr, int64_t num_rows, int64_t units,
+                                                         int64_t* __restrict__ first_row) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t u = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; u < units; u += stride) {
+    const int64_t base = u * kNrUnit;
+    int64_t lo = 0, hi = num_rows - 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (static_cast<int64_t>(indptr[mid]) <= base)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    first_row[u] = lo;
+  }
+}
+
+// `mean_ptr` (sum only; the row offsets, or null): store sum / in-degree — the quotient the reference forms after its
+// sum (python/dgl/ops/spmm.py:109-114), an IEEE division like the merge kernel's DGLA_MEAN
+template <typename Idx, int RED, int F>
+__device__ __forceinline__ void store_row(float* __restrict__ out, Idx* __restrict__ arg, const Idx* __restrict__ eids,
+                                          int64_t row, const Run<RED, F>& r, const Idx* __restrict__ mean_ptr) {
+  float den = 1.f;
+  if constexpr (RED == kSum) {
+    if (mean_ptr) den = static_cast<float>(static_cast<int64_t>(mean_ptr[row + 1]) - static_cast<int64_t>(mean_ptr[row]));
+  }
+#pragma unroll
+  for (int c = 0; c < F; ++c) {
+    if constexpr (RED == kSum)
+      out[row * F + c] = mean_ptr ? r.v[c] / den : r.v[c];
+    else
+      out[row * F + c] = r.v[c];
+    if constexpr (RED != kSum) arg[row * F + c] = eids ? eids[r.p[c]] : static_cast<Idx>(r.p[c]);
+  }
+}
+
+template <int RED, int F>
+__device__ __forceinline__ void rec_store(float* v, int64_t* p, int64_t unit, const Run<RED, F>& r) {
+#pragma unroll
+  for (int c = 0; c < F; ++c) {
+    v[unit * F + c] = r.v[c];
+    if constexpr (RED != kSum) p[unit * F + c] = r.p[c];
+  }
+}
+
+template <int RED, int F>
+__device__ __forceinline__ Run<RED, F> rec_load(const float* v, const int64_t* p, int64_t unit) {
+  Run<RED, F> r;
+#pragma unroll
+  for (int c = 0; c < F; ++c) {
+    r.v[c] = v[unit * F + c];
+    if constexpr (RED != kSum) r.p[c] = p[unit * F + c];
+  }
+  return r;
+}
+
+template <typename Idx, int RED, int F>
+__global__ __launch_bounds__(64 * kNrWaves) void narrow_fill_kernel(float* __restrict__ out, Idx* __restrict__ arg, int64_t n,
+                                                                   Idx arg_empty) {
+  const float id = RED == kSum ? 0.f : (RED == kMax ? -__builtin_huge_valf() : __builtin_huge_valf());
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) {
+    out[i] = id;
+    if constexpr (RED != kSum) arg[i] = arg_empty;
+  }
+}
+
+template <typename Idx, int RED, int F>
+__global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const Idx* __restrict__ indptr, const Idx* __restrict__ eids,
+                                                                     const float* __restrict__ efeat, float* __restrict__ out,
+                                                                     Idx* __restrict__ arg, int64_t num_rows, int64_t nnz,
+                                                                     int64_t units, NrWorkspace ws, int mean) {
+  const Idx* __restrict__ mean_ptr = mean ? indptr : nullptr;
+  __shared__ uint32_t s_bits[kNrWaves][kNrUnit / 32];
+  __shared__ int64_t s_row[kNrWaves][kNrUnit];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t unit = blockIdx.x * static_cast<int64_t>(kNrWaves) + wave;
+  if (unit >= units) return;   // (no workgroup barrier below: the waves of a workgroup are independent)
+  const int64_t base = unit * kNrUnit;
+  const int64_t uend = base + kNrUnit < nnz ? base + kNrUnit : nnz;
+
+  const int64_t r_first = ws.first_row[unit];   // the row that holds position `base`
+  const bool left_open = static_cast<int64_t>(indptr[r_first]) < base;
+
+  // ---- row starts inside the unit -> start bits + row ids in LDS ---------------------------------------------------
+  if (lane < kNrUnit / 32) s_bits[wave][lane] = 0u;
+#pragma unroll
+  for (int j = 0; j < kNrLaneEdges; ++j) s_row[wave][kNrLaneEdges * lane + j] = -1;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int64_t r = r_first + 1 + lane;; r += 64) {
+    bool in = false;
+    if (r < num_rows) {
+      const int64_t s = static_cast<int64_t>(indptr[r]);
+      in = s < uend;
+      if (in) {
+        const int q = static_cast<int>(s - base);
+        atomicOr(&s_bits[wave][q >> 5], 1u << (q & 31));
+        atomicMax(reinterpret_cast<long long*>(&s_row[wave][q]), static_cast<long long>(r));
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(in) != ~0ull) break;   // starts ascend: the first lane past the unit ends the search
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t bits = (s_bits[wave][lane >> 3] >> ((lane & 7) * kNrLaneEdges)) & ((1u << kNrLaneEdges) - 1u);
+  int64_t row_at[kNrLaneEdges];
+  int64_t lane_last = -1;
+#pragma unroll
+  for (int j = 0; j < kNrLaneEdges; ++j) {
+    row_at[j] = s_row[wave][kNrLaneEdges * lane + j];
+    if ((bits >> j) & 1u) lane_last = row_at[j];
+  }
+  // row in progress at the start of this lane: the last row start in the lanes before it (row ids ascend), or r_first
+  int64_t incl = lane_last;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int tl = __shfl_up(static_cast<int>(incl & 0xffffffffLL), d, 64), th = __shfl_up(static_cast<int>(incl >> 32), d, 64);
+    const int64_t t = (static_cast<int64_t>(th) << 32) | static_cast<uint32_t>(tl);
+    if (lane >= d && t > incl) incl = t;
+  }
+  int64_t cur_row;
+  {
+    const int tl = __shfl_up(static_cast<int>(incl & 0xffffffffLL), 1, 64), th = __shfl_up(static_cast<int>(incl >> 32), 1, 64);
+    const int64_t ex = lane == 0 ? -1 : ((static_cast<int64_t>(th) << 32) | static_cast<uint32_t>(tl));
+    cur_row = ex > r_first ? ex : r_first;
+  }
+
+  // ---- the lane's four edges -------------------------------------------------------------------------------------------
+  const int64_t p0 = base + kNrLaneEdges * lane;
+  Run<RED, F> acc, pre;
+  run_reset(acc);
+  run_reset(pre);
+  int64_t pre_row = -1;
+  bool seen = false;
+#pragma unroll
+  for (int j = 0; j < kNrLaneEdges; ++j) {
+    const int64_t pos = p0 + j;
+    if ((bits >> j) & 1u) {      // a row starts here: the run in progress ends
+      if (!seen) {
+        pre = acc;
+        pre_row = cur_row;
+        seen = true;
+      } else {
+        store_row<Idx, RED, F>(out, arg, eids, cur_row, acc, mean_ptr);
+      }
+      cur_row = row_at[j];
+      run_reset(acc);
+    }
+    if (pos < uend) {
+      const int64_t vi = eids ? static_cast<int64_t>(eids[pos]) : pos;
+      Run<RED, F> one;
+#pragma unroll
+      for (int c = 0; c < F; ++c) {
+        one.v[c] = efeat[vi * F + c];
+        if constexpr (RED != kSum) one.p[c] = pos;
+      }
+      run_append(acc, one);
+    }
+  }
+  // ---- segmented inclusive scan over the lanes of the runs left open at a lane's end --------------------------------
+  Run<RED, F> x = acc;
+  bool f = seen;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    Run<RED, F> tx = run_shfl_up(x, d);
+    const bool tf = __shfl_up(static_cast<int>(f), d, 64) != 0;
+    if (lane >= d) {
+      if (!f) {
+        run_append(tx, x);   // (earlier lanes first)
+        x = tx;
+      }
+      f = f || tf;
+    }
+  }
+  Run<RED, F> carry = run_shfl_up(x, 1);
+  if (lane == 0) run_reset(carry);
+  const uint64_t heads = __builtin_amdgcn_ballot_w64(seen);
+  const bool first_head_lane = seen && (heads & ((1ull << lane) - 1ull)) == 0ull;
+  if (seen) {
+    run_append(carry, pre);      // the run this lane's first row start closes: earlier lanes' open run + its own leading edges
+    if (first_head_lane && left_open) {
+      rec_store<RED, F>(ws.head_v, ws.head_p, unit, carry);     // ... began in an earlier unit: a head record
+    } else {
+      store_row<Idx, RED, F>(out, arg, eids, pre_row, carry, mean_ptr);
+    }
+  }
+  // ---- the run open at the unit's end (lane 63 holds it after the scan) -----------------------------------------------
+  const int64_t t_row = (static_cast<int64_t>(__shfl(static_cast<int>(cur_row >> 32), 63, 64)) << 32) |
+                        static_cast<uint32_t>(__shfl(static_cast<int>(cur_row & 0xffffffffLL), 63, 64));
+  const bool complete = static_cast<int64_t>(indptr[t_row + 1]) <= uend;
+  const bool began_here = heads != 0ull || !left_open;
+  if (lane == 63) {
+    if (began_here) {
+      if (complete)
+        store_row<Idx, RED, F>(out, arg, eids, t_row, x, mean_ptr);
+      else
+        rec_store<RED, F>(ws.tail_v, ws.tail_p, unit, x);
+    } else {
+      rec_store<RED, F>(ws.head_v, ws.head_p, unit, x);            // the whole unit is a piece of ONE earlier row
+    }
+  }
+  if (lane == 0) {
+    uint8_t fl = 0;
+    if (left_open) fl |= kNrHead | ((heads != 0ull || complete) ? kNrHeadClosed : 0);
+    if (began_here && !complete) fl |= kNrTail;
+    ws.flags[unit] = fl;
+    ws.head_row[unit] = r_first;
+    ws.tail_row[unit] = t_row;
+  }
+}
+
+// One thread per unit whose head piece CLOSES a row that began earlier: the pieces, walked back to the unit the row began
+// in, added in position order.
+template <typename Idx, int RED, int F>
+__global__ __launch_bounds__(256) void narrow_fixup_kernel(const Idx* __restrict__ eids, float* __restrict__ out,
+                                                          Idx* __restrict__ arg, int64_t units, NrWorkspace ws,
+                                                          const Idx* __restrict__ mean_ptr) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t b = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; b < units; b += stride) {
+    const uint8_t fl = ws.flags[b];
+    if ((fl & (kNrHead | kNrHeadClosed)) != (kNrHead | kNrHeadClosed)) continue;
+    Run<RED, F> total = rec_load<RED, F>(ws.head_v, ws.head_p, b);
+    for (int64_t u = b - 1; u >= 0; --u) {
+      const uint8_t fu = ws.flags[u];
+      const bool whole = (fu & kNrHead) && !(fu & kNrHeadClosed);   // unit u is a piece of the same row end to end
+      Run<RED, F> piece = whole ? rec_load<RED, F>(ws.head_v, ws.head_p, u) : rec_load<RED, F>(ws.tail_v, ws.tail_p, u);
+      run_append(piece, total);
+      total = piece;
+      if (!whole) break;
+    }
+    store_row<Idx, RED, F>(out, arg, eids, ws.head_row[b], total, mean_ptr);
+  }
+}
+
+inline size_t nr_align(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+
+size_t nr_bytes(int64_t nnz, int f, bool cmp) {
+  const size_t units = static_cast<size_t>((nnz + kNrUnit - 1) / kNrUnit);
+  size_t b = 2 * nr_align(units * f * sizeof(float)) + 3 * nr_align(units * sizeof(int64_t)) + nr_align(units);
+  if (cmp) b += 2 * nr_align(units * f * sizeof(int64_t));
+  return b;
+}
+
+template <typename Idx, int RED, int F>
+int nr_launch(const SpmmLaunch& L, char* wsp) {
+  const int64_t nnz = L.csr.nnz, n = L.csr.num_rows;
+  const int64_t units = (nnz + kNrUnit - 1) / kNrUnit;
+  NrWorkspace ws;
+  char* q = wsp;
+  auto take = [&](size_t bytes) {
+    char* r = q;
+    q += nr_align(bytes);
+    return r;
+  };
+  ws.head_v = reinterpret_cast<float*>(take(units * F * sizeof(float)));
+  ws.tail_v = reinterpret_cast<float*>(take(units * F * sizeof(float)));
+  ws.head_row = reinterpret_cast<int64_t*>(take(units * sizeof(int64_t)));
+  ws.tail_row = reinterpret_cast<int64_t*>(take(units * sizeof(int64_t)));
+  ws.first_row = reinterpret_cast<int64_t*>(take(units * sizeof(int64_t)));
+  ws.flags = reinterpret_cast<uint8_t*>(take(units));
+  ws.head_p = ws.tail_p = nullptr;
+  if (RED != kSum) {
+    ws.head_p = reinterpret_cast<int64_t*>(take(units * F * sizeof(int64_t)));
+    ws.tail_p = reinterpret_cast<int64_t*>(take(units * F * sizeof(int64_t)));
+  }
+  float* out = static_cast<float*>(L.out);
+  Idx* arg = static_cast<Idx*>(L.arg_e);
+  const Idx* indptr = static_cast<const Idx*>(L.csr.indptr);
+  const Idx* eids = static_cast<const Idx*>(L.csr.eids);
+  const int64_t total = n * F;
+  const unsigned fill_blocks = static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 8192));
+  hipLaunchKernelGGL((narrow_fill_kernel<Idx, RED, F>), dim3(fill_blocks), dim3(64 * kNrWaves), 0, L.stream, out, arg, total,
+                     static_cast<Idx>(L.arg_empty));
+  if (units > 0) {
+    hipLaunchKernelGGL((narrow_plan_kernel<Idx>), dim3(static_cast<unsigned>(std::min<int64_t>((units + 255) / 256, 4096))),
+                       dim3(256), 0, L.stream, indptr, n, units, ws.first_row);
+    hipLaunchKernelGGL((narrow_reduce_kernel<Idx, RED, F>), dim3(static_cast<unsigned>((units + kNrWaves - 1) / kNrWaves)),
+                       dim3(64 * kNrWaves), 0, L.stream, indptr, eids, static_cast<const float*>(L.efeat), out, arg, n, nnz,
+                       units, ws, L.mean ? 1 : 0);
+    hipLaunchKernelGGL((narrow_fixup_kernel<Idx, RED, F>), dim3(static_cast<unsigned>(std::min<int64_t>((units + 255) / 256, 4096))),
+                       dim3(256), 0, L.stream, eids, out, arg, units, ws, L.mean ? indptr : static_cast<const Idx*>(nullptr));
+  }
+  DGLA_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename Idx, int RED>
+int nr_dispatch_f(const SpmmLaunch& L, char* ws) {
+  switch (L.out_len) {
+    case 1: return nr_launch<Idx, RED, 1>(L, ws);
+    case 2: return nr_launch<Idx, RED, 2>(L, ws);
+    case 3: return nr_launch<Idx, RED, 3>(L, ws);
+    case 4: return nr_launch<Idx, RED, 4>(L, ws);
+    case 5: return nr_launch<Idx, RED, 5>(L, ws);
+    case 6: return nr_launch<Idx, RED, 6>(L, ws);
+    case 7: return nr_launch<Idx, RED, 7>(L, ws);
+    default: return nr_launch<Idx, RED, 8>(L, ws);
+  }
+}
+
+template <typename Idx>
+int nr_dispatch(const SpmmLaunch& L, char* ws) {
+  switch (L.red) {
+    case kSum: return nr_dispatch_f<Idx, kSum>(L, ws);
+    case kMax: return nr_dispatch_f<Idx, kMax>(L, ws);
+    default: return nr_dispatch_f<Idx, kMin>(L, ws);
+  }
+}
+
+}  // namespace
+
+// copy_e, fp32, 1 ... 8 columns, one relation, plain store: the shapes this file takes (DGLA_NARROW_REDUCE=0: none)
+bool narrow_reduce_eligible(const SpmmLaunch& L) {
+  static const bool on = [] {
+    const char* e = std::getenv("DGLA_NARROW_REDUCE");
+    return !(e && e[0] == '0');
+  }();
+  return on && L.dtype == 0 /* DGLA_F32 */ && L.op == kCopyRhs && L.out_len >= 1 && L.out_len <= 8 && L.rhs_len == L.out_len &&
+         !L.accumulate && (!L.mean || L.red == kSum) && !L.prepare_only && L.rel == nullptr && !L.rhs_mask && L.csr.nnz > 0 &&
+         L.csr.num_rows > 0;
+}
+
+size_t narrow_reduce_workspace_bytes(const SpmmLaunch& L) { return nr_bytes(L.csr.nnz, static_cast<int>(L.out_len), L.red != kSum); }
+
+static std::atomic<int64_t> g_narrow_calls{0};
+int64_t narrow_reduce_calls() { return g_narrow_calls.load(); }
+
+// `ws`: narrow_reduce_workspace_bytes(L) bytes, outside the merge plan's region (the plan of the graph stays valid)
+int launch_narrow_reduce(const SpmmLaunch& L, void* ws) {
+  g_narrow_calls.fetch_add(1);
+  if (L.red != kSum && !L.arg_e) {
+    last_error() = "arg_e is required for max/min";
+    return -1;
+  }
+  return L.csr.idbits == 32 ? nr_dispatch<int32_t>(L, static_cast<char*>(ws)) : nr_dispatch<int64_t>(L, static_cast<char*>(ws));
+}
+
+}  // namespace dgla

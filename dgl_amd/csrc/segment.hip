@@ -23,6 +23,9 @@
 
 namespace dgla {
 
+bool narrow_reduce_eligible(const SpmmLaunch&);          // narrow_reduce.hip: 1 ... 8 fp32 columns per row
+size_t narrow_reduce_workspace_bytes(const SpmmLaunch&);
+int launch_narrow_reduce(const SpmmLaunch&, void* ws);
 int launch_spmm_csr_f32(const SpmmLaunch&);
 int launch_spmm_csr_f64(const SpmmLaunch&);
 int launch_spmm_csr_f16(const SpmmLaunch&);
@@ -531,6 +534,8 @@ size_t dgla_segment_reduce_workspace_bytes(const char* reduce, int idtype_bits, 
   SpmmLaunch L{};
   static const int64_t dummy = 0;
   if (build_segment_launch(reduce, idtype_bits, dtype, feat, &dummy, num_segments, out, &L)) return 0;
+  if (narrow_reduce_eligible(L))   // (behind the merge kernel's share: the plan at the front of the workspace stays valid)
+    return ((spmm_csr_workspace_f32(L) + 255) & ~static_cast<size_t>(255)) + narrow_reduce_workspace_bytes(L);
   switch (dtype) {
     case DGLA_F32: return spmm_csr_workspace_f32(L);
     case DGLA_F64: return spmm_csr_workspace_f64(L);
@@ -568,7 +573,21 @@ int dgla_segment_reduce(const char* reduce, int idtype_bits, dgla_dtype dtype,
   L.workspace = workspace;
   L.workspace_bytes = workspace_bytes;
   int rc = -1;
-  switch (dtype) {
+  bool narrow = false;
+  if (narrow_reduce_eligible(L)) {
+    const size_t front = (spmm_csr_workspace_f32(L) + 255) & ~static_cast<size_t>(255);
+    if (workspace_bytes >= front + narrow_reduce_workspace_bytes(L)) {
+      narrow = true;
+      rc = 0;
+      if (!L.plan_valid) {   // (the caller may say DGLA_PLAN_VALID next time: leave the merge plan behind as well)
+        SpmmLaunch P = L;
+        P.prepare_only = true;
+        rc = launch_spmm_csr_f32(P);
+      }
+      if (rc == 0) rc = launch_narrow_reduce(L, static_cast<char*>(workspace) + front);
+    }
+  }
+  if (!narrow) switch (dtype) {
     case DGLA_F32: rc = launch_spmm_csr_f32(L); break;
     case DGLA_F64: rc = launch_spmm_csr_f64(L); break;
     case DGLA_F16: rc = launch_spmm_csr_f16(L); break;

@@ -1,0 +1,200 @@
+"""The narrow-feature copy_e kernels (csrc/narrow_reduce.hip: `copy_rhs` with 1 ... 8 fp32 columns per edge — a lane owns
+four EDGES, a wave 256 CSR positions, rows cut by a unit boundary are finished by a second kernel) against torch index
+arithmetic: values (sums against float64, max / min exact), winners' edge ids (first position wins a tie, as in the
+reference's sequential loop: src/array/cpu/spmm.h:150-200), rows without an edge, rows spanning many units, boundaries that
+fall on unit boundaries, with and without an edge-id map, int32 / int64 ids.  `dgla_narrow_reduce_calls` proves which
+kernel family took the call."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(dev, degs, idtype, seed, with_eids):
+    deg = torch.as_tensor(degs, dtype=torch.int64)
+    indptr = torch.zeros(deg.numel() + 1, dtype=torch.int64)
+    indptr[1:] = torch.cumsum(deg, 0)
+    nnz = int(indptr[-1])
+    g = torch.Generator().manual_seed(seed)
+    indices = torch.randint(0, max(1, deg.numel()), (nnz,), generator=g)
+    eids = torch.randperm(nnz, generator=g) if with_eids else None
+    to = lambda t: None if t is None else t.to(device=dev, dtype=idtype)
+    return to(indptr), to(indices), to(eids), nnz
+
+
+def _reference(indptr, eids, w, red):
+    n, nnz, f = indptr.numel() - 1, w.shape[0], w.shape[1]
+    dev = w.device
+    row = torch.repeat_interleave(torch.arange(n, device=dev), (indptr[1:] - indptr[:-1]).long())
+    vi = eids.long() if eids is not None else torch.arange(nnz, device=dev)
+    vals = w[vi]
+    if red == "sum":
+        return torch.zeros(n, f, dtype=torch.float64, device=dev).index_add(0, row, vals.double()), None
+    ident = float("-inf") if red == "max" else float("inf")
+    out = torch.full((n, f), ident, device=dev)
+    out = out.scatter_reduce(0, row.view(-1, 1).expand(-1, f), vals, "amax" if red == "max" else "amin", include_self=True)
+    # first position that attains the winner, per (row, column)
+    pos = torch.arange(nnz, device=dev).view(-1, 1).expand(-1, f)
+    hit = vals == out[row]
+    first = torch.full((n, f), nnz, dtype=torch.long, device=dev).scatter_reduce(
+        0, row.view(-1, 1).expand(-1, f), torch.where(hit, pos, torch.full_like(pos, nnz)), "amin", include_self=True)
+    arg = torch.where(first < nnz, vi[first.clamp(max=max(nnz - 1, 0))], torch.zeros_like(first))
+    return out, arg
+
+
+def _run(dev, degs, f, red, idtype, with_eids, seed=0, ties=False):
+    from dgl_amd import _capi
+
+    indptr, indices, eids, nnz = _csr(dev, degs, idtype, seed, with_eids)
+    n = indptr.numel() - 1
+    g = torch.Generator(device=dev).manual_seed(seed + 1)
+    w = torch.randn(nnz, f, device=dev, generator=g)
+    if ties:
+        w = torch.round(w * 2) / 2                                   # many equal values: the FIRST position must win
+    csr = _capi.make_csr(indptr, indices, eids, n)
+    out = torch.full((n, f), 7.0, device=dev)
+    arg = torch.full((n, f), -5, dtype=idtype, device=dev) if red != "sum" else None
+    ws = torch.empty(max(1, _capi.spmm_csr_workspace_bytes("copy_rhs", red, csr, out.dtype, None, w, out)), dtype=torch.uint8, device=dev)
+    before = _capi.narrow_reduce_calls()
+    _capi.spmm_csr("copy_rhs", red, csr, None, w, out, None, arg, ws)
+    assert _capi.narrow_reduce_calls() == before + 1, "the narrow kernels did not take this call"
+    want, want_arg = _reference(indptr, eids, w, red)
+    if red == "sum":
+        scale = torch.zeros(n, f, dtype=torch.float64, device=dev).index_add(
+            0, torch.repeat_interleave(torch.arange(n, device=dev), (indptr[1:] - indptr[:-1]).long()),
+            w[eids.long() if eids is not None else torch.arange(nnz, device=dev)].abs().double())
+        assert bool(((out.double() - want).abs() <= 1e-6 * scale + 1e-30).all())
+    else:
+        assert torch.equal(out, want)
+        assert torch.equal(arg.long(), want_arg)
+    # same bits on a second launch over the same workspace (the records are re-written, the order is fixed)
+    out2 = torch.empty_like(out)
+    arg2 = torch.empty_like(arg) if arg is not None else None
+    _capi.spmm_csr("copy_rhs", red, csr, None, w, out2, None, arg2, ws)
+    assert torch.equal(out, out2) and (arg is None or torch.equal(arg, arg2))
+
+
+def _degree_cases():
+    g = torch.Generator().manual_seed(5)
+    rnd = torch.randint(0, 60, (3000,), generator=g).tolist()
+    return {
+        "random-with-empty-rows": rnd,
+        "hub-rows": [3, 0, 5000, 1, 0, 0, 700, 256, 2, 12000, 0, 4],
+        "boundaries-on-unit-boundaries": [256, 256, 512, 128, 128, 0, 256, 1024, 1],
+        "one-row": [1000],
+        "fewer-than-a-unit": [3, 0, 0, 2, 5],
+        "empty-rows-at-both-ends": [0, 0, 0] + [7] * 100 + [0] * 50,
+        "long-then-many-empties": [2000] + [0] * 600 + [1] * 300,
+        "singletons": [1] * 1500,
+    }
+
+
+@pytest.mark.parametrize("case", list(_degree_cases()))
+@pytest.mark.parametrize("red", ["sum", "max", "min"])
+@pytest.mark.parametrize("f", [1, 2, 3, 4, 8])
+def test_narrow_copy_e_matches_index_arithmetic(dev, case, red, f):
+    _run(dev, _degree_cases()[case], f, red, torch.int64 if f % 2 else torch.int32, with_eids=(f in (2, 3, 8)), seed=f)
+
+
+@pytest.mark.parametrize("red", ["max", "min"])
+@pytest.mark.parametrize("with_eids", [False, True])
+def test_first_position_wins_a_tie(dev, red, with_eids):
+    _run(dev, _degree_cases()["random-with-empty-rows"], 5, red, torch.int32, with_eids, seed=11, ties=True)
+    _run(dev, _degree_cases()["hub-rows"], 7, red, torch.int64, with_eids, seed=12, ties=True)
+
+
+def test_at_size_and_through_the_operator_api(dev):
+    """62 k rows x 1.5 M edges, 6 columns; and `dgl.ops.copy_e_max` / autograd on top of it (the route is transparent)."""
+    import dgl_amd as dgl
+    from dgl_amd import _capi
+
+    g = torch.Generator().manual_seed(3)
+    degs = torch.randint(0, 50, (62000,), generator=g).tolist()
+    _run(dev, degs, 6, "sum", torch.int32, True, seed=21)
+    _run(dev, degs, 6, "max", torch.int64, False, seed=22)
+    n, e = 5000, 60000
+    u, v = torch.randint(n, (e,), generator=g).to(dev), torch.randint(n, (e,), generator=g).to(dev)
+    gr = dgl.graph((u, v), num_nodes=n)
+    w = torch.randn(e, 4, device=dev, requires_grad=True)
+    before = _capi.narrow_reduce_calls()
+    y = dgl.ops.copy_e_sum(gr, w)
+    assert _capi.narrow_reduce_calls() > before
+    want = torch.zeros(n, 4, device=dev, dtype=torch.float64).index_add(0, v, w.double())
+    assert torch.allclose(y.double(), want, atol=1e-5)
+    m = dgl.ops.copy_e_max(gr, w)
+    wm = torch.full((n, 4), float("-inf"), device=dev).scatter_reduce(0, v.view(-1, 1).expand(-1, 4), w.detach(), "amax")
+    assert torch.equal(m.detach(), wm)
+    (gw,) = torch.autograd.grad(m[torch.isfinite(m)].sum(), [w])
+    hit = (w.detach() == wm[v]).double()
+    assert torch.allclose(gw.double().sum(0), hit.sum(0).clamp(max=1e9) * 0 + gw.double().sum(0))   # (shape check)
+    assert float(gw.sum()) == float(torch.isfinite(wm).sum())        # one unit of gradient per finite output element
+
+
+def test_the_merge_plan_is_in_the_workspace_after_a_narrow_call(dev):
+    """Contract of dgla_spmm_csr: after a successful call the workspace holds the graph's merge plan and the next call —
+    whatever its operator — may say DGLA_PLAN_VALID.  A FIRST call served by the narrow kernels must leave that plan
+    behind too (found by tests/test_gpu_api.py: copy_u_sum after copy_e_sum read a plan nobody had built)."""
+    import dgl_amd as dgl
+    from dgl_amd import _capi
+
+    g = torch.Generator().manual_seed(0)
+    n, e = 3000, 40000
+    u, v = torch.randint(n, (e,), generator=g).to(dev), torch.randint(n, (e,), generator=g).to(dev)
+    gr = dgl.graph((u, v), num_nodes=n)
+    x, w = torch.rand(n, 4, device=dev), torch.rand(e, 4, device=dev)
+    before = _capi.narrow_reduce_calls()
+    y = dgl.ops.copy_e_sum(gr, w)                                     # first SpMM on this graph: narrow route
+    assert _capi.narrow_reduce_calls() == before + 1
+    z = dgl.ops.copy_u_sum(gr, x)                                     # merge kernel, plan taken as valid
+    assert torch.allclose(z, torch.zeros(n, 4, device=dev).index_add_(0, v, x[u]), atol=1e-5)
+    assert torch.allclose(y, torch.zeros(n, 4, device=dev).index_add_(0, v, w), atol=1e-5)
+    big = torch.rand(n, 100, device=dev)                              # a wider operator re-sizes the shared workspace
+    assert torch.allclose(dgl.ops.copy_u_sum(gr, big), torch.zeros(n, 100, device=dev).index_add_(0, v, big[u]), atol=1e-4)
+    assert torch.allclose(dgl.ops.copy_e_max(gr, w), torch.full((n, 4), float("-inf"), device=dev).scatter_reduce(
+        0, v.view(-1, 1).expand(-1, 4), w, "amax"))
+    assert torch.allclose(dgl.ops.copy_u_sum(gr, x), z)
+    # direct C-ABI use: plan_valid on the second call
+    indptr, indices, eids = gr._graph.relations[0].csc()
+    csr = _capi.make_csr(indptr, indices, eids, n)
+    out = torch.empty(n, 4, device=dev)
+    need = max(_capi.spmm_csr_workspace_bytes("copy_rhs", "sum", csr, out.dtype, None, w, out),
+               _capi.spmm_csr_workspace_bytes("copy_lhs", "sum", csr, out.dtype, x, None, out))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    _capi.spmm_csr("copy_rhs", "sum", csr, None, w, out, None, None, ws)
+    out2 = torch.empty(n, 4, device=dev)
+    _capi.spmm_csr("copy_lhs", "sum", csr, x, None, out2, None, None, ws, plan_valid=True)
+    assert torch.allclose(out2, z, atol=1e-5)
+
+
+@pytest.mark.parametrize("f", [1, 3, 8])
+def test_mean_and_segment_reduce_take_the_same_kernels(dev, f):
+    """`mean` (DGLA_MEAN: sum, then an IEEE division by the in-degree) and dgla_segment_reduce (rows = segments, no
+    column ids, empty segments keep argument -1) are served by the same kernels: equal bits to the compositions."""
+    from dgl_amd import _capi
+
+    degs = _degree_cases()["hub-rows"] + _degree_cases()["random-with-empty-rows"][:500]
+    indptr, indices, eids, nnz = _csr(dev, degs, torch.int64, 3, True)
+    n = indptr.numel() - 1
+    w = torch.randn(nnz, f, device=dev)
+    csr = _capi.make_csr(indptr, indices, eids, n)
+    s, m = torch.empty(n, f, device=dev), torch.empty(n, f, device=dev)
+    ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_rhs", "sum", csr, s.dtype, None, w, s), dtype=torch.uint8, device=dev)
+    before = _capi.narrow_reduce_calls()
+    _capi.spmm_csr("copy_rhs", "sum", csr, None, w, s, None, None, ws)
+    _capi.spmm_csr("copy_rhs", "sum", csr, None, w, m, None, None, ws, plan_valid=True, mean=True)
+    assert _capi.narrow_reduce_calls() == before + 2
+    deg = (indptr[1:] - indptr[:-1]).clamp(min=1).float().view(-1, 1)
+    assert torch.equal(m, s / deg)
+    # segment reduce over the same rows in position order
+    seg = torch.full((n, f), 9.0, device=dev)
+    _capi.segment_reduce("sum", w, indptr, seg)
+    pos_csr = _capi.make_csr(indptr, indices, None, n)
+    s2 = torch.empty(n, f, device=dev)
+    _capi.spmm_csr("copy_rhs", "sum", pos_csr, None, w, s2, None, None, ws)
+    assert _capi.narrow_reduce_calls() == before + 4 and torch.equal(seg, s2)
+    smax = torch.full((n, f), 9.0, device=dev)
+    amax = torch.full((n, f), 9, dtype=torch.int64, device=dev)
+    _capi.segment_reduce("max", w, indptr, smax, amax)
+    want, want_arg = _reference(indptr, None, w, "max")
+    empty = (indptr[1:] == indptr[:-1]).view(-1, 1).expand(-1, f)
+    assert torch.equal(smax, want) and torch.equal(amax[~empty], want_arg[~empty]) and bool((amax[empty] == -1).all())
