@@ -25,8 +25,10 @@
 namespace dgla {
 namespace {
 
-constexpr int kNrLaneEdges = 4;
-constexpr int kNrUnit = 64 * kNrLaneEdges;   // CSR positions per wave
+// Edges per lane (a wave's unit = 64 of them).  Four for every width: 16 (F = 1) and 8 (F <= 4) were built to spread the
+// per-unit scans over more edges and measured SLOWER — copy_e sum on C2 0.17 -> 0.21 ms (F = 1), 0.32 -> 0.49 (F = 4): with
+// rows of 25 edges nearly every lane then closes a row itself, and 32 KB of row ids per workgroup cost occupancy.
+constexpr int nr_lane_edges(int f) { return (void)f, 4; }
 constexpr int kNrWaves = 4;                  // waves (units) per workgroup
 constexpr uint8_t kNrHead = 1, kNrHeadClosed = 2, kNrTail = 4;
 
@@ -94,10 +96,10 @@ struct NrWorkspace {       // per unit: records of the rows it shares with its n
 // per WAVE inside the reduce kernel was 22 dependent loads in front of every unit: 59 rounds of them on this chip).
 template <typename Idx>
 __global__ __launch_bounds__(256) void narrow_plan_kernel(const Idx* __restrict__ indptr, int64_t num_rows, int64_t units,
-                                                         int64_t* __restrict__ first_row) {
+                                                         int64_t* __restrict__ first_row, int unit_edges) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t u = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; u < units; u += stride) {
-    const int64_t base = u * kNrUnit;
+    const int64_t base = u * unit_edges;
     int64_t lo = 0, hi = num_rows - 1;
     while (lo < hi) {
       const int64_t mid = (lo + hi + 1) >> 1;
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const Idx*
                                                                      Idx* __restrict__ arg, int64_t num_rows, int64_t nnz,
                                                                      int64_t units, NrWorkspace ws, int mean) {
   const Idx* __restrict__ mean_ptr = mean ? indptr : nullptr;
+  constexpr int kNrLaneEdges = nr_lane_edges(F), kNrUnit = 64 * kNrLaneEdges;
   __shared__ uint32_t s_bits[kNrWaves][kNrUnit / 32];
   __shared__ int64_t s_row[kNrWaves][kNrUnit];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -179,6 +182,7 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const Idx*
 
   // ---- row starts inside the unit -> start bits + row ids in LDS ---------------------------------------------------
   if (lane < kNrUnit / 32) s_bits[wave][lane] = 0u;
+  static_assert(32 % kNrLaneEdges == 0, "a lane's start bits lie inside one word");
 #pragma unroll
   for (int j = 0; j < kNrLaneEdges; ++j) s_row[wave][kNrLaneEdges * lane + j] = -1;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const Idx*
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  const uint32_t bits = (s_bits[wave][lane >> 3] >> ((lane & 7) * kNrLaneEdges)) & ((1u << kNrLaneEdges) - 1u);
+  const uint32_t bits = (s_bits[wave][(lane * kNrLaneEdges) >> 5] >> ((lane * kNrLaneEdges) & 31)) & ((1u << kNrLaneEdges) - 1u);
   int64_t row_at[kNrLaneEdges];
   int64_t lane_last = -1;
 #pragma unroll
@@ -331,7 +335,8 @@ __global__ __launch_bounds__(256) void narrow_fixup_kernel(const Idx* __restrict
 inline size_t nr_align(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
 size_t nr_bytes(int64_t nnz, int f, bool cmp) {
-  const size_t units = static_cast<size_t>((nnz + kNrUnit - 1) / kNrUnit);
+  const int64_t unit_edges = 64 * nr_lane_edges(f);
+  const size_t units = static_cast<size_t>((nnz + unit_edges - 1) / unit_edges);
   size_t b = 2 * nr_align(units * f * sizeof(float)) + 3 * nr_align(units * sizeof(int64_t)) + nr_align(units);
   if (cmp) b += 2 * nr_align(units * f * sizeof(int64_t));
   return b;
@@ -340,6 +345,7 @@ size_t nr_bytes(int64_t nnz, int f, bool cmp) {
 template <typename Idx, int RED, int F>
 int nr_launch(const SpmmLaunch& L, char* wsp) {
   const int64_t nnz = L.csr.nnz, n = L.csr.num_rows;
+  constexpr int kNrUnit = 64 * nr_lane_edges(F);
   const int64_t units = (nnz + kNrUnit - 1) / kNrUnit;
   NrWorkspace ws;
   char* q = wsp;
@@ -369,7 +375,7 @@ int nr_launch(const SpmmLaunch& L, char* wsp) {
                      static_cast<Idx>(L.arg_empty));
   if (units > 0) {
     hipLaunchKernelGGL((narrow_plan_kernel<Idx>), dim3(static_cast<unsigned>(std::min<int64_t>((units + 255) / 256, 4096))),
-                       dim3(256), 0, L.stream, indptr, n, units, ws.first_row);
+                       dim3(256), 0, L.stream, indptr, n, units, ws.first_row, kNrUnit);
     hipLaunchKernelGGL((narrow_reduce_kernel<Idx, RED, F>), dim3(static_cast<unsigned>((units + kNrWaves - 1) / kNrWaves)),
                        dim3(64 * kNrWaves), 0, L.stream, indptr, eids, static_cast<const float*>(L.efeat), out, arg, n, nnz,
                        units, ws, L.mean ? 1 : 0);

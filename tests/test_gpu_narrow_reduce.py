@@ -81,6 +81,7 @@ def _degree_cases():
         "random-with-empty-rows": rnd,
         "hub-rows": [3, 0, 5000, 1, 0, 0, 700, 256, 2, 12000, 0, 4],
         "boundaries-on-unit-boundaries": [256, 256, 512, 128, 128, 0, 256, 1024, 1],
+        "boundaries-on-large-units": [1024, 512, 1024, 2048, 0, 512, 512, 3072, 1, 1023, 1],   # (units of 512 / 1024 edges at F <= 4)
         "one-row": [1000],
         "fewer-than-a-unit": [3, 0, 0, 2, 5],
         "empty-rows-at-both-ends": [0, 0, 0] + [7] * 100 + [0] * 50,
