@@ -1,7 +1,8 @@
-// g-SpMM copy_e with NARROW edge features (1 ... 8 fp32 columns per edge) over the in-edge CSR, for gfx950.
+// g-SpMM with NARROW features (1 ... 8 fp32 output columns) over the in-edge CSR, for gfx950: copy_e, copy_u and the binary
+// operators u (+ - * /) e with an edge operand of the same width or one value per `rhs_group` columns.
 //
-// Same arithmetic as SpMMCsrKernel with the CopyRhs operator (src/array/cuda/spmm.cuh:440-520 — one edge feature row per
-// edge, reduced into its destination row; winners' edge ids for max / min).  The merge kernel (spmm_csr.hip.h) gives a
+// Same arithmetic as SpMMCsrKernel (src/array/cuda/spmm.cuh:440-520 — one message per edge, reduced into its destination
+// row; winners' column / edge ids for max / min).  The merge kernel (spmm_csr.hip.h) gives a
 // feature COLUMN to a lane: below 16 columns most of a wave idles and the kernel is bound by issue — 30 G edges/s on the
 // ogbn-products-shaped graph whatever the width, 1.84 ms for 250 MB of scalars (profiles/r5/narrow_feature_reductions.jsonl).
 // Here a lane owns four consecutive EDGES with all their columns, a wave 256 consecutive CSR positions (a "unit"):
@@ -112,22 +113,59 @@ __global__ __launch_bounds__(256) void narrow_plan_kernel(const Idx* __restrict_
   }
 }
 
-// `mean_ptr` (sum only; the row offsets, or null): store sum / in-degree — the quotient the reference forms after its
-// sum (python/dgl/ops/spmm.py:109-114), an IEEE division like the merge kernel's DGLA_MEAN
-template <typename Idx, int RED, int F>
-__device__ __forceinline__ void store_row(float* __restrict__ out, Idx* __restrict__ arg, const Idx* __restrict__ eids,
-                                          int64_t row, const Run<RED, F>& r, const Idx* __restrict__ mean_ptr) {
+template <typename Idx>
+struct NrOperands {
+  const Idx* indptr;
+  const Idx* indices;      // column ids (copy_u / binary operators)
+  const Idx* eids;         // edge id per position, or null
+  const float* ufeat;      // [num_cols][F]
+  const float* efeat;      // [nnz][rhs_len]
+  float* out;              // [num_rows][F]
+  Idx* arg_u;              // winners' column ids (max / min, operators that read u)
+  Idx* arg_e;              // winners' edge ids (max / min, operators that read e)
+  int op;                  // Op
+  int rhs_len;             // columns of an edge row: F, or F / rhs_group
+  int rhs_group;           // consecutive output columns sharing one edge value (1: none)
+  int mean;                // sum only: store sum / in-degree — the quotient the reference forms after its sum
+                           // (python/dgl/ops/spmm.py:109-114), an IEEE division like the merge kernel's DGLA_MEAN
+};
+
+template <typename Idx, int RED, int F, int OPK>
+__device__ __forceinline__ void store_row(const NrOperands<Idx>& o, int64_t row, const Run<RED, F>& r) {
   float den = 1.f;
   if constexpr (RED == kSum) {
-    if (mean_ptr) den = static_cast<float>(static_cast<int64_t>(mean_ptr[row + 1]) - static_cast<int64_t>(mean_ptr[row]));
+    if (o.mean) den = static_cast<float>(static_cast<int64_t>(o.indptr[row + 1]) - static_cast<int64_t>(o.indptr[row]));
   }
 #pragma unroll
   for (int c = 0; c < F; ++c) {
-    if constexpr (RED == kSum)
-      out[row * F + c] = mean_ptr ? r.v[c] / den : r.v[c];
-    else
-      out[row * F + c] = r.v[c];
-    if constexpr (RED != kSum) arg[row * F + c] = eids ? eids[r.p[c]] : static_cast<Idx>(r.p[c]);
+    if constexpr (RED == kSum) {
+      o.out[row * F + c] = o.mean ? r.v[c] / den : r.v[c];
+    } else {
+      o.out[row * F + c] = r.v[c];
+      if constexpr (OPK != 0) o.arg_u[row * F + c] = o.indices[r.p[c]];
+      if constexpr (OPK != 1) o.arg_e[row * F + c] = o.eids ? o.eids[r.p[c]] : static_cast<Idx>(r.p[c]);
+    }
+  }
+}
+
+// OPK: 0 = copy_e, 1 = copy_u, 2 = u (op) e
+template <typename Idx, int F, int OPK>
+__device__ __forceinline__ float message(const NrOperands<Idx>& o, int64_t pos, int c, int64_t col, int64_t eid) {
+  if constexpr (OPK == 1) {
+    return o.ufeat[col * F + c];
+  } else {
+    const float r = o.efeat[eid * o.rhs_len + (o.rhs_group > 1 ? c / o.rhs_group : c)];
+    if constexpr (OPK == 0) {
+      return r;
+    } else {
+      const float l = o.ufeat[col * F + c];
+      switch (o.op) {
+        case kAdd: return l + r;
+        case kSub: return l - r;
+        case kMul: return l * r;
+        default: return l / r;
+      }
+    }
   }
 }
 
@@ -151,23 +189,24 @@ __device__ __forceinline__ Run<RED, F> rec_load(const float* v, const int64_t* p
   return r;
 }
 
-template <typename Idx, int RED, int F>
-__global__ __launch_bounds__(64 * kNrWaves) void narrow_fill_kernel(float* __restrict__ out, Idx* __restrict__ arg, int64_t n,
-                                                                   Idx arg_empty) {
+template <typename Idx, int RED>
+__global__ __launch_bounds__(64 * kNrWaves) void narrow_fill_kernel(float* __restrict__ out, Idx* __restrict__ arg_u,
+                                                                   Idx* __restrict__ arg_e, int64_t n, Idx arg_empty) {
   const float id = RED == kSum ? 0.f : (RED == kMax ? -__builtin_huge_valf() : __builtin_huge_valf());
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) {
     out[i] = id;
-    if constexpr (RED != kSum) arg[i] = arg_empty;
+    if constexpr (RED != kSum) {
+      if (arg_u) arg_u[i] = arg_empty;
+      if (arg_e) arg_e[i] = arg_empty;
+    }
   }
 }
 
-template <typename Idx, int RED, int F>
-__global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const Idx* __restrict__ indptr, const Idx* __restrict__ eids,
-                                                                     const float* __restrict__ efeat, float* __restrict__ out,
-                                                                     Idx* __restrict__ arg, int64_t num_rows, int64_t nnz,
-                                                                     int64_t units, NrWorkspace ws, int mean) {
-  const Idx* __restrict__ mean_ptr = mean ? indptr : nullptr;
+template <typename Idx, int RED, int F, int OPK>
+__global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOperands<Idx> o, int64_t num_rows, int64_t nnz,
+                                                                     int64_t units, NrWorkspace ws) {
+  const Idx* __restrict__ indptr = o.indptr;
   constexpr int kNrLaneEdges = nr_lane_edges(F), kNrUnit = 64 * kNrLaneEdges;
   __shared__ uint32_t s_bits[kNrWaves][kNrUnit / 32];
   __shared__ int64_t s_row[kNrWaves][kNrUnit];
@@ -241,17 +280,18 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const Idx*
         pre_row = cur_row;
         seen = true;
       } else {
-        store_row<Idx, RED, F>(out, arg, eids, cur_row, acc, mean_ptr);
+        store_row<Idx, RED, F, OPK>(o, cur_row, acc);
       }
       cur_row = row_at[j];
       run_reset(acc);
     }
     if (pos < uend) {
-      const int64_t vi = eids ? static_cast<int64_t>(eids[pos]) : pos;
+      const int64_t eid = (OPK != 1 && o.eids) ? static_cast<int64_t>(o.eids[pos]) : pos;
+      const int64_t col = OPK != 0 ? static_cast<int64_t>(o.indices[pos]) : 0;
       Run<RED, F> one;
 #pragma unroll
       for (int c = 0; c < F; ++c) {
-        one.v[c] = efeat[vi * F + c];
+        one.v[c] = message<Idx, F, OPK>(o, pos, c, col, eid);
         if constexpr (RED != kSum) one.p[c] = pos;
       }
       run_append(acc, one);
@@ -281,7 +321,7 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const Idx*
     if (first_head_lane && left_open) {
       rec_store<RED, F>(ws.head_v, ws.head_p, unit, carry);     // ... began in an earlier unit: a head record
     } else {
-      store_row<Idx, RED, F>(out, arg, eids, pre_row, carry, mean_ptr);
+      store_row<Idx, RED, F, OPK>(o, pre_row, carry);
     }
   }
   // ---- the run open at the unit's end (lane 63 holds it after the scan) -----------------------------------------------
@@ -292,7 +332,7 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const Idx*
   if (lane == 63) {
     if (began_here) {
       if (complete)
-        store_row<Idx, RED, F>(out, arg, eids, t_row, x, mean_ptr);
+        store_row<Idx, RED, F, OPK>(o, t_row, x);
       else
         rec_store<RED, F>(ws.tail_v, ws.tail_p, unit, x);
     } else {
@@ -311,10 +351,8 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const Idx*
 
 // One thread per unit whose head piece CLOSES a row that began earlier: the pieces, walked back to the unit the row began
 // in, added in position order.
-template <typename Idx, int RED, int F>
-__global__ __launch_bounds__(256) void narrow_fixup_kernel(const Idx* __restrict__ eids, float* __restrict__ out,
-                                                          Idx* __restrict__ arg, int64_t units, NrWorkspace ws,
-                                                          const Idx* __restrict__ mean_ptr) {
+template <typename Idx, int RED, int F, int OPK>
+__global__ __launch_bounds__(256) void narrow_fixup_kernel(const NrOperands<Idx> o, int64_t units, NrWorkspace ws) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t b = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; b < units; b += stride) {
     const uint8_t fl = ws.flags[b];
@@ -328,7 +366,7 @@ __global__ __launch_bounds__(256) void narrow_fixup_kernel(const Idx* __restrict
       total = piece;
       if (!whole) break;
     }
-    store_row<Idx, RED, F>(out, arg, eids, ws.head_row[b], total, mean_ptr);
+    store_row<Idx, RED, F, OPK>(o, ws.head_row[b], total);
   }
 }
 
@@ -342,7 +380,7 @@ size_t nr_bytes(int64_t nnz, int f, bool cmp) {
   return b;
 }
 
-template <typename Idx, int RED, int F>
+template <typename Idx, int RED, int F, int OPK>
 int nr_launch(const SpmmLaunch& L, char* wsp) {
   const int64_t nnz = L.csr.nnz, n = L.csr.num_rows;
   constexpr int kNrUnit = 64 * nr_lane_edges(F);
@@ -365,61 +403,93 @@ int nr_launch(const SpmmLaunch& L, char* wsp) {
     ws.head_p = reinterpret_cast<int64_t*>(take(units * F * sizeof(int64_t)));
     ws.tail_p = reinterpret_cast<int64_t*>(take(units * F * sizeof(int64_t)));
   }
-  float* out = static_cast<float*>(L.out);
-  Idx* arg = static_cast<Idx*>(L.arg_e);
-  const Idx* indptr = static_cast<const Idx*>(L.csr.indptr);
-  const Idx* eids = static_cast<const Idx*>(L.csr.eids);
+  NrOperands<Idx> o;
+  o.indptr = static_cast<const Idx*>(L.csr.indptr);
+  o.indices = static_cast<const Idx*>(L.csr.indices);
+  o.eids = static_cast<const Idx*>(L.csr.eids);
+  o.ufeat = static_cast<const float*>(L.ufeat);
+  o.efeat = static_cast<const float*>(L.efeat);
+  o.out = static_cast<float*>(L.out);
+  o.arg_u = OPK != 0 ? static_cast<Idx*>(L.arg_u) : nullptr;
+  o.arg_e = OPK != 1 ? static_cast<Idx*>(L.arg_e) : nullptr;
+  o.op = L.op;
+  o.rhs_len = static_cast<int>(L.rhs_len);
+  o.rhs_group = L.bcast == kBcRhsGroup ? L.rhs_group : 1;
+  o.mean = L.mean ? 1 : 0;
   const int64_t total = n * F;
   const unsigned fill_blocks = static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 8192));
-  hipLaunchKernelGGL((narrow_fill_kernel<Idx, RED, F>), dim3(fill_blocks), dim3(64 * kNrWaves), 0, L.stream, out, arg, total,
-                     static_cast<Idx>(L.arg_empty));
+  hipLaunchKernelGGL((narrow_fill_kernel<Idx, RED>), dim3(fill_blocks), dim3(64 * kNrWaves), 0, L.stream, o.out, o.arg_u, o.arg_e,
+                     total, static_cast<Idx>(L.arg_empty));
   if (units > 0) {
     hipLaunchKernelGGL((narrow_plan_kernel<Idx>), dim3(static_cast<unsigned>(std::min<int64_t>((units + 255) / 256, 4096))),
-                       dim3(256), 0, L.stream, indptr, n, units, ws.first_row, kNrUnit);
-    hipLaunchKernelGGL((narrow_reduce_kernel<Idx, RED, F>), dim3(static_cast<unsigned>((units + kNrWaves - 1) / kNrWaves)),
-                       dim3(64 * kNrWaves), 0, L.stream, indptr, eids, static_cast<const float*>(L.efeat), out, arg, n, nnz,
-                       units, ws, L.mean ? 1 : 0);
-    hipLaunchKernelGGL((narrow_fixup_kernel<Idx, RED, F>), dim3(static_cast<unsigned>(std::min<int64_t>((units + 255) / 256, 4096))),
-                       dim3(256), 0, L.stream, eids, out, arg, units, ws, L.mean ? indptr : static_cast<const Idx*>(nullptr));
+                       dim3(256), 0, L.stream, o.indptr, n, units, ws.first_row, kNrUnit);
+    hipLaunchKernelGGL((narrow_reduce_kernel<Idx, RED, F, OPK>), dim3(static_cast<unsigned>((units + kNrWaves - 1) / kNrWaves)),
+                       dim3(64 * kNrWaves), 0, L.stream, o, n, nnz, units, ws);
+    hipLaunchKernelGGL((narrow_fixup_kernel<Idx, RED, F, OPK>),
+                       dim3(static_cast<unsigned>(std::min<int64_t>((units + 255) / 256, 4096))), dim3(256), 0, L.stream, o, units,
+                       ws);
   }
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-template <typename Idx, int RED>
+template <typename Idx, int RED, int OPK>
 int nr_dispatch_f(const SpmmLaunch& L, char* ws) {
   switch (L.out_len) {
-    case 1: return nr_launch<Idx, RED, 1>(L, ws);
-    case 2: return nr_launch<Idx, RED, 2>(L, ws);
-    case 3: return nr_launch<Idx, RED, 3>(L, ws);
-    case 4: return nr_launch<Idx, RED, 4>(L, ws);
-    case 5: return nr_launch<Idx, RED, 5>(L, ws);
-    case 6: return nr_launch<Idx, RED, 6>(L, ws);
-    case 7: return nr_launch<Idx, RED, 7>(L, ws);
-    default: return nr_launch<Idx, RED, 8>(L, ws);
+    case 1: return nr_launch<Idx, RED, 1, OPK>(L, ws);
+    case 2: return nr_launch<Idx, RED, 2, OPK>(L, ws);
+    case 3: return nr_launch<Idx, RED, 3, OPK>(L, ws);
+    case 4: return nr_launch<Idx, RED, 4, OPK>(L, ws);
+    case 5: return nr_launch<Idx, RED, 5, OPK>(L, ws);
+    case 6: return nr_launch<Idx, RED, 6, OPK>(L, ws);
+    case 7: return nr_launch<Idx, RED, 7, OPK>(L, ws);
+    default: return nr_launch<Idx, RED, 8, OPK>(L, ws);
+  }
+}
+
+template <typename Idx, int OPK>
+int nr_dispatch_r(const SpmmLaunch& L, char* ws) {
+  switch (L.red) {
+    case kSum: return nr_dispatch_f<Idx, kSum, OPK>(L, ws);
+    case kMax: return nr_dispatch_f<Idx, kMax, OPK>(L, ws);
+    default: return nr_dispatch_f<Idx, kMin, OPK>(L, ws);
   }
 }
 
 template <typename Idx>
 int nr_dispatch(const SpmmLaunch& L, char* ws) {
-  switch (L.red) {
-    case kSum: return nr_dispatch_f<Idx, kSum>(L, ws);
-    case kMax: return nr_dispatch_f<Idx, kMax>(L, ws);
-    default: return nr_dispatch_f<Idx, kMin>(L, ws);
-  }
+  if (L.op == kCopyRhs) return nr_dispatch_r<Idx, 0>(L, ws);
+  if (L.op == kCopyLhs) return nr_dispatch_r<Idx, 1>(L, ws);
+  return nr_dispatch_r<Idx, 2>(L, ws);
 }
 
 }  // namespace
 
-// copy_e, fp32, 1 ... 8 columns, one relation, plain store: the shapes this file takes (DGLA_NARROW_REDUCE=0: none)
+// fp32, 1 ... 8 output columns, one relation, plain store, operands of the output's width (an edge operand may be one value
+// per `rhs_group` columns): the shapes this file takes (DGLA_NARROW_REDUCE=0: none)
 bool narrow_reduce_eligible(const SpmmLaunch& L) {
   static const bool on = [] {
     const char* e = std::getenv("DGLA_NARROW_REDUCE");
     return !(e && e[0] == '0');
   }();
-  return on && L.dtype == 0 /* DGLA_F32 */ && L.op == kCopyRhs && L.out_len >= 1 && L.out_len <= 8 && L.rhs_len == L.out_len &&
-         !L.accumulate && (!L.mean || L.red == kSum) && !L.prepare_only && L.rel == nullptr && !L.rhs_mask && L.csr.nnz > 0 &&
-         L.csr.num_rows > 0;
+  if (!on || L.dtype != 0 /* DGLA_F32 */ || L.out_len < 1 || L.out_len > 8 || L.accumulate || (L.mean && L.red != kSum) ||
+      L.prepare_only || L.rel != nullptr || L.rhs_mask || L.csr.nnz <= 0 || L.csr.num_rows <= 0)
+    return false;
+  if (L.op == kDot) return false;
+  const bool use_l = op_uses_lhs(L.op), use_r = op_uses_rhs(L.op);
+  if (use_l && (L.lhs_len != L.out_len || L.csr.indices == nullptr)) return false;
+  if (use_r) {
+    if (L.bcast == kBcNone) {
+      if (L.rhs_len != L.out_len) return false;
+    } else if (L.bcast == kBcRhsGroup) {
+      if (L.rhs_group < 1 || L.rhs_len * L.rhs_group != L.out_len) return false;
+    } else {
+      return false;
+    }
+  } else if (L.bcast != kBcNone) {
+    return false;
+  }
+  return true;
 }
 
 size_t narrow_reduce_workspace_bytes(const SpmmLaunch& L) { return nr_bytes(L.csr.nnz, static_cast<int>(L.out_len), L.red != kSum); }
@@ -430,8 +500,8 @@ int64_t narrow_reduce_calls() { return g_narrow_calls.load(); }
 // `ws`: narrow_reduce_workspace_bytes(L) bytes, outside the merge plan's region (the plan of the graph stays valid)
 int launch_narrow_reduce(const SpmmLaunch& L, void* ws) {
   g_narrow_calls.fetch_add(1);
-  if (L.red != kSum && !L.arg_e) {
-    last_error() = "arg_e is required for max/min";
+  if (L.red != kSum && ((op_uses_rhs(L.op) && !L.arg_e) || (op_uses_lhs(L.op) && !L.arg_u))) {
+    last_error() = "arg_u / arg_e are required for max/min";
     return -1;
   }
   return L.csr.idbits == 32 ? nr_dispatch<int32_t>(L, static_cast<char*>(ws)) : nr_dispatch<int64_t>(L, static_cast<char*>(ws));

@@ -544,8 +544,8 @@ int dgla_peer_wait(const void* flags, int num_flags, uint64_t epoch, void* statu
 int dgla_set_tuning(uint32_t flags);
 uint32_t dgla_get_tuning(void);
 
-/* dgla_spmm_csr calls of this process served by the narrow-feature kernels (csrc/narrow_reduce.hip: `copy_rhs`
- * with 1 ... 8 fp32 columns per edge, one lane per four EDGES instead of one lane per column; same results as the
+/* dgla_spmm_csr / dgla_segment_reduce calls of this process served by the narrow-feature kernels (csrc/narrow_reduce.hip:
+ * 1 ... 8 fp32 output columns — copy_rhs, copy_lhs, u (+ - * /) e —, one lane per four EDGES instead of one lane per column; same results as the
  * merge kernel up to the order of fp32 additions, winners and their edge ids identical).  A counter for tests and
  * benches to see which kernel family took a call; DGLA_NARROW_REDUCE=0 in the environment keeps the merge kernel.
  * The reference has one kernel for every width (src/array/cuda/spmm.cuh:440-520). */

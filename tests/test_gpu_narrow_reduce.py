@@ -199,3 +199,94 @@ def test_mean_and_segment_reduce_take_the_same_kernels(dev, f):
     want, want_arg = _reference(indptr, None, w, "max")
     empty = (indptr[1:] == indptr[:-1]).view(-1, 1).expand(-1, f)
     assert torch.equal(smax, want) and torch.equal(amax[~empty], want_arg[~empty]) and bool((amax[empty] == -1).all())
+
+
+def _ref_general(indptr, indices, eids, op, red, x, w):
+    """out[r] = reduce over the positions of row r of op(x[col], w[eid]) (broadcast as torch does), + winners."""
+    n, nnz = indptr.numel() - 1, indices.shape[0]
+    dev = indices.device
+    row = torch.repeat_interleave(torch.arange(n, device=dev), (indptr[1:] - indptr[:-1]).long())
+    eid = eids.long() if eids is not None else torch.arange(nnz, device=dev)
+    col = indices.long()
+    if op == "copy_lhs":
+        msg = x[col]
+    elif op == "copy_rhs":
+        msg = w[eid]
+    else:
+        msg = {"add": torch.add, "sub": torch.sub, "mul": torch.mul, "div": torch.div}[op](x[col], w[eid])
+    msg = msg.reshape(nnz, -1)
+    f = msg.shape[1]
+    if red == "sum":
+        return torch.zeros(n, f, dtype=torch.float64, device=dev).index_add(0, row, msg.double()), None, msg
+    ident = float("-inf") if red == "max" else float("inf")
+    idx = row.view(-1, 1).expand(-1, f)
+    out = torch.full((n, f), ident, device=dev).scatter_reduce(0, idx, msg, "amax" if red == "max" else "amin", include_self=True)
+    pos = torch.arange(nnz, device=dev).view(-1, 1).expand(-1, f)
+    first = torch.full((n, f), nnz, dtype=torch.long, device=dev).scatter_reduce(
+        0, idx, torch.where(msg == out[row], pos, torch.full_like(pos, nnz)), "amin", include_self=True)
+    return out, first, msg
+
+
+@pytest.mark.parametrize("case", ["random-with-empty-rows", "hub-rows", "boundaries-on-unit-boundaries", "fewer-than-a-unit"])
+@pytest.mark.parametrize("red", ["sum", "max", "min"])
+@pytest.mark.parametrize("op,ushape,eshape", [("copy_lhs", (5,), None), ("copy_lhs", (1,), None), ("mul", (8,), (8,)),
+                                              ("add", (3,), (3,)), ("sub", (2, 4), (2, 1)), ("div", (4, 2), (4, 1)),
+                                              ("mul", (7,), (1,)), ("mul", (2, 2), (2, 2))])
+def test_narrow_copy_u_and_binary_operators(dev, case, red, op, ushape, eshape):
+    from dgl_amd import _capi
+
+    idtype = torch.int32 if red == "max" else torch.int64
+    with_eids = op != "add"
+    indptr, indices, eids, nnz = _csr(dev, _degree_cases()[case], idtype, 31, with_eids)
+    n = indptr.numel() - 1
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn((n,) + ushape, device=dev, generator=g)
+    w = None if eshape is None else torch.rand((nnz,) + eshape, device=dev, generator=g) + 0.5
+    csr = _capi.make_csr(indptr, indices, eids, n)
+    f = x.reshape(n, -1).shape[1]
+    out = torch.full((n,) + ushape, 7.0, device=dev)
+    au = torch.full(out.shape, -5, dtype=idtype, device=dev) if red != "sum" else None
+    ae = torch.full(out.shape, -5, dtype=idtype, device=dev) if (red != "sum" and w is not None) else None
+    ws = torch.empty(max(1, _capi.spmm_csr_workspace_bytes(op, red, csr, out.dtype, x, w, out)), dtype=torch.uint8, device=dev)
+    before = _capi.narrow_reduce_calls()
+    _capi.spmm_csr(op, red, csr, x, w, out, au, ae, ws)
+    assert _capi.narrow_reduce_calls() == before + 1
+    want, first, msg = _ref_general(indptr, indices, eids, op, red, x, w)
+    got = out.reshape(n, f)
+    if red == "sum":
+        row = torch.repeat_interleave(torch.arange(n, device=dev), (indptr[1:] - indptr[:-1]).long())
+        scale = torch.zeros(n, f, dtype=torch.float64, device=dev).index_add(0, row, msg.abs().double())
+        assert bool(((got.double() - want).abs() <= 2e-6 * scale + 1e-30).all())
+    else:
+        assert torch.equal(got, want)
+        has = first < nnz
+        eid = eids.long() if eids is not None else torch.arange(nnz, device=dev)
+        fc = first.clamp(max=max(nnz - 1, 0))
+        assert torch.equal(au.reshape(n, f).long()[has], indices.long()[fc][has]) and bool((au.reshape(n, f)[~has] == 0).all())
+        if ae is not None:
+            assert torch.equal(ae.reshape(n, f).long()[has], eid[fc][has]) and bool((ae.reshape(n, f)[~has] == 0).all())
+
+
+def test_narrow_operators_through_autograd(dev):
+    """APPNP / SGC-like propagation of class logits: u_mul_e_sum with 7 columns and a scalar edge weight, forward and both
+    gradients (the backward runs copy / SDDMM kernels of its own; the forward and dX = SpMM over the reverse graph are narrow)."""
+    import dgl_amd as dgl
+    from dgl_amd import _capi
+
+    g0 = torch.Generator().manual_seed(9)
+    n, e = 4000, 50000
+    u, v = torch.randint(n, (e,), generator=g0).to(dev), torch.randint(n, (e,), generator=g0).to(dev)
+    gr = dgl.graph((u, v), num_nodes=n)
+    x = torch.randn(n, 7, device=dev, requires_grad=True)
+    w = (torch.rand(e, 1, device=dev) + 0.5).requires_grad_(True)
+    before = _capi.narrow_reduce_calls()
+    y = dgl.ops.u_mul_e_sum(gr, x, w)
+    want = torch.zeros(n, 7, device=dev, dtype=torch.float64).index_add(0, v, (x[u] * w).double())
+    assert _capi.narrow_reduce_calls() > before and torch.allclose(y.double(), want, atol=1e-5)
+    up = torch.randn_like(y)
+    gx, gw = torch.autograd.grad((y * up).sum(), [x, w])
+    wx, ww = torch.autograd.grad((want * up.double()).sum(), [x, w])
+    assert torch.allclose(gx, wx, atol=1e-5) and torch.allclose(gw, ww, atol=1e-5)
+    m = dgl.ops.copy_u_max(gr, x)
+    wm = torch.full((n, 7), float("-inf"), device=dev).scatter_reduce(0, v.view(-1, 1).expand(-1, 7), x.detach()[u], "amax")
+    assert torch.equal(m.detach(), wm)
