@@ -17,8 +17,9 @@ from . import udf  # noqa: E402,F401
 from . import nn  # noqa: E402,F401
 from . import sampling  # noqa: E402,F401
 from . import dataloading  # noqa: E402,F401
-from .transforms import (add_self_loop, batch, bipartite_from_scipy, from_scipy, remove_edges,  # noqa: E402,F401
-                         remove_self_loop, reorder_graph, unbatch)
+from .transforms import (add_reverse_edges, add_self_loop, batch, bipartite_from_scipy, edge_subgraph,  # noqa: E402,F401
+                         from_scipy, in_subgraph, node_subgraph, remove_edges, remove_self_loop, reorder_graph,
+                         to_bidirected, to_simple, unbatch)
 from .readout import *  # noqa: E402,F401,F403
 from . import sparse  # noqa: E402,F401
 from .ops import edge_softmax  # noqa: E402,F401

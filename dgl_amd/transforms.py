@@ -1,6 +1,8 @@
 """Graph construction helpers around the hot path, in torch index arithmetic on the caller's device.
 
-``add_self_loop`` / ``remove_self_loop`` / ``remove_edges`` / ``reorder_graph`` (python/dgl/transforms/functional.py),
+``add_self_loop`` / ``remove_self_loop`` / ``remove_edges`` / ``reorder_graph`` / ``add_reverse_edges`` / ``to_simple`` /
+``to_bidirected`` (python/dgl/transforms/functional.py), ``node_subgraph`` / ``edge_subgraph`` / ``in_subgraph``
+(python/dgl/subgraph.py),
 ``batch`` (python/dgl/batch.py), ``from_scipy`` / ``bipartite_from_scipy`` (python/dgl/convert.py), ``adj_external``
 (heterograph.py) and ``EdgeWeightNorm`` (nn/pytorch/conv/graphconv.py:17-130): the handful the reference's own layer tests
 (tests/python/pytorch/nn/test_nn.py, tests/utils/graph_cases.py) build their graphs with — tools/ref_suite runs those
@@ -238,6 +240,180 @@ def adj_external(g, transpose=False, ctx=None, scipy_fmt=None, etype=None):
     return out.to(ctx) if ctx is not None else out
 
 
+def _homogeneous(g, what):
+    if len(g.ntypes) != 1 or len(g.canonical_etypes) != 1:
+        raise DGLAMDError("%s only supports homogeneous graphs; convert with to_homogeneous first" % what)
+
+
+def add_reverse_edges(g, readonly=None, copy_ndata=True, copy_edata=False, ignore_bipartite=False, exclude_self=True):  # noqa: ARG001
+    """Every edge (u, v) followed by its reverse (v, u), appended behind the existing edges — self-loops are not doubled
+    when ``exclude_self`` (transforms/functional.py add_reverse_edges); reverse edges get a copy of their edge's features
+    when ``copy_edata``."""
+    _homogeneous(g, "add_reverse_edges")
+    u, v = g.edges()
+    keep = (u != v) if exclude_self else torch.ones_like(u, dtype=torch.bool)
+    ru, rv = v[keep], u[keep]
+    out = graph((torch.cat([u, ru]), torch.cat([v, rv])), num_nodes=g.num_nodes(), idtype=g.idtype, device=g.device)
+    if copy_ndata:
+        for k, val in g._node_frames[0].items():
+            out._node_frames[0][k] = val
+    if copy_edata:
+        for k, val in g._edge_frames[0].items():
+            out._edge_frames[0][k] = torch.cat([val, val[keep]], 0)
+    return out
+
+
+def to_simple(g, return_counts="count", writeback_mapping=False, copy_ndata=True, copy_edata=False):  # noqa: ARG001
+    """Parallel edges merged into one, edges ordered by (source, destination); ``edata[return_counts]`` = multiplicity
+    (functional.py to_simple).  With ``writeback_mapping`` also returns, per original edge, the id of its merged edge."""
+    _homogeneous(g, "to_simple")
+    u, v = g.edges()
+    n = max(g.num_nodes(), 1)
+    key = u.long() * n + v.long()
+    uniq, inverse, counts = torch.unique(key, sorted=True, return_inverse=True, return_counts=True)
+    out = graph(((uniq // n).to(g.idtype), (uniq % n).to(g.idtype)), num_nodes=g.num_nodes(), idtype=g.idtype, device=g.device)
+    if return_counts is not None:
+        out.edata[return_counts] = counts
+    if copy_ndata:
+        for k, val in g._node_frames[0].items():
+            out._node_frames[0][k] = val
+    return (out, inverse.to(g.idtype)) if writeback_mapping else out
+
+
+def to_bidirected(g, copy_ndata=False, readonly=None):  # noqa: ARG001
+    """A simple graph with both directions of every edge (functional.py to_bidirected): reverse edges added, parallel edges
+    merged; edge features are not carried (there is no single value for a merged edge)."""
+    _homogeneous(g, "to_bidirected")
+    both = add_reverse_edges(g, copy_ndata=copy_ndata, copy_edata=False, exclude_self=True)
+    return to_simple(both, return_counts=None, copy_ndata=copy_ndata)
+
+
+def _induced(g, node_ids_per_type, edge_ids_per_etype, relabel_nodes, store_ids):
+    """Subgraph from per-etype edge ids (and, when relabelling, per-type node ids in their new order)."""
+    nts, cets = g.ntypes, g.canonical_etypes
+    dev, idt = g.device, g.idtype
+    if relabel_nodes:
+        maps = {}
+        for n in nts:
+            ids = node_ids_per_type[n].long()
+            m = torch.full((max(g.num_nodes(n), 1),), -1, dtype=torch.long, device=dev)
+            m[ids] = torch.arange(ids.shape[0], device=dev)
+            maps[n] = m
+        counts = {n: int(node_ids_per_type[n].shape[0]) for n in nts}
+    else:
+        counts = {n: g.num_nodes(n) for n in nts}
+    data = {}
+    for c in cets:
+        u, v = g.edges(etype=c)
+        e = edge_ids_per_etype[c].long()
+        uu, vv = u[e].long(), v[e].long()
+        if relabel_nodes:
+            uu, vv = maps[c[0]][uu], maps[c[2]][vv]
+        data[c] = (uu.to(idt), vv.to(idt))
+    if len(cets) == 1 and len(nts) == 1:
+        out = graph(data[cets[0]], num_nodes=counts[nts[0]], idtype=idt, device=dev)
+    else:
+        out = heterograph(data, counts, idtype=idt, device=dev)
+    for n in nts:
+        fr = g._node_frames[g.get_ntype_id(n)]
+        of = out._node_frames[out.get_ntype_id(n)]
+        for k, val in fr.items():
+            of[k] = val[node_ids_per_type[n].long()] if relabel_nodes else val
+        if store_ids and relabel_nodes:
+            of[NID] = node_ids_per_type[n].to(idt)
+    for c in cets:
+        fr = g._edge_frames[g.get_etype_id(c)]
+        of = out._edge_frames[out.get_etype_id(c)]
+        for k, val in fr.items():
+            of[k] = val[edge_ids_per_etype[c].long()]
+        if store_ids:
+            of[EID] = edge_ids_per_etype[c].to(idt)
+    return out
+
+
+def _per_type(g, x, names, what):
+    if isinstance(x, dict):
+        return {k: torch.as_tensor(v, device=g.device) for k, v in x.items()}
+    if len(names) != 1:
+        raise DGLAMDError("%s: a dict keyed by type is needed on a graph with several types" % what)
+    return {names[0]: torch.as_tensor(x, device=g.device)}
+
+
+def _ids_of(t, n):
+    return torch.nonzero(t).reshape(-1) if t.dtype == torch.bool else t.reshape(-1)
+
+
+def node_subgraph(g, nodes, relabel_nodes=True, store_ids=True, output_device=None):
+    """Subgraph induced on the given nodes (ids or a boolean mask; a dict per node type on heterographs): every edge whose
+    two ends are kept, in edge-id order (python/dgl/subgraph.py node_subgraph)."""
+    nodes = _per_type(g, nodes, g.ntypes, "node_subgraph")
+    ids = {n: _ids_of(nodes[n], g.num_nodes(n)) if n in nodes else torch.empty(0, dtype=torch.long, device=g.device) for n in g.ntypes}
+    inside = {}
+    for n in g.ntypes:
+        m = torch.zeros(max(g.num_nodes(n), 1), dtype=torch.bool, device=g.device)
+        m[ids[n].long()] = True
+        inside[n] = m
+    eids = {}
+    for c in g.canonical_etypes:
+        u, v = g.edges(etype=c)
+        eids[c] = torch.nonzero(inside[c[0]][u.long()] & inside[c[2]][v.long()]).reshape(-1)
+    out = _induced(g, ids, eids, relabel_nodes, store_ids)
+    return out.to(output_device) if output_device is not None else out
+
+
+def edge_subgraph(g, edges, relabel_nodes=True, store_ids=True, output_device=None):
+    """Subgraph of the given edges (ids or a boolean mask; a dict per edge type), its nodes the edges' end points in
+    ascending id order when relabelled (subgraph.py edge_subgraph)."""
+    edges = _per_type(g, edges, g.canonical_etypes if len(g.canonical_etypes) == 1 else g.etypes, "edge_subgraph")
+    eids = {}
+    for c in g.canonical_etypes:
+        t = edges.get(c, edges.get(c[1]))
+        eids[c] = _ids_of(t, g.num_edges(c)) if t is not None else torch.empty(0, dtype=torch.long, device=g.device)
+    ids = {}
+    for n in g.ntypes:
+        parts = []
+        for c in g.canonical_etypes:
+            u, v = g.edges(etype=c)
+            e = eids[c].long()
+            if c[0] == n:
+                parts.append(u[e].long())
+            if c[2] == n:
+                parts.append(v[e].long())
+        ids[n] = torch.unique(torch.cat(parts)) if parts else torch.empty(0, dtype=torch.long, device=g.device)
+    out = _induced(g, ids, eids, relabel_nodes, store_ids)
+    return out.to(output_device) if output_device is not None else out
+
+
+def in_subgraph(g, nodes, relabel_nodes=False, store_ids=True, output_device=None):
+    """Every inbound edge of the given nodes, all nodes kept unless ``relabel_nodes`` (subgraph.py in_subgraph)."""
+    nodes = _per_type(g, nodes, g.ntypes, "in_subgraph")
+    eids = {}
+    for c in g.canonical_etypes:
+        u, v = g.edges(etype=c)
+        if c[2] in nodes:
+            m = torch.zeros(max(g.num_nodes(c[2]), 1), dtype=torch.bool, device=g.device)
+            m[_ids_of(nodes[c[2]], 0).long()] = True
+            eids[c] = torch.nonzero(m[v.long()]).reshape(-1)
+        else:
+            eids[c] = torch.empty(0, dtype=torch.long, device=g.device)
+    if not relabel_nodes:
+        out = _induced(g, None, eids, False, store_ids)
+    else:
+        ids = {}
+        for n in g.ntypes:
+            parts = [_ids_of(nodes[n], 0).long()] if n in nodes else []
+            for c in g.canonical_etypes:
+                u, v = g.edges(etype=c)
+                e = eids[c].long()
+                if c[0] == n:
+                    parts.append(u[e].long())
+                if c[2] == n:
+                    parts.append(v[e].long())
+            ids[n] = torch.unique(torch.cat(parts)) if parts else torch.empty(0, dtype=torch.long, device=g.device)
+        out = _induced(g, ids, eids, True, store_ids)
+    return out.to(output_device) if output_device is not None else out
+
+
 class EdgeWeightNorm(torch.nn.Module):
     """Edge weights normalised as GraphConv normalises by degrees: ``c_ji = e_ji / sqrt(D_j D_i)`` ('both'), ``/ D_i``
     ('right') or none, with D the weighted degrees (nn/pytorch/conv/graphconv.py:17-130)."""
@@ -272,5 +448,6 @@ class EdgeWeightNorm(torch.nn.Module):
             return graph.edata["_norm_edge_weights"]
 
 
-__all__ = ["add_self_loop", "remove_self_loop", "remove_edges", "reorder_graph", "batch", "unbatch", "from_scipy", "bipartite_from_scipy",
+__all__ = ["add_self_loop", "remove_self_loop", "remove_edges", "reorder_graph", "add_reverse_edges", "to_simple", "to_bidirected",
+           "node_subgraph", "edge_subgraph", "in_subgraph", "batch", "unbatch", "from_scipy", "bipartite_from_scipy",
            "adj_external", "EdgeWeightNorm"]

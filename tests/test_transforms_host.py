@@ -91,3 +91,40 @@ def test_to_block_on_a_cpu_graph_and_without_destination_nodes():
     hb = dgl.to_block(hg)
     assert hb.dstnodes["game"].data["_ID"].tolist() == [0, 1, 2] and hb.num_dst_nodes("user") == 0
     assert hb.srcnodes["user"].data["_ID"].tolist() == [0, 1, 2] and hb.srcnodes["game"].data["_ID"].tolist() == [0, 1, 2]
+
+
+def test_reverse_edges_simple_and_bidirected():
+    g = dgl.graph((torch.tensor([0, 1, 1, 2, 2]), torch.tensor([1, 2, 2, 2, 0])), num_nodes=4)
+    g.edata["w"] = torch.arange(5.0)
+    r = dgl.add_reverse_edges(g, copy_edata=True)
+    assert r.edges()[0].tolist() == [0, 1, 1, 2, 2, 1, 2, 2, 0] and r.edges()[1].tolist() == [1, 2, 2, 2, 0, 0, 1, 1, 2]
+    assert r.edata["w"].tolist() == [0, 1, 2, 3, 4, 0, 1, 2, 4]              # the self-loop 2 -> 2 is not doubled
+    s, back = dgl.to_simple(g, writeback_mapping=True)
+    assert list(zip(*[t.tolist() for t in s.edges()])) == [(0, 1), (1, 2), (2, 0), (2, 2)]
+    assert s.edata["count"].tolist() == [1, 2, 1, 1] and back.tolist() == [0, 1, 1, 3, 2]
+    b = dgl.to_bidirected(g)
+    assert list(zip(*[t.tolist() for t in b.edges()])) == [(0, 1), (0, 2), (1, 0), (1, 2), (2, 0), (2, 1), (2, 2)]
+
+
+def test_subgraphs():
+    g = _g()                                                        # edges 0->1, 1->2, 2->3, 2->0 on 5 nodes
+    sg = dgl.node_subgraph(g, [2, 0, 3])
+    assert sg.ndata["_ID"].tolist() == [2, 0, 3] and sg.ndata["x"].tolist() == [2.0, 0.0, 3.0]
+    assert list(zip(*[t.tolist() for t in sg.edges()])) == [(0, 2), (0, 1)] and sg.edata["_ID"].tolist() == [2, 3]
+    assert sg.edata["w"].tolist() == [3.0, 4.0]
+    mask = torch.tensor([True, False, True, True, False])
+    assert torch.equal(dgl.node_subgraph(g, mask).ndata["_ID"], torch.tensor([0, 2, 3]))
+    eg = dgl.edge_subgraph(g, [3, 0])
+    assert eg.ndata["_ID"].tolist() == [0, 1, 2] and list(zip(*[t.tolist() for t in eg.edges()])) == [(2, 0), (0, 1)]
+    assert eg.edata["_ID"].tolist() == [3, 0]
+    keep = dgl.edge_subgraph(g, [3, 0], relabel_nodes=False)
+    assert keep.num_nodes() == 5 and list(zip(*[t.tolist() for t in keep.edges()])) == [(2, 0), (0, 1)]
+    ins = dgl.in_subgraph(g, [0, 3])
+    assert ins.num_nodes() == 5 and list(zip(*[t.tolist() for t in ins.edges()])) == [(2, 3), (2, 0)] and ins.edata["_ID"].tolist() == [2, 3]
+    hg = dgl.heterograph({("a", "r", "b"): (torch.tensor([0, 1, 2]), torch.tensor([1, 1, 0])),
+                          ("b", "s", "a"): (torch.tensor([0, 1]), torch.tensor([2, 0]))})
+    hs = dgl.node_subgraph(hg, {"a": [0, 2], "b": [0, 1]})
+    assert list(zip(*[t.tolist() for t in hs.edges(etype="r")])) == [(0, 1), (1, 0)]
+    assert list(zip(*[t.tolist() for t in hs.edges(etype="s")])) == [(0, 1), (1, 0)]
+    he = dgl.edge_subgraph(hg, {"r": [2], "s": torch.tensor([True, False])})
+    assert he.num_nodes("a") == 1 and he.num_nodes("b") == 1 and he.nodes["a"].data["_ID"].tolist() == [2]
