@@ -128,6 +128,8 @@ struct NrOperands {
   int rhs_group;           // consecutive output columns sharing one edge value (1: none)
   int mean;                // sum only: store sum / in-degree — the quotient the reference forms after its sum
                            // (python/dgl/ops/spmm.py:109-114), an IEEE division like the merge kernel's DGLA_MEAN
+  int accumulate;          // sum only: out += result (DGLA_ACCUMULATE: the relation loop of a heterograph, spmm.cuh:528-534);
+                           // every row is stored by exactly one thread of one kernel, rows without an edge are not touched
 };
 
 template <typename Idx, int RED, int F, int OPK>
@@ -139,7 +141,8 @@ __device__ __forceinline__ void store_row(const NrOperands<Idx>& o, int64_t row,
 #pragma unroll
   for (int c = 0; c < F; ++c) {
     if constexpr (RED == kSum) {
-      o.out[row * F + c] = o.mean ? r.v[c] / den : r.v[c];
+      const float val = o.mean ? r.v[c] / den : r.v[c];
+      o.out[row * F + c] = o.accumulate ? o.out[row * F + c] + val : val;
     } else {
       o.out[row * F + c] = r.v[c];
       if constexpr (OPK != 0) o.arg_u[row * F + c] = o.indices[r.p[c]];   // (OPK 1, 2, 3 read u)
@@ -424,10 +427,12 @@ int nr_launch(const SpmmLaunch& L, char* wsp) {
   o.rhs_len = static_cast<int>(L.rhs_len);
   o.rhs_group = L.bcast == kBcRhsGroup ? L.rhs_group : 1;
   o.mean = L.mean ? 1 : 0;
+  o.accumulate = L.accumulate ? 1 : 0;
   const int64_t total = n * F;
   const unsigned fill_blocks = static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 8192));
-  hipLaunchKernelGGL((narrow_fill_kernel<Idx, RED>), dim3(fill_blocks), dim3(64 * kNrWaves), 0, L.stream, o.out, o.arg_u, o.arg_e,
-                     total, static_cast<Idx>(L.arg_empty));
+  if (!L.accumulate)
+    hipLaunchKernelGGL((narrow_fill_kernel<Idx, RED>), dim3(fill_blocks), dim3(64 * kNrWaves), 0, L.stream, o.out, o.arg_u, o.arg_e,
+                       total, static_cast<Idx>(L.arg_empty));
   if (units > 0) {
     hipLaunchKernelGGL((narrow_plan_kernel<Idx>), dim3(static_cast<unsigned>(std::min<int64_t>((units + 255) / 256, 4096))),
                        dim3(256), 0, L.stream, o.indptr, n, units, ws.first_row, kNrUnit);
@@ -481,7 +486,8 @@ bool narrow_reduce_eligible(const SpmmLaunch& L) {
     const char* e = std::getenv("DGLA_NARROW_REDUCE");
     return !(e && e[0] == '0');
   }();
-  if (!on || L.dtype != 0 /* DGLA_F32 */ || L.out_len < 1 || L.out_len > 8 || L.accumulate || (L.mean && L.red != kSum) ||
+  if (!on || L.dtype != 0 /* DGLA_F32 */ || L.out_len < 1 || L.out_len > 8 || (L.accumulate && (L.red != kSum || L.mean)) ||
+      (L.mean && L.red != kSum) ||
       L.prepare_only || L.rel != nullptr || L.rhs_mask || L.csr.nnz <= 0 || L.csr.num_rows <= 0)
     return false;
   if (L.op == kDot) return false;

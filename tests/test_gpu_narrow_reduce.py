@@ -290,3 +290,47 @@ def test_narrow_operators_through_autograd(dev):
     m = dgl.ops.copy_u_max(gr, x)
     wm = torch.full((n, 7), float("-inf"), device=dev).scatter_reduce(0, v.view(-1, 1).expand(-1, 7), x.detach()[u], "amax")
     assert torch.equal(m.detach(), wm)
+
+
+def test_accumulating_calls_and_the_relation_loop_of_a_heterograph(dev):
+    """DGLA_ACCUMULATE (out += result; rows without an edge untouched) — what the per-relation loop behind `update_all` on a
+    heterograph uses for sums — on the narrow kernels, directly and through `multi`-relation `update_all`."""
+    import dgl_amd as dgl
+    import dgl_amd.function as fn
+    from dgl_amd import _capi
+
+    indptr, indices, eids, nnz = _csr(dev, _degree_cases()["hub-rows"] + [0, 3, 0, 9], torch.int64, 41, True)
+    n = indptr.numel() - 1
+    w = torch.randn(nnz, 3, device=dev)
+    csr = _capi.make_csr(indptr, indices, eids, n)
+    base = torch.randn(n, 3, device=dev)
+    out = base.clone()
+    ws = torch.empty(_capi.spmm_csr_workspace_bytes("copy_rhs", "sum", csr, out.dtype, None, w, out), dtype=torch.uint8, device=dev)
+    before = _capi.narrow_reduce_calls()
+    _capi.spmm_csr("copy_rhs", "sum", csr, None, w, out, None, None, ws, accumulate=True)
+    assert _capi.narrow_reduce_calls() == before + 1
+    plain = torch.empty(n, 3, device=dev)
+    _capi.spmm_csr("copy_rhs", "sum", csr, None, w, plain, None, None, ws, plan_valid=True)
+    assert torch.equal(out, base + plain)
+    g0 = torch.Generator().manual_seed(1)
+    na, nb, e = 300, 200, 4000
+    pair = lambda s, d: (torch.randint(s, (e,), generator=g0).to(dev), torch.randint(d, (e,), generator=g0).to(dev))
+    hg = dgl.heterograph({("a", "r1", "b"): pair(na, nb), ("a", "r2", "b"): pair(na, nb), ("b", "r3", "b"): pair(nb, nb)},
+                         {"a": na, "b": nb})
+    hg.nodes["a"].data["h"] = torch.randn(na, 5, device=dev)
+    hg.nodes["b"].data["h"] = torch.randn(nb, 5, device=dev)
+    hg.update_all(fn.copy_u("h", "m"), fn.sum("m", "y"))     # (relations sharing a destination type: ONE stacked merge launch,
+    want = torch.zeros(nb, 5, device=dev, dtype=torch.float64)
+    for c in hg.canonical_etypes:
+        u, v = hg.edges(etype=c)
+        want.index_add_(0, v, hg.nodes[c[0]].data["h"].double()[u])
+    assert torch.allclose(hg.nodes["b"].data["y"].double(), want, atol=1e-5)   #  not this file's kernels — values all the same)
+    hg2 = dgl.heterograph({("a", "r1", "b"): hg.edges(etype="r1"), ("b", "r3", "b"): hg.edges(etype="r3")}, {"a": na, "b": nb})
+    hg2.nodes["a"].data["h"], hg2.nodes["b"].data["h"] = hg.nodes["a"].data["h"], hg.nodes["b"].data["h"]
+    hg2.update_all(fn.copy_u("h", "m"), fn.max("m", "y"))     # max over relations: per-relation candidates + running compare
+    wm = torch.full((nb, 5), float("-inf"), device=dev)
+    for c in hg2.canonical_etypes:
+        u, v = hg2.edges(etype=c)
+        wm = wm.scatter_reduce(0, v.view(-1, 1).expand(-1, 5), hg2.nodes[c[0]].data["h"][u], "amax")
+    wm = torch.where(torch.isinf(wm), torch.zeros_like(wm), wm)
+    assert torch.equal(hg2.nodes["b"].data["y"], wm)
