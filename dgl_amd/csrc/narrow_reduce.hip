@@ -227,6 +227,16 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOp
   const int64_t base = unit * kNrUnit;
   const int64_t uend = base + kNrUnit < nnz ? base + kNrUnit : nnz;
 
+  // the operand rows first: their addresses depend on the positions alone, so they are under way while the rows are found
+  const int64_t p0 = base + kNrLaneEdges * lane;
+  float msg[kNrLaneEdges][F];
+#pragma unroll
+  for (int j = 0; j < kNrLaneEdges; ++j) {
+    const int64_t pos = p0 + j < uend ? p0 + j : (uend - 1);       // (a position past the end re-reads the last edge; unused)
+    const int64_t eid = (OPK != 1 && o.eids) ? static_cast<int64_t>(o.eids[pos]) : pos;
+    const int64_t col = OPK != 0 ? static_cast<int64_t>(o.indices[pos]) : 0;
+    message_row<Idx, F, OPK>(o, col, eid, msg[j]);
+  }
   const int64_t r_first = ws.first_row[unit];   // the row that holds position `base`
   const bool left_open = static_cast<int64_t>(indptr[r_first]) < base;
 
@@ -275,8 +285,8 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOp
     cur_row = ex > r_first ? ex : r_first;
   }
 
-  // ---- the lane's four edges -------------------------------------------------------------------------------------------
-  const int64_t p0 = base + kNrLaneEdges * lane;
+  // ---- the lane's four edges (their operand rows were loaded at the top: the loop below stores the rows it closes, and a
+  // load behind a store that may alias it is not moved up — four dependent round trips per lane) ----
   Run<RED, F> acc, pre;
   run_reset(acc);
   run_reset(pre);
@@ -297,13 +307,11 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOp
       run_reset(acc);
     }
     if (pos < uend) {
-      const int64_t eid = (OPK != 1 && o.eids) ? static_cast<int64_t>(o.eids[pos]) : pos;
-      const int64_t col = OPK != 0 ? static_cast<int64_t>(o.indices[pos]) : 0;
       Run<RED, F> one;
-      message_row<Idx, F, OPK>(o, col, eid, one.v);
-      if constexpr (RED != kSum) {
 #pragma unroll
-        for (int c = 0; c < F; ++c) one.p[c] = pos;
+      for (int c = 0; c < F; ++c) {
+        one.v[c] = msg[j][c];
+        if constexpr (RED != kSum) one.p[c] = pos;
       }
       run_append(acc, one);
     }
