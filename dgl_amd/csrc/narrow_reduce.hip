@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 #include <cstdlib>
 
 #include "common.h"
@@ -67,19 +68,52 @@ __device__ __forceinline__ void run_append(Run<RED, F>& a, const Run<RED, F>& b)
   }
 }
 
-template <int RED, int F>
-__device__ __forceinline__ Run<RED, F> run_shfl_up(const Run<RED, F>& r, int d) {
+// Cross-lane moves as DPP modifiers of a VALU move — row_shr:1/2/4/8 inside a row of 16 lanes (0x111 ... 0x118), row_bcast:15
+// into rows 1 and 3 (0x142, row mask 0xa), row_bcast:31 into rows 2 and 3 (0x143, 0xc), wave_shr:1 (0x138) — instead of
+// ds_bpermute: a scan step is ALU instructions, not an LDS round trip (the scans' chain of round trips was what the waves
+// of this kernel waited on).  Lanes without a source keep `old`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int nr_dpp(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float nr_dpp(float old, float src) {
+  return __builtin_bit_cast(float, nr_dpp<CTRL, ROW_MASK>(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src)));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int64_t nr_dpp(int64_t old, int64_t src) {
+  const uint32_t lo = static_cast<uint32_t>(nr_dpp<CTRL, ROW_MASK>(static_cast<int>(old & 0xffffffffLL), static_cast<int>(src & 0xffffffffLL)));
+  const int hi = nr_dpp<CTRL, ROW_MASK>(static_cast<int>(old >> 32), static_cast<int>(src >> 32));
+  return (static_cast<int64_t>(hi) << 32) | lo;
+}
+template <int CTRL, int ROW_MASK, int RED, int F>
+__device__ __forceinline__ Run<RED, F> run_dpp(const Run<RED, F>& old, const Run<RED, F>& r) {
   Run<RED, F> o;
 #pragma unroll
   for (int c = 0; c < F; ++c) {
-    o.v[c] = __shfl_up(r.v[c], d, 64);
-    if constexpr (RED != kSum) {
-      const int lo = __shfl_up(static_cast<int>(r.p[c] & 0xffffffffLL), d, 64);
-      const int hi = __shfl_up(static_cast<int>(r.p[c] >> 32), d, 64);
-      o.p[c] = (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
-    }
+    o.v[c] = nr_dpp<CTRL, ROW_MASK>(old.v[c], r.v[c]);
+    if constexpr (RED != kSum) o.p[c] = nr_dpp<CTRL, ROW_MASK>(old.p[c], r.p[c]);
   }
   return o;
+}
+// one step of the segmented inclusive scan: a lane that has a source and no row start yet takes the source's open run in
+// front of its own; the "row start seen" flags are OR-ed along
+template <int CTRL, int ROW_MASK, int RED, int F>
+__device__ __forceinline__ void scan_step(Run<RED, F>& x, int& f, bool has_src) {
+  Run<RED, F> tx = run_dpp<CTRL, ROW_MASK>(x, x);
+  const int tf = nr_dpp<CTRL, ROW_MASK>(f, f);
+  if (has_src) {
+    if (!f) {
+      run_append(tx, x);   // (earlier lanes first)
+      x = tx;
+    }
+    f |= tf;
+  }
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void max_step(int64_t& x, bool has_src) {
+  const int64_t t = nr_dpp<CTRL, ROW_MASK>(x, x);
+  if (has_src && t > x) x = t;
 }
 
 struct NrWorkspace {       // per unit: records of the rows it shares with its neighbours
@@ -128,6 +162,8 @@ struct NrOperands {
   int rhs_group;           // consecutive output columns sharing one edge value (1: none)
   int mean;                // sum only: store sum / in-degree — the quotient the reference forms after its sum
                            // (python/dgl/ops/spmm.py:109-114), an IEEE division like the merge kernel's DGLA_MEAN
+  int stage;               // edge rows of 4 / 8 columns in position order, 16-byte aligned: a unit's rows are fetched as whole
+                           // 1 KB wavefront loads and handed to their lanes through LDS (see narrow_reduce_kernel)
   int accumulate;          // sum only: out += result (DGLA_ACCUMULATE: the relation loop of a heterograph, spmm.cuh:528-534);
                            // every row is stored by exactly one thread of one kernel, rows without an edge are not touched
 };
@@ -155,16 +191,21 @@ __device__ __forceinline__ void store_row(const NrOperands<Idx>& o, int64_t row,
 // `rhs_group` columns.  The operand rows are loaded whole, in front of the arithmetic, with compile-time pitches wherever
 // they can be: with a run-time pitch (or the operator's switch between the loads) the compiler gave up the 16-byte loads
 // and copy_e at 8 columns went from 0.60 to 1.23 ms.
-template <typename Idx, int F, int OPK>
+template <typename Idx, int F, int OPK, bool HAVE_E = false>
 __device__ __forceinline__ void message_row(const NrOperands<Idx>& o, int64_t col, int64_t eid, float (&m)[F]) {
-  float lv[F], rv[F];
+  float lv[F], rv[F];   // (HAVE_E: m already holds the edge row)
   if constexpr (OPK != 0) {
 #pragma unroll
     for (int c = 0; c < F; ++c) lv[c] = o.ufeat[col * F + c];
   }
   if constexpr (OPK != 1) {
+    if constexpr (HAVE_E) {
 #pragma unroll
-    for (int c = 0; c < F; ++c) rv[c] = OPK == 3 ? o.efeat[eid * o.rhs_len + c / o.rhs_group] : o.efeat[eid * F + c];
+      for (int c = 0; c < F; ++c) rv[c] = m[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < F; ++c) rv[c] = OPK == 3 ? o.efeat[eid * o.rhs_len + c / o.rhs_group] : o.efeat[eid * F + c];
+    }
   }
   if constexpr (OPK == 0) {
 #pragma unroll
@@ -200,6 +241,35 @@ __device__ __forceinline__ Run<RED, F> rec_load(const float* v, const int64_t* p
   return r;
 }
 
+// Round H of the staged fetch of a unit's edge rows (narrow_reduce_kernel): loads H F / 2 ... H F / 2 + F / 2 - 1 of the
+// wavefront = the rows of lanes 32 H ... 32 H + 31 go through the wavefront's half-unit staging area.  Chunk g (16 bytes) sits
+// in slot g ^ ((g >> 3) & (F - 1)): the linear writes and the reads at a stride of F chunks are both free of bank conflicts.
+typedef float nr_f4 __attribute__((ext_vector_type(4)));   // (a native vector: an array of them stays in registers)
+template <int F>
+__device__ __forceinline__ int stage_slot(int g) {
+  return F == 8 ? ((g & ~7) | ((g ^ (g >> 3)) & 7)) : ((g & ~3) | ((g ^ (g >> 3)) & 3));
+}
+template <int F, int H>
+__device__ __forceinline__ void stage_round(nr_f4* st, const nr_f4 (&t)[F], int lane, float (&msg)[4][F]) {
+#pragma unroll
+  for (int i = 0; i < F / 2; ++i) st[stage_slot<F>(i * 64 + lane)] = t[H * (F / 2) + i];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const bool mine = (lane >> 5) == H;
+  constexpr int per = F / 4;   // chunks per edge row
+#pragma unroll
+  for (int c = 0; c < F; ++c) {
+    const nr_f4 q = st[stage_slot<F>((lane & 31) * F + c)];   // (every lane reads; the other half's lanes drop the value)
+    float* m = &msg[c / per][(c % per) * 4];
+    m[0] = (H == 0 || mine) ? q.x : m[0];
+    m[1] = (H == 0 || mine) ? q.y : m[1];
+    m[2] = (H == 0 || mine) ? q.z : m[2];
+    m[3] = (H == 0 || mine) ? q.w : m[3];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <typename Idx, int RED>
 __global__ __launch_bounds__(64 * kNrWaves) void narrow_fill_kernel(float* __restrict__ out, Idx* __restrict__ arg_u,
                                                                    Idx* __restrict__ arg_e, int64_t n, Idx arg_empty) {
@@ -214,7 +284,7 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_fill_kernel(float* __res
   }
 }
 
-template <typename Idx, int RED, int F, int OPK>
+template <typename Idx, int RED, int F, int OPK, bool STAGED>
 __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOperands<Idx> o, int64_t num_rows, int64_t nnz,
                                                                      int64_t units, NrWorkspace ws) {
   const Idx* __restrict__ indptr = o.indptr;
@@ -230,12 +300,42 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOp
   // the operand rows first: their addresses depend on the positions alone, so they are under way while the rows are found
   const int64_t p0 = base + kNrLaneEdges * lane;
   float msg[kNrLaneEdges][F];
+  // Edge rows in position order: a lane's four rows are 64 / 128 consecutive bytes, so a 16-byte load of the wavefront, lane by
+  // lane, touches 32 / 64 cache lines and every line is touched by 4 / 8 loads.  Staged instead: the unit's F KB are fetched
+  // as F whole 1 KB loads (chunk i * 64 + lane), written to LDS and read back lane-major; the chunk index is XOR-swizzled so
+  // that both the linear writes and the reads at a stride of F chunks are free of bank conflicts.
+  // The workgroup's staging area holds half a unit per wavefront (two rounds), so that it costs no occupancy.
+  static_assert(!STAGED || ((OPK == 0 || OPK == 2) && (F == 4 || F == 8) && kNrLaneEdges == 4), "staged: whole 16-byte chunks per row");
+  __shared__ nr_f4 s_stage[STAGED ? kNrWaves * 32 * F : 1];
+  if constexpr (STAGED) {
+    {
+      const nr_f4* __restrict__ src = reinterpret_cast<const nr_f4*>(o.efeat + base * F);
+      const int64_t last_chunk = (uend - base) * (F / 4) - 1;
+      nr_f4* st = s_stage + wave * 32 * F;
+      nr_f4 t[F];
 #pragma unroll
-  for (int j = 0; j < kNrLaneEdges; ++j) {
-    const int64_t pos = p0 + j < uend ? p0 + j : (uend - 1);       // (a position past the end re-reads the last edge; unused)
-    const int64_t eid = (OPK != 1 && o.eids) ? static_cast<int64_t>(o.eids[pos]) : pos;
-    const int64_t col = OPK != 0 ? static_cast<int64_t>(o.indices[pos]) : 0;
-    message_row<Idx, F, OPK>(o, col, eid, msg[j]);
+      for (int i = 0; i < F; ++i) {
+        const int64_t g = i * 64 + lane;   // (the last unit: a chunk past the end re-reads the last one; unused)
+        t[i] = src[g < last_chunk ? g : last_chunk];
+      }
+      int64_t cols[kNrLaneEdges];
+#pragma unroll
+      for (int j = 0; j < kNrLaneEdges; ++j) cols[j] = OPK != 0 ? static_cast<int64_t>(o.indices[p0 + j < uend ? p0 + j : uend - 1]) : 0;
+      stage_round<F, 0>(st, t, lane, msg);
+      stage_round<F, 1>(st, t, lane, msg);
+#pragma unroll
+      for (int j = 0; j < kNrLaneEdges; ++j) {
+        message_row<Idx, F, OPK, true>(o, cols[j], p0 + j, msg[j]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kNrLaneEdges; ++j) {
+      const int64_t pos = p0 + j < uend ? p0 + j : (uend - 1);       // (a position past the end re-reads the last edge; unused)
+      const int64_t eid = (OPK != 1 && o.eids) ? static_cast<int64_t>(o.eids[pos]) : pos;
+      const int64_t col = OPK != 0 ? static_cast<int64_t>(o.indices[pos]) : 0;
+      message_row<Idx, F, OPK>(o, col, eid, msg[j]);
+    }
   }
   const int64_t r_first = ws.first_row[unit];   // the row that holds position `base`
   const bool left_open = static_cast<int64_t>(indptr[r_first]) < base;
@@ -271,17 +371,18 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOp
     if ((bits >> j) & 1u) lane_last = row_at[j];
   }
   // row in progress at the start of this lane: the last row start in the lanes before it (row ids ascend), or r_first
+  const int lr = lane & 15;
+  const bool odd_row = ((lane >> 4) & 1) != 0, upper = lane >= 32;
   int64_t incl = lane_last;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int tl = __shfl_up(static_cast<int>(incl & 0xffffffffLL), d, 64), th = __shfl_up(static_cast<int>(incl >> 32), d, 64);
-    const int64_t t = (static_cast<int64_t>(th) << 32) | static_cast<uint32_t>(tl);
-    if (lane >= d && t > incl) incl = t;
-  }
+  max_step<0x111, 0xf>(incl, lr >= 1);
+  max_step<0x112, 0xf>(incl, lr >= 2);
+  max_step<0x114, 0xf>(incl, lr >= 4);
+  max_step<0x118, 0xf>(incl, lr >= 8);
+  max_step<0x142, 0xa>(incl, odd_row);
+  max_step<0x143, 0xc>(incl, upper);
   int64_t cur_row;
   {
-    const int tl = __shfl_up(static_cast<int>(incl & 0xffffffffLL), 1, 64), th = __shfl_up(static_cast<int>(incl >> 32), 1, 64);
-    const int64_t ex = lane == 0 ? -1 : ((static_cast<int64_t>(th) << 32) | static_cast<uint32_t>(tl));
+    const int64_t ex = nr_dpp<0x138, 0xf>(static_cast<int64_t>(-1), incl);   // wave_shr:1; lane 0 keeps -1
     cur_row = ex > r_first ? ex : r_first;
   }
 
@@ -318,21 +419,16 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOp
   }
   // ---- segmented inclusive scan over the lanes of the runs left open at a lane's end --------------------------------
   Run<RED, F> x = acc;
-  bool f = seen;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    Run<RED, F> tx = run_shfl_up(x, d);
-    const bool tf = __shfl_up(static_cast<int>(f), d, 64) != 0;
-    if (lane >= d) {
-      if (!f) {
-        run_append(tx, x);   // (earlier lanes first)
-        x = tx;
-      }
-      f = f || tf;
-    }
-  }
-  Run<RED, F> carry = run_shfl_up(x, 1);
-  if (lane == 0) run_reset(carry);
+  int f = seen ? 1 : 0;
+  scan_step<0x111, 0xf>(x, f, lr >= 1);
+  scan_step<0x112, 0xf>(x, f, lr >= 2);
+  scan_step<0x114, 0xf>(x, f, lr >= 4);
+  scan_step<0x118, 0xf>(x, f, lr >= 8);
+  scan_step<0x142, 0xa>(x, f, odd_row);
+  scan_step<0x143, 0xc>(x, f, upper);
+  Run<RED, F> ident;
+  run_reset(ident);
+  Run<RED, F> carry = run_dpp<0x138, 0xf>(ident, x);   // the open run at the end of the lane before (lane 0: none)
   const uint64_t heads = __builtin_amdgcn_ballot_w64(seen);
   const bool first_head_lane = seen && (heads & ((1ull << lane) - 1ull)) == 0ull;
   if (seen) {
@@ -344,8 +440,8 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOp
     }
   }
   // ---- the run open at the unit's end (lane 63 holds it after the scan) -----------------------------------------------
-  const int64_t t_row = (static_cast<int64_t>(__shfl(static_cast<int>(cur_row >> 32), 63, 64)) << 32) |
-                        static_cast<uint32_t>(__shfl(static_cast<int>(cur_row & 0xffffffffLL), 63, 64));
+  const int64_t t_row = (static_cast<int64_t>(__builtin_amdgcn_readlane(static_cast<int>(cur_row >> 32), 63)) << 32) |
+                        static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cur_row & 0xffffffffLL), 63));
   const bool complete = static_cast<int64_t>(indptr[t_row + 1]) <= uend;
   const bool began_here = heads != 0ull || !left_open;
   if (lane == 63) {
@@ -436,6 +532,13 @@ int nr_launch(const SpmmLaunch& L, char* wsp) {
   o.rhs_group = L.bcast == kBcRhsGroup ? L.rhs_group : 1;
   o.mean = L.mean ? 1 : 0;
   o.accumulate = L.accumulate ? 1 : 0;
+  {
+    static const bool stage_on = [] {
+      const char* e = std::getenv("DGLA_NARROW_STAGE");
+      return !(e && e[0] == '0');
+    }();
+    o.stage = (stage_on && (OPK == 0 || OPK == 2) && o.eids == nullptr && reinterpret_cast<uintptr_t>(o.efeat) % 16 == 0) ? 1 : 0;
+  }
   const int64_t total = n * F;
   const unsigned fill_blocks = static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 8192));
   if (!L.accumulate)
@@ -444,8 +547,17 @@ int nr_launch(const SpmmLaunch& L, char* wsp) {
   if (units > 0) {
     hipLaunchKernelGGL((narrow_plan_kernel<Idx>), dim3(static_cast<unsigned>(std::min<int64_t>((units + 255) / 256, 4096))),
                        dim3(256), 0, L.stream, o.indptr, n, units, ws.first_row, kNrUnit);
-    hipLaunchKernelGGL((narrow_reduce_kernel<Idx, RED, F, OPK>), dim3(static_cast<unsigned>((units + kNrWaves - 1) / kNrWaves)),
-                       dim3(64 * kNrWaves), 0, L.stream, o, n, nnz, units, ws);
+    const dim3 grid(static_cast<unsigned>((units + kNrWaves - 1) / kNrWaves));
+    constexpr bool kStageable = (OPK == 0 || OPK == 2) && (F == 4 || F == 8) && nr_lane_edges(F) == 4;
+    bool staged = false;
+    if constexpr (kStageable) {
+      if (o.stage) {
+        staged = true;
+        hipLaunchKernelGGL((narrow_reduce_kernel<Idx, RED, F, OPK, true>), grid, dim3(64 * kNrWaves), 0, L.stream, o, n, nnz, units, ws);
+      }
+    }
+    if (!staged)
+      hipLaunchKernelGGL((narrow_reduce_kernel<Idx, RED, F, OPK, false>), grid, dim3(64 * kNrWaves), 0, L.stream, o, n, nnz, units, ws);
     hipLaunchKernelGGL((narrow_fixup_kernel<Idx, RED, F, OPK>),
                        dim3(static_cast<unsigned>(std::min<int64_t>((units + 255) / 256, 4096))), dim3(256), 0, L.stream, o, units,
                        ws);

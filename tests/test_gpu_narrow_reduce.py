@@ -42,7 +42,7 @@ def _reference(indptr, eids, w, red):
     return out, arg
 
 
-def _run(dev, degs, f, red, idtype, with_eids, seed=0, ties=False):
+def _run(dev, degs, f, red, idtype, with_eids, seed=0, ties=False, misaligned=False):
     from dgl_amd import _capi
 
     indptr, indices, eids, nnz = _csr(dev, degs, idtype, seed, with_eids)
@@ -51,6 +51,11 @@ def _run(dev, degs, f, red, idtype, with_eids, seed=0, ties=False):
     w = torch.randn(nnz, f, device=dev, generator=g)
     if ties:
         w = torch.round(w * 2) / 2                                   # many equal values: the FIRST position must win
+    if misaligned:                                                   # rows that start 4 bytes off a 16-byte boundary
+        buf = torch.empty(nnz * f + 1, device=dev)
+        buf[1:] = w.reshape(-1)
+        w = buf[1:].view(nnz, f)
+        assert w.data_ptr() % 16 == 4 and w.is_contiguous()
     csr = _capi.make_csr(indptr, indices, eids, n)
     out = torch.full((n, f), 7.0, device=dev)
     arg = torch.full((n, f), -5, dtype=idtype, device=dev) if red != "sum" else None
@@ -95,6 +100,19 @@ def _degree_cases():
 @pytest.mark.parametrize("f", [1, 2, 3, 4, 8])
 def test_narrow_copy_e_matches_index_arithmetic(dev, case, red, f):
     _run(dev, _degree_cases()[case], f, red, torch.int64 if f % 2 else torch.int32, with_eids=(f in (2, 3, 8)), seed=f)
+
+
+@pytest.mark.parametrize("case", ["random-with-empty-rows", "hub-rows", "boundaries-on-unit-boundaries", "fewer-than-a-unit",
+                                  "long-then-many-empties", "singletons"])
+@pytest.mark.parametrize("red", ["sum", "max"])
+@pytest.mark.parametrize("f", [4, 8])
+@pytest.mark.parametrize("misaligned", [False, True])
+def test_edge_rows_in_position_order_staged_through_lds(dev, case, red, f, misaligned):
+    """Edge rows of 4 / 8 columns WITHOUT an edge-id map are fetched as whole 1 KB wavefront loads and handed to their lanes
+    through LDS (narrow_reduce_kernel<..., STAGED>): full units, a last unit cut short by the end of the edge list, ties; rows
+    that are not 16-byte aligned take the lane-by-lane loads and must give the same bits."""
+    for idtype in (torch.int32, torch.int64):
+        _run(dev, _degree_cases()[case], f, red, idtype, with_eids=False, seed=60 + f, ties=(red == "max"), misaligned=misaligned)
 
 
 @pytest.mark.parametrize("red", ["max", "min"])

@@ -67,3 +67,15 @@ def test_segment_kernels_reach_memory_through_global_instructions_only():
     (both counters, conservative waits); it now names the global address space."""
     seg = _stats("segment.o")
     assert seg and all(c["flat"] == 0 and c["scratch"] == 0 for c in seg.values())
+
+
+def test_narrow_feature_kernels_keep_their_rows_in_registers():
+    """narrow_reduce.o: a lane's four message rows, the staged 16-byte chunks and the runs live in registers — an array of
+    HIP's float4 structs passed by reference went to scratch (12 scratch instructions per kernel) until the staging used
+    native vectors; the cross-lane scans are DPP moves, not LDS permutes."""
+    nr = _stats("narrow_reduce.o")
+    main = {k: c for k, c in nr.items() if "narrow_reduce_kernel" in k}
+    assert len(main) >= 100
+    assert all(c["flat"] == 0 and c["scratch"] == 0 for c in nr.values())
+    text = isa_audit.disassemble(os.path.join(isa_audit.ROOT, "build", "csrc", "narrow_reduce.o"))
+    assert "ds_bpermute" not in text and text.count("row_shr:1") > 100
