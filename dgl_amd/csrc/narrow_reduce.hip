@@ -34,14 +34,17 @@ constexpr int nr_lane_edges(int f) { return (void)f, 4; }
 constexpr int kNrWaves = 4;                  // waves (units) per workgroup
 constexpr uint8_t kNrHead = 1, kNrHeadClosed = 2, kNrTail = 4;
 
-template <int RED, int F>
-struct Run {               // partial result of a run of edges: F values (+ the winners' CSR positions for max / min)
+// Partial result of a run of edges: F values (+ the winners' CSR positions for max / min).  P: int inside the unit kernel
+// (positions relative to the unit's first one: two DPP moves per column and scan step instead of three, F registers less),
+// int64_t in the records and in the fix-up kernel (absolute positions).
+template <int RED, int F, typename P = int64_t>
+struct Run {
   float v[F];
-  int64_t p[RED == kSum ? 1 : F];
+  P p[RED == kSum ? 1 : F];
 };
 
-template <int RED, int F>
-__device__ __forceinline__ void run_reset(Run<RED, F>& r) {
+template <int RED, int F, typename P>
+__device__ __forceinline__ void run_reset(Run<RED, F, P>& r) {
 #pragma unroll
   for (int c = 0; c < F; ++c) {
     r.v[c] = RED == kSum ? 0.f : (RED == kMax ? -__builtin_huge_valf() : __builtin_huge_valf());
@@ -50,8 +53,8 @@ __device__ __forceinline__ void run_reset(Run<RED, F>& r) {
 }
 
 // a = a (+) b with a the EARLIER positions: sums add in that order, max / min keep the earlier winner on a tie
-template <int RED, int F>
-__device__ __forceinline__ void run_append(Run<RED, F>& a, const Run<RED, F>& b) {
+template <int RED, int F, typename P>
+__device__ __forceinline__ void run_append(Run<RED, F, P>& a, const Run<RED, F, P>& b) {
 #pragma unroll
   for (int c = 0; c < F; ++c) {
     if constexpr (RED == kSum) {
@@ -86,9 +89,9 @@ __device__ __forceinline__ int64_t nr_dpp(int64_t old, int64_t src) {
   const int hi = nr_dpp<CTRL, ROW_MASK>(static_cast<int>(old >> 32), static_cast<int>(src >> 32));
   return (static_cast<int64_t>(hi) << 32) | lo;
 }
-template <int CTRL, int ROW_MASK, int RED, int F>
-__device__ __forceinline__ Run<RED, F> run_dpp(const Run<RED, F>& old, const Run<RED, F>& r) {
-  Run<RED, F> o;
+template <int CTRL, int ROW_MASK, int RED, int F, typename P>
+__device__ __forceinline__ Run<RED, F, P> run_dpp(const Run<RED, F, P>& old, const Run<RED, F, P>& r) {
+  Run<RED, F, P> o;
 #pragma unroll
   for (int c = 0; c < F; ++c) {
     o.v[c] = nr_dpp<CTRL, ROW_MASK>(old.v[c], r.v[c]);
@@ -98,9 +101,9 @@ __device__ __forceinline__ Run<RED, F> run_dpp(const Run<RED, F>& old, const Run
 }
 // one step of the segmented inclusive scan: a lane that has a source and no row start yet takes the source's open run in
 // front of its own; the "row start seen" flags are OR-ed along
-template <int CTRL, int ROW_MASK, int RED, int F>
-__device__ __forceinline__ void scan_step(Run<RED, F>& x, int& f, bool has_src) {
-  Run<RED, F> tx = run_dpp<CTRL, ROW_MASK>(x, x);
+template <int CTRL, int ROW_MASK, int RED, int F, typename P>
+__device__ __forceinline__ void scan_step(Run<RED, F, P>& x, int& f, bool has_src) {
+  Run<RED, F, P> tx = run_dpp<CTRL, ROW_MASK>(x, x);
   const int tf = nr_dpp<CTRL, ROW_MASK>(f, f);
   if (has_src) {
     if (!f) {
@@ -168,8 +171,8 @@ struct NrOperands {
                            // every row is stored by exactly one thread of one kernel, rows without an edge are not touched
 };
 
-template <typename Idx, int RED, int F, int OPK>
-__device__ __forceinline__ void store_row(const NrOperands<Idx>& o, int64_t row, const Run<RED, F>& r) {
+template <typename Idx, int RED, int F, int OPK, typename P>
+__device__ __forceinline__ void store_row(const NrOperands<Idx>& o, int64_t row, const Run<RED, F, P>& r, int64_t pbase) {
   float den = 1.f;
   if constexpr (RED == kSum) {
     if (o.mean) den = static_cast<float>(static_cast<int64_t>(o.indptr[row + 1]) - static_cast<int64_t>(o.indptr[row]));
@@ -181,8 +184,9 @@ __device__ __forceinline__ void store_row(const NrOperands<Idx>& o, int64_t row,
       o.out[row * F + c] = o.accumulate ? o.out[row * F + c] + val : val;
     } else {
       o.out[row * F + c] = r.v[c];
-      if constexpr (OPK != 0) o.arg_u[row * F + c] = o.indices[r.p[c]];   // (OPK 1, 2, 3 read u)
-      if constexpr (OPK != 1) o.arg_e[row * F + c] = o.eids ? o.eids[r.p[c]] : static_cast<Idx>(r.p[c]);
+      const int64_t pos = pbase + r.p[c];
+      if constexpr (OPK != 0) o.arg_u[row * F + c] = o.indices[pos];   // (OPK 1, 2, 3 read u)
+      if constexpr (OPK != 1) o.arg_e[row * F + c] = o.eids ? o.eids[pos] : static_cast<Idx>(pos);
     }
   }
 }
@@ -221,12 +225,12 @@ __device__ __forceinline__ void message_row(const NrOperands<Idx>& o, int64_t co
   }
 }
 
-template <int RED, int F>
-__device__ __forceinline__ void rec_store(float* v, int64_t* p, int64_t unit, const Run<RED, F>& r) {
+template <int RED, int F, typename P>
+__device__ __forceinline__ void rec_store(float* v, int64_t* p, int64_t unit, const Run<RED, F, P>& r, int64_t pbase) {
 #pragma unroll
   for (int c = 0; c < F; ++c) {
     v[unit * F + c] = r.v[c];
-    if constexpr (RED != kSum) p[unit * F + c] = r.p[c];
+    if constexpr (RED != kSum) p[unit * F + c] = r.p[c] < 0 ? static_cast<int64_t>(-1) : pbase + r.p[c];
   }
 }
 
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOp
 
   // ---- the lane's four edges (their operand rows were loaded at the top: the loop below stores the rows it closes, and a
   // load behind a store that may alias it is not moved up — four dependent round trips per lane) ----
-  Run<RED, F> acc, pre;
+  Run<RED, F, int> acc, pre;
   run_reset(acc);
   run_reset(pre);
   int64_t pre_row = -1;
@@ -402,23 +406,23 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOp
         pre_row = cur_row;
         seen = true;
       } else {
-        store_row<Idx, RED, F, OPK>(o, cur_row, acc);
+        store_row<Idx, RED, F, OPK>(o, cur_row, acc, base);
       }
       cur_row = row_at[j];
       run_reset(acc);
     }
     if (pos < uend) {
-      Run<RED, F> one;
+      Run<RED, F, int> one;
 #pragma unroll
       for (int c = 0; c < F; ++c) {
         one.v[c] = msg[j][c];
-        if constexpr (RED != kSum) one.p[c] = pos;
+        if constexpr (RED != kSum) one.p[c] = kNrLaneEdges * lane + j;   // (relative to the unit's first position)
       }
       run_append(acc, one);
     }
   }
   // ---- segmented inclusive scan over the lanes of the runs left open at a lane's end --------------------------------
-  Run<RED, F> x = acc;
+  Run<RED, F, int> x = acc;
   int f = seen ? 1 : 0;
   scan_step<0x111, 0xf>(x, f, lr >= 1);
   scan_step<0x112, 0xf>(x, f, lr >= 2);
@@ -426,17 +430,17 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOp
   scan_step<0x118, 0xf>(x, f, lr >= 8);
   scan_step<0x142, 0xa>(x, f, odd_row);
   scan_step<0x143, 0xc>(x, f, upper);
-  Run<RED, F> ident;
+  Run<RED, F, int> ident;
   run_reset(ident);
-  Run<RED, F> carry = run_dpp<0x138, 0xf>(ident, x);   // the open run at the end of the lane before (lane 0: none)
+  Run<RED, F, int> carry = run_dpp<0x138, 0xf>(ident, x);   // the open run at the end of the lane before (lane 0: none)
   const uint64_t heads = __builtin_amdgcn_ballot_w64(seen);
   const bool first_head_lane = seen && (heads & ((1ull << lane) - 1ull)) == 0ull;
   if (seen) {
     run_append(carry, pre);      // the run this lane's first row start closes: earlier lanes' open run + its own leading edges
     if (first_head_lane && left_open) {
-      rec_store<RED, F>(ws.head_v, ws.head_p, unit, carry);     // ... began in an earlier unit: a head record
+      rec_store<RED, F>(ws.head_v, ws.head_p, unit, carry, base);     // ... began in an earlier unit: a head record
     } else {
-      store_row<Idx, RED, F, OPK>(o, pre_row, carry);
+      store_row<Idx, RED, F, OPK>(o, pre_row, carry, base);
     }
   }
   // ---- the run open at the unit's end (lane 63 holds it after the scan) -----------------------------------------------
@@ -447,11 +451,11 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOp
   if (lane == 63) {
     if (began_here) {
       if (complete)
-        store_row<Idx, RED, F, OPK>(o, t_row, x);
+        store_row<Idx, RED, F, OPK>(o, t_row, x, base);
       else
-        rec_store<RED, F>(ws.tail_v, ws.tail_p, unit, x);
+        rec_store<RED, F>(ws.tail_v, ws.tail_p, unit, x, base);
     } else {
-      rec_store<RED, F>(ws.head_v, ws.head_p, unit, x);            // the whole unit is a piece of ONE earlier row
+      rec_store<RED, F>(ws.head_v, ws.head_p, unit, x, base);            // the whole unit is a piece of ONE earlier row
     }
   }
   if (lane == 0) {
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(256) void narrow_fixup_kernel(const NrOperands<Idx>
       total = piece;
       if (!whole) break;
     }
-    store_row<Idx, RED, F, OPK>(o, ws.head_row[b], total);
+    store_row<Idx, RED, F, OPK>(o, ws.head_row[b], total, 0);
   }
 }
 
