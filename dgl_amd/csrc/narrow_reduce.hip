@@ -33,6 +33,7 @@ namespace {
 constexpr int nr_lane_edges(int f) { return (void)f, 4; }
 constexpr int kNrWaves = 4;                  // waves (units) per workgroup
 constexpr uint8_t kNrHead = 1, kNrHeadClosed = 2, kNrTail = 4;
+constexpr int kNrInlineSteps = 4;            // pieces of a cut row one thread of the fix-up kernel walks itself
 
 // Partial result of a run of edges: F values (+ the winners' CSR positions for max / min).  P: int inside the unit kernel
 // (positions relative to the unit's first one: two DPP moves per column and scan step instead of three, F registers less),
@@ -128,13 +129,17 @@ struct NrWorkspace {       // per unit: records of the rows it shares with its n
   int64_t* tail_row;
   int64_t* first_row;      // [units] row holding the unit's first position (narrow_plan_kernel)
   uint8_t* flags;          // [units]
+  int64_t* long_list;      // [units / kNrInlineSteps + 2] units whose head closes a row cut into many units (narrow_fixup_long_kernel)
+  unsigned long long* long_count;
 };
 
 // The row that holds a unit's first position — the largest r with indptr[r] <= position: one thread per unit (a search
 // per WAVE inside the reduce kernel was 22 dependent loads in front of every unit: 59 rounds of them on this chip).
 template <typename Idx>
 __global__ __launch_bounds__(256) void narrow_plan_kernel(const Idx* __restrict__ indptr, int64_t num_rows, int64_t units,
-                                                         int64_t* __restrict__ first_row, int unit_edges) {
+                                                         int64_t* __restrict__ first_row, int unit_edges,
+                                                         unsigned long long* __restrict__ long_count) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *long_count = 0ull;   // (the fix-up kernel's list of long rows starts empty)
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t u = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; u < units; u += stride) {
     const int64_t base = u * unit_edges;
@@ -469,23 +474,106 @@ __global__ __launch_bounds__(64 * kNrWaves) void narrow_reduce_kernel(const NrOp
 }
 
 // One thread per unit whose head piece CLOSES a row that began earlier: the pieces, walked back to the unit the row began
-// in, added in position order.
+// in, added in position order.  A row cut into more than kNrInlineSteps units (a hub: 12 000 edges are 47 units, and a
+// thread walking them is 47 dependent round trips — longer than the whole unit kernel runs) goes on a list instead.
 template <typename Idx, int RED, int F, int OPK>
 __global__ __launch_bounds__(256) void narrow_fixup_kernel(const NrOperands<Idx> o, int64_t units, NrWorkspace ws) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t b = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; b < units; b += stride) {
     const uint8_t fl = ws.flags[b];
     if ((fl & (kNrHead | kNrHeadClosed)) != (kNrHead | kNrHeadClosed)) continue;
+    int64_t first = -1;   // the unit the row began in, if it is close
+    for (int k = 1; k <= kNrInlineSteps && b - k >= 0; ++k) {
+      const uint8_t fu = ws.flags[b - k];
+      if (!((fu & kNrHead) && !(fu & kNrHeadClosed))) {
+        first = b - k;
+        break;
+      }
+    }
+    if (first < 0) {
+      ws.long_list[atomicAdd(ws.long_count, 1ull)] = b;
+      continue;
+    }
     Run<RED, F> total = rec_load<RED, F>(ws.head_v, ws.head_p, b);
-    for (int64_t u = b - 1; u >= 0; --u) {
-      const uint8_t fu = ws.flags[u];
-      const bool whole = (fu & kNrHead) && !(fu & kNrHeadClosed);   // unit u is a piece of the same row end to end
-      Run<RED, F> piece = whole ? rec_load<RED, F>(ws.head_v, ws.head_p, u) : rec_load<RED, F>(ws.tail_v, ws.tail_p, u);
-      run_append(piece, total);
+    for (int64_t u = b - 1; u >= first; --u) {
+      Run<RED, F> piece = u > first ? rec_load<RED, F>(ws.head_v, ws.head_p, u) : rec_load<RED, F>(ws.tail_v, ws.tail_p, u);
+      run_append(piece, total);   // (unit u > first is a piece of the same row end to end: its head record)
       total = piece;
-      if (!whole) break;
     }
     store_row<Idx, RED, F, OPK>(o, ws.head_row[b], total, 0);
+  }
+}
+
+// a (+) b for two partial results of the SAME row whose positions interleave (lanes of the long-row kernel): sums commute;
+// max / min keep the better value and, on a tie, the smaller position — what adding them in position order would have kept
+template <int RED, int F>
+__device__ __forceinline__ void run_merge(Run<RED, F>& a, const Run<RED, F>& b) {
+#pragma unroll
+  for (int c = 0; c < F; ++c) {
+    if constexpr (RED == kSum) {
+      a.v[c] += b.v[c];
+    } else {
+      const bool better = RED == kMax ? b.v[c] > a.v[c] : b.v[c] < a.v[c];
+      const bool take = b.p[c] >= 0 && (a.p[c] < 0 || better || (b.v[c] == a.v[c] && b.p[c] < a.p[c]));
+      a.v[c] = take ? b.v[c] : a.v[c];
+      a.p[c] = take ? b.p[c] : a.p[c];
+    }
+  }
+}
+
+template <int RED, int F>
+__device__ __forceinline__ Run<RED, F> run_shfl_xor(const Run<RED, F>& r, int d) {
+  Run<RED, F> o;
+#pragma unroll
+  for (int c = 0; c < F; ++c) {
+    o.v[c] = __shfl_xor(r.v[c], d, 64);
+    if constexpr (RED != kSum) {
+      const uint32_t lo = static_cast<uint32_t>(__shfl_xor(static_cast<int>(r.p[c] & 0xffffffffLL), d, 64));
+      const int hi = __shfl_xor(static_cast<int>(r.p[c] >> 32), d, 64);
+      o.p[c] = (static_cast<int64_t>(hi) << 32) | lo;
+    }
+  }
+  return o;
+}
+
+// One WAVEFRONT per listed unit: 64 pieces of the row per step (lane i: unit b - 1 - i, ...), each lane adds its own pieces
+// in position order, the lanes' partial results are merged by a butterfly — a fixed order: the same bits on every run.
+template <typename Idx, int RED, int F, int OPK>
+__global__ __launch_bounds__(256) void narrow_fixup_long_kernel(const NrOperands<Idx> o, NrWorkspace ws) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) >> 6;
+  const int64_t waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  const int64_t n = static_cast<int64_t>(*ws.long_count);
+  for (int64_t j = wave; j < n; j += waves) {
+    const int64_t b = ws.long_list[j];
+    Run<RED, F> part;
+    run_reset(part);
+    for (int64_t k0 = 1;; k0 += 64) {
+      const int64_t u = b - (k0 + lane);
+      bool whole = false;
+      if (u >= 0) {
+        const uint8_t fu = ws.flags[u];
+        whole = (fu & kNrHead) && !(fu & kNrHeadClosed);
+      }
+      const uint64_t stop = __builtin_amdgcn_ballot_w64(!whole);   // (unit 0 is never a piece of an earlier row)
+      const int first = stop ? __builtin_ctzll(stop) : 64;
+      if (lane <= first && u >= 0) {
+        Run<RED, F> piece = lane < first ? rec_load<RED, F>(ws.head_v, ws.head_p, u) : rec_load<RED, F>(ws.tail_v, ws.tail_p, u);
+        run_append(piece, part);   // (this step's piece lies in front of the lane's earlier ones)
+        part = piece;
+      }
+      if (stop) break;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const Run<RED, F> other = run_shfl_xor(part, d);
+      run_merge(part, other);
+    }
+    if (lane == 0) {
+      const Run<RED, F> head = rec_load<RED, F>(ws.head_v, ws.head_p, b);
+      run_merge(part, head);
+      store_row<Idx, RED, F, OPK>(o, ws.head_row[b], part, 0);
+    }
   }
 }
 
@@ -494,7 +582,8 @@ inline size_t nr_align(size_t x) { return (x + 255) & ~static_cast<size_t>(255);
 size_t nr_bytes(int64_t nnz, int f, bool cmp) {
   const int64_t unit_edges = 64 * nr_lane_edges(f);
   const size_t units = static_cast<size_t>((nnz + unit_edges - 1) / unit_edges);
-  size_t b = 2 * nr_align(units * f * sizeof(float)) + 3 * nr_align(units * sizeof(int64_t)) + nr_align(units);
+  size_t b = 2 * nr_align(units * f * sizeof(float)) + 3 * nr_align(units * sizeof(int64_t)) + nr_align(units) +
+             nr_align((units / kNrInlineSteps + 2) * sizeof(int64_t)) + nr_align(sizeof(unsigned long long));
   if (cmp) b += 2 * nr_align(units * f * sizeof(int64_t));
   return b;
 }
@@ -517,6 +606,8 @@ int nr_launch(const SpmmLaunch& L, char* wsp) {
   ws.tail_row = reinterpret_cast<int64_t*>(take(units * sizeof(int64_t)));
   ws.first_row = reinterpret_cast<int64_t*>(take(units * sizeof(int64_t)));
   ws.flags = reinterpret_cast<uint8_t*>(take(units));
+  ws.long_list = reinterpret_cast<int64_t*>(take((units / kNrInlineSteps + 2) * sizeof(int64_t)));
+  ws.long_count = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long)));
   ws.head_p = ws.tail_p = nullptr;
   if (RED != kSum) {
     ws.head_p = reinterpret_cast<int64_t*>(take(units * F * sizeof(int64_t)));
@@ -550,7 +641,7 @@ int nr_launch(const SpmmLaunch& L, char* wsp) {
                        total, static_cast<Idx>(L.arg_empty));
   if (units > 0) {
     hipLaunchKernelGGL((narrow_plan_kernel<Idx>), dim3(static_cast<unsigned>(std::min<int64_t>((units + 255) / 256, 4096))),
-                       dim3(256), 0, L.stream, o.indptr, n, units, ws.first_row, kNrUnit);
+                       dim3(256), 0, L.stream, o.indptr, n, units, ws.first_row, kNrUnit, ws.long_count);
     const dim3 grid(static_cast<unsigned>((units + kNrWaves - 1) / kNrWaves));
     constexpr bool kStageable = (OPK == 0 || OPK == 2) && (F == 4 || F == 8) && nr_lane_edges(F) == 4;
     bool staged = false;
@@ -565,6 +656,9 @@ int nr_launch(const SpmmLaunch& L, char* wsp) {
     hipLaunchKernelGGL((narrow_fixup_kernel<Idx, RED, F, OPK>),
                        dim3(static_cast<unsigned>(std::min<int64_t>((units + 255) / 256, 4096))), dim3(256), 0, L.stream, o, units,
                        ws);
+    if (units > kNrInlineSteps)   // (rows cut into many units, if the graph has any: a list the kernel above filled)
+      hipLaunchKernelGGL((narrow_fixup_long_kernel<Idx, RED, F, OPK>),
+                         dim3(static_cast<unsigned>(std::min<int64_t>((units / kNrInlineSteps + 3) / 4, 1024))), dim3(256), 0, L.stream, o, ws);
   }
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;

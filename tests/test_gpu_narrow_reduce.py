@@ -115,6 +115,17 @@ def test_edge_rows_in_position_order_staged_through_lds(dev, case, red, f, misal
         _run(dev, _degree_cases()[case], f, red, idtype, with_eids=False, seed=60 + f, ties=(red == "max"), misaligned=misaligned)
 
 
+@pytest.mark.parametrize("red", ["sum", "max", "min"])
+@pytest.mark.parametrize("f", [1, 4, 7, 8])
+def test_rows_cut_into_many_units_take_the_long_row_fix_up(dev, red, f):
+    """A row of 12 000 edges is 47 units, one of 200 000 is 782: the fix-up kernel walks at most four pieces per thread and
+    lists longer rows for a kernel that merges 64 pieces per step and wavefront (narrow_fixup_long_kernel) — sums to the same
+    tolerance, winners and their FIRST positions exact with many ties, the same bits on a second launch (checked in _run)."""
+    degs = [5, 200000, 0, 3, 70000, 1, 1024 + 256 * 4, 256 * 5, 256 * 6 + 1, 0, 9, 16640, 2]
+    for idtype, with_eids in ((torch.int32, False), (torch.int64, True)):
+        _run(dev, degs, f, red, idtype, with_eids, seed=70 + f, ties=(red != "sum"))
+
+
 @pytest.mark.parametrize("red", ["max", "min"])
 @pytest.mark.parametrize("with_eids", [False, True])
 def test_first_position_wins_a_tie(dev, red, with_eids):

@@ -78,4 +78,6 @@ def test_narrow_feature_kernels_keep_their_rows_in_registers():
     assert len(main) >= 100
     assert all(c["flat"] == 0 and c["scratch"] == 0 for c in nr.values())
     text = isa_audit.disassemble(os.path.join(isa_audit.ROOT, "build", "csrc", "narrow_reduce.o"))
-    assert "ds_bpermute" not in text and text.count("row_shr:1") > 100
+    # (the long-row fix-up kernel merges its lanes' results with ds_bpermute butterflies: one wavefront per hub row, not hot)
+    units = [part for part in re.split(r"\n(?=[0-9a-f]+ <)", text) if "narrow_reduce_kernel" in part.split("\n", 1)[0]]
+    assert len(units) >= 100 and all("ds_bpermute" not in u and "row_shr:1" in u for u in units)
