@@ -1,4 +1,4 @@
-import sys, json, torch, numpy as np
+import sys, json, torch
 sys.path.insert(0, "/root/repo")
 from dgl_amd import _capi
 from tests.graphgen import synth_csr

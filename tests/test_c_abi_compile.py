@@ -3,7 +3,6 @@
 need no GPU behave (version, error strings, registry lookup, host-side partitioner)."""
 import os
 import subprocess
-import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -2,7 +2,6 @@
 shapes): what each layout adds to the scratch of a call, and the unit size of small graphs.
 Mirrors the decisions of csrc/spmm_csr.hip.h::spmm_geometry / spmm_split_shape_ok / spmm_tail_slices."""
 import ctypes
-import os
 
 import pytest
 

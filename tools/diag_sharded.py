@@ -1,5 +1,5 @@
 import sys, os
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.graphgen import synth_csr
 from dgl_amd import _capi

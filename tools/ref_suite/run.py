@@ -16,7 +16,6 @@ user-defined functions (edge batches + degree bucketing, dgl_amd/udf.py), forwar
 reference's own tolerances (rtol = atol = 1e-4; tests/python/common/ops/test_ops.py:87-181).
 """
 import argparse
-import importlib
 import json
 import os
 import shutil
