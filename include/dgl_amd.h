@@ -548,6 +548,8 @@ uint32_t dgla_get_tuning(void);
  * 1 ... 8 fp32 output columns — copy_rhs, copy_lhs, u (+ - * /) e —, one lane per four EDGES instead of one lane per column; same results as the
  * merge kernel up to the order of fp32 additions, winners and their edge ids identical).  A counter for tests and
  * benches to see which kernel family took a call; DGLA_NARROW_REDUCE=0 in the environment keeps the merge kernel.
+ * (DGLA_NARROW_STAGE=0: edge rows of 4 / 8 columns in position order are gathered lane by lane instead of being fetched as
+ * whole wavefront loads and transposed through LDS — an A/B switch, same bits either way.)
  * The reference has one kernel for every width (src/array/cuda/spmm.cuh:440-520). */
 int64_t dgla_narrow_reduce_calls(void);
 
