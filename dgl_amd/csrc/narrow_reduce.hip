@@ -9,10 +9,13 @@
 //   1. the row holding the unit's first position by one wave-uniform binary search; the row starts that fall inside the
 //      unit are marked in LDS by the lanes reading indptr[r_first + 1 + lane ...] (start bits + the id of the row that
 //      starts there; empty rows in between cost nothing: the largest id wins);
-//   2. every lane reduces its four edges into runs; a run that begins and ends inside a lane is stored at once;
-//   3. a segmented scan over the lanes (the open run at a lane's end is carried to the lane that closes it);
+//   2. every lane reduces its four edges into runs; a run that begins and ends inside a lane is stored at once (operand
+//      rows are loaded first, 16 bytes at a time; edge rows of 4 / 8 columns in position order as whole 1 KB wavefront
+//      loads transposed through LDS);
+//   3. a segmented scan over the lanes — DPP moves — (the open run at a lane's end is carried to the lane that closes it);
 //   4. a row cut by a unit boundary leaves its pieces in the workspace — (head: the piece at the start of a unit, tail:
-//      the piece at its end) — and a second, tiny kernel adds the pieces of each such row in position order.
+//      the piece at its end) — and a second, tiny kernel adds the pieces of each such row in position order: a thread per
+//      row for up to four pieces, a wavefront per row (64 pieces per step) for hubs.
 // Deterministic: the order of the additions depends on the CSR alone.  Rows without an edge keep the reducer's identity
 // (0, -inf, +inf) and argument 0, written by a fill kernel in front, as the merge kernel leaves them.
 #include <hip/hip_runtime.h>
