@@ -967,7 +967,7 @@ def from_networkx(nx_graph, idtype=None, device=None):
                  device=device or torch.device("cpu"))
 
 
-def to_homogeneous(G, ndata=None, edata=None):
+def to_homogeneous(G, ndata=None, edata=None, store_type=True, return_count=False):
     """One node / edge type: nodes concatenated in node-type order, edges in edge-type order; ``ndata[NTYPE]`` /
     ``ndata[NID]`` / ``edata[ETYPE]`` / ``edata[EID]`` remember the origin (dgl.to_homogeneous); ``ndata`` /
     ``edata`` name the feature fields to carry over (concatenated)."""
@@ -986,22 +986,29 @@ def to_homogeneous(G, ndata=None, edata=None):
         eid.append(torch.arange(u.shape[0], dtype=it, device=dev))
     cat = lambda xs: torch.cat(xs) if xs else torch.zeros(0, dtype=it, device=dev)
     hg = graph((cat(us), cat(vs)), num_nodes=offs[-1], idtype=it, device=dev)
-    hg.ndata[NTYPE] = torch.cat([torch.full((c,), i, dtype=it, device=dev) for i, c in enumerate(counts)]) \
-        if counts else torch.zeros(0, dtype=it, device=dev)
+    if store_type:
+        hg.ndata[NTYPE] = torch.cat([torch.full((c,), i, dtype=it, device=dev) for i, c in enumerate(counts)]) \
+            if counts else torch.zeros(0, dtype=it, device=dev)
     nid = torch.cat([torch.arange(c, dtype=it, device=dev) for c in counts]) if counts else torch.zeros(0, dtype=it, device=dev)
     hg._node_frames[0][NID] = nid
-    hg._edge_frames[0][ETYPE] = cat(ety)
+    if store_type:
+        hg._edge_frames[0][ETYPE] = cat(ety)
     hg._edge_frames[0][EID] = cat(eid)
     for k in (ndata or []):
         hg._node_frames[0][k] = torch.cat([f[k] for f in G._node_frames])
     for k in (edata or []):
         hg._edge_frames[0][k] = torch.cat([f[k] for f in G._edge_frames])
+    if return_count:    # python/dgl/convert.py to_homogeneous: (graph, nodes per type, edges per type)
+        return hg, counts, [int(t.shape[0]) for t in eid]
     return hg
 
 
 def to_heterogeneous(G, ntypes, etypes, ntype_field=NTYPE, etype_field=ETYPE, metagraph=None):
     """Split a homogeneous graph by ``ndata[ntype_field]`` / ``edata[etype_field]`` (dgl.to_heterogeneous): node ids
     inside a type follow their order in ``G``; every other feature field is sliced along (autograd kept)."""
+    if metagraph is not None:
+        raise DGLAMDError("to_heterogeneous: a caller-given metagraph is not supported; the metagraph is derived from the "
+                       "type fields")
     ntype_ids = G.ndata[ntype_field].long()
     etype_ids = G.edata[etype_field].long()
     dev, it = G.device, G.idtype
@@ -1039,4 +1046,9 @@ def to_heterogeneous(G, ntypes, etypes, ntype_field=NTYPE, etype_field=ETYPE, me
         for k, col in G._edge_frames[0].items():
             if k not in (etype_field, EID):
                 f[k] = col[mm]
+    # the ids the per-type nodes / edges had in G (python/dgl/convert.py:878-887: hg.ndata[dgl.NID] / edata[dgl.EID])
+    for i, nt in enumerate(ntypes):
+        hg._node_frames[hg.get_ntype_id(nt)][NID] = node_sel[i].to(it)
+    for cet, mm in edge_sel.items():
+        hg._edge_frames[hg.get_etype_id(cet)][EID] = mm.to(it)
     return hg

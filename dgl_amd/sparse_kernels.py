@@ -26,15 +26,25 @@ _static = {}             # id(tensor) -> (weakref to the tensor, token)
 _tokens = itertools.count(1)
 
 
+def _fingerprint(t):
+    # what must stay the same for a kept copy to still describe `t`: torch's in-place version counter
+    # (bumped by every in-place op, optimizer steps included), storage address, shape and strides
+    return (t._version, t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+
+
 def static_features(t):
     """Declare ``t`` (a source-node OR edge feature tensor) unchanging for as long as it lives.
     g-SpMM calls that read it as the node operand keep its split-row copy between calls instead
     of re-making it; sum-reducing calls that read it as the EDGE operand on a graph whose CSC has
     an edge-id map keep a copy in CSC position order and run map-free (GCN-style normalisation
-    weights: one random 128-byte line per 4-byte weight otherwise).  Writing into ``t``
-    afterwards is the caller's bug; ``release_static(t)`` takes the promise back.  Returns ``t``."""
+    weights: one random 128-byte line per 4-byte weight otherwise).  The promise is CHECKED at
+    every use (one host compare of ``t._version``, ``data_ptr()``, shape, strides): an in-place
+    write into ``t`` afterwards withdraws it — that call and later ones re-read ``t`` on the plain
+    path, like the reference does on every call (python/dgl/_sparse_ops.py:156-265) — until
+    ``static_features(t)`` is called again.  ``release_static(t)`` takes the promise back.
+    Returns ``t``."""
     key = id(t)
-    _static[key] = (weakref.ref(t, lambda _r, k=key: _static.pop(k, None)), next(_tokens))
+    _static[key] = (weakref.ref(t, lambda _r, k=key: _static.pop(k, None)), next(_tokens), _fingerprint(t))
     return t
 
 
@@ -56,7 +66,12 @@ def set_auto_edge_operand(min_edges):
 
 def _static_token(t):
     ent = _static.get(id(t))
-    return ent[1] if ent is not None and ent[0]() is t else 0
+    if ent is None or ent[0]() is not t:
+        return 0
+    if ent[2] != _fingerprint(t):       # written in place (or re-pointed) since the announcement: the kept copy is stale
+        _static.pop(id(t), None)
+        return 0
+    return ent[1]
 
 
 def infer_broadcast_shape(op, shp1, shp2):

@@ -19,3 +19,32 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """How the fp32-sum acceptance rule (tests/tolerance.py) was used in this run: the plain max rel err against the
+    reference and the number of elements that needed the "closer to the exact sum" escape / the degree widening —
+    printed at the end of the run and written to gpurun_out/fp32_sum_acceptance.json (VERDICT r5 Next #1c)."""
+    import json
+
+    from tests import tolerance
+
+    if not tolerance.TALLY:
+        return
+    s = tolerance.summary()
+    terminalreporter.write_sep("-", "fp32-sum acceptance rule")
+    terminalreporter.write_line(
+        "%(checks)d checks, %(elements)d elements; escape used by %(escape_elements)d elements in "
+        "%(checks_that_used_the_escape)d checks; plain max rel err vs reference %(max_plain_rel_err_vs_reference).3g "
+        "(%(max_plain_rel_err_where)s); largest widened rtol %(max_widened_rtol).3g; escape forbidden on rows under "
+        "%(short_row)d edges" % s)
+    for r in tolerance.TALLY:
+        if r["escape_elements"]:
+            terminalreporter.write_line("  escape: %(escape_elements)d of %(elements)d elements, plain %(max_rel_err_vs_reference).3g  %(where)s" % r)
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "fp32_sum_acceptance.json"), "w") as fh:
+            json.dump({"summary": s, "checks": tolerance.TALLY}, fh, indent=1)
+    except OSError:
+        pass

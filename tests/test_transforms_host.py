@@ -128,3 +128,35 @@ def test_subgraphs():
     assert list(zip(*[t.tolist() for t in hs.edges(etype="s")])) == [(0, 1), (1, 0)]
     he = dgl.edge_subgraph(hg, {"r": [2], "s": torch.tensor([True, False])})
     assert he.num_nodes("a") == 1 and he.num_nodes("b") == 1 and he.nodes["a"].data["_ID"].tolist() == [2]
+
+
+def test_to_heterogeneous_records_the_original_ids():
+    """python/dgl/convert.py:878-887: hg.ndata[dgl.NID] / hg.edata[dgl.EID] map per-type nodes / edges back to the
+    homogeneous graph; to_homogeneous(store_type=False, return_count=True) as the reference documents it."""
+    import pytest
+
+    import dgl_amd as dgl
+    from dgl_amd.heterograph import EID, ETYPE, NID, NTYPE
+
+    hg = dgl.heterograph({("a", "x", "b"): ([0, 1, 2], [1, 0, 1]), ("b", "y", "a"): ([0, 1], [2, 2])},
+                         {"a": 3, "b": 2})
+    g, ncount, ecount = dgl.to_homogeneous(hg, return_count=True)
+    assert ncount == [3, 2] and ecount == [3, 2]
+    g.ndata["h"] = torch.arange(5.0)
+    g.edata["w"] = torch.arange(5.0) * 10
+    back = dgl.to_heterogeneous(g, hg.ntypes, hg.etypes)
+    for nt in hg.ntypes:
+        nid = back.nodes[nt].data[NID]
+        assert torch.equal(g.ndata["h"][nid.long()], back.nodes[nt].data["h"])
+        assert torch.equal(g.ndata[NTYPE][nid.long()], torch.full_like(nid, hg.get_ntype_id(nt)))
+    for cet in back.canonical_etypes:
+        eid = back.edges[cet].data[EID]
+        assert torch.equal(g.edata["w"][eid.long()], back.edges[cet].data["w"])
+        u, v = back.edges(etype=cet)
+        gu, gv = g.edges()
+        assert torch.equal(back.nodes[cet[0]].data[NID][u.long()], gu[eid.long()])
+        assert torch.equal(back.nodes[cet[2]].data[NID][v.long()], gv[eid.long()])
+    plain = dgl.to_homogeneous(hg, store_type=False)
+    assert NTYPE not in plain.ndata and ETYPE not in plain.edata and NID in plain.ndata
+    with pytest.raises(dgl.DGLError):
+        dgl.to_heterogeneous(g, hg.ntypes, hg.etypes, metagraph=object())
