@@ -801,6 +801,18 @@ def main():
                 result["roofline"]["measured_copy_peak_error"] = repr(ex)
         if not args.no_variants:
             result["variants"] = variants(dev, ctx, n, e, f, args)
+            # the other operators north_star names, on this same clock (benchmarks/hot_path_variants.py): u_mul_e_sum,
+            # SDDMM u_dot_v, edge softmax, the GAT attention block, the stacked bf16 R-GCN launch — each with its
+            # algorithmic bytes and roofline fraction; timed outside the K steps
+            if args.variant == "U":
+                try:
+                    from benchmarks.hot_path_variants import op_variants
+
+                    t_ops = time.perf_counter()
+                    result["variants"].update(op_variants(dev, ctx["g"], args.scale))
+                    result["variants"]["op_variants_seconds"] = round(time.perf_counter() - t_ops, 1)
+                except Exception as ex:  # pragma: no cover  (the headline line must still be printed)
+                    result["variants"]["op_variants_error"] = repr(ex)
         if not args.no_cpu:
             cb, ref = cpu_baseline(ctx["g"], ctx["x"])
             result["cpu_baseline"] = cb

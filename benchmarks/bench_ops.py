@@ -571,7 +571,7 @@ def gat_graph(dev, args):
             layer()
         ms, mn = timeit(graph.replay, reps=20, warm=5)
         emit("GAT", "GATConv forward H=8 D=%d, one hipGraph replay" % d, e, ms, mn, nb)
-        # the same block written out once more inside the opt-in hand-off scope — what dgl_amd.nn.GATConv does around its
+        # the same block written out once more inside the opt-in hand-off scope — the opt-in scope around the
         # attention block (nothing tagged leaves the scope: the layer's output is a node tensor)
         def layer_scoped():
             with dgl.edge_order_handoff():
@@ -579,24 +579,29 @@ def gat_graph(dev, args):
 
         layer_scoped()
         ms, mn = timeit(layer_scoped, reps=20, warm=5)
-        emit("GAT", "GATConv forward H=8 D=%d, eager, attention block inside dgl_amd.edge_order_handoff() (as dgl_amd.nn.GATConv)" % d,
+        emit("GAT", "GATConv forward H=8 D=%d, eager, attention block inside dgl_amd.edge_order_handoff()" % d,
              e, ms, mn, nb)
-    # the whole module: fc + attention block + bias, forward and forward + backward (in_feats 128 -> 8 heads x 8)
-    conv = dgl.nn.GATConv(128, 8, num_heads=8, allow_zero_in_degree=True).to(dev)
+    # the whole layer written out with the operator API: fc + attention block + bias, forward and forward + backward
+    # (in_feats 128 -> 8 heads x 8); the block through dgl_amd.nn.gat_attention — composed operators vs the default route
+    lin = torch.nn.Linear(128, 64, bias=False).to(dev)
+    al, ar = torch.randn(1, 8, 8, device=dev, requires_grad=True), torch.randn(1, 8, 8, device=dev, requires_grad=True)
     x = torch.randn(n, 128, device=dev, requires_grad=True)
     nb = e * (8 * 4 * 6 + 8 * 8 * 4 + 3 * 4) + n * 8 * 8 * 4
-    for on in (True, False):
-        conv.handoff = on
-        ms, mn = timeit(lambda: conv(g, x), reps=20, warm=5)
-        emit("GAT", "dgl_amd.nn.GATConv(128, 8, heads=8) forward, handoff=%s" % on, e, ms, mn, nb)
+    for route, kw in (("composed", dict(fused=False)), ("composed + hand-off", dict(fused=False, handoff=True)), ("default", {})):
+        def fwd():
+            f = lin(x).view(n, 8, 8)
+            return dgl.nn.gat_attention(g, f, (f * al).sum(-1, keepdim=True), (f * ar).sum(-1, keepdim=True), 0.2, **kw)
+
+        ms, mn = timeit(fwd, reps=20, warm=5)
+        emit("GAT", "GAT layer (128 -> 8 heads x 8) forward, attention block %s" % route, e, ms, mn, nb)
 
         def train():
-            x.grad = None
-            conv.zero_grad()
-            conv(g, x).square().sum().backward()
+            x.grad = al.grad = ar.grad = None
+            lin.zero_grad()
+            fwd().square().sum().backward()
 
         ms, mn = timeit(train, reps=10, warm=3)
-        emit("GAT", "dgl_amd.nn.GATConv(128, 8, heads=8) forward + backward, handoff=%s" % on, e, ms, mn, 3 * nb)
+        emit("GAT", "GAT layer (128 -> 8 heads x 8) forward + backward, attention block %s" % route, e, ms, mn, 3 * nb)
 
 
 def edge_order(dev, args):

@@ -16,7 +16,6 @@ from .heterograph import (DGLGraph, ETYPE, NTYPE, create_block, from_networkx, g
 from . import udf  # noqa: E402,F401
 from . import nn  # noqa: E402,F401
 from . import sampling  # noqa: E402,F401
-from . import dataloading  # noqa: E402,F401
 from .transforms import (add_reverse_edges, add_self_loop, batch, bipartite_from_scipy, edge_subgraph,  # noqa: E402,F401
                          from_scipy, in_subgraph, node_subgraph, remove_edges, remove_self_loop, reorder_graph,
                          to_bidirected, to_simple, unbatch)

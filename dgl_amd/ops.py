@@ -12,7 +12,7 @@ import torch
 from . import autograd as _F
 from ._lib import DGLAMDError
 
-__all__ = ["gspmm", "gsddmm", "edge_softmax", "copy_u", "copy_v", "copy_e"]
+__all__ = ["gspmm", "gsddmm", "edge_softmax", "copy_u", "copy_v", "copy_e", "gat_attention", "gat_attention_applies"]
 
 
 def _reshape_for_broadcast(op, lhs, rhs):
@@ -146,6 +146,47 @@ def edge_softmax(graph, logits, eids=None, norm_by="dst"):
     if isinstance(logits, dict):
         return {graph.canonical_etypes[et]: o for et, o in enumerate(outs) if o is not None}
     return tuple(outs)
+
+
+# ---- GAT attention block as one operator ------------------------------------------------
+def gat_attention_applies(graph, ft, el, er):
+    """Whether the one-pass kernel takes this call: one relation with an in-edge CSC, fp32 / fp16 / bf16 operands on the
+    GPU of shapes (N_src, H, D), (N_src, H, 1), (N_dst, H, 1) with H * D <= 1024."""
+    from . import _ffi
+
+    gidx = graph._graph
+    if gidx.number_of_etypes() != 1 or not gidx.relations[0].allowed("csc"):
+        return False
+    if "dgl_amd._CAPI_GATAttentionForward" not in _registered():
+        return False
+    if ft.dim() != 3 or el.dim() != 3 or er.dim() != 3 or el.shape[2] != 1 or er.shape[2] != 1:
+        return False
+    if not (ft.dtype == el.dtype == er.dtype and ft.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+        return False
+    h, d = int(ft.shape[1]), int(ft.shape[2])
+    return (ft.is_cuda and el.shape[1] == h and er.shape[1] == h and 0 < h * d <= 1024 and
+            ft.shape[0] == el.shape[0] == graph.num_src_nodes() and er.shape[0] == graph.num_dst_nodes())
+
+
+_registry_names = []
+
+
+def _registered():
+    if not _registry_names:
+        from . import _ffi
+
+        _registry_names.append(frozenset(_ffi.list_global_func_names()))
+    return _registry_names[0]
+
+
+def gat_attention(graph, ft, el, er, negative_slope=0.2):
+    """``out[v] = sum_{u->v} softmax_v(leaky_relu(el[u] + er[v])) * ft[u]`` per head in ONE pass over the in-edges
+    (csrc/gat_attention.hip): no (E, H) tensor is written or read; the backward recomputes the attention weights from
+    the per-row (max, sum) the forward saved.  The composition it replaces: gatconv.py:330-347."""
+    if not gat_attention_applies(graph, ft, el, er):
+        raise DGLAMDError("gat_attention: the fused kernel does not take these operands (dgl_amd.nn.gat_attention "
+                          "falls back to the composed operators)")
+    return _F.gat_attention(graph._graph, ft, el, er, float(negative_slope))
 
 
 # ---- generated aliases -----------------------------------------------------------------

@@ -4,7 +4,7 @@
 ``to_bidirected`` (python/dgl/transforms/functional.py), ``node_subgraph`` / ``edge_subgraph`` / ``in_subgraph``
 (python/dgl/subgraph.py),
 ``batch`` (python/dgl/batch.py), ``from_scipy`` / ``bipartite_from_scipy`` (python/dgl/convert.py), ``adj_external``
-(heterograph.py) and ``EdgeWeightNorm`` (nn/pytorch/conv/graphconv.py:17-130): the handful the reference's own layer tests
+(heterograph.py): the handful the reference's own layer tests
 (tests/python/pytorch/nn/test_nn.py, tests/utils/graph_cases.py) build their graphs with — tools/ref_suite runs those
 files unmodified.  None of this is a kernel and none of it is timed; every graph these return builds its CSR / CSC with
 the library's COO -> CSR kernel the first time an operator asks for it, like any other graph.
@@ -414,40 +414,6 @@ def in_subgraph(g, nodes, relabel_nodes=False, store_ids=True, output_device=Non
     return out.to(output_device) if output_device is not None else out
 
 
-class EdgeWeightNorm(torch.nn.Module):
-    """Edge weights normalised as GraphConv normalises by degrees: ``c_ji = e_ji / sqrt(D_j D_i)`` ('both'), ``/ D_i``
-    ('right') or none, with D the weighted degrees (nn/pytorch/conv/graphconv.py:17-130)."""
-
-    def __init__(self, norm="both", eps=0.0):
-        super().__init__()
-        self._norm, self._eps = norm, eps
-
-    def forward(self, graph, edge_weight):
-        with graph.local_scope():
-            if isinstance(edge_weight, tuple):
-                raise DGLAMDError("edge_weight should be a tensor")
-            if edge_weight.dim() != 1:
-                raise DGLAMDError("Currently the normalization is only defined on scalar edge weight. Please customize the "
-                                  "normalization for your high-dimensional weights.")
-            if self._norm == "both" and bool((edge_weight <= 0).any()):
-                raise DGLAMDError('Non-positive edge weight detected with `norm="both"`. This leads to square root of '
-                                  "zero or negative values.")
-            dev = edge_weight.device
-            graph.srcdata["_src_out_w"] = torch.ones(graph.num_src_nodes(), device=dev, dtype=edge_weight.dtype)
-            graph.dstdata["_dst_in_w"] = torch.ones(graph.num_dst_nodes(), device=dev, dtype=edge_weight.dtype)
-            graph.edata["_edge_w"] = edge_weight
-            if self._norm == "both":
-                u = graph.edges()[0].long()
-                out_w = torch.zeros(graph.num_src_nodes(), device=dev, dtype=edge_weight.dtype).index_add(0, u, edge_weight)
-                graph.srcdata["_src_out_w"] = torch.pow(out_w + self._eps, -0.5)
-            if self._norm != "none":
-                graph.update_all(fn.copy_e("_edge_w", "m"), fn.sum("m", "in_weight"))
-                deg = graph.dstdata["in_weight"] + self._eps
-                graph.dstdata["_dst_in_w"] = torch.pow(deg, -0.5) if self._norm == "both" else 1.0 / deg
-            graph.apply_edges(lambda e: {"_norm_edge_weights": e.src["_src_out_w"] * e.dst["_dst_in_w"] * e.data["_edge_w"]})
-            return graph.edata["_norm_edge_weights"]
-
-
 __all__ = ["add_self_loop", "remove_self_loop", "remove_edges", "reorder_graph", "add_reverse_edges", "to_simple", "to_bidirected",
            "node_subgraph", "edge_subgraph", "in_subgraph", "batch", "unbatch", "from_scipy", "bipartite_from_scipy",
-           "adj_external", "EdgeWeightNorm"]
+           "adj_external"]
