@@ -109,15 +109,15 @@ def op_variants(dev, c2_graph=None, scale=1, reps=10):
         t = _time(fb, max(3, reps // 2))
         res["edge_softmax_fwd_bwd_C2size_" + tag] = _line(t, e * (5 * h * s + (2 * i if with_map else 0)) + 2 * (n + 1) * i, e, gathered=e * h * s)
         del sc, sg, up
-        if with_map:   # configs[2]'s block at C2 size, forward (VERDICT r5 Next #3: <= 3.5 ms with or without a map)
-            d = 32
-            ft, el, er = (torch.randn(n, h, d, device=dev), torch.randn(n, h, 1, device=dev), torch.randn(n, h, 1, device=dev))
-            nb = e * (h * d * s + h * s + i) + n * (h * d * s + 2 * h * s) + (n + 1) * i
-            for route, kw in (("composed", dict(fused=False)), ("default", {})):
-                with torch.no_grad():
-                    t = _time(lambda: dgl.nn.gat_attention(dg, ft, el, er, 0.2, **kw), max(3, reps // 2))
-                res["gat_attention_fwd_C2size_H8_D32_eid_map_" + route] = _line(t, nb, e, gathered=n * h * d * s)
-            del ft, el, er
+        if with_map:   # configs[2]'s block at C2 size, forward (VERDICT r5 Next #3: <= 3.5 ms at D = 8 with or without a map)
+            for d in (8, 32):
+                ft, el, er = (torch.randn(n, h, d, device=dev), torch.randn(n, h, 1, device=dev), torch.randn(n, h, 1, device=dev))
+                nb = e * (h * d * s + h * s + i) + n * (h * d * s + 2 * h * s) + (n + 1) * i
+                for route, kw in (("composed", dict(fused=False)), ("default", {})):
+                    with torch.no_grad():
+                        t = _time(lambda: dgl.nn.gat_attention(dg, ft, el, er, 0.2, **kw), max(3, reps // 2))
+                    res["gat_attention_fwd_C2size_H8_D%d_eid_map_%s" % (d, route)] = _line(t, nb, e, gathered=n * h * d * s)
+                del ft, el, er
         del dg
     del g
     torch.cuda.empty_cache()

@@ -200,6 +200,34 @@ def edge_softmax_backward(csr, out, sds, back, workspace=None, plan_valid=False,
                                               ctypes.byref(tb), wp, wn, fl, _stream(back)))
 
 
+def gat_attention_workspace_bytes(csc, heads, dim):
+    return int(LIB.dgla_gat_attention_workspace_bytes(ctypes.byref(csc), int(heads), int(dim)))
+
+
+def gat_attention_forward(csc, ft, el, er, slope, out, mz, workspace):
+    """out[v] = sum_u softmax_v(leaky_relu(el[u] + er[v])) ft[u] per head in one pass (dgla_gat_attention_forward);
+    `mz` (N_dst, H, 2) fp32 receives each row's softmax maximum and normaliser for the backward."""
+    keep = []
+    tf, tl, tr, to = (_tensor(t, keep) for t in (ft, el, er, out))
+    _require_gpu(mz)
+    check_call(LIB.dgla_gat_attention_forward(ctypes.byref(csc), _DTYPES[ft.dtype], ctypes.byref(tf), ctypes.byref(tl),
+                                              ctypes.byref(tr), float(slope), ctypes.byref(to), mz.data_ptr(),
+                                              _ptr(workspace), 0 if workspace is None else workspace.numel(),
+                                              _stream(out)))
+
+
+def gat_attention_backward(csc, csr, ft, el, er, out, mz, dout, slope, d_ft, d_el, d_er, workspace):
+    """Gradients of dgla_gat_attention_forward; `csr` = the out-edge CSR (rows = source nodes) of the same graph."""
+    keep = []
+    ts = [_tensor(t, keep) for t in (ft, el, er, out, dout, d_ft, d_el, d_er)]
+    check_call(LIB.dgla_gat_attention_backward(ctypes.byref(csc), ctypes.byref(csr), _DTYPES[ft.dtype],
+                                               ctypes.byref(ts[0]), ctypes.byref(ts[1]), ctypes.byref(ts[2]),
+                                               ctypes.byref(ts[3]), mz.data_ptr(), ctypes.byref(ts[4]), float(slope),
+                                               ctypes.byref(ts[5]), ctypes.byref(ts[6]), ctypes.byref(ts[7]),
+                                               _ptr(workspace), 0 if workspace is None else workspace.numel(),
+                                               _stream(d_ft)))
+
+
 def stream_copy(dst, src):
     _require_gpu(dst)
     check_call(LIB.dgla_stream_copy(dst.data_ptr(), src.data_ptr(),

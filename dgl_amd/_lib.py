@@ -92,6 +92,15 @@ LIB.dgla_edge_softmax_workspace_bytes.argtypes = [P(CSR), c_int, c_int64]
 LIB.dgla_edge_softmax_backward.restype = c_int
 LIB.dgla_edge_softmax_backward.argtypes = [P(CSR), c_int, P(Tensor), P(Tensor), P(Tensor),
                                            c_void_p, c_size_t, c_uint32, c_void_p]
+LIB.dgla_gat_attention_workspace_bytes.restype = c_size_t
+LIB.dgla_gat_attention_workspace_bytes.argtypes = [P(CSR), c_int64, c_int64]
+LIB.dgla_gat_attention_forward.restype = c_int
+LIB.dgla_gat_attention_forward.argtypes = [P(CSR), c_int, P(Tensor), P(Tensor), P(Tensor), ctypes.c_float, P(Tensor),
+                                           c_void_p, c_void_p, c_size_t, c_void_p]
+LIB.dgla_gat_attention_backward.restype = c_int
+LIB.dgla_gat_attention_backward.argtypes = [P(CSR), P(CSR), c_int, P(Tensor), P(Tensor), P(Tensor), P(Tensor), c_void_p,
+                                            P(Tensor), ctypes.c_float, P(Tensor), P(Tensor), P(Tensor), c_void_p,
+                                            c_size_t, c_void_p]
 LIB.dgla_spmm_set_profile_events.restype = c_int
 LIB.dgla_spmm_set_profile_events.argtypes = [c_void_p, c_void_p]
 LIB.dgla_segment_reduce_workspace_bytes.restype = c_size_t

@@ -326,6 +326,72 @@ class EdgeSoftmax(torch.autograd.Function):
         return None, _edge_softmax_backward(ctx.gidx, out, sds), None, None
 
 
+class GATAttention(torch.autograd.Function):
+    """``out[v] = sum_{u->v} softmax_v(leaky_relu(el[u] + er[v])) ft[u]`` per head as one operator
+    (csrc/gat_attention.hip).  Saved for the backward: the operands, ``out`` and the rows' softmax (max, normaliser) —
+    2 floats per (node, head); the attention weights are recomputed, no (E, H) tensor is kept."""
+
+    @staticmethod
+    def forward(ctx, gidx, ft, el, er, slope):
+        rel = gidx.relations[0]
+        ft, el, er = ft.contiguous(), el.contiguous(), er.contiguous()
+        n_dst, (h, d) = rel.num_dst, ft.shape[1:]
+        out = torch.empty((n_dst, h, d), dtype=ft.dtype, device=ft.device)
+        mz = torch.empty((n_dst, h, 2), dtype=torch.float32, device=ft.device)
+        ws = _gat_workspace(rel, h, d)
+        _call_unit("dgl_amd._CAPI_GATAttentionForward", rel, ("csc",), _nd(ft), _nd(el), _nd(er), float(slope), _nd(out),
+                   _nd(mz), _nd(ws))
+        ctx.meta = (gidx, float(slope))
+        ctx.save_for_backward(ft, el, er, out, mz)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        gidx, slope = ctx.meta
+        ft, el, er, out, mz = ctx.saved_tensors
+        rel = gidx.relations[0]
+        dout = _eo.plain(dout).contiguous()
+        d_ft, d_el, d_er = torch.empty_like(ft), torch.empty_like(el), torch.empty_like(er)
+        ws = _gat_workspace(rel, ft.shape[1], ft.shape[2])
+        _call_unit("dgl_amd._CAPI_GATAttentionBackward", rel, ("csc", "csr"), _nd(ft), _nd(el), _nd(er), _nd(out), _nd(mz),
+                   _nd(dout), slope, _nd(d_ft), _nd(d_el), _nd(d_er), _nd(ws))
+        return None, d_ft, d_el, d_er, None
+
+
+def _nd(t):
+    from . import _ffi
+    return None if t is None else _ffi.NDArray(t)
+
+
+def _call_unit(name, rel, fmts, *args):
+    from . import _ffi
+    _ffi.use_current_stream(rel.device)
+    h = None
+    for f in fmts:          # every format the call reads is registered on the one unit-graph handle
+        h = rel.handle(f)
+    return _ffi.get_global_func(name)(h, *args)
+
+
+def _gat_workspace(rel, heads, dim):
+    """Scratch of the one-pass GAT kernels (chunk table + partial rows + the backward's per-node record), kept on the
+    relation and grown on demand."""
+    key = (int(heads), int(dim))
+    need = rel.__dict__.setdefault("_gat_need", {})
+    nbytes = need.get(key)
+    if nbytes is None:
+        nbytes = need[key] = _call_unit("dgl_amd._CAPI_GATAttentionWorkspaceBytes", rel, ("csc",), key[0], key[1])
+    ws = rel.__dict__.get("_gat_ws")
+    if ws is None or ws.numel() < nbytes:
+        ws = rel.__dict__["_gat_ws"] = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=rel.device)
+    return ws
+
+
+def gat_attention(gidx, ft, el, er, slope):
+    ft, el, er = _eo.plain(ft), _eo.plain(el), _eo.plain(er)
+    with torch.autocast("cuda", enabled=False):
+        return GATAttention.apply(gidx, ft, el, er, slope)
+
+
 def _autocast(*tensors):
     # the reference casts operands to the autocast dtype and runs the Function with autocast
     # disabled (sparse.py:146-159,1030-1032)

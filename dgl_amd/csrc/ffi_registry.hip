@@ -68,6 +68,12 @@ static int get_int(const FfiArgs& a, int i, int64_t* out) {
   *out = a.v[i].v_int64;
   return 0;
 }
+static int get_float(const FfiArgs& a, int i, double* out) {
+  if (i >= a.n || (a.tc[i] != kObjectFloat && a.tc[i] != kObjectInt))
+    return ffi_fail("argument " + std::to_string(i) + ": expected a number");
+  *out = a.tc[i] == kObjectFloat ? a.v[i].v_float64 : static_cast<double>(a.v[i].v_int64);
+  return 0;
+}
 static int get_str(const FfiArgs& a, int i, const char** out) {
   if (i >= a.n || a.tc[i] != kStr)
     return ffi_fail("argument " + std::to_string(i) + ": expected a string");
@@ -963,6 +969,79 @@ static Registrar r_esb("sparse._CAPI_DGLKernelEdge_softmax_backward",
                        [](const FfiArgs& a, DGLValue*, int* rtc) {
   *rtc = kNull;
   return edge_softmax_ffi(a, true);
+});
+
+// ---- GAT attention block as one operator (csrc/gat_attention.hip) ---------------------------------------------
+static int seg_arrays_ok_fwd(std::initializer_list<const DGLArray*> arrs) {  // CheckCtx / CheckContiguous of the lambdas
+  for (const DGLArray* t : arrs) {
+    if (!t || t->ndim == 0) continue;
+    if (!on_gpu(t)) return ffi_fail("array is not on a GPU device");
+    if (check_contiguous(t, "array")) return -1;
+  }
+  return 0;
+}
+// (g, heads, dim) -> bytes of scratch
+static Registrar r_gatw("dgl_amd._CAPI_GATAttentionWorkspaceBytes", [](const FfiArgs& a, DGLValue* ret, int* rtc) {
+  void* h;
+  int64_t heads, dim;
+  if (get_handle(a, 0, &h) || get_int(a, 1, &heads) || get_int(a, 2, &dim)) return -1;
+  UnitGraph* g = static_cast<UnitGraph*>(h);
+  *rtc = kObjectInt;
+  ret->v_int64 = 0;
+  if (!g->csc.present) return ffi_fail("gat_attention needs the CSC format");
+  const dgla_csr csc = csr_of(g, g->csc, true);
+  ret->v_int64 = static_cast<int64_t>(dgla_gat_attention_workspace_bytes(&csc, heads, dim));
+  return 0;
+});
+// (g, ft, el, er, slope, out, mz, workspace)
+static Registrar r_gatf("dgl_amd._CAPI_GATAttentionForward", [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  void* h;
+  DGLArray *ft, *el, *er, *out, *mz, *ws;
+  double slope;
+  if (get_handle(a, 0, &h) || get_array(a, 1, &ft) || get_array(a, 2, &el) || get_array(a, 3, &er) ||
+      get_float(a, 4, &slope) || get_array(a, 5, &out) || get_array(a, 6, &mz) || get_array(a, 7, &ws))
+    return -1;
+  UnitGraph* g = static_cast<UnitGraph*>(h);
+  if (!g->csc.present) return ffi_fail("gat_attention needs the CSC format");
+  if (null_array(ft) || null_array(el) || null_array(er) || null_array(out) || null_array(mz))
+    return ffi_fail("gat_attention: ft / el / er / out / mz are required");
+  if (seg_arrays_ok_fwd({ft, el, er, out, mz, ws})) return -1;
+  dgla_dtype dt;
+  if (float_dtype(ft, &dt)) return -1;
+  const dgla_csr csc = csr_of(g, g->csc, true);
+  TensorArg tf, tl, tr, to;
+  to_tensor(ft, &tf);
+  to_tensor(el, &tl);
+  to_tensor(er, &tr);
+  to_tensor(out, &to);
+  return dgla_gat_attention_forward(&csc, dt, &tf.t, &tl.t, &tr.t, static_cast<float>(slope), &to.t, data_ptr(mz),
+                                    null_array(ws) ? nullptr : data_ptr(ws), null_array(ws) ? 0 : ws->shape[0], tls_stream);
+});
+// (g, ft, el, er, out, mz, dout, slope, d_ft, d_el, d_er, workspace)
+static Registrar r_gatb("dgl_amd._CAPI_GATAttentionBackward", [](const FfiArgs& a, DGLValue*, int* rtc) {
+  *rtc = kNull;
+  void* h;
+  DGLArray *ft, *el, *er, *out, *mz, *dout, *dft, *del_, *der, *ws;
+  double slope;
+  if (get_handle(a, 0, &h) || get_array(a, 1, &ft) || get_array(a, 2, &el) || get_array(a, 3, &er) ||
+      get_array(a, 4, &out) || get_array(a, 5, &mz) || get_array(a, 6, &dout) || get_float(a, 7, &slope) ||
+      get_array(a, 8, &dft) || get_array(a, 9, &del_) || get_array(a, 10, &der) || get_array(a, 11, &ws))
+    return -1;
+  UnitGraph* g = static_cast<UnitGraph*>(h);
+  if (!g->csc.present || !g->csr.present) return ffi_fail("gat_attention backward needs the CSC and the CSR format");
+  for (DGLArray* t : {ft, el, er, out, mz, dout, dft, del_, der})
+    if (null_array(t)) return ffi_fail("gat_attention backward: every tensor is required");
+  if (seg_arrays_ok_fwd({ft, el, er, out, mz, dout, dft, del_, der, ws})) return -1;
+  dgla_dtype dt;
+  if (float_dtype(ft, &dt)) return -1;
+  const dgla_csr csc = csr_of(g, g->csc, true), csr = csr_of(g, g->csr, false);
+  TensorArg t[8];
+  DGLArray* arrs[8] = {ft, el, er, out, dout, dft, del_, der};
+  for (int i = 0; i < 8; ++i) to_tensor(arrs[i], &t[i]);
+  return dgla_gat_attention_backward(&csc, &csr, dt, &t[0].t, &t[1].t, &t[2].t, &t[3].t, data_ptr(mz), &t[4].t,
+                                     static_cast<float>(slope), &t[5].t, &t[6].t, &t[7].t,
+                                     null_array(ws) ? nullptr : data_ptr(ws), null_array(ws) ? 0 : ws->shape[0], tls_stream);
 });
 
 // ---- segment reduce family (src/array/kernel.cc:658-708) -------------------------------------

@@ -150,10 +150,9 @@ def edge_softmax(graph, logits, eids=None, norm_by="dst"):
 
 # ---- GAT attention block as one operator ------------------------------------------------
 def gat_attention_applies(graph, ft, el, er):
-    """Whether the one-pass kernel takes this call: one relation with an in-edge CSC, fp32 / fp16 / bf16 operands on the
-    GPU of shapes (N_src, H, D), (N_src, H, 1), (N_dst, H, 1) with H * D <= 1024."""
-    from . import _ffi
-
+    """Whether the one-pass kernel takes this call: one relation with an in-edge CSC, fp32 operands on the GPU of
+    shapes (N_src, H, D), (N_src, H, 1), (N_dst, H, 1) with D a power of two >= 4 and H * D <= 256 (one 16-byte slab
+    per lane); anything else runs the composed operators (dgl_amd.nn.gat_attention)."""
     gidx = graph._graph
     if gidx.number_of_etypes() != 1 or not gidx.relations[0].allowed("csc"):
         return False
@@ -161,10 +160,10 @@ def gat_attention_applies(graph, ft, el, er):
         return False
     if ft.dim() != 3 or el.dim() != 3 or er.dim() != 3 or el.shape[2] != 1 or er.shape[2] != 1:
         return False
-    if not (ft.dtype == el.dtype == er.dtype and ft.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+    if not (ft.dtype == el.dtype == er.dtype == torch.float32) or type(ft) is not torch.Tensor:
         return False
     h, d = int(ft.shape[1]), int(ft.shape[2])
-    return (ft.is_cuda and el.shape[1] == h and er.shape[1] == h and 0 < h * d <= 1024 and
+    return (ft.is_cuda and el.shape[1] == h and er.shape[1] == h and d >= 4 and d & (d - 1) == 0 and h * d <= 256 and
             ft.shape[0] == el.shape[0] == graph.num_src_nodes() and er.shape[0] == graph.num_dst_nodes())
 
 

@@ -220,6 +220,33 @@ int dgla_edge_softmax_backward(const dgla_csr* csr, dgla_dtype dtype, const dgla
                                const dgla_tensor* sds, const dgla_tensor* back, void* workspace,
                                size_t workspace_bytes, uint32_t flags, void* hip_stream);
 
+/*
+ * GAT attention block as ONE operator (csrc/gat_attention.hip):
+ *     out[v, h, :] = sum_{u -> v} softmax_v( leaky_relu(el[u, h] + er[v, h]) ) * ft[u, h, :]
+ * i.e. the sequence u_add_v -> leaky_relu -> edge_softmax -> u_mul_e_sum of the reference's GATConv
+ * (python/dgl/nn/pytorch/conv/gatconv.py:330-347; the softmax alone is five launches on the reference's GPU path,
+ * python/dgl/backend/pytorch/sparse.py:709-713, with a fused version left as a TODO at src/array/kernel.cc:313,331)
+ * in one pass over the in-edges: no (E, H) tensor is written or read, so an edge-id map costs nothing.
+ *   csc        in-edge CSR (rows = destination nodes); its `data` (edge-id map) is not read
+ *   ft         (N_src, H, D) fp32;  el (N_src, H, 1);  er (N_dst, H, 1);  out (N_dst, H, D)
+ *              D a power of two >= 4 and H * D <= 256, otherwise -1 (callers compose the four operators instead)
+ *   mz         float [N_dst, H, 2]: the row's softmax maximum and normaliser, written by the forward and read by
+ *              the backward, which recomputes the attention weights from them
+ *   workspace  dgla_gat_attention_workspace_bytes(csc, H, D) bytes of device scratch (required when nnz > 0)
+ * Backward: `csr` is the out-edge CSR (rows = source nodes) of the same graph; d_ft / d_el / d_er get the gradients
+ * of ft / el / er for the upstream gradient `dout` (every row is written, rows without edges with zeros).
+ * Rows without in-edges: out = 0.  Deterministic: no atomics, partial rows are merged in a fixed order.
+ */
+size_t dgla_gat_attention_workspace_bytes(const dgla_csr* csc, int64_t heads, int64_t dim);
+int dgla_gat_attention_forward(const dgla_csr* csc, dgla_dtype dtype, const dgla_tensor* ft, const dgla_tensor* el,
+                               const dgla_tensor* er, float negative_slope, const dgla_tensor* out, void* mz,
+                               void* workspace, size_t workspace_bytes, void* hip_stream);
+int dgla_gat_attention_backward(const dgla_csr* csc, const dgla_csr* csr, dgla_dtype dtype, const dgla_tensor* ft,
+                                const dgla_tensor* el, const dgla_tensor* er, const dgla_tensor* out, const void* mz,
+                                const dgla_tensor* dout, float negative_slope, const dgla_tensor* d_ft,
+                                const dgla_tensor* d_el, const dgla_tensor* d_er, void* workspace,
+                                size_t workspace_bytes, void* hip_stream);
+
 /* ---- segment reduce / scatter add ----------------------------------------
  * Replace SegmentReduce / ScatterAdd / BackwardSegmentCmp<kDGLCUDA,…>
  * (src/array/kernel_decl.h, kernels src/array/cuda/segment_reduce.cuh:30-113; registered as
