@@ -25,10 +25,8 @@
 
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-
 #include "common.h"
+#include "sort.hip.h"
 
 namespace dgla {
 namespace {
@@ -442,19 +440,13 @@ unsigned grid1(int64_t n) { return static_cast<unsigned>((n + 255) / 256 < 1 ? 1
 
 template <typename Idx>
 size_t scan_temp_bytes(int64_t n) {
-  size_t b = 0;
-  (void)rocprim::exclusive_scan(nullptr, b, static_cast<const Idx*>(nullptr), static_cast<Idx*>(nullptr),
-                                Idx(0), static_cast<size_t>(n), rocprim::plus<Idx>(), nullptr);
-  return b;
+  return msd::scan_temp_bytes(n, sizeof(Idx));
 }
 
+// scratch of the keys-only sort (sort.hip.h); sized for the widest keys of the id type, so the same buffer serves
+// callers with and without a node count
 template <typename Idx>
-size_t sort_keys_temp_bytes(int64_t n) {
-  size_t b = 0;
-  (void)rocprim::radix_sort_keys(nullptr, b, static_cast<const Idx*>(nullptr), static_cast<Idx*>(nullptr),
-                                 static_cast<size_t>(n), 0, sizeof(Idx) * 8, nullptr);
-  return b;
-}
+size_t sort_keys_temp_bytes(int64_t n) { return msd::make_keys_plan(n, 0, sizeof(Idx)).bytes; }
 
 template <typename Idx>
 int run_sample(const dgla_csr* csc, const void* seeds, int64_t num_seeds, int fanout, int replace,
@@ -467,9 +459,7 @@ int run_sample(const dgla_csr* csc, const void* seeds, int64_t num_seeds, int fa
   hipLaunchKernelGGL(sample_count_kernel<Idx>, dim3(grid1(num_seeds + 1)), dim3(256), 0, s,
                      static_cast<const Idx*>(csc->indptr), static_cast<const Idx*>(seeds), num_seeds,
                      fanout, replace, counts, num_valid);
-  DGLA_CHECK_HIP(rocprim::exclusive_scan(temp, temp_bytes, static_cast<const Idx*>(counts),
-                                         static_cast<Idx*>(out_indptr), Idx(0),
-                                         static_cast<size_t>(num_seeds + 1), rocprim::plus<Idx>(), s));
+  if (msd::exclusive_scan<Idx, Idx>(counts, static_cast<Idx*>(out_indptr), num_seeds + 1, temp, s)) return -1;
   if (out_src) {
 #define DGLA_PICK(FM)                                                                                      \
   hipLaunchKernelGGL((sample_pick_kernel<Idx, FM>), dim3(grid1(num_seeds)), dim3(256), 0, s,                \
@@ -508,9 +498,7 @@ int run_sample_weighted(const dgla_csr* csc, const void* prob, const void* seeds
                      static_cast<const Idx*>(csc->indptr), static_cast<const Idx*>(csc->data),
                      static_cast<const F*>(prob), static_cast<const Idx*>(seeds), num_seeds, fanout, replace,
                      counts, num_valid);
-  DGLA_CHECK_HIP(rocprim::exclusive_scan(temp, temp_bytes, static_cast<const Idx*>(counts),
-                                         static_cast<Idx*>(out_indptr), Idx(0),
-                                         static_cast<size_t>(num_seeds + 1), rocprim::plus<Idx>(), s));
+  if (msd::exclusive_scan<Idx, Idx>(counts, static_cast<Idx*>(out_indptr), num_seeds + 1, temp, s)) return -1;
   if (out_src && num_seeds > 0)
     hipLaunchKernelGGL((weighted_pick_kernel<Idx, F>), dim3(static_cast<unsigned>((num_seeds + 3) / 4)),
                        dim3(256), 0, s, static_cast<const Idx*>(csc->indptr),
@@ -541,19 +529,13 @@ int run_to_block(const void* seeds, int64_t num_seeds, const void* src, int64_t 
   hipLaunchKernelGGL(scatter_seed_ids_kernel<Idx>, dim3(grid1(num_seeds)), dim3(256), 0, s,
                      static_cast<const Idx*>(seeds), num_seeds, node_map, static_cast<Idx*>(src_nodes), num_valid);
   if (nnz > 0) {
-    size_t tb = sort_keys_temp_bytes<Idx>(nnz);
-    // (ids are below the node count: sort only the bits they use — 3 passes instead of 8 for int64)
-    DGLA_CHECK_HIP(rocprim::radix_sort_keys(temp, tb, static_cast<const Idx*>(src), sorted,
-                                            static_cast<size_t>(nnz), 0,
-                                            key_bits > 0 ? key_bits : static_cast<int>(sizeof(Idx) * 8), s));
+    // (with a node count the sort looks at the bits the ids use: 3 passes at ogbn-products size; without one, at all
+    // 31 / 63 value bits of the id type: 4 / 7 passes — no read-back either way)
+    if (msd::sort_keys<Idx>(static_cast<const Idx*>(src), sorted, nnz, key_bits, static_cast<char*>(temp), s)) return -1;
   }
   hipLaunchKernelGGL(flag_new_nodes_kernel<Idx>, dim3(grid1(nnz + 1)), dim3(256), 0, s, sorted, nnz, node_map,
                      flag);
-  size_t tb2 = 0;
-  (void)rocprim::exclusive_scan(nullptr, tb2, static_cast<const int32_t*>(flag), rank, int32_t(0),
-                                static_cast<size_t>(nnz + 1), rocprim::plus<int32_t>(), s);
-  DGLA_CHECK_HIP(rocprim::exclusive_scan(temp, tb2, static_cast<const int32_t*>(flag), rank, int32_t(0),
-                                         static_cast<size_t>(nnz + 1), rocprim::plus<int32_t>(), s));
+  if (msd::exclusive_scan<int32_t, int32_t>(flag, rank, nnz + 1, temp, s)) return -1;
   hipLaunchKernelGGL(assign_new_ids_kernel<Idx>, dim3(grid1(nnz + 1)), dim3(256), 0, s, sorted, nnz, flag, rank,
                      num_seeds, node_map, static_cast<Idx*>(src_nodes), num_src_out);
   if (nnz > 0)
@@ -567,10 +549,7 @@ int run_to_block(const void* seeds, int64_t num_seeds, const void* src, int64_t 
 
 template <typename Idx>
 size_t to_block_ws(int64_t nnz) {
-  size_t scan_b = 0;
-  (void)rocprim::exclusive_scan(nullptr, scan_b, static_cast<const int32_t*>(nullptr),
-                                static_cast<int32_t*>(nullptr), int32_t(0), static_cast<size_t>(nnz + 1),
-                                rocprim::plus<int32_t>(), nullptr);
+  const size_t scan_b = msd::scan_temp_bytes(nnz + 1, sizeof(int32_t));
   const size_t sort_b = nnz > 0 ? sort_keys_temp_bytes<Idx>(nnz) : 0;
   return align256(sizeof(Idx) * (nnz + 1)) + 2 * align256(sizeof(int32_t) * (nnz + 1)) +
          align256(scan_b > sort_b ? scan_b : sort_b);
