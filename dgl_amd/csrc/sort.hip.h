@@ -32,8 +32,12 @@ constexpr int kTile = 64 * kTileRows;       // 1 024 elements staged in LDS at a
 constexpr int kItemLen = 8192;              // elements per item (one wavefront) of a large input: a multiple of kTile
 constexpr int64_t kSmallInput = 1 << 19;    // inputs up to this size use one-tile items (more wavefronts, fewer tiles each)
 inline int item_len_for(int64_t n) { return n <= kSmallInput ? kTile : kItemLen; }
-constexpr int kMaxDigit = 9;
-constexpr int kMaxNB = 1 << kMaxDigit;      // bins per level
+#ifndef DGLA_SORT_MAX_DIGIT
+#define DGLA_SORT_MAX_DIGIT 9
+#endif
+constexpr int kMaxDigit = DGLA_SORT_MAX_DIGIT;   // bits per level of the COO -> CSR sort
+constexpr int kMaxNB = 1 << kMaxDigit;           // bins per level
+constexpr int kKeysDigit = 9;                    // bits per pass of the keys-only sort (small inputs: fused one-block scan)
 constexpr int kMaxLevels = 8;
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -406,8 +410,8 @@ __global__ __launch_bounds__(64) void msd_scan0_top_kernel(const LevelArgs<Idx> 
 // level 0 with few items (small inputs: the block builder's id sorts): both steps in ONE launch, one thread per bin
 constexpr int kScan0FusedItems = 256;
 template <typename Idx>
-__global__ __launch_bounds__(kMaxNB) void msd_scan0_fused_kernel(const LevelArgs<Idx> a, int last_level) {
-  __shared__ int64_t wsum[kMaxNB / 64];
+__global__ __launch_bounds__(512) void msd_scan0_fused_kernel(const LevelArgs<Idx> a, int last_level) {   // nb <= 512
+  __shared__ int64_t wsum[8];
   const int d = threadIdx.x, nb = 1 << a.b;
   int64_t run = 0;
   if (d < nb) {
@@ -701,8 +705,8 @@ int run_levels(const Plan& p, LevelArgs<Idx> a0, char* ws, hipStream_t s) {
     if (l == 0) {
       a.n_items_host = (p.nnz + a.item_len - 1) / a.item_len;
       hipLaunchKernelGGL((msd_hist_kernel<WIDE, kInCoo, Idx>), dim3(grid), dim3(64), 0, s, a);
-      if (a.n_items_host <= kScan0FusedItems) {
-        hipLaunchKernelGGL(msd_scan0_fused_kernel<Idx>, dim3(1), dim3(kMaxNB), 0, s, a, last ? 1 : 0);
+      if (a.n_items_host <= kScan0FusedItems && a.b <= 9) {
+        hipLaunchKernelGGL(msd_scan0_fused_kernel<Idx>, dim3(1), dim3(512), 0, s, a, last ? 1 : 0);
       } else {
         hipLaunchKernelGGL(msd_scan0_bins_kernel<Idx>, dim3(1u << a.b), dim3(64), 0, s, a);
         hipLaunchKernelGGL(msd_scan0_top_kernel<Idx>, dim3(1), dim3(64), 0, s, a, last ? 1 : 0);
@@ -756,7 +760,7 @@ inline KeysPlan make_keys_plan(int64_t n, int key_bits, size_t key_size) {
   KeysPlan p;
   p.n = n;
   if (key_bits <= 0 || key_bits > static_cast<int>(key_size * 8 - 1)) key_bits = static_cast<int>(key_size * 8 - 1);
-  p.passes = (key_bits + kMaxDigit - 1) / kMaxDigit;
+  p.passes = (key_bits + kKeysDigit - 1) / kKeysDigit;
   const int base = key_bits / p.passes, extra = key_bits % p.passes;
   for (int l = 0; l < p.passes; ++l) p.b[l] = base + (l < extra ? 1 : 0);
   p.n_items = (n + item_len_for(n) - 1) / item_len_for(n);
@@ -836,7 +840,7 @@ int sort_keys(const Idx* keys, Idx* out, int64_t n, int key_bits, char* ws, hipS
     const unsigned grid = static_cast<unsigned>(p.n_items);
     hipLaunchKernelGGL((msd_hist_kernel<false, kInKeys, Idx>), dim3(grid), dim3(64), 0, s, a);
     if (a.n_items_host <= kScan0FusedItems) {
-      hipLaunchKernelGGL(msd_scan0_fused_kernel<Idx>, dim3(1), dim3(kMaxNB), 0, s, a, 0);
+      hipLaunchKernelGGL(msd_scan0_fused_kernel<Idx>, dim3(1), dim3(512), 0, s, a, 0);
     } else {
       hipLaunchKernelGGL(msd_scan0_bins_kernel<Idx>, dim3(1u << a.b), dim3(64), 0, s, a);
       hipLaunchKernelGGL(msd_scan0_top_kernel<Idx>, dim3(1), dim3(64), 0, s, a, 0);
