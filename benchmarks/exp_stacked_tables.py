@@ -3,7 +3,7 @@ launch (10.8 ms = 0.66 of 8 TB/s in round 4) lose against the request model's 8.
 
 Timing A/B (one run, HIP events):
   shared    8 relations gather from ONE 5-GB table (what bench_ops measures; R-GCN's layer input is one node type)
-  distinct  8 relations, 8 tables (41 GB): the address-translation hypothesis of DESIGN §3.2 predicts a slowdown
+  distinct  8 relations, 8 tables (41 GB): the address-translation hypothesis of docs/DESIGN_detail_r1_r5.md §3.2 predicts a slowdown
   single    the SAME 100 M edges as one relation through the plain merge-path kernel (no relation byte, no
             pointer table in LDS): what stacking itself costs; plus the XCD unit order toggled, and fp32 rows of the
             same BYTE length (F = 128): is it the bf16 arithmetic or the memory system?

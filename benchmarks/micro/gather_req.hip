@@ -1,6 +1,6 @@
 // Micro-benchmark (gfx950): what does one random 16-byte gather cost at the L2 <-> fabric interface,
 // by cache policy of the load and by where the array lives (39 MB = Infinity Cache resident, 4 GB =
-// HBM)?  Question behind it: the merge kernel's fourth request per edge fetches a
+// HBM)?  Question behind it (docs/DESIGN_detail_r1_r5.md §3.1): the merge kernel's fourth request per edge fetches a
 // whole 128-byte line for a 16-byte row tail; is there a load flavour whose miss is a narrower
 // request?  Build: hipcc --offload-arch=gfx950 -O3 gather_req.hip -o gather_req.bin
 #include <hip/hip_runtime.h>

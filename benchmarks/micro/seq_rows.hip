@@ -1,5 +1,5 @@
 // Micro-benchmark (gfx950): why does a kernel that reads 400-byte rows IN ORDER (segment reduce,
-// DESIGN.md §3.6) move fewer lines per second than the same instruction stream reading them at
+// docs/DESIGN_detail_r1_r5.md §3.6) move fewer lines per second than the same instruction stream reading them at
 // RANDOM (the g-SpMM gather, 55 G lines/s)?  Every pattern below issues the merge kernel's load
 // shape — 50 of 64 lanes, two 400-byte rows per instruction, U = 4 instructions in flight — and
 // differs only in WHICH rows a wave has in flight at a time:

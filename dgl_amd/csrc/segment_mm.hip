@@ -846,7 +846,7 @@ __global__ __launch_bounds__(64 * kWsWaves, 2) void segment_mm_ws_kernel(const W
   // costs no drain of the A ring (checking at once did: 9.3-9.9 ms instead of 7.6-8.0); a wave more than one
   // tile ahead of the slowest waits (bounded).  What bounds this kernel is not the A stream: with A always hitting
   // the cache and no stores it still runs 6.1 ms (MFMA pipe time of its 240 M instructions: 3.1 ms at 2.4 GHz) —
-  // DESIGN.md §3.7 has the breakdown.
+  // docs/DESIGN_detail_r1_r5.md §3.7 has the breakdown.
   const int ncg = wp.ncg;
   const int cg = qq % ncg;
   const bool pace = PIPE && wp.rot >= 0 && ncg > 1 && ncg <= 4;   // (rot < 0: pacing off, the words are still read)
@@ -2224,7 +2224,7 @@ int launch_segment_mm_ws(const MmParams& p, char* ws, const MmScratch& sc, hipSt
   }
   cus = std::min(cus, 512);
   const dim3 block(64 * kWsWaves);
-  // experiment switch (round 4 A/B): bit 0 = fp32 without the fragment double buffer, bit 2 = siblings unpaced, bit 3 = paced but every sibling walks the lines in order, bit 4 = static row chunks (no queue)
+  // experiment switch (round 4 A/B; docs/DESIGN_detail_r1_r5.md §3.7): bit 0 = fp32 without the fragment double buffer, bit 2 = siblings unpaced, bit 3 = paced but every sibling walks the lines in order, bit 4 = static row chunks (no queue)
   const char* ev = getenv("DGLA_MM_WS_VARIANT");
   const int variant = ev && *ev ? atoi(ev) : 0;
   // chunk queue (one column group only; variant bit 4 = static chunks): one ticket word, zeroed per launch

@@ -188,7 +188,7 @@ __device__ __forceinline__ VecT<DT, VEC> load_global(const DT* src) {
 // lines = 512 B of fabric traffic per edge).  Two side copies remove the extra line: the EDGE layout
 // (16-byte lanes, rows of two or more whole lines) and the STRADDLE layout (8-byte lanes).  Round 2's
 // whole-row copy ("classic" layout) and round 3's column-sliced tail pass were measured and removed in
-// round 4 (DESIGN.md §3.1 keeps the numbers: classic 0.33 ms of copy against the edge layout's 0.10;
+// round 4 (docs/DESIGN_detail_r1_r5.md §3.1 keeps the numbers: classic 0.33 ms of copy against the edge layout's 0.10;
 // tail pass -5 % .. +3.5 %).
 typedef uint32_t piece16_t __attribute__((ext_vector_type(4)));
 

@@ -5,7 +5,7 @@ The reference's GAT path is ``apply_edges(u_add_v)`` -> ``leaky_relu`` -> ``edge
 softmax alone, python/dgl/backend/pytorch/sparse.py:709-713).  Every one of those passes indexes an
 ``(E, H)`` tensor through the edge-id map of the in-edge CSR: with DGL's usual edge ids (the order
 of the COO the graph was built from) every edge's 32-byte score row is its own access to a 128-byte
-line, in both directions (0.20 of HBM instead of 0.36-0.66 map-free).
+line, in both directions (docs/DESIGN_detail_r1_r5.md §3.4: 0.20 of HBM instead of 0.36-0.66 map-free).
 
 Nothing forces the tensor that travels BETWEEN those operators to be in edge-id order: only what
 the user reads has to be.  So g-SDDMM / edge softmax hand out a :class:`PosOrdered` tensor — a

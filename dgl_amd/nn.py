@@ -1,6 +1,6 @@
 """``dgl_amd.nn`` — only what is NEW above the operator API.  The layers themselves (GraphConv, SAGEConv, GATConv,
 RelGraphConv, TypedLinear, HeteroGraphConv ...) are the reference's own ``python/dgl/nn/pytorch/*.py``: they stay
-untouched above ``update_all`` / ``dgl.ops`` and run on this package through the ``dgl`` -> ``dgl_amd``
+untouched above ``update_all`` / ``dgl.ops`` (docs/DESIGN_detail_r1_r5.md §1) and run on this package through the ``dgl`` -> ``dgl_amd``
 alias (``tools/ref_suite/run.py --suite nn`` imports them unmodified and runs the reference's layer tests).
 
 ``gat_attention`` is the one addition: GATConv's attention block (python/dgl/nn/pytorch/conv/gatconv.py:330-347 —
