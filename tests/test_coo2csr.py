@@ -82,6 +82,46 @@ def test_coo_to_csr_bit_exact(dev, idtype, n, m, e, with_eids):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["sorted_by_row", "one_row_holds_everything", "three_levels_large_items",
+                                   "two_buckets_only", "reverse_sorted", "rows_not_a_power_of_two_with_empty_tail"])
+def test_coo_to_csr_shapes_the_bucket_sort_is_sensitive_to(dev, shape):
+    """csrc/sort.hip.h: every lane of a wave in ONE bin (sorted input, a mega row), buckets that are empty or hold
+    everything, three digit levels with 8 192-element items (> 2^19 edges), row counts just above a power of two."""
+    from dgl_amd import _capi
+
+    g = torch.Generator(device=dev).manual_seed(5)
+    idt = torch.int32
+    if shape == "sorted_by_row":
+        n, e = 300_000, 1_200_000
+        row = torch.sort(torch.randint(0, n, (e,), device=dev, generator=g))[0]
+    elif shape == "reverse_sorted":
+        n, e = 300_000, 1_200_000
+        row = torch.sort(torch.randint(0, n, (e,), device=dev, generator=g), descending=True)[0]
+    elif shape == "one_row_holds_everything":
+        n, e = 70_000, 900_000
+        row = torch.full((e,), 12_345, device=dev, dtype=torch.int64)
+        row[::1000] = torch.randint(0, n, (e // 1000,), device=dev, generator=g)
+    elif shape == "three_levels_large_items":
+        n, e = 2_100_000, 3_000_000                    # 22 bits of key: levels of 8 / 7 / 7 bits, items of 8 192
+        row = torch.randint(0, n, (e,), device=dev, generator=g)
+    elif shape == "two_buckets_only":
+        n, e = 1 << 20, 700_000
+        row = torch.where(torch.rand(e, device=dev, generator=g) < 0.5, 3, n - 2) + torch.randint(0, 2, (e,), device=dev, generator=g)
+    else:
+        n, e = (1 << 16) + 3, 800_000
+        row = torch.randint(0, (1 << 16) - 100, (e,), device=dev, generator=g)
+    row = row.to(idt).contiguous()
+    col = torch.randint(0, n, (e,), device=dev, generator=g).to(idt)
+    order = torch.argsort(row, stable=True)
+    counts = torch.bincount(row.long(), minlength=n)
+    want_ip = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    want_ip[1:] = torch.cumsum(counts, 0)
+    for num_minor in (n, 0):
+        ip, ix, ei = _capi.coo_to_csr(row, col, None, n, num_minor)
+        assert torch.equal(ip.long(), want_ip) and torch.equal(ix, col[order]) and torch.equal(ei.long(), order)
+
+
+@pytest.mark.gpu
 def test_graph_formats_are_built_natively_and_round_trip(dev):
     """The DGLGraph shim builds CSR / CSC through the native path; COO -> CSC -> COO keeps
     every edge, and the conversion runs on the current stream."""

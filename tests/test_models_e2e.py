@@ -225,3 +225,26 @@ def test_rgcn_message_passing_matches_the_formula(dev, presorted):
     up = torch.randn_like(out)
     for a, b in zip(torch.autograd.grad((out * up).sum(), [h, w]), torch.autograd.grad((want * up).sum(), [h, w])):
         torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4)
+
+
+def test_gat_attention_on_a_block_fused_equals_composed(dev):
+    """A message-flow block (more source than destination nodes): the fused operator and the composed operators give the
+    same block output and the same gradients (ft / el live on the sources, er on the destinations)."""
+    import dgl_amd as dgl
+
+    n_src, n_dst, e, h, d = 5000, 1200, 40_000, 4, 16
+    g0 = torch.Generator().manual_seed(8)
+    src, dst = torch.randint(0, n_src, (e,), generator=g0).to(dev), torch.randint(5, n_dst, (e,), generator=g0).to(dev)
+    blk = dgl.create_block((src, dst), num_src_nodes=n_src, num_dst_nodes=n_dst, device=dev)
+    torch.manual_seed(2)
+    ps = [torch.randn(n_src, h, d, device=dev, requires_grad=True), torch.randn(n_src, h, 1, device=dev, requires_grad=True),
+          torch.randn(n_dst, h, 1, device=dev, requires_grad=True)]
+    up = torch.randn(n_dst, h, d, device=dev)
+    assert dgl.ops.gat_attention_applies(blk, *ps)
+    outs = []
+    for kw in (dict(fused=False), dict(fused=True)):
+        o = dgl.nn.gat_attention(blk, ps[0], ps[1], ps[2], 0.2, **kw)
+        outs.append([o.detach()] + list(torch.autograd.grad((o * up).sum(), ps)))
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5)
+    assert bool((outs[1][0][:5] == 0).all())            # destinations without in-edges
