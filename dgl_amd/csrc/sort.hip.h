@@ -53,14 +53,35 @@ inline int bits_for(int64_t n) {  // bits needed for values in [0, n)
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kScanBlock = 256, kScanPer = 16, kScanChunk = kScanBlock * kScanPer;
 
+// Inclusive sum over the 64 lanes.  32-bit values: six DPP-modified adds — row_shr:1/2/4/8 inside a row of 16 lanes
+// (0x111 .. 0x118; lanes without a source take the 0 passed as `old`), row_bcast:15 into rows 1 and 3 (0x142, row mask
+// 0xa), row_bcast:31 into rows 2 and 3 (0x143, 0xc) — instead of six ds_bpermute round trips (csrc/narrow_reduce.hip uses
+// the same moves); wider values go through shuffles.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_from_zero(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_inclusive_scan32(int v) {
+  v += dpp_from_zero<0x111, 0xf>(v);
+  v += dpp_from_zero<0x112, 0xf>(v);
+  v += dpp_from_zero<0x114, 0xf>(v);
+  v += dpp_from_zero<0x118, 0xf>(v);
+  v += dpp_from_zero<0x142, 0xa>(v);
+  v += dpp_from_zero<0x143, 0xc>(v);
+  return v;
+}
 template <typename T>
 __device__ __forceinline__ T wave_inclusive_scan(T v) {
+  if constexpr (sizeof(T) == 4) {
+    return static_cast<T>(wave_inclusive_scan32(static_cast<int>(v)));
+  } else {
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const T o = __shfl_up(v, d, 64);
-    if ((threadIdx.x & 63) >= d) v += o;
+    for (int d = 1; d < 64; d <<= 1) {
+      const T o = __shfl_up(v, d, 64);
+      if ((threadIdx.x & 63) >= d) v += o;
+    }
+    return v;
   }
-  return v;
 }
 
 template <typename TI, typename TO>
@@ -133,23 +154,23 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const TI* __rest
 constexpr int kScanSmall = 32768;
 template <typename TI, typename TO>
 __global__ __launch_bounds__(1024) void scan_small_kernel(const TI* __restrict__ in, int n, TO* __restrict__ out) {
+  // round k: thread t owns element k * 1024 + t (coalesced); a block scan per round, the running total carried in LDS
   __shared__ TO wsum[16];
-  const int per = (n + 1023) / 1024;
-  const int b0 = threadIdx.x * per;
-  TO s = 0;
-  for (int k = 0; k < per; ++k)
-    if (b0 + k < n) s += static_cast<TO>(in[b0 + k]);
-  const TO incl = wave_inclusive_scan(s);
-  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+  __shared__ TO carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  TO off = incl - s;
-  for (int w = 0; w < (threadIdx.x >> 6); ++w) off += wsum[w];
-  for (int k = 0; k < per; ++k) {
-    if (b0 + k < n) {
-      const TO v = static_cast<TO>(in[b0 + k]);   // (in == out allowed: read before the write of the same element)
-      out[b0 + k] = off;
-      off += v;
-    }
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const TO v = i < n ? static_cast<TO>(in[i]) : TO(0);
+    const TO incl = wave_inclusive_scan(v);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    TO off = carry_s;
+    for (int w = 0; w < (threadIdx.x >> 6); ++w) off += wsum[w];
+    if (i < n) out[i] = off + incl - v;   // (in == out allowed: element i is read before it is written, by the same thread)
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = off + incl;
+    __syncthreads();
   }
 }
 
@@ -411,17 +432,53 @@ __global__ __launch_bounds__(64) void msd_scan0_top_kernel(const LevelArgs<Idx> 
 constexpr int kScan0FusedItems = 256;
 template <typename Idx>
 __global__ __launch_bounds__(512) void msd_scan0_fused_kernel(const LevelArgs<Idx> a, int last_level) {   // nb <= 512
+  // step 1: wave w takes bins w, w + 8, ...: exclusive prefix of the bin's per-item counts in 64-item chunks (coalesced
+  // loads, one wave scan per chunk) -> the counts become prefixes in place, the bin totals go to LDS
+  __shared__ int64_t total[512];
   __shared__ int64_t wsum[8];
-  const int d = threadIdx.x, nb = 1 << a.b;
-  int64_t run = 0;
-  if (d < nb) {
-    uint64_t* c = a.counts + static_cast<int64_t>(d) * a.n_items_host;
-    for (int64_t i = 0; i < a.n_items_host; ++i) {
-      const uint64_t v = c[i];
-      c[i] = static_cast<uint64_t>(run);
-      run += static_cast<int64_t>(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nb = 1 << a.b;
+  // (the (bin, chunk) steps of a wave form one sequence; the loads run kAhead steps ahead of the scans: 32 bins of
+  // dependent global round trips were 20 us of a 90 k-key sort)
+  {
+    constexpr int kAhead = 4;
+    const int nch = static_cast<int>((a.n_items_host + 63) / 64);
+    const int nbw = (nb - wave + 7) / 8;                 // bins of this wave
+    const int steps = nbw * nch;
+    auto load = [&](int st) -> uint32_t {
+      if (st >= steps) return 0u;
+      const int d = wave + 8 * (st / nch);
+      const int64_t i = static_cast<int64_t>(st % nch) * 64 + lane;
+      return i < a.n_items_host ? static_cast<uint32_t>(a.counts[static_cast<int64_t>(d) * a.n_items_host + i]) : 0u;
+    };
+    uint32_t pre[kAhead];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) pre[k] = load(k);
+    int64_t run = 0;
+    for (int st = 0; st < steps; st += kAhead) {
+      uint32_t cur[kAhead];
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) cur[k] = pre[k];
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) pre[k] = load(st + kAhead + k);
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) {
+        const int s1 = st + k;
+        if (s1 >= steps) break;
+        const int d = wave + 8 * (s1 / nch), ch = s1 % nch;
+        if (ch == 0) run = 0;
+        const int64_t i = static_cast<int64_t>(ch) * 64 + lane;
+        const uint32_t v = cur[k];
+        const uint32_t incl = wave_inclusive_scan(v);
+        if (i < a.n_items_host) a.counts[static_cast<int64_t>(d) * a.n_items_host + i] = static_cast<uint64_t>(run) + incl - v;
+        run += __shfl(incl, 63, 64);
+        if (ch == nch - 1 && lane == 0) total[d] = run;
+      }
     }
   }
+  __syncthreads();
+  // step 2: exclusive scan over the bins
+  const int d = threadIdx.x;
+  const int64_t run = d < nb ? total[d] : 0;
   const int64_t incl = wave_inclusive_scan(run);
   if ((d & 63) == 63) wsum[d >> 6] = incl;
   __syncthreads();
@@ -777,44 +834,99 @@ inline KeysPlan make_keys_plan(int64_t n, int key_bits, size_t key_size) {
   return p;
 }
 
-// n <= 64 KiB of keys: ONE workgroup sorts them in LDS with a bitonic network (keys only: stability is moot) — the
-// mini-batch block builder sorts a few thousand ids per layer, where launch count is the whole cost
-constexpr int kSmallSortBytes = 64 * 1024;
+// Up to 8 192 keys of at most 32 bits: ONE workgroup, the whole LSD radix sort in LDS (the mini-batch block builder
+// sorts a few thousand ids per layer, where launch count is the whole cost).  16 wavefronts; wave w owns the 512 keys
+// [512 w, 512 w + 512) as 8 rows of 64, in order (stable).  A pass of 8 bits: per-wave histogram -> exclusive scan in
+// (bin, wave) order -> every wave ranks its rows one by one (lanes with my digit from 8 ballots, the wave's cursor of the
+// bin from LDS, the lowest lane of the bin advances it) and stores the key into the other LDS buffer.
+constexpr int kSmallKeys = 8192;
+constexpr size_t kSmallRadixLds = 2 * kSmallKeys * sizeof(uint32_t) + 16 * 256 * sizeof(uint32_t);
 template <typename Idx>
-__global__ __launch_bounds__(1024) void small_sort_kernel(const Idx* __restrict__ in, Idx* __restrict__ out, int n, int np2) {
+__global__ __launch_bounds__(1024) void small_radix_kernel(const Idx* __restrict__ in, Idx* __restrict__ out, int n, int key_bits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  Idx* buf = reinterpret_cast<Idx*>(lds_raw);
-  const Idx big = static_cast<Idx>((~static_cast<uint64_t>(0)) >> (65 - 8 * sizeof(Idx)));   // largest value of the id type
-  for (int i = threadIdx.x; i < np2; i += 1024) buf[i] = i < n ? in[i] : big;
+  uint32_t* buf0 = reinterpret_cast<uint32_t*>(lds_raw);
+  uint32_t* buf1 = buf0 + kSmallKeys;
+  uint32_t* cur = buf1 + kSmallKeys;            // [16][256] per-wave counts, then cursors
+  __shared__ uint32_t wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int i = tid; i < kSmallKeys; i += 1024) buf0[i] = i < n ? static_cast<uint32_t>(in[i]) : 0xffffffffu;
   __syncthreads();
-  for (int k = 2; k <= np2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < (np2 >> 1); t += 1024) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // the lower index of pair t at distance j
-        const int ixj = i | j;
-        const bool asc = (i & k) == 0;
-        const Idx x = buf[i], y = buf[ixj];
-        if ((x > y) == asc) {
-          buf[i] = y;
-          buf[ixj] = x;
-        }
+  uint32_t* src = buf0;
+  uint32_t* dst = buf1;
+  for (int shift = 0; shift < key_bits; shift += 8) {
+    for (int i = tid; i < 16 * 256; i += 1024) cur[i] = 0;
+    __syncthreads();
+    uint32_t key[8], dg[8];
+    unsigned long long same[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      key[r] = src[wave * 512 + r * 64 + lane];
+      dg[r] = (key[r] >> shift) & 255u;
+      unsigned long long m = ~0ull;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool bit = (dg[r] >> k) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
       }
-      __syncthreads();
+      same[r] = m;
+      if ((m & lt) == 0ull) atomicAdd(&cur[wave * 256 + dg[r]], static_cast<uint32_t>(__popcll(m)));   // (wave-private row)
     }
+    __syncthreads();
+    {  // exclusive scan of the 4 096 counts in (bin, wave) order: thread t owns bin t / 4, waves 4 (t % 4) .. + 3
+      const int d = tid >> 2, w0 = (tid & 3) * 4;
+      uint32_t v[4], s4 = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = cur[(w0 + k) * 256 + d];
+        s4 += v[k];
+      }
+      const uint32_t incl = wave_inclusive_scan(s4);
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      uint32_t off = incl - s4;
+      for (int w = 0; w < wave; ++w) off += wsum[w];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        cur[(w0 + k) * 256 + d] = off;
+        off += v[k];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      uint32_t* c = &cur[wave * 256 + dg[r]];
+      const uint32_t base = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      dst[base + __popcll(same[r] & lt)] = key[r];
+      if ((same[r] & lt) == 0ull)
+        __hip_atomic_store(c, base + static_cast<uint32_t>(__popcll(same[r])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    }
+    __syncthreads();
+    uint32_t* t = src;
+    src = dst;
+    dst = t;
   }
-  for (int i = threadIdx.x; i < n; i += 1024) out[i] = buf[i];
+  for (int i = tid; i < n; i += 1024) out[i] = static_cast<Idx>(src[i]);
 }
 
 // sorted copy of `keys` into `out` (out != keys); ws: make_keys_plan(n, key_bits, sizeof(Idx)).bytes
 template <typename Idx>
 int sort_keys(const Idx* keys, Idx* out, int64_t n, int key_bits, char* ws, hipStream_t s) {
   if (n <= 0) return 0;
-  if (static_cast<size_t>(n) * sizeof(Idx) <= static_cast<size_t>(kSmallSortBytes)) {
-    int np2 = 2;
-    while (np2 < n) np2 <<= 1;
-    hipLaunchKernelGGL(small_sort_kernel<Idx>, dim3(1), dim3(1024), sizeof(Idx) * np2, s, keys, out, static_cast<int>(n), np2);
-    DGLA_CHECK_HIP(hipGetLastError());
-    return 0;
+  if (key_bits <= 0 || key_bits > static_cast<int>(sizeof(Idx) * 8 - 1)) key_bits = static_cast<int>(sizeof(Idx) * 8 - 1);
+  if (n <= kSmallKeys && key_bits <= 32) {
+    static bool lds_ok = [] {   // more than the default 64 KiB of dynamic LDS: asked for once per process
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(&small_radix_kernel<Idx>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSmallRadixLds)) == hipSuccess;
+    }();
+    if (lds_ok) {
+      hipLaunchKernelGGL(small_radix_kernel<Idx>, dim3(1), dim3(1024), kSmallRadixLds, s, keys, out, static_cast<int>(n), key_bits);
+      DGLA_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
+    (void)hipGetLastError();
   }
   const KeysPlan p = make_keys_plan(n, key_bits, sizeof(Idx));
   Idx* tmp = reinterpret_cast<Idx*>(ws + p.off_tmp);
