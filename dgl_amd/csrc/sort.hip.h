@@ -11,13 +11,14 @@
 //   * a level is three launches over ITEMS (pieces of <= kItemLen elements of one bucket, one wavefront each, so a hub
 //     bucket is spread over many waves):  histogram of the level's digit per item -> exclusive scan (bucket-major,
 //     item-minor: stable) -> scatter;
-//   * the scatter ranks a tile of 2 048 elements exactly and stably with LDS match masks: per 64-element row every lane
+//   * the scatter ranks a tile of 1 024 elements exactly and stably with LDS match masks: per 64-element row every lane
 //     ORs its lane bit into mask[digit] (one ds_or_b64), reads the word back, and rank = popcount(mask & lanes below) —
 //     one LDS round trip per row, no per-bit ballots, no data-dependent loop; the tile is then staged in LDS in bucket
 //     order and written out as runs (consecutive lanes -> consecutive addresses of one bucket);
 //   * the LAST level's bins are the rows themselves: its scan writes indptr, its scatter unpacks (column, position)
 //     into indices / edge ids — no separate compress pass, no sorted-key array is ever written.
-// Traffic at C2 size (3 levels): 4 + 16 (level 1) + 24 + 24 bytes per edge.
+// Traffic at C2 size (3 levels): 4 + 16 (level 1) + 24 + 24 bytes per edge; measured 1.64 ms at 61.9 M edges (int32), see
+// profiles/r6/coo2csr_own_sort.jsonl for the kernel table and the variants that were measured and dropped.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
