@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64) void msd_scan0_top_kernel(const LevelArgs<Idx> 
 }
 
 // level 0 with few items (small inputs: the block builder's id sorts): both steps in ONE launch, one thread per bin
-constexpr int kScan0FusedItems = 256;
+constexpr int kScan0FusedItems = 16;   // (more items: one wave per bin in parallel beats one workgroup, even counting the second launch)
 template <typename Idx>
 __global__ __launch_bounds__(512) void msd_scan0_fused_kernel(const LevelArgs<Idx> a, int last_level) {   // nb <= 512
   // step 1: wave w takes bins w, w + 8, ...: exclusive prefix of the bin's per-item counts in 64-item chunks (coalesced
@@ -835,12 +835,13 @@ inline KeysPlan make_keys_plan(int64_t n, int key_bits, size_t key_size) {
   return p;
 }
 
-// Up to 8 192 keys of at most 32 bits: ONE workgroup, the whole LSD radix sort in LDS (the mini-batch block builder
-// sorts a few thousand ids per layer, where launch count is the whole cost).  16 wavefronts; wave w owns the 512 keys
-// [512 w, 512 w + 512) as 8 rows of 64, in order (stable).  A pass of 8 bits: per-wave histogram -> exclusive scan in
+// Up to 16 384 keys of at most 32 bits: ONE workgroup, the whole LSD radix sort in LDS (the mini-batch block builder
+// sorts a few thousand ids per layer, where launch count is the whole cost).  16 wavefronts; wave w owns the 1 024 keys
+// [1024 w, 1024 w + 1024) as 16 rows of 64, in order (stable).  A pass of 8 bits: per-wave histogram -> exclusive scan in
 // (bin, wave) order -> every wave ranks its rows one by one (lanes with my digit from 8 ballots, the wave's cursor of the
 // bin from LDS, the lowest lane of the bin advances it) and stores the key into the other LDS buffer.
-constexpr int kSmallKeys = 8192;
+constexpr int kSmallKeys = 16384;
+constexpr int kSmallRows = kSmallKeys / 1024;   // 64-key rows per wavefront
 constexpr size_t kSmallRadixLds = 2 * kSmallKeys * sizeof(uint32_t) + 16 * 256 * sizeof(uint32_t);
 template <typename Idx>
 __global__ __launch_bounds__(1024) void small_radix_kernel(const Idx* __restrict__ in, Idx* __restrict__ out, int n, int key_bits) {
@@ -858,11 +859,11 @@ __global__ __launch_bounds__(1024) void small_radix_kernel(const Idx* __restrict
   for (int shift = 0; shift < key_bits; shift += 8) {
     for (int i = tid; i < 16 * 256; i += 1024) cur[i] = 0;
     __syncthreads();
-    uint32_t key[8], dg[8];
-    unsigned long long same[8];
+    uint32_t key[kSmallRows], dg[kSmallRows];
+    unsigned long long same[kSmallRows];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      key[r] = src[wave * 512 + r * 64 + lane];
+    for (int r = 0; r < kSmallRows; ++r) {
+      key[r] = src[wave * (64 * kSmallRows) + r * 64 + lane];
       dg[r] = (key[r] >> shift) & 255u;
       unsigned long long m = ~0ull;
 #pragma unroll
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(1024) void small_radix_kernel(const Idx* __restrict
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < kSmallRows; ++r) {
       uint32_t* c = &cur[wave * 256 + dg[r]];
       const uint32_t base = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       dst[base + __popcll(same[r] & lt)] = key[r];
