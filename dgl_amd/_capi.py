@@ -403,6 +403,14 @@ def segment_mm_backward_b(a, dc, db, seglen, row_index=None):
         a.shape[1], dc.shape[1], None, 0, _stream(a)))
 
 
+def segment_mm_backward_b_last_route():
+    """(fell_back, listed_elements) of the most recent fp32 two-term weight-gradient launch
+    (dgla_segment_mm_backward_b_last_route; synchronises)."""
+    fb, n = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    check_call(LIB.dgla_segment_mm_backward_b_last_route(ctypes.byref(fb), ctypes.byref(n)))
+    return int(fb.value), int(n.value)
+
+
 def gather_mm(a, b, c, idx_a=None, idx_b=None, idx_c=None):
     """c[idx_c[i]] = a[idx_a[i]] @ b[idx_b[i]] (dgla_gather_mm); absent index = identity."""
     _mm_check(a, b, c, idx_a, idx_b, idx_c)

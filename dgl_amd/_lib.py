@@ -149,6 +149,8 @@ LIB.dgla_segment_mm_backward_b.argtypes = [c_int, c_int, c_void_p, c_void_p, c_v
 LIB.dgla_segment_mm_indexed.restype = c_int
 LIB.dgla_segment_mm_indexed.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                         c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]
+LIB.dgla_segment_mm_backward_b_last_route.restype = c_int
+LIB.dgla_segment_mm_backward_b_last_route.argtypes = [P(c_uint32), P(c_uint32)]
 LIB.dgla_segment_mm_backward_b_indexed.restype = c_int
 LIB.dgla_segment_mm_backward_b_indexed.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                                    c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p,

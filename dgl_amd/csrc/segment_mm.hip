@@ -1870,6 +1870,7 @@ struct MmBwdParams {
   int64_t slab_rows;     // rows per split-K slab
   const int64_t* row_index;  // optional: logical row r of A and dC lives at physical row row_index[r]
   uint32_t* nan_flag;  // X3 kernel: raised when an accumulator came out NaN (zeroed by the plan kernel)
+  const uint32_t* only_if = nullptr;  // X3 kernel behind the two-term kernel: run only when this word is non-zero
 };
 
 // ---- repair passes of the X3 kernels (see split3) ------------------------------------------------
@@ -2100,8 +2101,13 @@ constexpr int kWsQueueSplit = 8;            // dynamic chunks per group (chunk q
 constexpr size_t kWsQueueWords = 64;         // the queue's ticket, on a line of its own
 
 struct MmScratch {
-  size_t off_plan, off_t32, off_prog, off_bt, off_planes, off_acc, total;
+  size_t off_plan, off_t32, off_prog, off_bt, off_planes, off_acc, off_h2b, total;
 };
+// fp32 weight gradient on two fp16 terms: sample maxima, scales, 1 / scale, limits ([R][D1 + D2] words each), flags, list
+size_t h2b_scratch_bytes(int64_t num_rel, int64_t d1, int64_t d2) {
+  const size_t tab = (static_cast<size_t>(num_rel) * (d1 + d2) * 4 + 255) / 256 * 256;
+  return 4 * tab + 256 + static_cast<size_t>(16) * 16384;
+}
 
 MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool need_bt,
                      bool need_acc, bool forward = false) {
@@ -2124,6 +2130,8 @@ MmScratch mm_scratch(int64_t num_rel, int64_t K, int64_t N, size_t elem, bool ne
   }
   s.off_acc = off;
   if (need_acc) off = align256(off + static_cast<size_t>(num_rel) * K * N * sizeof(float));
+  s.off_h2b = off;
+  if (!forward && elem == 4) off = align256(off + h2b_scratch_bytes(num_rel, K, N));
   s.total = off;
   return s;
 }
@@ -2633,6 +2641,9 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_glds_f32_kernel(const
   constexpr int kLoads = 4;  // DMA instructions per wave and slot (2 per operand, 2 rows each)
   __shared__ __attribute__((aligned(1024))) char smem[NS * kSlot];
 
+  if constexpr (X3) {  // (uniform) the fallback launch behind segment_mm_bwd_b_h2_kernel
+    if (p.only_if && *p.only_if == 0) return;
+  }
   const int64_t L = blockIdx.x;
   const int64_t jd = L >> 3;
   const int tiles = p.tiles_i * p.tiles_j;
@@ -2781,6 +2792,429 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_glds_f32_kernel(const
     }
 }
 
+// ---- fp32 weight gradient as TWO scaled fp16 terms (round 6; VERDICT r5 Next #4) -------------------------------------
+// The X3 kernel above spends six bf16 MFMAs per tile and 16 contraction rows, and every operand half is split by the two
+// waves that multiply it: 9.1 ms at 10 M x 256 x 256.  Two fp16 terms (see the forward's H2 kernels: x s = h + 2^-11 l',
+// products hh, hl', l'h; 22 bits of x) need three.  The contraction runs over the ROWS here, so the power-of-two scale
+// that brings a value into fp16's range must be constant along a COLUMN of A / of dC inside a relation — and the column's
+// largest magnitude is only known after the whole segment has been read.  Reading it twice would cost what the split
+// saves, so the scale is an ESTIMATE that the main kernel VERIFIES while it converts:
+//   * h2_bwd_sample_kernel: largest |x| per (relation, column) over <= kH2bSample rows spread evenly over the segment
+//     (33 MB at 8 x 512 columns); h2_bwd_scales_kernel puts it into [2^11, 2^12): five binades of head room for the rows
+//     the sample did not see.  A column whose sample is all zero gets the scale 2^126, under which ANY non-zero fp32
+//     value converts to a non-zero or infinite fp16.
+//   * an fp16 overflow (a value above 32 x its column's sample maximum, Inf, NaN) turns every output of its row / column
+//     into Inf or NaN: the epilogue looks at its accumulators and raises flags[0]; so does anything non-zero in a
+//     zero-sample column (found by the test of the next item), a sample maximum that is Inf / NaN / outside 2^+-60, and
+//     an overflow of the list below.  A raised flag makes the launches behind the kernel zero the result and run the X3 kernel on
+//     the whole call (both exit on their first load otherwise): correct for any input, slow only for columns whose
+//     maximum lies more than 16 x above what 2 048 evenly spread rows show.
+//   * an element whose scaled magnitude falls below 2^-14 (25 binades under the sample maximum: 1 in 10^7 for continuous
+//     data) has a subnormal high term and would keep fewer than 21 bits.  The converting thread finds such elements with
+//     one packed 16-bit minimum per pair over |h| | |l|, removes them from both planes and writes (row, column, operand)
+//     into a short list; h2_bwd_fix_kernel, launched behind the main kernel and idle unless the list is non-empty, adds
+//     their rank-one contributions in plain fp32: A-side element (m, i): dB[i][:] += A[m][i] dC[m][:]; dC-side element
+//     (m, j): dB[:][j] += A0[m][:] dC[m][j] with the listed elements of A[m] left out (the same test, recomputed).
+//     What the test cannot see: elements whose BOTH terms round to zero (|x s| < 2^-36: 47 binades under a value present
+//     in the column's sample) are dropped.
+// Data path: the X3 kernel's ring of 16-row fp32 slots filled by global_load_lds; per slot the 256 threads convert it ONCE
+// (thread = (operand, k-half, feature): 8 rows of one feature -> one 16-byte piece per plane; fragment reads and piece
+// writes are conflict-free), barrier, and every wave reads its eight fragments with ds_read_b128 and issues twelve
+// v_mfma_f32_32x32x16_f16 into two accumulator sets (hh; hl' + l'h).
+// One barrier per slot: while a wave multiplies slot t it converts slot t + 1 IN PLACE (a wave's 2 KB of fp32 become its 2 KB
+// of fp16 pieces: no other wave's data is touched), the conversion's vector instructions placed behind the MFMAs in four
+// groups.  Epilogue: (acc0 + 2^-11 acc1) / (scale_A[i] scale_C[j]) — exact power-of-two factors — added with the fp32
+// atomics of the split-K scheme.  80 KB of LDS = a ring of five slots (one multiplied, one converted, three in flight), two
+// workgroups per CU.
+constexpr int64_t kH2bMinRows = 16384;  // smaller calls take the three-term kernel
+constexpr int kH2bSample = 2048;       // rows per relation the scale estimate looks at
+constexpr int kH2bChunks = 16;         // workgroups per relation of the sampling kernel
+constexpr int kH2bFixCap = 16384;      // list of elements too small for their column's scale
+constexpr uint32_t kH2bTiny = 0x0400;  // fp16 bits of 2^-14: a non-zero (high | low) pattern below it sends the element to the list
+
+struct H2bFix {
+  int64_t row;   // physical row of A and dC
+  int32_t col;   // column of A (op 0) or dC (op 1)
+  int32_t op_rel;  // (relation << 1) | op
+};
+
+struct H2bParams {
+  MmBwdParams m;
+  const float* scale;     // [R][D1 + D2] column scales: A's columns, then dC's
+  const float* inv;       // [R][D1 + D2] 1 / scale
+  const uint32_t* limit;  // [R][D1 + D2] smallest fp16 magnitude (bits) that must not appear: 0x7c00, or 1 (zero-sample column)
+  uint32_t* flags;        // [0]: the estimate failed -> X3 on the whole call; [1]: entries in `fix`
+  H2bFix* fix;
+};
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void h2_bwd_sample_kernel(const MmBwdParams p, uint32_t* __restrict__ umax) {
+  const int64_t* row_off = p.plan + p.num_rel + 1;
+  const int rel = blockIdx.x / kH2bChunks, chunk = blockIdx.x % kH2bChunks;
+  const int64_t r0 = row_off[rel], len = row_off[rel + 1] - r0;
+  if (len <= 0) return;
+  const int64_t ns = len < kH2bSample ? len : kH2bSample;                 // sampled rows: floor(k len / ns), k < ns
+  const int64_t k0 = ns * chunk / kH2bChunks, k1 = ns * (chunk + 1) / kH2bChunks;
+  const int cols = p.D1 + p.D2;
+  const uint32_t* A = static_cast<const uint32_t*>(p.a);
+  const uint32_t* C = static_cast<const uint32_t*>(p.dc);
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    const uint32_t* base = c < p.D1 ? A + c : C + (c - p.D1);
+    const int64_t pitch = c < p.D1 ? p.D1 : p.D2;
+    uint32_t mx = 0;
+    for (int64_t k = k0; k < k1; ++k) {
+      const int64_t m = r0 + (len == ns ? k : k * len / ns);
+      const uint32_t a = base[m * pitch] & 0x7fffffffu;
+      mx = a > mx ? a : mx;
+    }
+    if (mx) atomicMax(umax + static_cast<int64_t>(rel) * cols + c, mx);
+  }
+}
+
+__global__ __launch_bounds__(256) void h2_bwd_scales_kernel(const uint32_t* __restrict__ umax, int64_t n, float* __restrict__ scale,
+                                                            float* __restrict__ inv, uint32_t* __restrict__ limit,
+                                                            uint32_t* __restrict__ flags) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t u = umax[i];
+  const int e = static_cast<int>(u >> 23);
+  uint32_t sb = 127u << 23, ib = 127u << 23, lim = 0x7c00u;
+  if (u == 0u) {
+    sb = 253u << 23;   // 2^126: every non-zero fp32 value, denormals included, becomes a non-zero (or infinite) fp16
+    lim = 1u;
+  } else if (e < kH2MinExp || e > kH2MaxExp) {
+    atomicOr(flags, 1u);   // Inf / NaN / a magnitude whose unscaling could leave fp32's range: not this kernel's case
+  } else {
+    sb = static_cast<uint32_t>(127 + 11 + 127 - e) << 23;   // 2^(11 - (e - 127))
+    ib = static_cast<uint32_t>(e - 11) << 23;               // 2^((e - 127) - 11)
+  }
+  scale[i] = __builtin_bit_cast(float, sb);
+  inv[i] = __builtin_bit_cast(float, ib);
+  limit[i] = lim;
+}
+
+// is the element one the main kernel moved to the list?  (the same arithmetic as its conversion)
+__device__ __forceinline__ bool h2b_listed(float x, float s) {
+  const float v = x * s;
+  const _Float16 h = static_cast<_Float16>(v);
+  const _Float16 l = static_cast<_Float16>((v - static_cast<float>(h)) * 2048.f);
+  const uint32_t key = (__builtin_bit_cast(unsigned short, h) | __builtin_bit_cast(unsigned short, l)) & 0x7fffu;
+  return key != 0u && key < kH2bTiny;
+}
+
+constexpr int kH2bSlots = 5;
+__global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_h2_kernel(const H2bParams hp) {
+  const MmBwdParams& p = hp.m;
+  constexpr int NS = kH2bSlots;
+  constexpr int kPart = kBwdGldsRowsF32 * 512;  // one operand of a slot: 16 rows x 128 features x 4 B
+  constexpr int kSlot = 2 * kPart;
+  constexpr int kLoads = 4;                     // DMA instructions per wave and slot
+  __shared__ __attribute__((aligned(1024))) char smem[NS * kSlot];
+
+  const int64_t L = blockIdx.x;
+  const int64_t jd = L >> 3;
+  const int tiles = p.tiles_i * p.tiles_j;
+  const int64_t slab = (jd / tiles) * 8 + (L & 7);
+  const int tile = static_cast<int>(jd % tiles);
+  const int64_t* slab_off = p.plan;
+  const int64_t* row_off = p.plan + p.num_rel + 1;
+  if (slab >= slab_off[p.num_rel]) return;
+  const int64_t rel = find_segment(slab_off, p.num_rel, slab);
+  const int64_t m0 = row_off[rel] + (slab - slab_off[rel]) * p.slab_rows;
+  int64_t m1 = m0 + p.slab_rows;
+  if (m1 > row_off[rel + 1]) m1 = row_off[rel + 1];
+  const int i0 = (tile / p.tiles_j) * BM, j0 = (tile % p.tiles_j) * BN;
+  const int D1 = p.D1, D2 = p.D2;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc0[2][2], acc1[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[i][j][r] = acc1[i][j][r] = 0.f;
+
+  // DMA (as in segment_mm_bwd_b_glds_f32_kernel): instruction n of a wave covers slot rows 4 wave + 2 n, + 1
+  int drow[2];
+  int64_t offA[2], offC[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int r = 4 * wave + 2 * n + (lane >> 5);
+    drow[n] = r;
+    int fa = i0 + (lane & 31) * 4, fc = j0 + (lane & 31) * 4;
+    if (fa >= D1) fa = D1 - 4;
+    if (fc >= D2) fc = D2 - 4;
+    offA[n] = (static_cast<int64_t>(r) * D1 + fa) * 4;
+    offC[n] = (static_cast<int64_t>(r) * D2 + fc) * 4;
+  }
+  const char* __restrict__ baseA = static_cast<const char*>(p.a) + m0 * D1 * 4;
+  const char* __restrict__ baseC = static_cast<const char*>(p.dc) + m0 * D2 * 4;
+  const int64_t rows = m1 - m0;
+  const int nsl = static_cast<int>((rows + kBwdGldsRowsF32 - 1) / kBwdGldsRowsF32);
+  auto issue = [&](int t) {
+    if (t >= nsl) return;
+    char* dst = smem + (t % NS) * kSlot + wave * 2048;
+    const int64_t mrow = static_cast<int64_t>(t) * kBwdGldsRowsF32;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const bool in = mrow + drow[n] < rows;
+      const char* sa = in ? baseA + mrow * D1 * 4 + offA[n] : g_mm_zero_page;
+      const char* sc = in ? baseC + mrow * D2 * 4 + offC[n] : g_mm_zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)sa, (lds_ptr_t)(dst + n * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)sc, (lds_ptr_t)(dst + kPart + n * 1024), 16, 0, 0);
+    }
+  };
+  // this wave's DMA of a slot has landed while `later` slots issued behind it may stay in flight; lgkmcnt(0) with it:
+  // the wave's own LDS writes (the converted pieces) are out before the barrier that follows
+  auto wait_for_slot = [&](int later) {
+    switch (later) {
+      case 0: __builtin_amdgcn_s_waitcnt(0x0070); break;
+      case 1: __builtin_amdgcn_s_waitcnt(0x0070 | (1 * kLoads)); break;
+      case 2: __builtin_amdgcn_s_waitcnt(0x0070 | (2 * kLoads)); break;
+      default: __builtin_amdgcn_s_waitcnt(0x0070 | (3 * kLoads)); break;
+    }
+  };
+  static_assert(NS == 5, "the waits below assume a ring of five slots");
+
+  // Conversion task of this thread, the same for A and for dC: feature position fpos, k-half ckh (rows 8 ckh .. + 7).
+  // IN PLACE: a wave's 64 threads read the 8 rows x 256 bytes that hold their features' fp32 values and write their
+  // 64 + 64 sixteen-byte pieces (high plane, low plane) into the same 2 KB — rows 8 ckh + (j >> 4) (+ 4 for the low plane),
+  // byte (fpos >> 6) 256 + (j & 15) 16 for feature j = fpos & 63 — so no other wave's data is touched and the slot needs
+  // no second buffer.
+  const int fpos = tid & 127, ckh = tid >> 7;
+  const int64_t tab = rel * static_cast<int64_t>(D1 + D2);
+  // the column a feature position holds (DMA lanes past the width were clamped to the last four columns; such positions
+  // get the scale 0: their products land in accumulator rows / columns that are never stored)
+  const bool liveA = i0 + fpos < D1, liveC = j0 + fpos < D2;
+  const int colA = liveA ? i0 + fpos : 0, colC = liveC ? j0 + fpos : 0;
+  const float sA = liveA ? hp.scale[tab + colA] : 0.f, sC = liveC ? hp.scale[tab + D1 + colC] : 0.f;
+  // an element is LISTED (removed from both planes, added in fp32 by h2_bwd_fix_kernel) when its high term is subnormal
+  // (|x s| < 2^-14) and the pair is not zero: key = |h| | |l| as 15-bit patterns is then in [1, 0x400) — a normal high term
+  // makes the key >= 0x400 whatever the low term holds, and a zero high term leaves a low term below 2^-14 as well.  In a
+  // column whose sample was all zero (limit 1) ANY non-zero pattern takes that path and raises the flag instead.
+  // Only one of the workgroups that convert the same rows lists them (tile column 0 for A, tile row 0 for dC).
+  const bool listA = (tile % p.tiles_j) == 0, listC = (tile / p.tiles_j) == 0;
+  const uint32_t thrA = (liveA && hp.limit[tab + colA] == 1u) ? 0x8000u : kH2bTiny;
+  const uint32_t thrC = (liveC && hp.limit[tab + D1 + colC] == 1u) ? 0x8000u : kH2bTiny;
+  typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+  struct Conv {
+    uint32_t hw[4], lw[4];
+    u16x2 mn;
+  };
+  auto load8 = [&](const char* src, float (&x)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = *reinterpret_cast<const float*>(src + r * 512);
+  };
+  auto split_pair = [&](float x0, float x1, float s, Conv& c, int q) {
+    const f32x2v v = f32x2v{x0, x1} * s;
+    const h16x2v hb = __builtin_convertvector(v, h16x2v);                      // round to nearest
+    const f32x2v r = (v - __builtin_convertvector(hb, f32x2v)) * 2048.f;       // exact difference, exact scaling
+    const h16x2v lb = __builtin_convertvector(r, h16x2v);
+    c.hw[q] = __builtin_bit_cast(uint32_t, hb);
+    c.lw[q] = __builtin_bit_cast(uint32_t, lb);
+    const u16x2 key = __builtin_bit_cast(u16x2, (c.hw[q] | c.lw[q]) & 0x7fff7fffu);
+    c.mn = __builtin_elementwise_min(c.mn, key - u16x2{1, 1});                  // zero -> 0xffff
+  };
+  auto put = [&](char* dsth, const Conv& c) {
+    *reinterpret_cast<u32x4*>(dsth) = u32x4{c.hw[0], c.hw[1], c.hw[2], c.hw[3]};
+    *reinterpret_cast<u32x4*>(dsth + 2048) = u32x4{c.lw[0], c.lw[1], c.lw[2], c.lw[3]};
+  };
+  // rare: the thread's piece holds an element for the list — take it out (the thread rewrites its own piece)
+  auto slow = [&](char* dsth, Conv& c, uint32_t thr, int op, int col, int64_t row0, bool lists) {
+    if (thr == 0x8000u) {   // a zero-sample column that is not zero
+      atomicOr(hp.flags, 1u);
+      return;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t sh = (e & 1) * 16;
+      const uint32_t key = ((c.hw[e >> 1] | c.lw[e >> 1]) >> sh) & 0x7fffu;
+      if (key != 0u && key < kH2bTiny) {
+        c.hw[e >> 1] &= ~(0xffffu << sh);
+        c.lw[e >> 1] &= ~(0xffffu << sh);
+        if (lists) {
+          const uint32_t slot = atomicAdd(hp.flags + 1, 1u);
+          if (slot < static_cast<uint32_t>(kH2bFixCap)) {
+            H2bFix f;
+            f.row = row0 + e;
+            f.col = col;
+            f.op_rel = static_cast<int32_t>((rel << 1) | op);
+            hp.fix[slot] = f;
+          } else {
+            atomicOr(hp.flags, 1u);
+          }
+        }
+      }
+    }
+    put(dsth, c);
+  };
+  auto flagged = [&](const Conv& c, uint32_t thr) { return c.mn[0] < thr - 1u || c.mn[1] < thr - 1u; };
+
+  const int f = lane & 31, kh = lane >> 5;
+  const int src_off = ckh * 8 * 512 + fpos * 4;
+  const int dst_off = (ckh * 8 + ((fpos & 63) >> 4)) * 512 + (fpos >> 6) * 256 + (fpos & 15) * 16;
+  // fragment of MFMA tile i of this wave: features 64 w + 32 i + f  ->  piece row 8 kh + 2 i + (f >> 4)
+  const int fragA = (kh * 8 + (f >> 4)) * 512 + wm * 256 + (f & 15) * 16;
+  const int fragC = kPart + (kh * 8 + (f >> 4)) * 512 + wn * 256 + (f & 15) * 16;
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i) issue(i);
+  // slot 0, converted where it lies
+  {
+    wait_for_slot(nsl - 1 < 3 ? nsl - 1 : 3);
+    __builtin_amdgcn_s_barrier();
+    float xa[8], xc[8];
+    load8(smem + src_off, xa);
+    load8(smem + kPart + src_off, xc);
+    Conv ca, cc;
+    ca.mn = cc.mn = u16x2{0xffff, 0xffff};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      split_pair(xa[2 * q], xa[2 * q + 1], sA, ca, q);
+      split_pair(xc[2 * q], xc[2 * q + 1], sC, cc, q);
+    }
+    put(smem + dst_off, ca);
+    put(smem + kPart + dst_off, cc);
+    if (__builtin_expect(flagged(ca, thrA), 0)) slow(smem + dst_off, ca, thrA, 0, colA, m0 + ckh * 8, listA);
+    if (__builtin_expect(flagged(cc, thrC), 0)) slow(smem + kPart + dst_off, cc, thrC, 1, colC, m0 + ckh * 8, listC);
+  }
+  for (int t = 0; t < nsl; ++t) {
+    // slot t + 1 has landed (slots up to t + 3 are under way), this wave's converted pieces of slot t are out
+    const int behind = nsl - 2 - t;
+    if (behind >= 0)
+      wait_for_slot(behind < 2 ? behind : 2);
+    else
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();      // every wave: slot t converted, the fragments of slot t - 1 read
+    issue(t + NS - 1);                 // into the slot that held t - 1
+    const char* stg = smem + (t % NS) * kSlot;
+    char* slot = smem + ((t + 1) % NS) * kSlot;
+    const bool more = t + 1 < nsl;     // (uniform; the last pass converts a stale slot nobody reads)
+    const char* pa0 = stg + fragA;
+    const char* pb0 = stg + fragC;
+#define DGLA_H2B_MFMA(i, j, AH, AL, BH, BL)                                                  \
+  acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH, acc1[i][j], 0, 0, 0);          \
+  acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, acc0[i][j], 0, 0, 0);          \
+  acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL, acc1[i][j], 0, 0, 0);
+    // the next slot's conversion between the MFMAs of this one: four groups of three MFMAs, a quarter of the
+    // conversion's vector instructions issued behind each (the matrix pipe runs them while the wave goes on); fragments
+    // and fp32 rows are read group by group to keep the live registers under the 256 the two-workgroup occupancy allows
+    Conv ca, cc;
+    ca.mn = cc.mn = u16x2{0xffff, 0xffff};
+    float x[8];
+    const h16x8 ah0 = *reinterpret_cast<const h16x8*>(pa0), al0 = *reinterpret_cast<const h16x8*>(pa0 + 2048);
+    h16x8 bh = *reinterpret_cast<const h16x8*>(pb0), bl = *reinterpret_cast<const h16x8*>(pb0 + 2048);
+    load8(slot + src_off, x);
+    DGLA_H2B_MFMA(0, 0, ah0, al0, bh, bl)
+    split_pair(x[0], x[1], sA, ca, 0);
+    split_pair(x[2], x[3], sA, ca, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const h16x8 ah1 = *reinterpret_cast<const h16x8*>(pa0 + 1024), al1 = *reinterpret_cast<const h16x8*>(pa0 + 2048 + 1024);
+    DGLA_H2B_MFMA(1, 0, ah1, al1, bh, bl)
+    split_pair(x[4], x[5], sA, ca, 2);
+    split_pair(x[6], x[7], sA, ca, 3);
+    put(slot + dst_off, ca);
+    __builtin_amdgcn_sched_barrier(0);
+    bh = *reinterpret_cast<const h16x8*>(pb0 + 1024);
+    bl = *reinterpret_cast<const h16x8*>(pb0 + 2048 + 1024);
+    load8(slot + kPart + src_off, x);
+    DGLA_H2B_MFMA(1, 1, ah1, al1, bh, bl)
+    split_pair(x[0], x[1], sC, cc, 0);
+    split_pair(x[2], x[3], sC, cc, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    DGLA_H2B_MFMA(0, 1, ah0, al0, bh, bl)
+    split_pair(x[4], x[5], sC, cc, 2);
+    split_pair(x[6], x[7], sC, cc, 3);
+    put(slot + kPart + dst_off, cc);
+#undef DGLA_H2B_MFMA
+    if (__builtin_expect(more && (flagged(ca, thrA) || flagged(cc, thrC)), 0)) {
+      const int64_t row0 = m0 + static_cast<int64_t>(t + 1) * kBwdGldsRowsF32 + ckh * 8;
+      if (flagged(ca, thrA)) slow(slot + dst_off, ca, thrA, 0, colA, row0, listA);
+      if (flagged(cc, thrC)) slow(slot + kPart + dst_off, cc, thrC, 1, colC, row0, listC);
+    }
+  }
+
+  // overflow of a scaled value (a column whose maximum lies above what its sample showed; Inf; NaN) arrives as a
+  // non-finite accumulator: inf x = inf or NaN in every output of the element's row / column
+  {
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bad |= !(__builtin_fabsf(acc0[i][j][r]) < __builtin_inff());
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0) && lane == 0) atomicOr(hp.flags, 1u);
+  }
+  float* out = p.acc + rel * static_cast<int64_t>(D1) * D2;
+  const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+  const float* invA = hp.inv + tab;
+  const float* invC = hp.inv + tab + D1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = j0 + wn * 64 + j * 32 + col_l;
+      if (col >= D2) continue;
+      const float ic = invC[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+        if (row < D1) {
+          const float v = __builtin_fmaf(acc1[i][j][r], 0x1p-11f, acc0[i][j][r]);
+          atomicAdd(out + static_cast<int64_t>(row) * D2 + col, v * invA[row] * ic);
+        }
+      }
+    }
+}
+
+// The listed elements' rank-one contributions, in plain fp32 (one workgroup per entry).
+__global__ __launch_bounds__(256) void h2_bwd_fix_kernel(const H2bParams hp) {
+  const MmBwdParams& p = hp.m;
+  if (hp.flags[0] != 0u) return;   // the whole call is redone
+  uint32_t n = hp.flags[1];
+  if (n == 0u) return;
+  if (n > static_cast<uint32_t>(kH2bFixCap)) n = kH2bFixCap;
+  const float* A = static_cast<const float*>(p.a);
+  const float* dC = static_cast<const float*>(p.dc);
+  const int D1 = p.D1, D2 = p.D2;
+  for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+    const H2bFix fx = hp.fix[e];
+    const int64_t rel = fx.op_rel >> 1;
+    float* out = p.acc + rel * static_cast<int64_t>(D1) * D2;
+    const float* sA = hp.scale + rel * static_cast<int64_t>(D1 + D2);
+    if ((fx.op_rel & 1) == 0) {
+      const float x = A[fx.row * D1 + fx.col];
+      for (int j = threadIdx.x; j < D2; j += blockDim.x)
+        atomicAdd(out + static_cast<int64_t>(fx.col) * D2 + j, x * dC[fx.row * D2 + j]);
+    } else {
+      const float y = dC[fx.row * D2 + fx.col];
+      for (int i = threadIdx.x; i < D1; i += blockDim.x) {
+        const float a = A[fx.row * D1 + i];
+        if (h2b_listed(a, sA[i])) continue;   // that product was added by the A-side entry
+        atomicAdd(out + static_cast<int64_t>(i) * D2 + fx.col, a * y);
+      }
+    }
+  }
+}
+
+// flags[0] raised: the result is zeroed again for the X3 kernel launched behind this one.  (Also leaves a copy of the two
+// words where dgla_segment_mm_backward_b_last_route can read them after the call's scratch is gone.)
+__device__ uint32_t g_h2b_last_flags[2];
+__global__ __launch_bounds__(256) void h2_bwd_reset_kernel(const uint32_t* __restrict__ flags, float* __restrict__ acc, int64_t n) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_h2b_last_flags[0] = flags[0];
+    g_h2b_last_flags[1] = flags[1];
+  }
+  if (flags[0] == 0u) return;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    acc[i] = 0.f;
+}
+
 // Rows per split-K slab: every slab ends in one fp32 atomic add per output element, and the
 // atomics (not the MFMAs) bound the kernel when slabs are short (2048-row slabs: 320 M atomics
 // = 4.0 ms of a 4.0 ms launch at 10 M rows).  Long slabs cut them; enough slabs must remain to
@@ -2845,6 +3279,36 @@ int run_segment_mm_bwd_b(const void* a, const void* dc, void* db, int64_t M, int
     if constexpr (sizeof(DT) == 4) {
       direct = p.vec_a && p.vec_dc && !row_index && D1 >= 4 && D2 >= 4 && (tuning_flags() & kTuneGlds);
       const bool x3 = !(tuning_flags() & kTuneMmF32);  // fp32 as an exact 3 x bf16 split (default)
+      // Default: two scaled fp16 terms (segment_mm_bwd_b_h2_kernel) with the X3 kernel behind it as the route for inputs
+      // whose columns leave the estimated range (it exits on its first load otherwise).  DGLA_TUNE_MM_X3 / _F32: the wider routes.
+      // Calls of fewer than kH2bMinRows rows stay on the three-term kernel: nothing to gain there, and its 2^-26 per product
+      // keeps segments of one or two rows inside the fp32-level bound of tests/test_mm.py (two fp16 terms: 2^-21.5).
+      // DGLA_MM_BWD_H2 = 1 / 0 forces the choice (read per call: tests switch it inside one process).
+      const char* e = getenv("DGLA_MM_BWD_H2");
+      const int force = e && *e ? atoi(e) : -1;
+      const bool h2 = direct && x3 && !(tuning_flags() & kTuneMmX3) && M > 0 && force != 0 && (force == 1 || M >= kH2bMinRows);
+      if (h2) {
+        H2bParams hp;
+        hp.m = p;
+        const size_t tab = (static_cast<size_t>(num_rel) * (D1 + D2) * 4 + 255) / 256 * 256;
+        char* base = ws + sc.off_h2b;
+        uint32_t* umax = reinterpret_cast<uint32_t*>(base);
+        hp.scale = reinterpret_cast<const float*>(base + tab);
+        hp.inv = reinterpret_cast<const float*>(base + 2 * tab);
+        hp.limit = reinterpret_cast<const uint32_t*>(base + 3 * tab);
+        hp.flags = reinterpret_cast<uint32_t*>(base + 4 * tab);
+        hp.fix = reinterpret_cast<H2bFix*>(base + 4 * tab + 256);
+        DGLA_CHECK_HIP(hipMemsetAsync(umax, 0, tab, s));
+        DGLA_CHECK_HIP(hipMemsetAsync(hp.flags, 0, 256, s));
+        const int64_t ncol = num_rel * (D1 + D2);
+        hipLaunchKernelGGL(h2_bwd_sample_kernel, dim3(static_cast<unsigned>(num_rel * kH2bChunks)), dim3(256), 0, s, p, umax);
+        hipLaunchKernelGGL(h2_bwd_scales_kernel, dim3(static_cast<unsigned>((ncol + 255) / 256)), dim3(256), 0, s, umax, ncol,
+                           const_cast<float*>(hp.scale), const_cast<float*>(hp.inv), const_cast<uint32_t*>(hp.limit), hp.flags);
+        hipLaunchKernelGGL(segment_mm_bwd_b_h2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, hp);
+        hipLaunchKernelGGL(h2_bwd_fix_kernel, dim3(256), dim3(256), 0, s, hp);
+        hipLaunchKernelGGL(h2_bwd_reset_kernel, dim3(256), dim3(256), 0, s, hp.flags, acc, out_elems);
+        p.only_if = hp.flags;
+      }
       if (direct && p.tiles_i * p.tiles_j >= 8) {
         if (x3)
           hipLaunchKernelGGL((segment_mm_bwd_b_glds_f32_kernel<2, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
@@ -2901,7 +3365,7 @@ extern "C" {
 
 size_t dgla_segment_mm_workspace_bytes(dgla_dtype dtype, int64_t num_rel, int64_t d1, int64_t d2) {
   const size_t elem = dtype == DGLA_F64 ? 8 : (dtype == DGLA_F32 ? 4 : 2);
-  return mm_scratch(num_rel, d1, d2, elem, true, true, true).total;
+  return std::max(mm_scratch(num_rel, d1, d2, elem, true, true, true).total, mm_scratch(num_rel, d1, d2, elem, false, elem == 2).total);
 }
 
 int dgla_segment_mm_indexed(int idtype_bits, dgla_dtype dtype, const void* a, const void* b, void* c,
@@ -2983,6 +3447,14 @@ int dgla_segment_mm_backward_b(int idtype_bits, dgla_dtype dtype, const void* a,
   return dgla_segment_mm_backward_b_indexed(idtype_bits, dtype, a, dc, db, seglen, seglen_on_host, nullptr,
                                             num_rows, num_rel, d1, d2, workspace, workspace_bytes,
                                             hip_stream);
+}
+
+int dgla_segment_mm_backward_b_last_route(uint32_t* fell_back, uint32_t* listed_elements) {
+  uint32_t w[2] = {0, 0};
+  DGLA_CHECK_HIP(hipMemcpyFromSymbol(w, HIP_SYMBOL(g_h2b_last_flags), sizeof(w)));
+  if (fell_back) *fell_back = w[0];
+  if (listed_elements) *listed_elements = w[1];
+  return 0;
 }
 
 int dgla_gather_mm(int idtype_bits, dgla_dtype dtype, const void* a, const void* b, void* c,

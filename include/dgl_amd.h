@@ -328,7 +328,14 @@ int dgla_spmm_csr_masked(const dgla_csr* csr, dgla_dtype dtype, const dgla_tenso
  *   beyond sum(seglen) come back ZERO, as the reference's do (its output starts as th.zeros,
  *   python/dgl/backend/pytorch/sparse.py:975).
  * dgla_segment_mm_backward_b:  dB[r] (d1 x d2) = A[rows_r]^T (d1 x m) . dC[rows_r] (m x d2);
- *   relations without rows get zeros.
+ *   relations without rows get zeros.  fp32 default route (round 6): operands as two fp16 terms under per-column
+ *   power-of-two scales estimated from a row sample and verified in the launch (>= 2^-21 per element; elements more than
+ *   26 binades under their column's sample maximum are added exactly from a short list); inputs that leave the estimated
+ *   range, Inf / NaN included, are redone by the three-bf16-term kernel inside the same call.  DGLA_TUNE_MM_X3 /
+ *   DGLA_TUNE_MM_F32 select the three-term / v_mfma_f32_32x32x2_f32 routes.
+ * dgla_segment_mm_backward_b_last_route: statistics of the most recent fp32 two-term weight-gradient launch on the
+ *   current device (synchronising read): whether it was redone by the three-term kernel, and how many elements went
+ *   through the exact list.  No reference counterpart (diagnostics for tests / benchmarks).
  * dgla_gather_mm:  C[idx_c ? idx_c[i] : i] = A[idx_a ? idx_a[i] : i] (1 x k) . B[idx_b ? idx_b[i] : i]
  *   (k x n), one wavefront per row (the small-shape path of dgl.ops.gather_mm).
  * `workspace` may be NULL (stream-ordered scratch for the duration of the call). */
@@ -341,6 +348,7 @@ int dgla_segment_mm_backward_b(int idtype_bits, dgla_dtype dtype, const void* a,
                                void* db, const void* seglen, int seglen_on_host,
                                int64_t num_rows, int64_t num_rel, int64_t d1, int64_t d2,
                                void* workspace, size_t workspace_bytes, void* hip_stream);
+int dgla_segment_mm_backward_b_last_route(uint32_t* fell_back, uint32_t* listed_elements);
 /* The same two operators over rows that are NOT stored grouped by relation: logical row r (the
  * order `seglen` describes) lives at physical row row_index[r] of A and of C (forward) / of A and
  * dC (weight gradient).  This is dgl.ops.gather_mm for large inputs without its two
