@@ -636,6 +636,67 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
     }
   };
 
+  // ---- masked launch (dgla_spmm_csr_masked: rhs words are bit masks): the mask word is fetched ONE BATCH AHEAD of the row
+  // gather, and a lane whose VEC columns are all switched off for an edge reads a fixed, cache-resident address instead of
+  // its piece of the row: a 128-byte line of the gathered operand is requested only when one of its columns is wanted
+  // (max / min backward: an edge wins ~F / degree columns, so 2.3 instead of 4 lines per edge at C2).
+  constexpr bool kGated = UL && UR && !MULTI && OP == kMul && BC == kBcRhsGroup && RED == kSum && RV == 1;
+  [[maybe_unused]] auto load_w_only = [&](int e, Batch& b) {
+    if constexpr (kGated) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int ee = e + u;
+        if (ee >= e_e) ee = e_e - 1;
+        const int64_t eid = has_eid ? static_cast<int64_t>(eidl[ee]) : j0 + ee;
+        b.w[u] = *reinterpret_cast<const WV*>(Wt + eid * rhs_len);
+      }
+    }
+  };
+  [[maybe_unused]] const XV* const gate_dummy =
+      reinterpret_cast<const XV*>(edge_layout ? static_cast<const DT*>(p.umain) : static_cast<const DT*>(p.ufeat)) + (lane & 7);
+  [[maybe_unused]] auto load_x_gated = [&](int e, Batch& b) {
+    if constexpr (kGated) {
+      constexpr int BITS = 8 * static_cast<int>(sizeof(DT));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int ee = e + u;
+        if (ee >= e_e) ee = e_e - 1;
+        const int64_t c = cols[ee];
+        const XV* ptr;
+        bool done = false;
+        if constexpr (VEC * sizeof(DT) == 16) {
+          if (edge_layout) {
+            const unsigned o16 = (e_t16 * static_cast<unsigned>(c) + e_base16) & 7u;
+            const unsigned head = 8u - o16;
+            const bool in_place = (ej - head) < e_in_place;
+            const int side_off = ej < head ? e_piece_lo : e_piece_hi;
+            const DT* base = in_place ? X : e_side;
+            const int64_t pitch = in_place ? lhs_len : static_cast<int64_t>(e_pitch);
+            const int add = in_place ? 0 : side_off;
+            ptr = reinterpret_cast<const XV*>(base + (c * pitch + add));
+            done = true;
+          }
+        }
+        if constexpr (VEC * sizeof(DT) == 8) {
+          if (straddle) {
+            const unsigned o = static_cast<unsigned>((static_cast<uint64_t>(c) * static_cast<unsigned>(p.split_row_bytes) +
+                                                      static_cast<unsigned>(p.split_base_bytes)) & 127u);
+            const bool from_side = o > static_cast<unsigned>(p.split_straddle_slack);
+            const DT* base = from_side ? static_cast<const DT*>(p.umain) + lo_off : X;
+            const int64_t pitch = from_side ? static_cast<int64_t>(p.split_main) : lhs_len;
+            ptr = reinterpret_cast<const XV*>(base + c * pitch);
+            done = true;
+          }
+        }
+        if (!done) ptr = reinterpret_cast<const XV*>(X + c * lhs_len);
+        uint64_t wb = 0;
+        __builtin_memcpy(&wb, &b.w[u].v[0], sizeof(DT));
+        const bool wanted = ((wb >> (k0 & (BITS - 1))) & ((1u << VEC) - 1u)) != 0u;
+        b.x[u] = *(wanted ? ptr : gate_dummy);
+      }
+    }
+  };
+
   A acc[VEC];
   int best[ARG ? VEC : 1];
   // RED is kSum or kMax; the kMax instantiation also runs min (p.red_min: wave-uniform compare direction)
@@ -873,7 +934,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   // The prefetch is unconditional (load_batch clamps to the group's last edge) so the
   // loop body is branch-free up to the reduction and the compiler can wait with a counted
   // vmcnt(U) instead of draining the prefetched batch.
-  if (e_s < e_e) {
+  bool gated_done = false;
+  if constexpr (kGated) {
+    if (rhs_mask && VEC <= static_cast<int>(8 * sizeof(DT)) && (p.tune & kTuneNoGate) == 0) {  // (wave-uniform)
+      gated_done = true;
+      if (e_s < e_e) {
+        // three batches in rotation: mask words two batches ahead of the reduction, rows one batch ahead
+        int e = e_s;
+        Batch b0, b1, b2;
+        load_w_only(e, b0);
+        load_w_only(e + U, b1);
+        load_x_gated(e, b0);
+        for (; e < e_e; e += 3 * U) {
+          load_w_only(e + 2 * U, b2);
+          load_x_gated(e + U, b1);
+          reduce_batch(e, b0);
+          load_w_only(e + 3 * U, b0);
+          load_x_gated(e + 2 * U, b2);
+          reduce_batch(e + U, b1);
+          load_w_only(e + 4 * U, b1);
+          load_x_gated(e + 3 * U, b0);
+          reduce_batch(e + 2 * U, b2);
+        }
+      }
+    }
+  }
+  if (!gated_done && e_s < e_e) {
     int e = e_s;
     Batch ba, bb;  // ping-pong: copying a batch would wait for its loads
     load_batch(e, ba);
