@@ -9,6 +9,7 @@ warm-up, events on the launch stream), with its ALGORITHMIC bytes per SURVEY.md 
   gat_attention      configs[2]'s block (u_add_v -> leaky_relu -> edge_softmax -> u_mul_e_sum), fwd and fwd + bwd at C3 and
                      C2-size (fwd), mapped graph: the composed operators and the default route (the fused kernel)
   rgcn_stacked_bf16  configs[4]'s one-GPU piece: 8 relations x 12.5 M edges, N = 10 M, F = 256, bf16, ONE stacked launch
+  coo_to_csc, copy_u_max fwd + bwd, segment_mm fwd / dB (bf16, fp32)   the §8 "next" rows f2, f3 and the max / min gradient
 
 Byte models: SpMM  E*(F_l*s + w*s + i [+ i map]) + (N+1)*i + N*F_out*s;  SDDMM dot  E*(2*H*D*s + 2*i) + E*H*s;
 softmax fwd  E*(2*H*s [+ i map]) + (N+1)*i, fwd + bwd  E*(5*H*s [+ 2*i map]) + 2*(N+1)*i;
@@ -92,7 +93,33 @@ def op_variants(dev, c2_graph=None, scale=1, reps=10):
     oe = torch.empty(e, 1, device=dev)
     t = _time(lambda: _capi.sddmm_coo("dot", coo, x, x, oe, 0, 2), max(3, reps // 2))
     res["sddmm_u_dot_v_C2size_D100"] = _line(t, e * (2 * f * s + 2 * i) + e * s, e, gathered=n * f * s, op="dgla_sddmm_coo dot(u, v)")
-    del coo, oe, dst, deg, x, w1, out
+    del coo, oe
+    # COO -> CSC of the same graph given as an UNSORTED COO (reference: COOSort + cusparseXcoo2csr)
+    perm = torch.randperm(e, device=dev, generator=gen)
+    rsrc, rdst = g["indices"][perm].contiguous(), dst[perm].contiguous()
+    del perm
+    t = _time(lambda: _capi.coo_to_csr(rdst, rsrc, None, n, n), max(3, reps // 2), warm=2)
+    res["coo_to_csc_C2_int32"] = _line(t, e * i * 4 + (n + 1) * i, e, op="dgla_coo_to_csr, 61.9 M unsorted edges -> indptr, indices, edge ids (own MSD sort)")
+    del rsrc, rdst, dst, deg
+    # copy_u + max, forward + backward through the operator API (autograd): forward with winners, backward = winner bits +
+    # gated masked g-SpMM over the reverse graph (no atomics).  Bytes: forward E*(F*s + i) + (N+1)*i + 2*N*F*s (out, arg_u),
+    # backward N*F*(s + i) (dZ, arg_u) + E*i (column ids) + E*W*s (bit words written) + E*(F*s + W*s + i) + (N+1)*i + N*F*s
+    dgm = _dgl_graph(g, False, dev)
+    xg = x.clone().requires_grad_(True)
+    up = torch.rand(n, f, device=dev)
+
+    def fb_max():
+        xg.grad = None
+        dgl.ops.copy_u_max(dgm, xg).backward(up)
+
+    fb_max()   # (builds the out-edge CSR and the position map once, like the forward CSC)
+    t = _time(fb_max, max(3, reps // 2), warm=2)
+    words = (f + 31) // 32
+    nb = (e * (f * s + i) + (n + 1) * i + 2 * n * f * s) + n * f * (s + i) + e * i + e * words * s + \
+         e * (f * s + words * s + i) + (n + 1) * i + n * f * s
+    res["copy_u_max_fwd_bwd_C2"] = _line(t, nb, e, gathered=n * f * s, op="dgl.ops.copy_u_max(...).backward(), fp32, int32 ids")
+    del dgm, xg, up, x, w1, out
+    torch.cuda.empty_cache()
     # edge softmax through the operator API (what a caller pays: allocation + FFI + kernels), H = 8
     for tag, with_map in (("map_free", False), ("eid_map", True)):
         dg = _dgl_graph(g, with_map, dev)
@@ -190,4 +217,29 @@ def op_variants(dev, c2_graph=None, scale=1, reps=10):
               max(3, reps // 2), warm=2)
     res["rgcn_stacked_bf16_C5_one_gpu"] = _line(t, r * e * (f * 2 + i + 1) + (n + 1) * i + n * f * 2, r * e, gathered=n * f * 2,
                                                op="dgla_spmm_csr_stacked copy_lhs/sum, 8 relations x %d edges, N = %d, F = 256, bf16" % (e, n))
+    del scsr, sws, tabs, xs, x, out, indptr, indices, eids, relid
+    torch.cuda.empty_cache()
+    # ---------------- configs[4]'s per-relation transform: segment_mm -------------------------------
+    # 10 M rows x 256 x 256, 8 relations; bytes: A + C once, weights once (weight gradient: A + dC once, dB once)
+    rows, k, m_, r = 10_000_000 // scale, 256, 256, 8
+    seglen = torch.full((r,), rows // r, dtype=torch.int64, device=dev)
+    seglen[-1] += rows - int(seglen.sum())
+    for dt, tag in ((torch.bfloat16, "bf16"), (torch.float32, "fp32")):
+        torch.manual_seed(4)
+        a = (torch.rand(rows, k, device=dev) - 0.5).to(dt)
+        b = (torch.rand(r, k, m_, device=dev) - 0.5).to(dt)
+        c = torch.empty(rows, m_, device=dev, dtype=dt)
+        es = a.element_size()
+        nb = rows * (k + m_) * es + r * k * m_ * es
+        t = _time(lambda: _capi.segment_mm(a, b, c, seglen), max(3, reps // 2), warm=2)
+        res["segment_mm_fwd_%s" % tag] = _line(t, nb, rows, tflops=2.0 * rows * k * m_ / (t[0] * 1e-3) / 1e12,
+                                               op="dgla_segment_mm, MFMA" + (", fp32 as two scaled fp16 terms" if dt == torch.float32 else ""))
+        t = _time(lambda: _capi.segment_mm_backward_b(a, c, b, seglen), max(3, reps // 2), warm=2)
+        extra = {}
+        if dt == torch.float32:
+            fell_back, listed = _capi.segment_mm_backward_b_last_route()
+            extra = {"redone_by_three_term_kernel": bool(fell_back), "listed_elements": listed}
+        res["segment_mm_dB_%s" % tag] = _line(t, nb, rows, tflops=2.0 * rows * k * m_ / (t[0] * 1e-3) / 1e12,
+                                              op="dgla_segment_mm_backward_b" + (", fp32 as two scaled fp16 terms" if dt == torch.float32 else ""), **extra)
+        del a, b, c
     return res
