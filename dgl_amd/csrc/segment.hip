@@ -392,33 +392,47 @@ __device__ __forceinline__ int64_t bcast_lane(int64_t v, int j) {
          static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), j));
 }
 
-template <typename Idx, typename W, typename DT>
+// CPL columns per lane (round 6): a wave covers 64 CPL columns of a row — F = 100 is ONE wave per row with two columns per lane
+// instead of two waves (the second with 36 live lanes): the per-row overhead and the key broadcast are paid once
+// (mask kernel 1.68 -> see profiles/r6/cmp_backward_gated.jsonl).
+template <typename Idx, typename W, typename DT, int CPL>
 __global__ __launch_bounds__(256) void spmm_cmp_mask_kernel(
     const Idx* __restrict__ indptr, const Idx* __restrict__ indices, const Idx* __restrict__ eids,
     const Idx* __restrict__ arg, int by_edge, int64_t rows, int F, int words, W* __restrict__ mask,
     const DT* __restrict__ dz, DT* __restrict__ dx, int64_t dx_rows, typename Acc<DT>::type* __restrict__ leak) {
   using A = typename Acc<DT>::type;
   constexpr int BITS = 8 * static_cast<int>(sizeof(W));
-  constexpr int WPC = 64 / BITS;  // words per 64-column chunk
-  const int chunks = (F + 63) >> 6;
+  constexpr int WPC = 64 / BITS;  // words per 64 columns
+  const int chunks = (F + 64 * CPL - 1) / (64 * CPL);
   const int lane = threadIdx.x & 63;
   // wave -> (fixed chunk c, rows slot, slot + slots, ...): the grid is a whole number of chunk groups, so a wave's
-  // unclaimed elements all belong to the same 64 columns and can be summed in registers in ROW order
+  // unclaimed elements all belong to the same columns and can be summed in registers in ROW order
   const int64_t nw = static_cast<int64_t>(gridDim.x) * (blockDim.x >> 6);
   const int64_t wid = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t slots = nw / chunks;
   const int c = static_cast<int>(wid % chunks);
   const int64_t slot = wid / chunks;
   if (slot >= slots) return;
-  const int f = c * 64 + lane;
-  const bool live = f < F;
-  A leaked = A(0);
-  __shared__ uint64_t s_bits[4][64];
-  uint64_t* const wb = s_bits[threadIdx.x >> 6];  // this wave's 64 words: edge j of the batch -> its column bits
+  int f[CPL];
+  bool live[CPL];
+  A leaked[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    f[k] = (c * CPL + k) * 64 + lane;
+    live[k] = f[k] < F;
+    leaked[k] = A(0);
+  }
+  __shared__ uint64_t s_bits[4][CPL][64];
+  uint64_t(*const wb)[64] = s_bits[threadIdx.x >> 6];  // this wave's words: edge j of the batch -> bits of columns 64 k ..
   for (int64_t row = slot; row < rows; row += slots) {
     const int64_t b = static_cast<int64_t>(indptr[row]), e = static_cast<int64_t>(indptr[row + 1]);
-    const Idx a = live ? arg[row * F + f] : static_cast<Idx>(-1);
-    bool found = !live;
+    Idx a[CPL];
+    bool found[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      a[k] = live[k] ? arg[row * F + f[k]] : static_cast<Idx>(-1);
+      found[k] = !live[k];
+    }
     for (int64_t p0 = b; p0 < e; p0 += 64) {
       const int nb = static_cast<int>(e - p0 < 64 ? e - p0 : 64);
       Idx key = static_cast<Idx>(-2);  // (never equal to a column's winner: ids are >= 0, a dead lane asks for -1)
@@ -428,46 +442,65 @@ __global__ __launch_bounds__(256) void spmm_cmp_mask_kernel(
         else
           key = indices[p0 + lane];
       }
-      // lane = column: scan the batch's keys from the LAST edge to the first, so the first match stays — three
-      // vector instructions per edge (broadcast, compare, select); the per-edge ballot + park-in-lane-j form of the
-      // first version cost ten and made this kernel 5 ms at 62 M edges
-      int pos = -1;
+      // lane = column(s): scan the batch's keys from the LAST edge to the first, so the first match stays — one
+      // broadcast per edge and a compare + select per column; the per-edge ballot + park-in-lane-j form of the
+      // first version cost ten instructions and made this kernel 5 ms at 62 M edges
+      int pos[CPL];
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) pos[k] = -1;
 #pragma unroll
       for (int j8 = 56; j8 >= 0; j8 -= 8) {
         if (j8 < nb) {  // (uniform) lanes >= nb hold the never-matching key: whole groups of eight, lane numbers constant
 #pragma unroll
-          for (int j = 7; j >= 0; --j) pos = (a == bcast_lane(key, j8 + j)) ? j8 + j : pos;
+          for (int j = 7; j >= 0; --j) {
+            const Idx kj = bcast_lane(key, j8 + j);
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) pos[k] = (a[k] == kj) ? j8 + j : pos[k];
+          }
         }
       }
       // column -> edge: every winning column ORs its bit into its edge's word (one LDS atomic per lane), then lane j
-      // picks up the word of edge j.  One wave's LDS operations execute in order; the wave barriers keep the
+      // picks up the word(s) of edge j.  One wave's LDS operations execute in order; the wave barriers keep the
       // compiler from re-ordering them.
-      wb[lane] = 0;
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) wb[k][lane] = 0;
       __builtin_amdgcn_wave_barrier();
-      if (!found && pos >= 0) atomicOr(reinterpret_cast<unsigned long long*>(wb + pos), 1ull << lane);
-      found |= pos >= 0;
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) {
+        if (!found[k] && pos[k] >= 0) atomicOr(reinterpret_cast<unsigned long long*>(wb[k] + pos[k]), 1ull << lane);
+        found[k] |= pos[k] >= 0;
+      }
       __builtin_amdgcn_wave_barrier();
-      const uint64_t m = wb[lane];
+      uint64_t m[CPL];
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) m[k] = wb[k][lane];
       __builtin_amdgcn_wave_barrier();
       if (lane < nb) {
-        W* dst = mask + (p0 + lane) * words + c * WPC;
+        W* dst = mask + (p0 + lane) * words + c * CPL * WPC;
 #pragma unroll
-        for (int w = 0; w < WPC; ++w)
-          if (c * WPC + w < words) dst[w] = static_cast<W>(m >> (w * BITS));
+        for (int k = 0; k < CPL; ++k)
+#pragma unroll
+          for (int w = 0; w < WPC; ++w)
+            if ((c * CPL + k) * WPC + w < words) dst[k * WPC + w] = static_cast<W>(m[k] >> (w * BITS));
       }
     }
-    if (live && !found) {
-      // nothing of the row claimed this element.  From the library's own forward that means arg = 0 (the value an
-      // element without a winner gets): summed here in row order, added to dX[0] by spmm_cmp_leak_kernel in slot
-      // order — the same bits on every run.  Any other target (a hand-made arg): one atomic add, like the scatter.
-      const int64_t a64 = static_cast<int64_t>(a);
-      if (a64 == 0)
-        leaked += to_acc<DT>(dz[row * F + f]);
-      else if (a64 > 0 && a64 < dx_rows)
-        atomic_add_elem<DT>(dx + a64 * F + f, dz[row * F + f]);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      if (live[k] && !found[k]) {
+        // nothing of the row claimed this element.  From the library's own forward that means arg = 0 (the value an
+        // element without a winner gets): summed here in row order, added to dX[0] by spmm_cmp_leak_kernel in slot
+        // order — the same bits on every run.  Any other target (a hand-made arg): one atomic add, like the scatter.
+        const int64_t a64 = static_cast<int64_t>(a[k]);
+        if (a64 == 0)
+          leaked[k] += to_acc<DT>(dz[row * F + f[k]]);
+        else if (a64 > 0 && a64 < dx_rows)
+          atomic_add_elem<DT>(dx + a64 * F + f[k], dz[row * F + f[k]]);
+      }
     }
   }
-  if (live) leak[slot * F + f] = leaked;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k)
+    if (live[k]) leak[slot * F + f[k]] = leaked[k];
 }
 
 // dX[0][k] += sum over the mask kernel's slots in a FIXED order: one workgroup per column, thread t sums slots
@@ -489,14 +522,17 @@ __global__ __launch_bounds__(256) void spmm_cmp_leak_kernel(const typename Acc<D
   if (threadIdx.x == 0) dx[k] = from_acc<DT>(to_acc<DT>(dx[k]) + part[0]);
 }
 
-// Launch shape of the mask kernel: every wave keeps ONE 64-column chunk; at most 8192 waves.
+// Launch shape of the mask kernel: every wave keeps ONE chunk of 64 CPL columns (two columns per lane above 64 columns, four above 128);
+// at most 8192 waves.
 struct CmpMaskShape {
   int64_t chunks, slots;
   unsigned blocks;
+  int cpl;
 };
 inline CmpMaskShape cmp_mask_shape(int64_t rows, int64_t F) {
   CmpMaskShape m;
-  m.chunks = (F + 63) / 64;
+  m.cpl = F > 128 ? 4 : (F > 64 ? 2 : 1);
+  m.chunks = (F + 64 * m.cpl - 1) / (64 * m.cpl);
   int64_t slots = std::min<int64_t>(rows, std::max<int64_t>(1, 8192 / m.chunks));
   m.blocks = static_cast<unsigned>((slots * m.chunks + 3) / 4);
   m.slots = static_cast<int64_t>(m.blocks) * 4 / m.chunks;  // what the kernel derives from its grid
@@ -516,10 +552,21 @@ int run_spmm_cmp_mask(const void* indptr, const void* indices, const void* eids,
   // the per-slot partial sums of unclaimed elements live BEHIND the mask words in the caller's buffer
   // (dgla_spmm_cmp_mask_bytes): no allocation in here, so the call can be captured in a hipGraph
   A* leak = reinterpret_cast<A*>(static_cast<char*>(mask) + cmp_mask_align(sizeof(W) * static_cast<size_t>(nnz) * words));
-  hipLaunchKernelGGL((spmm_cmp_mask_kernel<Idx, W, DT>), dim3(m.blocks), dim3(256), 0, s, static_cast<const Idx*>(indptr),
-                     static_cast<const Idx*>(indices), static_cast<const Idx*>(eids), static_cast<const Idx*>(arg), by_edge,
-                     rows, static_cast<int>(F), words, static_cast<W*>(mask), static_cast<const DT*>(dz),
-                     static_cast<DT*>(dx), dx_rows, leak);
+  if (m.cpl == 4)
+    hipLaunchKernelGGL((spmm_cmp_mask_kernel<Idx, W, DT, 4>), dim3(m.blocks), dim3(256), 0, s, static_cast<const Idx*>(indptr),
+                       static_cast<const Idx*>(indices), static_cast<const Idx*>(eids), static_cast<const Idx*>(arg), by_edge,
+                       rows, static_cast<int>(F), words, static_cast<W*>(mask), static_cast<const DT*>(dz),
+                       static_cast<DT*>(dx), dx_rows, leak);
+  else if (m.cpl == 2)
+    hipLaunchKernelGGL((spmm_cmp_mask_kernel<Idx, W, DT, 2>), dim3(m.blocks), dim3(256), 0, s, static_cast<const Idx*>(indptr),
+                       static_cast<const Idx*>(indices), static_cast<const Idx*>(eids), static_cast<const Idx*>(arg), by_edge,
+                       rows, static_cast<int>(F), words, static_cast<W*>(mask), static_cast<const DT*>(dz),
+                       static_cast<DT*>(dx), dx_rows, leak);
+  else
+    hipLaunchKernelGGL((spmm_cmp_mask_kernel<Idx, W, DT, 1>), dim3(m.blocks), dim3(256), 0, s, static_cast<const Idx*>(indptr),
+                       static_cast<const Idx*>(indices), static_cast<const Idx*>(eids), static_cast<const Idx*>(arg), by_edge,
+                       rows, static_cast<int>(F), words, static_cast<W*>(mask), static_cast<const DT*>(dz),
+                       static_cast<DT*>(dx), dx_rows, leak);
   hipLaunchKernelGGL((spmm_cmp_leak_kernel<DT>), dim3(static_cast<unsigned>(F)), dim3(256), 0, s, leak,
                      std::min<int64_t>(m.slots, rows), static_cast<int>(F), static_cast<DT*>(dx));
   DGLA_CHECK_HIP(hipGetLastError());

@@ -176,7 +176,7 @@ def _graph(dev, n, e, idtype, seed, multi=True, hub=True):
 
 @pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", [(1,), (7,), (32,), (100,), (130,), (4, 8), (2, 3, 5)])
+@pytest.mark.parametrize("shape", [(1,), (7,), (32,), (65,), (100,), (128,), (130,), (257,), (4, 8), (2, 3, 5)])
 @pytest.mark.parametrize("red", ["max", "min"])
 def test_gather_backward_equals_the_scatter_of_the_reference(dev, monkeypatch, idtype, dtype, shape, red):
     """copy_u_max / copy_u_min: dX through the winner-bit gather == ``zeros.scatter_add_(0, arg_u, dZ)`` of the
