@@ -584,8 +584,10 @@ def reduce(input, dim=None, rtype="sum"):  # noqa: A002
     scalar = v.dim() == 1
     out = _F.gspmm(gidx, "copy_rhs", _REDUCERS[rtype], None, v.unsqueeze(-1) if scalar else v) \
         if rtype != "smean" else _mean(gidx, v.unsqueeze(-1) if scalar else v)
-    if rtype in ("smax", "smin"):   # the kernels leave the reducer's identity in a row / column without a nonzero
-        out = torch.where(torch.isinf(out), torch.zeros_like(out), out)
+    if rtype in ("smax", "smin"):   # the kernels leave the reducer's identity in a row / column without a nonzero:
+        # zero exactly those (a row whose true maximum is +-inf keeps it, as scatter_reduce(include_self=False) does)
+        empty = gidx.relations[0].in_degrees() == 0
+        out = torch.where(empty.view((-1,) + (1,) * (out.dim() - 1)), torch.zeros_like(out), out)
     return out.squeeze(-1) if scalar else out
 
 

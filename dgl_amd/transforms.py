@@ -50,9 +50,11 @@ def add_self_loop(g, edge_feat_names=None, fill_data=1.0, etype=None):
     old = g._edge_frames[etid]
     frame = _Frame(int(u.shape[0]) + n)
     for k, col in old.items():
-        if edge_feat_names is not None and k not in edge_feat_names:
-            continue
         shape = (n,) + tuple(col.shape[1:])
+        if edge_feat_names is not None and k not in edge_feat_names:
+            # not named: the feature stays, the new self-loop rows are zero (the reference goes through add_edges(data=...))
+            dict.__setitem__(frame, k, torch.cat([col, torch.zeros(shape, dtype=col.dtype, device=col.device)], 0))
+            continue
         if isinstance(fill_data, str):
             if fill_data not in ("sum", "mean", "max", "min"):
                 raise DGLAMDError("Unsupported aggregation: {}".format(fill_data))

@@ -20,6 +20,8 @@ import torch
 
 from ._lib import DGLAMDError
 
+NID = EID = "_ID"   # python/dgl/base.py:14-15
+
 
 class _Rows:
     """Read-only ``{field: frame[field][index]}`` evaluated lazily (only the fields a UDF touches are gathered)."""
@@ -136,9 +138,10 @@ def _check_result(res, what, rows):
     return res
 
 
-def invoke_edge_udf(g, func, eid=None):
+def invoke_edge_udf(g, func, eid=None, orig_eid=None):
     """``func(EdgeBatch)`` over all edges (``eid`` None) or the given edge ids of the single relation of ``g``
-    (core.py:53-96).  Returns ``{field: (number of edges, ...)}`` in the order of ``eid``."""
+    (core.py:53-96).  Returns ``{field: (number of edges, ...)}`` in the order of ``eid``.  ``orig_eid``: the ids the
+    batch reports (``edges.edges()[2]``) when ``g`` is an extracted compute graph (core.py:65, 90)."""
     s_t, d_t = g.get_ntype_id_from_src(None), g.get_ntype_id_from_dst(None)
     u, v = g.edges()
     if eid is None:
@@ -148,7 +151,7 @@ def invoke_edge_udf(g, func, eid=None):
         ids = eid
         sel = eid.long()
         u, v = u[sel], v[sel]
-    ebatch = EdgeBatch(g, ids, g.canonical_etypes[0],
+    ebatch = EdgeBatch(g, ids if orig_eid is None else orig_eid, g.canonical_etypes[0],
                        _Rows(g._node_frames[s_t], u.long()), _Rows(g._edge_frames[0], sel),
                        _Rows(g._node_frames[d_t], v.long()), (u, v))
     return _check_result(func(ebatch), "message", int(ids.shape[0]))
@@ -221,7 +224,7 @@ def message_passing(g, mfunc, rfunc, afunc, fused):
         if is_builtin(mfunc):
             msgdata = _invoke_gsddmm(g, mfunc)
         else:
-            msgdata = invoke_edge_udf(g, mfunc)
+            msgdata = invoke_edge_udf(g, mfunc, orig_eid=g._edge_frames[0].get(EID))          # core.py:405-407
         # reduce phase
         if is_builtin(rfunc):
             m = rfunc.msg_field
@@ -230,10 +233,11 @@ def message_passing(g, mfunc, rfunc, afunc, fused):
                                   "produce the field the reduce function reads.".format(mfunc, rfunc))
             ndata = _invoke_gspmm(g, fn.copy_e(m, m), rfunc, edata=msgdata)
         else:
-            ndata = invoke_udf_reduce(g, rfunc, msgdata)
+            ndata = invoke_udf_reduce(g, rfunc, msgdata,
+                                      orig_nid=g._node_frames[g.get_ntype_id_from_dst(None)].get(NID))   # core.py:414-415
     if afunc is not None:
         d_t = g.get_ntype_id_from_dst(None)
         full = dict(g._node_frames[d_t])             # include original node features (core.py:416-419)
         full.update(ndata)
-        ndata = invoke_node_udf(g, afunc, d_t, ndata=full)
+        ndata = invoke_node_udf(g, afunc, d_t, ndata=full, orig_nid=g._node_frames[d_t].get(NID))   # core.py:421-423
     return ndata

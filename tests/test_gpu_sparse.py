@@ -108,6 +108,13 @@ def test_softmax_and_reductions_along_a_dimension(dev, dim, val_shape):
         assert _close(g1, g2), name
         assert _close(dglsp.reduce(A, dim, name), wantr)
     assert _close(A.sum(), vd.sum(0)) and _close(A.smax(), vd.amax(0))
+    # a row whose true maximum is -inf keeps it (only rows WITHOUT a nonzero give 0), as scatter_reduce does
+    r0 = int(row[0])
+    v2 = val.detach().clone()
+    v2[row == r0] = float("-inf")
+    B = dglsp.val_like(A, v2)
+    got = B.smax(1)
+    assert bool(torch.isinf(got[r0]).all()) and float(got[r0].reshape(-1)[0]) < 0
 
 
 @pytest.mark.parametrize("dim", [0, 1])

@@ -161,3 +161,34 @@ def test_pull_builtin_equals_pull_udf(dev):
         assert _close(r1, r2), red
         assert bool((r1[1::2] == 0).all())            # rows outside nid keep the zero initializer
         assert _close(gu1, g.ndata["u"].grad) and _close(ge1, g.edata["e"].grad), red
+
+
+def test_pull_udfs_see_the_original_ids(dev):
+    """Inside ``pull`` the UDFs run on an extracted compute graph; ``nodes.nodes()`` and ``edges.edges()[2]`` must report
+    the ORIGINAL node / edge ids (core.py:405-423 passes g.dstdata[NID] / g.edata[EID] as orig_nid / orig_eid)."""
+    import dgl_amd as dgl
+
+    g = dgl.rand_graph(60, 400, seed=5)
+    g.add_edges(g.nodes(), g.nodes())
+    g = g.to(dev)
+    g.ndata["x"] = torch.rand(60, 3, device=dev)
+    nid = torch.tensor([3, 17, 42, 59], device=dev)
+    seen = {}
+
+    def msg(edges):
+        seen["eid"] = edges.edges()[2].clone()
+        return {"m": edges.src["x"]}
+
+    def red(nodes):
+        seen.setdefault("nid", []).append(nodes.nodes().clone())
+        return {"r": nodes.mailbox["m"].sum(1)}
+
+    def app(nodes):
+        seen["apply"] = nodes.nodes().clone()
+        return {"r": nodes.data["r"] + 1}
+
+    g.pull(nid, msg, red, app)
+    _, _, want_eid = g.in_edges(nid, form="all")
+    assert sorted(seen["eid"].tolist()) == sorted(want_eid.tolist())
+    assert sorted(torch.cat(seen["nid"]).tolist()) == nid.tolist()
+    assert sorted(seen["apply"].tolist()) == nid.tolist()

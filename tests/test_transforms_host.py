@@ -21,6 +21,10 @@ def test_add_and_remove_self_loops_and_edges():
     assert h.num_edges() == 9 and u[4:].tolist() == [0, 1, 2, 3, 4] and v[4:].tolist() == [0, 1, 2, 3, 4]
     assert h.edata["w"].tolist() == [1, 2, 3, 4, 1, 1, 1, 1, 1] and torch.equal(h.ndata["x"], g.ndata["x"])
     assert dgl.add_self_loop(g, fill_data="sum").edata["w"][4:].tolist() == [4.0, 1.0, 2.0, 3.0, 0.0]
+    g2 = _g()
+    g2.edata["t"] = torch.tensor([5.0, 6.0, 7.0, 8.0])
+    h2 = dgl.add_self_loop(g2, edge_feat_names=["w"], fill_data=2.0)     # "t" is not named: kept, zeros on the new edges
+    assert h2.edata["w"][4:].tolist() == [2.0] * 5 and h2.edata["t"].tolist() == [5, 6, 7, 8, 0, 0, 0, 0, 0]
     back = dgl.remove_self_loop(h)
     assert torch.equal(back.edges()[0], g.edges()[0]) and torch.equal(back.edata["w"], g.edata["w"])
     r = dgl.remove_edges(g, [1, 3], store_ids=True)
