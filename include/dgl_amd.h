@@ -564,6 +564,10 @@ int dgla_peer_wait(const void* flags, int num_flags, uint64_t epoch, void* statu
  *                     per-column power-of-two scales — three products (hh, hl, lh) instead of six, dropped term
  *                     < 2^-22 |a b|; a row whose non-zero magnitudes span more than 2^18, or whose maximum is not finite
  *                     or outside 2^+-60, is recomputed as the plain fp32 dot product inside the same launch
+ *   DGLA_TUNE_NO_GATE dgla_spmm_csr_masked (max / min backward as a gather): gather every piece of every row.  Default (bit
+ *                     off, round 6): the bit words are fetched one batch ahead and a lane whose columns are all off for an
+ *                     edge reads a fixed cached address instead of its piece of the row — a 128-byte line of the gathered
+ *                     operand is requested only when one of its columns is wanted.  Changes no result bit (A/B switch).
  * Removed in round 4 (values retired, dgla_set_tuning rejects them): NT_OUT 2 and NT_IDX 4 (non-temporal
  * output-row stores / index-stream loads: measured neutral), SPLIT_NT 32, SPLIT_CLASSIC 256
  * (whole-row copy: 0.33 ms against 0.10), TAIL_PASS 512 (column-sliced pass over the 16-byte row tails:
@@ -576,6 +580,7 @@ int dgla_peer_wait(const void* flags, int num_flags, uint64_t epoch, void* statu
 #define DGLA_TUNE_SPLIT_FORCE 64u
 #define DGLA_TUNE_MM_F32 128u
 #define DGLA_TUNE_MM_X3 2048u
+#define DGLA_TUNE_NO_GATE 4096u
 int dgla_set_tuning(uint32_t flags);
 uint32_t dgla_get_tuning(void);
 
