@@ -2825,7 +2825,9 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_glds_f32_kernel(const
 // of fp16 pieces: no other wave's data is touched), the conversion's vector instructions placed behind the MFMAs in four
 // groups.  Epilogue: (acc0 + 2^-11 acc1) / (scale_A[i] scale_C[j]) — exact power-of-two factors — added with the fp32
 // atomics of the split-K scheme.  80 KB of LDS = a ring of five slots (one multiplied, one converted, three in flight), two
-// workgroups per CU.
+// workgroups of eight waves per CU.  What bounds it (profiles/r6/segment_mm_dB_two_term.jsonl): on this chip the vector and
+// the matrix instructions of a SIMD do not overlap — compute alone takes VALU (139 instructions x 4 cycles) + MFMA (12 x 32
+// cycles) per wave and slot, 4.7 ms — and the memory side (3.9 ms alone) overlaps with that only in part.
 constexpr int64_t kH2bMinRows = 16384;  // smaller calls take the three-term kernel
 constexpr int kH2bSample = 2048;       // rows per relation the scale estimate looks at
 constexpr int kH2bChunks = 16;         // workgroups per relation of the sampling kernel
@@ -2904,12 +2906,15 @@ __device__ __forceinline__ bool h2b_listed(float x, float s) {
 }
 
 constexpr int kH2bSlots = 5;
-__global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_h2_kernel(const H2bParams hp) {
+// EIGHT waves per workgroup: a wave multiplies a 32 x 64 piece of the 128 x 128 tile (64 accumulator registers in two sets)
+// and converts 8 elements per slot (waves 0-3: A, waves 4-7: dC), 123 VGPRs, so two workgroups = four waves per SIMD fit.
+// (A first form with four waves of 64 x 64 — 215 VGPRs, two waves per SIMD — ran 6.90 ms against 6.63.)
+__global__ __launch_bounds__(512, 2) void segment_mm_bwd_b_h2_kernel(const H2bParams hp) {
   const MmBwdParams& p = hp.m;
   constexpr int NS = kH2bSlots;
   constexpr int kPart = kBwdGldsRowsF32 * 512;  // one operand of a slot: 16 rows x 128 features x 4 B
   constexpr int kSlot = 2 * kPart;
-  constexpr int kLoads = 4;                     // DMA instructions per wave and slot
+  constexpr int kLoads = 2;                     // DMA instructions per wave and slot
   __shared__ __attribute__((aligned(1024))) char smem[NS * kSlot];
 
   const int64_t L = blockIdx.x;
@@ -2928,27 +2933,22 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
   const int D1 = p.D1, D2 = p.D2;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  f32x16 acc0[2][2], acc1[2][2];
+  const int wm = wave >> 1, wn = wave & 1;   // A tile wm (features 32 wm ..), dC tiles 2 wn, 2 wn + 1
+  f32x16 acc0[2], acc1[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[i][j][r] = acc1[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc0[j][r] = acc1[j][r] = 0.f;
 
-  // DMA (as in segment_mm_bwd_b_glds_f32_kernel): instruction n of a wave covers slot rows 4 wave + 2 n, + 1
-  int drow[2];
-  int64_t offA[2], offC[2];
-#pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int r = 4 * wave + 2 * n + (lane >> 5);
-    drow[n] = r;
+  // DMA: one instruction per operand and wave: slot rows 2 wave (lanes 0-31), 2 wave + 1 (lanes 32-63)
+  const int drow = 2 * wave + (lane >> 5);
+  int64_t offA, offC;
+  {
     int fa = i0 + (lane & 31) * 4, fc = j0 + (lane & 31) * 4;
     if (fa >= D1) fa = D1 - 4;
     if (fc >= D2) fc = D2 - 4;
-    offA[n] = (static_cast<int64_t>(r) * D1 + fa) * 4;
-    offC[n] = (static_cast<int64_t>(r) * D2 + fc) * 4;
+    offA = (static_cast<int64_t>(drow) * D1 + fa) * 4;
+    offC = (static_cast<int64_t>(drow) * D2 + fc) * 4;
   }
   const char* __restrict__ baseA = static_cast<const char*>(p.a) + m0 * D1 * 4;
   const char* __restrict__ baseC = static_cast<const char*>(p.dc) + m0 * D2 * 4;
@@ -2956,16 +2956,13 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
   const int nsl = static_cast<int>((rows + kBwdGldsRowsF32 - 1) / kBwdGldsRowsF32);
   auto issue = [&](int t) {
     if (t >= nsl) return;
-    char* dst = smem + (t % NS) * kSlot + wave * 2048;
+    char* dst = smem + (t % NS) * kSlot + wave * 1024;
     const int64_t mrow = static_cast<int64_t>(t) * kBwdGldsRowsF32;
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const bool in = mrow + drow[n] < rows;
-      const char* sa = in ? baseA + mrow * D1 * 4 + offA[n] : g_mm_zero_page;
-      const char* sc = in ? baseC + mrow * D2 * 4 + offC[n] : g_mm_zero_page;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)sa, (lds_ptr_t)(dst + n * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)sc, (lds_ptr_t)(dst + kPart + n * 1024), 16, 0, 0);
-    }
+    const bool in = mrow + drow < rows;
+    const char* sa = in ? baseA + mrow * D1 * 4 + offA : g_mm_zero_page;
+    const char* sc = in ? baseC + mrow * D2 * 4 + offC : g_mm_zero_page;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)sa, (lds_ptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)sc, (lds_ptr_t)(dst + kPart), 16, 0, 0);
   };
   // this wave's DMA of a slot has landed while `later` slots issued behind it may stay in flight; lgkmcnt(0) with it:
   // the wave's own LDS writes (the converted pieces) are out before the barrier that follows
@@ -2984,21 +2981,21 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
   // 64 + 64 sixteen-byte pieces (high plane, low plane) into the same 2 KB — rows 8 ckh + (j >> 4) (+ 4 for the low plane),
   // byte (fpos >> 6) 256 + (j & 15) 16 for feature j = fpos & 63 — so no other wave's data is touched and the slot needs
   // no second buffer.
-  const int fpos = tid & 127, ckh = tid >> 7;
+  const int fpos = tid & 127, ckh = (tid >> 7) & 1, cop = tid >> 8;   // waves 0-3 convert A, waves 4-7 dC
   const int64_t tab = rel * static_cast<int64_t>(D1 + D2);
   // the column a feature position holds (DMA lanes past the width were clamped to the last four columns; such positions
   // get the scale 0: their products land in accumulator rows / columns that are never stored)
-  const bool liveA = i0 + fpos < D1, liveC = j0 + fpos < D2;
-  const int colA = liveA ? i0 + fpos : 0, colC = liveC ? j0 + fpos : 0;
-  const float sA = liveA ? hp.scale[tab + colA] : 0.f, sC = liveC ? hp.scale[tab + D1 + colC] : 0.f;
+  const bool liveX = cop ? j0 + fpos < D2 : i0 + fpos < D1;
+  const int colX = liveX ? (cop ? j0 : i0) + fpos : 0;
+  const int64_t tabX = tab + (cop ? D1 : 0) + colX;
+  const float sX = liveX ? hp.scale[tabX] : 0.f;
   // an element is LISTED (removed from both planes, added in fp32 by h2_bwd_fix_kernel) when its high term is subnormal
   // (|x s| < 2^-14) and the pair is not zero: key = |h| | |l| as 15-bit patterns is then in [1, 0x400) — a normal high term
   // makes the key >= 0x400 whatever the low term holds, and a zero high term leaves a low term below 2^-14 as well.  In a
   // column whose sample was all zero (limit 1) ANY non-zero pattern takes that path and raises the flag instead.
   // Only one of the workgroups that convert the same rows lists them (tile column 0 for A, tile row 0 for dC).
-  const bool listA = (tile % p.tiles_j) == 0, listC = (tile / p.tiles_j) == 0;
-  const uint32_t thrA = (liveA && hp.limit[tab + colA] == 1u) ? 0x8000u : kH2bTiny;
-  const uint32_t thrC = (liveC && hp.limit[tab + D1 + colC] == 1u) ? 0x8000u : kH2bTiny;
+  const bool listX = cop ? (tile / p.tiles_j) == 0 : (tile % p.tiles_j) == 0;
+  const uint32_t thrX = (liveX && hp.limit[tabX] == 1u) ? 0x8000u : kH2bTiny;
   typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
   typedef float f32x2v __attribute__((ext_vector_type(2)));
 
@@ -3056,10 +3053,11 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
   auto flagged = [&](const Conv& c, uint32_t thr) { return c.mn[0] < thr - 1u || c.mn[1] < thr - 1u; };
 
   const int f = lane & 31, kh = lane >> 5;
-  const int src_off = ckh * 8 * 512 + fpos * 4;
-  const int dst_off = (ckh * 8 + ((fpos & 63) >> 4)) * 512 + (fpos >> 6) * 256 + (fpos & 15) * 16;
-  // fragment of MFMA tile i of this wave: features 64 w + 32 i + f  ->  piece row 8 kh + 2 i + (f >> 4)
-  const int fragA = (kh * 8 + (f >> 4)) * 512 + wm * 256 + (f & 15) * 16;
+  const int src_off = cop * kPart + ckh * 8 * 512 + fpos * 4;
+  const int dst_off = cop * kPart + (ckh * 8 + ((fpos & 63) >> 4)) * 512 + (fpos >> 6) * 256 + (fpos & 15) * 16;
+  // fragments: A tile wm = features 32 wm + f -> piece row 8 kh + 2 (wm & 1) + (f >> 4), byte (wm >> 1) 256;
+  // dC tile j = features 64 wn + 32 j + f -> piece row 8 kh + 2 j + (f >> 4), byte wn 256
+  const int fragA = (kh * 8 + 2 * (wm & 1) + (f >> 4)) * 512 + (wm >> 1) * 256 + (f & 15) * 16;
   const int fragC = kPart + (kh * 8 + (f >> 4)) * 512 + wn * 256 + (f & 15) * 16;
 #pragma unroll
   for (int i = 0; i < NS - 1; ++i) issue(i);
@@ -3067,20 +3065,14 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
   {
     wait_for_slot(nsl - 1 < 3 ? nsl - 1 : 3);
     __builtin_amdgcn_s_barrier();
-    float xa[8], xc[8];
-    load8(smem + src_off, xa);
-    load8(smem + kPart + src_off, xc);
-    Conv ca, cc;
-    ca.mn = cc.mn = u16x2{0xffff, 0xffff};
+    float xx[8];
+    load8(smem + src_off, xx);
+    Conv cx;
+    cx.mn = u16x2{0xffff, 0xffff};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      split_pair(xa[2 * q], xa[2 * q + 1], sA, ca, q);
-      split_pair(xc[2 * q], xc[2 * q + 1], sC, cc, q);
-    }
-    put(smem + dst_off, ca);
-    put(smem + kPart + dst_off, cc);
-    if (__builtin_expect(flagged(ca, thrA), 0)) slow(smem + dst_off, ca, thrA, 0, colA, m0 + ckh * 8, listA);
-    if (__builtin_expect(flagged(cc, thrC), 0)) slow(smem + kPart + dst_off, cc, thrC, 1, colC, m0 + ckh * 8, listC);
+    for (int q = 0; q < 4; ++q) split_pair(xx[2 * q], xx[2 * q + 1], sX, cx, q);
+    put(smem + dst_off, cx);
+    if (__builtin_expect(flagged(cx, thrX), 0)) slow(smem + dst_off, cx, thrX, cop, colX, m0 + ckh * 8, listX);
   }
   for (int t = 0; t < nsl; ++t) {
     // slot t + 1 has landed (slots up to t + 3 are under way), this wave's converted pieces of slot t are out
@@ -3096,46 +3088,29 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
     const bool more = t + 1 < nsl;     // (uniform; the last pass converts a stale slot nobody reads)
     const char* pa0 = stg + fragA;
     const char* pb0 = stg + fragC;
-#define DGLA_H2B_MFMA(i, j, AH, AL, BH, BL)                                                  \
-  acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH, acc1[i][j], 0, 0, 0);          \
-  acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, acc0[i][j], 0, 0, 0);          \
-  acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL, acc1[i][j], 0, 0, 0);
-    // the next slot's conversion between the MFMAs of this one: four groups of three MFMAs, a quarter of the
-    // conversion's vector instructions issued behind each (the matrix pipe runs them while the wave goes on); fragments
-    // and fp32 rows are read group by group to keep the live registers under the 256 the two-workgroup occupancy allows
-    Conv ca, cc;
-    ca.mn = cc.mn = u16x2{0xffff, 0xffff};
+#define DGLA_H2B_MFMA(j, AH, AL, BH, BL)                                               \
+  acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH, acc1[j], 0, 0, 0);          \
+  acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, acc0[j], 0, 0, 0);          \
+  acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL, acc1[j], 0, 0, 0);
+    Conv cx;
+    cx.mn = u16x2{0xffff, 0xffff};
     float x[8];
-    const h16x8 ah0 = *reinterpret_cast<const h16x8*>(pa0), al0 = *reinterpret_cast<const h16x8*>(pa0 + 2048);
+    const h16x8 ah = *reinterpret_cast<const h16x8*>(pa0), al = *reinterpret_cast<const h16x8*>(pa0 + 2048);
     h16x8 bh = *reinterpret_cast<const h16x8*>(pb0), bl = *reinterpret_cast<const h16x8*>(pb0 + 2048);
     load8(slot + src_off, x);
-    DGLA_H2B_MFMA(0, 0, ah0, al0, bh, bl)
-    split_pair(x[0], x[1], sA, ca, 0);
-    split_pair(x[2], x[3], sA, ca, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    const h16x8 ah1 = *reinterpret_cast<const h16x8*>(pa0 + 1024), al1 = *reinterpret_cast<const h16x8*>(pa0 + 2048 + 1024);
-    DGLA_H2B_MFMA(1, 0, ah1, al1, bh, bl)
-    split_pair(x[4], x[5], sA, ca, 2);
-    split_pair(x[6], x[7], sA, ca, 3);
-    put(slot + dst_off, ca);
+    DGLA_H2B_MFMA(0, ah, al, bh, bl)
+    split_pair(x[0], x[1], sX, cx, 0);
+    split_pair(x[2], x[3], sX, cx, 1);
     __builtin_amdgcn_sched_barrier(0);
     bh = *reinterpret_cast<const h16x8*>(pb0 + 1024);
     bl = *reinterpret_cast<const h16x8*>(pb0 + 2048 + 1024);
-    load8(slot + kPart + src_off, x);
-    DGLA_H2B_MFMA(1, 1, ah1, al1, bh, bl)
-    split_pair(x[0], x[1], sC, cc, 0);
-    split_pair(x[2], x[3], sC, cc, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    DGLA_H2B_MFMA(0, 1, ah0, al0, bh, bl)
-    split_pair(x[4], x[5], sC, cc, 2);
-    split_pair(x[6], x[7], sC, cc, 3);
-    put(slot + kPart + dst_off, cc);
+    DGLA_H2B_MFMA(1, ah, al, bh, bl)
+    split_pair(x[4], x[5], sX, cx, 2);
+    split_pair(x[6], x[7], sX, cx, 3);
+    put(slot + dst_off, cx);
 #undef DGLA_H2B_MFMA
-    if (__builtin_expect(more && (flagged(ca, thrA) || flagged(cc, thrC)), 0)) {
-      const int64_t row0 = m0 + static_cast<int64_t>(t + 1) * kBwdGldsRowsF32 + ckh * 8;
-      if (flagged(ca, thrA)) slow(slot + dst_off, ca, thrA, 0, colA, row0, listA);
-      if (flagged(cc, thrC)) slow(slot + kPart + dst_off, cc, thrC, 1, colC, row0, listC);
-    }
+    if (__builtin_expect(more && flagged(cx, thrX), 0))
+      slow(slot + dst_off, cx, thrX, cop, colX, m0 + static_cast<int64_t>(t + 1) * kBwdGldsRowsF32 + ckh * 8, listX);
   }
 
   // overflow of a scaled value (a column whose maximum lies above what its sample showed; Inf; NaN) arrives as a
@@ -3143,11 +3118,9 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
   {
     bool bad = false;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bad |= !(__builtin_fabsf(acc0[i][j][r]) < __builtin_inff());
+      for (int r = 0; r < 16; ++r) bad |= !(__builtin_fabsf(acc0[j][r]) < __builtin_inff());
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0) && lane == 0) atomicOr(hp.flags, 1u);
   }
   float* out = p.acc + rel * static_cast<int64_t>(D1) * D2;
@@ -3155,21 +3128,19 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
   const float* invA = hp.inv + tab;
   const float* invC = hp.inv + tab + D1;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 2; ++j) {
+    const int col = j0 + wn * 64 + j * 32 + col_l;
+    if (col >= D2) continue;
+    const float ic = invC[col];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = j0 + wn * 64 + j * 32 + col_l;
-      if (col >= D2) continue;
-      const float ic = invC[col];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-        if (row < D1) {
-          const float v = __builtin_fmaf(acc1[i][j][r], 0x1p-11f, acc0[i][j][r]);
-          atomicAdd(out + static_cast<int64_t>(row) * D2 + col, v * invA[row] * ic);
-        }
+    for (int r = 0; r < 16; ++r) {
+      const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+      if (row < D1) {
+        const float v = __builtin_fmaf(acc1[j][r], 0x1p-11f, acc0[j][r]);
+        atomicAdd(out + static_cast<int64_t>(row) * D2 + col, v * invA[row] * ic);
       }
     }
+  }
 }
 
 // The listed elements' rank-one contributions, in plain fp32 (one workgroup per entry).
@@ -3304,7 +3275,7 @@ int run_segment_mm_bwd_b(const void* a, const void* dc, void* db, int64_t M, int
         hipLaunchKernelGGL(h2_bwd_sample_kernel, dim3(static_cast<unsigned>(num_rel * kH2bChunks)), dim3(256), 0, s, p, umax);
         hipLaunchKernelGGL(h2_bwd_scales_kernel, dim3(static_cast<unsigned>((ncol + 255) / 256)), dim3(256), 0, s, umax, ncol,
                            const_cast<float*>(hp.scale), const_cast<float*>(hp.inv), const_cast<uint32_t*>(hp.limit), hp.flags);
-        hipLaunchKernelGGL(segment_mm_bwd_b_h2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, hp);
+        hipLaunchKernelGGL(segment_mm_bwd_b_h2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(512), 0, s, hp);
         hipLaunchKernelGGL(h2_bwd_fix_kernel, dim3(256), dim3(256), 0, s, hp);
         hipLaunchKernelGGL(h2_bwd_reset_kernel, dim3(256), dim3(256), 0, s, hp.flags, acc, out_elems);
         p.only_if = hp.flags;
