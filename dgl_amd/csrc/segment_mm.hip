@@ -2801,8 +2801,8 @@ __global__ __launch_bounds__(256, 2) void segment_mm_bwd_b_glds_f32_kernel(const
 // saves, so the scale is an ESTIMATE that the main kernel VERIFIES while it converts:
 //   * h2_bwd_sample_kernel: largest |x| per (relation, column) over <= kH2bSample rows spread evenly over the segment
 //     (33 MB at 8 x 512 columns); h2_bwd_scales_kernel puts it into [2^11, 2^12): five binades of head room for the rows
-//     the sample did not see.  A column whose sample is all zero gets the scale 2^126, under which ANY non-zero fp32
-//     value converts to a non-zero or infinite fp16.
+//     the sample did not see.  A column whose sample is all zero gets the scale 2^115, under which ANY non-zero fp32
+//     value leaves a non-zero or infinite pattern in the planes.
 //   * an fp16 overflow (a value above 32 x its column's sample maximum, Inf, NaN) turns every output of its row / column
 //     into Inf or NaN: the epilogue looks at its accumulators and raises flags[0]; so does anything non-zero in a
 //     zero-sample column (found by the test of the next item), a sample maximum that is Inf / NaN / outside 2^+-60, and
@@ -2883,7 +2883,9 @@ __global__ __launch_bounds__(256) void h2_bwd_scales_kernel(const uint32_t* __re
   const int e = static_cast<int>(u >> 23);
   uint32_t sb = 127u << 23, ib = 127u << 23, lim = 0x7c00u;
   if (u == 0u) {
-    sb = 253u << 23;   // 2^126: every non-zero fp32 value, denormals included, becomes a non-zero (or infinite) fp16
+    sb = 242u << 23;   // 2^115 (2^126 with the low term's 2^11): every non-zero fp32 value, denormals included, leaves a
+                       // non-zero (or infinite) pattern in the low plane; a zero stays zero (2^126 itself would make the
+                       // low term's factor 2^137 = inf and 0 x inf = NaN)
     lim = 1u;
   } else if (e < kH2MinExp || e > kH2MaxExp) {
     atomicOr(flags, 1u);   // Inf / NaN / a magnitude whose unscaling could leave fp32's range: not this kernel's case
@@ -2954,9 +2956,9 @@ __global__ __launch_bounds__(512, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
   const char* __restrict__ baseC = static_cast<const char*>(p.dc) + m0 * D2 * 4;
   const int64_t rows = m1 - m0;
   const int nsl = static_cast<int>((rows + kBwdGldsRowsF32 - 1) / kBwdGldsRowsF32);
-  auto issue = [&](int t) {
+  auto issue = [&](int t, int ring) {   // `ring` = t % NS, a compile-time constant at every call site
     if (t >= nsl) return;
-    char* dst = smem + (t % NS) * kSlot + wave * 1024;
+    char* dst = smem + ring * kSlot + wave * 1024;
     const int64_t mrow = static_cast<int64_t>(t) * kBwdGldsRowsF32;
     const bool in = mrow + drow < rows;
     const char* sa = in ? baseA + mrow * D1 * 4 + offA : g_mm_zero_page;
@@ -2998,6 +3000,7 @@ __global__ __launch_bounds__(512, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
   const uint32_t thrX = (liveX && hp.limit[tabX] == 1u) ? 0x8000u : kH2bTiny;
   typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
   typedef float f32x2v __attribute__((ext_vector_type(2)));
+  const f32x2v spX = {sX, sX * 2048.f};
 
   struct Conv {
     uint32_t hw[4], lw[4];
@@ -3007,15 +3010,26 @@ __global__ __launch_bounds__(512, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
 #pragma unroll
     for (int r = 0; r < 8; ++r) x[r] = *reinterpret_cast<const float*>(src + r * 512);
   };
-  auto split_pair = [&](float x0, float x1, float s, Conv& c, int q) {
-    const f32x2v v = f32x2v{x0, x1} * s;
+  auto split_pair = [&](float x0, float x1, f32x2v sp, Conv& c, int q) {   // sp = (scale, 2^11 scale)
+    const f32x2v xp = f32x2v{x0, x1};
+    f32x2v v, w;   // x s and 2^11 x s (exact): packed multiplies, the scale pair's low / high word for both lanes
+    // (the scale pairs are broadcast in registers: with op_sel picking one word of a (scale, 2^11 scale) pair for both lanes the
+    // products came out wrong on this chip)
+    {
+      const f32x2v s_lo = {sp[0], sp[0]}, s_hi = {sp[1], sp[1]};
+      asm("v_pk_mul_f32 %0, %1, %2" : "=v"(v) : "v"(xp), "v"(s_lo));
+      asm("v_pk_mul_f32 %0, %1, %2" : "=v"(w) : "v"(xp), "v"(s_hi));
+    }
     const h16x2v hb = __builtin_convertvector(v, h16x2v);                      // round to nearest
-    const f32x2v r = (v - __builtin_convertvector(hb, f32x2v)) * 2048.f;       // exact difference, exact scaling
-    const h16x2v lb = __builtin_convertvector(r, h16x2v);
     c.hw[q] = __builtin_bit_cast(uint32_t, hb);
+    float d0, d1;                                          // 2^11 (x s - h) = w - 2^11 h: one mixed-precision fma each, exact
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(c.hw[q]), "s"(-2048.f), "v"(w[0]));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(c.hw[q]), "s"(-2048.f), "v"(w[1]));
+    const h16x2v lb = __builtin_convertvector(f32x2v{d0, d1}, h16x2v);
     c.lw[q] = __builtin_bit_cast(uint32_t, lb);
-    const u16x2 key = __builtin_bit_cast(u16x2, (c.hw[q] | c.lw[q]) & 0x7fff7fffu);
-    c.mn = __builtin_elementwise_min(c.mn, key - u16x2{1, 1});                  // zero -> 0xffff
+    // key = |h| | |l| with the sign bits forced on (one v_or3), minus 0x8001: zero -> 0xffff, a listed pattern -> below 0x3ff
+    const u16x2 key = __builtin_bit_cast(u16x2, c.hw[q] | c.lw[q] | 0x80008000u);
+    c.mn = __builtin_elementwise_min(c.mn, key - u16x2{0x8001, 0x8001});
   };
   auto put = [&](char* dsth, const Conv& c) {
     *reinterpret_cast<u32x4*>(dsth) = u32x4{c.hw[0], c.hw[1], c.hw[2], c.hw[3]};
@@ -3060,7 +3074,7 @@ __global__ __launch_bounds__(512, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
   const int fragA = (kh * 8 + 2 * (wm & 1) + (f >> 4)) * 512 + (wm >> 1) * 256 + (f & 15) * 16;
   const int fragC = kPart + (kh * 8 + (f >> 4)) * 512 + wn * 256 + (f & 15) * 16;
 #pragma unroll
-  for (int i = 0; i < NS - 1; ++i) issue(i);
+  for (int i = 0; i < NS - 1; ++i) issue(i, i);
   // slot 0, converted where it lies
   {
     wait_for_slot(nsl - 1 < 3 ? nsl - 1 : 3);
@@ -3070,11 +3084,17 @@ __global__ __launch_bounds__(512, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
     Conv cx;
     cx.mn = u16x2{0xffff, 0xffff};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) split_pair(xx[2 * q], xx[2 * q + 1], sX, cx, q);
+    for (int q = 0; q < 4; ++q) split_pair(xx[2 * q], xx[2 * q + 1], spX, cx, q);
     put(smem + dst_off, cx);
     if (__builtin_expect(flagged(cx, thrX), 0)) slow(smem + dst_off, cx, thrX, cop, colX, m0 + ckh * 8, listX);
   }
-  for (int t = 0; t < nsl; ++t) {
+  // the ring is walked in rounds of NS slots with the round unrolled: every LDS address is a per-thread base plus an immediate
+  // (the t % NS arithmetic per slot cost 14 of the loop's 72 vector instructions)
+  for (int t0 = 0; t0 < nsl; t0 += NS) {
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const int t = t0 + u;
+    if (t >= nsl) break;
     // slot t + 1 has landed (slots up to t + 3 are under way), this wave's converted pieces of slot t are out
     const int behind = nsl - 2 - t;
     if (behind >= 0)
@@ -3082,9 +3102,9 @@ __global__ __launch_bounds__(512, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
     else
       __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();      // every wave: slot t converted, the fragments of slot t - 1 read
-    issue(t + NS - 1);                 // into the slot that held t - 1
-    const char* stg = smem + (t % NS) * kSlot;
-    char* slot = smem + ((t + 1) % NS) * kSlot;
+    issue(t + NS - 1, (u + NS - 1) % NS);   // into the slot that held t - 1
+    const char* stg = smem + u * kSlot;
+    char* slot = smem + ((u + 1) % NS) * kSlot;
     const bool more = t + 1 < nsl;     // (uniform; the last pass converts a stale slot nobody reads)
     const char* pa0 = stg + fragA;
     const char* pb0 = stg + fragC;
@@ -3099,18 +3119,19 @@ __global__ __launch_bounds__(512, 2) void segment_mm_bwd_b_h2_kernel(const H2bPa
     h16x8 bh = *reinterpret_cast<const h16x8*>(pb0), bl = *reinterpret_cast<const h16x8*>(pb0 + 2048);
     load8(slot + src_off, x);
     DGLA_H2B_MFMA(0, ah, al, bh, bl)
-    split_pair(x[0], x[1], sX, cx, 0);
-    split_pair(x[2], x[3], sX, cx, 1);
+    split_pair(x[0], x[1], spX, cx, 0);
+    split_pair(x[2], x[3], spX, cx, 1);
     __builtin_amdgcn_sched_barrier(0);
     bh = *reinterpret_cast<const h16x8*>(pb0 + 1024);
     bl = *reinterpret_cast<const h16x8*>(pb0 + 2048 + 1024);
     DGLA_H2B_MFMA(1, ah, al, bh, bl)
-    split_pair(x[4], x[5], sX, cx, 2);
-    split_pair(x[6], x[7], sX, cx, 3);
+    split_pair(x[4], x[5], spX, cx, 2);
+    split_pair(x[6], x[7], spX, cx, 3);
     put(slot + dst_off, cx);
 #undef DGLA_H2B_MFMA
     if (__builtin_expect(more && flagged(cx, thrX), 0))
       slow(slot + dst_off, cx, thrX, cop, colX, m0 + static_cast<int64_t>(t + 1) * kBwdGldsRowsF32 + ckh * 8, listX);
+  }
   }
 
   // overflow of a scaled value (a column whose maximum lies above what its sample showed; Inf; NaN) arrives as a
