@@ -653,7 +653,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
     }
   };
   [[maybe_unused]] const XV* const gate_dummy =
-      reinterpret_cast<const XV*>(edge_layout ? static_cast<const DT*>(p.umain) : static_cast<const DT*>(p.ufeat)) + (lane & 7);
+      reinterpret_cast<const XV*>(edge_layout ? static_cast<const DT*>(p.umain) : static_cast<const DT*>(p.ufeat));   // (the first piece of the operand: always inside it)
   [[maybe_unused]] auto load_x_gated = [&](int e, Batch& b) {
     if constexpr (kGated) {
       constexpr int BITS = 8 * static_cast<int>(sizeof(DT));
