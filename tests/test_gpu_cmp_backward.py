@@ -322,3 +322,29 @@ def test_gather_backward_replays_inside_a_hipgraph(dev):
         ex = sx.detach().clone().requires_grad_()
         dgl.ops.copy_u_max(g, ex).backward(sup)
         assert torch.equal(got, ex.grad)
+
+
+@pytest.mark.parametrize("feat", [4, 36, 100, 256])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gated_row_gathers_change_no_bit(dev, feat, dtype):
+    """The masked g-SpMM fetches a row piece only when one of its columns is wanted (round 6); DGLA_TUNE_NO_GATE gathers
+    every piece as before.  Same bits either way, hub row and rows without in-edges included."""
+    import dgl_amd as dgl
+    from dgl_amd import _capi
+
+    n, e = 3000, 60000
+    g, src, dst = _graph(dev, n, e, torch.int32, seed=feat)
+    gen = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn(n, feat, device=dev, generator=gen).to(dtype).requires_grad_()
+    up = torch.randn(n, feat, device=dev, generator=gen).to(dtype)
+    default = _capi.get_tuning()
+    got = []
+    try:
+        for flags in (default, default | _capi.TUNE_NO_GATE):
+            _capi.set_tuning(flags)
+            x.grad = None
+            dgl.ops.copy_u_max(g, x).backward(up)
+            got.append(x.grad.clone())
+    finally:
+        _capi.set_tuning(default)
+    assert torch.equal(got[0], got[1])
