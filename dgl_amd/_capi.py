@@ -338,14 +338,18 @@ def spmm_cmp_mask_bytes(dtype, num_rows, nnz, feat_len):
     return int(LIB.dgla_spmm_cmp_mask_bytes(_DTYPES[dtype], int(num_rows), int(nnz), int(feat_len)))
 
 
-def spmm_cmp_mask(csr, arg, dz, mask, dx, by_edge=False):
+CMP_MASK_DEFER, CMP_MASK_FINISH = 0x100, 0x200   # include/dgl_amd.h DGLA_CMP_MASK_*
+
+
+def spmm_cmp_mask(csr, arg, dz, mask, dx, by_edge=False, mode=0):
     """Winner bits of a max / min g-SpMM over the FORWARD matrix `csr` (dgla_spmm_cmp_mask): for every edge in
     position order, one bit per output column; elements no edge claims go to ``dx[arg]`` here (``dx`` zeroed by
-    the caller)."""
+    the caller).  ``mode=CMP_MASK_DEFER``: ``dx`` is not touched (the masked g-SpMM then stores instead of accumulating);
+    the same call with ``mode=CMP_MASK_FINISH`` behind the g-SpMM adds what was kept aside."""
     keep = []
     tz, tx = _tensor(dz, keep), _tensor(dx, keep)
     _require_gpu(arg)
-    check_call(LIB.dgla_spmm_cmp_mask(ctypes.byref(csr), _DTYPES[dz.dtype], arg.data_ptr(), 1 if by_edge else 0,
+    check_call(LIB.dgla_spmm_cmp_mask(ctypes.byref(csr), _DTYPES[dz.dtype], arg.data_ptr(), (1 if by_edge else 0) | int(mode),
                                       ctypes.byref(tz), _ptr(mask), ctypes.byref(tx), _stream(dx)))
 
 

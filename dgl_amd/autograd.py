@@ -130,16 +130,20 @@ def _cmp_backward_node_gather(gidx, dZ, arg_u, rows):
         cache["csr"] = _capi.make_csr(rip, ridx, pmap.contiguous(), rel.num_dst)
         cache["ws"] = {}
     dz2 = dZ.reshape(dZ.shape[0], feat)
-    dX = torch.zeros(rows, feat, dtype=dZ.dtype, device=dZ.device)
+    # two-step form: the bit kernel leaves dX alone, the gated g-SpMM STORES its rows (no zero fill, no read of dX), the finish
+    # call adds the elements no edge claimed (dX[0]; and whatever a hand-made arg names)
+    dX = torch.empty(rows, feat, dtype=dZ.dtype, device=dZ.device)
     mask = torch.empty(_capi.spmm_cmp_mask_bytes(dZ.dtype, dZ.shape[0], n_edges, feat), dtype=torch.uint8, device=dZ.device)
-    _capi.spmm_cmp_mask(cache["fwd"], arg_u.reshape(arg_u.shape[0], feat).contiguous(), dz2, mask, dX)
+    arg2 = arg_u.reshape(arg_u.shape[0], feat).contiguous()
+    _capi.spmm_cmp_mask(cache["fwd"], arg2, dz2, mask, dX, mode=_capi.CMP_MASK_DEFER)
     key = (dZ.dtype, feat)
     ws = cache["ws"].get(key)
     fresh = ws is None
     if fresh:
         ws = cache["ws"][key] = torch.empty(max(int(_capi.spmm_csr_masked_workspace_bytes(cache["csr"], dz2, dX)), 1),
                                             dtype=torch.uint8, device=dZ.device)
-    _capi.spmm_csr_masked(cache["csr"], dz2, mask, dX, workspace=ws, accumulate=True, plan_valid=not fresh)
+    _capi.spmm_csr_masked(cache["csr"], dz2, mask, dX, workspace=ws, accumulate=False, plan_valid=not fresh)
+    _capi.spmm_cmp_mask(cache["fwd"], arg2, dz2, mask, dX, mode=_capi.CMP_MASK_FINISH)
     return dX.reshape((rows,) + tuple(dZ.shape[1:]))
 
 

@@ -395,12 +395,22 @@ __device__ __forceinline__ int64_t bcast_lane(int64_t v, int j) {
 // CPL columns per lane (round 6): a wave covers 64 CPL columns of a row — F = 100 is ONE wave per row with two columns per lane
 // instead of two waves (the second with 36 live lanes): the per-row overhead and the key broadcast are paid once
 // (mask kernel 1.68 -> see profiles/r6/cmp_backward_gated.jsonl).
-template <typename Idx, typename W, typename DT, int CPL>
+// MODE 0: bits, the partial sums of unclaimed elements, and the atomic add of an unclaimed element with a non-zero target (a
+//         hand-made arg), all in one launch: dx must be zeroed before and the masked g-SpMM must accumulate into it.
+// MODE 1 (DGLA_CMP_MASK_DEFER): bits and partial sums only — dx is NOT touched, so the masked g-SpMM can STORE its rows (no
+//         zero fill, no read of dx); an unclaimed element with a non-zero target only raises `rare`.
+// MODE 2 (DGLA_CMP_MASK_FINISH, launched behind the g-SpMM): exits on its first load unless `rare` is up; else scans again and
+//         does those atomic adds.  (The sums for dX[0] are added by spmm_cmp_leak_kernel behind it.)
+template <typename Idx, typename W, typename DT, int CPL, int MODE>
 __global__ __launch_bounds__(256) void spmm_cmp_mask_kernel(
     const Idx* __restrict__ indptr, const Idx* __restrict__ indices, const Idx* __restrict__ eids,
     const Idx* __restrict__ arg, int by_edge, int64_t rows, int F, int words, W* __restrict__ mask,
-    const DT* __restrict__ dz, DT* __restrict__ dx, int64_t dx_rows, typename Acc<DT>::type* __restrict__ leak) {
+    const DT* __restrict__ dz, DT* __restrict__ dx, int64_t dx_rows, typename Acc<DT>::type* __restrict__ leak,
+    uint32_t* __restrict__ rare) {
   using A = typename Acc<DT>::type;
+  if constexpr (MODE == 2) {
+    if (*rare == 0u) return;
+  }
   constexpr int BITS = 8 * static_cast<int>(sizeof(W));
   constexpr int WPC = 64 / BITS;  // words per 64 columns
   const int chunks = (F + 64 * CPL - 1) / (64 * CPL);
@@ -462,26 +472,31 @@ __global__ __launch_bounds__(256) void spmm_cmp_mask_kernel(
       // column -> edge: every winning column ORs its bit into its edge's word (one LDS atomic per lane), then lane j
       // picks up the word(s) of edge j.  One wave's LDS operations execute in order; the wave barriers keep the
       // compiler from re-ordering them.
+      if constexpr (MODE == 2) {
 #pragma unroll
-      for (int k = 0; k < CPL; ++k) wb[k][lane] = 0;
-      __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < CPL; ++k) found[k] |= pos[k] >= 0;
+      } else {
 #pragma unroll
-      for (int k = 0; k < CPL; ++k) {
-        if (!found[k] && pos[k] >= 0) atomicOr(reinterpret_cast<unsigned long long*>(wb[k] + pos[k]), 1ull << lane);
-        found[k] |= pos[k] >= 0;
-      }
-      __builtin_amdgcn_wave_barrier();
-      uint64_t m[CPL];
+        for (int k = 0; k < CPL; ++k) wb[k][lane] = 0;
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int k = 0; k < CPL; ++k) m[k] = wb[k][lane];
-      __builtin_amdgcn_wave_barrier();
-      if (lane < nb) {
-        W* dst = mask + (p0 + lane) * words + c * CPL * WPC;
+        for (int k = 0; k < CPL; ++k) {
+          if (!found[k] && pos[k] >= 0) atomicOr(reinterpret_cast<unsigned long long*>(wb[k] + pos[k]), 1ull << lane);
+          found[k] |= pos[k] >= 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint64_t m[CPL];
 #pragma unroll
-        for (int k = 0; k < CPL; ++k)
+        for (int k = 0; k < CPL; ++k) m[k] = wb[k][lane];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nb) {
+          W* dst = mask + (p0 + lane) * words + c * CPL * WPC;
 #pragma unroll
-          for (int w = 0; w < WPC; ++w)
-            if ((c * CPL + k) * WPC + w < words) dst[k * WPC + w] = static_cast<W>(m[k] >> (w * BITS));
+          for (int k = 0; k < CPL; ++k)
+#pragma unroll
+            for (int w = 0; w < WPC; ++w)
+              if ((c * CPL + k) * WPC + w < words) dst[k * WPC + w] = static_cast<W>(m[k] >> (w * BITS));
+        }
       }
     }
 #pragma unroll
@@ -491,16 +506,22 @@ __global__ __launch_bounds__(256) void spmm_cmp_mask_kernel(
         // element without a winner gets): summed here in row order, added to dX[0] by spmm_cmp_leak_kernel in slot
         // order — the same bits on every run.  Any other target (a hand-made arg): one atomic add, like the scatter.
         const int64_t a64 = static_cast<int64_t>(a[k]);
-        if (a64 == 0)
-          leaked[k] += to_acc<DT>(dz[row * F + f[k]]);
-        else if (a64 > 0 && a64 < dx_rows)
-          atomic_add_elem<DT>(dx + a64 * F + f[k], dz[row * F + f[k]]);
+        if (a64 == 0) {
+          if constexpr (MODE != 2) leaked[k] += to_acc<DT>(dz[row * F + f[k]]);
+        } else if (a64 > 0 && a64 < dx_rows) {
+          if constexpr (MODE == 1)
+            atomicOr(rare, 1u);
+          else
+            atomic_add_elem<DT>(dx + a64 * F + f[k], dz[row * F + f[k]]);
+        }
       }
     }
   }
+  if constexpr (MODE != 2) {
 #pragma unroll
-  for (int k = 0; k < CPL; ++k)
-    if (live[k]) leak[slot * F + f[k]] = leaked[k];
+    for (int k = 0; k < CPL; ++k)
+      if (live[k]) leak[slot * F + f[k]] = leaked[k];
+  }
 }
 
 // dX[0][k] += sum over the mask kernel's slots in a FIXED order: one workgroup per column, thread t sums slots
@@ -552,23 +573,35 @@ int run_spmm_cmp_mask(const void* indptr, const void* indices, const void* eids,
   // the per-slot partial sums of unclaimed elements live BEHIND the mask words in the caller's buffer
   // (dgla_spmm_cmp_mask_bytes): no allocation in here, so the call can be captured in a hipGraph
   A* leak = reinterpret_cast<A*>(static_cast<char*>(mask) + cmp_mask_align(sizeof(W) * static_cast<size_t>(nnz) * words));
-  if (m.cpl == 4)
-    hipLaunchKernelGGL((spmm_cmp_mask_kernel<Idx, W, DT, 4>), dim3(m.blocks), dim3(256), 0, s, static_cast<const Idx*>(indptr),
-                       static_cast<const Idx*>(indices), static_cast<const Idx*>(eids), static_cast<const Idx*>(arg), by_edge,
-                       rows, static_cast<int>(F), words, static_cast<W*>(mask), static_cast<const DT*>(dz),
-                       static_cast<DT*>(dx), dx_rows, leak);
-  else if (m.cpl == 2)
-    hipLaunchKernelGGL((spmm_cmp_mask_kernel<Idx, W, DT, 2>), dim3(m.blocks), dim3(256), 0, s, static_cast<const Idx*>(indptr),
-                       static_cast<const Idx*>(indices), static_cast<const Idx*>(eids), static_cast<const Idx*>(arg), by_edge,
-                       rows, static_cast<int>(F), words, static_cast<W*>(mask), static_cast<const DT*>(dz),
-                       static_cast<DT*>(dx), dx_rows, leak);
-  else
-    hipLaunchKernelGGL((spmm_cmp_mask_kernel<Idx, W, DT, 1>), dim3(m.blocks), dim3(256), 0, s, static_cast<const Idx*>(indptr),
-                       static_cast<const Idx*>(indices), static_cast<const Idx*>(eids), static_cast<const Idx*>(arg), by_edge,
-                       rows, static_cast<int>(F), words, static_cast<W*>(mask), static_cast<const DT*>(dz),
-                       static_cast<DT*>(dx), dx_rows, leak);
-  hipLaunchKernelGGL((spmm_cmp_leak_kernel<DT>), dim3(static_cast<unsigned>(F)), dim3(256), 0, s, leak,
-                     std::min<int64_t>(m.slots, rows), static_cast<int>(F), static_cast<DT*>(dx));
+  uint32_t* rare = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(leak) + cmp_mask_align(sizeof(A) * static_cast<size_t>(m.slots) * F));
+  const int mode = (by_edge & DGLA_CMP_MASK_FINISH) ? 2 : ((by_edge & DGLA_CMP_MASK_DEFER) ? 1 : 0);
+  by_edge &= 1;
+  if (mode == 1) DGLA_CHECK_HIP(hipMemsetAsync(rare, 0, sizeof(uint32_t), s));
+#define DGLA_CMP_MASK_LAUNCH(CPLV, MODEV)                                                                                       \
+  hipLaunchKernelGGL((spmm_cmp_mask_kernel<Idx, W, DT, CPLV, MODEV>), dim3(m.blocks), dim3(256), 0, s,                          \
+                     static_cast<const Idx*>(indptr), static_cast<const Idx*>(indices), static_cast<const Idx*>(eids),          \
+                     static_cast<const Idx*>(arg), by_edge, rows, static_cast<int>(F), words, static_cast<W*>(mask),            \
+                     static_cast<const DT*>(dz), static_cast<DT*>(dx), dx_rows, leak, rare)
+#define DGLA_CMP_MASK_CPL(MODEV)                      \
+  if (m.cpl == 4) {                                   \
+    DGLA_CMP_MASK_LAUNCH(4, MODEV);                   \
+  } else if (m.cpl == 2) {                            \
+    DGLA_CMP_MASK_LAUNCH(2, MODEV);                   \
+  } else {                                            \
+    DGLA_CMP_MASK_LAUNCH(1, MODEV);                   \
+  }
+  if (mode == 0) {
+    DGLA_CMP_MASK_CPL(0)
+  } else if (mode == 1) {
+    DGLA_CMP_MASK_CPL(1)
+  } else {
+    DGLA_CMP_MASK_CPL(2)
+  }
+#undef DGLA_CMP_MASK_CPL
+#undef DGLA_CMP_MASK_LAUNCH
+  if (mode != 1)   // (deferred: the sums wait for the FINISH call behind the g-SpMM)
+    hipLaunchKernelGGL((spmm_cmp_leak_kernel<DT>), dim3(static_cast<unsigned>(F)), dim3(256), 0, s, leak,
+                       std::min<int64_t>(m.slots, rows), static_cast<int>(F), static_cast<DT*>(dx));
   DGLA_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -720,7 +753,7 @@ size_t dgla_spmm_cmp_mask_bytes(dgla_dtype dtype, int64_t num_rows, int64_t nnz,
   const size_t asize = dtype == DGLA_F64 ? 8 : 4;  // accumulator type of the partial sums
   const CmpMaskShape m = cmp_mask_shape(num_rows > 0 ? num_rows : 1, feat_len);
   return cmp_mask_align(wsize * static_cast<size_t>(nnz) * dgla_spmm_cmp_mask_words(dtype, feat_len)) +
-         asize * static_cast<size_t>(m.slots) * feat_len;
+         cmp_mask_align(asize * static_cast<size_t>(m.slots) * feat_len) + 256;   // (+ the word of the deferred mode)
 }
 
 int dgla_spmm_cmp_mask(const dgla_csr* csr, dgla_dtype dtype, const void* arg, int by_edge, const dgla_tensor* dz,

@@ -298,10 +298,16 @@ int dgla_spmm_cmp_backward(int idtype_bits, dgla_dtype dtype, const dgla_tensor*
  *       words of the feature type's width (16 / 32 / 64 bits), bit (k mod width) of word k / width = column k.  An
  *       element no edge of its row claims (empty row, or nothing beat the identity: arg = 0) goes to dX[0, k] here,
  *       exactly where the reference's scatter sends it, summed in a fixed order: `dx` must be ZEROED before this call.
+ *       Two-step form (round 6, saves the zero fill and the g-SpMM's read of dx): `by_edge | DGLA_CMP_MASK_DEFER` writes
+ *       the bits and keeps the sums aside WITHOUT touching dx; dgla_spmm_csr_masked then STORES its rows (no
+ *       DGLA_ACCUMULATE, dx may be uninitialised memory); the same call again with `by_edge | DGLA_CMP_MASK_FINISH` adds
+ *       what was kept aside (and, only if an unclaimed element named a non-zero target, scans again for those).
  *   dgla_spmm_csr_masked  `csr` = the REVERSE matrix (rows = sources) whose `data` maps each of ITS positions to the
  *       forward position of the same edge (always present); `ufeat` = dZ, `mask` from above, `out` = dX with
  *       DGLA_ACCUMULATE (the atomics above are already in it).  One merge-path launch of the g-SpMM kernel.
  */
+#define DGLA_CMP_MASK_DEFER 0x100
+#define DGLA_CMP_MASK_FINISH 0x200
 int64_t dgla_spmm_cmp_mask_words(dgla_dtype dtype, int64_t feat_len);
 /* bytes of `mask`: the words of every edge + the mask pass's own partial sums behind them (no allocation inside the
  * call: it can be captured in a hipGraph) */

@@ -199,7 +199,7 @@ def test_gather_backward_equals_the_scatter_of_the_reference(dev, monkeypatch, i
     up = torch.randn((n,) + shape, device=dev, generator=gen).to(dtype)
     out = getattr(dgl.ops, "copy_u_" + red)(g, x)
     out.backward(up)
-    assert ran == ["mask", "spmm"]
+    assert ran == ["mask", "spmm", "mask"]      # bits (dX untouched) -> gated g-SpMM (stores) -> finish (unclaimed elements)
     got = x.grad.clone()
     # the reference composition on the winners the forward recorded (taken from a second forward: deterministic)
     gidx = g._graph
@@ -215,7 +215,7 @@ def test_gather_backward_equals_the_scatter_of_the_reference(dev, monkeypatch, i
     monkeypatch.setenv("DGLA_CMP_BACKWARD", "atomic")
     x.grad = None
     getattr(dgl.ops, "copy_u_" + red)(g, x).backward(up)
-    assert ran == ["mask", "spmm"] * 2
+    assert ran == ["mask", "spmm", "mask"] * 2
     # the atomic kernel adds in the tensor's own type, in whatever order the atomics land (as the reference's
     # scatter_add_ does): node 0 collects the gradient of every destination without an in-edge — dozens of 16-bit
     # additions — so its row is held to the bound of that many roundings, the others to the plain tolerance
@@ -285,6 +285,59 @@ def test_mask_kernel_by_edge_and_long_rows(dev):
     assert (bits == want).all()
     # nothing claimed in the empty row only: its dz went to dx[0]
     assert torch.equal(dx[0], dz[3]) and float(dx[1:].abs().max()) == 0.0
+
+
+def test_mask_kernel_two_step_form_equals_the_one_step_form(dev):
+    """DGLA_CMP_MASK_DEFER / _FINISH around a storing g-SpMM == the one-step form with a zeroed dX and an accumulating g-SpMM,
+    bit for bit — including elements no edge claims whose (hand-made) arg names a NON-ZERO row, which the finish call finds by
+    scanning again (the library's own forward never produces those)."""
+    from dgl_amd import _capi
+
+    rows, ncols, f = 300, 200, 100
+    gen = torch.Generator(device=dev).manual_seed(12)
+    deg = torch.randint(0, 90, (rows,), device=dev, generator=gen)
+    deg[5] = 0
+    indptr = torch.zeros(rows + 1, dtype=torch.int32, device=dev)
+    indptr[1:] = deg.cumsum(0).to(torch.int32)
+    e = int(indptr[-1])
+    indices = torch.randint(0, ncols, (e,), device=dev, generator=gen).to(torch.int32)
+    # winners: a random edge's source; some elements name a source that is NOT among the row's edges (unclaimed, target != 0)
+    pick = (torch.rand(rows, f, device=dev, generator=gen) * deg[:, None].clamp(min=1)).long()
+    pos = (indptr[:-1, None].long() + pick).clamp(max=max(e - 1, 0))
+    arg_u = torch.where(deg[:, None] > 0, indices[pos].long(), torch.zeros_like(pos)).to(torch.int32)
+    for rare in (False, True):
+        arg = arg_u.clone()
+        if rare:
+            arg[7, 3] = ncols - 1 if int((indices[indptr[7]:indptr[8]] == ncols - 1).sum()) == 0 else arg[7, 3]
+            arg[5, 9] = 17                              # the empty row naming a non-zero target
+        dz = torch.randn(rows, f, device=dev, generator=gen)
+        fwd = _capi.make_csr(indptr, indices, None, ncols)
+        # reverse matrix with the position map, as autograd builds it
+        dst = torch.repeat_interleave(torch.arange(rows, device=dev), deg).to(torch.int32)
+        order = torch.argsort(indices.long() * rows + dst.long(), stable=True)
+        rip = torch.zeros(ncols + 1, dtype=torch.int32, device=dev)
+        rip[1:] = torch.bincount(indices.long(), minlength=ncols).cumsum(0).to(torch.int32)
+        rev = _capi.make_csr(rip, dst[order].contiguous(), order.to(torch.int32).contiguous(), rows)
+        nbytes = _capi.spmm_cmp_mask_bytes(torch.float32, rows, e, f)
+        outs = []
+        for two_step in (False, True):
+            mask = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            dx = torch.zeros(ncols, f, device=dev) if not two_step else torch.full((ncols, f), float("nan"), device=dev)
+            ws = torch.empty(max(int(_capi.spmm_csr_masked_workspace_bytes(rev, dz, dx)), 1), dtype=torch.uint8, device=dev)
+            if two_step:
+                _capi.spmm_cmp_mask(fwd, arg, dz, mask, dx, mode=_capi.CMP_MASK_DEFER)
+                _capi.spmm_csr_masked(rev, dz, mask, dx, workspace=ws, accumulate=False)
+                _capi.spmm_cmp_mask(fwd, arg, dz, mask, dx, mode=_capi.CMP_MASK_FINISH)
+            else:
+                _capi.spmm_cmp_mask(fwd, arg, dz, mask, dx)
+                _capi.spmm_csr_masked(rev, dz, mask, dx, workspace=ws, accumulate=True)
+            outs.append(dx)
+        want = torch.zeros(ncols, f, dtype=torch.float64, device=dev).scatter_add_(0, arg.long(), dz.double())
+        torch.testing.assert_close(outs[1].double(), want, rtol=1e-5, atol=1e-5)
+        if rare:   # (the two forms add the rare elements by atomics at different moments: equal to rounding only)
+            torch.testing.assert_close(outs[0], outs[1], rtol=1e-6, atol=1e-6)
+        else:
+            assert torch.equal(outs[0], outs[1])
 
 
 def test_gather_backward_replays_inside_a_hipgraph(dev):
