@@ -251,7 +251,7 @@ def set_profile_events(before, after):
         LIB.dgla_spmm_set_profile_events(before.cuda_event, after.cuda_event)
 
 
-(TUNE_XCD, TUNE_SPLIT, TUNE_GLDS, TUNE_SPLIT_FORCE, TUNE_MM_F32, TUNE_MM_X3, TUNE_NO_GATE) = (1, 8, 16, 64, 128, 2048, 4096)  # include/dgl_amd.h DGLA_TUNE_*
+(TUNE_XCD, TUNE_SPLIT, TUNE_GLDS, TUNE_SPLIT_FORCE, TUNE_MM_F32, TUNE_MM_X3, TUNE_NO_GATE, TUNE_NO_STAGE_W) = (1, 8, 16, 64, 128, 2048, 4096, 8192)  # include/dgl_amd.h DGLA_TUNE_*
 
 
 def set_tuning(flags):

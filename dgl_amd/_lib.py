@@ -222,7 +222,7 @@ DGLA_PREPARE_ONLY = 32
 DGLA_ESM_OUT_POSITION = 128
 DGLA_ESM_B_IS_GRAD = 256
 DGLA_TUNE_XCD, DGLA_TUNE_SPLIT, DGLA_TUNE_GLDS = 1, 8, 16
-DGLA_TUNE_NO_GATE = 4096
+DGLA_TUNE_NO_GATE, DGLA_TUNE_NO_STAGE_W = 4096, 8192
 DGLA_TUNE_SPLIT_FORCE, DGLA_TUNE_MM_F32, DGLA_TUNE_MM_X3 = 64, 128, 2048   # (2, 4, 32, 256, 512, 1024 were retired in round 4)
 DEFAULT_TUNING = DGLA_TUNE_XCD | DGLA_TUNE_SPLIT | DGLA_TUNE_GLDS  # csrc/common.h kDefaultTuning
 

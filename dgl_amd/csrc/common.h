@@ -185,9 +185,10 @@ enum Tune : uint32_t {
   kTuneSplitForce = 64u,  // split layouts whenever the shape allows, whatever the locality probe says
   kTuneMmF32 = 128u,      // segment_mm fp32: v_mfma_f32_32x32x2_f32 instead of the split-operand kernels
   kTuneNoGate = 4096u,     // masked g-SpMM (max / min backward): gather every row piece, wanted or not (A/B switch of the gated loads)
+  kTuneNoStageW = 8192u,   // g-SpMM with scalar edge weights (u_mul_e + sum): read the weight per gather batch from global memory instead of staging the unit's weights in LDS (A/B switch)
   kTuneMmX3 = 2048u,       // segment_mm fp32, weights-stationary kernel: three bf16 terms instead of two scaled fp16 terms
 };
-constexpr uint32_t kTuneKnown = 1u | 8u | 16u | 64u | 128u | 2048u | 4096u;
+constexpr uint32_t kTuneKnown = 1u | 8u | 16u | 64u | 128u | 2048u | 4096u | 8192u;
 // Default: XCD-contiguous order (measured on C2: variant L -3 % time, variant U neutral); the
 // Split layouts (C2, F = 100 fp32): the edge-layout copy costs 0.10 ms
 // and the gather drops 4.86 -> 4.35 ms on variant U; on variant L the locality probe declines it only

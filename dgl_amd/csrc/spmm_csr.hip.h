@@ -50,6 +50,7 @@ struct SpmmParams {
   int accumulate;
   int rhs_neg, rhs_div;  // sub / div on the add / mul instantiations
   int rhs_mask;          // mul on kBcRhsGroup: rhs words are BIT masks, bit (k mod bits-per-word) gates output column k
+  int stage_w;           // scalar edge weights (rhs_len == 1, 4-byte type, sum): staged in LDS with the unit's column ids
   int red_min;           // min on the max instantiation
   int arg_empty;  // arg_u / arg_e of an output element no edge won: 0 (g-SpMM) or -1 (segment reduce)
   int mean;       // reduce == sum only: divide every row by max(its edge count, 1) before storing
@@ -420,6 +421,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
   }
   const int64_t w = static_cast<int64_t>(blk) * kWavesPerBlock + wib;
   const bool has_eid = p.eids != nullptr;
+  // scalar edge weights staged in LDS with the unit's column ids (u_mul_e / u_add_e + sum, 4-byte types): one load per EDGE in
+  // the staging phase instead of one global instruction per gather batch in the main loop
+  constexpr bool kStageW = UL && UR && !MULTI && !NTR && BC == kBcRhsGroup && RED == kSum && sizeof(DT) == 4;
+  [[maybe_unused]] const bool stage_w = kStageW && p.stage_w != 0;
   // NTR (spmm_nt_stream(): copy_rhs over long rows without an edge-id map, i.e. a readout-like segment reduce):
   // the edge operand is loaded non-temporally.  A compile-time switch: selecting the load flavour per load at run
   // time put a branch between the prefetch loads and made the compiler drain them (vmcnt(0)) before
@@ -446,6 +451,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
     if (items > 0) {
       Idx itemv[kWaveItems / 64];
       Idx eidv[kWaveItems / 64];
+      [[maybe_unused]] uint32_t wv[kStageW ? kWaveItems / 64 : 1];   // scalar edge weights of the unit (stage_w)
       uint8_t relv[MULTI ? kWaveItems / 64 : 1];
 #pragma unroll
       for (int k = 0; k < kWaveItems / 64; ++k) {
@@ -465,6 +471,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
             // kernel-argument ADDRESS and loaded through a flat pointer — tests/test_isa_audit.py)
             eidv[k] = nE > 0 ? load_global<Idx, 1>(p.eids + (j0 + ie)).v[0] : static_cast<Idx>(p.arg_empty);
           }
+          if constexpr (kStageW) {
+            if (stage_w && !has_eid)   // position order: one coalesced load with the column ids
+              wv[k] = nE > 0 ? load_global<uint32_t, 1>(static_cast<const uint32_t*>(p.efeat) + (j0 + (it < nE ? it : nE - 1))).v[0] : 0u;
+          }
+        }
+      }
+      if constexpr (kStageW) {
+        if (stage_w && has_eid) {   // behind the edge ids: the unit's weights gathered once per edge (not once per lane and edge)
+#pragma unroll
+          for (int k = 0; k < kWaveItems / 64; ++k) {
+            if (64 * k >= p.wave_items) break;
+            wv[k] = nE > 0 ? load_global<uint32_t, 1>(static_cast<const uint32_t*>(p.efeat) + static_cast<int64_t>(eidv[k])).v[0] : 0u;
+          }
         }
       }
       const int64_t first = static_cast<int64_t>(p.indptr[i0]) - j0;
@@ -475,7 +494,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
         if (it < nE) {
           if constexpr (UL) s_cols[wib][it] = static_cast<int>(itemv[k]);
           if constexpr (UR) {
-            if (has_eid) reinterpret_cast<Idx*>(s_dyn)[wib * kWaveItems + it] = eidv[k];
+            bool staged = false;
+            if constexpr (kStageW) {
+              if (stage_w) {   // (the weights take the edge ids' place: a sum names no edge)
+                reinterpret_cast<uint32_t*>(s_dyn)[wib * kWaveItems + it] = wv[k];
+                staged = true;
+              }
+            }
+            if (!staged && has_eid) reinterpret_cast<Idx*>(s_dyn)[wib * kWaveItems + it] = eidv[k];
           }
           if constexpr (MULTI) s_rel[wib][it] = relv[k];
         } else if (it < items) {
@@ -693,6 +719,48 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
         __builtin_memcpy(&wb, &b.w[u].v[0], sizeof(DT));
         const bool wanted = ((wb >> (k0 & (BITS - 1))) & ((1u << VEC) - 1u)) != 0u;
         b.x[u] = *(wanted ? ptr : gate_dummy);
+      }
+    }
+  };
+
+  // load_batch with the edge operand read from the staged weights (stage_w): no global load for it
+  [[maybe_unused]] auto load_batch_sw = [&](int e, Batch& b) {
+    if constexpr (kStageW) {
+      typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
+      const lds_u32_ptr sw = (lds_u32_ptr)s_dyn + wib * kWaveItems;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int ee = e + u;
+        if (ee >= e_e) ee = e_e - 1;
+        const int64_t c = cols[ee];
+        bool done = false;
+        if constexpr (VEC * sizeof(DT) == 16) {
+          if (edge_layout) {
+            const unsigned o16 = (e_t16 * static_cast<unsigned>(c) + e_base16) & 7u;
+            const unsigned head = 8u - o16;
+            const bool in_place = (ej - head) < e_in_place;
+            const int side_off = ej < head ? e_piece_lo : e_piece_hi;
+            const DT* base = in_place ? X : e_side;
+            const int64_t pitch = in_place ? lhs_len : static_cast<int64_t>(e_pitch);
+            const int add = in_place ? 0 : side_off;
+            b.x[u] = *reinterpret_cast<const XV*>(base + (c * pitch + add));
+            done = true;
+          }
+        }
+        if constexpr (VEC * sizeof(DT) == 8) {
+          if (straddle) {
+            const unsigned o = static_cast<unsigned>((static_cast<uint64_t>(c) * static_cast<unsigned>(p.split_row_bytes) +
+                                                      static_cast<unsigned>(p.split_base_bytes)) & 127u);
+            const bool from_side = o > static_cast<unsigned>(p.split_straddle_slack);
+            const DT* base = from_side ? static_cast<const DT*>(p.umain) + lo_off : X;
+            const int64_t pitch = from_side ? static_cast<int64_t>(p.split_main) : lhs_len;
+            b.x[u] = *reinterpret_cast<const XV*>(base + c * pitch);
+            done = true;
+          }
+        }
+        if (!done) b.x[u] = *reinterpret_cast<const XV*>(X + c * lhs_len);
+        const uint32_t wbits = sw[ee];
+        __builtin_memcpy(&b.w[u].v[0], &wbits, 4);
       }
     }
   };
@@ -955,6 +1023,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_csr_merge_kernel(
           load_w_only(e + 4 * U, b1);
           load_x_gated(e + 3 * U, b0);
           reduce_batch(e + 2 * U, b2);
+        }
+      }
+    }
+  }
+  if constexpr (kStageW) {
+    if (stage_w && !gated_done) {   // (wave-uniform)
+      gated_done = true;
+      if (e_s < e_e) {
+        int e = e_s;
+        Batch ba, bb;
+        load_batch_sw(e, ba);
+        for (; e < e_e; e += 2 * U) {
+          load_batch_sw(e + U, bb);
+          reduce_batch(e, ba);
+          load_batch_sw(e + 2 * U, ba);
+          reduce_batch(e + U, bb);
         }
       }
     }
@@ -1378,6 +1462,7 @@ inline SpmmParams<Idx> make_params(const SpmmLaunch& L, const SpmmGeometry& g) {
   p.rhs_neg = L.op == kSub ? 1 : 0;
   p.rhs_div = L.op == kDiv ? 1 : 0;
   p.rhs_mask = L.rhs_mask ? 1 : 0;
+  p.stage_w = 0;   // (launch_spmm_one decides)
   p.red_min = L.red == kMin ? 1 : 0;
   p.arg_empty = L.arg_empty;
   p.mean = L.mean ? 1 : 0;
@@ -1438,7 +1523,7 @@ inline bool spmm_nt_stream(const SpmmLaunch& L) {
 
 template <typename Idx, typename DT, int VEC, int OP, int RED, int BC>
 inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
-  const SpmmParams<Idx> p = make_params<Idx, DT>(L, g);
+  SpmmParams<Idx> p = make_params<Idx, DT>(L, g);
   const unsigned blocks =
       static_cast<unsigned>((g.num_waves + kWavesPerBlock - 1) / kWavesPerBlock);
   if (g.split_straddle && !L.split_valid) {
@@ -1470,9 +1555,16 @@ inline int launch_spmm_one(const SpmmLaunch& L, const SpmmGeometry& g) {
   }
   if (L.prepare_only) return 0;  // the producer's half of the call: plan + side copy are in the workspace
   // dynamic LDS: the unit's edge ids, only when the operator reads edge features through a map
-  const unsigned dyn_lds = (op_uses_rhs(OP) && L.csr.eids != nullptr)
-                               ? static_cast<unsigned>(kWavesPerBlock * kWaveItems * sizeof(Idx))
-                               : 0u;
+  unsigned dyn_lds = (op_uses_rhs(OP) && L.csr.eids != nullptr)
+                         ? static_cast<unsigned>(kWavesPerBlock * kWaveItems * sizeof(Idx))
+                         : 0u;
+  if constexpr (op_uses_lhs(OP) && op_uses_rhs(OP) && BC == kBcRhsGroup && RED == kSum && sizeof(DT) == 4) {
+    // scalar edge weights (one 4-byte value per edge), plain sum: staged in LDS with the unit's column ids
+    if (L.rel == nullptr && L.rhs_len == 1 && !L.rhs_mask && L.efeat != nullptr && (L.tune & kTuneNoStageW) == 0) {
+      p.stage_w = 1;
+      dyn_lds = std::max<unsigned>(dyn_lds, static_cast<unsigned>(kWavesPerBlock * kWaveItems * sizeof(uint32_t)));
+    }
+  }
   const ProfileEvents pe = profile_events();
   if (pe.before) DGLA_CHECK_HIP(hipEventRecord(pe.before, L.stream));
   if (L.rel != nullptr) {

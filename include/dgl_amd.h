@@ -574,6 +574,9 @@ int dgla_peer_wait(const void* flags, int num_flags, uint64_t epoch, void* statu
  *                     off, round 6): the bit words are fetched one batch ahead and a lane whose columns are all off for an
  *                     edge reads a fixed cached address instead of its piece of the row — a 128-byte line of the gathered
  *                     operand is requested only when one of its columns is wanted.  Changes no result bit (A/B switch).
+ *   DGLA_TUNE_NO_STAGE_W  dgla_spmm_csr with ONE 4-byte edge weight per edge and the sum reducer (u_mul_e / u_add_e + sum): read the
+ *                     weight from global memory in every gather batch.  Default (bit off, round 6): the unit's weights are
+ *                     staged in LDS together with its column ids (one load per edge).  Changes no result bit (A/B switch).
  * Removed in round 4 (values retired, dgla_set_tuning rejects them): NT_OUT 2 and NT_IDX 4 (non-temporal
  * output-row stores / index-stream loads: measured neutral), SPLIT_NT 32, SPLIT_CLASSIC 256
  * (whole-row copy: 0.33 ms against 0.10), TAIL_PASS 512 (column-sliced pass over the 16-byte row tails:
@@ -587,6 +590,7 @@ int dgla_peer_wait(const void* flags, int num_flags, uint64_t epoch, void* statu
 #define DGLA_TUNE_MM_F32 128u
 #define DGLA_TUNE_MM_X3 2048u
 #define DGLA_TUNE_NO_GATE 4096u
+#define DGLA_TUNE_NO_STAGE_W 8192u
 int dgla_set_tuning(uint32_t flags);
 uint32_t dgla_get_tuning(void);
 

@@ -619,8 +619,9 @@ def test_spmm_tuning_bits_do_not_change_results(dev, feat, tdtype, op, reduce):
     results = {}
     default = _capi.get_tuning()
     try:
-        # the full cross product of the layout / memory-system bits: XCD, SPLIT, SPLIT_FORCE
-        for flags in [a | d | f for a in (0, 1) for d in (0, 8) for f in (0, 64)]:
+        # the full cross product of the layout / memory-system bits: XCD, SPLIT, SPLIT_FORCE, NO_STAGE_W (scalar edge weights
+        # staged in LDS or read per gather batch: only the `mul` cases differ)
+        for flags in [a | d | f | sw for a in (0, 1) for d in (0, 8) for f in (0, 64) for sw in ((0, 8192) if op == "mul" else (0,))]:
             _capi.set_tuning(flags)
             assert _capi.get_tuning() == flags
             out = torch.full((n_dst, feat), -3.0, dtype=tdtype, device=dev)

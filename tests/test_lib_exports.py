@@ -145,7 +145,7 @@ def test_tuning_constants_match_header_and_library_default():
     text = open(os.path.join(root, "include", "dgl_amd.h")).read()
     defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (DGLA_TUNE_\w+) (\d+)u", text)}
     assert defs == {"DGLA_TUNE_XCD": 1, "DGLA_TUNE_SPLIT": 8, "DGLA_TUNE_GLDS": 16, "DGLA_TUNE_SPLIT_FORCE": 64,
-                    "DGLA_TUNE_MM_F32": 128, "DGLA_TUNE_MM_X3": 2048, "DGLA_TUNE_NO_GATE": 4096}
+                    "DGLA_TUNE_MM_F32": 128, "DGLA_TUNE_MM_X3": 2048, "DGLA_TUNE_NO_GATE": 4096, "DGLA_TUNE_NO_STAGE_W": 8192}
     for name, value in defs.items():
         assert getattr(_lib, name) == value
     default = int(_lib.LIB.dgla_get_tuning())
